@@ -1,0 +1,170 @@
+#!/usr/bin/env python3
+"""Generate golden vectors from the REAL reference (test infrastructure).
+
+Runs only in the build container, where ``/root/reference`` is mounted
+read-only: it imports ``networks.py`` / ``network_generator.py`` from there
+(CPU, fp32, bytecode writing disabled, ``torchvision`` stubbed because
+networks.py:5 imports it and it is not installed), runs the reference modules
+on seeded synthetic inputs and writes small fixtures to ``tests/golden/``.
+The fixtures travel to the GPU box; the reference does not.
+
+    python oracle/make_golden.py            # rewrites tests/golden/*.pt
+"""
+import os
+import sys
+import types
+from argparse import Namespace
+
+sys.dont_write_bytecode = True
+REF = os.environ.get("HRV_REFERENCE", "/root/reference")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def _import_reference():
+    import numpy as np
+    if not hasattr(np, "float"):
+        np.float = float  # numpy>=1.24 removed the alias the reference uses
+    tv = types.ModuleType("torchvision")
+    tvm = types.ModuleType("torchvision.models")
+    tv.models = tvm
+    sys.modules.setdefault("torchvision", tv)
+    sys.modules.setdefault("torchvision.models", tvm)
+    sys.path.insert(0, REF)
+    import networks as ref_networks  # noqa
+    import network_generator as ref_gen  # noqa
+    sys.path.pop(0)
+    return ref_networks, ref_gen
+
+
+def _randomize_bn(model, g):
+    import torch
+    for m in model.modules():
+        if isinstance(m, torch.nn.BatchNorm2d):
+            m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.2)
+            m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) + 0.5)
+            m.weight.data.copy_(1.0 + 0.2 * torch.randn(m.weight.shape, generator=g))
+            m.bias.data.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
+
+
+def main():
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref_networks, ref_gen = _import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    g = torch.Generator().manual_seed(1234)
+
+    # ---------------- primitives ----------------
+    prim = {}
+    x = torch.randn(2, 5, 7, 6, generator=g)
+    grid = (torch.rand(2, 9, 8, 2, generator=g) * 2.6 - 1.3)
+    prim["gs_in"], prim["gs_grid"] = x, grid
+    prim["gs_out"] = F.grid_sample(x, grid, padding_mode="border")
+    prim["bil_in"] = torch.randn(2, 3, 5, 4, generator=g)
+    prim["bil_x2"] = F.interpolate(prim["bil_in"], scale_factor=2, mode="bilinear")
+    prim["bil_size"] = F.interpolate(prim["bil_in"], size=(13, 9), mode="bilinear")
+    prim["near_size"] = F.interpolate(prim["bil_in"], size=(10, 12), mode="nearest")
+    opt_cpu = Namespace(cuda=False)
+    prim["grid_7x5"] = ref_networks.make_grid(2, 7, 5, opt_cpu)
+    prim["grid_24x18"] = ref_networks.make_grid(1, 24, 18, opt_cpu)
+    prim["in_in"] = torch.randn(2, 4, 9, 7, generator=g) * 3 + 1
+    prim["in_out"] = nn.InstanceNorm2d(4, affine=False)(prim["in_in"])
+    torch.save(prim, os.path.join(OUT, "primitives.pt"))
+
+    # ---------------- tocg ----------------
+    torch.manual_seed(7)
+    opt = Namespace(cuda=False, warp_feature="T1", out_layer="relu")
+    NGF = 8
+    tocg = ref_networks.ConditionGenerator(opt, input1_nc=4, input2_nc=16, output_nc=13, ngf=NGF,
+                                           norm_layer=nn.BatchNorm2d)
+    with torch.no_grad():
+        _randomize_bn(tocg, g)
+        # default conv init leaves flows tiny; scale flow_conv so warps are exercised
+        for fc in tocg.flow_conv:
+            fc.weight.mul_(4.0)
+    tocg.eval()
+    N, H, W = 2, 96, 64
+    input1 = torch.cat([torch.rand(N, 3, H, W, generator=g) * 2 - 1,
+                        (torch.rand(N, 1, H, W, generator=g) > 0.5).float()], 1)
+    lab = torch.randint(0, 13, (N, 1, H, W), generator=g)
+    input2 = torch.cat([torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0),
+                        torch.rand(N, 3, H, W, generator=g) * 2 - 1], 1)
+    with torch.no_grad():
+        flow_list, seg, wc, wcm = tocg(opt, input1, input2)
+    torch.save({"ngf": NGF, "state_dict": {k: v.clone() for k, v in tocg.state_dict().items()},
+                "input1": input1, "input2": input2, "flow_list": flow_list, "seg": seg,
+                "warped_c": wc, "warped_cm": wcm}, os.path.join(OUT, "tocg_ngf8_96x64.pt"))
+
+    # ---------------- SPADE generator ----------------
+    torch.manual_seed(11)
+    gopt = Namespace(cuda=False, norm_G="spectralaliasinstance", gen_semantic_nc=7, ngf=2,
+                     num_upsampling_layers="most", fine_height=256, fine_width=128,
+                     ndf=8, norm_D="spectralinstance", n_layers_D=3, num_D=2, no_ganFeat_loss=False)
+    gen = ref_gen.SPADEGenerator(gopt, 9)
+    gen.init_weights("xavier", 0.02)
+    with torch.no_grad():
+        for name, p in gen.named_parameters():
+            if name.endswith("noise_scale"):
+                p.copy_(0.3 * torch.randn(p.shape, generator=g))
+            elif name.endswith("weight") or name.endswith("weight_orig"):
+                p.mul_(30.0)  # xavier(gain .02) weights are ~1e-3: scale so activations are O(1)
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    gen.eval()
+    N = 2
+    x9 = torch.rand(N, 9, 256, 128, generator=g) * 2 - 1
+    lab7 = torch.randint(0, 7, (N, 1, 256, 128), generator=g)
+    # blob-ify labels a little: nearest-upsampled coarse map
+    lab7 = F.interpolate(lab7[:, :, ::8, ::8].float(), size=(256, 128), mode="nearest").long()
+    seg7 = torch.zeros(N, 7, 256, 128).scatter_(1, lab7, 1.0)
+    draws = []
+    real_randn = torch.randn
+
+    def rec_randn(*a, **k):
+        z = real_randn(*a, **k)
+        draws.append(z.clone())
+        return z
+
+    torch.randn = rec_randn
+    try:
+        with torch.no_grad():
+            gout = gen(x9, seg7)
+    finally:
+        torch.randn = real_randn
+    # map the draws (call order) to blocks: norm_s, norm_0, norm_1 per block; head_0 has no norm_s
+    blocks = ["head_0", "G_middle_0", "G_middle_1", "up_0", "up_1", "up_2", "up_3", "up_4"]
+    noise, k = {}, 0
+    for b in blocks:
+        n = 2 if b == "head_0" else 3
+        noise[b] = draws[k:k + n]
+        k += n
+    assert k == len(draws) == 23
+    gsd = gen.state_dict()
+    torch.save({"opt": vars(gopt), "state_dict": {k: v.clone() for k, v in gsd.items()},
+                "metadata": dict(gsd._metadata), "x": x9, "seg": seg7, "noise": noise, "out": gout},
+               os.path.join(OUT, "gen_ngf2_256x128.pt"))
+
+    # ---------------- generator's discriminator ----------------
+    torch.manual_seed(13)
+    D = ref_gen.MultiscaleDiscriminator(gopt)
+    D.init_weights("xavier", 0.02)
+    with torch.no_grad():
+        for name, p in D.named_parameters():
+            if name.endswith("weight") or name.endswith("weight_orig"):
+                p.mul_(20.0)
+    D.eval()
+    dinp = torch.cat([seg7[:, :, ::2, ::2], torch.rand(N, 3, 128, 64, generator=g) * 2 - 1], 1)
+    with torch.no_grad():
+        dout = D(dinp)
+    torch.save({"state_dict": {k: v.clone() for k, v in D.state_dict().items()}, "input": dinp, "out": dout},
+               os.path.join(OUT, "gend_ndf8_128x64.pt"))
+
+    # ---------------- parse glue inputs (restated blur: parity unpinned) ----------------
+    for f in sorted(os.listdir(OUT)):
+        print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,58 @@
+"""CPU: the oracle restatement vs golden vectors produced by the REAL reference
+(oracle/make_golden.py imports /root/reference).  This is what pins the oracle."""
+import torch
+
+from conftest import load_golden
+from oracle import hrviton_oracle as O
+
+
+def _close(a, b, tol=2e-5):
+    err = (a - b).abs().max().item()
+    ref = b.abs().max().item()
+    assert err <= tol * max(ref, 1.0), f"max err {err} vs max |ref| {ref}"
+
+
+def test_primitives():
+    g = load_golden("primitives.pt")
+    _close(O.grid_sample_bilinear_border(g["gs_in"], g["gs_grid"]), g["gs_out"], 1e-6)
+    _close(O.resize_bilinear(g["bil_in"], scale_factor=2), g["bil_x2"], 1e-6)
+    _close(O.resize_bilinear(g["bil_in"], size=(13, 9)), g["bil_size"], 1e-6)
+    assert torch.equal(O.resize_nearest(g["bil_in"], (10, 12)), g["near_size"])
+    # torch.linspace's vectorised CPU kernel differs from the scalar formula by <=1 ulp
+    # (lane-strided base + lane*step); the restatement is held to 1 ulp of 1.0.
+    assert (O.make_grid(2, 7, 5) - g["grid_7x5"]).abs().max() <= 1.2e-7
+    assert (O.make_grid(1, 24, 18) - g["grid_24x18"]).abs().max() <= 1.2e-7
+    _close(O.instance_norm(g["in_in"]), g["in_out"], 1e-5)
+
+
+def test_tocg_matches_reference():
+    g = load_golden("tocg_ngf8_96x64.pt")
+    flow_list, seg, wc, wcm = O.tocg_forward(g["state_dict"], g["input1"], g["input2"])
+    for a, b in zip(flow_list, g["flow_list"]):
+        assert a.shape == b.shape
+        _close(a, b)
+    _close(seg, g["seg"])
+    # white-noise images amplify 1e-6-px flow differences: |dI/dx| ~ 2 per px
+    _close(wc, g["warped_c"], 1e-4)
+    _close(wcm, g["warped_cm"], 1e-4)
+    # the flows are non-trivial (otherwise the warp is not exercised)
+    assert g["flow_list"][-1].abs().max() > 0.5
+
+
+def test_spade_generator_matches_reference():
+    g = load_golden("gen_ngf2_256x128.pt")
+    out = O.spade_generator_forward(g["state_dict"], g["x"], g["seg"], 256, 128, "most", noise=g["noise"])
+    assert out.shape == g["out"].shape
+    _close(out, g["out"], 5e-5)
+    assert g["out"].std() > 1e-2
+
+
+def test_gen_discriminator_matches_reference():
+    g = load_golden("gend_ndf8_128x64.pt")
+    out = O.gen_discriminator_forward(g["state_dict"], g["input"])
+    assert len(out) == len(g["out"]) == 2
+    for a_s, b_s in zip(out, g["out"]):
+        assert len(a_s) == len(b_s) == 4
+        for a, b in zip(a_s, b_s):
+            assert a.shape == b.shape
+            _close(a, b, 5e-5)
