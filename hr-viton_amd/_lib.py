@@ -1,0 +1,90 @@
+"""ctypes binding of the C ABI declared in include/hrviton_hip.h.
+
+The product path has no CPU fallback: if the gfx950 library is missing or a
+kernel launch fails, this raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhrviton_hip.so")
+
+HRV_MAX_SRC = 4
+ACT_NONE, ACT_RELU, ACT_LRELU, ACT_TANH = 0, 1, 2, 3
+
+
+class hrv_src_t(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("C", C.c_int32), ("cstride", C.c_int32), ("coff", C.c_int32),
+                ("up_shift", C.c_int32), ("pre_act", C.c_int32), ("C_real", C.c_int32)]
+
+
+class hrv_conv2d_t(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
+                ("nsrc", C.c_int32), ("src", hrv_src_t * HRV_MAX_SRC),
+                ("w_packed", C.c_void_p), ("w_oihw", C.c_void_p), ("Cout", C.c_int32), ("tile_cfg", C.c_int32),
+                ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
+                ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32)]
+
+
+class hrv_flow_warp_t(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("src_cstride", C.c_int32), ("src_coff", C.c_int32), ("flow", C.c_void_p),
+                ("fh", C.c_int32), ("fw", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
+                ("rh", C.c_float), ("rw", C.c_float), ("norm_x", C.c_float), ("norm_y", C.c_float),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("flow_up", C.c_void_p)]
+
+
+# every symbol include/hrviton_hip.h declares: (restype, argtypes)
+_i32, _i64, _f, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
+_ip = C.POINTER(C.c_int32)
+SYMBOLS = {
+    "hrv_version": (C.c_char_p, []),
+    "hrv_last_error": (C.c_char_p, []),
+    "hrv_device_check": (C.c_int, []),
+    "hrv_conv2d_pick_tile": (C.c_int, [_i64, _i32]),
+    "hrv_conv2d_tile_bn": (C.c_int, [_i32]),
+    "hrv_conv2d_tile_bm": (C.c_int, [_i32]),
+    "hrv_conv2d_packed_elems": (_i64, [_i32, _i32, _i32, _i32, _ip, _i32]),
+    "hrv_conv2d_pack_weight_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _vp]),
+    "hrv_conv2d_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
+    "hrv_conv2d_naive_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
+    "hrv_nchw_to_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,
+                                               _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_flow_warp_nhwc_f32": (C.c_int, [C.POINTER(hrv_flow_warp_t), _vp]),
+}
+
+_lib = None
+
+
+class HrvError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the in-tree library and bind every declared symbol (loud on failure)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HrvError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback for the HIP path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the .so does not export it
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = load().hrv_last_error().decode("utf-8", "replace")
+        raise HrvError(f"{what} failed (rc={rc}): {msg}")

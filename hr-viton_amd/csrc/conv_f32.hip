@@ -1,0 +1,465 @@
+// Implicit-GEMM NHWC convolution on the gfx950 fp32 matrix cores.
+//
+//   M = N*Ho*Wo output pixels, Ncols = Cout, K = KH*KW*sum(C_src)
+//   D[pixel][cout] = sum_k A[pixel][k] * B[k][cout]
+//
+// * A is gathered on the fly from up to 4 NHWC sources (channel concatenation,
+//   optional nearest-x2 upsample and LeakyReLU folded into the gather): no
+//   im2col buffer, no torch.cat copy ever touches HBM.
+// * B is the pre-packed weight [kt][CoutPad][16] (hrv_conv2d_pack_weight_f32),
+//   so a block's B tile is one contiguous BN*16-float run.
+// * Both tiles are staged through LDS as [row][16 + 4 pad] so every lane
+//   fetches its 4 k-values with one conflict-free ds_read_b128; the k index is
+//   permuted consistently on A and B (lane half h takes k = kq*8 + h*4 + e),
+//   which is legal because the MFMA sums over k.
+// * v_mfma_f32_32x32x2_f32: exact fp32 (a k-ordered fmaf chain), 157 TFLOP/s
+//   peak, 64 cycles per instruction per SIMD -> a wave with TM*TN >= 2
+//   independent accumulators keeps its SIMD's matrix pipe full; global loads for
+//   K-tile t+1 are in flight (registers) while tile t is multiplied, one
+//   __syncthreads per K-tile (double-buffered LDS).
+// * Epilogue (fused): out = act(acc*scale[c] + shift[c] + residual).
+//
+// Reference ops replaced: see include/hrviton_hip.h (hrv_conv2d_nhwc_f32).
+#include <stdarg.h>
+#include <string.h>
+
+#include <vector>
+
+#include "hrv_common.h"
+
+namespace hrv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;   // k-values per K-tile
+constexpr int LS = 20;   // LDS row stride in floats (16 + 4 pad, 80 B: 16-B aligned)
+
+struct SrcDev {
+  const float* ptr;
+  int C, cstride, coff, up_shift, pre_act, chunks;
+};
+
+struct ConvParams {
+  SrcDev src[HRV_MAX_SRC];
+  int nsrc;
+  int N, H, W, Ho, Wo, KH, KW, stride, pad;
+  int M;        // N*Ho*Wo
+  int Cout, CoutPad;
+  int chunks_total;  // sum over sources of ceil(C/16)
+  int KT;            // KH*KW*chunks_total
+  int m_tiles, n_tiles;
+  const float* wp;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  int res_cs, res_co;
+  int act;
+  float slope;
+  float pre_slope;
+  float* out;
+  int out_cs, out_co;
+};
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) {
+  static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int BM = 32 * TM * WM;
+  constexpr int BN = 32 * TN * WN;
+  constexpr int AR = BM / 64;                 // float4 A loads per thread per K-tile
+  constexpr int BR = (BN * 4 + 255) / 256;    // float4 B loads per thread per K-tile
+  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave / WN;
+  const int wn = wave % WN;
+
+  const int lid = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+  const int mt = lid / p.n_tiles;
+  const int nt = lid - mt * p.n_tiles;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
+
+  // ---- per-thread gather coordinates (fixed for the whole K loop) ----
+  const int a_c4 = tid & 3;    // which float4 of the 16-channel chunk
+  const int a_row = tid >> 2;  // + 64*r
+  int a_n[AR], a_hi0[AR], a_wi0[AR];
+  bool a_ok[AR];
+#pragma unroll
+  for (int r = 0; r < AR; ++r) {
+    const int pidx = m0 + a_row + 64 * r;
+    a_ok[r] = pidx < p.M;
+    const int pp = a_ok[r] ? pidx : 0;
+    const int n = pp / (p.Ho * p.Wo);
+    const int rem = pp - n * (p.Ho * p.Wo);
+    const int ho = rem / p.Wo;
+    const int wo = rem - ho * p.Wo;
+    a_n[r] = n;
+    a_hi0[r] = ho * p.stride - p.pad;
+    a_wi0[r] = wo * p.stride - p.pad;
+  }
+
+  // K-tile iterator state: (tap kh,kw) x (source s) x (chunk c)
+  int it_kh = 0, it_kw = 0, it_s = 0, it_c = 0;
+
+  f32x4 a_reg[AR];
+  f32x4 b_reg[BR];
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int l31 = lane & 31;
+  const int lh = lane >> 5;
+
+  // kt = -1 is the prologue (fetch + stage tile 0, nothing to multiply yet).
+  for (int kt = -1; kt < p.KT; ++kt) {
+    const bool more = kt + 1 < p.KT;
+    if (more) {
+      // ---- global -> registers for K-tile kt+1 (in flight during the MFMAs below)
+      // uniform per-field selects keep the by-value kernarg struct out of scratch
+      const float* s_ptr = p.src[0].ptr;
+      int s_C = p.src[0].C, s_cs = p.src[0].cstride, s_co = p.src[0].coff, s_up = p.src[0].up_shift,
+          s_pre = p.src[0].pre_act, s_chunks = p.src[0].chunks;
+#pragma unroll
+      for (int q = 1; q < HRV_MAX_SRC; ++q)
+        if (it_s == q) {
+          s_ptr = p.src[q].ptr; s_C = p.src[q].C; s_cs = p.src[q].cstride; s_co = p.src[q].coff;
+          s_up = p.src[q].up_shift; s_pre = p.src[q].pre_act; s_chunks = p.src[q].chunks;
+        }
+      const int c = it_c * BK + a_c4 * 4;
+      const bool c_ok = c < s_C;
+      const int Hs = p.H >> s_up, Ws = p.W >> s_up;
+#pragma unroll
+      for (int r = 0; r < AR; ++r) {
+        const int hi = a_hi0[r] + it_kh;
+        const int wi = a_wi0[r] + it_kw;
+        const bool ok = a_ok[r] && c_ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        // branch-free: always load from a valid address, then select
+        const size_t off =
+            ok ? ((size_t)(a_n[r] * Hs + (hi >> s_up)) * Ws + (wi >> s_up)) * s_cs + s_co + c : (size_t)0;
+        f32x4 v = *reinterpret_cast<const f32x4*>(s_ptr + off);
+        if (s_pre == HRV_ACT_LRELU) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
+        }
+        if (!ok) v = (f32x4)(0.f);
+        a_reg[r] = v;
+      }
+      const float* wt = p.wp + ((size_t)(kt + 1) * p.CoutPad + n0) * BK;
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        const int idx = tid + 256 * j;
+        b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * 4) % 256 == 0 || idx < BN * 4 ? idx : 0) * 4);
+      }
+      if (++it_c == s_chunks) {
+        it_c = 0;
+        if (++it_s == p.nsrc) {
+          it_s = 0;
+          if (++it_kw == p.KW) {
+            it_kw = 0;
+            ++it_kh;
+          }
+        }
+      }
+    }
+
+    if (kt >= 0) {
+      const int buf = kt & 1;
+      const float* As = smem + buf * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;
+      const float* Bs = smem + buf * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;
+#pragma unroll
+      for (int kq = 0; kq < 2; ++kq) {
+        f32x4 a[TM], b[TN];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LS + kq * 8);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + kq * 8);
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
+          }
+      }
+    }
+
+    if (more) {
+      // ---- registers -> LDS buffer (kt+1)&1 (its last readers passed the previous barrier)
+      float* Asw = smem + ((kt + 1) & 1) * (BM + BN) * LS;
+      float* Bsw = Asw + BM * LS;
+#pragma unroll
+      for (int r = 0; r < AR; ++r)
+        *reinterpret_cast<f32x4*>(Asw + (a_row + 64 * r) * LS + a_c4 * 4) = a_reg[r];
+#pragma unroll
+      for (int j = 0; j < BR; ++j) {
+        const int idx = tid + 256 * j;
+        if ((BN * 4) % 256 == 0 || idx < BN * 4)
+          *reinterpret_cast<f32x4*>(Bsw + (idx >> 2) * LS + (idx & 3) * 4) = b_reg[j];
+      }
+    }
+    __syncthreads();
+  }
+
+  // ---- fused epilogue: D layout col = lane&31 (cout), row = (reg&3)+8*(reg>>2)+4*(lane>>5) (pixel)
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int c = n0 + (wn * TN + j) * 32 + l31;
+    const bool c_ok = c < p.Cout;
+    const float sc = (c_ok && p.scale) ? p.scale[c] : 1.f;
+    const float sh = (c_ok && p.shift) ? p.shift[c] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      const int prow0 = m0 + (wm * TM + i) * 32 + 4 * lh;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int pidx = prow0 + (e & 3) + 8 * (e >> 2);
+        if (c_ok && pidx < p.M) {
+          float v = acc[i][j][e] * sc + sh;
+          if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
+          v = apply_act(v, p.act, p.slope);
+          p.out[(size_t)pidx * p.out_cs + p.out_co + c] = v;
+        }
+      }
+    }
+  }
+}
+
+// One thread per output element, raw OIHW weights: a device-side cross-check.
+__global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restrict__ w, int Cin_real_total,
+                                      const int* __restrict__ real_c /*[nsrc]*/) {
+  const size_t total = (size_t)p.M * p.Cout;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(idx % p.Cout);
+    const int pidx = (int)(idx / p.Cout);
+    const int n = pidx / (p.Ho * p.Wo);
+    const int rem = pidx - n * (p.Ho * p.Wo);
+    const int ho = rem / p.Wo, wo = rem - (rem / p.Wo) * p.Wo;
+    float acc = 0.f;
+    for (int kh = 0; kh < p.KH; ++kh)
+      for (int kw = 0; kw < p.KW; ++kw) {
+        const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+        if (hi < 0 || hi >= p.H || wi < 0 || wi >= p.W) continue;
+        int cbase = 0;
+        for (int s = 0; s < p.nsrc; ++s) {
+          const SrcDev sd = p.src[s];
+          const int Hs = p.H >> sd.up_shift, Ws = p.W >> sd.up_shift;
+          const float* px = sd.ptr + ((size_t)(n * Hs + (hi >> sd.up_shift)) * Ws + (wi >> sd.up_shift)) * sd.cstride + sd.coff;
+          for (int c = 0; c < real_c[s]; ++c) {
+            float x = px[c];
+            if (sd.pre_act == HRV_ACT_LRELU) x = x > 0.f ? x : x * p.pre_slope;
+            acc = fmaf(x, w[(((size_t)co * Cin_real_total + cbase + c) * p.KH + kh) * p.KW + kw], acc);
+          }
+          cbase += real_c[s];
+        }
+      }
+    float v = acc * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
+    if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + co];
+    p.out[(size_t)pidx * p.out_cs + p.out_co + co] = apply_act(v, p.act, p.slope);
+  }
+}
+
+struct TileCfg {
+  int TM, TN, WM, WN;
+};
+// id -> (TM,TN,WM,WN); BM = 32*TM*WM, BN = 32*TN*WN
+static const TileCfg kCfgs[] = {
+    {2, 2, 2, 2},  // 0: 128 x 128
+    {1, 3, 4, 1},  // 1: 128 x 96
+    {2, 3, 4, 1},  // 2: 256 x 96
+    {2, 1, 4, 1},  // 3: 256 x 32
+    {2, 2, 4, 1},  // 4: 256 x 64
+    {1, 1, 4, 1},  // 5: 128 x 32
+    {1, 2, 4, 1},  // 6: 128 x 64
+    {4, 2, 2, 2},  // 7: 256 x 128
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+static int cfg_bm(int c) { return 32 * kCfgs[c].TM * kCfgs[c].WM; }
+static int cfg_bn(int c) { return 32 * kCfgs[c].TN * kCfgs[c].WN; }
+
+static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
+  HRV_REQUIRE(d != nullptr, "conv2d: null descriptor");
+  HRV_REQUIRE(d->nsrc >= 1 && d->nsrc <= HRV_MAX_SRC, "conv2d: nsrc=%d out of range", d->nsrc);
+  HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "conv2d: bad extent");
+  HRV_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
+  HRV_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+              "conv2d: Ho/Wo (%d,%d) inconsistent with H,W,k,stride,pad", d->Ho, d->Wo);
+  HRV_REQUIRE(d->Cout > 0 && d->out != nullptr, "conv2d: bad output");
+  HRV_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (int64_t)1 << 31, "conv2d: too many output pixels");
+  memset(&p, 0, sizeof(p));
+  p.nsrc = d->nsrc;
+  int chunks_total = 0;
+  for (int i = 0; i < d->nsrc; ++i) {
+    const hrv_src_t& s = d->src[i];
+    HRV_REQUIRE(s.ptr != nullptr, "conv2d: src[%d] null", i);
+    HRV_REQUIRE(s.C > 0 && s.C % 4 == 0 && s.cstride % 4 == 0 && s.coff % 4 == 0 && s.coff + s.C <= s.cstride,
+                "conv2d: src[%d] channels C=%d cstride=%d coff=%d must be multiples of 4 and in range", i, s.C,
+                s.cstride, s.coff);
+    HRV_REQUIRE(((uintptr_t)s.ptr & 15) == 0, "conv2d: src[%d] not 16-byte aligned", i);
+    HRV_REQUIRE(s.up_shift == 0 || (s.up_shift == 1 && d->H % 2 == 0 && d->W % 2 == 0), "conv2d: src[%d] up_shift", i);
+    HRV_REQUIRE(s.pre_act == HRV_ACT_NONE || s.pre_act == HRV_ACT_LRELU, "conv2d: src[%d] pre_act", i);
+    p.src[i].ptr = (const float*)s.ptr;
+    p.src[i].C = s.C;
+    p.src[i].cstride = s.cstride;
+    p.src[i].coff = s.coff;
+    p.src[i].up_shift = s.up_shift;
+    p.src[i].pre_act = s.pre_act;
+    p.src[i].chunks = (s.C + BK - 1) / BK;
+    chunks_total += p.src[i].chunks;
+  }
+  p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
+  p.M = d->N * d->Ho * d->Wo;
+  p.Cout = d->Cout;
+  p.chunks_total = chunks_total;
+  p.KT = d->KH * d->KW * chunks_total;
+  p.scale = d->scale; p.shift = d->shift;
+  p.res = (const float*)d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff;
+  p.act = d->act; p.slope = d->act_slope; p.pre_slope = 0.2f;
+  p.out = (float*)d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
+  HRV_REQUIRE(d->out_cstride >= d->out_coff + d->Cout, "conv2d: out slice out of range");
+  HRV_REQUIRE(d->residual == nullptr || d->res_cstride >= d->res_coff + d->Cout, "conv2d: residual slice out of range");
+  if (need_packed) {
+    HRV_REQUIRE(d->tile_cfg >= 0 && d->tile_cfg < kNumCfgs, "conv2d: tile_cfg=%d invalid", d->tile_cfg);
+    HRV_REQUIRE(d->w_packed != nullptr && ((uintptr_t)d->w_packed & 15) == 0, "conv2d: w_packed null/unaligned");
+    const int bm = cfg_bm(d->tile_cfg), bn = cfg_bn(d->tile_cfg);
+    p.wp = (const float*)d->w_packed;
+    p.n_tiles = (d->Cout + bn - 1) / bn;
+    p.CoutPad = p.n_tiles * bn;
+    p.m_tiles = (p.M + bm - 1) / bm;
+  }
+  return HRV_OK;
+}
+
+template <int TM, int TN, int WM, int WN>
+static int launch_cfg(const ConvParams& p, hipStream_t st) {
+  const int nblk = p.m_tiles * p.n_tiles;
+  hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN>), dim3(nblk), dim3(256), 0, st, p);
+  return check_launch("conv_f32_mfma_kernel");
+}
+
+}  // namespace hrv
+
+using namespace hrv;
+
+extern "C" int hrv_conv2d_tile_bn(int32_t c) { return (c >= 0 && c < kNumCfgs) ? cfg_bn(c) : -1; }
+extern "C" int hrv_conv2d_tile_bm(int32_t c) { return (c >= 0 && c < kNumCfgs) ? cfg_bm(c) : -1; }
+
+extern "C" int hrv_conv2d_pick_tile(int64_t M, int32_t Cout) {
+  // 1) output-channel tile: least padding waste, ties -> wider tile (more A reuse)
+  const int bns[4] = {128, 96, 64, 32};
+  int best_bn = 32;
+  int64_t best_pad = INT64_MAX;
+  for (int i = 0; i < 4; ++i) {
+    const int64_t padded = (int64_t)((Cout + bns[i] - 1) / bns[i]) * bns[i];
+    if (padded < best_pad) { best_pad = padded; best_bn = bns[i]; }
+  }
+  // 2) pixel tile: 256 rows when that still leaves >= 2 blocks per CU, else 128
+  const int64_t n_tiles = (Cout + best_bn - 1) / best_bn;
+  const bool big = ((M + 255) / 256) * n_tiles >= 512;
+  switch (best_bn) {
+    case 128: return big ? 7 : 0;
+    case 96: return big ? 2 : 1;
+    case 64: return big ? 4 : 6;
+    default: return big ? 3 : 5;
+  }
+}
+
+extern "C" int64_t hrv_conv2d_packed_elems(int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
+                                           int32_t tile_cfg) {
+  if (tile_cfg < 0 || tile_cfg >= kNumCfgs || nsrc < 1 || nsrc > HRV_MAX_SRC || !srcC) return -1;
+  const int bn = cfg_bn(tile_cfg);
+  const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
+  int64_t chunks = 0;
+  for (int i = 0; i < nsrc; ++i) chunks += (srcC[i] + BK - 1) / BK;
+  return (int64_t)KH * KW * chunks * cpad * BK;
+}
+
+extern "C" int hrv_conv2d_pack_weight_f32(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                          const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
+                                          float* out) {
+  HRV_REQUIRE(w && out && srcC && srcC_real, "pack_weight: null pointer");
+  HRV_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumCfgs, "pack_weight: bad tile_cfg %d", tile_cfg);
+  HRV_REQUIRE(nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_weight: bad nsrc");
+  const int bn = cfg_bn(tile_cfg);
+  const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
+  int cin_real = 0, chunks_total = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    HRV_REQUIRE(srcC_real[i] > 0 && srcC_real[i] <= srcC[i] && srcC[i] % 4 == 0, "pack_weight: bad channel counts");
+    cin_real += srcC_real[i];
+    chunks_total += (srcC[i] + BK - 1) / BK;
+  }
+  const int64_t total = (int64_t)KH * KW * chunks_total * cpad * BK;
+  memset(out, 0, sizeof(float) * total);
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) {
+      int chunk0 = 0, cbase = 0;
+      for (int s = 0; s < nsrc; ++s) {
+        const int chunks = (srcC[s] + BK - 1) / BK;
+        for (int c = 0; c < srcC_real[s]; ++c) {
+          const int64_t kt = (int64_t)(kh * KW + kw) * chunks_total + chunk0 + c / BK;
+          float* dst = out + (kt * cpad) * BK + (c % BK);
+          const float* srcw = w + ((int64_t)(cbase + c) * KH + kh) * KW + kw;
+          const int64_t ostride = (int64_t)cin_real * KH * KW;
+          for (int co = 0; co < Cout; ++co) dst[(int64_t)co * BK] = srcw[co * ostride];
+        }
+        chunk0 += chunks;
+        cbase += srcC_real[s];
+      }
+    }
+  return HRV_OK;
+}
+
+extern "C" int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {
+  ConvParams p;
+  int rc = fill_params(d, p, true);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  switch (d->tile_cfg) {
+    case 0: return launch_cfg<2, 2, 2, 2>(p, st);
+    case 1: return launch_cfg<1, 3, 4, 1>(p, st);
+    case 2: return launch_cfg<2, 3, 4, 1>(p, st);
+    case 3: return launch_cfg<2, 1, 4, 1>(p, st);
+    case 4: return launch_cfg<2, 2, 4, 1>(p, st);
+    case 5: return launch_cfg<1, 1, 4, 1>(p, st);
+    case 6: return launch_cfg<1, 2, 4, 1>(p, st);
+    case 7: return launch_cfg<4, 2, 2, 2>(p, st);
+  }
+  set_error("conv2d: tile_cfg=%d invalid", d->tile_cfg);
+  return HRV_ERR_ARG;
+}
+
+extern "C" int hrv_conv2d_naive_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {
+  ConvParams p;
+  int rc = fill_params(d, p, false);
+  if (rc) return rc;
+  HRV_REQUIRE(d->w_oihw != nullptr, "conv2d_naive: w_oihw null");
+  int real_c[HRV_MAX_SRC];
+  int cin = 0;
+  for (int i = 0; i < d->nsrc; ++i) {
+    real_c[i] = d->src[i].C_real > 0 ? d->src[i].C_real : d->src[i].C;
+    cin += real_c[i];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  int* d_real = nullptr;
+  if (hipMalloc(&d_real, sizeof(real_c)) != hipSuccess) { set_error("conv2d_naive: hipMalloc"); return HRV_ERR_LAUNCH; }
+  (void)hipMemcpyAsync(d_real, real_c, sizeof(real_c), hipMemcpyHostToDevice, st);
+  const size_t total = (size_t)p.M * p.Cout;
+  const int blocks = (int)((total + 255) / 256 > 65536 ? 65536 : (total + 255) / 256);
+  hipLaunchKernelGGL(conv_f32_naive_kernel, dim3(blocks), dim3(256), 0, st, p, d->w_oihw, cin, d_real);
+  rc = check_launch("conv_f32_naive_kernel");
+  (void)hipStreamSynchronize(st);
+  (void)hipFree(d_real);
+  return rc;
+}

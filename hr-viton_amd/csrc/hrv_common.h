@@ -1,0 +1,49 @@
+// Shared host/device helpers for the gfx950 HR-VITON kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "../../include/hrviton_hip.h"
+
+namespace hrv {
+
+void set_error(const char* fmt, ...);
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return HRV_ERR_LAUNCH;
+  }
+  return HRV_OK;
+}
+
+#define HRV_REQUIRE(cond, ...)     \
+  do {                             \
+    if (!(cond)) {                 \
+      hrv::set_error(__VA_ARGS__); \
+      return HRV_ERR_ARG;          \
+    }                              \
+  } while (0)
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case HRV_ACT_RELU: return v > 0.f ? v : 0.f;
+    case HRV_ACT_LRELU: return v > 0.f ? v : v * slope;
+    case HRV_ACT_TANH: return tanhf(v);
+    default: return v;
+  }
+}
+
+// Bijective XCD-aware remap: hardware places block b on XCD b % 8; give each XCD
+// a contiguous range of logical tiles so neighbouring tiles (shared halo rows,
+// shared weight panels) hit the same 4 MiB L2.  Speed only, never correctness.
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+  const int xcd = bid & 7;
+  const int q = nblk >> 3, r = nblk & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (bid >> 3);
+}
+
+}  // namespace hrv

@@ -1,0 +1,260 @@
+// HBM-bound sampling kernels of the HR-VITON path (NHWC, fp32, float4 per lane):
+// layout converters, bilinear resize (+fused addend) and the appearance-flow
+// warp (flow upsample + normalise + base grid + bilinear/border grid_sample
+// in one pass).  Reference ops replaced: see include/hrviton_hip.h.
+#include <stdarg.h>
+#include <string.h>
+
+#include "hrv_common.h"
+
+namespace hrv {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+static inline int grid_for(size_t work, int block = 256) {
+  size_t g = (work + block - 1) / block;
+  const size_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride the rest
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+// ---------------------------------------------------------------- layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int N, int C, int HW, float* __restrict__ out,
+                                    int cs, int co) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const float* src = in + n * (size_t)C * HW + hw;
+    float* dst = out + i * cs + co;
+    for (int c = 0; c < C; ++c) dst[c] = src[(size_t)c * HW];
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, int co, int N, int C, int HW,
+                                    float* __restrict__ out) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const float* src = in + i * cs + co;
+    float* dst = out + n * (size_t)C * HW + hw;
+    for (int c = 0; c < C; ++c) dst[(size_t)c * HW] = src[c];
+  }
+}
+
+// ---------------------------------------------------------------- bilinear
+// torch area_pixel_compute_source_index (align_corners=False, not cubic):
+//   src = max(ratio*(dst+0.5) - 0.5, 0); i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0
+struct Lin {
+  int i0, i1;
+  float l0, l1;
+};
+__device__ __forceinline__ Lin lin_src(int dst, int in_size, float ratio) {
+  float src = ratio * ((float)dst + 0.5f) - 0.5f;
+  src = src < 0.f ? 0.f : src;
+  int i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  Lin r;
+  r.i0 = i0;
+  r.i1 = i0 + (i0 < in_size - 1 ? 1 : 0);
+  float l1 = src - (float)i0;
+  l1 = l1 < 0.f ? 0.f : (l1 > 1.f ? 1.f : l1);
+  r.l1 = l1;
+  r.l0 = 1.f - l1;
+  return r;
+}
+
+__device__ __forceinline__ float4 f4_bilerp(float4 v00, float4 v01, float4 v10, float4 v11, float wl0, float wl1,
+                                            float hl0, float hl1) {
+  float4 o;
+  o.x = hl0 * (wl0 * v00.x + wl1 * v01.x) + hl1 * (wl0 * v10.x + wl1 * v11.x);
+  o.y = hl0 * (wl0 * v00.y + wl1 * v01.y) + hl1 * (wl0 * v10.y + wl1 * v11.y);
+  o.z = hl0 * (wl0 * v00.z + wl1 * v01.z) + hl1 * (wl0 * v10.z + wl1 * v11.z);
+  o.w = hl0 * (wl0 * v00.w + wl1 * v01.w) + hl1 * (wl0 * v10.w + wl1 * v11.w);
+  return o;
+}
+
+__global__ void resize_bilinear_kernel(const float* __restrict__ in, int N, int H, int W, int C4, int ics, int ico,
+                                       int Ho, int Wo, float rh, float rw, const float* __restrict__ add, int acs,
+                                       int aco, float* __restrict__ out, int ocs, int oco) {
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int wo = (int)(pix % Wo);
+    const size_t t = pix / Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const Lin ly = lin_src(ho, H, rh), lx = lin_src(wo, W, rw);
+    const float* base = in + (size_t)n * H * W * ics + ico + c4 * 4;
+    const float4 v00 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i0 * W + lx.i0) * ics);
+    const float4 v01 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i0 * W + lx.i1) * ics);
+    const float4 v10 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i1 * W + lx.i0) * ics);
+    const float4 v11 = *reinterpret_cast<const float4*>(base + ((size_t)ly.i1 * W + lx.i1) * ics);
+    float4 o = f4_bilerp(v00, v01, v10, v11, lx.l0, lx.l1, ly.l0, ly.l1);
+    if (add) {
+      const float4 a = *reinterpret_cast<const float4*>(add + pix * acs + aco + c4 * 4);
+      o.x += a.x; o.y += a.y; o.z += a.z; o.w += a.w;
+    }
+    *reinterpret_cast<float4*>(out + pix * ocs + oco + c4 * 4) = o;
+  }
+}
+
+// ---------------------------------------------------------------- flow warp
+struct WarpParams {
+  const float* src;
+  int N, H, W, C4, scs, sco;
+  const float* flow;
+  int fh, fw, Ho, Wo;
+  float rh, rw, norm_x, norm_y;
+  float step_x, step_y;  // fp32 linspace step 2/(Wo-1), 2/(Ho-1)
+  float* out;
+  int ocs, oco;
+  float* flow_up;
+};
+
+// torch.linspace(-1, 1, n)[i] in fp32 (networks.py:162-163): first half from the
+// start, second half from the end.
+__device__ __forceinline__ float lin_m1_1(int i, int n, float step) {
+  return i < n / 2 ? -1.f + step * (float)i : 1.f - step * (float)(n - 1 - i);
+}
+
+__global__ void flow_warp_kernel(const WarpParams p) {
+  const size_t total = (size_t)p.N * p.Ho * p.Wo * p.C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % p.C4);
+    const size_t pix = i / p.C4;
+    const int wo = (int)(pix % p.Wo);
+    const size_t t = pix / p.Wo;
+    const int ho = (int)(t % p.Ho);
+    const int n = (int)(t / p.Ho);
+    // 1) bilinear upsample of the previous flow (2 channels, NHWC)
+    const Lin ly = lin_src(ho, p.fh, p.rh), lx = lin_src(wo, p.fw, p.rw);
+    const float2* fb = reinterpret_cast<const float2*>(p.flow) + (size_t)n * p.fh * p.fw;
+    const float2 f00 = fb[(size_t)ly.i0 * p.fw + lx.i0], f01 = fb[(size_t)ly.i0 * p.fw + lx.i1];
+    const float2 f10 = fb[(size_t)ly.i1 * p.fw + lx.i0], f11 = fb[(size_t)ly.i1 * p.fw + lx.i1];
+    const float fx = ly.l0 * (lx.l0 * f00.x + lx.l1 * f01.x) + ly.l1 * (lx.l0 * f10.x + lx.l1 * f11.x);
+    const float fy = ly.l0 * (lx.l0 * f00.y + lx.l1 * f01.y) + ly.l1 * (lx.l0 * f10.y + lx.l1 * f11.y);
+    if (p.flow_up && c4 == 0) reinterpret_cast<float2*>(p.flow_up)[pix] = make_float2(fx, fy);
+    // 2) normalise, add the linspace(-1,1) base grid
+    const float gx = fx / p.norm_x + lin_m1_1(wo, p.Wo, p.step_x);
+    const float gy = fy / p.norm_y + lin_m1_1(ho, p.Ho, p.step_y);
+    // 3) grid_sample: un-normalise (align_corners=False), clamp to the border, 4 taps
+    float ix = ((gx + 1.f) * (float)p.W - 1.f) / 2.f;
+    float iy = ((gy + 1.f) * (float)p.H - 1.f) / 2.f;
+    ix = fminf(fmaxf(ix, 0.f), (float)(p.W - 1));
+    iy = fminf(fmaxf(iy, 0.f), (float)(p.H - 1));
+    const float x0f = floorf(ix), y0f = floorf(iy);
+    const int x0 = (int)x0f, y0 = (int)y0f;
+    const int x1 = x0 + 1, y1 = y0 + 1;
+    const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix;
+    const float wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+    const float* sb = p.src + (size_t)n * p.H * p.W * p.scs + p.sco + c4 * 4;
+    float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto tap = [&](int x, int y, float w) {
+      if (x >= 0 && x < p.W && y >= 0 && y < p.H) {
+        const float4 v = *reinterpret_cast<const float4*>(sb + ((size_t)y * p.W + x) * p.scs);
+        o.x += v.x * w; o.y += v.y * w; o.z += v.z * w; o.w += v.w * w;
+      }
+    };
+    tap(x0, y0, wx0 * wy0);
+    tap(x1, y0, wx1 * wy0);
+    tap(x0, y1, wx0 * wy1);
+    tap(x1, y1, wx1 * wy1);
+    *reinterpret_cast<float4*>(p.out + pix * p.ocs + p.oco + c4 * 4) = o;
+  }
+}
+
+}  // namespace hrv
+
+using namespace hrv;
+
+extern "C" const char* hrv_version(void) { return "hrviton-hip 0.1 (gfx950)"; }
+extern "C" const char* hrv_last_error(void) { return g_err; }
+
+extern "C" int hrv_device_check(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
+    set_error("no HIP device visible");
+    return HRV_ERR_NODEV;
+  }
+  hipDeviceProp_t prop;
+  int dev = 0;
+  hipGetDevice(&dev);
+  if (hipGetDeviceProperties(&prop, dev) != hipSuccess) {
+    set_error("hipGetDeviceProperties failed");
+    return HRV_ERR_NODEV;
+  }
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+    set_error("device is %s, this library is built for gfx950 only", prop.gcnArchName);
+    return HRV_ERR_NODEV;
+  }
+  return HRV_OK;
+}
+
+extern "C" int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, float* out,
+                                    int32_t out_cstride, int32_t out_coff, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
+  HRV_REQUIRE(out_coff >= 0 && out_coff + C <= out_cstride, "nchw_to_nhwc: slice out of range");
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, C, H * W,
+                     out, out_cstride, out_coff);
+  return check_launch("nchw_to_nhwc_kernel");
+}
+
+extern "C" int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
+                                    int32_t H, int32_t W, float* out, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad args");
+  HRV_REQUIRE(in_coff >= 0 && in_coff + C <= in_cstride, "nhwc_to_nchw: slice out of range");
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cstride,
+                     in_coff, N, C, H * W, out);
+  return check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int hrv_resize_bilinear_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C,
+                                            int32_t in_cstride, int32_t in_coff, int32_t Ho, int32_t Wo, float rh,
+                                            float rw, const float* addend, int32_t add_cstride, int32_t add_coff,
+                                            float* out, int32_t out_cstride, int32_t out_coff,
+                                            hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_bilinear: bad args");
+  HRV_REQUIRE(C > 0 && C % 4 == 0 && in_cstride % 4 == 0 && in_coff % 4 == 0 && out_cstride % 4 == 0 && out_coff % 4 == 0,
+              "resize_bilinear: channel counts/offsets must be multiples of 4");
+  HRV_REQUIRE(in_coff + C <= in_cstride && out_coff + C <= out_cstride, "resize_bilinear: slice out of range");
+  HRV_REQUIRE(!addend || (add_cstride % 4 == 0 && add_coff % 4 == 0 && add_coff + C <= add_cstride),
+              "resize_bilinear: addend slice");
+  HRV_REQUIRE((((uintptr_t)in | (uintptr_t)out | (uintptr_t)addend) & 15) == 0, "resize_bilinear: 16-byte alignment");
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(resize_bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, H, W,
+                     C / 4, in_cstride, in_coff, Ho, Wo, rh, rw, addend, add_cstride, add_coff, out, out_cstride,
+                     out_coff);
+  return check_launch("resize_bilinear_kernel");
+}
+
+extern "C" int hrv_flow_warp_nhwc_f32(const hrv_flow_warp_t* d, hrv_stream_t stream) {
+  HRV_REQUIRE(d && d->src && d->flow && d->out, "flow_warp: null pointer");
+  HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->fh > 0 && d->fw > 0 && d->Ho > 0 && d->Wo > 0, "flow_warp: extent");
+  HRV_REQUIRE(d->C > 0 && d->C % 4 == 0 && d->src_cstride % 4 == 0 && d->src_coff % 4 == 0 &&
+                  d->out_cstride % 4 == 0 && d->out_coff % 4 == 0,
+              "flow_warp: channel counts/offsets must be multiples of 4");
+  HRV_REQUIRE(d->src_coff + d->C <= d->src_cstride && d->out_coff + d->C <= d->out_cstride, "flow_warp: slice range");
+  HRV_REQUIRE((((uintptr_t)d->src | (uintptr_t)d->out) & 15) == 0 && ((uintptr_t)d->flow & 7) == 0 &&
+                  ((uintptr_t)d->flow_up & 7) == 0,
+              "flow_warp: alignment");
+  HRV_REQUIRE(d->norm_x != 0.f && d->norm_y != 0.f, "flow_warp: zero normaliser");
+  WarpParams p;
+  p.src = d->src; p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = d->C / 4; p.scs = d->src_cstride; p.sco = d->src_coff;
+  p.flow = d->flow; p.fh = d->fh; p.fw = d->fw; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.rh = d->rh; p.rw = d->rw; p.norm_x = d->norm_x; p.norm_y = d->norm_y;
+  p.step_x = d->Wo > 1 ? 2.0f / (float)(d->Wo - 1) : 0.f;
+  p.step_y = d->Ho > 1 ? 2.0f / (float)(d->Ho - 1) : 0.f;
+  p.out = d->out; p.ocs = d->out_cstride; p.oco = d->out_coff; p.flow_up = d->flow_up;
+  const size_t total = (size_t)d->N * d->Ho * d->Wo * p.C4;
+  hipLaunchKernelGGL(flow_warp_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("flow_warp_kernel");
+}

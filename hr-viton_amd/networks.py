@@ -1,0 +1,264 @@
+"""MI355X-native mirror of the reference's ``networks.py`` for the hot path.
+
+Same class names, constructor / forward signatures and ``state_dict`` keys as
+/root/reference/networks.py (ConditionGenerator :13-159, make_grid :161-168,
+ResBlock :171-198, save/load_checkpoint :411-425), so the reference's entry
+scripts and ``.pth`` checkpoints are drop-in -- but ``forward`` runs on
+hand-written gfx950 kernels through the C ABI (include/hrviton_hip.h):
+NHWC fp32 activations, implicit-GEMM MFMA convolutions with eval-BatchNorm /
+bias / residual / ReLU fused into the epilogue, torch.cat folded into the conv
+gather, and one fused kernel for flow-upsample + normalise + base-grid +
+grid_sample.  The nn.Conv2d / nn.BatchNorm2d objects below are parameter
+containers only; they are never called.
+
+There is no CPU fallback: CPU tensors raise (ops.require_cuda).
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from .ops import ACT_NONE, ACT_RELU, Act, ConvLayer
+
+
+class ResBlock(nn.Module):
+    """Parameter container with the reference's key layout (networks.py:171-198):
+    scale (down: 3x3 s2 | same: 1x1 | up: [Upsample, 1x1]) and block =
+    [conv3x3, norm, ReLU, conv3x3, norm]."""
+
+    def __init__(self, in_nc, out_nc, scale="down", norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        if scale not in ("up", "down", "same"):
+            raise AssertionError("ResBlock scale must be in 'up' 'down' 'same'")
+        self.kind = scale
+        self.in_nc, self.out_nc = in_nc, out_nc
+        with_bias = norm_layer == nn.InstanceNorm2d
+        if scale == "down":
+            self.scale = nn.Conv2d(in_nc, out_nc, 3, stride=2, padding=1, bias=with_bias)
+        elif scale == "same":
+            self.scale = nn.Conv2d(in_nc, out_nc, 1, bias=True)
+        else:
+            self.scale = nn.Sequential(nn.Upsample(scale_factor=2, mode="bilinear"),
+                                       nn.Conv2d(in_nc, out_nc, 1, bias=True))
+        body = []
+        for k in range(2):
+            body += [nn.Conv2d(out_nc, out_nc, 3, stride=1, padding=1, bias=with_bias), norm_layer(out_nc)]
+            if k == 0:
+                body.append(nn.ReLU(inplace=True))
+        self.block = nn.Sequential(*body)
+        self.relu = nn.ReLU(inplace=True)
+
+    def forward(self, x):  # pragma: no cover - containers are driven by the owning network's plan
+        raise RuntimeError("hr-viton_amd ResBlock is executed by its owner's HIP plan, not called directly")
+
+
+def _bn_fold(bn: nn.BatchNorm2d):
+    """Eval-mode BatchNorm as per-channel (scale, shift) for the conv epilogue."""
+    inv = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
+    g = bn.weight.detach().double() if bn.affine else torch.ones_like(inv)
+    b = bn.bias.detach().double() if bn.affine else torch.zeros_like(inv)
+    scale = g * inv
+    shift = b - bn.running_mean.detach().double() * scale
+    return scale.float(), shift.float()
+
+
+class _ResBlockPlan:
+    """HIP execution of one ResBlock in eval mode (3 conv launches [+1 resize])."""
+
+    def __init__(self, rb: ResBlock, src_split: List[int], device, name: str):
+        assert isinstance(rb.block[1], nn.BatchNorm2d), "HIP plan implements the BatchNorm2d configuration"
+        self.kind = rb.kind
+        if rb.kind == "down":
+            self.scale = ConvLayer(rb.scale.weight, src_split, device, stride=2, pad=1, name=name + ".scale")
+        else:
+            conv = rb.scale if rb.kind == "same" else rb.scale[1]
+            self.scale = ConvLayer(conv.weight, src_split, device, shift=conv.bias, stride=1, pad=0,
+                                   name=name + (".scale" if rb.kind == "same" else ".scale.1"))
+        s1, b1 = _bn_fold(rb.block[1])
+        s2, b2 = _bn_fold(rb.block[4])
+        c = rb.out_nc
+        self.c1 = ConvLayer(rb.block[0].weight, [c], device, scale=s1, shift=b1, act=ACT_RELU, name=name + ".block.0")
+        self.c2 = ConvLayer(rb.block[3].weight, [c], device, scale=s2, shift=b2, act=ACT_RELU, name=name + ".block.3")
+
+    def __call__(self, srcs: List[Act]) -> Act:
+        r = self.scale(srcs)
+        if self.kind == "up":
+            # nn.Upsample(bilinear x2) and the 1x1 conv commute (both linear, bilinear weights
+            # sum to 1 so the bias passes through): convolve at low resolution (4x fewer MACs,
+            # no full-resolution Cin-wide intermediate), then upsample the Cout-wide result.
+            r = ops.resize_bilinear(r, r.H * 2, r.W * 2, 0.5, 0.5)
+        t = self.c1([r])
+        return self.c2([t], residual=r)  # relu(r + bn(conv(t)))
+
+
+def make_grid(N, iH, iW, opt=None):
+    """Reference signature (networks.py:161-168).  The HIP warp kernel builds this
+    grid in registers; this host version exists for callers that want the tensor."""
+    gx = torch.linspace(-1.0, 1.0, iW).view(1, 1, iW, 1).expand(N, iH, -1, -1)
+    gy = torch.linspace(-1.0, 1.0, iH).view(1, iH, 1, 1).expand(N, -1, iW, -1)
+    grid = torch.cat([gx, gy], 3)
+    return grid.cuda() if (opt is not None and getattr(opt, "cuda", False)) else grid
+
+
+class ConditionGenerator(nn.Module):
+    """Try-on condition generator (reference networks.py:13-159), HIP inference path."""
+
+    def __init__(self, opt, input1_nc, input2_nc, output_nc, ngf=64, norm_layer=nn.BatchNorm2d):
+        super().__init__()
+        self.warp_feature = opt.warp_feature
+        self.out_layer_opt = opt.out_layer
+        if self.warp_feature != "T1" or self.out_layer_opt != "relu":
+            raise NotImplementedError("hr-viton_amd implements the reference defaults warp_feature='T1', "
+                                      "out_layer='relu' (test_generator.py:54-55)")
+        self.input1_nc, self.input2_nc, self.output_nc, self.ngf = input1_nc, input2_nc, output_nc, ngf
+        enc = [ngf, ngf * 2, ngf * 4, ngf * 4, ngf * 4]
+
+        def encoder(cin):
+            chans = [cin] + enc
+            return nn.Sequential(*[ResBlock(chans[i], chans[i + 1], "down", norm_layer) for i in range(5)])
+
+        self.ClothEncoder = encoder(input1_nc)
+        self.PoseEncoder = encoder(input2_nc)
+        self.conv = ResBlock(ngf * 4, ngf * 8, "same", norm_layer)
+        dec_io = [(ngf * 8, ngf * 4), (ngf * 4 * 2 + ngf * 4, ngf * 4), (ngf * 4 * 2 + ngf * 4, ngf * 2),
+                  (ngf * 2 * 2 + ngf * 4, ngf), (ngf * 1 * 2 + ngf * 4, ngf)]
+        self.SegDecoder = nn.Sequential(*[ResBlock(i, o, "up", norm_layer) for i, o in dec_io])
+        self.out_layer = ResBlock(ngf + input1_nc + input2_nc, output_nc, "same", norm_layer)
+        lat = [ngf, ngf * 2, ngf * 4, ngf * 4]
+        self.conv1 = nn.Sequential(*[nn.Conv2d(c, ngf * 4, 1, bias=True) for c in lat])
+        self.conv2 = nn.Sequential(*[nn.Conv2d(c, ngf * 4, 1, bias=True) for c in lat])
+        self.flow_conv = nn.ModuleList([nn.Conv2d(ngf * 8, 2, 3, 1, 1, bias=True) for _ in range(5)])
+        self.bottleneck = nn.Sequential(*[nn.Sequential(nn.Conv2d(c, ngf * 4, 3, 1, 1, bias=True), nn.ReLU())
+                                          for c in (ngf * 4, ngf * 4, ngf * 2, ngf)])
+        self._plan = None
+        self._plan_key = None
+
+    def normalize(self, x):
+        return x
+
+    # ------------------------------------------------------------------ plan
+    def _state_version(self):
+        return tuple(t._version for t in list(self.parameters()) + list(self.buffers()))
+
+    def _build_plan(self, device):
+        ngf, c4 = self.ngf, self.ngf * 4
+        P = {}
+        P["E1"] = [_ResBlockPlan(self.ClothEncoder[i], [self.ClothEncoder[i].in_nc], device, f"ClothEncoder.{i}")
+                   for i in range(5)]
+        P["E2"] = [_ResBlockPlan(self.PoseEncoder[i], [self.PoseEncoder[i].in_nc], device, f"PoseEncoder.{i}")
+                   for i in range(5)]
+        P["conv"] = _ResBlockPlan(self.conv, [c4], device, "conv")
+        enc = [ngf, ngf * 2, ngf * 4, ngf * 4, ngf * 4]
+        dec_out = [c4, c4, ngf * 2, ngf, ngf]
+        seg = [_ResBlockPlan(self.SegDecoder[0], [ngf * 8], device, "SegDecoder.0")]
+        for i in range(1, 5):
+            # cat([x, E2[4-i], warped_T1]) -- networks.py:141
+            seg.append(_ResBlockPlan(self.SegDecoder[i], [dec_out[i - 1], enc[4 - i], c4], device, f"SegDecoder.{i}"))
+        P["seg"] = seg
+        P["out"] = _ResBlockPlan(self.out_layer, [ngf, self.input2_nc, self.input1_nc], device, "out_layer")
+        P["conv1"] = [ConvLayer(m.weight, [m.in_channels], device, shift=m.bias, pad=0, name=f"conv1.{i}")
+                      for i, m in enumerate(self.conv1)]
+        P["conv2"] = [ConvLayer(m.weight, [m.in_channels], device, shift=m.bias, pad=0, name=f"conv2.{i}")
+                      for i, m in enumerate(self.conv2)]
+        P["flow"] = [ConvLayer(m.weight, [c4, c4], device, shift=m.bias, pad=1, name=f"flow_conv.{i}")
+                     for i, m in enumerate(self.flow_conv)]
+        P["bott"] = [ConvLayer(m[0].weight, [m[0].in_channels], device, shift=m[0].bias, pad=1, act=ACT_RELU,
+                               name=f"bottleneck.{i}") for i, m in enumerate(self.bottleneck)]
+        return P
+
+    def _get_plan(self, device):
+        key = (str(device), self._state_version())
+        if self._plan is None or self._plan_key != key:
+            self._plan = self._build_plan(device)
+            self._plan_key = key
+        return self._plan
+
+    # --------------------------------------------------------------- forward
+    def forward(self, *args, upsample="bilinear"):
+        """Reference signature ``forward(opt, input1, input2, upsample='bilinear')``
+        (networks.py:98); the 2-argument form the reference's training scripts use
+        (train_generator.py:215 ...) is accepted too."""
+        if len(args) == 3:
+            _, input1, input2 = args
+        elif len(args) == 2:
+            input1, input2 = args
+        else:
+            raise TypeError("forward(opt, input1, input2) or forward(input1, input2)")
+        if upsample != "bilinear":
+            raise NotImplementedError("HIP path implements upsample='bilinear' (the reference default)")
+        if self.training:
+            raise NotImplementedError("hr-viton_amd ConditionGenerator: training-mode (batch-stat BatchNorm + "
+                                      "backward) HIP kernels are not built yet; call .eval()")
+        return self._forward_eval(input1, input2)
+
+    @torch.no_grad()
+    def _forward_eval(self, input1: torch.Tensor, input2: torch.Tensor):
+        ops.require_cuda(input1, "ConditionGenerator.forward(input1)")
+        ops.require_cuda(input2, "ConditionGenerator.forward(input2)")
+        N, _, H, W = input1.shape
+        if H % 32 or W % 32:
+            raise ValueError(f"input size {H}x{W} must be a multiple of 32 (five stride-2 stages)")
+        P = self._get_plan(input1.device)
+        x1 = ops.to_nhwc(input1)
+        x2 = ops.to_nhwc(input2)
+        E1: List[Act] = []
+        E2: List[Act] = []
+        for i in range(5):
+            E1.append(P["E1"][i]([x1 if i == 0 else E1[-1]]))
+            E2.append(P["E2"][i]([x2 if i == 0 else E2[-1]]))
+        flow_list: List[torch.Tensor] = []
+        T1 = T2 = x = None
+        for i in range(5):
+            e1, e2 = E1[4 - i], E2[4 - i]
+            iH, iW = e1.H, e1.W
+            if i == 0:
+                T1, T2 = e1, e2
+                fl = Act(torch.empty((N, iH, iW, 2), dtype=torch.float32, device=input1.device), 2)
+                P["flow"][0]([T1, T2], out=fl)
+                flow_list.append(fl.t)
+                x = P["seg"][0]([P["conv"]([T2])])
+            else:
+                # T = up2(T) + conv1x1(E)  (networks.py:130-131): 1x1 conv, then resize with fused addend
+                a1 = P["conv1"][4 - i]([e1])
+                T1 = ops.resize_bilinear(T1, iH, iW, 0.5, 0.5, addend=a1)
+                a2 = P["conv2"][4 - i]([e2])
+                T2 = ops.resize_bilinear(T2, iH, iW, 0.5, 0.5, addend=a2)
+                # flow upsample + flow_norm + make_grid + grid_sample in one kernel (networks.py:133-135)
+                warped, fup = ops.flow_warp(T1, flow_list[-1], iH, iW, 0.5, 0.5,
+                                            (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
+                b = P["bott"][i - 1]([x])
+                fl = Act(torch.empty((N, iH, iW, 2), dtype=torch.float32, device=input1.device), 2)
+                # flow = up(flow) + flow_conv(cat([warped_T1, bottleneck(x)]))  (networks.py:137)
+                P["flow"][i]([warped, b], out=fl, residual=Act(fup, 2))
+                flow_list.append(fl.t)
+                x = P["seg"][i]([x, e2, warped])
+        warped_in, _ = ops.flow_warp(x1, flow_list[-1], H, W, 0.5, 0.5, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0,
+                                     want_flow_up=False)
+        seg = P["out"]([x, x2, warped_in])
+        seg_nchw = ops.to_nchw(seg)
+        warped_nchw = ops.to_nchw(warped_in)
+        c = self.input1_nc
+        return flow_list, seg_nchw, warped_nchw[:, :c - 1], warped_nchw[:, c - 1:]
+
+
+def save_checkpoint(model, save_path, opt=None):
+    """networks.py:411-417 -- torch.save of the CPU state_dict (same file format)."""
+    d = os.path.dirname(save_path)
+    if d and not os.path.exists(d):
+        os.makedirs(d)
+    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, save_path)
+
+
+def load_checkpoint(model, checkpoint_path, opt=None):
+    """networks.py:419-425 (strict=False).  A missing file raises FileNotFoundError
+    (the reference's bare ``raise`` surfaces as 'No active exception to reraise')."""
+    if not os.path.exists(checkpoint_path):
+        print("no checkpoint")
+        raise FileNotFoundError(checkpoint_path)
+    model.load_state_dict(torch.load(checkpoint_path, map_location="cpu"), strict=False)
+    if opt is not None and getattr(opt, "cuda", False):
+        model.cuda()

@@ -1,0 +1,265 @@
+"""Tensor-level host wrappers over the C ABI (include/hrviton_hip.h).
+
+PyTorch is plumbing here: it owns device memory and the stream; every byte of
+compute goes through libhrviton_hip.so.  Activations are NHWC fp32 ``Act``
+views (tensor [N,H,W,Cs], a channel offset and a logical channel count) so
+that channel concatenation / slicing never copies.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple, Union
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, HrvError  # noqa: F401
+
+
+def _ceil4(c: int) -> int:
+    return (c + 3) // 4 * 4
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_cuda(t: torch.Tensor, what: str):
+    if not t.is_cuda:
+        raise HrvError(f"{what}: tensor is on {t.device}; the MI355X path has no CPU fallback "
+                       "(move inputs to cuda, reference semantics of opt.cuda=True)")
+    if t.dtype != torch.float32:
+        raise HrvError(f"{what}: expected float32, got {t.dtype}")
+
+
+@dataclass
+class Act:
+    """NHWC activation view: channels [coff, coff+C) of ``t`` ([N,H,W,Cs], contiguous)."""
+    t: torch.Tensor
+    C: int
+    coff: int = 0
+
+    @property
+    def N(self): return self.t.shape[0]
+    @property
+    def H(self): return self.t.shape[1]
+    @property
+    def W(self): return self.t.shape[2]
+    @property
+    def cstride(self): return self.t.shape[3]
+    @property
+    def Cp(self):
+        """Channels the conv engine consumes (padded to a multiple of 4; pad channels are zero)."""
+        return _ceil4(self.C)
+
+    def slice(self, c0: int, c: int) -> "Act":
+        return Act(self.t, c, self.coff + c0)
+
+
+def alloc(N: int, H: int, W: int, C: int, device) -> Act:
+    cs = _ceil4(C)
+    if cs == C:
+        t = torch.empty((N, H, W, cs), dtype=torch.float32, device=device)
+    else:  # pad channels must read as zero
+        t = torch.zeros((N, H, W, cs), dtype=torch.float32, device=device)
+    return Act(t, C, 0)
+
+
+def to_nhwc(x: torch.Tensor, out: Optional[Act] = None) -> Act:
+    """NCHW (reference layout) -> NHWC Act.  hrv_nchw_to_nhwc_f32."""
+    require_cuda(x, "to_nhwc")
+    x = x.contiguous()
+    N, Cc, H, W = x.shape
+    if out is None:
+        out = alloc(N, H, W, Cc, x.device)
+    lib = _lib.load()
+    _lib.check(lib.hrv_nchw_to_nhwc_f32(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
+                                        _stream()), "hrv_nchw_to_nhwc_f32")
+    return out
+
+
+def to_nchw(a: Act, c0: int = 0, c: Optional[int] = None) -> torch.Tensor:
+    """NHWC Act (channel range) -> contiguous NCHW tensor.  hrv_nhwc_to_nchw_f32."""
+    c = a.C - c0 if c is None else c
+    out = torch.empty((a.N, c, a.H, a.W), dtype=torch.float32, device=a.t.device)
+    lib = _lib.load()
+    _lib.check(lib.hrv_nhwc_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W, out.data_ptr(),
+                                        _stream()), "hrv_nhwc_to_nchw_f32")
+    return out
+
+
+# --------------------------------------------------------------------------
+# profiling hook (bench.py): per-launch HIP events on the launch stream
+# --------------------------------------------------------------------------
+class _Prof:
+    enabled = False
+    records: list = []
+
+
+def profile_begin():
+    _Prof.enabled = True
+    _Prof.records = []
+
+
+def profile_end():
+    """Returns [(kind, name, flops, bytes, ms)] for every launch since profile_begin()."""
+    _Prof.enabled = False
+    torch.cuda.synchronize()
+    out = [(k, n, fl, by, s.elapsed_time(e)) for (k, n, fl, by, s, e) in _Prof.records]
+    _Prof.records = []
+    return out
+
+
+class _Timed:
+    def __init__(self, kind, name, flops, nbytes):
+        self.args = (kind, name, flops, nbytes)
+
+    def __enter__(self):
+        if _Prof.enabled:
+            self.s = torch.cuda.Event(enable_timing=True)
+            self.e = torch.cuda.Event(enable_timing=True)
+            self.s.record()
+        return self
+
+    def __exit__(self, *a):
+        if _Prof.enabled:
+            self.e.record()
+            _Prof.records.append((*self.args, self.s, self.e))
+        return False
+
+
+SrcSpec = Union[Act, Tuple[Act, int, int]]  # Act or (Act, up_shift, pre_act)
+
+
+class ConvLayer:
+    """One convolution of the path with its fused epilogue (hrv_conv2d_nhwc_f32).
+
+    ``weight``: torch OIHW fp32 (any device); ``src_real``: how the Cin axis splits
+    over the (channel-concatenated) sources.  Packed weights are built lazily per
+    tile configuration with the HOST packer hrv_conv2d_pack_weight_f32.
+    """
+
+    def __init__(self, weight: torch.Tensor, src_real: Sequence[int], device, scale: Optional[torch.Tensor] = None,
+                 shift: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1, act: int = ACT_NONE,
+                 slope: float = 0.2, name: str = "conv"):
+        w = weight.detach().to("cpu", torch.float32).contiguous()
+        self.Cout, cin, self.KH, self.KW = w.shape
+        assert sum(src_real) == cin, (name, src_real, cin)
+        assert 1 <= len(src_real) <= _lib.HRV_MAX_SRC
+        self.w_cpu = w
+        self.src_real = list(src_real)
+        self.src_pad = [_ceil4(c) for c in src_real]
+        self.device = device
+        self.stride, self.pad, self.act, self.slope, self.name = stride, pad, act, slope, name
+        self.scale = None if scale is None else scale.detach().to(device, torch.float32).contiguous()
+        self.shift = None if shift is None else shift.detach().to(device, torch.float32).contiguous()
+        self._packed = {}
+        self._w_dev = None
+
+    def _get_packed(self, cfg: int) -> torch.Tensor:
+        if cfg not in self._packed:
+            lib = _lib.load()
+            n = len(self.src_pad)
+            srcC = (C.c_int32 * n)(*self.src_pad)
+            srcR = (C.c_int32 * n)(*self.src_real)
+            elems = lib.hrv_conv2d_packed_elems(self.Cout, self.KH, self.KW, n, srcC, cfg)
+            if elems <= 0:
+                raise HrvError(f"{self.name}: hrv_conv2d_packed_elems failed")
+            buf = torch.empty(elems, dtype=torch.float32)
+            _lib.check(lib.hrv_conv2d_pack_weight_f32(self.w_cpu.data_ptr(), self.Cout, self.KH, self.KW, n, srcC,
+                                                      srcR, cfg, buf.data_ptr()), "hrv_conv2d_pack_weight_f32")
+            self._packed[cfg] = buf.to(self.device)
+        return self._packed[cfg]
+
+    def out_hw(self, H: int, W: int) -> Tuple[int, int]:
+        return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
+
+    def flops(self, N, Ho, Wo) -> float:
+        return 2.0 * N * Ho * Wo * self.Cout * sum(self.src_real) * self.KH * self.KW
+
+    def __call__(self, srcs: Sequence[SrcSpec], out: Optional[Act] = None, residual: Optional[Act] = None,
+                 H: Optional[int] = None, W: Optional[int] = None) -> Act:
+        lib = _lib.load()
+        specs = [(s, 0, ACT_NONE) if isinstance(s, Act) else s for s in srcs]
+        assert len(specs) == len(self.src_real), (self.name, len(specs), self.src_real)
+        a0, up0, _ = specs[0]
+        N = a0.N
+        if H is None:
+            H, W = a0.H << up0, a0.W << up0
+        Ho, Wo = self.out_hw(H, W)
+        if out is None:
+            out = alloc(N, Ho, Wo, self.Cout, a0.t.device)
+        d = _lib.hrv_conv2d_t()
+        d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
+        d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
+        d.nsrc = len(specs)
+        for i, (a, up, pre) in enumerate(specs):
+            assert a.C == self.src_real[i], (self.name, i, a.C, self.src_real[i])
+            assert (a.H << up, a.W << up) == (H, W) and a.N == N, (self.name, i, a.t.shape, up, H, W)
+            s = d.src[i]
+            s.ptr, s.C, s.cstride, s.coff = a.t.data_ptr(), self.src_pad[i], a.cstride, a.coff
+            s.up_shift, s.pre_act, s.C_real = up, pre, self.src_real[i]
+        naive = os.environ.get("HRV_CONV_IMPL", "mfma") == "naive"
+        cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, self.Cout)
+        forced = os.environ.get("HRV_CONV_TILE")
+        if forced is not None:
+            cfg = int(forced)
+        d.Cout, d.tile_cfg = self.Cout, cfg
+        if naive:
+            if self._w_dev is None:
+                self._w_dev = self.w_cpu.to(self.device)
+            d.w_oihw = self._w_dev.data_ptr()
+        else:
+            d.w_packed = self._get_packed(cfg).data_ptr()
+        d.scale = None if self.scale is None else self.scale.data_ptr()
+        d.shift = None if self.shift is None else self.shift.data_ptr()
+        if residual is not None:
+            assert (residual.N, residual.H, residual.W) == (N, Ho, Wo) and residual.C == self.Cout
+            d.residual, d.res_cstride, d.res_coff = residual.t.data_ptr(), residual.cstride, residual.coff
+        d.act, d.act_slope = self.act, self.slope
+        assert (out.N, out.H, out.W) == (N, Ho, Wo) and out.C == self.Cout, (self.name, out.t.shape, out.C)
+        d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+        fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else lib.hrv_conv2d_nhwc_f32
+        with _Timed("conv", self.name, self.flops(N, Ho, Wo), 0):
+            _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")
+        return out
+
+
+def resize_bilinear(a: Act, Ho: int, Wo: int, rh: float, rw: float, addend: Optional[Act] = None,
+                    out: Optional[Act] = None) -> Act:
+    """hrv_resize_bilinear_nhwc_f32: out = bilinear(a) (+ addend)."""
+    lib = _lib.load()
+    if out is None:
+        out = alloc(a.N, Ho, Wo, a.C, a.t.device)
+    add_ptr, acs, aco = (None, 0, 0) if addend is None else (addend.t.data_ptr(), addend.cstride, addend.coff)
+    nbytes = 4.0 * a.N * Ho * Wo * a.Cp * (2 if addend is None else 3)
+    with _Timed("resize", "bilinear", 0.0, nbytes):
+        _lib.check(lib.hrv_resize_bilinear_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, Ho, Wo,
+                                                    rh, rw, add_ptr, acs, aco, out.t.data_ptr(), out.cstride,
+                                                    out.coff, _stream()), "hrv_resize_bilinear_nhwc_f32")
+    return out
+
+
+def flow_warp(src: Act, flow: torch.Tensor, Ho: int, Wo: int, rh: float, rw: float, norm_x: float, norm_y: float,
+              out: Optional[Act] = None, want_flow_up: bool = True):
+    """hrv_flow_warp_nhwc_f32.  ``flow`` is [N,fh,fw,2] (reference layout).
+    Returns (warped Act [N,Ho,Wo,C], flow_up tensor [N,Ho,Wo,2] or None)."""
+    lib = _lib.load()
+    require_cuda(flow, "flow_warp")
+    assert flow.is_contiguous() and flow.shape[-1] == 2 and flow.shape[0] == src.N
+    if out is None:
+        out = alloc(src.N, Ho, Wo, src.C, src.t.device)
+    fup = torch.empty((src.N, Ho, Wo, 2), dtype=torch.float32, device=flow.device) if want_flow_up else None
+    d = _lib.hrv_flow_warp_t()
+    d.src, d.N, d.H, d.W, d.C = src.t.data_ptr(), src.N, src.H, src.W, src.Cp
+    d.src_cstride, d.src_coff = src.cstride, src.coff
+    d.flow, d.fh, d.fw, d.Ho, d.Wo = flow.data_ptr(), flow.shape[1], flow.shape[2], Ho, Wo
+    d.rh, d.rw, d.norm_x, d.norm_y = rh, rw, norm_x, norm_y
+    d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+    d.flow_up = None if fup is None else fup.data_ptr()
+    nbytes = 4.0 * src.N * Ho * Wo * src.Cp * 2
+    with _Timed("warp", "flow_warp", 0.0, nbytes):
+        _lib.check(lib.hrv_flow_warp_nhwc_f32(C.byref(d), _stream()), "hrv_flow_warp_nhwc_f32")
+    return out, fup

@@ -1,0 +1,169 @@
+/*
+ * hrviton_hip.h -- C ABI of the MI355X (gfx950) HR-VITON hot path.
+ *
+ * The reference (sangyun884/HR-VITON) is pure Python/PyTorch: it has no FFI of
+ * its own, so the "plugin boundary" for the hot path is the set of torch ops
+ * its modules dispatch.  Every entry point below replaces
+ * one such dispatch (file:line into /root/reference cited per function) and is
+ * what a ctypes / cffi / pybind stub on the reference side would bind
+ * (INTEGRATION.md shows the stub).  Conventions:
+ *
+ *   - plain C: raw device pointers + sizes, no torch types, no C++ in the
+ *     signatures.  `hrv_stream_t` is a `hipStream_t` passed as void*.
+ *   - activations are NHWC fp32 (or bf16 where the name says so); a tensor is
+ *     addressed as base[pixel * cstride + coff + c] so channel-concatenation and
+ *     channel-slicing never need a copy.  Channel counts handed to the conv
+ *     engine are multiples of 4 (callers zero-pad, e.g. 9 -> 12).
+ *   - all memory is caller-owned; kernels borrow pointers for the duration of
+ *     the launch on `stream`; no hidden allocation, no global state but the
+ *     thread-local last-error string.
+ *   - return value: 0 (HRV_OK) or a negative hrv_status; hrv_last_error() gives
+ *     the message.  Nothing here ever falls back to a CPU path.
+ */
+#ifndef HRVITON_HIP_H
+#define HRVITON_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* hrv_stream_t; /* hipStream_t */
+
+enum hrv_status {
+  HRV_OK = 0,
+  HRV_ERR_ARG = -1,    /* bad shape / alignment / null pointer */
+  HRV_ERR_LAUNCH = -2, /* hipLaunch / hipGetLastError failure */
+  HRV_ERR_NODEV = -3   /* no gfx950 device */
+};
+
+enum hrv_act { HRV_ACT_NONE = 0, HRV_ACT_RELU = 1, HRV_ACT_LRELU = 2, HRV_ACT_TANH = 3 };
+
+const char* hrv_version(void);
+const char* hrv_last_error(void);
+/* 0 if a gfx950 device is visible to the process. */
+int hrv_device_check(void);
+
+/* ------------------------------------------------------------------------
+ * Convolution engine (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
+ * Replaces every nn.Conv2d on the path: networks.py:171-198 (ResBlock
+ * 3x3 s1/s2, 1x1), :63-93 (conv1/conv2/flow_conv/bottleneck);
+ * network_generator.py:97-99,132-143,184-186,201 (SPADE / resblock / stem
+ * convs) and :263-272 (4x4 s2 PatchGAN), with the surrounding
+ * eval-BatchNorm / bias / residual / ReLU|LeakyReLU|tanh fused as an epilogue:
+ *     out = act( acc * scale[c] + shift[c] + residual )
+ * and torch.cat(..., 1) / nn.Upsample(nearest, x2) of the *inputs* folded into
+ * the gather (several sources, optional half-resolution source).
+ * ---------------------------------------------------------------------- */
+#define HRV_MAX_SRC 4
+
+typedef struct hrv_src {
+  const void* ptr;  /* NHWC base */
+  int32_t C;        /* channels taken from this source (multiple of 4)       */
+  int32_t cstride;  /* channels per pixel in memory (multiple of 4)          */
+  int32_t coff;     /* first channel (multiple of 4)                         */
+  int32_t up_shift; /* 0: source is H x W; 1: source is (H/2) x (W/2) and is
+                       read through a nearest x2 upsample                    */
+  int32_t pre_act;  /* hrv_act applied to the loaded values (NONE / LRELU,
+                       slope 0.2: network_generator.py:244)                  */
+  int32_t C_real;   /* channels that exist in the raw OIHW weight for this
+                       source (<= C; 0 means C).  Only the naive cross-check
+                       reads it; the packed weight already has zero rows.    */
+} hrv_src_t;
+
+typedef struct hrv_conv2d {
+  int32_t N, H, W;   /* conv input extent (after any folded upsample)        */
+  int32_t Ho, Wo;    /* output extent                                        */
+  int32_t KH, KW, stride, pad;
+  int32_t nsrc;
+  hrv_src_t src[HRV_MAX_SRC];
+  const void* w_packed; /* from hrv_conv2d_pack_weight_f32 (device copy)     */
+  const float* w_oihw;  /* device copy of the raw [Cout][Cin][KH][KW] weight;
+                           only read by hrv_conv2d_naive_nhwc_f32            */
+  int32_t Cout;
+  int32_t tile_cfg;     /* from hrv_conv2d_pick_tile                         */
+  const float* scale;   /* [Cout] or NULL (=1)                               */
+  const float* shift;   /* [Cout] or NULL (=0)                               */
+  const void* residual; /* NHWC, same pixels as out, or NULL                 */
+  int32_t res_cstride, res_coff;
+  int32_t act;          /* hrv_act                                           */
+  float act_slope;      /* LeakyReLU negative slope                          */
+  void* out;            /* NHWC                                              */
+  int32_t out_cstride, out_coff;
+} hrv_conv2d_t;
+
+/* Tile configuration for (M = N*Ho*Wo output pixels, Cout): returns cfg id. */
+int hrv_conv2d_pick_tile(int64_t M, int32_t Cout);
+/* BN (output-channel tile) / BM (pixel tile) of a cfg; <0 if cfg is invalid. */
+int hrv_conv2d_tile_bn(int32_t tile_cfg);
+int hrv_conv2d_tile_bm(int32_t tile_cfg);
+/* Number of floats of the packed weight for this layer. */
+int64_t hrv_conv2d_packed_elems(int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                const int32_t* srcC, int32_t tile_cfg);
+/* HOST function: repack w[Cout][sum(srcC_real)][KH][KW] (torch layout) into the
+ * K-tiled layout the MFMA kernel streams:  [kt][CoutPad][16] with
+ * kt = ((kh*KW + kw) * chunks_total + chunk) and chunk running over the
+ * sources' 16-channel groups.  srcC[i] are the padded per-source channel
+ * counts used by the kernel (multiples of 4), srcC_real[i] the channels that
+ * exist in w (<= srcC[i]); padded rows are zero. */
+int hrv_conv2d_pack_weight_f32(const float* w_oihw, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                               const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
+                               float* out);
+int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
+/* Same contract, one thread per output element, raw OIHW weights.  A device
+ * side cross-check used by the tests to localise faults; never on the product
+ * path. */
+int hrv_conv2d_naive_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Layout converters at the module boundary (the reference's tensors are NCHW).
+ * ---------------------------------------------------------------------- */
+int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, float* out,
+                         int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
+                         int32_t H, int32_t W, float* out, hrv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Bilinear resize, align_corners=False (F.interpolate / nn.Upsample bilinear:
+ * networks.py:130-133,150,181; test_generator.py:144-150,179,207), NHWC, with
+ * an optional fused addend: out = resize(in) + addend   (networks.py:130-131).
+ * rh, rw are the source-index ratios: 1/scale_factor, or in/out for size=.
+ * ---------------------------------------------------------------------- */
+int hrv_resize_bilinear_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C,
+                                 int32_t in_cstride, int32_t in_coff, int32_t Ho, int32_t Wo, float rh,
+                                 float rw, const float* addend, int32_t add_cstride, int32_t add_coff,
+                                 float* out, int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * Appearance-flow warp: the fused form of
+ *     flow  = F.interpolate(flow_prev, bilinear)            networks.py:133,150
+ *     fnorm = flow / (norm_x, norm_y)                        networks.py:134,151
+ *     grid  = make_grid(N, Ho, Wo) (= linspace(-1,1))        networks.py:161-168
+ *     out   = F.grid_sample(src, fnorm + grid, 'bilinear',
+ *                           padding_mode='border',
+ *                           align_corners=False)             networks.py:135,152
+ * (also test_generator.py:206-213 with size= resize and the hard-coded norms).
+ * flow_prev is the reference's own [N,fh,fw,2] (x,y) layout.  flow_up
+ * (optional) receives the un-normalised upsampled flow [N,Ho,Wo,2].
+ * ---------------------------------------------------------------------- */
+typedef struct hrv_flow_warp {
+  const float* src;
+  int32_t N, H, W, C; /* sampled tensor extent (C multiple of 4)             */
+  int32_t src_cstride, src_coff;
+  const float* flow;
+  int32_t fh, fw;
+  int32_t Ho, Wo;
+  float rh, rw;
+  float norm_x, norm_y;
+  float* out;
+  int32_t out_cstride, out_coff;
+  float* flow_up; /* or NULL */
+} hrv_flow_warp_t;
+int hrv_flow_warp_nhwc_f32(const hrv_flow_warp_t* d, hrv_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HRVITON_HIP_H */

@@ -1,0 +1,236 @@
+"""GPU parity tests proper: every kernel is called through the C ABI
+(hr_viton_amd.ops -> ctypes -> libhrviton_hip.so) and compared with the CPU
+oracle on the same seeded inputs.  Tolerances are stated per test; fp32 paths
+are held to <=1e-4 relative of the tensor's max (north_star allows 1e-3)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hrviton_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+DIAG_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+
+
+def _ops():
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops
+    return ops
+
+
+def _nhwc(ops, x):
+    return ops.to_nhwc(x.cuda())
+
+
+def _diag(name, got, want):
+    """On mismatch, dump an error histogram keyed by (pixel%32, channel%32) -- the MFMA
+    fragment coordinates -- so a single GPU run localises lane-mapping faults."""
+    os.makedirs(DIAG_DIR, exist_ok=True)
+    err = (got - want).abs()
+    bad = err > 1e-3 * max(1.0, want.abs().max().item())
+    lines = [f"{name}: shape {tuple(got.shape)} max_err {err.max().item():.4e} max_ref {want.abs().max().item():.4e} "
+             f"bad_frac {bad.float().mean().item():.4f} got_nan {torch.isnan(got).sum().item()}"]
+    if got.dim() == 4:  # NCHW
+        N, C, H, W = got.shape
+        pix = torch.arange(N * H * W).view(N, 1, H, W).expand(N, C, H, W)
+        ch = torch.arange(C).view(1, C, 1, 1).expand(N, C, H, W)
+        lines.append("bad by channel%32: " + str(torch.bincount((ch[bad] % 32), minlength=32).tolist()))
+        lines.append("bad by pixel%32:   " + str(torch.bincount((pix[bad] % 32), minlength=32).tolist()))
+        lines.append("bad by pixel//32%8:" + str(torch.bincount((pix[bad] // 32 % 8), minlength=8).tolist()))
+        idx = bad.nonzero()[:8].tolist()
+        for i in idx:
+            lines.append(f"  at {i}: got {got[tuple(i)].item():.6f} want {want[tuple(i)].item():.6f}")
+    with open(os.path.join(DIAG_DIR, "diag_" + name.replace("/", "_") + ".txt"), "w") as f:
+        f.write("\n".join(lines) + "\n")
+    return "\n".join(lines)
+
+
+def _assert_close(name, got, want, tol=1e-4):
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (name, got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = max(1.0, want.abs().max().item())
+    if not (err <= tol * ref) or torch.isnan(got).any():
+        pytest.fail(_diag(name, got, want))
+
+
+def test_device_is_gfx950():
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import _lib
+    lib = _lib.load()
+    assert lib.hrv_device_check() == 0, lib.hrv_last_error()
+
+
+def test_layout_roundtrip():
+    ops = _ops()
+    g = torch.Generator().manual_seed(0)
+    for C in (4, 13, 16, 3):
+        x = torch.randn(2, C, 9, 7, generator=g)
+        a = _nhwc(ops, x)
+        assert a.t.shape == (2, 9, 7, (C + 3) // 4 * 4)
+        assert torch.equal(a.t[..., :C].cpu(), x.permute(0, 2, 3, 1))
+        assert (a.t[..., C:] == 0).all()
+        assert torch.equal(ops.to_nchw(a).cpu(), x)
+
+
+@pytest.mark.parametrize("shape,out", [((2, 8, 5, 4), (10, 8)), ((1, 12, 6, 9), (12, 18)), ((2, 4, 7, 3), (19, 11))])
+def test_resize_bilinear(shape, out):
+    ops = _ops()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(*shape, generator=g)
+    N, C, H, W = shape
+    Ho, Wo = out
+    if (Ho, Wo) == (2 * H, 2 * W):
+        want = O.resize_bilinear(x, scale_factor=2)
+        rh = rw = 0.5
+    else:
+        want = O.resize_bilinear(x, size=out)
+        rh, rw = H / Ho, W / Wo
+    got = ops.to_nchw(ops.resize_bilinear(_nhwc(ops, x), Ho, Wo, rh, rw))
+    _assert_close("resize_bilinear", got, want, 1e-6)
+    add = torch.randn(N, C, Ho, Wo, generator=g)
+    got = ops.to_nchw(ops.resize_bilinear(_nhwc(ops, x), Ho, Wo, rh, rw, addend=_nhwc(ops, add)))
+    _assert_close("resize_bilinear_add", got, want + add, 1e-6)
+
+
+@pytest.mark.parametrize("C,H,W,scale", [(4, 12, 8, 2), (24, 6, 10, 2), (8, 16, 12, 4)])
+def test_flow_warp(C, H, W, scale):
+    """Fused flow upsample + normalise + base grid + grid_sample vs the oracle's
+    step-by-step composition (networks.py:133-135 / test_generator.py:206-213)."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(2)
+    N = 2
+    fh, fw = H // scale, W // scale
+    src = torch.randn(N, C, H, W, generator=g)
+    flow = torch.randn(N, fh, fw, 2, generator=g) * 3.0  # large enough to hit the border clamp
+    if scale == 2:
+        fup = O.resize_bilinear(flow.permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1)
+        rh = rw = 0.5
+    else:
+        fup = O.resize_bilinear(flow.permute(0, 3, 1, 2), size=(H, W)).permute(0, 2, 3, 1)
+        rh, rw = fh / H, fw / W
+    nx, ny = (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0
+    fnorm = torch.cat([fup[..., 0:1] / nx, fup[..., 1:2] / ny], 3)
+    want = O.grid_sample_bilinear_border(src, fnorm + O.make_grid(N, H, W))
+    out, fup_gpu = ops.flow_warp(_nhwc(ops, src), flow.cuda().contiguous(), H, W, rh, rw, nx, ny)
+    _assert_close("flow_up", fup_gpu.cpu(), fup, 1e-6)
+    _assert_close("flow_warp", ops.to_nchw(out), want, 2e-5)
+    # property: bilinear/border sampling is a convex combination of source pixels
+    o = ops.to_nchw(out).cpu()
+    assert o.max() <= src.max() + 1e-5 and o.min() >= src.min() - 1e-5
+
+
+CONV_CASES = [
+    # name, sources(real C), Cout, k, stride, pad, H, W, extras
+    ("first_4ch_s2", [4], 96, 3, 2, 1, 32, 24, {}),
+    ("3x3_96", [96], 96, 3, 1, 1, 16, 12, {"bn": True, "act": "relu"}),
+    ("3x3_res_relu", [32], 192, 3, 1, 1, 16, 12, {"bn": True, "act": "relu", "res": True}),
+    ("1x1_cat3", [96, 16, 4], 13, 1, 1, 0, 16, 12, {"bias": True}),
+    ("flow_cat2", [48, 48], 2, 3, 1, 1, 16, 12, {"bias": True, "res": True, "out_cs": 2}),
+    ("wide_384", [64], 384, 3, 1, 1, 8, 6, {"bias": True, "act": "relu"}),
+    ("cout_128", [20], 128, 3, 1, 1, 12, 8, {"bias": True}),
+    ("cin9_pad12", [9], 40, 3, 1, 1, 16, 8, {"bias": True}),
+    ("patchgan_4x4_s2", [10], 64, 4, 2, 2, 18, 14, {"bias": True, "act": "lrelu"}),
+    ("up_cat_nearest", [32, 16], 64, 3, 1, 1, 16, 12, {"bias": True, "up0": True}),
+    ("img_preact_tanh", [32], 3, 3, 1, 1, 16, 12, {"bias": True, "pre": True, "act": "tanh"}),
+    ("big_m", [16], 32, 3, 1, 1, 96, 80, {"bias": True}),
+]
+
+
+def _run_conv_case(ops, case, impl, tile=None):
+    name, real, cout, k, stride, pad, H, W, ex = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    N = 2
+    xs = []
+    for i, c in enumerate(real):
+        if ex.get("up0") and i == 0:
+            xs.append(torch.randn(N, c, H // 2, W // 2, generator=g))
+        else:
+            xs.append(torch.randn(N, c, H, W, generator=g))
+    w = torch.randn(cout, sum(real), k, k, generator=g) * (1.0 / (sum(real) * k * k) ** 0.5)
+    scale = (torch.rand(cout, generator=g) + 0.5) if ex.get("bn") else None
+    shift = torch.randn(cout, generator=g) * 0.3 if (ex.get("bn") or ex.get("bias")) else None
+    act = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}.get(ex.get("act"), ops.ACT_NONE)
+    # ---- oracle (torch CPU fp32)
+    full = []
+    for i, x in enumerate(xs):
+        if ex.get("up0") and i == 0:
+            x = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        full.append(x)
+    xin = torch.cat(full, 1)
+    if ex.get("pre"):
+        xin = F.leaky_relu(xin, 0.2)
+    ref = F.conv2d(xin, w, None, stride=stride, padding=pad)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        ref = ref + shift.view(1, -1, 1, 1)
+    res = torch.randn(ref.shape, generator=g) if ex.get("res") else None
+    if res is not None:
+        ref = ref + res
+    ref = {ops.ACT_RELU: F.relu, ops.ACT_LRELU: lambda t: F.leaky_relu(t, 0.2), ops.ACT_TANH: torch.tanh,
+           ops.ACT_NONE: lambda t: t}[act](ref)
+    # ---- HIP
+    layer = ops.ConvLayer(w, real, "cuda", scale=scale, shift=shift, stride=stride, pad=pad, act=act, name=name)
+    srcs = []
+    for i, x in enumerate(xs):
+        a = _nhwc(ops, x)
+        up = 1 if (ex.get("up0") and i == 0) else 0
+        srcs.append((a, up, ops.ACT_LRELU if ex.get("pre") else ops.ACT_NONE))
+    out = None
+    Ho, Wo = ref.shape[2:]
+    if ex.get("out_cs"):
+        out = ops.Act(torch.empty((N, Ho, Wo, ex["out_cs"]), device="cuda"), cout)
+    res_act = None
+    if res is not None:
+        if ex.get("out_cs"):
+            res_act = ops.Act(res.permute(0, 2, 3, 1).contiguous().cuda(), cout)
+        else:
+            res_act = _nhwc(ops, res)
+    old = {k_: os.environ.get(k_) for k_ in ("HRV_CONV_IMPL", "HRV_CONV_TILE")}
+    try:
+        os.environ["HRV_CONV_IMPL"] = impl
+        if tile is not None:
+            os.environ["HRV_CONV_TILE"] = str(tile)
+        else:
+            os.environ.pop("HRV_CONV_TILE", None)
+        o = layer(srcs, out=out, residual=res_act, H=H, W=W)
+        torch.cuda.synchronize()
+    finally:
+        for k_, v in old.items():
+            if v is None:
+                os.environ.pop(k_, None)
+            else:
+                os.environ[k_] = v
+    if ex.get("out_cs"):
+        got = o.t[..., :cout].permute(0, 3, 1, 2).contiguous()
+    else:
+        got = ops.to_nchw(o)
+        assert (o.t[..., cout:] == 0).all(), "pad channels must stay zero"
+    return got, ref
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_naive_device_crosscheck(case):
+    ops = _ops()
+    got, ref = _run_conv_case(ops, case, "naive")
+    _assert_close("conv_naive_" + case[0], got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_mfma_default_tile(case):
+    ops = _ops()
+    got, ref = _run_conv_case(ops, case, "mfma")
+    _assert_close("conv_mfma_" + case[0], got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("tile", list(range(8)))
+def test_conv_mfma_every_tile_config(tile):
+    ops = _ops()
+    for case in (CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[11]):
+        got, ref = _run_conv_case(ops, case, "mfma", tile=tile)
+        _assert_close(f"conv_mfma_t{tile}_" + case[0], got, ref, 2e-5)

@@ -1,0 +1,130 @@
+"""GPU parity of the whole condition generator (product module
+hr_viton_amd.networks.ConditionGenerator -> C ABI -> HIP kernels) against
+(1) golden vectors from the real reference and (2) the oracle run live.
+Tolerances: flows / seg logits 1e-4 of the tensor max (fp32 path; north_star
+allows 1e-3); warped white-noise images 5e-4 (a 1e-5-px flow difference times
+|dI/dx|~2, see tests/test_oracle_golden.py)."""
+from argparse import Namespace
+
+import pytest
+import torch
+import torch.nn as nn
+
+from conftest import load_golden
+from oracle import hrviton_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def _build(ngf, sd=None, seed=0):
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.networks import ConditionGenerator
+    opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu")
+    torch.manual_seed(seed)
+    m = ConditionGenerator(opt, 4, 16, 13, ngf=ngf, norm_layer=nn.BatchNorm2d)
+    if sd is not None:
+        m.load_state_dict(sd)
+    return opt, m
+
+
+def _rand_inputs(N, H, W, seed):
+    g = torch.Generator().manual_seed(seed)
+    input1 = torch.cat([torch.rand(N, 3, H, W, generator=g) * 2 - 1,
+                        (torch.rand(N, 1, H, W, generator=g) > 0.5).float()], 1)
+    lab = torch.randint(0, 13, (N, 1, H, W), generator=g)
+    input2 = torch.cat([torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0), torch.rand(N, 3, H, W, generator=g) * 2 - 1], 1)
+    return input1, input2
+
+
+def _randomize(m, seed):
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for mod in m.modules():
+            if isinstance(mod, nn.BatchNorm2d):
+                mod.running_mean.copy_(torch.randn(mod.running_mean.shape, generator=g) * 0.2)
+                mod.running_var.copy_(torch.rand(mod.running_var.shape, generator=g) + 0.5)
+                mod.weight.copy_(1.0 + 0.2 * torch.randn(mod.weight.shape, generator=g))
+                mod.bias.copy_(0.1 * torch.randn(mod.bias.shape, generator=g))
+        for fc in m.flow_conv:
+            fc.weight.mul_(4.0)
+
+
+def _check(outs, want, tol=1e-4, tol_warp=5e-4):
+    flow_list, seg, wc, wcm = outs
+    wflow, wseg, wwc, wwcm = want
+    assert len(flow_list) == 5
+    for i, (a, b) in enumerate(zip(flow_list, wflow)):
+        assert tuple(a.shape) == tuple(b.shape)
+        assert _rel(a, b) <= tol, f"flow[{i}] rel err {_rel(a, b)}"
+    assert tuple(seg.shape) == tuple(wseg.shape) and _rel(seg, wseg) <= tol, f"seg rel err {_rel(seg, wseg)}"
+    assert tuple(wc.shape) == tuple(wwc.shape) and _rel(wc, wwc) <= tol_warp, f"warped_c rel err {_rel(wc, wwc)}"
+    assert tuple(wcm.shape) == tuple(wwcm.shape) and _rel(wcm, wwcm) <= tol_warp, f"warped_cm {_rel(wcm, wwcm)}"
+    # argmax label map: exact match expected; report the top-2 margin at any mismatch
+    la, lb = seg.cpu().argmax(1), wseg.argmax(1)
+    mism = (la != lb)
+    if mism.any():
+        top2 = wseg.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])[mism]
+        assert margin.max() < 1e-5, f"{mism.sum().item()} argmax mismatches, max top-2 margin {margin.max().item()}"
+
+
+def test_tocg_golden_reference_vectors():
+    g = load_golden("tocg_ngf8_96x64.pt")
+    opt, m = _build(g["ngf"], g["state_dict"])
+    m.cuda().eval()
+    outs = m(opt, g["input1"].cuda(), g["input2"].cuda())
+    _check(outs, (g["flow_list"], g["seg"], g["warped_c"], g["warped_cm"]))
+
+
+def test_tocg_two_arg_forward_and_plan_refresh():
+    g = load_golden("tocg_ngf8_96x64.pt")
+    opt, m = _build(g["ngf"], g["state_dict"])
+    m.cuda().eval()
+    a = m(g["input1"].cuda(), g["input2"].cuda())  # the arity the reference's train scripts use
+    _check(a, (g["flow_list"], g["seg"], g["warped_c"], g["warped_cm"]))
+    with torch.no_grad():
+        m.out_layer.block[4].bias.add_(1.0)       # weights changed -> plan must be rebuilt
+    b = m(opt, g["input1"].cuda(), g["input2"].cuda())
+    assert (b[1] - a[1]).abs().max() > 1e-3
+
+
+def test_tocg_ngf96_256x192_vs_oracle_live():
+    """The released configuration (ngf=96, 256x192: test_generator.py:144-159,260)."""
+    opt, m = _build(96, seed=3)
+    _randomize(m, 5)
+    m.eval()
+    input1, input2 = _rand_inputs(2, 256, 192, 11)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = O.tocg_forward(sd, input1, input2)
+    m.cuda()
+    outs = m(opt, input1.cuda(), input2.cuda())
+    _check(outs, want)
+
+
+def test_tocg_full_size_properties():
+    """BASELINE config #2 size (1024x768): the oracle needs ~12 s/image on CPU, so check
+    size-independent properties: determinism (bitwise), per-sample independence
+    (batch of two identical images == single image, bitwise), convexity of the warp."""
+    opt, m = _build(96, seed=3)
+    _randomize(m, 5)
+    m.cuda().eval()
+    i1, i2 = _rand_inputs(1, 1024, 768, 21)
+    i1, i2 = i1.cuda(), i2.cuda()
+    a = m(opt, i1, i2)
+    b = m(opt, i1, i2)
+    for x, y in zip(a[0] + [a[1], a[2], a[3]], b[0] + [b[1], b[2], b[3]]):
+        assert torch.equal(x, y), "non-deterministic"
+        assert torch.isfinite(x).all()
+    c = m(opt, torch.cat([i1, i1]), torch.cat([i2, i2]))
+    assert torch.equal(c[1][0], a[1][0]) and torch.equal(c[1][1], a[1][0])
+    assert torch.equal(c[0][-1][1], a[0][-1][0])
+    assert a[1].shape == (1, 13, 1024, 768) and a[0][-1].shape == (1, 512, 384, 2)
+    assert a[3].min() >= 0.0 and a[3].max() <= 1.0          # warped mask stays in [0,1]
+    assert a[2].min() >= i1[:, :3].min() - 1e-6 and a[2].max() <= i1[:, :3].max() + 1e-6
+    assert (a[1] >= 0).all()                                  # out_layer='relu' ends in ReLU
