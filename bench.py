@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(cores, 32))")
+    ap.add_argument("--dump-launches", default=None, help="write the per-launch table of one step to this file")
     args = ap.parse_args()
 
     import torch
@@ -96,6 +98,11 @@ def main():
     ops.profile_begin()
     step(0)
     recs = ops.profile_end()
+    if args.dump_launches and rank == 0:
+        with open(args.dump_launches, "w") as f:
+            for k, n, fl, by, ms in recs:
+                f.write(f"{k:8s} {n:44s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s  "
+                        f"{by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s\n")
     conv = [r for r in recs if r[0] == "conv"]
     conv_flops = sum(r[2] for r in conv)
     conv_ms = sum(r[4] for r in conv)
@@ -118,7 +125,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import hrviton_oracle as O
         c1, c2 = i1[:1].cpu(), i2[:1].cpu()
-        torch.set_num_threads(os.cpu_count() or 1)
+        # all 256 host threads of the GPU box are slower than 32 on this shape (oversubscribed oneDNN)
+        torch.set_num_threads(args.cpu_threads or min(os.cpu_count() or 1, 32))
         t0 = time.perf_counter()
         with torch.no_grad():
             want = O.tocg_forward(sd_cpu, c1, c2)

@@ -21,6 +21,7 @@
 //
 // Reference ops replaced: see include/hrviton_hip.h (hrv_conv2d_nhwc_f32).
 #include <stdarg.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -59,6 +60,7 @@ struct ConvParams {
   float pre_slope;
   float* out;
   int out_cs, out_co;
+  int debug;  // HRV_CONV_DEBUG ablation bits (perf investigation only; 0 on the product path)
 };
 
 template <int TM, int TN, int WM, int WN>
@@ -140,7 +142,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
       for (int r = 0; r < AR; ++r) {
         const int hi = a_hi0[r] + it_kh;
         const int wi = a_wi0[r] + it_kw;
-        const bool ok = a_ok[r] && c_ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W;
+        const bool ok = a_ok[r] && c_ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W && !(p.debug & 4);
         // branch-free: always load from a valid address, then select
         const size_t off =
             ok ? ((size_t)(a_n[r] * Hs + (hi >> s_up)) * Ws + (wi >> s_up)) * s_cs + s_co + c : (size_t)0;
@@ -170,7 +172,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
       }
     }
 
-    if (kt >= 0) {
+    if (kt >= 0 && !(p.debug & 8)) {
       const int buf = kt & 1;
       const float* As = smem + buf * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;
       const float* Bs = smem + buf * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;
@@ -210,6 +212,17 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
     __syncthreads();
   }
 
+  if (p.debug & 1) {  // ablation: main loop only (one dependent store keeps the accumulators live)
+    float t = 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) t += acc[i][j][e];
+    if (t == 12345.678f) p.out[0] = t;
+    return;
+  }
   // ---- fused epilogue: D layout col = lane&31 (cout), row = (reg&3)+8*(reg>>2)+4*(lane>>5) (pixel)
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
@@ -328,6 +341,10 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   p.res = (const float*)d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff;
   p.act = d->act; p.slope = d->act_slope; p.pre_slope = 0.2f;
   p.out = (float*)d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
+  {
+    static const int dbg = getenv("HRV_CONV_DEBUG") ? atoi(getenv("HRV_CONV_DEBUG")) : 0;
+    p.debug = dbg;
+  }
   HRV_REQUIRE(d->out_cstride >= d->out_coff + d->Cout, "conv2d: out slice out of range");
   HRV_REQUIRE(d->residual == nullptr || d->res_cstride >= d->res_coff + d->Cout, "conv2d: residual slice out of range");
   if (need_packed) {

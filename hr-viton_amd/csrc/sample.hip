@@ -170,6 +170,41 @@ __global__ void flow_warp_kernel(const WarpParams p) {
   }
 }
 
+
+// ---------------------------------------------------------------- tap-sum
+// Second half of a KxK convolution with a tiny Cout (the 768->2 flow_conv,
+// networks.py:85-92): the conv engine first runs it as a 1x1 convolution with
+// Cout' = KH*KW*Cout "tap channels" (y[q][tap][co] = sum_c x[q][c] w[co][c][tap]),
+// reading the wide input exactly once; this kernel then gathers
+//   out[p][co] = bias[co] + sum_tap y[p + off(tap)][tap][co] (+ residual)
+// with zero padding (out-of-range q contributes nothing).  stride 1 only.
+__global__ void tapsum_kernel(const float* __restrict__ y, int N, int H, int W, int KH, int KW, int pad, int Cout,
+                              int ycs, const float* __restrict__ bias, const float* __restrict__ res, int rcs,
+                              float* __restrict__ out, int ocs) {
+  const size_t total = (size_t)N * H * W * Cout;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int co = (int)(i % Cout);
+    const size_t pix = i / Cout;
+    const int w = (int)(pix % W);
+    const size_t t = pix / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    float acc = 0.f;
+    for (int kh = 0; kh < KH; ++kh) {
+      const int hh = h + kh - pad;
+      if (hh < 0 || hh >= H) continue;
+      for (int kw = 0; kw < KW; ++kw) {
+        const int ww = w + kw - pad;
+        if (ww < 0 || ww >= W) continue;
+        acc += y[((size_t)(n * H + hh) * W + ww) * ycs + (kh * KW + kw) * Cout + co];
+      }
+    }
+    if (bias) acc += bias[co];
+    if (res) acc += res[pix * rcs + co];
+    out[pix * ocs + co] = acc;
+  }
+}
+
 }  // namespace hrv
 
 using namespace hrv;
@@ -257,4 +292,18 @@ extern "C" int hrv_flow_warp_nhwc_f32(const hrv_flow_warp_t* d, hrv_stream_t str
   const size_t total = (size_t)d->N * d->Ho * d->Wo * p.C4;
   hipLaunchKernelGGL(flow_warp_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("flow_warp_kernel");
+}
+
+extern "C" int hrv_tapsum_nhwc_f32(const float* y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW,
+                                   int32_t pad, int32_t Cout, int32_t y_cstride, const float* bias,
+                                   const float* residual, int32_t res_cstride, float* out, int32_t out_cstride,
+                                   hrv_stream_t stream) {
+  HRV_REQUIRE(y && out && N > 0 && H > 0 && W > 0 && KH > 0 && KW > 0 && pad >= 0 && Cout > 0, "tapsum: bad args");
+  HRV_REQUIRE(KH == 2 * pad + 1 && KW == 2 * pad + 1, "tapsum: only 'same' stride-1 geometry (k = 2*pad+1)");
+  HRV_REQUIRE(y_cstride >= KH * KW * Cout && out_cstride >= Cout && (!residual || res_cstride >= Cout),
+              "tapsum: channel strides too small");
+  const size_t total = (size_t)N * H * W * Cout;
+  hipLaunchKernelGGL(tapsum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, N, H, W, KH, KW,
+                     pad, Cout, y_cstride, bias, residual, res_cstride, out, out_cstride);
+  return check_launch("tapsum_kernel");
 }

@@ -22,7 +22,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ACT_NONE, ACT_RELU, Act, ConvLayer
+from .ops import ACT_NONE, ACT_RELU, Act, ConvLayer, TapConvLayer
 
 
 class ResBlock(nn.Module):
@@ -164,7 +164,8 @@ class ConditionGenerator(nn.Module):
                       for i, m in enumerate(self.conv1)]
         P["conv2"] = [ConvLayer(m.weight, [m.in_channels], device, shift=m.bias, pad=0, name=f"conv2.{i}")
                       for i, m in enumerate(self.conv2)]
-        P["flow"] = [ConvLayer(m.weight, [c4, c4], device, shift=m.bias, pad=1, name=f"flow_conv.{i}")
+        # 768 -> 2 channels: taps-as-channels 1x1 on the MFMA engine + tap-sum gather
+        P["flow"] = [TapConvLayer(m.weight, [c4, c4], device, bias=m.bias, name=f"flow_conv.{i}")
                      for i, m in enumerate(self.flow_conv)]
         P["bott"] = [ConvLayer(m[0].weight, [m[0].in_channels], device, shift=m[0].bias, pad=1, act=ACT_RELU,
                                name=f"bottleneck.{i}") for i, m in enumerate(self.bottleneck)]

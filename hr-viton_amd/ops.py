@@ -227,6 +227,38 @@ class ConvLayer:
         return out
 
 
+class TapConvLayer:
+    """KxK stride-1 'same' convolution with a tiny Cout (flow_conv: 768 -> 2), executed as
+    a 1x1 convolution with KH*KW*Cout tap-channels on the MFMA engine + hrv_tapsum_nhwc_f32."""
+
+    def __init__(self, weight: torch.Tensor, src_real: Sequence[int], device, bias: Optional[torch.Tensor] = None,
+                 name: str = "tapconv"):
+        w = weight.detach().to("cpu", torch.float32)
+        self.Cout, cin, self.KH, self.KW = w.shape
+        assert self.KH == self.KW and self.KH % 2 == 1
+        self.pad = self.KH // 2
+        # [co][c][kh][kw] -> [(kh*KW+kw)*Cout + co][c][1][1]
+        w1 = w.permute(2, 3, 0, 1).reshape(self.KH * self.KW * self.Cout, cin, 1, 1).contiguous()
+        self.inner = ConvLayer(w1, src_real, device, stride=1, pad=0, name=name + "[taps-as-channels 1x1]")
+        self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
+        self.name = name
+
+    def __call__(self, srcs, out: Act, residual: Optional[Act] = None) -> Act:
+        lib = _lib.load()
+        y = self.inner(srcs)
+        res_ptr, rcs = (None, 0) if residual is None else (residual.t.data_ptr(), residual.cstride)
+        if residual is not None:
+            assert residual.coff == 0 and residual.C == self.Cout
+        assert out.coff == 0 and out.C == self.Cout
+        nbytes = 4.0 * y.N * y.H * y.W * (y.cstride + 2 * self.Cout)
+        with _Timed("tapsum", self.name, 0.0, nbytes):
+            _lib.check(lib.hrv_tapsum_nhwc_f32(y.t.data_ptr(), y.N, y.H, y.W, self.KH, self.KW, self.pad, self.Cout,
+                                               y.cstride, None if self.bias is None else self.bias.data_ptr(),
+                                               res_ptr, rcs, out.t.data_ptr(), out.cstride, _stream()),
+                       "hrv_tapsum_nhwc_f32")
+        return out
+
+
 def resize_bilinear(a: Act, Ho: int, Wo: int, rh: float, rw: float, addend: Optional[Act] = None,
                     out: Optional[Act] = None) -> Act:
     """hrv_resize_bilinear_nhwc_f32: out = bilinear(a) (+ addend)."""

@@ -117,6 +117,15 @@ int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
  * path. */
 int hrv_conv2d_naive_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
 
+/* Second half of a KxK stride-1 'same' convolution with a tiny Cout (the
+ * 768->2 flow_conv, networks.py:85-92,122,137), run as a 1x1 convolution with
+ * KH*KW*Cout "tap channels" on the conv engine (input read once, 16x fewer
+ * padded MFMA columns) followed by this gather:
+ *   out[p][co] = bias[co] + sum_tap y[p + off(tap)][tap*Cout + co] (+ residual[p][co]) */
+int hrv_tapsum_nhwc_f32(const float* y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad,
+                        int32_t Cout, int32_t y_cstride, const float* bias, const float* residual,
+                        int32_t res_cstride, float* out, int32_t out_cstride, hrv_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Layout converters at the module boundary (the reference's tensors are NCHW).
  * ---------------------------------------------------------------------- */

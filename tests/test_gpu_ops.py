@@ -234,3 +234,20 @@ def test_conv_mfma_every_tile_config(tile):
     for case in (CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[11]):
         got, ref = _run_conv_case(ops, case, "mfma", tile=tile)
         _assert_close(f"conv_mfma_t{tile}_" + case[0], got, ref, 2e-5)
+
+
+@pytest.mark.parametrize("real,H,W", [([48, 48], 16, 12), ([384, 384], 8, 6), ([8], 5, 7)])
+def test_tapconv_small_cout(real, H, W):
+    """flow_conv (Cin -> 2, 3x3): taps-as-channels 1x1 on the MFMA engine + hrv_tapsum_nhwc_f32."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(7)
+    N = 2
+    xs = [torch.randn(N, c, H, W, generator=g) for c in real]
+    w = torch.randn(2, sum(real), 3, 3, generator=g) * (1.0 / (sum(real) * 9) ** 0.5)
+    b = torch.randn(2, generator=g)
+    res = torch.randn(N, H, W, 2, generator=g)
+    want = F.conv2d(torch.cat(xs, 1), w, b, padding=1).permute(0, 2, 3, 1) + res
+    layer = ops.TapConvLayer(w, real, "cuda", bias=b, name="flow")
+    out = ops.Act(torch.empty((N, H, W, 2), device="cuda"), 2)
+    layer([_nhwc(ops, x) for x in xs], out=out, residual=ops.Act(res.cuda().contiguous(), 2))
+    _assert_close("tapconv", out.t.cpu(), want, 2e-5)
