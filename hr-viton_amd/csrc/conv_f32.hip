@@ -60,16 +60,22 @@ struct ConvParams {
   float pre_slope;
   float* out;
   int out_cs, out_co;
-  int debug;  // HRV_CONV_DEBUG ablation bits (perf investigation only; 0 on the product path)
 };
 
-template <int TM, int TN, int WM, int WN>
+// VAR bit0: swapped-operand MFMA (D[cout][pixel]) -> each lane owns 4 consecutive
+//           output channels of one pixel -> float4 epilogue loads/stores.
+// VAR bit1: software-pipelined body: fragment ds_reads first, next tile's global
+//           loads issued between them and the MFMAs, scheduler hints interleave
+//           the address arithmetic with the matrix pipe.
+template <int TM, int TN, int WM, int WN, int VAR>
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
-  constexpr int AR = BM / 64;                 // float4 A loads per thread per K-tile
-  constexpr int BR = (BN * 4 + 255) / 256;    // float4 B loads per thread per K-tile
+  constexpr int AR = BM / 64;                 // 16-byte A loads per thread per K-tile
+  constexpr int BR = (BN * 4 + 255) / 256;    // 16-byte B loads per thread per K-tile
+  constexpr bool SWAP = (VAR & 1) != 0;
+  constexpr bool PIPE = (VAR & 2) != 0;
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
 
   const int tid = threadIdx.x;
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
   const int n0 = nt * BN;
 
   // ---- per-thread gather coordinates (fixed for the whole K loop) ----
-  const int a_c4 = tid & 3;    // which float4 of the 16-channel chunk
+  const int a_c4 = tid & 3;    // which 16-byte group of the 16-channel chunk
   const int a_row = tid >> 2;  // + 64*r
   int a_n[AR], a_hi0[AR], a_wi0[AR];
   bool a_ok[AR];
@@ -120,127 +126,194 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
   const int l31 = lane & 31;
   const int lh = lane >> 5;
 
-  // kt = -1 is the prologue (fetch + stage tile 0, nothing to multiply yet).
-  for (int kt = -1; kt < p.KT; ++kt) {
-    const bool more = kt + 1 < p.KT;
-    if (more) {
-      // ---- global -> registers for K-tile kt+1 (in flight during the MFMAs below)
-      // uniform per-field selects keep the by-value kernarg struct out of scratch
-      const float* s_ptr = p.src[0].ptr;
-      int s_C = p.src[0].C, s_cs = p.src[0].cstride, s_co = p.src[0].coff, s_up = p.src[0].up_shift,
-          s_pre = p.src[0].pre_act, s_chunks = p.src[0].chunks;
-#pragma unroll
-      for (int q = 1; q < HRV_MAX_SRC; ++q)
-        if (it_s == q) {
-          s_ptr = p.src[q].ptr; s_C = p.src[q].C; s_cs = p.src[q].cstride; s_co = p.src[q].coff;
-          s_up = p.src[q].up_shift; s_pre = p.src[q].pre_act; s_chunks = p.src[q].chunks;
-        }
-      const int c = it_c * BK + a_c4 * 4;
-      const bool c_ok = c < s_C;
-      const int Hs = p.H >> s_up, Ws = p.W >> s_up;
-#pragma unroll
-      for (int r = 0; r < AR; ++r) {
-        const int hi = a_hi0[r] + it_kh;
-        const int wi = a_wi0[r] + it_kw;
-        const bool ok = a_ok[r] && c_ok && hi >= 0 && hi < p.H && wi >= 0 && wi < p.W && !(p.debug & 4);
-        // branch-free: always load from a valid address, then select
-        const size_t off =
-            ok ? ((size_t)(a_n[r] * Hs + (hi >> s_up)) * Ws + (wi >> s_up)) * s_cs + s_co + c : (size_t)0;
-        f32x4 v = *reinterpret_cast<const f32x4*>(s_ptr + off);
-        if (s_pre == HRV_ACT_LRELU) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.pre_slope;
-        }
-        if (!ok) v = (f32x4)(0.f);
-        a_reg[r] = v;
-      }
-      const float* wt = p.wp + ((size_t)(kt + 1) * p.CoutPad + n0) * BK;
-#pragma unroll
-      for (int j = 0; j < BR; ++j) {
-        const int idx = tid + 256 * j;
-        b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * 4) % 256 == 0 || idx < BN * 4 ? idx : 0) * 4);
-      }
-      if (++it_c == s_chunks) {
-        it_c = 0;
-        if (++it_s == p.nsrc) {
-          it_s = 0;
-          if (++it_kw == p.KW) {
-            it_kw = 0;
-            ++it_kh;
-          }
-        }
-      }
-    }
+// ---- global -> registers for K-tile KTN (stays in flight while the MFMAs run).
+// Branch-free (uniform per-field selects; loads from a valid address then select) so
+// the steady-state loop body is a single scheduling region.
+#define HRV_LOAD_TILE(KTN)                                                                                   \
+  {                                                                                                          \
+    const float* s_ptr = p.src[0].ptr;                                                                       \
+    int s_C = p.src[0].C, s_cs = p.src[0].cstride, s_co = p.src[0].coff, s_up = p.src[0].up_shift;          \
+    _Pragma("unroll") for (int q = 1; q < HRV_MAX_SRC; ++q) {                                                \
+      const bool sel = it_s == q;                                                                            \
+      s_ptr = sel ? p.src[q].ptr : s_ptr;                                                                    \
+      s_C = sel ? p.src[q].C : s_C;                                                                          \
+      s_cs = sel ? p.src[q].cstride : s_cs;                                                                  \
+      s_co = sel ? p.src[q].coff : s_co;                                                                     \
+      s_up = sel ? p.src[q].up_shift : s_up;                                                                 \
+    }                                                                                                        \
+    const int c = it_c * BK + a_c4 * 4;                                                                      \
+    const bool c_ok = c < s_C;                                                                               \
+    /* up_shift > 0: source is 2^up smaller (nearest upsample); < 0: 2^-up larger (nearest downsample) */    \
+    const int sh_r = s_up > 0 ? s_up : 0, sh_l = s_up < 0 ? -s_up : 0;                                       \
+    const int Hs = (p.H >> sh_r) << sh_l, Ws = (p.W >> sh_r) << sh_l;                                        \
+    const int cc = c_ok ? c : 0;                                                                             \
+    _Pragma("unroll") for (int r = 0; r < AR; ++r) {                                                         \
+      const int hi = a_hi0[r] + it_kh;                                                                       \
+      const int wi = a_wi0[r] + it_kw;                                                                       \
+      const bool ok = a_ok[r] && c_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;       \
+      /* clamp instead of branching: the address is always valid, the value is zeroed below */              \
+      const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);                              \
+      const unsigned off =                                                                                   \
+          ((unsigned)(a_n[r] * Hs + ((hic >> sh_r) << sh_l)) * Ws + ((wic >> sh_r) << sh_l)) * s_cs + s_co + cc; \
+      f32x4 v = *reinterpret_cast<const f32x4*>(s_ptr + off);                                                \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                                  \
+      a_reg[r] = v;                                                                                          \
+    }                                                                                                        \
+    const float* wt = p.wp + ((size_t)(KTN)*p.CoutPad + n0) * BK;                                            \
+    _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
+      const int idx = tid + 256 * j;                                                                         \
+      b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * 4) % 256 == 0 || idx < BN * 4 ? idx : 0) * 4);  \
+    }                                                                                                        \
+  }
 
-    if (kt >= 0 && !(p.debug & 8)) {
-      const int buf = kt & 1;
-      const float* As = smem + buf * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;
-      const float* Bs = smem + buf * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;
-#pragma unroll
-      for (int kq = 0; kq < 2; ++kq) {
-        f32x4 a[TM], b[TN];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(As + i * 32 * LS + kq * 8);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) b[j] = *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + kq * 8);
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-          for (int j = 0; j < TN; ++j) {
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].x, b[j].x, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].y, b[j].y, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].z, b[j].z, acc[i][j], 0, 0, 0);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i].w, b[j].w, acc[i][j], 0, 0, 0);
-          }
-      }
-    }
+#define HRV_ADVANCE_ITER()                                                                  \
+  {                                                                                         \
+    int chunks = p.src[0].chunks;                                                           \
+    _Pragma("unroll") for (int q = 1; q < HRV_MAX_SRC; ++q) chunks = it_s == q ? p.src[q].chunks : chunks; \
+    if (++it_c == chunks) {                                                                 \
+      it_c = 0;                                                                             \
+      if (++it_s == p.nsrc) {                                                               \
+        it_s = 0;                                                                           \
+        if (++it_kw == p.KW) {                                                              \
+          it_kw = 0;                                                                        \
+          ++it_kh;                                                                          \
+        }                                                                                   \
+      }                                                                                     \
+    }                                                                                       \
+  }
 
-    if (more) {
-      // ---- registers -> LDS buffer (kt+1)&1 (its last readers passed the previous barrier)
-      float* Asw = smem + ((kt + 1) & 1) * (BM + BN) * LS;
-      float* Bsw = Asw + BM * LS;
+#define HRV_STORE_TILE(BUF)                                                                             \
+  {                                                                                                     \
+    float* Asw = smem + (BUF) * (BM + BN) * LS;                                                         \
+    float* Bsw = Asw + BM * LS;                                                                         \
+    _Pragma("unroll") for (int r = 0; r < AR; ++r)                                                      \
+        *reinterpret_cast<f32x4*>(Asw + (a_row + 64 * r) * LS + a_c4 * 4) = a_reg[r];                   \
+    _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                    \
+      const int idx = tid + 256 * j;                                                                    \
+      if ((BN * 4) % 256 == 0 || idx < BN * 4)                                                          \
+        *reinterpret_cast<f32x4*>(Bsw + (idx >> 2) * LS + (idx & 3) * 4) = b_reg[j];                    \
+    }                                                                                                   \
+  }
+
+#define HRV_READ_FRAGS(BUF)                                                                                  \
+  {                                                                                                          \
+    const float* As = smem + (BUF) * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;                    \
+    const float* Bs = smem + (BUF) * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;          \
+    _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                                       \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[kq][i] =                                             \
+          *reinterpret_cast<const f32x4*>(As + i * 32 * LS + kq * 8);                                        \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[kq][j] =                                             \
+          *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + kq * 8);                                        \
+    }                                                                                                        \
+  }
+
+#define HRV_MMA1(I, J, AV, BV)                                                              \
+  acc[I][J] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(BV, AV, acc[I][J], 0, 0, 0)       \
+                   : __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc[I][J], 0, 0, 0);
+
+#define HRV_MMA_FRAGS()                                                       \
+  {                                                                           \
+    _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                          \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e)                         \
+            _Pragma("unroll") for (int i = 0; i < TM; ++i)                    \
+                _Pragma("unroll") for (int j = 0; j < TN; ++j) {              \
+      HRV_MMA1(i, j, fa[kq][i][e], fb[kq][j][e])                              \
+    }                                                                         \
+  }
+
+  f32x4 fa[2][TM], fb[2][TN];
+
+  // prologue: fetch + stage K-tile 0
+  HRV_LOAD_TILE(0)
+  HRV_ADVANCE_ITER()
+  HRV_STORE_TILE(0)
+  __syncthreads();
+
+  // steady state: tile kt is multiplied while tile kt+1 travels global -> regs -> LDS
+  for (int kt = 0; kt < p.KT - 1; ++kt) {
+    if (PIPE) {
+      HRV_READ_FRAGS(kt & 1)
+      HRV_LOAD_TILE(kt + 1)
+      HRV_MMA_FRAGS()
+      // scheduling recipe for this region: fragment reads first, then every MFMA is
+      // followed by a slice of the gather's address arithmetic / load issue.
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
 #pragma unroll
-      for (int r = 0; r < AR; ++r)
-        *reinterpret_cast<f32x4*>(Asw + (a_row + 64 * r) * LS + a_c4 * 4) = a_reg[r];
-#pragma unroll
-      for (int j = 0; j < BR; ++j) {
-        const int idx = tid + 256 * j;
-        if ((BN * 4) % 256 == 0 || idx < BN * 4)
-          *reinterpret_cast<f32x4*>(Bsw + (idx >> 2) * LS + (idx & 3) * 4) = b_reg[j];
+      for (int m = 0; m < 8 * TM * TN; ++m) {
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
+        if (m < AR + BR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
+    } else {
+      HRV_LOAD_TILE(kt + 1)
+      HRV_READ_FRAGS(kt & 1)
+      HRV_MMA_FRAGS()
     }
+    HRV_ADVANCE_ITER()
+    HRV_STORE_TILE((kt + 1) & 1)
     __syncthreads();
   }
+  // last tile: nothing left to fetch
+  HRV_READ_FRAGS((p.KT - 1) & 1)
+  HRV_MMA_FRAGS()
 
-  if (p.debug & 1) {  // ablation: main loop only (one dependent store keeps the accumulators live)
-    float t = 0.f;
+#undef HRV_LOAD_TILE
+#undef HRV_ADVANCE_ITER
+#undef HRV_STORE_TILE
+#undef HRV_READ_FRAGS
+#undef HRV_MMA1
+#undef HRV_MMA_FRAGS
+
+  // ---- fused epilogue: out = act(acc * scale[c] + shift[c] + residual)
+  if (!SWAP) {
+    // D layout: col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int j = 0; j < TN; ++j) {
+      const int c = n0 + (wn * TN + j) * 32 + l31;
+      const bool c_ok = c < p.Cout;
+      const float sc = (c_ok && p.scale) ? p.scale[c] : 1.f;
+      const float sh = (c_ok && p.shift) ? p.shift[c] : 0.f;
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
+      for (int i = 0; i < TM; ++i) {
+        const int prow0 = m0 + (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
-        for (int e = 0; e < 16; ++e) t += acc[i][j][e];
-    if (t == 12345.678f) p.out[0] = t;
-    return;
-  }
-  // ---- fused epilogue: D layout col = lane&31 (cout), row = (reg&3)+8*(reg>>2)+4*(lane>>5) (pixel)
+        for (int e = 0; e < 16; ++e) {
+          const int pidx = prow0 + (e & 3) + 8 * (e >> 2);
+          if (c_ok && pidx < p.M) {
+            float v = acc[i][j][e] * sc + sh;
+            if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
+            v = apply_act(v, p.act, p.slope);
+            p.out[(size_t)pidx * p.out_cs + p.out_co + c] = v;
+          }
+        }
+      }
+    }
+  } else {
+    // D layout: col = lane&31 (pixel), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout):
+    // regs 4g..4g+3 are 4 consecutive output channels of this lane's pixel.
+    // (host side only selects this variant when Cout, out/residual strides and offsets are
+    //  multiples of 4, so every group of 4 channels is stored as one 16-byte access)
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int c = n0 + (wn * TN + j) * 32 + l31;
-    const bool c_ok = c < p.Cout;
-    const float sc = (c_ok && p.scale) ? p.scale[c] : 1.f;
-    const float sh = (c_ok && p.shift) ? p.shift[c] : 0.f;
+    for (int j = 0; j < TN; ++j) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      const int prow0 = m0 + (wm * TM + i) * 32 + 4 * lh;
+      for (int g = 0; g < 4; ++g) {
+        const int c0 = n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh;
+        const bool c_ok = c0 < p.Cout;
+        const int cs = c_ok ? c0 : 0;
+        const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cs) : (f32x4)(1.f);
+        const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cs) : (f32x4)(0.f);
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const int pidx = prow0 + (e & 3) + 8 * (e >> 2);
-        if (c_ok && pidx < p.M) {
-          float v = acc[i][j][e] * sc + sh;
-          if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
-          v = apply_act(v, p.act, p.slope);
-          p.out[(size_t)pidx * p.out_cs + p.out_co + c] = v;
+        for (int i = 0; i < TM; ++i) {
+          const int pidx = m0 + (wm * TM + i) * 32 + l31;
+          if (c_ok && pidx < p.M) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * sc[e] + sh[e];
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)pidx * p.res_cs + p.res_co + c0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+            *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
+          }
         }
       }
     }
@@ -320,8 +393,16 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
                 "conv2d: src[%d] channels C=%d cstride=%d coff=%d must be multiples of 4 and in range", i, s.C,
                 s.cstride, s.coff);
     HRV_REQUIRE(((uintptr_t)s.ptr & 15) == 0, "conv2d: src[%d] not 16-byte aligned", i);
-    HRV_REQUIRE(s.up_shift == 0 || (s.up_shift == 1 && d->H % 2 == 0 && d->W % 2 == 0), "conv2d: src[%d] up_shift", i);
-    HRV_REQUIRE(s.pre_act == HRV_ACT_NONE || s.pre_act == HRV_ACT_LRELU, "conv2d: src[%d] pre_act", i);
+    HRV_REQUIRE(s.up_shift >= -7 && s.up_shift <= 1 && (s.up_shift != 1 || (d->H % 2 == 0 && d->W % 2 == 0)),
+                "conv2d: src[%d] up_shift=%d out of range", i, s.up_shift);
+    HRV_REQUIRE(!need_packed || s.pre_act == HRV_ACT_NONE, "conv2d: src[%d] pre_act is not supported by the MFMA gather "
+                "(fuse the activation into the producer's epilogue)", i);
+    {
+      const int sr = s.up_shift > 0 ? s.up_shift : 0, sl = s.up_shift < 0 ? -s.up_shift : 0;
+      const int64_t elems = (int64_t)d->N * ((d->H >> sr) << sl) * ((d->W >> sr) << sl) * s.cstride;
+      HRV_REQUIRE(elems < ((int64_t)1 << 32), "conv2d: src[%d] has %lld elements; the gather uses 32-bit offsets", i,
+                  (long long)elems);
+    }
     p.src[i].ptr = (const float*)s.ptr;
     p.src[i].C = s.C;
     p.src[i].cstride = s.cstride;
@@ -341,10 +422,6 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   p.res = (const float*)d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff;
   p.act = d->act; p.slope = d->act_slope; p.pre_slope = 0.2f;
   p.out = (float*)d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
-  {
-    static const int dbg = getenv("HRV_CONV_DEBUG") ? atoi(getenv("HRV_CONV_DEBUG")) : 0;
-    p.debug = dbg;
-  }
   HRV_REQUIRE(d->out_cstride >= d->out_coff + d->Cout, "conv2d: out slice out of range");
   HRV_REQUIRE(d->residual == nullptr || d->res_cstride >= d->res_coff + d->Cout, "conv2d: residual slice out of range");
   if (need_packed) {
@@ -359,10 +436,24 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   return HRV_OK;
 }
 
+// Product default variant; HRV_CONV_VARIANT (0..3) overrides it for A/B measurements.
+constexpr int kDefaultVariant = 1;
+
 template <int TM, int TN, int WM, int WN>
 static int launch_cfg(const ConvParams& p, hipStream_t st) {
   const int nblk = p.m_tiles * p.n_tiles;
-  hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN>), dim3(nblk), dim3(256), 0, st, p);
+  const char* ev = getenv("HRV_CONV_VARIANT");
+  int var = ev ? atoi(ev) : kDefaultVariant;
+  const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
+                      (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0;
+  if (!vec_ok) var &= ~1;  // scalar epilogue for odd channel counts / unaligned slices
+  switch (var) {
+    case 0: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 0>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 2>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 3>), dim3(nblk), dim3(256), 0, st, p); break;
+    default: set_error("conv2d: HRV_CONV_VARIANT=%d invalid", var); return HRV_ERR_ARG;
+  }
   return check_launch("conv_f32_mfma_kernel");
 }
 

@@ -187,7 +187,7 @@ class ConvLayer:
         a0, up0, _ = specs[0]
         N = a0.N
         if H is None:
-            H, W = a0.H << up0, a0.W << up0
+            H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
         Ho, Wo = self.out_hw(H, W)
         if out is None:
             out = alloc(N, Ho, Wo, self.Cout, a0.t.device)
@@ -197,7 +197,8 @@ class ConvLayer:
         d.nsrc = len(specs)
         for i, (a, up, pre) in enumerate(specs):
             assert a.C == self.src_real[i], (self.name, i, a.C, self.src_real[i])
-            assert (a.H << up, a.W << up) == (H, W) and a.N == N, (self.name, i, a.t.shape, up, H, W)
+            assert ((a.H << up, a.W << up) if up >= 0 else (a.H >> -up, a.W >> -up)) == (H, W) and a.N == N, \
+                (self.name, i, a.t.shape, up, H, W)
             s = d.src[i]
             s.ptr, s.C, s.cstride, s.coff = a.t.data_ptr(), self.src_pad[i], a.cstride, a.coff
             s.up_shift, s.pre_act, s.C_real = up, pre, self.src_real[i]

@@ -64,10 +64,13 @@ typedef struct hrv_src {
   int32_t C;        /* channels taken from this source (multiple of 4)       */
   int32_t cstride;  /* channels per pixel in memory (multiple of 4)          */
   int32_t coff;     /* first channel (multiple of 4)                         */
-  int32_t up_shift; /* 0: source is H x W; 1: source is (H/2) x (W/2) and is
-                       read through a nearest x2 upsample                    */
-  int32_t pre_act;  /* hrv_act applied to the loaded values (NONE / LRELU,
-                       slope 0.2: network_generator.py:244)                  */
+  int32_t up_shift; /* 0: source is H x W; 1: source is (H/2) x (W/2), read through
+                       a nearest x2 upsample (network_generator.py:203);
+                       -k: source is (H<<k) x (W<<k), read through a nearest
+                       1/2^k downsample (F.interpolate nearest, :164,222)    */
+  int32_t pre_act;  /* must be HRV_ACT_NONE for the MFMA engine (activations are
+                       fused into the producer's epilogue); LRELU(0.2) is
+                       honoured by the naive cross-check only               */
   int32_t C_real;   /* channels that exist in the raw OIHW weight for this
                        source (<= C; 0 means C).  Only the naive cross-check
                        reads it; the packed weight already has zero rows.    */

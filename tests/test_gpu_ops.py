@@ -136,7 +136,8 @@ CONV_CASES = [
     ("cin9_pad12", [9], 40, 3, 1, 1, 16, 8, {"bias": True}),
     ("patchgan_4x4_s2", [10], 64, 4, 2, 2, 18, 14, {"bias": True, "act": "lrelu"}),
     ("up_cat_nearest", [32, 16], 64, 3, 1, 1, 16, 12, {"bias": True, "up0": True}),
-    ("img_preact_tanh", [32], 3, 3, 1, 1, 16, 12, {"bias": True, "pre": True, "act": "tanh"}),
+    ("img_tanh", [32], 3, 3, 1, 1, 16, 12, {"bias": True, "act": "tanh"}),
+    ("seg_down4_nearest", [8], 128, 3, 1, 1, 8, 6, {"bias": True, "act": "relu", "down0": 2}),
     ("big_m", [16], 32, 3, 1, 1, 96, 80, {"bias": True}),
 ]
 
@@ -149,6 +150,8 @@ def _run_conv_case(ops, case, impl, tile=None):
     for i, c in enumerate(real):
         if ex.get("up0") and i == 0:
             xs.append(torch.randn(N, c, H // 2, W // 2, generator=g))
+        elif ex.get("down0") and i == 0:
+            xs.append(torch.randn(N, c, H << ex["down0"], W << ex["down0"], generator=g))
         else:
             xs.append(torch.randn(N, c, H, W, generator=g))
     w = torch.randn(cout, sum(real), k, k, generator=g) * (1.0 / (sum(real) * k * k) ** 0.5)
@@ -160,6 +163,8 @@ def _run_conv_case(ops, case, impl, tile=None):
     for i, x in enumerate(xs):
         if ex.get("up0") and i == 0:
             x = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        if ex.get("down0") and i == 0:
+            x = O.resize_nearest(x, (H, W))
         full.append(x)
     xin = torch.cat(full, 1)
     if ex.get("pre"):
@@ -179,7 +184,7 @@ def _run_conv_case(ops, case, impl, tile=None):
     srcs = []
     for i, x in enumerate(xs):
         a = _nhwc(ops, x)
-        up = 1 if (ex.get("up0") and i == 0) else 0
+        up = 1 if (ex.get("up0") and i == 0) else (-ex["down0"] if (ex.get("down0") and i == 0) else 0)
         srcs.append((a, up, ops.ACT_LRELU if ex.get("pre") else ops.ACT_NONE))
     out = None
     Ho, Wo = ref.shape[2:]
@@ -228,12 +233,21 @@ def test_conv_mfma_default_tile(case):
     _assert_close("conv_mfma_" + case[0], got, ref, 2e-5)
 
 
+@pytest.mark.parametrize("variant", [0, 1, 2, 3])
 @pytest.mark.parametrize("tile", list(range(8)))
-def test_conv_mfma_every_tile_config(tile):
+def test_conv_mfma_every_tile_config_and_variant(tile, variant):
     ops = _ops()
-    for case in (CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[11]):
-        got, ref = _run_conv_case(ops, case, "mfma", tile=tile)
-        _assert_close(f"conv_mfma_t{tile}_" + case[0], got, ref, 2e-5)
+    old = os.environ.get("HRV_CONV_VARIANT")
+    os.environ["HRV_CONV_VARIANT"] = str(variant)
+    try:
+        for case in (CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[9], CONV_CASES[12]):
+            got, ref = _run_conv_case(ops, case, "mfma", tile=tile)
+            _assert_close(f"conv_mfma_t{tile}_v{variant}_" + case[0], got, ref, 2e-5)
+    finally:
+        if old is None:
+            os.environ.pop("HRV_CONV_VARIANT", None)
+        else:
+            os.environ["HRV_CONV_VARIANT"] = old
 
 
 @pytest.mark.parametrize("real,H,W", [([48, 48], 16, 12), ([384, 384], 8, 6), ([8], 5, 7)])
