@@ -20,6 +20,12 @@ class hrv_src_t(C.Structure):
                 ("up_shift", C.c_int32), ("pre_act", C.c_int32), ("C_real", C.c_int32)]
 
 
+class hrv_spade_epi_t(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_cstride", C.c_int32), ("x_coff", C.c_int32), ("C", C.c_int32),
+                ("_pad", C.c_int32), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("noise_z", C.c_void_p),
+                ("noise_scale", C.c_void_p)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -27,7 +33,8 @@ class hrv_conv2d_t(C.Structure):
                 ("w_packed", C.c_void_p), ("w_oihw", C.c_void_p), ("Cout", C.c_int32), ("tile_cfg", C.c_int32),
                 ("scale", C.c_void_p), ("shift", C.c_void_p), ("residual", C.c_void_p),
                 ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
-                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32)]
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
+                ("spade", C.POINTER(hrv_spade_epi_t)), ("out_up_shift", C.c_int32), ("_pad2", C.c_int32)]
 
 
 class hrv_flow_warp_t(C.Structure):
@@ -54,6 +61,12 @@ SYMBOLS = {
     "hrv_conv2d_naive_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
     "hrv_tapsum_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32,
                                       _vp]),
+    "hrv_instnorm_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
+    "hrv_instnorm_stats_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
+                                              _vp]),
+    "hrv_instnorm_apply_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32,
+                                              _i32, _vp]),
+    "hrv_avgpool3x3s2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "hrv_nchw_to_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,

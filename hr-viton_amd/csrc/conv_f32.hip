@@ -60,6 +60,15 @@ struct ConvParams {
   float pre_slope;
   float* out;
   int out_cs, out_co;
+  int out_up;  // 1: replicate every result to its 2x2 block of a (2Ho x 2Wo) output
+  // SPADE epilogue (epi == 1)
+  int epi;
+  const float* sx;
+  int sx_cs, sx_co, sC;
+  const float* smean;
+  const float* srstd;
+  const float* sz;
+  const float* sns;
 };
 
 // VAR bit0: swapped-operand MFMA (D[cout][pixel]) -> each lane owns 4 consecutive
@@ -283,7 +292,15 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
             float v = acc[i][j][e] * sc + sh;
             if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
             v = apply_act(v, p.act, p.slope);
-            p.out[(size_t)pidx * p.out_cs + p.out_co + c] = v;
+            if (!p.out_up) {
+              p.out[(size_t)pidx * p.out_cs + p.out_co + c] = v;
+            } else {
+              const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
+              const int h = rem / p.Wo, w = rem - h * p.Wo;
+              float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c;
+              o[0] = v; o[p.out_cs] = v;
+              o[(size_t)2 * p.Wo * p.out_cs] = v; o[(size_t)2 * p.Wo * p.out_cs + p.out_cs] = v;
+            }
           }
         }
       }
@@ -293,6 +310,52 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
     // regs 4g..4g+3 are 4 consecutive output channels of this lane's pixel.
     // (host side only selects this variant when Cout, out/residual strides and offsets are
     //  multiples of 4, so every group of 4 channels is stored as one 16-byte access)
+    if (p.epi == 1) {
+      // SPADE: tiles come in (gamma | beta) pairs of the same 32 channels, so this lane holds
+      // gamma and beta of its pixel for the same 4 channels in acc[i][2q] / acc[i][2q+1].
+      if constexpr (TN % 2 == 0) {
+        const int HWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int q = 0; q < TN / 2; ++q) {
+          const int col0 = n0 + (wn * TN + 2 * q) * 32;  // first gamma column of the pair
+          const int cb = (col0 >> 6) * 32;               // channel base of the pair
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = cb + 8 * g + 4 * lh;
+            const bool c_ok = c0 < p.sC;
+            const int cs = c_ok ? c0 : 0;
+            const int colg = c_ok ? col0 + 8 * g + 4 * lh : 0;
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(p.shift + colg);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(p.shift + colg + (c_ok ? 32 : 0));
+            const f32x4 ns4 = p.sns ? *reinterpret_cast<const f32x4*>(p.sns + cs) : (f32x4)(0.f);
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const int pidx = m0 + (wm * TM + i) * 32 + l31;
+              if (c_ok && pidx < p.M) {
+                const int n = pidx / HWo;
+                f32x4 x = *reinterpret_cast<const f32x4*>(p.sx + (size_t)pidx * p.sx_cs + p.sx_co + c0);
+                if (p.sz) {
+                  const int rem = pidx - n * HWo;
+                  const int h = rem / p.Wo, w = rem - h * p.Wo;
+                  x += p.sz[((size_t)n * p.Wo + w) * p.Ho + h] * ns4;
+                }
+                const f32x4 mu = *reinterpret_cast<const f32x4*>(p.smean + (size_t)n * p.sC + c0);
+                const f32x4 rs = *reinterpret_cast<const f32x4*>(p.srstd + (size_t)n * p.sC + c0);
+                f32x4 v;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float gam = acc[i][2 * q][4 * g + e] + bg[e];
+                  const float bet = acc[i][2 * q + 1][4 * g + e] + bb[e];
+                  v[e] = apply_act((x[e] - mu[e]) * rs[e] * (1.f + gam) + bet, p.act, p.slope);
+                }
+                *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
+              }
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll
@@ -312,7 +375,17 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
             if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)pidx * p.res_cs + p.res_co + c0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
-            *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
+            if (!p.out_up) {
+              *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
+            } else {
+              const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
+              const int h = rem / p.Wo, w = rem - h * p.Wo;
+              float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c0;
+              *reinterpret_cast<f32x4*>(o) = v;
+              *reinterpret_cast<f32x4*>(o + p.out_cs) = v;
+              *reinterpret_cast<f32x4*>(o + (size_t)2 * p.Wo * p.out_cs) = v;
+              *reinterpret_cast<f32x4*>(o + (size_t)2 * p.Wo * p.out_cs + p.out_cs) = v;
+            }
           }
         }
       }
@@ -339,8 +412,9 @@ __global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restric
         int cbase = 0;
         for (int s = 0; s < p.nsrc; ++s) {
           const SrcDev sd = p.src[s];
-          const int Hs = p.H >> sd.up_shift, Ws = p.W >> sd.up_shift;
-          const float* px = sd.ptr + ((size_t)(n * Hs + (hi >> sd.up_shift)) * Ws + (wi >> sd.up_shift)) * sd.cstride + sd.coff;
+          const int sr = sd.up_shift > 0 ? sd.up_shift : 0, sl = sd.up_shift < 0 ? -sd.up_shift : 0;
+          const int Hs = (p.H >> sr) << sl, Ws = (p.W >> sr) << sl;
+          const float* px = sd.ptr + ((size_t)(n * Hs + ((hi >> sr) << sl)) * Ws + ((wi >> sr) << sl)) * sd.cstride + sd.coff;
           for (int c = 0; c < real_c[s]; ++c) {
             float x = px[c];
             if (sd.pre_act == HRV_ACT_LRELU) x = x > 0.f ? x : x * p.pre_slope;
@@ -351,7 +425,14 @@ __global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restric
       }
     float v = acc * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
     if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + co];
-    p.out[(size_t)pidx * p.out_cs + p.out_co + co] = apply_act(v, p.act, p.slope);
+    v = apply_act(v, p.act, p.slope);
+    if (!p.out_up) {
+      p.out[(size_t)pidx * p.out_cs + p.out_co + co] = v;
+    } else {
+      float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * ho) * 2 * p.Wo + 2 * wo) * p.out_cs + p.out_co + co;
+      o[0] = v; o[p.out_cs] = v;
+      o[(size_t)2 * p.Wo * p.out_cs] = v; o[(size_t)2 * p.Wo * p.out_cs + p.out_cs] = v;
+    }
   }
 }
 
@@ -422,7 +503,27 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   p.res = (const float*)d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff;
   p.act = d->act; p.slope = d->act_slope; p.pre_slope = 0.2f;
   p.out = (float*)d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
-  HRV_REQUIRE(d->out_cstride >= d->out_coff + d->Cout, "conv2d: out slice out of range");
+  HRV_REQUIRE(d->out_up_shift == 0 || (d->out_up_shift == 1 && !d->spade), "conv2d: out_up_shift must be 0 or 1");
+  p.out_up = d->out_up_shift;
+  if (d->spade) {
+    const hrv_spade_epi_t& e = *d->spade;
+    HRV_REQUIRE(need_packed, "conv2d: the SPADE epilogue exists on the MFMA engine only");
+    HRV_REQUIRE(e.x && e.mean && e.rstd && d->shift, "conv2d/spade: null pointer");
+    HRV_REQUIRE(e.C > 0 && e.C % 4 == 0 && e.x_cstride % 4 == 0 && e.x_coff % 4 == 0 && e.x_coff + e.C <= e.x_cstride,
+                "conv2d/spade: channels must be multiples of 4 and in range");
+    HRV_REQUIRE(d->Cout == (e.C + 31) / 32 * 64, "conv2d/spade: Cout must be 2*ceil32(C) = %d", (e.C + 31) / 32 * 64);
+    HRV_REQUIRE(d->stride == 1 && d->Ho == d->H && d->Wo == d->W, "conv2d/spade: 'same' stride-1 geometry only");
+    HRV_REQUIRE((e.noise_z == nullptr) == (e.noise_scale == nullptr), "conv2d/spade: noise_z/noise_scale go together");
+    HRV_REQUIRE(d->out_cstride % 4 == 0 && d->out_coff % 4 == 0 && d->out_cstride >= d->out_coff + e.C,
+                "conv2d/spade: out slice");
+    HRV_REQUIRE((((uintptr_t)e.x | (uintptr_t)e.mean | (uintptr_t)e.rstd | (uintptr_t)e.noise_scale |
+                  (uintptr_t)d->shift | (uintptr_t)d->out) & 15) == 0, "conv2d/spade: 16-byte alignment");
+    p.epi = 1; p.sx = e.x; p.sx_cs = e.x_cstride; p.sx_co = e.x_coff; p.sC = e.C;
+    p.smean = e.mean; p.srstd = e.rstd; p.sz = e.noise_z; p.sns = e.noise_scale;
+    p.res = nullptr; p.scale = nullptr;
+  } else {
+    HRV_REQUIRE(d->out_cstride >= d->out_coff + d->Cout, "conv2d: out slice out of range");
+  }
   HRV_REQUIRE(d->residual == nullptr || d->res_cstride >= d->res_coff + d->Cout, "conv2d: residual slice out of range");
   if (need_packed) {
     HRV_REQUIRE(d->tile_cfg >= 0 && d->tile_cfg < kNumCfgs, "conv2d: tile_cfg=%d invalid", d->tile_cfg);
@@ -446,7 +547,12 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
   int var = ev ? atoi(ev) : kDefaultVariant;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
                       (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0;
-  if (!vec_ok) var &= ~1;  // scalar epilogue for odd channel counts / unaligned slices
+  if (p.epi == 1) {
+    if (TN % 2 != 0) { set_error("conv2d/spade: tile_cfg must have an even TN (cfg 0, 4, 6 or 7)"); return HRV_ERR_ARG; }
+    var |= 1;  // the SPADE epilogue lives in the swapped-operand layout
+  } else if (!vec_ok) {
+    var &= ~1;  // scalar epilogue for odd channel counts / unaligned slices
+  }
   switch (var) {
     case 0: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 0>), dim3(nblk), dim3(256), 0, st, p); break;
     case 1: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 1>), dim3(nblk), dim3(256), 0, st, p); break;
@@ -473,14 +579,15 @@ extern "C" int hrv_conv2d_pick_tile(int64_t M, int32_t Cout) {
     const int64_t padded = (int64_t)((Cout + bns[i] - 1) / bns[i]) * bns[i];
     if (padded < best_pad) { best_pad = padded; best_bn = bns[i]; }
   }
-  // 2) pixel tile: 256 rows when that still leaves >= 2 blocks per CU, else 128
-  const int64_t n_tiles = (Cout + best_bn - 1) / best_bn;
-  const bool big = ((M + 255) / 256) * n_tiles >= 512;
+  // 2) pixel tile: the 128-row tiles (3-6 resident waves per SIMD) beat the 256-row ones on every
+  //    layer of the path (tools/conv_bench.py on MI355X: 110-122 vs 97-118 TFLOP/s): the fp32 MFMA is
+  //    slow enough (64 cycles) that LDS traffic is irrelevant and occupancy hides the barrier.
+  (void)M;
   switch (best_bn) {
-    case 128: return big ? 7 : 0;
-    case 96: return big ? 2 : 1;
-    case 64: return big ? 4 : 6;
-    default: return big ? 3 : 5;
+    case 128: return 0;
+    case 96: return 1;
+    case 64: return 6;
+    default: return 5;
   }
 }
 

@@ -1,0 +1,210 @@
+// Normalisation-side kernels of the generator / discriminator path (NHWC fp32):
+//   * InstanceNorm statistics (per sample, per channel; biased variance) with the
+//     SPADE noise term folded in:  v = x + z[n,w,h] * noise_scale[c]
+//     (network_generator.py:104-110).  Two deterministic stages: shifted partial
+//     sums per pixel-slab, then a double-precision fixed-order finalise.
+//   * InstanceNorm apply + LeakyReLU (PatchGAN: network_generator.py:263-272,427).
+//   * 3x3 stride-2 average pool, count_include_pad=False (:301-302).
+// HBM-bound: one float4 per lane, wavefront-contiguous channel groups.
+#include "hrv_common.h"
+
+namespace hrv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct StatsParams {
+  const float* x;
+  int N, H, W, C4, cs, co;
+  const float* z;   // [N][W][H] or null
+  const float* ns;  // [C] or null
+  int NB;           // pixel slabs per sample
+  float* part;      // [N][NB][C4*4][2]
+};
+
+__device__ __forceinline__ f32x4 stats_value(const StatsParams& p, int n, int pix, int g) {
+  f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)n * p.H * p.W + pix) * p.cs + p.co + g * 4);
+  if (p.z) {
+    const int h = pix / p.W, w = pix - h * p.W;
+    const float zz = p.z[((size_t)n * p.W + w) * p.H + h];
+    v += zz * *reinterpret_cast<const f32x4*>(p.ns + g * 4);
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams p) {
+  __shared__ f32x4 red[2][256];
+  const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+  const int HW = p.H * p.W;
+  const int PB = (HW + p.NB - 1) / p.NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, HW);
+  const int GB = p.C4 < 256 ? p.C4 : 256;  // channel groups handled per pass
+  const int R = 256 / GB;                  // pixel rows in flight per pass
+  const int r = t / GB, gl = t - r * GB;
+  for (int g0 = 0; g0 < p.C4; g0 += GB) {
+    const int g = g0 + gl;
+    const bool active = r < R && g < p.C4;
+    f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
+    if (active) {
+      const f32x4 K = stats_value(p, n, 0, g);  // shift: kills the cancellation in E[v^2]-E[v]^2
+      for (int px = p0 + r; px < p1; px += R) {
+        const f32x4 d = stats_value(p, n, px, g) - K;
+        s1 += d;
+        s2 += d * d;
+      }
+    }
+    red[0][t] = s1;
+    red[1][t] = s2;
+    __syncthreads();
+    if (r == 0 && g < p.C4) {
+      for (int rr = 1; rr < R; ++rr) {
+        s1 += red[0][rr * GB + gl];
+        s2 += red[1][rr * GB + gl];
+      }
+      float* dst = p.part + (((size_t)n * p.NB + b) * p.C4 * 4 + g * 4) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        dst[2 * e] = s1[e];
+        dst[2 * e + 1] = s2[e];
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void instnorm_finalize_kernel(const StatsParams p, float eps, float* __restrict__ mean,
+                                         float* __restrict__ rstd) {
+  const int C = p.C4 * 4;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= p.N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < p.NB; ++b) {
+    const float* src = p.part + (((size_t)n * p.NB + b) * C + c) * 2;
+    s1 += (double)src[0];
+    s2 += (double)src[1];
+  }
+  float K = p.x[(size_t)n * p.H * p.W * p.cs + p.co + c];
+  if (p.z) K += p.z[(size_t)n * p.W * p.H] * p.ns[c];
+  const double cnt = (double)p.H * p.W;
+  const double m = s1 / cnt;
+  double var = s2 / cnt - m * m;
+  var = var < 0.0 ? 0.0 : var;
+  mean[i] = (float)((double)K + m);
+  rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// out = lrelu((x - mean) * rstd)   (InstanceNorm2d(affine=False) + LeakyReLU(0.2), in place allowed)
+__global__ void instnorm_apply_kernel(const float* __restrict__ x, int N, int HW, int C4, int cs, int co,
+                                      const float* __restrict__ mean, const float* __restrict__ rstd, int act,
+                                      float slope, float* __restrict__ out, int ocs, int oco) {
+  const size_t total = (size_t)N * HW * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int n = (int)(pix / HW);
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * cs + co + g * 4);
+    const f32x4 m = *reinterpret_cast<const f32x4*>(mean + (size_t)n * C4 * 4 + g * 4);
+    const f32x4 r = *reinterpret_cast<const f32x4*>(rstd + (size_t)n * C4 * 4 + g * 4);
+    v = (v - m) * r;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+    *reinterpret_cast<f32x4*>(out + pix * ocs + oco + g * 4) = v;
+  }
+}
+
+// F.avg_pool2d(k=3, s=2, p=1, count_include_pad=False)
+__global__ void avgpool3s2_kernel(const float* __restrict__ x, int N, int H, int W, int C4, int cs, int co, int Ho,
+                                  int Wo, float* __restrict__ out, int ocs, int oco) {
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int wo = (int)(pix % Wo);
+    const size_t t = pix / Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    f32x4 s = (f32x4)(0.f);
+    int cnt = 0;
+    for (int dy = -1; dy <= 1; ++dy) {
+      const int h = 2 * ho + dy;
+      if (h < 0 || h >= H) continue;
+      for (int dx = -1; dx <= 1; ++dx) {
+        const int w = 2 * wo + dx;
+        if (w < 0 || w >= W) continue;
+        s += *reinterpret_cast<const f32x4*>(x + ((size_t)(n * H + h) * W + w) * cs + co + g * 4);
+        ++cnt;
+      }
+    }
+    *reinterpret_cast<f32x4*>(out + pix * ocs + oco + g * 4) = s / (float)cnt;
+  }
+}
+
+static inline int grid_for(size_t work, int block = 256) {
+  size_t g = (work + block - 1) / block;
+  const size_t cap = 256 * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+}  // namespace hrv
+
+using namespace hrv;
+
+extern "C" int64_t hrv_instnorm_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
+  const int HW = H * W;
+  int nb = (HW + 511) / 512;
+  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  return (int64_t)N * nb * ((C + 3) / 4 * 4) * 2;
+}
+
+extern "C" int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                                           int32_t cstride, int32_t coff, const float* noise_z,
+                                           const float* noise_scale, float eps, float* workspace, float* mean,
+                                           float* rstd, hrv_stream_t stream) {
+  HRV_REQUIRE(x && workspace && mean && rstd && N > 0 && H > 0 && W > 0, "instnorm_stats: bad args");
+  HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && coff + C <= cstride,
+              "instnorm_stats: channels must be multiples of 4 and in range");
+  HRV_REQUIRE((noise_z == nullptr) == (noise_scale == nullptr), "instnorm_stats: noise_z and noise_scale go together");
+  HRV_REQUIRE((((uintptr_t)x | (uintptr_t)noise_scale) & 15) == 0, "instnorm_stats: 16-byte alignment");
+  StatsParams p;
+  p.x = x; p.N = N; p.H = H; p.W = W; p.C4 = C / 4; p.cs = cstride; p.co = coff;
+  p.z = noise_z; p.ns = noise_scale;
+  const int HW = H * W;
+  int nb = (HW + 511) / 512;
+  p.NB = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  p.part = workspace;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(p.NB, N), dim3(256), 0, st, p);
+  int rc = check_launch("instnorm_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, p, eps, mean, rstd);
+  return check_launch("instnorm_finalize_kernel");
+}
+
+extern "C" int hrv_instnorm_apply_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                                           int32_t coff, const float* mean, const float* rstd, int32_t act,
+                                           float act_slope, float* out, int32_t out_cstride, int32_t out_coff,
+                                           hrv_stream_t stream) {
+  HRV_REQUIRE(x && out && mean && rstd && N > 0 && H > 0 && W > 0, "instnorm_apply: bad args");
+  HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && out_cstride % 4 == 0 && out_coff % 4 == 0 &&
+                  coff + C <= cstride && out_coff + C <= out_cstride,
+              "instnorm_apply: channels must be multiples of 4 and in range");
+  const size_t total = (size_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(instnorm_apply_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, H * W,
+                     C / 4, cstride, coff, mean, rstd, act, act_slope, out, out_cstride, out_coff);
+  return check_launch("instnorm_apply_kernel");
+}
+
+extern "C" int hrv_avgpool3x3s2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                                         int32_t coff, float* out, int32_t out_cstride, int32_t out_coff,
+                                         hrv_stream_t stream) {
+  HRV_REQUIRE(x && out && N > 0 && H > 0 && W > 0, "avgpool: bad args");
+  HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && out_cstride % 4 == 0 && out_coff % 4 == 0 &&
+                  coff + C <= cstride && out_coff + C <= out_cstride,
+              "avgpool: channels must be multiples of 4 and in range");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * Ho * Wo * (C / 4);
+  hipLaunchKernelGGL(avgpool3s2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, H, W, C / 4,
+                     cstride, coff, Ho, Wo, out, out_cstride, out_coff);
+  return check_launch("avgpool3s2_kernel");
+}

@@ -1,0 +1,445 @@
+"""MI355X-native mirror of the reference's ``network_generator.py`` for the hot path.
+
+Same class names, constructor / forward signatures and ``state_dict`` keys
+(including torch's spectral-norm ``weight_orig / weight_u / weight_v`` entries and
+their ``_metadata`` versions) as /root/reference/network_generator.py:
+BaseNetwork :9-50, SPADENorm :75-122, SPADEResBlock :125-173, SPADEGenerator
+:176-245, NLayerDiscriminator :250-288, MultiscaleDiscriminator :291-316.  The
+nn.Conv2d objects are parameter containers; ``forward`` executes a HIP plan over
+the C ABI (include/hrviton_hip.h):
+
+  * every conv on the fp32 MFMA implicit-GEMM engine, spectral-norm 1/sigma, bias,
+    residual add, LeakyReLU / tanh fused into its epilogue;
+  * SPADE: instance-norm statistics kernel (noise folded in), then ONE conv for
+    conv_gamma||conv_beta whose epilogue applies IN(x+noise)*(1+gamma)+beta and
+    the LeakyReLU -- gamma/beta never reach HBM;
+  * nearest x2 upsample + torch.cat fused away: the producing conv stores each
+    result to its 2x2 block of the next block's input buffer, the stem conv
+    writes its 16 channels next to it; seg / x nearest-resizes are folded into
+    the conv gather (power-of-two strides).
+
+No CPU fallback: CPU tensors raise.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+import torch.nn as nn
+from torch.nn import init
+from torch.nn.utils import spectral_norm
+
+from . import ops
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, Act, ConvLayer, SpadeModulate
+
+
+class BaseNetwork(nn.Module):
+    """network_generator.py:9-50."""
+
+    def __init__(self):
+        super().__init__()
+
+    def print_network(self):
+        n = sum(p.numel() for p in self.parameters())
+        print("Network [{}] was created. Total number of parameters: {:.1f} million. "
+              "To see the architecture, do print(network).".format(self.__class__.__name__, n / 1000000))
+
+    def init_weights(self, init_type="normal", gain=0.02):
+        table = {
+            "normal": lambda w: init.normal_(w, 0.0, gain),
+            "xavier": lambda w: init.xavier_normal_(w, gain=gain),
+            "xavier_uniform": lambda w: init.xavier_uniform_(w, gain=1.0),
+            "kaiming": lambda w: init.kaiming_normal_(w, a=0, mode="fan_in"),
+            "orthogonal": lambda w: init.orthogonal_(w, gain=gain),
+        }
+
+        def visit(m):
+            cname = m.__class__.__name__
+            if "BatchNorm2d" in cname:
+                if getattr(m, "weight", None) is not None:
+                    init.normal_(m.weight.data, 1.0, gain)
+                if getattr(m, "bias", None) is not None:
+                    init.constant_(m.bias.data, 0.0)
+            elif ("Conv" in cname or "Linear" in cname) and hasattr(m, "weight"):
+                if init_type == "none":
+                    m.reset_parameters()
+                elif init_type in table:
+                    table[init_type](m.weight.data)
+                else:
+                    raise NotImplementedError("initialization method '{}' is not implemented".format(init_type))
+                if getattr(m, "bias", None) is not None:
+                    init.constant_(m.bias.data, 0.0)
+
+        self.apply(visit)
+
+    def forward(self, *inputs):
+        pass
+
+
+def _sn_sigma(conv: nn.Module) -> float:
+    """Eval-mode spectral norm sigma = u . (W v) (torch SpectralNorm.compute_weight without
+    the power iteration); 1.0 for a plain conv."""
+    if hasattr(conv, "weight_orig"):
+        w = conv.weight_orig.detach().double().cpu()
+        u = conv.weight_u.detach().double().cpu()
+        v = conv.weight_v.detach().double().cpu()
+        return float(torch.dot(u, torch.mv(w.reshape(w.shape[0], -1), v)))
+    return 1.0
+
+
+def _raw_weight(conv: nn.Module) -> torch.Tensor:
+    return conv.weight_orig if hasattr(conv, "weight_orig") else conv.weight
+
+
+class SPADENorm(nn.Module):
+    """Parameter container, network_generator.py:75-99."""
+
+    def __init__(self, opt, norm_type, norm_nc, label_nc):
+        super().__init__()
+        self.param_opt = opt
+        self.noise_scale = nn.Parameter(torch.zeros(norm_nc))
+        assert norm_type.startswith("alias")
+        kind = norm_type[len("alias"):]
+        if kind != "instance":
+            raise ValueError("hr-viton_amd SPADENorm implements 'aliasinstance' (the reference default "
+                             "norm_G='spectralaliasinstance'); got '{}'".format(norm_type))
+        self.param_free_norm = nn.InstanceNorm2d(norm_nc, affine=False)  # parameter-free; executed by the HIP plan
+        nhidden, ks = 128, 3
+        self.conv_shared = nn.Sequential(nn.Conv2d(label_nc, nhidden, kernel_size=ks, padding=ks // 2), nn.ReLU())
+        self.conv_gamma = nn.Conv2d(nhidden, norm_nc, kernel_size=ks, padding=ks // 2)
+        self.conv_beta = nn.Conv2d(nhidden, norm_nc, kernel_size=ks, padding=ks // 2)
+
+
+class SPADEResBlock(nn.Module):
+    """Parameter container, network_generator.py:125-156."""
+
+    def __init__(self, opt, input_nc, output_nc, use_mask_norm=True):
+        super().__init__()
+        if use_mask_norm:
+            raise NotImplementedError("MaskNorm blocks are never constructed by the reference generator "
+                                      "(network_generator.py:188-198) and are out of scope")
+        self.param_opt = opt
+        self.learned_shortcut = input_nc != output_nc
+        middle_nc = min(input_nc, output_nc)
+        self.input_nc, self.middle_nc, self.output_nc = input_nc, middle_nc, output_nc
+        self.conv_0 = nn.Conv2d(input_nc, middle_nc, kernel_size=3, padding=1)
+        self.conv_1 = nn.Conv2d(middle_nc, output_nc, kernel_size=3, padding=1)
+        if self.learned_shortcut:
+            self.conv_s = nn.Conv2d(input_nc, output_nc, kernel_size=1, bias=False)
+        subnorm = opt.norm_G
+        if subnorm.startswith("spectral"):
+            subnorm = subnorm[len("spectral"):]
+            self.conv_0 = spectral_norm(self.conv_0)
+            self.conv_1 = spectral_norm(self.conv_1)
+            if self.learned_shortcut:
+                self.conv_s = spectral_norm(self.conv_s)
+        nc = opt.gen_semantic_nc
+        self.norm_0 = SPADENorm(opt, subnorm, input_nc, nc)
+        self.norm_1 = SPADENorm(opt, subnorm, middle_nc, nc)
+        if self.learned_shortcut:
+            self.norm_s = SPADENorm(opt, subnorm, input_nc, nc)
+        self.relu = nn.LeakyReLU(0.2)
+
+
+class _SpadePlan:
+    """One SPADENorm on the HIP path: stats -> conv_shared(+ReLU) -> fused gamma||beta+modulate."""
+
+    def __init__(self, norm: SPADENorm, device, act: int, name: str):
+        cs = norm.conv_shared[0]
+        self.label_nc = cs.in_channels
+        self.shared = ConvLayer(cs.weight, [self.label_nc], device, shift=cs.bias, pad=1, act=ACT_RELU,
+                                name=name + ".conv_shared")
+        self.mod = SpadeModulate(norm.conv_gamma.weight, norm.conv_gamma.bias, norm.conv_beta.weight,
+                                 norm.conv_beta.bias, norm.noise_scale, device, act, name + ".conv_gamma|beta")
+
+    def __call__(self, x: Act, seg: Act, seg_shift: int, z: Optional[torch.Tensor]) -> Act:
+        zz = z if (z is not None and self.mod.has_noise) else None
+        mean, rstd = ops.instnorm_stats(x, zz, self.mod.ns if zz is not None else None)
+        actv = self.shared([(seg, -seg_shift, ACT_NONE)])
+        return self.mod(actv, x, mean, rstd, zz)
+
+
+class _BlockPlan:
+    def __init__(self, blk: SPADEResBlock, device, name: str):
+        self.learned = blk.learned_shortcut
+        self.n0 = _SpadePlan(blk.norm_0, device, ACT_LRELU, name + ".norm_0")
+        self.n1 = _SpadePlan(blk.norm_1, device, ACT_LRELU, name + ".norm_1")
+        s0, s1 = _sn_sigma(blk.conv_0), _sn_sigma(blk.conv_1)
+        self.c0 = ConvLayer(_raw_weight(blk.conv_0), [blk.input_nc], device,
+                            scale=torch.full((blk.middle_nc,), 1.0 / s0), shift=blk.conv_0.bias, pad=1,
+                            name=name + ".conv_0")
+        self.c1_scale = torch.full((blk.output_nc,), 1.0 / s1)
+        self.c1_w, self.c1_b = _raw_weight(blk.conv_1), blk.conv_1.bias
+        self.device, self.name, self.blk = device, name, blk
+        self._c1 = {}
+        if self.learned:
+            self.ns_ = _SpadePlan(blk.norm_s, device, ACT_NONE, name + ".norm_s")
+            ss = _sn_sigma(blk.conv_s)
+            self.cs = ConvLayer(_raw_weight(blk.conv_s), [blk.input_nc], device,
+                                scale=torch.full((blk.output_nc,), 1.0 / ss), pad=0, name=name + ".conv_s")
+
+    def conv1(self, act: int) -> ConvLayer:
+        if act not in self._c1:
+            self._c1[act] = ConvLayer(self.c1_w, [self.blk.middle_nc], self.device, scale=self.c1_scale,
+                                      shift=self.c1_b, pad=1, act=act, name=self.name + ".conv_1")
+        return self._c1[act]
+
+    def __call__(self, x: Act, seg: Act, seg_shift: int, zs: Sequence[Optional[torch.Tensor]], out: Optional[Act],
+                 out_up: int, out_act: int) -> Act:
+        """x_s + conv_1(lrelu(norm_1(conv_0(lrelu(norm_0(x)))))) -- network_generator.py:163-173.
+        ``zs``: noise draws in the reference's call order (norm_s, norm_0, norm_1)."""
+        zi = iter(zs)
+        if self.learned:
+            x_s = self.cs([self.ns_(x, seg, seg_shift, next(zi))])
+        else:
+            x_s = x
+        dx = self.c0([self.n0(x, seg, seg_shift, next(zi))])
+        h1 = self.n1(dx, seg, seg_shift, next(zi))
+        return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
+
+
+class SPADEGenerator(BaseNetwork):
+    """Try-on image generator (network_generator.py:176-245), HIP inference path."""
+
+    BLOCKS = ["head_0", "G_middle_0", "G_middle_1", "up_0", "up_1", "up_2", "up_3", "up_4"]
+
+    def __init__(self, opt, input_nc):
+        super().__init__()
+        self.num_upsampling_layers = opt.num_upsampling_layers
+        self.param_opt = opt
+        self.sh, self.sw = self.compute_latent_vector_size(opt)
+        self.input_nc = input_nc
+        nf = opt.ngf
+        self.conv_0 = nn.Conv2d(input_nc, nf * 16, kernel_size=3, padding=1)
+        for i in range(1, 8):
+            self.add_module("conv_{}".format(i), nn.Conv2d(input_nc, 16, kernel_size=3, padding=1))
+        self.head_0 = SPADEResBlock(opt, nf * 16, nf * 16, use_mask_norm=False)
+        self.G_middle_0 = SPADEResBlock(opt, nf * 16 + 16, nf * 16, use_mask_norm=False)
+        self.G_middle_1 = SPADEResBlock(opt, nf * 16 + 16, nf * 16, use_mask_norm=False)
+        self.up_0 = SPADEResBlock(opt, nf * 16 + 16, nf * 8, use_mask_norm=False)
+        self.up_1 = SPADEResBlock(opt, nf * 8 + 16, nf * 4, use_mask_norm=False)
+        self.up_2 = SPADEResBlock(opt, nf * 4 + 16, nf * 2, use_mask_norm=False)
+        self.up_3 = SPADEResBlock(opt, nf * 2 + 16, nf * 1, use_mask_norm=False)
+        if self.num_upsampling_layers == "most":
+            self.up_4 = SPADEResBlock(opt, nf * 1 + 16, nf // 2, use_mask_norm=False)
+            nf = nf // 2
+        self.conv_img = nn.Conv2d(nf, 3, kernel_size=3, padding=1)
+        self.up = nn.Upsample(scale_factor=2, mode="nearest")
+        self.relu = nn.LeakyReLU(0.2)
+        self.tanh = nn.Tanh()
+        self._plan = None
+        self._plan_key = None
+
+    def compute_latent_vector_size(self, opt):
+        table = {"normal": 5, "more": 6, "most": 7}
+        if self.num_upsampling_layers not in table:
+            raise ValueError("opt.num_upsampling_layers '{}' is not recognized".format(self.num_upsampling_layers))
+        n = table[self.num_upsampling_layers]
+        return opt.fine_height // 2 ** n, opt.fine_width // 2 ** n
+
+    # ------------------------------------------------------------------ plan
+    def _blocks(self) -> List[str]:
+        names = list(self.BLOCKS[:7])
+        if self.num_upsampling_layers == "most":
+            names.append("up_4")
+        return names
+
+    def _build_plan(self, device):
+        P = {"blocks": [_BlockPlan(getattr(self, n), device, n) for n in self._blocks()]}
+        P["stem"] = [ConvLayer(getattr(self, f"conv_{i}").weight, [self.input_nc], device,
+                               shift=getattr(self, f"conv_{i}").bias, pad=1, name=f"conv_{i}")
+                     for i in range(len(P["blocks"]))]
+        P["img"] = ConvLayer(self.conv_img.weight, [self.conv_img.in_channels], device, shift=self.conv_img.bias, pad=1,
+                             act=ACT_TANH, name="conv_img")
+        return P
+
+    def _get_plan(self, device):
+        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())))
+        if self._plan is None or self._plan_key != key:
+            self._plan = self._build_plan(device)
+            self._plan_key = key
+        return self._plan
+
+    # --------------------------------------------------------------- forward
+    def forward(self, x, seg, noise: Optional[Dict[str, Sequence[torch.Tensor]]] = None):
+        """``forward(x, seg)`` as the reference (network_generator.py:221).  ``noise`` optionally
+        injects the per-SPADENorm N(0,1) draws ([b,w,h,1] each, in the reference's call order per
+        block) so a run can be compared against a recorded reference run; by default they are drawn
+        with torch.randn on the device exactly where the reference draws them (:104-107)."""
+        if self.training:
+            raise NotImplementedError("hr-viton_amd SPADEGenerator: training-mode forward/backward HIP kernels are "
+                                      "not built yet; call .eval()")
+        if self.num_upsampling_layers == "normal":
+            raise ValueError("num_upsampling_layers='normal' is broken in the reference itself (shape mismatch at "
+                             "G_middle_1, network_generator.py:228-230)")
+        with torch.no_grad():
+            return self._forward_eval(x, seg, noise)
+
+    def _forward_eval(self, x, seg, noise):
+        ops.require_cuda(x, "SPADEGenerator.forward(x)")
+        ops.require_cuda(seg, "SPADEGenerator.forward(seg)")
+        N, _, H, W = x.shape
+        names = self._blocks()
+        nb = len(names)
+        top = nb - 1                        # blocks run at (sh,sw) * 2^j, j = 0..top
+        if (self.sh << top, self.sw << top) != (H, W):
+            raise ValueError(f"input {H}x{W} does not match fine_height/fine_width and num_upsampling_layers="
+                             f"'{self.num_upsampling_layers}' (needs {self.sh << top}x{self.sw << top}; 'most' "
+                             "needs H, W multiples of 128 -- see network_generator.py:207-218)")
+        P = self._get_plan(x.device)
+        xin = ops.to_nhwc(x)       # [N,H,W,12] (9 real channels)
+        sg = ops.to_nhwc(seg)      # [N,H,W,8]  (7 real channels)
+        dev = x.device
+
+        def draws(name, blk, h, w):
+            if noise is not None:
+                return [z.to(dev).contiguous() for z in noise[name]]
+            k = 3 if blk.learned else 2
+            return [torch.randn(N, w, h, 1, device=dev) for _ in range(k)]
+
+        cur: Optional[Act] = None
+        for j, name in enumerate(names):
+            blk = P["blocks"][j]
+            h, w = self.sh << j, self.sw << j
+            shift = top - j                 # log2 of the nearest down-sampling of x / seg at this scale
+            cin = getattr(self, name).input_nc
+            if j == 0:
+                cur = P["stem"][0]([(xin, -shift, ACT_NONE)])
+            else:
+                # cur already holds up(prev) in channels [0, cin-16); the stem conv fills the rest
+                P["stem"][j]([(xin, -shift, ACT_NONE)], out=cur.slice(cin - 16, 16))
+            assert cur.C == cin and (cur.H, cur.W) == (h, w)
+            last = j == nb - 1
+            if last:
+                # the generator ends with conv_img(leaky_relu(x)): fuse that LeakyReLU here
+                cur = blk(cur, sg, shift, draws(name, blk, h, w), None, 0, ACT_LRELU)
+            else:
+                nxt_c = getattr(self, names[j + 1]).input_nc
+                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)
+                blk(cur, sg, shift, draws(name, blk, h, w), nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
+                cur = nxt
+        img = P["img"]([cur])
+        return ops.to_nchw(img)
+
+
+# ----------------------------------------------------------------------------
+# PatchGAN discriminator of the generator (network_generator.py:250-316)
+# ----------------------------------------------------------------------------
+
+def get_nonspade_norm_layer(norm_type="instance"):
+    """network_generator.py:401-433 (spectral + instance / none)."""
+
+    def add_norm_layer(layer):
+        sub = norm_type
+        if norm_type.startswith("spectral"):
+            layer = spectral_norm(layer)
+            sub = norm_type[len("spectral"):]
+        if sub == "none" or len(sub) == 0:
+            return layer
+        if getattr(layer, "bias", None) is not None:
+            delattr(layer, "bias")
+            layer.register_parameter("bias", None)
+        if sub == "instance":
+            norm_layer = nn.InstanceNorm2d(layer.out_channels, affine=False)
+        elif sub == "batch":
+            norm_layer = nn.BatchNorm2d(layer.out_channels, affine=True)
+        else:
+            raise ValueError("normalization layer %s is not recognized" % sub)
+        return nn.Sequential(layer, norm_layer)
+
+    return add_norm_layer
+
+
+class NLayerDiscriminator(BaseNetwork):
+    def __init__(self, opt):
+        super().__init__()
+        self.no_ganFeat_loss = opt.no_ganFeat_loss
+        nf = opt.ndf
+        kw = 4
+        pw = int(np.ceil((kw - 1.0) / 2))
+        norm_layer = get_nonspade_norm_layer(opt.norm_D)
+        input_nc = opt.gen_semantic_nc + 3
+        seq = [[nn.Conv2d(input_nc, nf, kernel_size=kw, stride=2, padding=pw), nn.LeakyReLU(0.2, False)]]
+        for _ in range(1, opt.n_layers_D):
+            nf_prev, nf = nf, min(nf * 2, 512)
+            seq += [[norm_layer(nn.Conv2d(nf_prev, nf, kernel_size=kw, stride=2, padding=pw)), nn.LeakyReLU(0.2, False)]]
+        seq += [[nn.Conv2d(nf, 1, kernel_size=kw, stride=1, padding=pw)]]
+        for n, mods in enumerate(seq):
+            self.add_module("model" + str(n), nn.Sequential(*mods))
+        self.n_models = len(seq)
+        self._plan = None
+        self._plan_key = None
+
+    def _build_plan(self, device):
+        plan = []
+        for n in range(self.n_models):
+            m = getattr(self, "model" + str(n))
+            first = m[0]
+            if isinstance(first, nn.Sequential):          # [SN conv (no bias), InstanceNorm] + LeakyReLU
+                conv = first[0]
+                if not isinstance(first[1], nn.InstanceNorm2d):
+                    raise NotImplementedError("HIP discriminator implements norm_D='spectralinstance'")
+                layer = ConvLayer(_raw_weight(conv), [conv.in_channels], device,
+                                  scale=torch.full((conv.out_channels,), 1.0 / _sn_sigma(conv)),
+                                  stride=conv.stride[0], pad=conv.padding[0], name=f"model{n}")
+                plan.append(("in_lrelu", layer))
+            else:
+                conv = first
+                act = ACT_LRELU if len(m) > 1 else ACT_NONE
+                layer = ConvLayer(_raw_weight(conv), [conv.in_channels], device,
+                                  scale=torch.full((conv.out_channels,), 1.0 / _sn_sigma(conv)), shift=conv.bias,
+                                  stride=conv.stride[0], pad=conv.padding[0], act=act, name=f"model{n}")
+                plan.append(("plain", layer))
+        return plan
+
+    def _get_plan(self, device):
+        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())))
+        if self._plan is None or self._plan_key != key:
+            self._plan = self._build_plan(device)
+            self._plan_key = key
+        return self._plan
+
+    def forward_act(self, a: Act) -> List[Act]:
+        feats = []
+        for kind, layer in self._get_plan(a.t.device):
+            a = layer([a])
+            if kind == "in_lrelu":
+                mean, rstd = ops.instnorm_stats(a)
+                a = ops.instnorm_apply(a, mean, rstd, ACT_LRELU, 0.2, out=a)
+            feats.append(a)
+        return feats
+
+    def forward(self, input):
+        if self.training:
+            raise NotImplementedError("hr-viton_amd NLayerDiscriminator: training-mode kernels are not built yet")
+        with torch.no_grad():
+            feats = [ops.to_nchw(f) for f in self.forward_act(ops.to_nhwc(input))]
+        return feats if not self.no_ganFeat_loss else feats[-1]
+
+
+class MultiscaleDiscriminator(BaseNetwork):
+    def __init__(self, opt):
+        super().__init__()
+        self.no_ganFeat_loss = opt.no_ganFeat_loss
+        for i in range(opt.num_D):
+            self.add_module("discriminator_%d" % i, NLayerDiscriminator(opt))
+
+    def downsample(self, input):
+        raise RuntimeError("executed inside forward() by hrv_avgpool3x3s2_nhwc_f32")
+
+    def forward(self, input):
+        """List (scales) of lists (layers) of NCHW tensors -- network_generator.py:306-316."""
+        if self.training:
+            raise NotImplementedError("hr-viton_amd MultiscaleDiscriminator: training-mode kernels are not built yet")
+        ops.require_cuda(input, "MultiscaleDiscriminator.forward")
+        result = []
+        with torch.no_grad():
+            a = ops.to_nhwc(input)
+            ds = list(self.children())
+            for k, D in enumerate(ds):
+                feats = [ops.to_nchw(f) for f in D.forward_act(a)]
+                result.append(feats if not self.no_ganFeat_loss else [feats[-1]])
+                if k + 1 < len(ds):
+                    a = ops.avgpool3x3s2(a)
+        return result

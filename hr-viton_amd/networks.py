@@ -251,7 +251,11 @@ def save_checkpoint(model, save_path, opt=None):
     d = os.path.dirname(save_path)
     if d and not os.path.exists(d):
         os.makedirs(d)
-    torch.save({k: v.detach().cpu() for k, v in model.state_dict().items()}, save_path)
+    sd = model.state_dict()
+    out = type(sd)((k, v.detach().cpu()) for k, v in sd.items())
+    if hasattr(sd, "_metadata"):
+        out._metadata = sd._metadata      # spectral-norm version entries travel with the file
+    torch.save(out, save_path)
 
 
 def load_checkpoint(model, checkpoint_path, opt=None):

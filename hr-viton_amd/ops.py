@@ -177,10 +177,14 @@ class ConvLayer:
         return ((H + 2 * self.pad - self.KH) // self.stride + 1, (W + 2 * self.pad - self.KW) // self.stride + 1)
 
     def flops(self, N, Ho, Wo) -> float:
-        return 2.0 * N * Ho * Wo * self.Cout * sum(self.src_real) * self.KH * self.KW
+        return 2.0 * N * Ho * Wo * getattr(self, "flops_cout", self.Cout) * sum(self.src_real) * self.KH * self.KW
 
     def __call__(self, srcs: Sequence[SrcSpec], out: Optional[Act] = None, residual: Optional[Act] = None,
-                 H: Optional[int] = None, W: Optional[int] = None) -> Act:
+                 H: Optional[int] = None, W: Optional[int] = None, out_up: int = 0, spade=None,
+                 out_channels: Optional[int] = None, cfg: Optional[int] = None) -> Act:
+        """``out_up=1``: ``out`` is (2Ho x 2Wo), results replicated 2x2 (fused nearest upsample).
+        ``spade``: hrv_spade_epi_t for the fused gamma||beta + modulate epilogue (then
+        ``out_channels`` = C of the normalised tensor)."""
         lib = _lib.load()
         specs = [(s, 0, ACT_NONE) if isinstance(s, Act) else s for s in srcs]
         assert len(specs) == len(self.src_real), (self.name, len(specs), self.src_real)
@@ -189,8 +193,9 @@ class ConvLayer:
         if H is None:
             H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
         Ho, Wo = self.out_hw(H, W)
+        oc = self.Cout if out_channels is None else out_channels
         if out is None:
-            out = alloc(N, Ho, Wo, self.Cout, a0.t.device)
+            out = alloc(N, Ho << out_up, Wo << out_up, oc, a0.t.device)
         d = _lib.hrv_conv2d_t()
         d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
@@ -203,8 +208,9 @@ class ConvLayer:
             s.ptr, s.C, s.cstride, s.coff = a.t.data_ptr(), self.src_pad[i], a.cstride, a.coff
             s.up_shift, s.pre_act, s.C_real = up, pre, self.src_real[i]
         naive = os.environ.get("HRV_CONV_IMPL", "mfma") == "naive"
-        cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, self.Cout)
-        forced = os.environ.get("HRV_CONV_TILE")
+        if cfg is None:
+            cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, self.Cout)
+        forced = os.environ.get("HRV_CONV_TILE") if spade is None else None
         if forced is not None:
             cfg = int(forced)
         d.Cout, d.tile_cfg = self.Cout, cfg
@@ -220,8 +226,11 @@ class ConvLayer:
             assert (residual.N, residual.H, residual.W) == (N, Ho, Wo) and residual.C == self.Cout
             d.residual, d.res_cstride, d.res_coff = residual.t.data_ptr(), residual.cstride, residual.coff
         d.act, d.act_slope = self.act, self.slope
-        assert (out.N, out.H, out.W) == (N, Ho, Wo) and out.C == self.Cout, (self.name, out.t.shape, out.C)
+        assert (out.N, out.H, out.W) == (N, Ho << out_up, Wo << out_up) and out.C == oc, (self.name, out.t.shape, out.C)
         d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+        d.out_up_shift = out_up
+        if spade is not None:
+            d.spade = C.pointer(spade)
         fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else lib.hrv_conv2d_nhwc_f32
         with _Timed("conv", self.name, self.flops(N, Ho, Wo), 0):
             _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")
@@ -258,6 +267,92 @@ class TapConvLayer:
                                                res_ptr, rcs, out.t.data_ptr(), out.cstride, _stream()),
                        "hrv_tapsum_nhwc_f32")
         return out
+
+
+def instnorm_stats(a: Act, z: Optional[torch.Tensor] = None, noise_scale: Optional[torch.Tensor] = None,
+                   eps: float = 1e-5):
+    """hrv_instnorm_stats_nhwc_f32 -> (mean, rstd) float32 [N, Cp] for v = a + z[n,w,h]*noise_scale[c]."""
+    lib = _lib.load()
+    Cp = a.Cp
+    dev = a.t.device
+    ws = torch.empty(lib.hrv_instnorm_workspace_elems(a.N, a.H, a.W, Cp), dtype=torch.float32, device=dev)
+    mean = torch.empty((a.N, Cp), dtype=torch.float32, device=dev)
+    rstd = torch.empty((a.N, Cp), dtype=torch.float32, device=dev)
+    if z is not None:
+        assert z.is_contiguous() and z.numel() == a.N * a.W * a.H and noise_scale.numel() == Cp
+    with _Timed("stats", "instnorm_stats", 0.0, 4.0 * a.N * a.H * a.W * Cp):
+        _lib.check(lib.hrv_instnorm_stats_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, Cp, a.cstride, a.coff,
+                                                   None if z is None else z.data_ptr(),
+                                                   None if z is None else noise_scale.data_ptr(), eps,
+                                                   ws.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream()),
+                   "hrv_instnorm_stats_nhwc_f32")
+    return mean, rstd
+
+
+def instnorm_apply(a: Act, mean: torch.Tensor, rstd: torch.Tensor, act: int = ACT_NONE, slope: float = 0.2,
+                   out: Optional[Act] = None) -> Act:
+    lib = _lib.load()
+    if out is None:
+        out = alloc(a.N, a.H, a.W, a.C, a.t.device)
+    with _Timed("apply", "instnorm_apply", 0.0, 8.0 * a.N * a.H * a.W * a.Cp):
+        _lib.check(lib.hrv_instnorm_apply_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff,
+                                                   mean.data_ptr(), rstd.data_ptr(), act, slope, out.t.data_ptr(),
+                                                   out.cstride, out.coff, _stream()), "hrv_instnorm_apply_nhwc_f32")
+    return out
+
+
+def avgpool3x3s2(a: Act) -> Act:
+    lib = _lib.load()
+    Ho, Wo = (a.H + 2 - 3) // 2 + 1, (a.W + 2 - 3) // 2 + 1
+    out = alloc(a.N, Ho, Wo, a.C, a.t.device)
+    with _Timed("pool", "avgpool3x3s2", 0.0, 4.0 * a.N * a.H * a.W * a.Cp * 1.25):
+        _lib.check(lib.hrv_avgpool3x3s2_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff,
+                                                 out.t.data_ptr(), out.cstride, out.coff, _stream()),
+                   "hrv_avgpool3x3s2_nhwc_f32")
+    return out
+
+
+class SpadeModulate:
+    """Fused conv_gamma || conv_beta (128 -> 2C, 3x3) whose epilogue applies
+    IN(x + noise) * (1 + gamma) + beta (+ LeakyReLU): network_generator.py:101-122,170-171."""
+
+    def __init__(self, w_gamma, b_gamma, w_beta, b_beta, noise_scale, device, act: int, name: str):
+        wg = w_gamma.detach().to("cpu", torch.float32)
+        wb = w_beta.detach().to("cpu", torch.float32)
+        self.Creal = wg.shape[0]
+        self.Cp = _ceil4(self.Creal)
+        G = (self.Creal + 31) // 32
+        hid, k = wg.shape[1], wg.shape[2]
+        w = torch.zeros(G * 64, hid, k, k)
+        b = torch.zeros(G * 64)
+        for g in range(G):
+            n = min(32, self.Creal - g * 32)
+            w[g * 64: g * 64 + n] = wg[g * 32: g * 32 + n]
+            w[g * 64 + 32: g * 64 + 32 + n] = wb[g * 32: g * 32 + n]
+            b[g * 64: g * 64 + n] = b_gamma.detach().cpu().float()[g * 32: g * 32 + n]
+            b[g * 64 + 32: g * 64 + 32 + n] = b_beta.detach().cpu().float()[g * 32: g * 32 + n]
+        self.conv = ConvLayer(w, [hid], device, shift=b, stride=1, pad=k // 2, act=act, name=name)
+        self.conv.flops_cout = 2 * self.Creal   # algorithmic (unpadded) gamma+beta columns
+        self.cfg = 0 if (G % 2 == 0) else 6   # 128x128 tile when the pair count is even, else 128x64
+        ns = torch.zeros(self.Cp)
+        ns[: self.Creal] = noise_scale.detach().cpu().float()
+        self.ns = ns.to(device)
+        self.has_noise = bool((ns != 0).any().item())
+
+    def flops(self, N, H, W):
+        return 2.0 * N * H * W * 2 * self.Creal * self.conv.w_cpu.shape[1] * self.conv.KH * self.conv.KW
+
+    def __call__(self, actv: Act, x: Act, mean, rstd, z: Optional[torch.Tensor], out: Optional[Act] = None) -> Act:
+        assert x.C == self.Creal, (self.conv.name, x.C, self.Creal)
+        e = _lib.hrv_spade_epi_t()
+        e.x, e.x_cstride, e.x_coff, e.C = x.t.data_ptr(), x.cstride, x.coff, self.Cp
+        e.mean, e.rstd = mean.data_ptr(), rstd.data_ptr()
+        use_noise = z is not None and self.has_noise
+        e.noise_z = z.data_ptr() if use_noise else None
+        e.noise_scale = self.ns.data_ptr() if use_noise else None
+        if out is None:
+            out = alloc(x.N, x.H, x.W, self.Creal, x.t.device)
+        return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=self.cfg)
 
 
 def resize_bilinear(a: Act, Ho: int, Wo: int, rh: float, rw: float, addend: Optional[Act] = None,

@@ -76,6 +76,27 @@ typedef struct hrv_src {
                        reads it; the packed weight already has zero rows.    */
 } hrv_src_t;
 
+/* SPADE epilogue (network_generator.py:101-122 + the LeakyReLU of :170-171): when
+ * hrv_conv2d_t.spade is set the convolution is the fused conv_gamma||conv_beta
+ * (128 -> 2C, 3x3) and the epilogue modulates the tensor being normalised:
+ *     v   = x + noise_z[n,w,h] * noise_scale[c]
+ *     out = act( (v - mean[n,c]) * rstd[n,c] * (1 + gamma) + beta )
+ * w_packed holds 2*ceil32(C) output columns ordered in (gamma[32] | beta[32])
+ * pairs per 32-channel group; `shift` holds the two biases in the same column
+ * order; `scale`/`residual` are ignored; `Cout` is that column count; `out`
+ * has C channels.  mean/rstd come from hrv_instnorm_stats_nhwc_f32. */
+typedef struct hrv_spade_epi {
+  const float* x;      /* NHWC, same pixels as out */
+  int32_t x_cstride, x_coff;
+  int32_t C;           /* channels (multiple of 4; pad channels are zero)     */
+  int32_t _pad;
+  const float* mean;   /* [N][C] */
+  const float* rstd;   /* [N][C] */
+  const float* noise_z;     /* [N][W][H] N(0,1) draw, layout of torch.randn(b,w,h,1)
+                               (network_generator.py:104-107), or NULL        */
+  const float* noise_scale; /* [C] or NULL */
+} hrv_spade_epi_t;
+
 typedef struct hrv_conv2d {
   int32_t N, H, W;   /* conv input extent (after any folded upsample)        */
   int32_t Ho, Wo;    /* output extent                                        */
@@ -95,6 +116,12 @@ typedef struct hrv_conv2d {
   float act_slope;      /* LeakyReLU negative slope                          */
   void* out;            /* NHWC                                              */
   int32_t out_cstride, out_coff;
+  const hrv_spade_epi_t* spade; /* NULL: standard epilogue                   */
+  int32_t out_up_shift; /* 1: `out` is (2*Ho) x (2*Wo) and every result is stored
+                           to its 2x2 block -- the nn.Upsample(nearest, x2) that
+                           follows each SPADEResBlock (network_generator.py:226-
+                           241) fused into the producer's store; 0: plain      */
+  int32_t _pad2;
 } hrv_conv2d_t;
 
 /* Tile configuration for (M = N*Ho*Wo output pixels, Cout): returns cfg id. */
@@ -128,6 +155,25 @@ int hrv_conv2d_naive_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
 int hrv_tapsum_nhwc_f32(const float* y, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad,
                         int32_t Cout, int32_t y_cstride, const float* bias, const float* residual,
                         int32_t res_cstride, float* out, int32_t out_cstride, hrv_stream_t stream);
+
+/* ------------------------------------------------------------------------
+ * InstanceNorm2d(affine=False) pieces (network_generator.py:86,427; eps 1e-5,
+ * biased variance over H*W per (n,c)).  stats: mean/rstd of x (+ SPADE noise
+ * z[n,w,h]*noise_scale[c], :104-110) -- two deterministic stages (shifted
+ * partial sums, double-precision fixed-order finalise); `workspace` needs
+ * hrv_instnorm_workspace_elems floats.  apply: out = act((x-mean)*rstd).
+ * avgpool: F.avg_pool2d(3, stride 2, pad 1, count_include_pad=False) (:301-302).
+ * ---------------------------------------------------------------------- */
+int64_t hrv_instnorm_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
+int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                                int32_t coff, const float* noise_z, const float* noise_scale, float eps,
+                                float* workspace, float* mean, float* rstd, hrv_stream_t stream);
+int hrv_instnorm_apply_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                                int32_t coff, const float* mean, const float* rstd, int32_t act, float act_slope,
+                                float* out, int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+int hrv_avgpool3x3s2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                              int32_t coff, float* out, int32_t out_cstride, int32_t out_coff,
+                              hrv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Layout converters at the module boundary (the reference's tensors are NCHW).

@@ -39,7 +39,8 @@ def test_struct_layout_matches_c(lib):
     from hr_viton_amd import _lib
     # sizes implied by the C declarations (LP64): see include/hrviton_hip.h
     assert C.sizeof(_lib.hrv_src_t) == 32
-    assert C.sizeof(_lib.hrv_conv2d_t) == 40 + 4 * 32 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.hrv_conv2d_t) == 40 + 4 * 32 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8
+    assert C.sizeof(_lib.hrv_spade_epi_t) == 8 + 16 + 32
     assert C.sizeof(_lib.hrv_flow_warp_t) == 8 + 24 + 8 + 16 + 16 + 8 + 8 + 8
 
 
@@ -47,7 +48,7 @@ def test_pick_tile(lib):
     for M, cout in [(3072, 768), (786432, 96), (3145728, 96), (786432, 2), (196608, 384), (100, 13), (50000, 1040)]:
         cfg = lib.hrv_conv2d_pick_tile(M, cout)
         bn, bm = lib.hrv_conv2d_tile_bn(cfg), lib.hrv_conv2d_tile_bm(cfg)
-        assert bn in (32, 64, 96, 128) and bm in (128, 256)
+        assert bn in (32, 64, 96, 128) and bm == 128
         padded = -(-cout // bn) * bn
         assert padded - cout < bn
         # never waste more than the minimum achievable over the tile widths
