@@ -58,11 +58,12 @@ class ResBlock(nn.Module):
 
 def _bn_fold(bn: nn.BatchNorm2d):
     """Eval-mode BatchNorm as per-channel (scale, shift) for the conv epilogue."""
-    inv = torch.rsqrt(bn.running_var.detach().double() + bn.eps)
-    g = bn.weight.detach().double() if bn.affine else torch.ones_like(inv)
-    b = bn.bias.detach().double() if bn.affine else torch.zeros_like(inv)
+    # host-side weight preparation (once per plan), in double on the CPU
+    inv = torch.rsqrt(bn.running_var.detach().cpu().double() + bn.eps)
+    g = bn.weight.detach().cpu().double() if bn.affine else torch.ones_like(inv)
+    b = bn.bias.detach().cpu().double() if bn.affine else torch.zeros_like(inv)
     scale = g * inv
-    shift = b - bn.running_mean.detach().double() * scale
+    shift = b - bn.running_mean.detach().cpu().double() * scale
     return scale.float(), shift.float()
 
 
