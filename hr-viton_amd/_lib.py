@@ -67,6 +67,11 @@ SYMBOLS = {
     "hrv_instnorm_apply_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32,
                                               _i32, _vp]),
     "hrv_avgpool3x3s2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_mul_channel_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _vp]),
+    "hrv_gauss_blur_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp, _vp, _vp]),
+    "hrv_parse_argmax_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _i32, _vp]),
+    "hrv_resize_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_occlusion_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     "hrv_nchw_to_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
     "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,

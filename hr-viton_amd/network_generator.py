@@ -278,7 +278,8 @@ class SPADEGenerator(BaseNetwork):
 
     def _forward_eval(self, x, seg, noise):
         ops.require_cuda(x, "SPADEGenerator.forward(x)")
-        ops.require_cuda(seg, "SPADEGenerator.forward(seg)")
+        if not isinstance(seg, Act):
+            ops.require_cuda(seg, "SPADEGenerator.forward(seg)")
         N, _, H, W = x.shape
         names = self._blocks()
         nb = len(names)
@@ -289,7 +290,7 @@ class SPADEGenerator(BaseNetwork):
                              "needs H, W multiples of 128 -- see network_generator.py:207-218)")
         P = self._get_plan(x.device)
         xin = ops.to_nhwc(x)       # [N,H,W,12] (9 real channels)
-        sg = ops.to_nhwc(seg)      # [N,H,W,8]  (7 real channels)
+        sg = seg if isinstance(seg, Act) else ops.to_nhwc(seg)      # [N,H,W,8]  (7 real channels)
         dev = x.device
 
         def draws(name, blk, h, w):

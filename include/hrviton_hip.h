@@ -176,6 +176,33 @@ int hrv_avgpool3x3s2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, i
                               hrv_stream_t stream);
 
 /* ------------------------------------------------------------------------
+ * Parse-map glue between the two networks (test_generator.py:161-217;
+ * train_generator.py:217-275).
+ *   mul_channel : fake_segmap[:,3] *= warped_cm (:167-176; binarize=1 is the
+ *                 'detach' composition: (cm > 0.5))
+ *   gauss_blur  : tgm.image.GaussianBlur((k,k),(s,s)) = depthwise conv with zero
+ *                 padding, run as two separable passes; `taps_host` are the k
+ *                 normalised 1-D weights (HOST pointer, copied into the launch);
+ *                 `tmp` is a scratch tensor of the input's size (:179)
+ *   parse_argmax: argmax(dim=1) (first maximum wins) -> int64 labels (nullable)
+ *                 + the 13->7 merged one-hot map, NHWC [.,8] (:180-203)
+ *   occlusion   : remove_overlap(softmax(gauss), cm) and cloth compositing
+ *                 (:19-24,214-216); cm lives in channel cm_ch of an NHWC tensor
+ * ---------------------------------------------------------------------- */
+int hrv_mul_channel_nhwc_f32(float* x, int32_t x_cstride, int32_t ch, const float* m, int32_t m_cstride,
+                             int32_t m_ch, int32_t binarize, int64_t npix, hrv_stream_t stream);
+int hrv_gauss_blur_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                            const float* taps_host, int32_t ksize, float* tmp, float* out, hrv_stream_t stream);
+int hrv_parse_argmax_nhwc_f32(const float* g, int32_t cstride, int32_t nclass, int64_t npix, int64_t* labels,
+                              float* parse7, int32_t parse_cstride, hrv_stream_t stream);
+/* F.interpolate(size=(Ho,Wo), mode='bilinear'|'nearest') on contiguous NCHW planes
+ * (planes = N*C): the input pre-processing of test_generator.py:144-150. */
+int hrv_resize_nchw_f32(const float* in, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                        int32_t nearest, float* out, hrv_stream_t stream);
+int hrv_occlusion_nhwc_f32(const float* g, int32_t g_cstride, int32_t nclass, float* cloth, int32_t cloth_cstride,
+                           float* cm, int32_t cm_cstride, int32_t cm_ch, int64_t npix, hrv_stream_t stream);
+
+/* ------------------------------------------------------------------------
  * Layout converters at the module boundary (the reference's tensors are NCHW).
  * ---------------------------------------------------------------------- */
 int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, float* out,
