@@ -60,6 +60,8 @@ struct ConvParams {
   float pre_slope;
   float* out;
   int out_cs, out_co;
+  int splitk;  // >1: K range split over `splitk` blocks per tile; raw partials go to `ws`
+  float* ws;   // [splitk][M][CoutPad]
   int out_up;  // 1: replicate every result to its 2x2 block of a (2Ho x 2Wo) output
   // SPADE epilogue (epi == 1)
   int epi;
@@ -93,11 +95,15 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
   const int wm = wave / WN;
   const int wn = wave % WN;
 
-  const int lid = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles);
+  const int lid_all = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles * p.splitk);
+  const int lid = lid_all / p.splitk;       // the splits of one tile are neighbours (same XCD)
+  const int ks = lid_all - lid * p.splitk;
   const int mt = lid / p.n_tiles;
   const int nt = lid - mt * p.n_tiles;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+  const int kt_begin = (int)(((long long)p.KT * ks) / p.splitk);
+  const int kt_end = (int)(((long long)p.KT * (ks + 1)) / p.splitk);
 
   // ---- per-thread gather coordinates (fixed for the whole K loop) ----
   const int a_c4 = tid & 3;    // which 16-byte group of the 16-channel chunk
@@ -118,8 +124,21 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
     a_wi0[r] = wo * p.stride - p.pad;
   }
 
-  // K-tile iterator state: (tap kh,kw) x (source s) x (chunk c)
-  int it_kh = 0, it_kw = 0, it_s = 0, it_c = 0;
+  // K-tile iterator state: (tap kh,kw) x (source s) x (chunk c), positioned at kt_begin
+  int it_kh, it_kw, it_s = 0, it_c;
+  {
+    const int tap = kt_begin / p.chunks_total;
+    int r = kt_begin - tap * p.chunks_total;
+    it_kh = tap / p.KW;
+    it_kw = tap - it_kh * p.KW;
+#pragma unroll
+    for (int q = 0; q < HRV_MAX_SRC - 1; ++q)
+      if (it_s == q && q < p.nsrc - 1 && r >= p.src[q].chunks) {
+        r -= p.src[q].chunks;
+        ++it_s;
+      }
+    it_c = r;
+  }
 
   f32x4 a_reg[AR];
   f32x4 b_reg[BR];
@@ -232,14 +251,14 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
 
   f32x4 fa[2][TM], fb[2][TN];
 
-  // prologue: fetch + stage K-tile 0
-  HRV_LOAD_TILE(0)
+  // prologue: fetch + stage the first K-tile of this block's range
+  HRV_LOAD_TILE(kt_begin)
   HRV_ADVANCE_ITER()
-  HRV_STORE_TILE(0)
+  HRV_STORE_TILE(kt_begin & 1)
   __syncthreads();
 
   // steady state: tile kt is multiplied while tile kt+1 travels global -> regs -> LDS
-  for (int kt = 0; kt < p.KT - 1; ++kt) {
+  for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
     if (PIPE) {
       HRV_READ_FRAGS(kt & 1)
       HRV_LOAD_TILE(kt + 1)
@@ -263,7 +282,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
     __syncthreads();
   }
   // last tile: nothing left to fetch
-  HRV_READ_FRAGS((p.KT - 1) & 1)
+  HRV_READ_FRAGS((kt_end - 1) & 1)
   HRV_MMA_FRAGS()
 
 #undef HRV_LOAD_TILE
@@ -273,6 +292,36 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
 #undef HRV_MMA1
 #undef HRV_MMA_FRAGS
 
+  if (p.splitk > 1) {
+    // raw partial sums -> workspace; hrv::splitk_reduce_kernel applies the epilogue
+    float* wsp = p.ws + (size_t)ks * p.M * p.CoutPad;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        if (SWAP) {
+          const int pidx = m0 + (wm * TM + i) * 32 + l31;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh;
+            if (pidx < p.M) {
+              f32x4 v;
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e];
+              *reinterpret_cast<f32x4*>(wsp + (size_t)pidx * p.CoutPad + c0) = v;
+            }
+          }
+        } else {
+          const int c = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const int pidx = m0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+            if (pidx < p.M) wsp[(size_t)pidx * p.CoutPad + c] = acc[i][j][e];
+          }
+        }
+      }
+    return;
+  }
   // ---- fused epilogue: out = act(acc * scale[c] + shift[c] + residual)
   if (!SWAP) {
     // D layout: col = lane&31 (cout), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (pixel)
@@ -393,6 +442,42 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
   }
 }
 
+// Split-K second stage: fixed-order sum of the partial tiles + the standard epilogue.
+__global__ void splitk_reduce_kernel(const ConvParams p) {
+  const int C4 = (p.Cout + 3) / 4;
+  const size_t total = (size_t)p.M * C4;
+  for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+       idx += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(idx % C4);
+    const int pidx = (int)(idx / C4);
+    f32x4 v = (f32x4)(0.f);
+    for (int s = 0; s < p.splitk; ++s)
+      v += *reinterpret_cast<const f32x4*>(p.ws + ((size_t)s * p.M + pidx) * p.CoutPad + g * 4);
+    int on = 0, oh = 0, ow = 0;
+    if (p.out_up) {
+      on = pidx / (p.Ho * p.Wo);
+      const int rem = pidx - on * (p.Ho * p.Wo);
+      oh = rem / p.Wo;
+      ow = rem - oh * p.Wo;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int c = g * 4 + e;
+      if (c >= p.Cout) break;
+      float t = v[e] * (p.scale ? p.scale[c] : 1.f) + (p.shift ? p.shift[c] : 0.f);
+      if (p.res) t += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
+      t = apply_act(t, p.act, p.slope);
+      if (!p.out_up) {
+        p.out[(size_t)pidx * p.out_cs + p.out_co + c] = t;
+      } else {
+        float* o = p.out + (((size_t)on * 2 * p.Ho + 2 * oh) * 2 * p.Wo + 2 * ow) * p.out_cs + p.out_co + c;
+        o[0] = t; o[p.out_cs] = t;
+        o[(size_t)2 * p.Wo * p.out_cs] = t; o[(size_t)2 * p.Wo * p.out_cs + p.out_cs] = t;
+      }
+    }
+  }
+}
+
 // One thread per output element, raw OIHW weights: a device-side cross-check.
 __global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restrict__ w, int Cin_real_total,
                                       const int* __restrict__ real_c /*[nsrc]*/) {
@@ -454,6 +539,16 @@ constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 static int cfg_bm(int c) { return 32 * kCfgs[c].TM * kCfgs[c].WM; }
 static int cfg_bn(int c) { return 32 * kCfgs[c].TN * kCfgs[c].WN; }
+
+// Split-K factor for a launch that would otherwise leave most of the 256 CUs idle
+// (tocg levels 3-4 and the generator's 8x6..32x24 blocks: few pixels, K up to 9360).
+static int pick_splitk(int nblk, int KT, bool allowed) {
+  if (!allowed || nblk >= 192 || KT < 16) return 1;
+  int s = (512 + nblk - 1) / nblk;
+  if (s > 32) s = 32;
+  if (s > KT / 8) s = KT / 8;
+  return s < 2 ? 1 : s;
+}
 
 static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   HRV_REQUIRE(d != nullptr, "conv2d: null descriptor");
@@ -533,6 +628,21 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
     p.n_tiles = (d->Cout + bn - 1) / bn;
     p.CoutPad = p.n_tiles * bn;
     p.m_tiles = (p.M + bm - 1) / bm;
+    p.splitk = 1;
+    const char* ev = getenv("HRV_CONV_SPLITK");   // 0 disables, N forces (A/B measurements)
+    int want = pick_splitk(p.m_tiles * p.n_tiles, p.KT, d->spade == nullptr);
+    if (ev) want = atoi(ev) > 0 ? atoi(ev) : 1;
+    if (d->spade) want = 1;
+    if (want > p.KT) want = p.KT;
+    if (want > 1) {
+      const int64_t need = (int64_t)want * p.M * p.CoutPad * (int64_t)sizeof(float);
+      if (d->workspace && d->workspace_bytes >= need && (((uintptr_t)d->workspace) & 15) == 0) {
+        p.splitk = want;
+        p.ws = (float*)d->workspace;
+      }  // no/too small workspace: run unsplit (correct, slower)
+    }
+  } else {
+    p.splitk = 1;
   }
   return HRV_OK;
 }
@@ -542,7 +652,7 @@ constexpr int kDefaultVariant = 1;
 
 template <int TM, int TN, int WM, int WN>
 static int launch_cfg(const ConvParams& p, hipStream_t st) {
-  const int nblk = p.m_tiles * p.n_tiles;
+  const int nblk = p.m_tiles * p.n_tiles * p.splitk;
   const char* ev = getenv("HRV_CONV_VARIANT");
   int var = ev ? atoi(ev) : kDefaultVariant;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
@@ -560,7 +670,12 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
     case 3: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 3>), dim3(nblk), dim3(256), 0, st, p); break;
     default: set_error("conv2d: HRV_CONV_VARIANT=%d invalid", var); return HRV_ERR_ARG;
   }
-  return check_launch("conv_f32_mfma_kernel");
+  int rc = check_launch("conv_f32_mfma_kernel");
+  if (rc || p.splitk <= 1) return rc;
+  const size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
+  const size_t gsz = (total + 255) / 256;
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(gsz > 4096 ? 4096 : gsz)), dim3(256), 0, st, p);
+  return check_launch("splitk_reduce_kernel");
 }
 
 }  // namespace hrv
@@ -634,6 +749,22 @@ extern "C" int hrv_conv2d_pack_weight_f32(const float* w, int32_t Cout, int32_t 
       }
     }
   return HRV_OK;
+}
+
+extern "C" int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d) {
+  if (!d || d->tile_cfg < 0 || d->tile_cfg >= kNumCfgs || d->spade) return 0;
+  const int bm = cfg_bm(d->tile_cfg), bn = cfg_bn(d->tile_cfg);
+  const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
+  const int n_tiles = (d->Cout + bn - 1) / bn;
+  const int m_tiles = (int)((M + bm - 1) / bm);
+  int chunks = 0;
+  for (int i = 0; i < d->nsrc && i < HRV_MAX_SRC; ++i) chunks += (d->src[i].C + BK - 1) / BK;
+  const int KT = d->KH * d->KW * chunks;
+  const char* ev = getenv("HRV_CONV_SPLITK");
+  int s = pick_splitk(m_tiles * n_tiles, KT, true);
+  if (ev) s = atoi(ev) > 0 ? atoi(ev) : 1;
+  if (s > KT) s = KT;
+  return s > 1 ? (int64_t)s * M * n_tiles * bn * (int64_t)sizeof(float) : 0;
 }
 
 extern "C" int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {

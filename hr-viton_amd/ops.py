@@ -130,6 +130,20 @@ class _Timed:
         return False
 
 
+_WS = {}
+
+
+def _workspace(device, nbytes: int) -> torch.Tensor:
+    """Per-device split-K scratch (stream-ordered reuse: every conv launch on the stream finishes
+    reading it before the next one writes)."""
+    key = str(device)
+    t = _WS.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)
+        _WS[key] = t
+    return t
+
+
 SrcSpec = Union[Act, Tuple[Act, int, int]]  # Act or (Act, up_shift, pre_act)
 
 
@@ -231,6 +245,11 @@ class ConvLayer:
         d.out_up_shift = out_up
         if spade is not None:
             d.spade = C.pointer(spade)
+        if not naive and spade is None:
+            need = lib.hrv_conv2d_workspace_bytes(C.byref(d))
+            if need > 0:
+                ws = _workspace(a0.t.device, need)
+                d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else lib.hrv_conv2d_nhwc_f32
         with _Timed("conv", self.name, self.flops(N, Ho, Wo), 0):
             _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")

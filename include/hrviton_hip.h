@@ -122,6 +122,8 @@ typedef struct hrv_conv2d {
                            follows each SPADEResBlock (network_generator.py:226-
                            241) fused into the producer's store; 0: plain      */
   int32_t _pad2;
+  void* workspace;          /* optional scratch for split-K (small-M / large-K layers):   */
+  int64_t workspace_bytes;  /* >= hrv_conv2d_workspace_bytes(d); NULL => run unsplit     */
 } hrv_conv2d_t;
 
 /* Tile configuration for (M = N*Ho*Wo output pixels, Cout): returns cfg id. */
@@ -141,6 +143,10 @@ int64_t hrv_conv2d_packed_elems(int32_t Cout, int32_t KH, int32_t KW, int32_t ns
 int hrv_conv2d_pack_weight_f32(const float* w_oihw, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
                                const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
                                float* out);
+/* Scratch the engine would like for this launch (0: none).  Layers with fewer than
+ * ~192 output tiles split their K range over up to 32 blocks per tile (partials in
+ * the workspace, fixed-order reduction + epilogue in a second kernel: deterministic). */
+int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d);
 int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
 /* Same contract, one thread per output element, raw OIHW weights.  A device
  * side cross-check used by the tests to localise faults; never on the product

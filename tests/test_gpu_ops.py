@@ -265,3 +265,25 @@ def test_tapconv_small_cout(real, H, W):
     out = ops.Act(torch.empty((N, H, W, 2), device="cuda"), 2)
     layer([_nhwc(ops, x) for x in xs], out=out, residual=ops.Act(res.cuda().contiguous(), 2))
     _assert_close("tapconv", out.t.cpu(), want, 2e-5)
+
+
+@pytest.mark.parametrize("splitk", [0, 2, 5])
+def test_conv_split_k(splitk):
+    """Small-M / large-K layers split their K range over several blocks (deterministic 2-stage)."""
+    ops = _ops()
+    old = os.environ.get("HRV_CONV_SPLITK")
+    os.environ["HRV_CONV_SPLITK"] = str(splitk)
+    try:
+        for case in (CONV_CASES[2], CONV_CASES[4], CONV_CASES[5], CONV_CASES[9], CONV_CASES[3]):
+            for variant in (0, 1):
+                os.environ["HRV_CONV_VARIANT"] = str(variant)
+                got, ref = _run_conv_case(ops, case, "mfma")
+                _assert_close(f"conv_splitk{splitk}_v{variant}_" + case[0], got, ref, 2e-5)
+                got2, _ = _run_conv_case(ops, case, "mfma")
+                assert torch.equal(got, got2), "split-K must be deterministic"
+    finally:
+        os.environ.pop("HRV_CONV_VARIANT", None)
+        if old is None:
+            os.environ.pop("HRV_CONV_SPLITK", None)
+        else:
+            os.environ["HRV_CONV_SPLITK"] = old
