@@ -543,8 +543,9 @@ static int cfg_bn(int c) { return 32 * kCfgs[c].TN * kCfgs[c].WN; }
 // Split-K factor for a launch that would otherwise leave most of the 256 CUs idle
 // (tocg levels 3-4 and the generator's 8x6..32x24 blocks: few pixels, K up to 9360).
 static int pick_splitk(int nblk, int KT, bool allowed) {
-  if (!allowed || nblk >= 192 || KT < 16) return 1;
-  int s = (512 + nblk - 1) / nblk;
+  // target >= 4 blocks per CU: below that the 4-wave blocks cannot hide each other's barriers
+  if (!allowed || nblk >= 768 || KT < 16) return 1;
+  int s = (1024 + nblk - 1) / nblk;
   if (s > 32) s = 32;
   if (s > KT / 8) s = KT / 8;
   return s < 2 ? 1 : s;

@@ -122,8 +122,10 @@ def test_tocg_full_size_properties():
         assert torch.equal(x, y), "non-deterministic"
         assert torch.isfinite(x).all()
     c = m(opt, torch.cat([i1, i1]), torch.cat([i2, i2]))
-    assert torch.equal(c[1][0], a[1][0]) and torch.equal(c[1][1], a[1][0])
-    assert torch.equal(c[0][-1][1], a[0][-1][0])
+    # the two copies inside one batch are bitwise equal; vs the batch-1 run only the split-K
+    # factor of the small layers may differ (it depends on M), i.e. fp32 reassociation
+    assert torch.equal(c[1][0], c[1][1]) and torch.equal(c[0][-1][0], c[0][-1][1])
+    assert _rel(c[1][0], a[1][0]) < 1e-4 and _rel(c[0][-1][1], a[0][-1][0]) < 1e-4
     assert a[1].shape == (1, 13, 1024, 768) and a[0][-1].shape == (1, 512, 384, 2)
     assert a[3].min() >= 0.0 and a[3].max() <= 1.0          # warped mask stays in [0,1]
     assert a[2].min() >= i1[:, :3].min() - 1e-6 and a[2].max() <= i1[:, :3].max() + 1e-6

@@ -26,7 +26,9 @@ def main():
         "COMBOS", "1:0,1:1,1:3,2:0,2:1,2:3,0:1,7:1").split(","))]
     rounds = int(os.environ.get("ROUNDS", "5"))
     g = torch.Generator().manual_seed(0)
-    for name, cins, cout, k, stride, pad, N, H, W, res in LAYERS:
+    sel = os.environ.get("LAYER_IDX")
+    layers = LAYERS if sel is None else [LAYERS[int(i)] for i in sel.split(",")]
+    for name, cins, cout, k, stride, pad, N, H, W, res in layers:
         xs = [ops.to_nhwc(torch.randn(N, c, H, W, generator=g).cuda()) for c in cins]
         w = torch.randn(cout, sum(cins), k, k, generator=g) * 0.05
         sc = torch.rand(cout, generator=g) + 0.5
