@@ -110,9 +110,19 @@ def main():
     other_bytes = sum(r[3] for r in recs if r[0] != "conv")
     achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     top = sorted(conv, key=lambda r: -r[4])[:5]
+    # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC
+    # passes of this same command (profiles/, see tools/profile_pmc.sh), per conv launch.
+    traffic, traffic_src = None, None
+    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp):
+        with open(tp) as f:
+            tj = json.load(f)
+        traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
     roofline = {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel (all tile configs)",
                 "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                "traffic_unit": "HBM bytes per conv launch (average over the step's launches)", "traffic_source": traffic_src,
+                "algorithmic_flops_per_launch": conv_flops / max(1, len(conv)),
                 "launches_per_step": len(conv), "flops_per_step": conv_flops,
                 "conv_ms_per_step": round(conv_ms, 3),
                 "hbm_kernels_ms_per_step": round(other_ms, 3),
