@@ -35,7 +35,10 @@ class hrv_conv2d_t(C.Structure):
                 ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
                 ("spade", C.POINTER(hrv_spade_epi_t)), ("out_up_shift", C.c_int32), ("_pad2", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("pad_w_plus1", C.c_int32), ("free_extent", C.c_int32), ("out_step", C.c_int32),
+                ("out_off_h", C.c_int32), ("out_off_w", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32),
+                ("res_mode", C.c_int32)]
 
 
 class hrv_flow_warp_t(C.Structure):
@@ -58,6 +61,13 @@ SYMBOLS = {
     "hrv_conv2d_tile_bm": (C.c_int, [_i32]),
     "hrv_conv2d_packed_elems": (_i64, [_i32, _i32, _i32, _i32, _ip, _i32]),
     "hrv_conv2d_pack_weight_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _vp]),
+    "hrv_conv2d_pack_weight_dev_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _i32, _i32, _i32,
+                                                 _i32, _f, _vp, _ip, _vp]),
+    "hrv_conv2d_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i64]),
+    "hrv_conv2d_wgrad_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                            _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32,
+                                            _vp]),
+    "hrv_colsum_nhwc_f32": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hrv_conv2d_workspace_bytes": (_i64, [C.POINTER(hrv_conv2d_t)]),
     "hrv_conv2d_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
     "hrv_conv2d_naive_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),

@@ -1,0 +1,428 @@
+// Training-side convolution kernels (NHWC fp32, gfx950 MFMA):
+//   * device-side weight packing for the forward / data-gradient engine (weights change
+//     every optimiser step, so the host packer is only for frozen/inference weights);
+//   * weight gradient  dW[co][ci][kh][kw] = sum_p dY[p][co] * Xgather[p][kh,kw][ci]
+//     as an MFMA GEMM whose reduction dimension is the pixel index, split over pixel
+//     slabs with a fixed-order second stage (deterministic);
+//   * bias gradient (column sums of dY).
+// The data gradient itself is the forward engine (conv_f32.hip) run on dY with
+// transposed / flipped (and, for stride 2, per-phase) weights packed here.
+#include <stdlib.h>
+#include <string.h>
+
+#include "hrv_common.h"
+
+namespace hrv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int BK = 16;
+
+// ------------------------------------------------------------------ device pack
+struct PackParams {
+  const float* w;  // [Cout][CinTot][KH][KW]
+  int Cout, CinTot, KH, KW;
+  int transposed;  // 0: rows = cout, k runs over the sources' input channels (forward)
+                   // 1: rows = cin,  k runs over cout (data gradient: one "source" of Cout channels)
+  int nsrc;
+  int src_cpad[HRV_MAX_SRC], src_creal[HRV_MAX_SRC], src_cbase[HRV_MAX_SRC], src_chunk0[HRV_MAX_SRC];
+  int chunks_total;
+  int KHp, KWp;          // packed tap grid
+  int kh_of[8], kw_of[8];  // packed tap -> weight tap (or -1: absent)
+  int rows, rows_pad;    // output rows (Cout or CinTot) and their padded count
+  float wscale;
+  float* out;            // [KHp*KWp*chunks_total][rows_pad][16]
+};
+
+__global__ void pack_weight_kernel(const PackParams p) {
+  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % BK);
+    const size_t t = i / BK;
+    const int row = (int)(t % p.rows_pad);
+    const int kt = (int)(t / p.rows_pad);
+    const int tap = kt / p.chunks_total, chunk = kt - tap * p.chunks_total;
+    const int jh = tap / p.KWp, jw = tap - jh * p.KWp;
+    const int kh = p.kh_of[jh], kw = p.kw_of[jw];
+    float v = 0.f;
+    if (row < p.rows && kh >= 0 && kw >= 0) {
+      int s = 0;
+#pragma unroll
+      for (int q = 1; q < HRV_MAX_SRC; ++q)
+        if (q < p.nsrc && chunk >= p.src_chunk0[q]) s = q;
+      const int c = (chunk - p.src_chunk0[s]) * BK + k;  // channel within source s
+      if (c < p.src_creal[s]) {
+        const int cc = p.src_cbase[s] + c;
+        const int co = p.transposed ? cc : row;
+        const int ci = p.transposed ? row : cc;
+        v = p.w[(((size_t)co * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * p.wscale;
+      }
+    }
+    p.out[i] = v;
+  }
+}
+
+// ------------------------------------------------------------------ wgrad
+struct WgradParams {
+  const float* dy;
+  int dy_cs, dy_co, Cout;
+  const float* x;
+  int x_C, x_cs, x_co, x_up;  // source channels (padded to 4), stride, offset, nearest shift
+  int N, H, W, Ho, Wo, KH, KW, stride, pad;
+  int P;            // N*Ho*Wo
+  int ci_base;      // position of this source on the weight's Cin axis
+  int ci_real;      // real channels of this source (<= x_C)
+  int CinTot;
+  int co_tiles, ci_tiles, taps, S;
+  float* ws;        // [S][taps][Cout][CinTot]  (only this source's ci range is written)
+};
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams p) {
+  constexpr int BMc = 32 * TM * WM;  // couts per block
+  constexpr int BNc = 32 * TN * WN;  // cins per block
+  constexpr int LY = BMc + 4, LX = BNc + 4;
+  constexpr int YR = (BK * BMc / 4 + 255) / 256;  // float4 loads of dY per thread per pixel tile
+  constexpr int XR = (BK * BNc / 4 + 255) / 256;
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * (LY + LX)];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  int b = blockIdx.x;
+  const int s = b % p.S; b /= p.S;
+  const int tap = b % p.taps; b /= p.taps;
+  const int it = b % p.ci_tiles;
+  const int ct = b / p.ci_tiles;
+  const int kh = tap / p.KW, kw = tap - kh * p.KW;
+  const int co0 = ct * BMc, ci0 = it * BNc;
+
+  const int ptiles = (p.P + BK - 1) / BK;
+  const int t_begin = (int)(((long long)ptiles * s) / p.S);
+  const int t_end = (int)(((long long)ptiles * (s + 1)) / p.S);
+
+  const int sr = p.x_up > 0 ? p.x_up : 0, sl = p.x_up < 0 ? -p.x_up : 0;
+  const int Hs = (p.H >> sr) << sl, Ws = (p.W >> sr) << sl;
+
+  f32x4 yreg[YR], xreg[XR];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define WG_LOAD(T)                                                                                        \
+  {                                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < YR; ++r) {                                                      \
+      const int idx = tid + 256 * r;                                                                      \
+      const int row = idx / (BMc / 4), c4 = idx - row * (BMc / 4);                                        \
+      const int pix = (T)*BK + row;                                                                       \
+      const int c = co0 + c4 * 4;                                                                         \
+      const bool ok = idx < BK * BMc / 4 && pix < p.P && c < p.Cout;                                      \
+      const size_t off = ok ? (size_t)pix * p.dy_cs + p.dy_co + c : (size_t)p.dy_co;                      \
+      f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + off);                                              \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = (ok && c + e < p.Cout) ? v[e] : 0.f;           \
+      yreg[r] = v;                                                                                        \
+    }                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r) {                                                      \
+      const int idx = tid + 256 * r;                                                                      \
+      const int row = idx / (BNc / 4), c4 = idx - row * (BNc / 4);                                        \
+      const int pix = (T)*BK + row;                                                                       \
+      const int pp = pix < p.P ? pix : 0;                                                                 \
+      const int n = pp / (p.Ho * p.Wo);                                                                   \
+      const int rem = pp - n * (p.Ho * p.Wo);                                                             \
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;                                                    \
+      const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;                         \
+      const int c = ci0 + c4 * 4;                                                                         \
+      const bool ok = idx < BK * BNc / 4 && pix < p.P && c < p.x_C && (unsigned)hi < (unsigned)p.H &&     \
+                      (unsigned)wi < (unsigned)p.W;                                                       \
+      const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);                           \
+      const size_t off = ((size_t)(n * Hs + ((hic >> sr) << sl)) * Ws + ((wic >> sr) << sl)) * p.x_cs +   \
+                         p.x_co + (c < p.x_C ? c : 0);                                                    \
+      f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                               \
+      _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                               \
+      xreg[r] = v;                                                                                        \
+    }                                                                                                     \
+  }
+
+#define WG_STORE(BUF)                                                                       \
+  {                                                                                         \
+    float* Ys = smem + (BUF)*BK * (LY + LX);                                                \
+    float* Xs = Ys + BK * LY;                                                               \
+    _Pragma("unroll") for (int r = 0; r < YR; ++r) {                                        \
+      const int idx = tid + 256 * r;                                                        \
+      const int row = idx / (BMc / 4), c4 = idx - row * (BMc / 4);                          \
+      if (idx < BK * BMc / 4) *reinterpret_cast<f32x4*>(Ys + row * LY + c4 * 4) = yreg[r];  \
+    }                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < XR; ++r) {                                        \
+      const int idx = tid + 256 * r;                                                        \
+      const int row = idx / (BNc / 4), c4 = idx - row * (BNc / 4);                          \
+      if (idx < BK * BNc / 4) *reinterpret_cast<f32x4*>(Xs + row * LX + c4 * 4) = xreg[r];  \
+    }                                                                                       \
+  }
+
+#define WG_MMA(BUF)                                                                                   \
+  {                                                                                                   \
+    const float* Ys = smem + (BUF)*BK * (LY + LX) + wm * TM * 32 + l31;                               \
+    const float* Xs = smem + (BUF)*BK * (LY + LX) + BK * LY + wn * TN * 32 + l31;                     \
+    _Pragma("unroll") for (int kk = 0; kk < BK / 2; ++kk) {                                           \
+      float a[TM], bb[TN];                                                                            \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) a[i] = Ys[(2 * kk + lh) * LY + i * 32];          \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) bb[j] = Xs[(2 * kk + lh) * LX + j * 32];         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                  \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                              \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i], bb[j], acc[i][j], 0, 0, 0);      \
+    }                                                                                                 \
+  }
+
+  if (t_begin < t_end) {
+    WG_LOAD(t_begin)
+    WG_STORE(t_begin & 1)
+    __syncthreads();
+    for (int t = t_begin; t < t_end - 1; ++t) {
+      WG_LOAD(t + 1)
+      WG_MMA(t & 1)
+      WG_STORE((t + 1) & 1)
+      __syncthreads();
+    }
+    WG_MMA((t_end - 1) & 1)
+  }
+#undef WG_LOAD
+#undef WG_STORE
+#undef WG_MMA
+
+  // D[i = cout][j = cin]: col = lane&31 (cin), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
+  float* wsp = p.ws + ((size_t)s * p.taps + tap) * p.Cout * p.CinTot;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ci = ci0 + (wn * TN + j) * 32 + l31;
+    if (ci >= p.ci_real) continue;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+        if (co < p.Cout) wsp[(size_t)co * p.CinTot + p.ci_base + ci] = acc[i][j][e];
+      }
+  }
+}
+
+// dW[co][ci][tap] (torch OIHW) (+)= sum_s ws[s][tap][co][ci], for ci in [ci_base, ci_base+ci_real)
+__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int taps, int Cout, int CinTot, int ci_base,
+                                    int ci_real, float* __restrict__ dw, int accumulate) {
+  const size_t total = (size_t)Cout * ci_real * taps;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int ci = (int)(i % ci_real);
+    const size_t t = i / ci_real;
+    const int tap = (int)(t % taps);
+    const int co = (int)(t / taps);
+    float sum = 0.f;
+    for (int s = 0; s < S; ++s) sum += ws[(((size_t)s * taps + tap) * Cout + co) * CinTot + ci_base + ci];
+    float* dst = dw + ((size_t)co * CinTot + ci_base + ci) * taps + tap;
+    *dst = accumulate ? *dst + sum : sum;
+  }
+}
+
+// ------------------------------------------------------------------ column sums (bias gradient)
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int P, int C4, int cs, int co,
+                                                             int NB, float* __restrict__ part) {
+  __shared__ f32x4 red[256];
+  const int b = blockIdx.x, t = threadIdx.x;
+  const int PB = (P + NB - 1) / NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, P);
+  const int GB = C4 < 256 ? C4 : 256;
+  const int R = 256 / GB;
+  const int r = t / GB, gl = t - r * GB;
+  for (int g0 = 0; g0 < C4; g0 += GB) {
+    const int g = g0 + gl;
+    f32x4 s1 = (f32x4)(0.f);
+    if (r < R && g < C4)
+      for (int px = p0 + r; px < p1; px += R) s1 += *reinterpret_cast<const f32x4*>(x + (size_t)px * cs + co + g * 4);
+    red[t] = s1;
+    __syncthreads();
+    if (r == 0 && g < C4) {
+      for (int rr = 1; rr < R; ++rr) s1 += red[rr * GB + gl];
+      *reinterpret_cast<f32x4*>(part + ((size_t)b * C4 + g) * 4) = s1;
+    }
+    __syncthreads();
+  }
+}
+
+__global__ void colsum_final_kernel(const float* __restrict__ part, int NB, int C, int Cpad, float* __restrict__ out,
+                                    int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int b = 0; b < NB; ++b) s += (double)part[(size_t)b * Cpad + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+static inline int grid_for(size_t work, int block = 256) {
+  size_t g = (work + block - 1) / block;
+  const size_t cap = 256 * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+struct WTile { int TM, TN, WM, WN; };
+// wgrad tiles: (couts x cins) per block
+static const WTile kWTiles[] = {{2, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {3, 1, 1, 4}};  // 128x128, 64x64, 128x32, 96x128
+static int wt_bm(int i) { return 32 * kWTiles[i].TM * kWTiles[i].WM; }
+static int wt_bn(int i) { return 32 * kWTiles[i].TN * kWTiles[i].WN; }
+
+static int pick_wtile(int Cout, int Cin) {
+  if (Cin <= 32) return 2;
+  if (Cout <= 64 && Cin <= 64) return 1;
+  if (Cout % 128 != 0 && Cout % 96 == 0) return 3;
+  return 0;
+}
+
+}  // namespace hrv
+
+using namespace hrv;
+
+extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW,
+                                              int32_t nsrc, const int32_t* srcC, const int32_t* srcC_real,
+                                              int32_t tile_cfg, int32_t mode, int32_t stride, int32_t pad,
+                                              int32_t phase_a, int32_t phase_b, float wscale, float* out_dev,
+                                              int32_t* out_geom, hrv_stream_t stream) {
+  HRV_REQUIRE(w_oihw_dev && out_dev && srcC && srcC_real && nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_dev: bad args");
+  const int bn = hrv_conv2d_tile_bn(tile_cfg);
+  HRV_REQUIRE(bn > 0, "pack_dev: bad tile_cfg %d", tile_cfg);
+  HRV_REQUIRE(mode >= 0 && mode <= 2, "pack_dev: mode must be 0 (forward), 1 (dgrad stride 1), 2 (dgrad stride-2 phase)");
+  HRV_REQUIRE(KH <= 8 && KW <= 8, "pack_dev: kernel too large");
+  PackParams p;
+  memset(&p, 0, sizeof(p));
+  p.w = w_oihw_dev; p.Cout = Cout; p.KH = KH; p.KW = KW; p.wscale = wscale; p.out = out_dev;
+  int cin = 0;
+  for (int i = 0; i < nsrc; ++i) cin += srcC_real[i];
+  p.CinTot = cin;
+  int geom_pad_h = pad, geom_pad_w = pad;
+  if (mode == 0) {
+    p.transposed = 0; p.nsrc = nsrc; p.rows = Cout;
+    int chunk0 = 0, cbase = 0;
+    for (int i = 0; i < nsrc; ++i) {
+      HRV_REQUIRE(srcC[i] % 4 == 0 && srcC_real[i] > 0 && srcC_real[i] <= srcC[i], "pack_dev: channel counts");
+      p.src_cpad[i] = srcC[i]; p.src_creal[i] = srcC_real[i]; p.src_cbase[i] = cbase; p.src_chunk0[i] = chunk0;
+      chunk0 += (srcC[i] + BK - 1) / BK; cbase += srcC_real[i];
+    }
+    p.chunks_total = chunk0; p.KHp = KH; p.KWp = KW;
+    for (int j = 0; j < KH; ++j) p.kh_of[j] = j;
+    for (int j = 0; j < KW; ++j) p.kw_of[j] = j;
+  } else {
+    // data gradient: the conv runs over dY (one source of Cout channels), rows are the Cin axis
+    p.transposed = 1; p.nsrc = 1; p.rows = cin;
+    p.src_cpad[0] = (Cout + 3) / 4 * 4; p.src_creal[0] = Cout; p.src_cbase[0] = 0; p.src_chunk0[0] = 0;
+    p.chunks_total = (p.src_cpad[0] + BK - 1) / BK;
+    if (mode == 1) {
+      HRV_REQUIRE(stride == 1, "pack_dev: mode 1 is the stride-1 data gradient");
+      p.KHp = KH; p.KWp = KW;
+      for (int j = 0; j < KH; ++j) p.kh_of[j] = KH - 1 - j;
+      for (int j = 0; j < KW; ++j) p.kw_of[j] = KW - 1 - j;
+      geom_pad_h = KH - 1 - pad; geom_pad_w = KW - 1 - pad;
+    } else {
+      HRV_REQUIRE(stride == 2 && phase_a >= 0 && phase_a < 2 && phase_b >= 0 && phase_b < 2, "pack_dev: mode 2 phase");
+      // dX[2h'+a] = sum_j dY[h' + j] * W[a + pad - 2j]  for the j with a valid tap
+      auto build = [&](int a, int K, int* of, int& Kp, int& padp) {
+        int jmin = 0, jmax = -1;
+        bool any = false;
+        for (int j = -8; j <= 8; ++j) {
+          const int k = a + pad - 2 * j;
+          if (k >= 0 && k < K) { if (!any) { jmin = j; any = true; } jmax = j; }
+        }
+        Kp = any ? jmax - jmin + 1 : 1;
+        padp = any ? -jmin : 0;
+        for (int jj = 0; jj < Kp; ++jj) {
+          const int k = a + pad - 2 * (jj + jmin);
+          of[jj] = (any && k >= 0 && k < K) ? k : -1;
+        }
+      };
+      build(phase_a, KH, p.kh_of, p.KHp, geom_pad_h);
+      build(phase_b, KW, p.kw_of, p.KWp, geom_pad_w);
+    }
+  }
+  p.rows_pad = (p.rows + bn - 1) / bn * bn;
+  if (out_geom) {  // {KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, packed elems}
+    out_geom[0] = p.KHp; out_geom[1] = p.KWp; out_geom[2] = geom_pad_h; out_geom[3] = geom_pad_w;
+    out_geom[4] = p.rows; out_geom[5] = p.rows_pad; out_geom[6] = p.chunks_total;
+    out_geom[7] = p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  }
+  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
+  return check_launch("pack_weight_kernel");
+}
+
+extern "C" int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P) {
+  // upper bound on S is 256 slabs
+  const int64_t ptiles = (P + BK - 1) / BK;
+  int64_t S = ptiles / 4 < 1 ? 1 : ptiles / 4;
+  if (S > 256) S = 256;
+  return S * KH * KW * (int64_t)Cout * CinTot * (int64_t)sizeof(float);
+}
+
+extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+                                         const float* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
+                                         int32_t x_up_shift, int32_t x_C_real, int32_t ci_base, int32_t CinTot,
+                                         int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
+                                         int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes,
+                                         float* dw_oihw, int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(dy && x && workspace && dw_oihw, "wgrad: null pointer");
+  HRV_REQUIRE(Cout > 0 && x_C > 0 && x_C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 && dy_cstride % 4 == 0 &&
+                  dy_coff % 4 == 0 && x_C_real > 0 && x_C_real <= x_C && ci_base >= 0 && ci_base + x_C_real <= CinTot,
+              "wgrad: channel layout");
+  HRV_REQUIRE(N > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0, "wgrad: geometry");
+  HRV_REQUIRE((((uintptr_t)dy | (uintptr_t)x | (uintptr_t)workspace) & 15) == 0, "wgrad: 16-byte alignment");
+  HRV_REQUIRE(dy_coff + Cout <= dy_cstride + 3, "wgrad: dy slice");
+  WgradParams p;
+  p.dy = dy; p.dy_cs = dy_cstride; p.dy_co = dy_coff; p.Cout = Cout;
+  p.x = x; p.x_C = x_C; p.x_cs = x_cstride; p.x_co = x_coff; p.x_up = x_up_shift;
+  p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
+  p.P = N * Ho * Wo; p.ci_base = ci_base; p.ci_real = x_C_real; p.CinTot = CinTot;
+  const int wt = pick_wtile(Cout, x_C);
+  const int bm = wt_bm(wt), bn = wt_bn(wt);
+  p.co_tiles = (Cout + bm - 1) / bm; p.ci_tiles = (x_C + bn - 1) / bn; p.taps = KH * KW;
+  const int tiles = p.co_tiles * p.ci_tiles * p.taps;
+  const int ptiles = (p.P + BK - 1) / BK;
+  int S = (1024 + tiles - 1) / tiles;
+  if (S > ptiles / 4) S = ptiles / 4;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  const int64_t need = (int64_t)S * p.taps * Cout * CinTot * (int64_t)sizeof(float);
+  HRV_REQUIRE(workspace_bytes >= need, "wgrad: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
+  p.S = S; p.ws = workspace;
+  hipStream_t st = (hipStream_t)stream;
+  const int nblk = tiles * S;
+  switch (wt) {
+    case 0: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2, 2, 2, 2>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+    default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3, 1, 1, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+  }
+  int rc = check_launch("conv_wgrad_mfma_kernel");
+  if (rc) return rc;
+  const size_t total = (size_t)Cout * x_C_real * p.taps;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, workspace, S, p.taps, Cout, CinTot,
+                     ci_base, x_C_real, dw_oihw, accumulate);
+  return check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,
+                                   int64_t workspace_bytes, float* out, int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(x && workspace && out && P > 0 && C > 0, "colsum: bad args");
+  HRV_REQUIRE(cstride % 4 == 0 && coff % 4 == 0 && coff + C <= cstride + 3 && (((uintptr_t)x | (uintptr_t)workspace) & 15) == 0,
+              "colsum: layout");
+  const int Cpad = (C + 3) / 4 * 4;
+  HRV_REQUIRE(coff + Cpad <= cstride, "colsum: padded channel group must lie inside the pixel row");
+  int nb = (int)((P + 1023) / 1024);
+  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  HRV_REQUIRE(workspace_bytes >= (int64_t)nb * Cpad * 4, "colsum: workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3(nb), dim3(256), 0, st, x, (int)P, Cpad / 4, cstride, coff, nb, workspace);
+  int rc = check_launch("colsum_partial_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, nb, C, Cpad, out, accumulate);
+  return check_launch("colsum_final_kernel");
+}

@@ -62,7 +62,10 @@ struct ConvParams {
   int out_cs, out_co;
   int splitk;  // >1: K range split over `splitk` blocks per tile; raw partials go to `ws`
   float* ws;   // [splitk][M][CoutPad]
+  int pad_w;   // horizontal padding (pad is the vertical one)
   int out_up;  // 1: replicate every result to its 2x2 block of a (2Ho x 2Wo) output
+  int out_step, out_oh, out_ow, out_H, out_W;  // out_step 2: scatter to (2h+oh, 2w+ow) of an out_H x out_W output
+  int res_mode;  // 0: + residual; 1: * (residual > 0 ? 1 : slope)   (activation derivative, backward)
   // SPADE epilogue (epi == 1)
   int epi;
   const float* sx;
@@ -78,6 +81,19 @@ struct ConvParams {
 // VAR bit1: software-pipelined body: fragment ds_reads first, next tile's global
 //           loads issued between them and the MFMAs, scheduler hints interleave
 //           the address arithmetic with the matrix pipe.
+// Output pixel index of GEMM row `pidx`: dense, or the (2h+oh, 2w+ow) scatter of one phase of a
+// stride-2 data gradient.
+__device__ __forceinline__ size_t out_pixel(const ConvParams& p, int pidx) {
+  if (p.out_step != 2) return (size_t)pidx;
+  const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
+  const int h = rem / p.Wo, w = rem - h * p.Wo;
+  return ((size_t)n * p.out_H + 2 * h + p.out_oh) * p.out_W + 2 * w + p.out_ow;
+}
+
+__device__ __forceinline__ float res_combine(float v, float r, int mode, float slope) {
+  return mode == 0 ? v + r : v * (r > 0.f ? 1.f : slope);
+}
+
 template <int TM, int TN, int WM, int WN, int VAR>
 __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
@@ -121,7 +137,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
     const int wo = rem - ho * p.Wo;
     a_n[r] = n;
     a_hi0[r] = ho * p.stride - p.pad;
-    a_wi0[r] = wo * p.stride - p.pad;
+    a_wi0[r] = wo * p.stride - p.pad_w;
   }
 
   // K-tile iterator state: (tap kh,kw) x (source s) x (chunk c), positioned at kt_begin
@@ -339,10 +355,11 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
           const int pidx = prow0 + (e & 3) + 8 * (e >> 2);
           if (c_ok && pidx < p.M) {
             float v = acc[i][j][e] * sc + sh;
-            if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
+            const size_t opix = out_pixel(p, pidx);
+            if (p.res) v = res_combine(v, p.res[opix * p.res_cs + p.res_co + c], p.res_mode, p.slope);
             v = apply_act(v, p.act, p.slope);
             if (!p.out_up) {
-              p.out[(size_t)pidx * p.out_cs + p.out_co + c] = v;
+              p.out[opix * p.out_cs + p.out_co + c] = v;
             } else {
               const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
               const int h = rem / p.Wo, w = rem - h * p.Wo;
@@ -421,11 +438,16 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
             f32x4 v;
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * sc[e] + sh[e];
-            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (size_t)pidx * p.res_cs + p.res_co + c0);
+            const size_t opix = out_pixel(p, pidx);
+            if (p.res) {
+              const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + opix * p.res_cs + p.res_co + c0);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = res_combine(v[e], r4[e], p.res_mode, p.slope);
+            }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
             if (!p.out_up) {
-              *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
+              *reinterpret_cast<f32x4*>(p.out + opix * p.out_cs + p.out_co + c0) = v;
             } else {
               const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
               const int h = rem / p.Wo, w = rem - h * p.Wo;
@@ -465,10 +487,11 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
       const int c = g * 4 + e;
       if (c >= p.Cout) break;
       float t = v[e] * (p.scale ? p.scale[c] : 1.f) + (p.shift ? p.shift[c] : 0.f);
-      if (p.res) t += p.res[(size_t)pidx * p.res_cs + p.res_co + c];
+      const size_t opix = out_pixel(p, pidx);
+      if (p.res) t = res_combine(t, p.res[opix * p.res_cs + p.res_co + c], p.res_mode, p.slope);
       t = apply_act(t, p.act, p.slope);
       if (!p.out_up) {
-        p.out[(size_t)pidx * p.out_cs + p.out_co + c] = t;
+        p.out[opix * p.out_cs + p.out_co + c] = t;
       } else {
         float* o = p.out + (((size_t)on * 2 * p.Ho + 2 * oh) * 2 * p.Wo + 2 * ow) * p.out_cs + p.out_co + c;
         o[0] = t; o[p.out_cs] = t;
@@ -492,7 +515,7 @@ __global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restric
     float acc = 0.f;
     for (int kh = 0; kh < p.KH; ++kh)
       for (int kw = 0; kw < p.KW; ++kw) {
-        const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;
+        const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad_w + kw;
         if (hi < 0 || hi >= p.H || wi < 0 || wi >= p.W) continue;
         int cbase = 0;
         for (int s = 0; s < p.nsrc; ++s) {
@@ -509,10 +532,11 @@ __global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restric
         }
       }
     float v = acc * (p.scale ? p.scale[co] : 1.f) + (p.shift ? p.shift[co] : 0.f);
-    if (p.res) v += p.res[(size_t)pidx * p.res_cs + p.res_co + co];
+    const size_t opix = out_pixel(p, pidx);
+    if (p.res) v = res_combine(v, p.res[opix * p.res_cs + p.res_co + co], p.res_mode, p.slope);
     v = apply_act(v, p.act, p.slope);
     if (!p.out_up) {
-      p.out[(size_t)pidx * p.out_cs + p.out_co + co] = v;
+      p.out[opix * p.out_cs + p.out_co + co] = v;
     } else {
       float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * ho) * 2 * p.Wo + 2 * wo) * p.out_cs + p.out_co + co;
       o[0] = v; o[p.out_cs] = v;
@@ -556,8 +580,15 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   HRV_REQUIRE(d->nsrc >= 1 && d->nsrc <= HRV_MAX_SRC, "conv2d: nsrc=%d out of range", d->nsrc);
   HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "conv2d: bad extent");
   HRV_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
-  HRV_REQUIRE(d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * d->pad - d->KW) / d->stride + 1,
+  const int padw = d->pad_w_plus1 > 0 ? d->pad_w_plus1 - 1 : d->pad;
+  HRV_REQUIRE(d->free_extent ||
+                  (d->Ho == (d->H + 2 * d->pad - d->KH) / d->stride + 1 && d->Wo == (d->W + 2 * padw - d->KW) / d->stride + 1),
               "conv2d: Ho/Wo (%d,%d) inconsistent with H,W,k,stride,pad", d->Ho, d->Wo);
+  HRV_REQUIRE(d->out_step == 0 || (d->out_step == 2 && d->out_up_shift == 0 && !d->spade && d->out_off_h >= 0 &&
+                                   d->out_off_w >= 0 && 2 * (d->Ho - 1) + d->out_off_h < d->out_H &&
+                                   2 * (d->Wo - 1) + d->out_off_w < d->out_W),
+              "conv2d: out_step/out_off/out_H/out_W inconsistent");
+  HRV_REQUIRE(d->res_mode == 0 || d->res_mode == 1, "conv2d: res_mode");
   HRV_REQUIRE(d->Cout > 0 && d->out != nullptr, "conv2d: bad output");
   HRV_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (int64_t)1 << 31, "conv2d: too many output pixels");
   memset(&p, 0, sizeof(p));
@@ -599,6 +630,9 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   p.res = (const float*)d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff;
   p.act = d->act; p.slope = d->act_slope; p.pre_slope = 0.2f;
   p.out = (float*)d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
+  p.pad_w = padw;
+  p.out_step = d->out_step; p.out_oh = d->out_off_h; p.out_ow = d->out_off_w; p.out_H = d->out_H; p.out_W = d->out_W;
+  p.res_mode = d->res_mode;
   HRV_REQUIRE(d->out_up_shift == 0 || (d->out_up_shift == 1 && !d->spade), "conv2d: out_up_shift must be 0 or 1");
   p.out_up = d->out_up_shift;
   if (d->spade) {

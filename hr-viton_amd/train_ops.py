@@ -1,0 +1,156 @@
+"""Backward-pass building blocks over the C ABI (conv_bwd.hip + the forward engine):
+device-side weight packing, data gradient (stride 1 and the four phases of stride 2),
+weight gradient, bias gradient.  Everything is NHWC fp32 ``Act`` views like ops.py."""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _lib, ops
+from .ops import ACT_NONE, Act, _ceil4, _stream, _Timed, _workspace
+
+
+def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
+                    stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0):
+    """hrv_conv2d_pack_weight_dev_f32.  ``w``: OIHW fp32 on the device.  Returns (packed, geom)
+    with geom = (KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, elems)."""
+    lib = _lib.load()
+    ops.require_cuda(w, "pack_weight_dev")
+    w = w.contiguous()
+    Cout, cin, KH, KW = w.shape
+    n = len(src_pad)
+    srcC = (C.c_int32 * n)(*src_pad)
+    srcR = (C.c_int32 * n)(*src_real)
+    bn = lib.hrv_conv2d_tile_bn(cfg)
+    rows = Cout if mode == 0 else cin
+    rows_pad = (rows + bn - 1) // bn * bn
+    chunks = sum((c + 15) // 16 for c in src_pad) if mode == 0 else (_ceil4(Cout) + 15) // 16
+    buf = torch.empty(KH * KW * chunks * rows_pad * 16, dtype=torch.float32, device=w.device)
+    geom = (C.c_int32 * 8)()
+    _lib.check(lib.hrv_conv2d_pack_weight_dev_f32(w.data_ptr(), Cout, KH, KW, n, srcC, srcR, cfg, mode, stride, pad,
+                                                  phase[0], phase[1], wscale, buf.data_ptr(), geom, _stream()),
+               "hrv_conv2d_pack_weight_dev_f32")
+    return buf, tuple(geom)
+
+
+def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_h, pad_w, out: Act, scale=None,
+                shift=None, residual: Optional[Act] = None, res_mode: int = 0, act: int = ACT_NONE, slope: float = 0.2,
+                free_extent: int = 0, out_step: int = 0, out_off=(0, 0), out_hw=(0, 0), out_up: int = 0,
+                name: str = "conv", flops: float = 0.0):
+    """Raw launch of hrv_conv2d_nhwc_f32 with an explicit, already packed weight."""
+    lib = _lib.load()
+    d = _lib.hrv_conv2d_t()
+    d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
+    d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad_h
+    d.pad_w_plus1 = pad_w + 1
+    d.nsrc = len(srcs)
+    for i, (a, up, creal) in enumerate(srcs):
+        s = d.src[i]
+        s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = (a.t.data_ptr(), _ceil4(creal), a.cstride,
+                                                                          a.coff, up, 0, creal)
+    d.w_packed = w_packed.data_ptr()
+    d.Cout, d.tile_cfg = Cout, cfg
+    d.scale = None if scale is None else scale.data_ptr()
+    d.shift = None if shift is None else shift.data_ptr()
+    if residual is not None:
+        d.residual, d.res_cstride, d.res_coff = residual.t.data_ptr(), residual.cstride, residual.coff
+    d.res_mode = res_mode
+    d.act, d.act_slope = act, slope
+    d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+    d.out_up_shift = out_up
+    d.free_extent, d.out_step = free_extent, out_step
+    d.out_off_h, d.out_off_w, d.out_H, d.out_W = out_off[0], out_off[1], out_hw[0], out_hw[1]
+    need = lib.hrv_conv2d_workspace_bytes(C.byref(d))
+    if need > 0:
+        ws = _workspace(out.t.device, need)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    with _Timed("conv", name, flops, 0):
+        _lib.check(lib.hrv_conv2d_nhwc_f32(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{name}]")
+    return out
+
+
+def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
+                     shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
+                     slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv") -> Act:
+    """Forward convolution with device-resident, per-step packed weights.  ``srcs``: (Act, up_shift)."""
+    lib = _lib.load()
+    Cout, cin, KH, KW = w.shape
+    a0, up0 = srcs[0]
+    N = a0.N
+    H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
+    cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
+    real = [a.C for a, _ in srcs]
+    assert sum(real) == cin, (name, real, cin)
+    packed, _ = pack_weight_dev(w, [_ceil4(c) for c in real], real, cfg, 0, stride, pad, wscale=wscale)
+    if out is None:
+        out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device)
+    fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
+    return _run_engine([(a, up, a.C) for a, up in srcs], packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad, pad,
+                       out, shift=shift, residual=residual, act=act, slope=slope, out_up=out_up, name=name, flops=fl)
+
+
+def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
+               act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
+               name: str = "dgrad") -> Act:
+    """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
+    activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x)."""
+    lib = _lib.load()
+    Cout, cin, KH, KW = w.shape
+    N, Ho, Wo = dy.N, dy.H, dy.W
+    assert dy.C == Cout
+    if out is None:
+        out = ops.alloc(N, H, W, cin, dy.t.device)
+    cfg = lib.hrv_conv2d_pick_tile(N * H * W, cin)
+    res_mode = 1 if act_mask is not None else 0
+    fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
+    if stride == 1:
+        packed, g = pack_weight_dev(w, [], [cin], cfg, 1, 1, pad, wscale=wscale) if False else \
+            pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale)
+        _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
+                    residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl)
+        return out
+    assert stride == 2, "data gradient implemented for stride 1 and 2"
+    for a in range(2):
+        for b in range(2):
+            Hp, Wp = (H - a + 1) // 2, (W - b + 1) // 2
+            if Hp <= 0 or Wp <= 0:
+                continue
+            cfg_p = lib.hrv_conv2d_pick_tile(N * Hp * Wp, cin)
+            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale)
+            _run_engine([(dy, 0, Cout)], packed, cin, cfg_p, N, Ho, Wo, Hp, Wp, g[0], g[1], 1, g[2], g[3], out,
+                        residual=act_mask, res_mode=res_mode, slope=slope, free_extent=1, out_step=2, out_off=(a, b),
+                        out_hw=(H, W), name=f"{name}[phase {a}{b}]", flops=fl / 4)
+    return out
+
+
+def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, KW: int, stride: int, pad: int,
+               dw: torch.Tensor, accumulate: bool = False, name: str = "wgrad"):
+    """dW[:, ci_base:ci_base+x.C] (+)= wgrad(dY, x) -- hrv_conv2d_wgrad_nhwc_f32.  ``dw``: OIHW fp32 device."""
+    lib = _lib.load()
+    N, Ho, Wo, Cout = dy.N, dy.H, dy.W, dy.C
+    H, W = (x.H << x_up, x.W << x_up) if x_up >= 0 else (x.H >> -x_up, x.W >> -x_up)
+    assert dw.is_contiguous() and tuple(dw.shape) == (Cout, cin_tot, KH, KW), (dw.shape, Cout, cin_tot, KH, KW)
+    need = lib.hrv_conv2d_wgrad_workspace_bytes(Cout, cin_tot, KH, KW, N * Ho * Wo)
+    ws = _workspace(dy.t.device, need)
+    fl = 2.0 * N * Ho * Wo * Cout * x.C * KH * KW
+    with _Timed("wgrad", name, fl, 0):
+        _lib.check(lib.hrv_conv2d_wgrad_nhwc_f32(dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp,
+                                                 x.cstride, x.coff, x_up, x.C, ci_base, cin_tot, N, H, W, Ho, Wo, KH, KW,
+                                                 stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
+                                                 1 if accumulate else 0, _stream()), "hrv_conv2d_wgrad_nhwc_f32")
+
+
+def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
+    """out[c] (+)= sum over pixels of a[..., c]  (bias gradient) -- hrv_colsum_nhwc_f32."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty(a.C, dtype=torch.float32, device=a.t.device)
+        accumulate = False
+    P = a.N * a.H * a.W
+    ws = _workspace(a.t.device, 256 * a.Cp * 4)
+    _lib.check(lib.hrv_colsum_nhwc_f32(a.t.data_ptr(), P, a.C, a.cstride, a.coff, ws.data_ptr(), ws.numel() * 4,
+                                       out.data_ptr(), 1 if accumulate else 0, _stream()), "hrv_colsum_nhwc_f32")
+    return out

@@ -124,6 +124,15 @@ typedef struct hrv_conv2d {
   int32_t _pad2;
   void* workspace;          /* optional scratch for split-K (small-M / large-K layers):   */
   int64_t workspace_bytes;  /* >= hrv_conv2d_workspace_bytes(d); NULL => run unsplit     */
+  /* --- backward-pass extensions (all 0 for an ordinary forward convolution) --- */
+  int32_t pad_w_plus1;  /* 0: horizontal padding = pad; else horizontal padding + 1        */
+  int32_t free_extent;  /* 1: Ho/Wo are taken as given; taps outside the input read zeros  */
+  int32_t out_step;     /* 2: row (n,h,w) is stored at (2h+out_off_h, 2w+out_off_w) of an
+                           out_H x out_W tensor: one phase of a stride-2 data gradient     */
+  int32_t out_off_h, out_off_w, out_H, out_W;
+  int32_t res_mode;     /* 0: epilogue adds `residual`; 1: multiplies by the activation
+                           derivative (residual > 0 ? 1 : act_slope) -- LeakyReLU/ReLU
+                           backward fused into the data-gradient convolution             */
 } hrv_conv2d_t;
 
 /* Tile configuration for (M = N*Ho*Wo output pixels, Cout): returns cfg id. */
@@ -143,6 +152,33 @@ int64_t hrv_conv2d_packed_elems(int32_t Cout, int32_t KH, int32_t KW, int32_t ns
 int hrv_conv2d_pack_weight_f32(const float* w_oihw, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
                                const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
                                float* out);
+/* ---- training side (conv_bwd.hip) ---------------------------------------
+ * Device-side weight packing (weights change every optimiser step).  mode 0: the
+ * forward layout of hrv_conv2d_pack_weight_f32; mode 1: the stride-1 data gradient
+ * (rows = Cin, k over Cout, taps flipped; run the engine on dY with pad K-1-pad);
+ * mode 2: one phase (phase_a, phase_b) of the stride-2 data gradient
+ * (dX[2h'+a] = sum_j dY[h'+j-pad_p] W[a+pad-2(j-pad_p)]).  `wscale` multiplies
+ * every weight (spectral-norm 1/sigma).  out_geom[8] = {KHp, KWp, pad_h, pad_w,
+ * rows, rows_pad, chunks_total, packed elems}; out_dev must hold that many floats
+ * (<= KH*KW*chunks*rows_pad*16).
+ * Weight gradient of one source of a (possibly concatenated) input:
+ *   dW[co][ci_base+ci][kh][kw] (+)= sum_p dY[p][co] * X[p shifted by (kh,kw)][ci]
+ * MFMA GEMM over pixel slabs + fixed-order reduction (deterministic).
+ * colsum: out[c] (+)= sum_p x[p][c]  (bias gradient).
+ * ---------------------------------------------------------------------- */
+int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                   const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
+                                   int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
+                                   float* out_dev, int32_t* out_geom, hrv_stream_t stream);
+int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P);
+int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
+                              int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
+                              int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                              int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,
+                              int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, hrv_stream_t stream);
+int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,
+                        int64_t workspace_bytes, float* out, int32_t accumulate, hrv_stream_t stream);
+
 /* Scratch the engine would like for this launch (0: none).  Layers with fewer than
  * ~192 output tiles split their K range over up to 32 blocks per tile (partials in
  * the workspace, fixed-order reduction + epilogue in a second kernel: deterministic). */
