@@ -23,7 +23,21 @@ class hrv_src_t(C.Structure):
 class hrv_spade_epi_t(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_cstride", C.c_int32), ("x_coff", C.c_int32), ("C", C.c_int32),
                 ("_pad", C.c_int32), ("mean", C.c_void_p), ("rstd", C.c_void_p), ("noise_z", C.c_void_p),
-                ("noise_scale", C.c_void_p)]
+                ("noise_scale", C.c_void_p), ("g1p_out", C.c_void_p)]
+
+
+class hrv_norm_bwd_t(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("x", C.c_void_p), ("x_cstride", C.c_int32), ("x_coff", C.c_int32),
+                ("noise_z", C.c_void_p), ("noise_scale", C.c_void_p), ("mean", C.c_void_p), ("rstd", C.c_void_p),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
+                ("g1p", C.c_void_p), ("g1p_cstride", C.c_int32), ("g1p_coff", C.c_int32),
+                ("dout", C.c_void_p), ("dout_cstride", C.c_int32), ("dout_coff", C.c_int32),
+                ("dnh", C.c_void_p), ("dnh_cstride", C.c_int32), ("dnh_coff", C.c_int32),
+                ("dgb", C.c_void_p), ("dgb_cstride", C.c_int32), ("dgb_coff", C.c_int32),
+                ("dx", C.c_void_p), ("dx_cstride", C.c_int32), ("dx_coff", C.c_int32),
+                ("dx_accumulate", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+                ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p)]
 
 
 class hrv_conv2d_t(C.Structure):
@@ -68,6 +82,16 @@ SYMBOLS = {
                                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32,
                                             _vp]),
     "hrv_colsum_nhwc_f32": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
+    "hrv_norm_bwd_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
+    "hrv_spade_norm_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), _vp]),
+    "hrv_loss_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f, _f, _vp, _vp, _vp, _i32, _vp]),
+    "hrv_downsum2x2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "hrv_avgpool3x3s2_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "hrv_maxpool2x2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_maxpool2x2_bwd_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_adam_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _f, _vp]),
+    "hrv_spectral_norm_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _f, _vp, _vp, _vp]),
+    "hrv_spectral_norm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "hrv_conv2d_workspace_bytes": (_i64, [C.POINTER(hrv_conv2d_t)]),
     "hrv_conv2d_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
     "hrv_conv2d_naive_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),

@@ -74,6 +74,7 @@ struct ConvParams {
   const float* srstd;
   const float* sz;
   const float* sns;
+  float* sg1p;  // optional (1+gamma) output, dense [M][sC]
 };
 
 // VAR bit0: swapped-operand MFMA (D[cout][pixel]) -> each lane owns 4 consecutive
@@ -407,13 +408,14 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
                 }
                 const f32x4 mu = *reinterpret_cast<const f32x4*>(p.smean + (size_t)n * p.sC + c0);
                 const f32x4 rs = *reinterpret_cast<const f32x4*>(p.srstd + (size_t)n * p.sC + c0);
-                f32x4 v;
+                f32x4 v, g1;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                  const float gam = acc[i][2 * q][4 * g + e] + bg[e];
+                  g1[e] = 1.f + acc[i][2 * q][4 * g + e] + bg[e];
                   const float bet = acc[i][2 * q + 1][4 * g + e] + bb[e];
-                  v[e] = apply_act((x[e] - mu[e]) * rs[e] * (1.f + gam) + bet, p.act, p.slope);
+                  v[e] = apply_act((x[e] - mu[e]) * rs[e] * g1[e] + bet, p.act, p.slope);
                 }
+                if (p.sg1p) *reinterpret_cast<f32x4*>(p.sg1p + (size_t)pidx * p.sC + c0) = g1;
                 *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
               }
             }
@@ -649,7 +651,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
     HRV_REQUIRE((((uintptr_t)e.x | (uintptr_t)e.mean | (uintptr_t)e.rstd | (uintptr_t)e.noise_scale |
                   (uintptr_t)d->shift | (uintptr_t)d->out) & 15) == 0, "conv2d/spade: 16-byte alignment");
     p.epi = 1; p.sx = e.x; p.sx_cs = e.x_cstride; p.sx_co = e.x_coff; p.sC = e.C;
-    p.smean = e.mean; p.srstd = e.rstd; p.sz = e.noise_z; p.sns = e.noise_scale;
+    p.smean = e.mean; p.srstd = e.rstd; p.sz = e.noise_z; p.sns = e.noise_scale; p.sg1p = e.g1p_out;
     p.res = nullptr; p.scale = nullptr;
   } else {
     HRV_REQUIRE(d->out_cstride >= d->out_coff + d->Cout, "conv2d: out slice out of range");

@@ -1,0 +1,574 @@
+// Training-side HBM-bound kernels (NHWC fp32): InstanceNorm / SPADE backward, loss
+// reductions with their gradients, 2x2 gradient down-sum (nearest-upsample backward),
+// avg-pool backward, 2x2 max-pool forward/backward (VGG19), fused Adam, and the
+// GEMVs of the spectral-norm power iteration.  All reductions are two-stage with a
+// fixed summation order (deterministic).
+#include "hrv_common.h"
+
+namespace hrv {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+static inline int grid_for(size_t work, int block = 256) {
+  size_t g = (work + block - 1) / block;
+  const size_t cap = 256 * 16;
+  return (int)(g < 1 ? 1 : (g > cap ? cap : g));
+}
+
+__device__ __forceinline__ float dact(float y, int act, float slope) {
+  // derivative of ReLU / LeakyReLU expressed through the activation's OUTPUT y
+  if (act == HRV_ACT_RELU) return y > 0.f ? 1.f : 0.f;
+  if (act == HRV_ACT_LRELU) return y > 0.f ? 1.f : slope;
+  return 1.f;
+}
+
+// ---------------------------------------------------------------------------
+// SPADE / InstanceNorm backward, stage 1 (elementwise + per-(n,c) partial sums).
+//   forward:  v = x + z*ns;  nh = (v - mean)*rstd;  out = act(nh*g1p + beta)   (g1p = 1+gamma)
+//   given dout:  dpre = dout * act'(out);  dnh = dpre*g1p;  dgamma = dpre*nh;  dbeta = dpre
+// plain InstanceNorm (+act) is the same with g1p == NULL (=1) and no dgamma/dbeta outputs.
+// Writes dnh (needed again by stage 2), optionally dgb = [dgamma | dbeta] (2C channels) and
+// the partial sums S1 = sum dnh, S2 = sum dnh*nh per (n, slab, c).
+// ---------------------------------------------------------------------------
+struct NormBwdParams {
+  const float* x; int x_cs, x_co;
+  const float* z; const float* ns;           // noise (nullable)
+  const float* mean; const float* rstd;      // [N][C]
+  const float* out; int out_cs, out_co;      // activation output (mask), nullable when act == NONE
+  const float* g1p; int g_cs, g_co;          // 1+gamma, nullable
+  const float* dout; int do_cs, do_co;
+  float* dnh; int dn_cs, dn_co;
+  float* dgb; int dgb_cs, dgb_co;            // nullable; [.., 2C]: dgamma at [0,C), dbeta at [C,2C)
+  int N, H, W, C4, act; float slope;
+  int NB; float* part;                       // [N][NB][C][2]
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+__global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParams p) {
+  __shared__ f32x4 red[2][256];
+  const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+  const int HW = p.H * p.W, C = p.C4 * 4;
+  const int PB = (HW + p.NB - 1) / p.NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, HW);
+  const int GB = p.C4 < 256 ? p.C4 : 256;
+  const int R = 256 / GB;
+  const int r = t / GB, gl = t - r * GB;
+  for (int g0 = 0; g0 < p.C4; g0 += GB) {
+    const int g = g0 + gl;
+    f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
+    if (r < R && g < p.C4) {
+      const f32x4 mu = ld4(p.mean + (size_t)n * C + g * 4), rs = ld4(p.rstd + (size_t)n * C + g * 4);
+      const f32x4 ns4 = p.z ? ld4(p.ns + g * 4) : (f32x4)(0.f);
+      for (int px = p0 + r; px < p1; px += R) {
+        const size_t pix = (size_t)n * HW + px;
+        f32x4 v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        if (p.z) {
+          const int h = px / p.W, w = px - h * p.W;
+          v += p.z[((size_t)n * p.W + w) * p.H + h] * ns4;
+        }
+        const f32x4 nh = (v - mu) * rs;
+        f32x4 dpre = ld4(p.dout + pix * p.do_cs + p.do_co + g * 4);
+        if (p.act != HRV_ACT_NONE) {
+          const f32x4 o = ld4(p.out + pix * p.out_cs + p.out_co + g * 4);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dpre[e] *= dact(o[e], p.act, p.slope);
+        }
+        f32x4 dnh = dpre;
+        if (p.g1p) dnh *= ld4(p.g1p + pix * p.g_cs + p.g_co + g * 4);
+        *reinterpret_cast<f32x4*>(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) = dnh;
+        if (p.dgb) {
+          *reinterpret_cast<f32x4*>(p.dgb + pix * p.dgb_cs + p.dgb_co + g * 4) = dpre * nh;
+          *reinterpret_cast<f32x4*>(p.dgb + pix * p.dgb_cs + p.dgb_co + C + g * 4) = dpre;
+        }
+        s1 += dnh;
+        s2 += dnh * nh;
+      }
+    }
+    red[0][t] = s1;
+    red[1][t] = s2;
+    __syncthreads();
+    if (r == 0 && g < p.C4) {
+      for (int rr = 1; rr < R; ++rr) { s1 += red[0][rr * GB + gl]; s2 += red[1][rr * GB + gl]; }
+      float* dst = p.part + (((size_t)n * p.NB + b) * C + g * 4) * 2;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
+    }
+    __syncthreads();
+  }
+}
+
+// fixed-order reduction of the slab partials: m1[n][c] = S1/HW, m2[n][c] = S2/HW
+__global__ void norm_bwd_finalize_kernel(const float* __restrict__ part, int N, int NB, int C, int HW,
+                                         float* __restrict__ m1, float* __restrict__ m2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < NB; ++b) {
+    const float* src = part + (((size_t)n * NB + b) * C + c) * 2;
+    s1 += (double)src[0];
+    s2 += (double)src[1];
+  }
+  m1[i] = (float)(s1 / HW);
+  m2[i] = (float)(s2 / HW);
+}
+
+// stage 2: dx = rstd * (dnh - m1 - nh*m2)  (+ optional accumulate into dx), and partial sums of
+// dx*z per (n, slab, c) for the noise_scale gradient.
+struct NormBwd2Params {
+  const float* x; int x_cs, x_co;
+  const float* z; const float* ns;
+  const float* mean; const float* rstd; const float* m1; const float* m2;
+  const float* dnh; int dn_cs, dn_co;
+  float* dx; int dx_cs, dx_co; int accumulate;
+  int N, H, W, C4;
+  int NB; float* part;  // [N][NB][C] (only when z != NULL)
+};
+
+__global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Params p) {
+  __shared__ f32x4 red[256];
+  const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+  const int HW = p.H * p.W, C = p.C4 * 4;
+  const int PB = (HW + p.NB - 1) / p.NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, HW);
+  const int GB = p.C4 < 256 ? p.C4 : 256;
+  const int R = 256 / GB;
+  const int r = t / GB, gl = t - r * GB;
+  for (int g0 = 0; g0 < p.C4; g0 += GB) {
+    const int g = g0 + gl;
+    f32x4 sz = (f32x4)(0.f);
+    if (r < R && g < p.C4) {
+      const size_t sc = (size_t)n * C + g * 4;
+      const f32x4 mu = ld4(p.mean + sc), rs = ld4(p.rstd + sc), a1 = ld4(p.m1 + sc), a2 = ld4(p.m2 + sc);
+      const f32x4 ns4 = p.z ? ld4(p.ns + g * 4) : (f32x4)(0.f);
+      for (int px = p0 + r; px < p1; px += R) {
+        const size_t pix = (size_t)n * HW + px;
+        f32x4 v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        float zz = 0.f;
+        if (p.z) {
+          const int h = px / p.W, w = px - h * p.W;
+          zz = p.z[((size_t)n * p.W + w) * p.H + h];
+          v += zz * ns4;
+        }
+        const f32x4 nh = (v - mu) * rs;
+        f32x4 d = rs * (ld4(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) - a1 - nh * a2);
+        sz += d * zz;
+        float* o = p.dx + pix * p.dx_cs + p.dx_co + g * 4;
+        if (p.accumulate) d += ld4(o);
+        *reinterpret_cast<f32x4*>(o) = d;
+      }
+    }
+    if (p.z) {
+      red[t] = sz;
+      __syncthreads();
+      if (r == 0 && g < p.C4) {
+        for (int rr = 1; rr < R; ++rr) sz += red[rr * GB + gl];
+        *reinterpret_cast<f32x4*>(p.part + ((size_t)n * p.NB + b) * C + g * 4) = sz;
+      }
+      __syncthreads();
+    }
+  }
+}
+
+__global__ void sum_rows_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+// ---------------------------------------------------------------------------
+// losses: value + gradient in one pass.  mode: 0 L1 |a-b| ; 1 hinge-D fake max(1+a,0) ;
+// 2 hinge-D real max(1-a,0) ; 3 -a (generator hinge / wgan) ; 4 (a-b)^2 (LSGAN/MSE)
+// grad[i] = gscale * dl/da ; loss = lscale * sum(l)   (callers pass 1/numel etc.)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
+                                                   int mode, float gscale, float* __restrict__ grad,
+                                                   float* __restrict__ part) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float x = a[i];
+    float l, g;
+    if (mode == 0) { const float d = x - b[i]; l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    else if (mode == 1) { l = fmaxf(1.f + x, 0.f); g = x > -1.f ? 1.f : 0.f; }
+    else if (mode == 2) { l = fmaxf(1.f - x, 0.f); g = x < 1.f ? -1.f : 0.f; }
+    else if (mode == 3) { l = -x; g = -1.f; }
+    else { const float d = x - b[i]; l = d * d; g = 2.f * d; }
+    s += l;
+    if (grad) grad[i] = gscale * g;
+  }
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+__global__ void loss_final_kernel(const float* __restrict__ part, int nb, float lscale, float* __restrict__ out,
+                                  int accumulate) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double s = 0.0;
+    for (int i = 0; i < nb; ++i) s += (double)part[i];
+    const float v = (float)(s * (double)lscale);
+    out[0] = accumulate ? out[0] + v : v;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// nearest-x2 upsample backward: dlo[n,h,w,c] = sum of the 2x2 block of dhi
+// ---------------------------------------------------------------------------
+__global__ void downsum2x2_kernel(const float* __restrict__ dhi, int N, int Hl, int Wl, int C4, int hcs, int hco,
+                                  float* __restrict__ dlo, int lcs, int lco, int accumulate) {
+  const size_t total = (size_t)N * Hl * Wl * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int w = (int)(pix % Wl);
+    const size_t t = pix / Wl;
+    const int h = (int)(t % Hl);
+    const int n = (int)(t / Hl);
+    const float* s = dhi + (((size_t)n * 2 * Hl + 2 * h) * 2 * Wl + 2 * w) * hcs + hco + g * 4;
+    f32x4 v = ld4(s) + ld4(s + hcs) + ld4(s + (size_t)2 * Wl * hcs) + ld4(s + (size_t)2 * Wl * hcs + hcs);
+    float* o = dlo + pix * lcs + lco + g * 4;
+    if (accumulate) v += ld4(o);
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
+// avg_pool2d(3, s2, p1, count_include_pad=False) backward: dx[h,w] = sum over the (<= 4) windows that
+// contain (h,w) of dy[ho,wo] / count(ho,wo)
+__global__ void avgpool3s2_bwd_kernel(const float* __restrict__ dy, int N, int H, int W, int C4, int Ho, int Wo,
+                                      int ycs, int yco, float* __restrict__ dx, int xcs, int xco, int accumulate) {
+  const size_t total = (size_t)N * H * W * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int w = (int)(pix % W);
+    const size_t t = pix / W;
+    const int h = (int)(t % H);
+    const int n = (int)(t / H);
+    f32x4 s = (f32x4)(0.f);
+    for (int ho = h / 2; ho <= (h + 1) / 2; ++ho) {
+      if (ho >= Ho) continue;
+      const int ch = min(2 * ho + 1, H - 1) - max(2 * ho - 1, 0) + 1;
+      for (int wo = w / 2; wo <= (w + 1) / 2; ++wo) {
+        if (wo >= Wo) continue;
+        const int cw = min(2 * wo + 1, W - 1) - max(2 * wo - 1, 0) + 1;
+        s += ld4(dy + ((size_t)(n * Ho + ho) * Wo + wo) * ycs + yco + g * 4) / (float)(ch * cw);
+      }
+    }
+    float* o = dx + pix * xcs + xco + g * 4;
+    if (accumulate) s += ld4(o);
+    *reinterpret_cast<f32x4*>(o) = s;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// VGG19: 2x2 stride-2 max pool, forward and backward (first maximum in (0,0),(0,1),(1,0),(1,1)
+// scan order takes the gradient, like torch)
+// ---------------------------------------------------------------------------
+__global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int Wo, int C4, int xcs, float* __restrict__ y,
+                                int ycs) {
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int wo = (int)(pix % Wo);
+    const size_t t = pix / Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const float* s = x + (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
+    const f32x4 a = ld4(s), b = ld4(s + xcs), c = ld4(s + (size_t)2 * Wo * xcs), d = ld4(s + (size_t)2 * Wo * xcs + xcs);
+    f32x4 m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+    *reinterpret_cast<f32x4*>(y + pix * ycs + g * 4) = m;
+  }
+}
+
+__global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Ho, int Wo,
+                                    int C4, int xcs, int ycs, float* __restrict__ dx) {
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const int wo = (int)(pix % Wo);
+    const size_t t = pix / Wo;
+    const int ho = (int)(t % Ho);
+    const int n = (int)(t / Ho);
+    const size_t base = (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
+    const size_t o01 = xcs, o10 = (size_t)2 * Wo * xcs, o11 = o10 + xcs;
+    const f32x4 a = ld4(x + base), b = ld4(x + base + o01), c = ld4(x + base + o10), d = ld4(x + base + o11);
+    const f32x4 gy = ld4(dy + pix * ycs + g * 4);
+    f32x4 ga = (f32x4)(0.f), gb = ga, gc = ga, gd = ga;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float m = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+      if (a[e] == m) ga[e] = gy[e];
+      else if (b[e] == m) gb[e] = gy[e];
+      else if (c[e] == m) gc[e] = gy[e];
+      else gd[e] = gy[e];
+    }
+    *reinterpret_cast<f32x4*>(dx + base) = ga;
+    *reinterpret_cast<f32x4*>(dx + base + o01) = gb;
+    *reinterpret_cast<f32x4*>(dx + base + o10) = gc;
+    *reinterpret_cast<f32x4*>(dx + base + o11) = gd;
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Adam (torch.optim.Adam semantics: no amsgrad, optional L2 weight decay), fused over one
+// flat buffer.  step_size = lr / (1 - b1^t);  denom = sqrt(v)/sqrt(1 - b2^t) + eps
+// ---------------------------------------------------------------------------
+__global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, float lr, float b1, float b2, float eps, float wd,
+                            float bc1, float bc2_sqrt, float gscale) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float wi = w[i];
+    if (wd != 0.f) gi += wd * wi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w[i] = wi - (lr / bc1) * (mi / denom);
+  }
+}
+
+// ---------------------------------------------------------------------------
+// Spectral-norm power iteration GEMVs on W [R][K] (row-major):  y = W x  and  y = W^T x
+// (one block per row / per 64-column strip; fixed order => deterministic)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
+                                                        int K, float* __restrict__ y) {
+  __shared__ float red[256];
+  const int r = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s += Wm[(size_t)r * K + k] * x[k];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) y[r] = red[0];
+}
+
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
+                                                        int K, float* __restrict__ y) {
+  // block handles 64 columns; 4 row-groups of 64 lanes each stride the rows
+  __shared__ float red[4][64];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int rg = threadIdx.x >> 6;
+  float s = 0.f;
+  if (c < K)
+    for (int r = rg; r < R; r += 4) s += Wm[(size_t)r * K + c] * x[r];
+  red[rg][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (rg == 0 && c < K) y[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// x <- x / max(||x||, eps); also returns ||x|| in out_norm (single block)
+__global__ __launch_bounds__(256) void normalize_kernel(float* __restrict__ x, int n, float eps, float* __restrict__ out_norm) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) s += x[i] * x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float nrm = sqrtf(red[0]);
+  const float inv = 1.f / fmaxf(nrm, eps);
+  for (int i = threadIdx.x; i < n; i += 256) x[i] *= inv;
+  if (threadIdx.x == 0 && out_norm) out_norm[0] = nrm;
+}
+
+// dot(a, b) over n elements -> out[0] (two-stage)
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                          size_t n, float* __restrict__ part) {
+  __shared__ float red[256];
+  float s = 0.f;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) s += a[i] * b[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) part[blockIdx.x] = red[0];
+}
+
+// spectral-norm weight-gradient transform (torch SpectralNorm backward with u, v constants):
+//   dW_orig[r][k] = (G[r][k] - c * u[r] * v[k]) / sigma,   c = <G, W_orig> / sigma = <G, W_sn>
+__global__ void sn_grad_kernel(const float* __restrict__ G, const float* __restrict__ u, const float* __restrict__ v,
+                               const float* __restrict__ dotGW, const float* __restrict__ sigma, int R, int K,
+                               float* __restrict__ out, int accumulate) {
+  const size_t total = (size_t)R * K;
+  const float sg = sigma[0];
+  const float c = dotGW[0] / sg;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int r = (int)(i / K), k = (int)(i - (size_t)r * K);
+    const float d = (G[i] - c * u[r] * v[k]) / sg;
+    out[i] = accumulate ? out[i] + d : d;
+  }
+}
+
+}  // namespace hrv
+
+using namespace hrv;
+
+extern "C" int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C) {
+  if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
+  int nb = (H * W + 511) / 512;
+  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  return (int64_t)N * nb * ((C + 3) / 4 * 4) * 2 + (int64_t)N * ((C + 3) / 4 * 4) * 2;
+}
+
+extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream) {
+  HRV_REQUIRE(d && d->x && d->mean && d->rstd && d->dout && d->dnh && d->dx && d->workspace, "norm_bwd: null pointer");
+  HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 4 == 0, "norm_bwd: extent (C %% 4 == 0)");
+  HRV_REQUIRE((d->noise_z == nullptr) == (d->noise_scale == nullptr), "norm_bwd: noise_z/noise_scale go together");
+  HRV_REQUIRE(d->act == HRV_ACT_NONE || d->out, "norm_bwd: activation output needed for its derivative");
+  HRV_REQUIRE(((d->x_cstride | d->x_coff | d->out_cstride | d->out_coff | d->g1p_cstride | d->g1p_coff | d->dout_cstride |
+                d->dout_coff | d->dnh_cstride | d->dnh_coff | d->dgb_cstride | d->dgb_coff | d->dx_cstride | d->dx_coff) & 3) == 0,
+              "norm_bwd: strides/offsets must be multiples of 4");
+  const int HW = d->H * d->W, C = d->C;
+  int nb = (HW + 511) / 512;
+  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  float* part = d->workspace;
+  float* m1 = part + (size_t)d->N * nb * C * 2;
+  float* m2 = m1 + (size_t)d->N * C;
+  hipStream_t st = (hipStream_t)stream;
+  NormBwdParams p;
+  p.x = d->x; p.x_cs = d->x_cstride; p.x_co = d->x_coff; p.z = d->noise_z; p.ns = d->noise_scale;
+  p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
+  p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff;
+  p.dout = d->dout; p.do_cs = d->dout_cstride; p.do_co = d->dout_coff;
+  p.dnh = d->dnh; p.dn_cs = d->dnh_cstride; p.dn_co = d->dnh_coff;
+  p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
+  p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;
+  hipLaunchKernelGGL(norm_bwd_stage1_kernel, dim3(nb, d->N), dim3(256), 0, st, p);
+  int rc = check_launch("norm_bwd_stage1_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((d->N * C + 255) / 256), dim3(256), 0, st, part, d->N, nb, C, HW, m1, m2);
+  rc = check_launch("norm_bwd_finalize_kernel");
+  if (rc) return rc;
+  NormBwd2Params q;
+  q.x = d->x; q.x_cs = d->x_cstride; q.x_co = d->x_coff; q.z = d->noise_z; q.ns = d->noise_scale;
+  q.mean = d->mean; q.rstd = d->rstd; q.m1 = m1; q.m2 = m2;
+  q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff;
+  q.dx = d->dx; q.dx_cs = d->dx_cstride; q.dx_co = d->dx_coff; q.accumulate = d->dx_accumulate;
+  q.N = d->N; q.H = d->H; q.W = d->W; q.C4 = C / 4; q.NB = nb; q.part = part;  // partials are free again
+  hipLaunchKernelGGL(norm_bwd_stage2_kernel, dim3(nb, d->N), dim3(256), 0, st, q);
+  rc = check_launch("norm_bwd_stage2_kernel");
+  if (rc) return rc;
+  if (d->noise_z && d->dnoise_scale) {
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, d->N * nb, C, d->dnoise_scale,
+                       d->dns_accumulate);
+    rc = check_launch("sum_rows_kernel");
+  }
+  return rc;
+}
+
+extern "C" int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t mode, float lscale, float gscale,
+                            float* grad, float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(a && workspace && loss_out && n > 0 && mode >= 0 && mode <= 4, "loss: bad args");
+  HRV_REQUIRE((mode != 0 && mode != 4) || b, "loss: mode needs a target tensor");
+  const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_kernel, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, mode, gscale, grad, workspace);
+  int rc = check_launch("loss_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, workspace, nb, lscale, loss_out, accumulate);
+  return check_launch("loss_final_kernel");
+}
+
+extern "C" int hrv_downsum2x2_nhwc_f32(const float* dhi, int32_t N, int32_t Hl, int32_t Wl, int32_t C, int32_t hi_cstride,
+                                       int32_t hi_coff, float* dlo, int32_t lo_cstride, int32_t lo_coff,
+                                       int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(dhi && dlo && N > 0 && Hl > 0 && Wl > 0 && C > 0 && C % 4 == 0 &&
+                  ((hi_cstride | hi_coff | lo_cstride | lo_coff) & 3) == 0, "downsum2x2: bad args");
+  const size_t total = (size_t)N * Hl * Wl * (C / 4);
+  hipLaunchKernelGGL(downsum2x2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dhi, N, Hl, Wl, C / 4,
+                     hi_cstride, hi_coff, dlo, lo_cstride, lo_coff, accumulate);
+  return check_launch("downsum2x2_kernel");
+}
+
+extern "C" int hrv_avgpool3x3s2_bwd_nhwc_f32(const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dy_cstride,
+                                             int32_t dy_coff, float* dx, int32_t dx_cstride, int32_t dx_coff,
+                                             int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(dy && dx && N > 0 && H > 0 && W > 0 && C > 0 && C % 4 == 0 &&
+                  ((dy_cstride | dy_coff | dx_cstride | dx_coff) & 3) == 0, "avgpool_bwd: bad args");
+  const int Ho = (H + 2 - 3) / 2 + 1, Wo = (W + 2 - 3) / 2 + 1;
+  const size_t total = (size_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(avgpool3s2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dy, N, H, W, C / 4,
+                     Ho, Wo, dy_cstride, dy_coff, dx, dx_cstride, dx_coff, accumulate);
+  return check_launch("avgpool3s2_bwd_kernel");
+}
+
+extern "C" int hrv_maxpool2x2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y,
+                                       hrv_stream_t stream) {
+  HRV_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool: bad args");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, H / 2, W / 2, C / 4, C,
+                     y, C);
+  return check_launch("maxpool2_kernel");
+}
+
+extern "C" int hrv_maxpool2x2_bwd_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                           float* dx, hrv_stream_t stream) {
+  HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad args");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
+                     C / 4, C, C, dx);
+  return check_launch("maxpool2_bwd_kernel");
+}
+
+extern "C" int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                            float eps, float weight_decay, int32_t step, float grad_scale, hrv_stream_t stream) {
+  HRV_REQUIRE(w && g && m && v && n > 0 && step >= 1, "adam: bad args");
+  const float bc1 = 1.f - powf(beta1, (float)step);
+  const float bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (size_t)n, lr,
+                     beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
+  return check_launch("adam_kernel");
+}
+
+extern "C" int hrv_spectral_norm_f32(const float* w, int32_t R, int32_t K, float* u, float* v, int32_t power_iterations,
+                                     float eps, float* wv_scratch, float* sigma_out, hrv_stream_t stream) {
+  HRV_REQUIRE(w && u && v && wv_scratch && sigma_out && R > 0 && K > 0 && power_iterations >= 0, "spectral_norm: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  for (int it = 0; it < power_iterations; ++it) {
+    // v <- normalize(W^T u) ; u <- normalize(W v)    (torch SpectralNorm.compute_weight)
+    hipLaunchKernelGGL(gemv_cols_kernel, dim3((K + 63) / 64), dim3(256), 0, st, w, u, R, K, v);
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, st, v, K, eps, (float*)nullptr);
+    hipLaunchKernelGGL(gemv_rows_kernel, dim3(R), dim3(256), 0, st, w, v, R, K, u);
+    hipLaunchKernelGGL(normalize_kernel, dim3(1), dim3(256), 0, st, u, R, eps, (float*)nullptr);
+  }
+  // sigma = u . (W v)
+  hipLaunchKernelGGL(gemv_rows_kernel, dim3(R), dim3(256), 0, st, w, v, R, K, wv_scratch);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(1), dim3(256), 0, st, u, wv_scratch, (size_t)R, sigma_out);
+  return check_launch("spectral_norm kernels");
+}
+
+extern "C" int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* u, const float* v,
+                                         const float* sigma, int32_t R, int32_t K, float* workspace, float* dw_orig,
+                                         int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(G && w_orig && u && v && sigma && workspace && dw_orig && R > 0 && K > 0, "spectral_norm_bwd: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  const size_t n = (size_t)R * K;
+  const int nb = grid_for(n) > 512 ? 512 : grid_for(n);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(nb), dim3(256), 0, st, G, w_orig, n, workspace);
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, workspace, nb, 1.0f, workspace + 512, 0);
+  hipLaunchKernelGGL(sn_grad_kernel, dim3(grid_for(n)), dim3(256), 0, st, G, u, v, workspace + 512, sigma, R, K, dw_orig,
+                     accumulate);
+  return check_launch("spectral_norm_bwd kernels");
+}

@@ -154,3 +154,132 @@ def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False)
     _lib.check(lib.hrv_colsum_nhwc_f32(a.t.data_ptr(), P, a.C, a.cstride, a.coff, ws.data_ptr(), ws.numel() * 4,
                                        out.data_ptr(), 1 if accumulate else 0, _stream()), "hrv_colsum_nhwc_f32")
     return out
+
+
+# ---------------------------------------------------------------------------------------------
+# HBM-bound training kernels (train.hip)
+# ---------------------------------------------------------------------------------------------
+def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int = ACT_NONE, slope: float = 0.2,
+             out: Optional[Act] = None, g1p: Optional[Act] = None, z: Optional[torch.Tensor] = None,
+             noise_scale: Optional[torch.Tensor] = None, want_dgb: bool = False, dx: Optional[Act] = None,
+             dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False):
+    """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None)."""
+    lib = _lib.load()
+    N, H, W, Cp = x.N, x.H, x.W, x.Cp
+    dev = x.t.device
+    if dx is None:
+        dx = ops.alloc(N, H, W, x.C, dev)
+        dx_accumulate = False
+    dnh = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
+    dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.float32, device=dev), 2 * Cp) if want_dgb else None
+    ws = torch.empty(lib.hrv_norm_bwd_workspace_elems(N, H, W, Cp), dtype=torch.float32, device=dev)
+    d = _lib.hrv_norm_bwd_t()
+    d.N, d.H, d.W, d.C = N, H, W, Cp
+    d.x, d.x_cstride, d.x_coff = x.t.data_ptr(), x.cstride, x.coff
+    if z is not None:
+        d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
+    d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
+    if out is not None:
+        d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+    if g1p is not None:
+        d.g1p, d.g1p_cstride, d.g1p_coff = g1p.t.data_ptr(), g1p.cstride, g1p.coff
+    d.dout, d.dout_cstride, d.dout_coff = dout.t.data_ptr(), dout.cstride, dout.coff
+    d.dnh, d.dnh_cstride, d.dnh_coff = dnh.data_ptr(), Cp, 0
+    if dgb is not None:
+        d.dgb, d.dgb_cstride, d.dgb_coff = dgb.t.data_ptr(), 2 * Cp, 0
+    d.dx, d.dx_cstride, d.dx_coff = dx.t.data_ptr(), dx.cstride, dx.coff
+    d.dx_accumulate = 1 if dx_accumulate else 0
+    d.act, d.act_slope = act, slope
+    d.dns_accumulate = 1 if dns_accumulate else 0
+    d.dnoise_scale = None if dnoise_scale is None else dnoise_scale.data_ptr()
+    d.workspace = ws.data_ptr()
+    with _Timed("norm_bwd", "spade_norm_bwd", 0.0, 4.0 * N * H * W * Cp * (7 + (2 if want_dgb else 0))):
+        _lib.check(lib.hrv_spade_norm_bwd_nhwc_f32(C.byref(d), _stream()), "hrv_spade_norm_bwd_nhwc_f32")
+    return dx, dgb
+
+
+LOSS_L1, LOSS_HINGE_D_FAKE, LOSS_HINGE_D_REAL, LOSS_NEG_MEAN, LOSS_MSE = 0, 1, 2, 3, 4
+
+
+def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, gscale: float, loss_out: torch.Tensor,
+         accumulate: bool = True, want_grad: bool = True) -> Optional[torch.Tensor]:
+    """hrv_loss_f32 over flat contiguous tensors: loss_out[0] (+)= lscale*sum(l); returns grad (same shape as a)."""
+    lib = _lib.load()
+    assert a.is_contiguous() and (b is None or (b.is_contiguous() and b.numel() == a.numel()))
+    grad = torch.empty_like(a) if want_grad else None
+    ws = _workspace(a.device, 4096)
+    _lib.check(lib.hrv_loss_f32(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), mode, lscale, gscale,
+                                None if grad is None else grad.data_ptr(), ws.data_ptr(), loss_out.data_ptr(),
+                                1 if accumulate else 0, _stream()), "hrv_loss_f32")
+    return grad
+
+
+def downsum2x2(dhi: Act, dlo: Optional[Act] = None, accumulate: bool = False) -> Act:
+    lib = _lib.load()
+    Hl, Wl = dhi.H // 2, dhi.W // 2
+    if dlo is None:
+        dlo = ops.alloc(dhi.N, Hl, Wl, dhi.C, dhi.t.device)
+        accumulate = False
+    _lib.check(lib.hrv_downsum2x2_nhwc_f32(dhi.t.data_ptr(), dhi.N, Hl, Wl, dhi.Cp, dhi.cstride, dhi.coff,
+                                           dlo.t.data_ptr(), dlo.cstride, dlo.coff, 1 if accumulate else 0, _stream()),
+               "hrv_downsum2x2_nhwc_f32")
+    return dlo
+
+
+def avgpool3x3s2_bwd(dy: Act, H: int, W: int, dx: Optional[Act] = None, accumulate: bool = False) -> Act:
+    lib = _lib.load()
+    if dx is None:
+        dx = ops.alloc(dy.N, H, W, dy.C, dy.t.device)
+        accumulate = False
+    _lib.check(lib.hrv_avgpool3x3s2_bwd_nhwc_f32(dy.t.data_ptr(), dy.N, H, W, dy.Cp, dy.cstride, dy.coff,
+                                                 dx.t.data_ptr(), dx.cstride, dx.coff, 1 if accumulate else 0,
+                                                 _stream()), "hrv_avgpool3x3s2_bwd_nhwc_f32")
+    return dx
+
+
+def maxpool2x2(x: Act) -> Act:
+    lib = _lib.load()
+    assert x.coff == 0 and x.cstride == x.Cp
+    y = ops.alloc(x.N, x.H // 2, x.W // 2, x.C, x.t.device)
+    _lib.check(lib.hrv_maxpool2x2_nhwc_f32(x.t.data_ptr(), x.N, x.H, x.W, x.Cp, y.t.data_ptr(), _stream()),
+               "hrv_maxpool2x2_nhwc_f32")
+    return y
+
+
+def maxpool2x2_bwd(x: Act, dy: Act) -> Act:
+    lib = _lib.load()
+    dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
+    _lib.check(lib.hrv_maxpool2x2_bwd_nhwc_f32(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(),
+                                               _stream()), "hrv_maxpool2x2_bwd_nhwc_f32")
+    return dx
+
+
+def adam_step(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
+              eps: float, weight_decay: float, step: int, grad_scale: float = 1.0):
+    lib = _lib.load()
+    _lib.check(lib.hrv_adam_f32(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), lr, beta1, beta2, eps,
+                                weight_decay, step, grad_scale, _stream()), "hrv_adam_f32")
+
+
+def spectral_sigma(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, power_iterations: int,
+                   eps: float = 1e-12) -> torch.Tensor:
+    """In-place power iteration on (u, v) + sigma (device scalar tensor [1])."""
+    lib = _lib.load()
+    R = w_orig.shape[0]
+    K = w_orig.numel() // R
+    scratch = torch.empty(R, dtype=torch.float32, device=w_orig.device)
+    sigma = torch.empty(1, dtype=torch.float32, device=w_orig.device)
+    _lib.check(lib.hrv_spectral_norm_f32(w_orig.data_ptr(), R, K, u.data_ptr(), v.data_ptr(), power_iterations, eps,
+                                         scratch.data_ptr(), sigma.data_ptr(), _stream()), "hrv_spectral_norm_f32")
+    return sigma
+
+
+def spectral_grad(G: torch.Tensor, w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, sigma: torch.Tensor,
+                  out: torch.Tensor, accumulate: bool = False):
+    lib = _lib.load()
+    R = w_orig.shape[0]
+    K = w_orig.numel() // R
+    ws = _workspace(G.device, 8192)
+    _lib.check(lib.hrv_spectral_norm_bwd_f32(G.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(),
+                                             sigma.data_ptr(), R, K, ws.data_ptr(), out.data_ptr(),
+                                             1 if accumulate else 0, _stream()), "hrv_spectral_norm_bwd_f32")

@@ -95,6 +95,8 @@ typedef struct hrv_spade_epi {
   const float* noise_z;     /* [N][W][H] N(0,1) draw, layout of torch.randn(b,w,h,1)
                                (network_generator.py:104-107), or NULL        */
   const float* noise_scale; /* [C] or NULL */
+  float* g1p_out;      /* training: (1 + gamma) is also stored here, NHWC [.,C] dense
+                          (needed by hrv_spade_norm_bwd_nhwc_f32), or NULL          */
 } hrv_spade_epi_t;
 
 typedef struct hrv_conv2d {
@@ -178,6 +180,66 @@ int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_co
                               int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, hrv_stream_t stream);
 int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,
                         int64_t workspace_bytes, float* out, int32_t accumulate, hrv_stream_t stream);
+
+/* ---- training side, HBM-bound kernels (train.hip) -------------------------
+ * SPADE / InstanceNorm backward (network_generator.py:101-122 + LeakyReLU :170-171;
+ * PatchGAN IN+LeakyReLU :263-272) for
+ *     v = x + noise_z*noise_scale;  nh = (v - mean)*rstd;  out = act(nh*g1p + beta)
+ * given dout:  dpre = dout*act'(out); dnh = dpre*g1p; dgamma = dpre*nh; dbeta = dpre;
+ *     dx = rstd*(dnh - mean_hw(dnh) - nh*mean_hw(dnh*nh));  dnoise_scale = sum dx*z.
+ * g1p = 1+gamma (NULL: plain InstanceNorm, dgb must be NULL); dgb receives
+ * [dgamma | dbeta] (2C channels); dnh is a C-channel scratch/output tensor.
+ * workspace: hrv_norm_bwd_workspace_elems floats.  Deterministic (2-stage sums). */
+typedef struct hrv_norm_bwd {
+  int32_t N, H, W, C;
+  const float* x;     int32_t x_cstride, x_coff;
+  const float* noise_z; const float* noise_scale;      /* nullable (together) */
+  const float* mean;  const float* rstd;               /* [N][C] */
+  const float* out;   int32_t out_cstride, out_coff;   /* activation output (its mask) */
+  const float* g1p;   int32_t g1p_cstride, g1p_coff;   /* 1+gamma, nullable */
+  const float* dout;  int32_t dout_cstride, dout_coff;
+  float* dnh;         int32_t dnh_cstride, dnh_coff;
+  float* dgb;         int32_t dgb_cstride, dgb_coff;   /* nullable */
+  float* dx;          int32_t dx_cstride, dx_coff;
+  int32_t dx_accumulate;                               /* 1: dx += ... */
+  int32_t act;        float act_slope;
+  int32_t dns_accumulate;
+  float* dnoise_scale;                                 /* [C], nullable */
+  float* workspace;
+} hrv_norm_bwd_t;
+int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
+int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);
+/* Loss value + gradient in one pass.  mode 0: L1 |a-b| (feature matching / VGG,
+ * train_generator.py:300-312); 1: hinge-D fake max(1+a,0); 2: hinge-D real max(1-a,0);
+ * 3: -a (generator hinge) (network_generator.py:365-376); 4: (a-b)^2 (LSGAN, networks.py:258-299).
+ * loss_out[0] (+)= lscale*sum(l);  grad[i] = gscale*dl/da (grad may be NULL).
+ * workspace: 1024 floats. */
+int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t mode, float lscale, float gscale, float* grad,
+                 float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream);
+/* nn.Upsample(nearest, x2) backward: dlo (+)= 2x2 block sums of dhi. */
+int hrv_downsum2x2_nhwc_f32(const float* dhi, int32_t N, int32_t Hl, int32_t Wl, int32_t C, int32_t hi_cstride,
+                            int32_t hi_coff, float* dlo, int32_t lo_cstride, int32_t lo_coff, int32_t accumulate,
+                            hrv_stream_t stream);
+int hrv_avgpool3x3s2_bwd_nhwc_f32(const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, int32_t dy_cstride,
+                                  int32_t dy_coff, float* dx, int32_t dx_cstride, int32_t dx_coff, int32_t accumulate,
+                                  hrv_stream_t stream);
+/* VGG19 2x2/2 max pool (networks.py:201-232 via torchvision cfg 'E'), dense NHWC. */
+int hrv_maxpool2x2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, hrv_stream_t stream);
+int hrv_maxpool2x2_bwd_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx,
+                                hrv_stream_t stream);
+/* torch.optim.Adam step over one flat buffer (train_generator.py:154-157,322,360);
+ * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
+int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
+                 float weight_decay, int32_t step, float grad_scale, hrv_stream_t stream);
+/* torch spectral_norm (SpectralNorm.compute_weight): `power_iterations` rounds of
+ * v<-normalize(W^T u), u<-normalize(W v) in place (eps 1e-12), then sigma = u.(W v).
+ * W is [R][K] = weight_orig.reshape(Cout,-1); wv_scratch holds R floats.
+ * bwd: dW_orig (+)= (G - <G,W_orig>/sigma * u v^T)/sigma; workspace 1024 floats. */
+int hrv_spectral_norm_f32(const float* w, int32_t R, int32_t K, float* u, float* v, int32_t power_iterations, float eps,
+                          float* wv_scratch, float* sigma_out, hrv_stream_t stream);
+int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* u, const float* v, const float* sigma,
+                              int32_t R, int32_t K, float* workspace, float* dw_orig, int32_t accumulate,
+                              hrv_stream_t stream);
 
 /* Scratch the engine would like for this launch (0: none).  Layers with fewer than
  * ~192 output tiles split their K range over up to 32 blocks per tile (partials in

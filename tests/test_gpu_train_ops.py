@@ -114,3 +114,124 @@ def test_wgrad_nearest_upsampled_source():
     T.conv_wgrad(dya, ops.to_nhwc(xp.cuda()), 1, 0, 48, 3, 3, 1, 1, dw)
     T.conv_wgrad(dya, ops.to_nhwc(ft.cuda()), 0, 32, 48, 3, 3, 1, 1, dw)
     assert _rel(dw, w.grad) < 5e-5
+
+
+@pytest.mark.parametrize("C,H,W,noise,spade", [(32, 12, 10, True, True), (80, 9, 7, False, True), (64, 17, 13, False, False),
+                                               (20, 33, 5, True, True)])
+def test_spade_norm_backward_vs_autograd(C, H, W, noise, spade):
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(C + H)
+    N = 2
+    x = (torch.randn(N, C, H, W, generator=g) * 2 + 1).requires_grad_()
+    ns = (torch.randn(C, generator=g) * 0.5).requires_grad_() if noise else None
+    z = torch.randn(N, W, H, 1, generator=g) if noise else None
+    gamma = torch.randn(N, C, H, W, generator=g, requires_grad=True) if spade else None
+    beta = torch.randn(N, C, H, W, generator=g, requires_grad=True) if spade else None
+    v = x + ((z * ns).transpose(1, 3) if noise else 0)
+    mean = v.mean(dim=(2, 3), keepdim=True)
+    var = v.var(dim=(2, 3), unbiased=False, keepdim=True)
+    nh = (v - mean) / torch.sqrt(var + 1e-5)
+    pre = nh * (1 + gamma) + beta if spade else nh
+    out = F.leaky_relu(pre, 0.2)
+    dout = torch.randn(out.shape, generator=g)
+    out.backward(dout)
+    # ---- HIP
+    xa = ops.to_nhwc(x.detach().cuda())
+    zc = z.cuda().contiguous() if noise else None
+    nsc = ns.detach().cuda() if noise else None
+    mu, rs = ops.instnorm_stats(xa, zc, nsc)
+    dns = torch.zeros(C, device="cuda") if noise else None
+    dx, dgb = T.norm_bwd(xa, mu, rs, ops.to_nhwc(dout.cuda()), act=ops.ACT_LRELU, slope=0.2,
+                         out=ops.to_nhwc(out.detach().cuda()),
+                         g1p=ops.to_nhwc((1 + gamma).detach().cuda()) if spade else None, z=zc, noise_scale=nsc,
+                         want_dgb=spade, dnoise_scale=dns)
+    assert _rel(ops.to_nchw(dx), x.grad) < 5e-5, _rel(ops.to_nchw(dx), x.grad)
+    if spade:
+        assert _rel(ops.to_nchw(dgb, 0, C), gamma.grad) < 2e-5
+        assert _rel(ops.to_nchw(dgb, C, C), beta.grad) < 2e-5
+    if noise:
+        assert _rel(dns, ns.grad) < 5e-5
+
+
+def test_losses_value_and_gradient():
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(3, 5, 17, 11, generator=g, requires_grad=True)
+    b = torch.randn(3, 5, 17, 11, generator=g)
+    n = a.numel()
+    cases = [(T.LOSS_L1, lambda: (a - b).abs().mean()), (T.LOSS_HINGE_D_FAKE, lambda: -torch.min(-a - 1, torch.zeros(1)).mean()),
+             (T.LOSS_HINGE_D_REAL, lambda: -torch.min(a - 1, torch.zeros(1)).mean()), (T.LOSS_NEG_MEAN, lambda: -a.mean()),
+             (T.LOSS_MSE, lambda: ((a - b) ** 2).mean())]
+    for mode, fn in cases:
+        a.grad = None
+        want = fn()
+        want.backward()
+        lo = torch.zeros(1, device="cuda")
+        grad = T.loss(a.detach().cuda().contiguous(), b.cuda().contiguous(), mode, 1.0 / n, 1.0 / n, lo, accumulate=False)
+        assert abs(lo.item() - want.item()) < 1e-5 * max(1.0, abs(want.item())), (mode, lo.item(), want.item())
+        assert _rel(grad, a.grad) < 1e-6, mode
+
+
+def test_downsum_avgpool_maxpool_backward():
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(2, 8, 6, 5, generator=g, requires_grad=True)
+    up = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+    d = torch.randn(up.shape, generator=g)
+    up.backward(d)
+    assert _rel(ops.to_nchw(T.downsum2x2(ops.to_nhwc(d.cuda()))), x.grad) < 1e-6
+    for shape in [(2, 12, 9, 7), (1, 8, 16, 12), (2, 4, 5, 5)]:
+        x = torch.randn(*shape, generator=g, requires_grad=True)
+        y = F.avg_pool2d(x, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)
+        d = torch.randn(y.shape, generator=g)
+        y.backward(d)
+        got = T.avgpool3x3s2_bwd(ops.to_nhwc(d.cuda()), shape[2], shape[3])
+        assert _rel(ops.to_nchw(got), x.grad) < 1e-6
+    x = torch.randn(2, 16, 12, 8, generator=g, requires_grad=True)
+    y = F.max_pool2d(x, 2, 2)
+    d = torch.randn(y.shape, generator=g)
+    y.backward(d)
+    xa = ops.to_nhwc(x.detach().cuda())
+    assert torch.equal(ops.to_nchw(T.maxpool2x2(xa)).cpu(), y.detach())
+    assert torch.equal(ops.to_nchw(T.maxpool2x2_bwd(xa, ops.to_nhwc(d.cuda()))).cpu(), x.grad)
+
+
+def test_adam_matches_torch():
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(3)
+    w = torch.randn(1000, generator=g)
+    p = torch.nn.Parameter(w.clone())
+    opt = torch.optim.Adam([p], lr=2e-4, betas=(0.0, 0.9))
+    wd, m, v = w.clone().cuda(), torch.zeros(1000, device="cuda"), torch.zeros(1000, device="cuda")
+    for step in range(1, 4):
+        gr = torch.randn(1000, generator=g)
+        p.grad = gr.clone()
+        opt.step()
+        T.adam_step(wd, gr.cuda(), m, v, 2e-4, 0.0, 0.9, 1e-8, 0.0, step)
+        assert _rel(wd, p.detach()) < 1e-6
+
+
+def test_spectral_norm_power_iteration_and_gradient():
+    ops, T = _mods()
+    from torch.nn.utils import spectral_norm
+    torch.manual_seed(4)
+    conv = spectral_norm(torch.nn.Conv2d(20, 24, 3, padding=1))
+    w0 = conv.weight_orig.detach().clone()
+    u0, v0 = conv.weight_u.clone(), conv.weight_v.clone()
+    x = torch.randn(2, 20, 8, 6)
+    conv.train()
+    y = conv(x)                      # one power iteration (in place on u, v), then W/sigma
+    dy = torch.randn_like(y)
+    y.backward(dy)
+    # ---- HIP: same iteration from the same starting u, v
+    wc, uc, vc = w0.cuda(), u0.cuda(), v0.cuda()
+    sigma = T.spectral_sigma(wc, uc, vc, 1)
+    assert _rel(uc, conv.weight_u) < 1e-5 and _rel(vc, conv.weight_v) < 1e-5
+    w_sn = w0 / sigma.cpu()
+    assert _rel(w_sn, conv.weight.detach()) < 1e-5
+    # G = dL/dW_sn from our wgrad; transform to dW_orig
+    G = torch.empty_like(wc)
+    T.conv_wgrad(ops.to_nhwc(dy.cuda()), ops.to_nhwc(x.cuda()), 0, 0, 20, 3, 3, 1, 1, G)
+    dwo = torch.empty_like(wc)
+    T.spectral_grad(G, wc, uc, vc, sigma, dwo)
+    assert _rel(dwo, conv.weight_orig.grad) < 1e-4, _rel(dwo, conv.weight_orig.grad)
