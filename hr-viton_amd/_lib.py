@@ -76,7 +76,7 @@ SYMBOLS = {
     "hrv_conv2d_packed_elems": (_i64, [_i32, _i32, _i32, _i32, _ip, _i32]),
     "hrv_conv2d_pack_weight_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _vp]),
     "hrv_conv2d_pack_weight_dev_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _i32, _i32, _i32,
-                                                 _i32, _f, _vp, _ip, _vp]),
+                                                 _i32, _f, _vp, _vp, _ip, _vp]),
     "hrv_conv2d_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i64]),
     "hrv_conv2d_wgrad_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32,
@@ -85,6 +85,10 @@ SYMBOLS = {
     "hrv_norm_bwd_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "hrv_spade_norm_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), _vp]),
     "hrv_loss_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f, _f, _vp, _vp, _vp, _i32, _vp]),
+    "hrv_scale_f32": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
+    "hrv_act_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _f, _vp]),
+    "hrv_tanh_bwd_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "hrv_add_slice_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "hrv_downsum2x2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "hrv_avgpool3x3s2_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "hrv_maxpool2x2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -32,11 +32,13 @@ struct PackParams {
   int kh_of[8], kw_of[8];  // packed tap -> weight tap (or -1: absent)
   int rows, rows_pad;    // output rows (Cout or CinTot) and their padded count
   float wscale;
+  const float* sigma;    // optional device scalar: weights are divided by sigma[0] (spectral norm)
   float* out;            // [KHp*KWp*chunks_total][rows_pad][16]
 };
 
 __global__ void pack_weight_kernel(const PackParams p) {
   const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % BK);
     const size_t t = i / BK;
@@ -56,7 +58,7 @@ __global__ void pack_weight_kernel(const PackParams p) {
         const int cc = p.src_cbase[s] + c;
         const int co = p.transposed ? cc : row;
         const int ci = p.transposed ? row : cc;
-        v = p.w[(((size_t)co * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * p.wscale;
+        v = p.w[(((size_t)co * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
       }
     }
     p.out[i] = v;
@@ -287,8 +289,9 @@ using namespace hrv;
 extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW,
                                               int32_t nsrc, const int32_t* srcC, const int32_t* srcC_real,
                                               int32_t tile_cfg, int32_t mode, int32_t stride, int32_t pad,
-                                              int32_t phase_a, int32_t phase_b, float wscale, float* out_dev,
-                                              int32_t* out_geom, hrv_stream_t stream) {
+                                              int32_t phase_a, int32_t phase_b, float wscale,
+                                              const float* sigma_dev, float* out_dev, int32_t* out_geom,
+                                              hrv_stream_t stream) {
   HRV_REQUIRE(w_oihw_dev && out_dev && srcC && srcC_real && nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_dev: bad args");
   const int bn = hrv_conv2d_tile_bn(tile_cfg);
   HRV_REQUIRE(bn > 0, "pack_dev: bad tile_cfg %d", tile_cfg);
@@ -296,7 +299,7 @@ extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t C
   HRV_REQUIRE(KH <= 8 && KW <= 8, "pack_dev: kernel too large");
   PackParams p;
   memset(&p, 0, sizeof(p));
-  p.w = w_oihw_dev; p.Cout = Cout; p.KH = KH; p.KW = KW; p.wscale = wscale; p.out = out_dev;
+  p.w = w_oihw_dev; p.Cout = Cout; p.KH = KH; p.KW = KW; p.wscale = wscale; p.sigma = sigma_dev; p.out = out_dev;
   int cin = 0;
   for (int i = 0; i < nsrc; ++i) cin += srcC_real[i];
   p.CinTot = cin;

@@ -219,6 +219,49 @@ __global__ void loss_final_kernel(const float* __restrict__ part, int nb, float 
   }
 }
 
+// x *= s_host * (s_dev ? s_dev[0] : 1)   (upstream loss-gradient scalar without a host sync)
+__global__ void scale_kernel(float* __restrict__ x, size_t n, float s_host, const float* __restrict__ s_dev) {
+  const float s = s_dev ? s_host * s_dev[0] : s_host;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) x[i] *= s;
+}
+
+// out = dy * (1 - y*y)   (tanh backward through its output)   /   out (+)= a  (gradient accumulation)
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, size_t n, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float t = y[i];
+    out[i] = dy[i] * (1.f - t * t);
+  }
+}
+
+// d <- d * act'(y)  in place (activation derivative through the activation's output)
+__global__ void act_bwd_kernel(float* __restrict__ d, int dcs, int dco, const float* __restrict__ y, int ycs, int yco, int C4,
+                               size_t npix, int act, float slope) {
+  const size_t total = npix * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    float* o = d + pix * dcs + dco + g * 4;
+    f32x4 v = ld4(o);
+    const f32x4 yy = ld4(y + pix * ycs + yco + g * 4);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= dact(yy[e], act, slope);
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
+__global__ void add_slice_kernel(const float* __restrict__ a, int acs, int aco, float* __restrict__ out, int ocs, int oco,
+                                 int C4, size_t npix, int accumulate) {
+  const size_t total = npix * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    f32x4 v = ld4(a + pix * acs + aco + g * 4);
+    float* o = out + pix * ocs + oco + g * 4;
+    if (accumulate) v += ld4(o);
+    *reinterpret_cast<f32x4*>(o) = v;
+  }
+}
+
 // ---------------------------------------------------------------------------
 // nearest-x2 upsample backward: dlo[n,h,w,c] = sum of the 2x2 block of dhi
 // ---------------------------------------------------------------------------
@@ -571,4 +614,35 @@ extern "C" int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, co
   hipLaunchKernelGGL(sn_grad_kernel, dim3(grid_for(n)), dim3(256), 0, st, G, u, v, workspace + 512, sigma, R, K, dw_orig,
                      accumulate);
   return check_launch("spectral_norm_bwd kernels");
+}
+
+extern "C" int hrv_tanh_bwd_f32(const float* dy, const float* y, int64_t n, float* out, hrv_stream_t stream) {
+  HRV_REQUIRE(dy && y && out && n > 0, "tanh_bwd: bad args");
+  hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, dy, y, (size_t)n, out);
+  return check_launch("tanh_bwd_kernel");
+}
+
+extern "C" int hrv_add_slice_nhwc_f32(const float* a, int32_t a_cstride, int32_t a_coff, float* out, int32_t out_cstride,
+                                      int32_t out_coff, int32_t C, int64_t npix, int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(a && out && npix > 0 && C > 0 && C % 4 == 0 && ((a_cstride | a_coff | out_cstride | out_coff) & 3) == 0,
+              "add_slice: bad args");
+  hipLaunchKernelGGL(add_slice_kernel, dim3(grid_for((size_t)npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, a,
+                     a_cstride, a_coff, out, out_cstride, out_coff, C / 4, (size_t)npix, accumulate);
+  return check_launch("add_slice_kernel");
+}
+
+extern "C" int hrv_act_bwd_nhwc_f32(float* d, int32_t d_cstride, int32_t d_coff, const float* y, int32_t y_cstride,
+                                    int32_t y_coff, int32_t C, int64_t npix, int32_t act, float act_slope,
+                                    hrv_stream_t stream) {
+  HRV_REQUIRE(d && y && npix > 0 && C > 0 && C % 4 == 0 && ((d_cstride | d_coff | y_cstride | y_coff) & 3) == 0,
+              "act_bwd: bad args");
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for((size_t)npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, d, d_cstride,
+                     d_coff, y, y_cstride, y_coff, C / 4, (size_t)npix, act, act_slope);
+  return check_launch("act_bwd_kernel");
+}
+
+extern "C" int hrv_scale_f32(float* x, int64_t n, float s_host, const float* s_dev, hrv_stream_t stream) {
+  HRV_REQUIRE(x && n > 0, "scale: bad args");
+  hipLaunchKernelGGL(scale_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, x, (size_t)n, s_host, s_dev);
+  return check_launch("scale_kernel");
 }

@@ -1,0 +1,453 @@
+"""Training-mode forward/backward of the SPADE generator and its PatchGAN on the HIP
+path (train_generator.py:279-360).  Every module call is ONE ``torch.autograd.Function``
+whose backward is a hand-written plan over the training kernels (train_ops.py):
+torch.autograd only stitches the module-level graph of the reference's training
+script (torch.cat of images, loss sums); no per-op autograd, no torch compute.
+
+Forward saves, per SPADENorm: its input, (mean, rstd), the noise draw, the 128-ch
+``actv``, (1+gamma) and its activated output; per conv: its sources.  Backward walks the
+blocks in reverse: conv wgrad / dgrad (MFMA), SPADE + InstanceNorm backward, the 2x2
+down-sum of the fused nearest-upsample store, spectral-norm gradient transform.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import train_ops as T
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, Act, _ceil4
+
+Grads = Dict[nn.Parameter, torch.Tensor]
+
+
+def _acc(grads: Grads, p: nn.Parameter, g: torch.Tensor):
+    grads[p] = g if p not in grads else grads[p] + g
+
+
+class TConv:
+    """A trainable (optionally spectral-normalised) convolution of the plan."""
+
+    def __init__(self, conv: nn.Module, stride: int, pad: int, name: str):
+        self.conv, self.stride, self.pad, self.name = conv, stride, pad, name
+        self.spectral = hasattr(conv, "weight_orig")
+        self.sigma: Optional[torch.Tensor] = None
+
+    @property
+    def wparam(self) -> nn.Parameter:
+        return self.conv.weight_orig if self.spectral else self.conv.weight
+
+    @property
+    def bparam(self) -> Optional[nn.Parameter]:
+        return getattr(self.conv, "bias", None)
+
+    def prepare(self, power_iteration: bool):
+        """torch SpectralNorm.compute_weight: one in-place power iteration on (u, v) when the
+        module is in training mode, then sigma (kept on the device)."""
+        if self.spectral:
+            self.sigma = T.spectral_sigma(self.wparam.data, self.conv.weight_u, self.conv.weight_v,
+                                          1 if power_iteration else 0)
+            # keep the (u, v) that produced sigma: the backward treats them as constants
+            self.u, self.v = self.conv.weight_u.clone(), self.conv.weight_v.clone()
+
+    def forward(self, srcs: Sequence[Tuple[Act, int]], act: int = ACT_NONE, residual: Optional[Act] = None,
+                out: Optional[Act] = None, out_up: int = 0, slope: float = 0.2) -> Act:
+        b = self.bparam
+        return T.conv_forward_dev(self.wparam.data, srcs, self.stride, self.pad, sigma=self.sigma,
+                                  shift=None if b is None else b.data, residual=residual, act=act, slope=slope, out=out,
+                                  out_up=out_up, name=self.name)
+
+    def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
+                 act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True) -> Optional[Act]:
+        w = self.wparam.data
+        Cout, cin, KH, KW = w.shape
+        if need_w:
+            G = torch.empty_like(w)
+            base = 0
+            for a, up in srcs:
+                T.conv_wgrad(dy, a, up, base, cin, KH, KW, self.stride, self.pad, G, name=self.name + ".wgrad")
+                base += a.C
+            if self.spectral:
+                dwo = torch.empty_like(w)
+                T.spectral_grad(G, w, self.u, self.v, self.sigma, dwo)
+                _acc(grads, self.wparam, dwo)
+            else:
+                _acc(grads, self.wparam, G)
+            if self.bparam is not None:
+                _acc(grads, self.bparam, T.colsum(dy))
+        if not need_dx:
+            return None
+        a0, up0 = srcs[0]
+        H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
+        return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope,
+                            name=self.name + ".dgrad")
+
+
+class SpadeT:
+    """One SPADENorm (+ optional LeakyReLU) in training mode."""
+
+    def __init__(self, norm: nn.Module, act: int, name: str):
+        self.norm, self.act, self.name = norm, act, name
+        self.shared = TConv(norm.conv_shared[0], 1, 1, name + ".conv_shared")
+        self.C = norm.conv_gamma.out_channels
+        self.Cp = _ceil4(self.C)
+        self.hid = norm.conv_gamma.in_channels
+        G = (self.C + 31) // 32
+        self.G = G
+        self.cfg = 0 if G % 2 == 0 else 6
+        dev = norm.conv_gamma.weight.device
+        rows_g = torch.tensor([g * 64 + l for g in range(G) for l in range(32) if g * 32 + l < self.C], device=dev)
+        self.rows_g, self.rows_b = rows_g, rows_g + 32
+
+    def forward(self, x: Act, seg: Act, seg_shift: int, z: Optional[torch.Tensor]):
+        n = self.norm
+        dev = x.t.device
+        ns = torch.zeros(self.Cp, device=dev)
+        ns[: self.C] = n.noise_scale.data
+        zz = z  # the noise term is always applied in training (noise_scale is a learnable parameter)
+        mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
+        actv = self.shared.forward([(seg, -seg_shift)], act=ACT_RELU)
+        # combined (gamma32 | beta32) weight / bias for the fused modulate epilogue (device gather)
+        wc = torch.zeros((self.G * 64, self.hid, 3, 3), device=dev)
+        wc.index_copy_(0, self.rows_g, n.conv_gamma.weight.data)
+        wc.index_copy_(0, self.rows_b, n.conv_beta.weight.data)
+        bc = torch.zeros(self.G * 64, device=dev)
+        bc.index_copy_(0, self.rows_g, n.conv_gamma.bias.data)
+        bc.index_copy_(0, self.rows_b, n.conv_beta.bias.data)
+        packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], self.cfg, 0, 1, 1)
+        out = ops.alloc(x.N, x.H, x.W, self.C, dev)
+        g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev)
+        e = ops._lib.hrv_spade_epi_t()
+        e.x, e.x_cstride, e.x_coff, e.C = x.t.data_ptr(), x.cstride, x.coff, self.Cp
+        e.mean, e.rstd = mean.data_ptr(), rstd.data_ptr()
+        if zz is not None:
+            e.noise_z, e.noise_scale = zz.data_ptr(), ns.data_ptr()
+        e.g1p_out = g1p.data_ptr()
+        import ctypes as C
+        lib = ops._lib.load()
+        d = ops._lib.hrv_conv2d_t()
+        d.N, d.H, d.W, d.Ho, d.Wo = x.N, x.H, x.W, x.H, x.W
+        d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
+        d.nsrc = 1
+        s = d.src[0]
+        s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = actv.t.data_ptr(), self.hid, actv.cstride, 0, 0, 0, self.hid
+        d.w_packed, d.Cout, d.tile_cfg = packed.data_ptr(), self.G * 64, self.cfg
+        d.shift = bc.data_ptr()
+        d.act, d.act_slope = self.act, 0.2
+        d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+        d.spade = C.pointer(e)
+        fl = 2.0 * x.N * x.H * x.W * 2 * self.C * self.hid * 9
+        with ops._Timed("conv", self.name + ".conv_gamma|beta", fl, 0):
+            ops._lib.check(lib.hrv_conv2d_nhwc_f32(C.byref(d), ops._stream()), "hrv_conv2d_nhwc_f32[spade]")
+        ctx = dict(x=x, seg=seg, seg_shift=seg_shift, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv,
+                   g1p=Act(g1p, self.C), out=out)
+        return out, ctx
+
+    def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool) -> Act:
+        n = self.norm
+        C_, Cp = self.C, self.Cp
+        dev = dout.t.device
+        dns = torch.empty(Cp, device=dev) if ctx["z"] is not None else None
+        dx, dgb = T.norm_bwd(ctx["x"], ctx["mean"], ctx["rstd"], dout, act=self.act, slope=0.2,
+                             out=ctx["out"] if self.act != ACT_NONE else None, g1p=ctx["g1p"], z=ctx["z"],
+                             noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dx=dx,
+                             dx_accumulate=dx_accumulate, dnoise_scale=dns)
+        if dns is not None:
+            _acc(grads, n.noise_scale, dns[:C_].clone())
+        else:
+            _acc(grads, n.noise_scale, torch.zeros(C_, device=dev))
+        # gamma/beta convs: one conv with Wcat = [Wgamma ; Wbeta] over dgb = [dgamma | dbeta]
+        actv = ctx["actv"]
+        wcat = torch.zeros((2 * Cp, self.hid, 3, 3), device=dev)
+        wcat[:C_] = n.conv_gamma.weight.data
+        wcat[Cp:Cp + C_] = n.conv_beta.weight.data
+        dwcat = torch.empty_like(wcat)
+        T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad")
+        _acc(grads, n.conv_gamma.weight, dwcat[:C_].clone())
+        _acc(grads, n.conv_beta.weight, dwcat[Cp:Cp + C_].clone())
+        db = T.colsum(dgb)
+        _acc(grads, n.conv_gamma.bias, db[:C_].clone())
+        _acc(grads, n.conv_beta.bias, db[Cp:Cp + C_].clone())
+        # d actv, with the ReLU derivative of conv_shared fused (slope 0)
+        dact = T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, name=self.name + ".gb.dgrad")
+        self.shared.backward(dact, [(ctx["seg"], -ctx["seg_shift"])], grads, need_dx=False)
+        return dx
+
+
+class BlockT:
+    def __init__(self, blk: nn.Module, name: str):
+        self.blk, self.name = blk, name
+        self.learned = blk.learned_shortcut
+        self.n0 = SpadeT(blk.norm_0, ACT_LRELU, name + ".norm_0")
+        self.n1 = SpadeT(blk.norm_1, ACT_LRELU, name + ".norm_1")
+        self.c0 = TConv(blk.conv_0, 1, 1, name + ".conv_0")
+        self.c1 = TConv(blk.conv_1, 1, 1, name + ".conv_1")
+        if self.learned:
+            self.ns_ = SpadeT(blk.norm_s, ACT_NONE, name + ".norm_s")
+            self.cs = TConv(blk.conv_s, 1, 0, name + ".conv_s")
+
+    def convs(self):
+        return [self.c0, self.c1] + ([self.cs] if self.learned else [])
+
+    def forward(self, x: Act, seg: Act, seg_shift: int, zs, out: Optional[Act], out_up: int, out_act: int):
+        zi = iter(zs)
+        ctx = {"x": x}
+        if self.learned:
+            hs, ctx["ns"] = self.ns_.forward(x, seg, seg_shift, next(zi))
+            x_s = self.cs.forward([(hs, 0)])
+            ctx["hs"] = hs
+        else:
+            x_s = x
+        h0, ctx["n0"] = self.n0.forward(x, seg, seg_shift, next(zi))
+        dx = self.c0.forward([(h0, 0)])
+        h1, ctx["n1"] = self.n1.forward(dx, seg, seg_shift, next(zi))
+        o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up)
+        ctx.update(h0=h0, h1=h1)
+        return o, ctx
+
+    def backward(self, ctx, d_out: Act, grads: Grads) -> Act:
+        """d_out: gradient w.r.t. the block's PRE-activation output (x_s + conv_1(...)) at block resolution."""
+        x = ctx["x"]
+        d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads)
+        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False)
+        d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads)
+        d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False)
+        if self.learned:
+            d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads)
+            self.ns_.backward(ctx["ns"], d_hs, grads, d_x, True)
+        else:
+            T.add_slice(d_out, d_x, True)
+        return d_x
+
+
+class GeneratorTrainPlan:
+    def __init__(self, gen: nn.Module):
+        self.gen = gen
+        names = gen._blocks()
+        self.names = names
+        self.blocks = [BlockT(getattr(gen, n), n) for n in names]
+        self.stems = [TConv(getattr(gen, f"conv_{i}"), 1, 1, f"conv_{i}") for i in range(len(names))]
+        self.img = TConv(gen.conv_img, 1, 1, "conv_img")
+
+    def forward(self, x: torch.Tensor, seg, noise, power_iteration: bool):
+        gen = self.gen
+        N, _, H, W = x.shape
+        nb = len(self.names)
+        top = nb - 1
+        dev = x.device
+        for b in self.blocks:
+            for c in b.convs():
+                c.prepare(power_iteration)
+        xin = ops.to_nhwc(x)
+        sg = seg if isinstance(seg, Act) else ops.to_nhwc(seg)
+        ctxs = []
+        cur = None
+        for j, name in enumerate(self.names):
+            blk = self.blocks[j]
+            h, w = gen.sh << j, gen.sw << j
+            shift = top - j
+            cin = getattr(gen, name).input_nc
+            if j == 0:
+                cur = self.stems[0].forward([(xin, -shift)])
+            else:
+                self.stems[j].forward([(xin, -shift)], out=cur.slice(cin - 16, 16))
+            k = 3 if blk.learned else 2
+            zs = [z.to(dev).contiguous() for z in noise[name]] if noise is not None else \
+                [torch.randn(N, w, h, 1, device=dev) for _ in range(k)]
+            if j == nb - 1:
+                o, c = blk.forward(cur, sg, shift, zs, None, 0, ACT_LRELU)
+            else:
+                nxt_c = getattr(gen, self.names[j + 1]).input_nc
+                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)
+                o, c = blk.forward(cur, sg, shift, zs, nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
+                o = nxt
+            c["shift"] = shift
+            ctxs.append(c)
+            cur = o
+        img = self.img.forward([(cur, 0)], act=ACT_TANH)
+        return ops.to_nchw(img), dict(blocks=ctxs, last=cur, img=img, xin=xin)
+
+    def backward(self, ctx, d_img: torch.Tensor) -> Grads:
+        grads: Grads = {}
+        gen = self.gen
+        img: Act = ctx["img"]
+        dimg = ops.to_nhwc(d_img.contiguous())
+        dpre = Act(T.tanh_bwd(dimg.t, img.t), 3)
+        # conv_img reads lrelu(x_last): its dgrad carries that LeakyReLU's derivative
+        d_cur = self.img.backward(dpre, [(ctx["last"], 0)], grads, act_mask=ctx["last"], slope=0.2)
+        xin = ctx["xin"]
+        for j in range(len(self.names) - 1, -1, -1):
+            blk, c = self.blocks[j], ctx["blocks"][j]
+            d_x = blk.backward(c, d_cur, grads)
+            cin = getattr(gen, self.names[j]).input_nc
+            if j == 0:
+                self.stems[0].backward(d_x, [(xin, -c["shift"])], grads, need_dx=False)
+            else:
+                self.stems[j].backward(d_x.slice(cin - 16, 16), [(xin, -c["shift"])], grads, need_dx=False)
+                d_cur = T.downsum2x2(d_x.slice(0, cin - 16))
+        return grads
+
+
+class _GenFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, gen, plan, x, seg, noise, *params):
+        out, saved = plan.forward(x, seg, noise, power_iteration=True)
+        ctx.plan, ctx.saved, ctx.params = plan, saved, params
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        grads = ctx.plan.backward(ctx.saved, d_out)
+        ctx.saved = None
+        return (None, None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+def generator_train_forward(gen: nn.Module, x: torch.Tensor, seg, noise=None) -> torch.Tensor:
+    ops.require_cuda(x, "SPADEGenerator.forward(x)")
+    plan = getattr(gen, "_train_plan", None)
+    if plan is None:
+        plan = gen._train_plan = GeneratorTrainPlan(gen)
+    params = [p for p in gen.parameters()]
+    if not torch.is_grad_enabled():
+        # train-mode forward under no_grad (train_generator.py:327-330): same math, incl. the
+        # spectral-norm power iteration, nothing saved
+        out, _ = plan.forward(x, seg, noise, power_iteration=True)
+        return out
+    return _GenFn.apply(gen, plan, x, seg, noise, *params)
+
+
+# ----------------------------------------------------------------------------
+# PatchGAN (network_generator.py:250-316)
+# ----------------------------------------------------------------------------
+class DiscTrainPlan:
+    """One NLayerDiscriminator: conv0+lrelu, [SNconv, IN, lrelu] x (n_layers-1), conv_last."""
+
+    def __init__(self, D: nn.Module, name: str):
+        self.D = D
+        self.layers = []
+        for n in range(D.n_models):
+            m = getattr(D, "model" + str(n))
+            first = m[0]
+            if isinstance(first, nn.Sequential):
+                conv = first[0]
+                self.layers.append(("in", TConv(conv, conv.stride[0], conv.padding[0], f"{name}.model{n}")))
+            else:
+                self.layers.append(("lrelu" if len(m) > 1 else "plain",
+                                    TConv(first, first.stride[0], first.padding[0], f"{name}.model{n}")))
+
+    def forward(self, a: Act, power_iteration: bool):
+        feats, ctx = [], []
+        for kind, conv in self.layers:
+            conv.prepare(power_iteration)
+            if kind == "in":
+                c = conv.forward([(a, 0)])
+                mean, rstd = ops.instnorm_stats(c)
+                f = ops.instnorm_apply(c, mean, rstd, ACT_LRELU, 0.2)
+                ctx.append(dict(src=a, c=c, mean=mean, rstd=rstd, f=f))
+            else:
+                f = conv.forward([(a, 0)], act=ACT_LRELU if kind == "lrelu" else ACT_NONE)
+                ctx.append(dict(src=a, f=f))
+            feats.append(f)
+            a = f
+        return feats, ctx
+
+    def backward(self, ctx, dfeats: List[Optional[Act]], grads: Grads, need_dx: bool) -> Optional[Act]:
+        d_next: Optional[Act] = None   # gradient flowing back into feats[i] from layer i+1
+        for i in range(len(self.layers) - 1, -1, -1):
+            kind, conv = self.layers[i]
+            c = ctx[i]
+            d = dfeats[i]
+            if d is None and d_next is None:
+                continue
+            if d is None:
+                d = d_next
+            elif d_next is not None:
+                T.add_slice(d_next, d, True)
+            if kind == "in":
+                d_c, _ = T.norm_bwd(c["c"], c["mean"], c["rstd"], d, act=ACT_LRELU, slope=0.2, out=c["f"])
+            elif kind == "lrelu":
+                T.act_bwd_(d, c["f"], ACT_LRELU, 0.2)
+                d_c = d
+            else:
+                d_c = d
+            d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx))
+        return d_next
+
+
+class MultiscaleDTrainPlan:
+    def __init__(self, msd: nn.Module):
+        self.msd = msd
+        self.plans = [DiscTrainPlan(D, f"discriminator_{k}") for k, D in enumerate(msd.children())]
+
+    def forward(self, inp: torch.Tensor, power_iteration: bool):
+        a = ops.to_nhwc(inp)
+        feats_all, ctxs, inputs = [], [], []
+        for k, p in enumerate(self.plans):
+            inputs.append(a)
+            feats, c = p.forward(a, power_iteration)
+            feats_all.append(feats)
+            ctxs.append(c)
+            if k + 1 < len(self.plans):
+                a = ops.avgpool3x3s2(a)
+        return feats_all, dict(ctxs=ctxs, inputs=inputs)
+
+    def backward(self, ctx, dfeats_all, need_dx: bool):
+        grads: Grads = {}
+        d_in_next: Optional[Act] = None
+        for k in range(len(self.plans) - 1, -1, -1):
+            a = ctx["inputs"][k]
+            d_a = self.plans[k].backward(ctx["ctxs"][k], dfeats_all[k], grads, need_dx)
+            if need_dx:
+                if d_a is None:
+                    d_a = Act(torch.zeros_like(a.t), a.C)
+                if d_in_next is not None:
+                    T.avgpool3x3s2_bwd(d_in_next, a.H, a.W, dx=d_a, accumulate=True)
+                d_in_next = d_a
+        return grads, d_in_next
+
+
+class _DiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, msd, plan, inp, *params):
+        feats_all, saved = plan.forward(inp, power_iteration=True)
+        ctx.plan, ctx.saved, ctx.params = plan, saved, params
+        ctx.shapes = [[(f.N, f.H, f.W, f.C) for f in fs] for fs in feats_all]
+        outs = tuple(ops.to_nchw(f) for fs in feats_all for f in fs)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        it = iter(d_outs)
+        dfeats_all = []
+        for fs in ctx.shapes:
+            row = []
+            for _ in fs:
+                d = next(it)
+                row.append(None if d is None else ops.to_nhwc(d.contiguous()))
+            dfeats_all.append(row)
+        need_dx = ctx.needs_input_grad[2]
+        grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx)
+        ctx.saved = None
+        d_inp = ops.to_nchw(d_in) if (need_dx and d_in is not None) else None
+        return (None, None, d_inp) + tuple(grads.get(p) for p in ctx.params)
+
+
+def discriminator_train_forward(msd: nn.Module, inp: torch.Tensor):
+    ops.require_cuda(inp, "MultiscaleDiscriminator.forward")
+    plan = getattr(msd, "_train_plan", None)
+    if plan is None:
+        plan = msd._train_plan = MultiscaleDTrainPlan(msd)
+    params = [p for p in msd.parameters()]
+    nD = len(plan.plans)
+    if not torch.is_grad_enabled():
+        feats_all, _ = plan.forward(inp, power_iteration=True)
+        flat = [ops.to_nchw(f) for fs in feats_all for f in fs]
+    else:
+        flat = list(_DiscFn.apply(msd, plan, inp, *params))
+    per = len(flat) // nD
+    result = [flat[k * per:(k + 1) * per] for k in range(nD)]
+    if msd.no_ganFeat_loss:
+        result = [[r[-1]] for r in result]
+    return result

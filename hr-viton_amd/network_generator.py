@@ -267,12 +267,13 @@ class SPADEGenerator(BaseNetwork):
         injects the per-SPADENorm N(0,1) draws ([b,w,h,1] each, in the reference's call order per
         block) so a run can be compared against a recorded reference run; by default they are drawn
         with torch.randn on the device exactly where the reference draws them (:104-107)."""
-        if self.training:
-            raise NotImplementedError("hr-viton_amd SPADEGenerator: training-mode forward/backward HIP kernels are "
-                                      "not built yet; call .eval()")
         if self.num_upsampling_layers == "normal":
             raise ValueError("num_upsampling_layers='normal' is broken in the reference itself (shape mismatch at "
                              "G_middle_1, network_generator.py:228-230)")
+        if self.training:
+            # one autograd.Function whose backward is the hand-written HIP plan (gen_train.py)
+            from .gen_train import generator_train_forward
+            return generator_train_forward(self, x, seg, noise)
         with torch.no_grad():
             return self._forward_eval(x, seg, noise)
 
@@ -432,7 +433,8 @@ class MultiscaleDiscriminator(BaseNetwork):
     def forward(self, input):
         """List (scales) of lists (layers) of NCHW tensors -- network_generator.py:306-316."""
         if self.training:
-            raise NotImplementedError("hr-viton_amd MultiscaleDiscriminator: training-mode kernels are not built yet")
+            from .gen_train import discriminator_train_forward
+            return discriminator_train_forward(self, input)
         ops.require_cuda(input, "MultiscaleDiscriminator.forward")
         result = []
         with torch.no_grad():

@@ -13,7 +13,8 @@ from .ops import ACT_NONE, Act, _ceil4, _stream, _Timed, _workspace
 
 
 def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
-                    stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0):
+                    stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0,
+                    sigma: Optional[torch.Tensor] = None):
     """hrv_conv2d_pack_weight_dev_f32.  ``w``: OIHW fp32 on the device.  Returns (packed, geom)
     with geom = (KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, elems)."""
     lib = _lib.load()
@@ -30,7 +31,9 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     buf = torch.empty(KH * KW * chunks * rows_pad * 16, dtype=torch.float32, device=w.device)
     geom = (C.c_int32 * 8)()
     _lib.check(lib.hrv_conv2d_pack_weight_dev_f32(w.data_ptr(), Cout, KH, KW, n, srcC, srcR, cfg, mode, stride, pad,
-                                                  phase[0], phase[1], wscale, buf.data_ptr(), geom, _stream()),
+                                                  phase[0], phase[1], wscale,
+                                                  None if sigma is None else sigma.data_ptr(), buf.data_ptr(), geom,
+                                                  _stream()),
                "hrv_conv2d_pack_weight_dev_f32")
     return buf, tuple(geom)
 
@@ -72,7 +75,7 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
 
 
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
-                     shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
+                     sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv") -> Act:
     """Forward convolution with device-resident, per-step packed weights.  ``srcs``: (Act, up_shift)."""
     lib = _lib.load()
@@ -84,7 +87,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
-    packed, _ = pack_weight_dev(w, [_ceil4(c) for c in real], real, cfg, 0, stride, pad, wscale=wscale)
+    packed, _ = pack_weight_dev(w, [_ceil4(c) for c in real], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma)
     if out is None:
         out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
@@ -93,7 +96,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
 
 
 def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
-               act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
+               sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
                name: str = "dgrad") -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
     activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x)."""
@@ -107,8 +110,7 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     if stride == 1:
-        packed, g = pack_weight_dev(w, [], [cin], cfg, 1, 1, pad, wscale=wscale) if False else \
-            pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale)
+        packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
                     residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl)
         return out
@@ -119,7 +121,7 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
             if Hp <= 0 or Wp <= 0:
                 continue
             cfg_p = lib.hrv_conv2d_pick_tile(N * Hp * Wp, cin)
-            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale)
+            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale, sigma)
             _run_engine([(dy, 0, Cout)], packed, cin, cfg_p, N, Ho, Wo, Hp, Wp, g[0], g[1], 1, g[2], g[3], out,
                         residual=act_mask, res_mode=res_mode, slope=slope, free_extent=1, out_step=2, out_off=(a, b),
                         out_hw=(H, W), name=f"{name}[phase {a}{b}]", flops=fl / 4)
@@ -283,3 +285,32 @@ def spectral_grad(G: torch.Tensor, w_orig: torch.Tensor, u: torch.Tensor, v: tor
     _lib.check(lib.hrv_spectral_norm_bwd_f32(G.data_ptr(), w_orig.data_ptr(), u.data_ptr(), v.data_ptr(),
                                              sigma.data_ptr(), R, K, ws.data_ptr(), out.data_ptr(),
                                              1 if accumulate else 0, _stream()), "hrv_spectral_norm_bwd_f32")
+
+
+def tanh_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    out = torch.empty_like(dy)
+    _lib.check(lib.hrv_tanh_bwd_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), out.data_ptr(), _stream()), "hrv_tanh_bwd_f32")
+    return out
+
+
+def add_slice(a: Act, out: Act, accumulate: bool):
+    """out (+)= a over a's channels (both views may be channel slices)."""
+    lib = _lib.load()
+    assert (a.N, a.H, a.W) == (out.N, out.H, out.W) and a.Cp <= out.cstride - out.coff
+    _lib.check(lib.hrv_add_slice_nhwc_f32(a.t.data_ptr(), a.cstride, a.coff, out.t.data_ptr(), out.cstride, out.coff, a.Cp,
+                                          a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc_f32")
+
+
+def act_bwd_(d: Act, y: Act, act: int, slope: float = 0.2):
+    """d *= act'(y) in place."""
+    lib = _lib.load()
+    _lib.check(lib.hrv_act_bwd_nhwc_f32(d.t.data_ptr(), d.cstride, d.coff, y.t.data_ptr(), y.cstride, y.coff, d.Cp,
+                                        d.N * d.H * d.W, act, slope, _stream()), "hrv_act_bwd_nhwc_f32")
+
+
+def scale_(x: torch.Tensor, s_host: float = 1.0, s_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
+    lib = _lib.load()
+    _lib.check(lib.hrv_scale_f32(x.data_ptr(), x.numel(), s_host, None if s_dev is None else s_dev.data_ptr(), _stream()),
+               "hrv_scale_f32")
+    return x

@@ -160,7 +160,8 @@ int hrv_conv2d_pack_weight_f32(const float* w_oihw, int32_t Cout, int32_t KH, in
  * (rows = Cin, k over Cout, taps flipped; run the engine on dY with pad K-1-pad);
  * mode 2: one phase (phase_a, phase_b) of the stride-2 data gradient
  * (dX[2h'+a] = sum_j dY[h'+j-pad_p] W[a+pad-2(j-pad_p)]).  `wscale` multiplies
- * every weight (spectral-norm 1/sigma).  out_geom[8] = {KHp, KWp, pad_h, pad_w,
+ * every weight; if sigma_dev != NULL the weights are also divided by the device
+ * scalar sigma_dev[0] (spectral norm, no host sync).  out_geom[8] = {KHp, KWp, pad_h, pad_w,
  * rows, rows_pad, chunks_total, packed elems}; out_dev must hold that many floats
  * (<= KH*KW*chunks*rows_pad*16).
  * Weight gradient of one source of a (possibly concatenated) input:
@@ -171,7 +172,7 @@ int hrv_conv2d_pack_weight_f32(const float* w_oihw, int32_t Cout, int32_t KH, in
 int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
                                    const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
                                    int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
-                                   float* out_dev, int32_t* out_geom, hrv_stream_t stream);
+                                   const float* sigma_dev, float* out_dev, int32_t* out_geom, hrv_stream_t stream);
 int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P);
 int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
                               int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
@@ -216,6 +217,16 @@ int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);
  * workspace: 1024 floats. */
 int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t mode, float lscale, float gscale, float* grad,
                  float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream);
+/* tanh backward through its output: out = dy*(1-y*y) (network_generator.py:245);
+ * add_slice: out[.., out_coff:+C] (+)= a[.., a_coff:+C]  (gradient accumulation / channel split). */
+/* x *= s_host * (s_dev ? s_dev[0] : 1): applies an upstream (device-resident) loss-gradient scalar. */
+int hrv_scale_f32(float* x, int64_t n, float s_host, const float* s_dev, hrv_stream_t stream);
+/* d *= act'(y) in place (ReLU / LeakyReLU derivative through the activation output y). */
+int hrv_act_bwd_nhwc_f32(float* d, int32_t d_cstride, int32_t d_coff, const float* y, int32_t y_cstride, int32_t y_coff,
+                         int32_t C, int64_t npix, int32_t act, float act_slope, hrv_stream_t stream);
+int hrv_tanh_bwd_f32(const float* dy, const float* y, int64_t n, float* out, hrv_stream_t stream);
+int hrv_add_slice_nhwc_f32(const float* a, int32_t a_cstride, int32_t a_coff, float* out, int32_t out_cstride,
+                           int32_t out_coff, int32_t C, int64_t npix, int32_t accumulate, hrv_stream_t stream);
 /* nn.Upsample(nearest, x2) backward: dlo (+)= 2x2 block sums of dhi. */
 int hrv_downsum2x2_nhwc_f32(const float* dhi, int32_t N, int32_t Hl, int32_t Wl, int32_t C, int32_t hi_cstride,
                             int32_t hi_coff, float* dlo, int32_t lo_cstride, int32_t lo_coff, int32_t accumulate,

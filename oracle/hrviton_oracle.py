@@ -234,10 +234,24 @@ def spectral_sigma(w_orig: Tensor, u: Tensor, v: Tensor) -> Tensor:
     return torch.dot(u, torch.mv(w_mat, v))
 
 
+# Training-mode spectral norm (torch SpectralNorm.compute_weight with module.training): one power
+# iteration v <- normalize(W^T u), u <- normalize(W v) (eps 1e-12) under no_grad, then
+# sigma = u.(W v) differentiated through W only.  When SN_TRAIN["on"] is set the oracle applies
+# it and records the updated (u, v) in SN_TRAIN["uv"] (the reference updates its buffers in place).
+SN_TRAIN = {"on": False, "uv": {}}
+
+
 def _sn_weight(sd: SD, p: str) -> Tensor:
     if p + ".weight_orig" in sd:
         w = sd[p + ".weight_orig"]
-        return w / spectral_sigma(w, sd[p + ".weight_u"], sd[p + ".weight_v"])
+        u, v = sd[p + ".weight_u"], sd[p + ".weight_v"]
+        if SN_TRAIN["on"]:
+            with torch.no_grad():
+                wm = w.reshape(w.shape[0], -1)
+                v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+                u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+            SN_TRAIN["uv"][p] = (u.clone(), v.clone())
+        return w / spectral_sigma(w, u, v)
     return sd[p + ".weight"]
 
 
@@ -393,3 +407,40 @@ def hires_warp(flow_last: Tensor, clothes: Tensor, cloth_mask: Tensor):
     flow_norm = torch.cat([flow[..., 0:1] / ((96 - 1.0) / 2.0), flow[..., 1:2] / ((128 - 1.0) / 2.0)], 3)
     wg = make_grid(N, iH, iW) + flow_norm
     return grid_sample_bilinear_border(clothes, wg), grid_sample_bilinear_border(cloth_mask, wg)
+
+
+# --------------------------------------------------------------------------
+# Losses of the generator training step (train_generator.py:279-360)
+# --------------------------------------------------------------------------
+
+
+def hinge_loss(preds: List[List[Tensor]], target_is_real: bool, for_discriminator: bool) -> Tensor:
+    """GANLoss('hinge').__call__ on a list (scales) of lists (layers) -- network_generator.py:365-398:
+    the last tensor of each scale, averaged over scales."""
+    total = 0
+    for p in preds:
+        x = p[-1]
+        if for_discriminator:
+            l = -torch.mean(torch.min(x - 1, torch.zeros_like(x))) if target_is_real else \
+                -torch.mean(torch.min(-x - 1, torch.zeros_like(x)))
+        else:
+            l = -torch.mean(x)
+        total = total + l
+    return total / len(preds)
+
+
+def feat_match_loss(pred_fake: List[List[Tensor]], pred_real: List[List[Tensor]], lambda_feat: float = 10.0) -> Tensor:
+    """train_generator.py:300-309."""
+    num_D = len(pred_fake)
+    total = 0
+    for i in range(num_D):
+        for j in range(len(pred_fake[i]) - 1):
+            total = total + F.l1_loss(pred_fake[i][j], pred_real[i][j].detach()) * lambda_feat / num_D
+    return total
+
+
+def split_fake_real(pred: List[List[Tensor]]):
+    """train_generator.py:287-295: first half of the batch is fake, second half real."""
+    fake = [[t[: t.size(0) // 2] for t in p] for p in pred]
+    real = [[t[t.size(0) // 2:] for t in p] for p in pred]
+    return fake, real

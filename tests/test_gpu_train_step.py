@@ -1,0 +1,137 @@
+"""GPU: one generator step and one discriminator step of train_generator.py:279-360 on the HIP
+path (module-level autograd Functions with hand-written backward plans) against torch autograd
+over the oracle on the CPU: loss values and EVERY parameter gradient."""
+from argparse import Namespace
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import hrviton_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    a, b = a.detach().float().cpu(), b.detach().float().cpu()
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+def _setup(seed=0, H=256, W=128, N=2):
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.network_generator import MultiscaleDiscriminator, SPADEGenerator
+    opt = Namespace(cuda=True, norm_G="spectralaliasinstance", gen_semantic_nc=7, ngf=8, num_upsampling_layers="most",
+                    fine_height=H, fine_width=W, ndf=8, norm_D="spectralinstance", n_layers_D=3, num_D=2,
+                    no_ganFeat_loss=False)
+    torch.manual_seed(seed)
+    gen = SPADEGenerator(opt, 9)
+    gen.init_weights("xavier", 0.02)
+    D = MultiscaleDiscriminator(opt)
+    D.init_weights("xavier", 0.02)
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n_, p in list(gen.named_parameters()) + list(D.named_parameters()):
+            if n_.endswith("noise_scale"):
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+            elif n_.endswith("weight") or n_.endswith("weight_orig"):
+                p.mul_(25.0)
+            elif n_.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.rand(N, 9, H, W, generator=g) * 2 - 1
+    lab = torch.randint(0, 7, (N, 1, H // 16, W // 16), generator=g).repeat_interleave(16, 2).repeat_interleave(16, 3)
+    seg = torch.zeros(N, 7, H, W).scatter_(1, lab, 1.0)
+    real = torch.rand(N, 3, H, W, generator=g) * 2 - 1
+    noise = {}
+    for j, name in enumerate(gen._blocks()):
+        h, w = gen.sh << j, gen.sw << j
+        k = 3 if getattr(gen, name).learned_shortcut else 2
+        noise[name] = [torch.randn(N, w, h, 1, generator=g) for _ in range(k)]
+    return opt, gen, D, x, seg, real, noise
+
+
+def _oracle_sd(mod):
+    return {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith(("weight_u", "weight_v")))
+            for k, v in mod.state_dict().items()}
+
+
+def _compare_grads(mod, sd, tol, what):
+    worst = ("", 0.0)
+    for name, p in mod.named_parameters():
+        want = sd[name].grad
+        if want is None:
+            assert p.grad is None or p.grad.abs().max() == 0, f"{what}: {name} has a gradient but the oracle has none"
+            continue
+        assert p.grad is not None, f"{what}: {name} got no gradient"
+        scale = max(want.abs().max().item(), 1e-6 * max(1.0, float(p.numel()) ** 0.5))
+        err = (p.grad.detach().cpu() - want).abs().max().item() / scale
+        if err > worst[1]:
+            worst = (name, err)
+    assert worst[1] < tol, f"{what}: worst gradient mismatch {worst}"
+
+
+def test_generator_step_matches_oracle_autograd():
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    opt, gen, D, x, seg, real, noise = _setup()
+    sd_g, sd_d = _oracle_sd(gen), _oracle_sd(D)
+    # ---------------- oracle: train_generator.py:279-314 (no VGG term here) ----------------
+    O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+    try:
+        fake = O.spade_generator_forward(sd_g, x, seg, opt.fine_height, opt.fine_width, "most", noise=noise)
+        pred = O.gen_discriminator_forward(sd_d, torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0))
+    finally:
+        O.SN_TRAIN["on"] = False
+    pf, pr = O.split_fake_real(pred)
+    l_gan = O.hinge_loss(pf, True, False)
+    l_feat = O.feat_match_loss(pf, pr, 10.0)
+    (l_gan + l_feat).backward()
+    # ---------------- HIP ----------------
+    gen.cuda().train()
+    D.cuda().train()
+    crit_gan, crit_feat = GANLoss("hinge"), L1Loss()
+    xc, sc, rc = x.cuda(), seg.cuda(), real.cuda()
+    out = gen(xc, sc, noise=noise)
+    assert _rel(out, fake) < 2e-4
+    pred_h = D(torch.cat([torch.cat([sc, out], 1), torch.cat([sc, rc], 1)], 0))
+    pf_h = [[t[: t.size(0) // 2] for t in p] for p in pred_h]
+    pr_h = [[t[t.size(0) // 2:] for t in p] for p in pred_h]
+    g_gan = crit_gan(pf_h, True, for_discriminator=False)
+    g_feat = 0
+    for i in range(2):
+        for j in range(len(pf_h[i]) - 1):
+            g_feat = g_feat + crit_feat(pf_h[i][j], pr_h[i][j].detach()) * 10.0 / 2
+    assert abs(g_gan.item() - l_gan.item()) < 1e-4 * max(1.0, abs(l_gan.item()))
+    assert abs(g_feat.item() - l_feat.item()) < 1e-4 * max(1.0, abs(l_feat.item()))
+    (g_gan + g_feat).mean().backward()
+    _compare_grads(gen, sd_g, 2e-3, "generator")
+    _compare_grads(D, sd_d, 2e-3, "discriminator (through the G loss)")
+    # the power iteration updated the spectral-norm buffers like the reference does
+    u_w, v_w = O.SN_TRAIN["uv"]["up_0.conv_0"]
+    assert _rel(gen.up_0.conv_0.weight_u, u_w) < 1e-4 and _rel(gen.up_0.conv_0.weight_v, v_w) < 1e-4
+
+
+def test_discriminator_step_matches_oracle_autograd():
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.losses import GANLoss
+    opt, gen, D, x, seg, real, noise = _setup(seed=3)
+    sd_d = _oracle_sd(D)
+    g = torch.Generator().manual_seed(9)
+    fake = torch.rand(real.shape, generator=g) * 2 - 1          # stands for the no_grad generator output (:327-330)
+    inp = torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0)
+    O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+    try:
+        pred = O.gen_discriminator_forward(sd_d, inp)
+    finally:
+        O.SN_TRAIN["on"] = False
+    pf, pr = O.split_fake_real(pred)
+    l_d = O.hinge_loss(pf, False, True) + O.hinge_loss(pr, True, True)
+    l_d.backward()
+    D.cuda().train()
+    crit = GANLoss("hinge")
+    pred_h = D(inp.cuda())
+    pf_h = [[t[: t.size(0) // 2] for t in p] for p in pred_h]
+    pr_h = [[t[t.size(0) // 2:] for t in p] for p in pred_h]
+    loss = crit(pf_h, False, for_discriminator=True) + crit(pr_h, True, for_discriminator=True)
+    assert abs(loss.item() - l_d.item()) < 1e-4 * max(1.0, abs(l_d.item()))
+    loss.mean().backward()
+    _compare_grads(D, sd_d, 2e-3, "discriminator step")
