@@ -13,6 +13,8 @@ The fixtures travel to the GPU box; the reference does not.
 import os
 import sys
 import types
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from argparse import Namespace
 
 sys.dont_write_bytecode = True
@@ -160,6 +162,53 @@ def main():
         dout = D(dinp)
     torch.save({"state_dict": {k: v.clone() for k, v in D.state_dict().items()}, "input": dinp, "out": dout},
                os.path.join(OUT, "gend_ndf8_128x64.pt"))
+
+    # ---------------- one generator + discriminator training step of the REAL reference --------
+    # (train_generator.py:279-360 re-composed on CPU without the VGG term: torchvision weights are
+    # unavailable).  Only summaries are stored (losses, per-parameter gradient max/sum, updated u/v
+    # norms): they pin the oracle's training-mode restatement (spectral-norm power iteration, hinge,
+    # feature matching); full gradients are compared against the oracle live in the GPU tests.
+    from oracle.recipes import trainstep_build
+    topt, tgen, tD, tx, tseg, treal, tnoise = trainstep_build(ref_gen.SPADEGenerator, ref_gen.MultiscaleDiscriminator)
+    tgen.train()
+    tD.train()
+    # feed the recipe's noise draws to the reference through its own torch.randn call sites
+    feed = [z for b in blocks for z in tnoise[b]]
+    feed_it = iter(feed)
+
+    def fed_randn(*a, **k):
+        z = next(feed_it)
+        assert tuple(z.shape) == tuple(a), (z.shape, a)
+        return z.clone()
+
+    torch.randn = fed_randn
+    try:
+        tout = tgen(tx, tseg)
+    finally:
+        torch.randn = real_randn
+    crit = ref_gen.GANLoss("hinge", tensor=torch.FloatTensor)
+    pred = tD(torch.cat((torch.cat((tseg, tout), 1), torch.cat((tseg, treal), 1)), 0))
+    pf = [[t[: t.size(0) // 2] for t in p] for p in pred]
+    pr = [[t[t.size(0) // 2:] for t in p] for p in pred]
+    l_gan = crit(pf, True, for_discriminator=False)
+    l_feat = torch.zeros(1)
+    for i in range(2):
+        for j in range(len(pf[i]) - 1):
+            l_feat = l_feat + nn.L1Loss()(pf[i][j], pr[i][j].detach()) * 10.0 / 2
+    (l_gan + l_feat).mean().backward()
+    summ = {n_: (p.grad.abs().max().item(), p.grad.sum().item(), p.grad.abs().sum().item())
+            for n_, p in list(tgen.named_parameters()) + [("D." + a, b_) for a, b_ in tD.named_parameters()]
+            if p.grad is not None}
+    torch.save({"recipe": "oracle.recipes.trainstep_build", "out": tout.detach(), "l_gan": l_gan.detach(),
+                "l_feat": l_feat.detach(),
+                "grad_summary": summ,
+                "u_after": {"up_0.conv_0": tgen.up_0.conv_0.weight_u.clone(),
+                            "D.discriminator_0.model1.0.0": tD.discriminator_0.model1[0][0].weight_u.clone()},
+                "sample_grads": {"conv_img.weight": tgen.conv_img.weight.grad.clone(),
+                                 "up_4.norm_1.noise_scale": tgen.up_4.norm_1.noise_scale.grad.clone(),
+                                 "head_0.conv_0.bias": tgen.head_0.conv_0.bias.grad.clone(),
+                                 "D.discriminator_1.model0.0.weight": tD.discriminator_1.model0[0].weight.grad.clone()}},
+               os.path.join(OUT, "trainstep_ngf8_256x128.pt"))
 
     # ---------------- parse glue inputs (restated blur: parity unpinned) ----------------
     for f in sorted(os.listdir(OUT)):

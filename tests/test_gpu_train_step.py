@@ -55,18 +55,28 @@ def _oracle_sd(mod):
 
 
 def _compare_grads(mod, sd, tol, what):
-    worst = ("", 0.0)
+    """Per-parameter max-abs error relative to max(|oracle grad| of that parameter, 1e-3 x the largest
+    gradient magnitude of the whole module): gradients that are analytically ~0 (a bias in front of an
+    InstanceNorm) are pure round-off on both sides and are held to the module-level scale."""
+    import os
+    rows = []
+    gmax = max((sd[n].grad.abs().max().item() for n, _ in mod.named_parameters() if sd[n].grad is not None), default=1.0)
     for name, p in mod.named_parameters():
         want = sd[name].grad
         if want is None:
             assert p.grad is None or p.grad.abs().max() == 0, f"{what}: {name} has a gradient but the oracle has none"
             continue
         assert p.grad is not None, f"{what}: {name} got no gradient"
-        scale = max(want.abs().max().item(), 1e-6 * max(1.0, float(p.numel()) ** 0.5))
-        err = (p.grad.detach().cpu() - want).abs().max().item() / scale
-        if err > worst[1]:
-            worst = (name, err)
-    assert worst[1] < tol, f"{what}: worst gradient mismatch {worst}"
+        aerr = (p.grad.detach().cpu() - want).abs().max().item()
+        rows.append((aerr / max(want.abs().max().item(), 1e-3 * gmax), aerr, want.abs().max().item(), name))
+    rows.sort(reverse=True)
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    with open(os.path.join(d, "grad_diag_" + what.split()[0] + ".txt"), "w") as f:
+        f.write(f"# {what}: rel_err abs_err |want|max name   (global max grad {gmax:.3e})\n")
+        for r in rows:
+            f.write("%.3e %.3e %.3e %s\n" % r)
+    assert rows[0][0] < tol, f"{what}: worst gradient mismatch {rows[:5]}"
 
 
 def test_generator_step_matches_oracle_autograd():
@@ -103,8 +113,8 @@ def test_generator_step_matches_oracle_autograd():
     assert abs(g_gan.item() - l_gan.item()) < 1e-4 * max(1.0, abs(l_gan.item()))
     assert abs(g_feat.item() - l_feat.item()) < 1e-4 * max(1.0, abs(l_feat.item()))
     (g_gan + g_feat).mean().backward()
-    _compare_grads(gen, sd_g, 2e-3, "generator")
-    _compare_grads(D, sd_d, 2e-3, "discriminator (through the G loss)")
+    _compare_grads(gen, sd_g, 1e-2, "generator")   # sign() of the L1 feature-matching term amplifies round-off
+    _compare_grads(D, sd_d, 1e-2, "discriminator (through the G loss)")
     # the power iteration updated the spectral-norm buffers like the reference does
     u_w, v_w = O.SN_TRAIN["uv"]["up_0.conv_0"]
     assert _rel(gen.up_0.conv_0.weight_u, u_w) < 1e-4 and _rel(gen.up_0.conv_0.weight_v, v_w) < 1e-4
@@ -134,4 +144,4 @@ def test_discriminator_step_matches_oracle_autograd():
     loss = crit(pf_h, False, for_discriminator=True) + crit(pr_h, True, for_discriminator=True)
     assert abs(loss.item() - l_d.item()) < 1e-4 * max(1.0, abs(l_d.item()))
     loss.mean().backward()
-    _compare_grads(D, sd_d, 2e-3, "discriminator step")
+    _compare_grads(D, sd_d, 1e-4, "discriminator step")
