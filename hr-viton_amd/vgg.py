@@ -1,0 +1,166 @@
+"""VGG19 perceptual loss (reference networks.py:201-251) on the HIP path.
+
+``Vgg19`` mirrors the reference's module/key layout (slice1..slice5 holding torchvision's
+``features`` layers under their original indices).  The reference downloads torchvision's
+pretrained weights; there is no network here, so the module is random-initialised unless a
+torchvision ``vgg19`` state dict is given (``load_torchvision_state_dict``) -- pretrained-weight
+parity is therefore unpinned, the computation is pinned by the oracle restatement.
+
+``VGGLoss(opt)(x, y)`` = sum_i w_i * L1(vgg(x)_i, vgg(y)_i.detach()), one autograd.Function:
+forward = 13 conv3x3+ReLU on the MFMA engine (frozen, host-packed weights) + 4 max-pools for both
+images; backward = data-gradient convolutions (ReLU derivative fused) + max-pool backward, through
+x only.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+
+from . import ops
+from . import train_ops as T
+from .ops import ACT_RELU, Act, ConvLayer
+
+# torchvision vgg19 cfg 'E' up to features[29]: (index, in, out) of the convs; pools at 4, 9, 18, 27
+_CONVS = [(0, 3, 64), (2, 64, 64), (5, 64, 128), (7, 128, 128), (10, 128, 256), (12, 256, 256), (14, 256, 256),
+          (16, 256, 256), (19, 256, 512), (21, 512, 512), (23, 512, 512), (25, 512, 512), (28, 512, 512)]
+_POOLS = [4, 9, 18, 27]
+_SLICES = [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)]
+_TAPS = [0, 5, 10, 19, 28]   # conv indices whose ReLU output is h_relu1..5
+
+
+class Vgg19(nn.Module):
+    def __init__(self, requires_grad=False):
+        super().__init__()
+        layers: Dict[int, nn.Module] = {}
+        for idx, cin, cout in _CONVS:
+            layers[idx] = nn.Conv2d(cin, cout, kernel_size=3, padding=1)
+            layers[idx + 1] = nn.ReLU(inplace=True)
+        for idx in _POOLS:
+            layers[idx] = nn.MaxPool2d(kernel_size=2, stride=2)
+        for k, (a, b) in enumerate(_SLICES):
+            seq = nn.Sequential()
+            for i in range(a, b):
+                seq.add_module(str(i), layers[i])
+            setattr(self, f"slice{k + 1}", seq)
+        if not requires_grad:
+            for p in self.parameters():
+                p.requires_grad = False
+        self._plan = None
+
+    def load_torchvision_state_dict(self, sd):
+        """Accepts torchvision.models.vgg19().state_dict() (keys 'features.N.weight')."""
+        own = {}
+        for k, (a, b) in enumerate(_SLICES):
+            for i in range(a, b):
+                for suf in ("weight", "bias"):
+                    key = f"features.{i}.{suf}"
+                    if key in sd:
+                        own[f"slice{k + 1}.{i}.{suf}"] = sd[key]
+        self.load_state_dict(own, strict=True)
+        self._plan = None
+
+    def conv(self, idx: int) -> nn.Conv2d:
+        for k, (a, b) in enumerate(_SLICES):
+            if a <= idx < b:
+                return getattr(self, f"slice{k + 1}")._modules[str(idx)]
+        raise KeyError(idx)
+
+    def plan(self, device):
+        if self._plan is None or self._plan[0] != str(device):
+            layers = {idx: ConvLayer(self.conv(idx).weight, [cin], device, shift=self.conv(idx).bias, pad=1, act=ACT_RELU,
+                                     name=f"vgg.features.{idx}") for idx, cin, cout in _CONVS}
+            self._plan = (str(device), layers)
+        return self._plan[1]
+
+    def features(self, x: Act, save: bool):
+        """Runs the 13 convs + 4 pools; returns (taps [5 Acts], saved list for backward)."""
+        layers = self.plan(x.t.device)
+        taps, saved = [], []
+        cur = x
+        for idx, cin, cout in _CONVS:
+            if (idx - 1) in _POOLS:
+                pooled = T.maxpool2x2(cur)
+                if save:
+                    saved.append(("pool", cur))
+                cur = pooled
+            out = layers[idx]([cur])
+            if save:
+                saved.append(("conv", idx, cur, out))
+            cur = out
+            if idx in _TAPS:
+                taps.append(out)
+        return taps, saved
+
+    def forward(self, X):
+        with torch.no_grad():
+            taps, _ = self.features(ops.to_nhwc(X), save=False)
+            return [ops.to_nchw(t) for t in taps]
+
+
+class _VGGLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, vgg, weights, layids, x, y):
+        ops.require_cuda(x, "VGGLoss(x)")
+        need = ctx.needs_input_grad[3]
+        xa, ya = ops.to_nhwc(x), ops.to_nhwc(y)
+        ty, _ = vgg.features(ya, save=False)
+        tx, saved = vgg.features(xa, save=need)
+        loss = torch.zeros(1, dtype=torch.float32, device=x.device)
+        grads: List[Optional[torch.Tensor]] = [None] * 5
+        for i in layids:
+            n = tx[i].t.numel()          # dense tensors (channels are multiples of 4)
+            grads[i] = T.loss(tx[i].t, ty[i].t, T.LOSS_L1, weights[i] / n, weights[i] / n, loss, accumulate=True,
+                              want_grad=need)
+        ctx.vgg, ctx.saved, ctx.grads, ctx.tx = vgg, saved, grads, tx
+        return loss
+
+    @staticmethod
+    def backward(ctx, g_out):
+        vgg, saved, grads = ctx.vgg, ctx.saved, ctx.grads
+        d: Optional[Act] = None
+        for item in reversed(saved):
+            if item[0] == "pool":
+                if d is not None:
+                    d = T.maxpool2x2_bwd(item[1], d)
+                continue
+            _, idx, src, out = item
+            if idx in _TAPS:
+                gi = grads[_TAPS.index(idx)]
+                if gi is not None:
+                    gact = Act(gi, out.C)
+                    if d is None:
+                        d = gact
+                    else:
+                        T.add_slice(gact, d, True)
+            if d is None:
+                continue
+            T.act_bwd_(d, out, ACT_RELU, 0.0)          # through this conv's ReLU
+            if idx == 0:
+                w = vgg.conv(0).weight.data
+                d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, name="vgg.features.0.dgrad")
+            else:
+                w = vgg.conv(idx).weight.data
+                d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, name=f"vgg.features.{idx}.dgrad")
+        ctx.saved = ctx.grads = None
+        dx = ops.to_nchw(d)
+        T.scale_(dx, 1.0, g_out.contiguous())
+        return None, None, None, dx, None
+
+
+class VGGLoss(nn.Module):
+    """networks.py:235-251 -- VGGLoss(opt, layids=None)(x, y)."""
+
+    def __init__(self, opt=None, layids=None):
+        super().__init__()
+        self.vgg = Vgg19()
+        if opt is not None and getattr(opt, "cuda", False):
+            self.vgg.cuda()
+        self.weights = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+        self.layids = layids
+
+    def forward(self, x, y):
+        if self.layids is None:
+            self.layids = list(range(5))
+        return _VGGLossFn.apply(self.vgg, self.weights, self.layids, x, y).squeeze(0)

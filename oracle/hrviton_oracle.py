@@ -444,3 +444,32 @@ def split_fake_real(pred: List[List[Tensor]]):
     fake = [[t[: t.size(0) // 2] for t in p] for p in pred]
     real = [[t[t.size(0) // 2:] for t in p] for p in pred]
     return fake, real
+
+
+VGG_CONVS = [0, 2, 5, 7, 10, 12, 14, 16, 19, 21, 23, 25, 28]
+VGG_POOLS = [4, 9, 18, 27]
+VGG_TAPS = [0, 5, 10, 19, 28]
+
+
+def vgg19_features(sd: SD, x: Tensor) -> List[Tensor]:
+    """Vgg19.forward -- networks.py:201-232: torchvision vgg19 ``features[0:30]`` tapped after
+    relu1_1, 2_1, 3_1, 4_1, 5_1.  ``sd`` uses the reference module's keys (sliceK.IDX.weight)."""
+    def key(i):
+        k = 1 + sum(i >= b for _, b in [(0, 2), (2, 7), (7, 12), (12, 21), (21, 30)])
+        return f"slice{k}.{i}"
+    out = []
+    h = x
+    for i in VGG_CONVS:
+        if (i - 1) in VGG_POOLS:
+            h = F.max_pool2d(h, 2, 2)
+        h = F.relu(F.conv2d(h, sd[key(i) + ".weight"], sd[key(i) + ".bias"], padding=1))
+        if i in VGG_TAPS:
+            out.append(h)
+    return out
+
+
+def vgg_loss(sd: SD, x: Tensor, y: Tensor) -> Tensor:
+    """VGGLoss.forward -- networks.py:244-251."""
+    w = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
+    fx, fy = vgg19_features(sd, x), vgg19_features(sd, y)
+    return sum(w[i] * F.l1_loss(fx[i], fy[i].detach()) for i in range(5))

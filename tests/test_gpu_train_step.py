@@ -145,3 +145,27 @@ def test_discriminator_step_matches_oracle_autograd():
     assert abs(loss.item() - l_d.item()) < 1e-4 * max(1.0, abs(l_d.item()))
     loss.mean().backward()
     _compare_grads(D, sd_d, 1e-4, "discriminator step")
+
+
+def test_vgg_loss_value_and_input_gradient():
+    """VGGLoss (networks.py:235-251) forward + backward through x vs autograd over the oracle."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.vgg import VGGLoss
+    torch.manual_seed(2)
+    crit = VGGLoss(Namespace(cuda=False))
+    sd = {k: v.detach().clone() for k, v in crit.vgg.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 3, 64, 48, generator=g) * 2 - 1).requires_grad_()
+    y = torch.rand(2, 3, 64, 48, generator=g) * 2 - 1
+    want = O.vgg_loss(sd, x, y)
+    (want * 10.0).backward()
+    crit.cuda()
+    xc = x.detach().cuda().requires_grad_()
+    got = crit(xc, y.cuda())
+    assert abs(got.item() - want.item()) < 1e-5 * max(1.0, abs(want.item()))
+    (got * 10.0).backward()
+    err = (xc.grad.cpu() - x.grad).abs().max().item() / x.grad.abs().max().item()
+    assert err < 2e-2, err      # sign() gradients of the L1 terms flip on round-off-level differences
+    feats = crit.vgg(y.cuda())
+    for a, b in zip(feats, O.vgg19_features(sd, y)):
+        assert _rel(a, b) < 1e-4
