@@ -23,8 +23,22 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, Act, _ceil4
 Grads = Dict[nn.Parameter, torch.Tensor]
 
 
+# parameter -> GradSync: the backward plan reports every finished gradient so its bucket's
+# all-reduce can start while the rest of the backward is still running (parallel.py)
+GRAD_SYNC: Dict[nn.Parameter, object] = {}
+
+
+def attach_grad_sync(sync):
+    for p in sync.params:
+        GRAD_SYNC[p] = sync
+
+
 def _acc(grads: Grads, p: nn.Parameter, g: torch.Tensor):
-    grads[p] = g if p not in grads else grads[p] + g
+    assert p not in grads, "each parameter is used once per forward on this path"
+    grads[p] = g
+    s = GRAD_SYNC.get(p)
+    if s is not None:
+        s.on_grad(p, g)
 
 
 class TConv:

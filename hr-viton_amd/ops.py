@@ -18,6 +18,11 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, HrvError  # noqa: F401
 
 
+# bumped by hr_viton_amd.optim.Adam.step(): the fused Adam kernel writes parameters through raw
+# pointers (no torch version-counter bump), so cached inference plans key on this as well
+WEIGHTS_EPOCH = [0]
+
+
 def _ceil4(c: int) -> int:
     return (c + 3) // 4 * 4
 

@@ -1,0 +1,62 @@
+"""torch.optim.Adam drop-in whose step is ONE fused HIP launch over a flat parameter buffer
+(train_generator.py:154-157,322,360).  Parameters are re-pointed to views of the flat buffer on the
+first step; gradients are gathered into a flat buffer (or taken from a ``GradSync``'s all-reduced
+buckets).  LambdaLR and friends work unchanged (it is a torch.optim.Optimizer)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops
+from . import train_ops as T
+
+
+class Adam(torch.optim.Optimizer):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None):
+        defaults = dict(lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        self.grad_sync = grad_sync
+        self._flat = {}
+
+    def _setup(self, gi, group):
+        ps = [p for p in group["params"] if p.requires_grad]
+        for p in ps:
+            ops.require_cuda(p.data, "hr_viton_amd.optim.Adam parameter")
+        n = sum(p.numel() for p in ps)
+        dev = ps[0].device
+        w = torch.empty(n, dtype=torch.float32, device=dev)
+        off = 0
+        spans = []
+        for p in ps:
+            k = p.numel()
+            w[off:off + k].copy_(p.data.reshape(-1))
+            p.data = w[off:off + k].view_as(p.data)      # the parameter now lives in the flat buffer
+            spans.append((p, off, k))
+            off += k
+        st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w), g=torch.zeros_like(w), spans=spans, step=0)
+        self._flat[gi] = st
+        return st
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        world_scale = 1.0
+        if self.grad_sync is not None:
+            self.grad_sync.wait()
+            world_scale = 1.0 / self.grad_sync.world
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi) or self._setup(gi, group)
+            g = st["g"]
+            for p, off, k in st["spans"]:
+                src = self.grad_sync.grad_of(p) if self.grad_sync is not None else p.grad
+                if src is None:
+                    g[off:off + k].zero_()               # torch's Adam skips it; a zero gradient is a no-op here
+                else:
+                    g[off:off + k].copy_(src.reshape(-1))
+            st["step"] += 1
+            b1, b2 = group["betas"]
+            T.adam_step(st["w"], g, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
+                        st["step"], world_scale)
+        ops.WEIGHTS_EPOCH[0] += 1      # cached inference plans (packed weights) are stale now
+        return loss

@@ -1,0 +1,83 @@
+"""CPU, world_size 2, gloo: the data-parallel gradient path (parallel.GradSync): bucket assignment,
+all-reduce fired from inside the backward as buckets complete, unused parameters, averaging."""
+import os
+import socket
+import sys
+
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    try:
+        _worker_body(rank, world, port, q)
+    except Exception as e:  # noqa: BLE001 -- surface the failure instead of a queue timeout
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc()))
+
+
+def _worker_body(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import dist as hdist
+    from hr_viton_amd.gen_train import GRAD_SYNC, _acc, attach_grad_sync
+    from hr_viton_amd.parallel import GradSync, broadcast_module
+    hdist.init_from_env("gloo")
+    torch.manual_seed(rank)                         # replicas start different ...
+    net = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 100), torch.nn.Linear(100, 7))
+    broadcast_module(net)                           # ... and are made identical
+    w0 = net[0].weight.detach().clone()
+    sync = GradSync(net.parameters(), bucket_mb=0.1)   # ~26k floats per bucket -> several buckets
+    attach_grad_sync(sync)
+    assert len(sync.buckets) >= 2
+    params = list(net.parameters())
+    fired_early = []
+    sync.begin()
+    grads = {}
+    # the "backward plan": gradients appear in reverse order; the last Linear's bias is unused
+    for p in reversed(params[:-1]):
+        _acc(grads, p, torch.full_like(p, float(rank + 1)))
+        fired_early.append(sum(1 for b in sync.buckets if b["handle"] is not None))
+    sync.wait()
+    ok = all(torch.allclose(sync.grad_of(p), torch.full_like(p, 3.0)) for p in params[:-1])   # 1 + 2 summed
+    unused = sync.grad_of(params[-1])
+    q.put((rank, bool(ok), unused is None, fired_early[-1] >= 1 and fired_early[0] == 0 or len(sync.buckets) == 1,
+           float(w0.sum()), sync.world))
+    for p in params:
+        GRAD_SYNC.pop(p, None)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradsync_world2_gloo():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for r in res:
+        assert len(r) == 6, r
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, ok0, un0, early0, w0, world0), (r1, ok1, un1, early1, w1, world1) = res
+    assert ok0 and ok1, "all-reduced gradients must be the sum over ranks"
+    assert un0 and un1, "a parameter that got no gradient reports None (its bucket is flushed with zeros)"
+    assert early0 and early1, "buckets fire during the backward, not only at the end"
+    assert w0 == w1, "broadcast_module makes the replicas identical"
+    assert world0 == world1 == 2
