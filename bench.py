@@ -60,6 +60,92 @@ def build_model(torch, nn):
     return opt, m
 
 
+def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
+    """Secondary workloads (not the driver's default bench): same timing contract, same JSON shape."""
+    from argparse import Namespace
+    import train_generator as tg
+    from hr_viton_amd.gen_train import attach_grad_sync
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    from hr_viton_amd.network_generator import MultiscaleDiscriminator, SPADEGenerator
+    from hr_viton_amd.networks import ConditionGenerator
+    from hr_viton_amd.optim import Adam
+    from hr_viton_amd.parallel import GradSync, broadcast_module
+    from hr_viton_amd.pipeline import generator_train_step, make_generator_inputs, tryon_step
+    from hr_viton_amd.vgg import VGGLoss
+    train = args.workload == "train_generator"
+    B = args.batch or 4
+    opt = tg.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world)])
+    torch.manual_seed(0)
+    tocg = ConditionGenerator(opt, 4, 16, 13, ngf=96, norm_layer=nn.BatchNorm2d).to(dev).eval()
+    gen = SPADEGenerator(opt, 9)
+    gen.init_weights("xavier", 0.02)
+    gen.to(dev)
+    batch = tg.synthetic_batch(opt, B, hdist.shard_seed(1234, rank), dev)
+    if train:
+        dis = MultiscaleDiscriminator(opt)
+        dis.init_weights("xavier", 0.02)
+        dis.to(dev).train()
+        gen.train()
+        crit_vgg = VGGLoss(opt).to(dev)
+        for m in (gen, dis, crit_vgg):
+            broadcast_module(m)
+        sg = GradSync(gen.parameters()) if world > 1 else None
+        sd = GradSync(dis.parameters()) if world > 1 else None
+        for s_ in (sg, sd):
+            if s_ is not None:
+                attach_grad_sync(s_)
+        og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9), grad_sync=sg)
+        od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9), grad_sync=sd)
+        cg, cf = GANLoss("hinge"), L1Loss()
+
+        def step(_i):
+            x, parse7 = make_generator_inputs(opt, tocg, batch)
+            generator_train_step(opt, gen, dis, cg, cf, crit_vgg, og, od, x, parse7, batch["image"], sg, sd)
+        metric = "1024x768 try-on images/sec (train_generator.py step: tocg+glue, G fwd/bwd, D fwd/bwd x2, VGG, Adam)"
+        flops_per_img = 8.8e12
+    else:
+        gen.eval()
+
+        def step(_i):
+            tryon_step(opt, tocg, gen, batch)
+        metric = "1024x768 try-on images/sec (test_generator.py step: tocg@256x192 + glue + SPADE generator)"
+        flops_per_img = 1.73e12
+    dt = hdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
+    ops.profile_begin()
+    step(0)
+    recs = ops.profile_end()
+    kinds = {}
+    for k, n, fl, by, ms in recs:
+        a = kinds.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += fl
+    if args.dump_launches and rank == 0:
+        with open(args.dump_launches, "w") as f:
+            for k, n, fl, by, ms in recs:
+                f.write(f"{k:8s} {n:52s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s\n")
+    mf_ms = sum(v[1] for k, v in kinds.items() if k in ("conv", "wgrad"))
+    mf_fl = sum(v[2] for k, v in kinds.items() if k in ("conv", "wgrad"))
+    if rank == 0:
+        ach = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        line = {"metric": metric, "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": args.workload + " 1024x768 fp32 ngf=64, random-init weights", "global_batch": B * world,
+                           "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
+                "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
+                             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                             "end_to_end_TFLOPs_vs_survey_work": round(B * flops_per_img / (dt / args.steps) / 1e12, 2)},
+                "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(kinds.items())},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +154,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(cores, 32))")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch table of one step to this file")
+    ap.add_argument("--workload", default="tocg_infer", choices=["tocg_infer", "train_generator", "tryon_infer"],
+                    help="tocg_infer = BASELINE configs[1] (default, the driver's bench); train_generator = configs[3] "
+                         "shape in fp32 (4 img/GPU, G+D step incl. VGG, DP all-reduce); tryon_infer = end-to-end "
+                         "test_generator.py step (configs[4] shape, fp32)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch for the non-default workloads")
     args = ap.parse_args()
 
     import torch
@@ -80,6 +171,8 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    if args.workload != "tocg_infer":
+        return other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev)
 
     opt, model = build_model(torch, nn)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
