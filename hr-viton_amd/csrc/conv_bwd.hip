@@ -109,6 +109,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
   const int Hs = (p.H >> sr) << sl, Ws = (p.W >> sr) << sl;
 
   f32x4 yreg[YR], xreg[XR];
+  // per-thread gather rows: pixel (n, ho, wo) of X-row r at the current tile, advanced by BK
+  // pixels per tile without integer division
+  int xr_n[XR], xr_ho[XR], xr_wo[XR];
+#pragma unroll
+  for (int r = 0; r < XR; ++r) {
+    const int idx = tid + 256 * r;
+    const int row = idx / (BNc / 4);
+    const int pix = t_begin * BK + row;
+    const int pp = pix < p.P ? pix : 0;
+    xr_n[r] = pp / (p.Ho * p.Wo);
+    const int rem = pp - xr_n[r] * (p.Ho * p.Wo);
+    xr_ho[r] = rem / p.Wo;
+    xr_wo[r] = rem - xr_ho[r] * p.Wo;
+  }
   f32x16 acc[TM][TN];
 #pragma unroll
   for (int i = 0; i < TM; ++i)
@@ -134,10 +148,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
       const int idx = tid + 256 * r;                                                                      \
       const int row = idx / (BNc / 4), c4 = idx - row * (BNc / 4);                                        \
       const int pix = (T)*BK + row;                                                                       \
-      const int pp = pix < p.P ? pix : 0;                                                                 \
-      const int n = pp / (p.Ho * p.Wo);                                                                   \
-      const int rem = pp - n * (p.Ho * p.Wo);                                                             \
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;                                                    \
+      const int n = xr_n[r], ho = xr_ho[r], wo = xr_wo[r];                                                \
       const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;                         \
       const int c = ci0 + c4 * 4;                                                                         \
       const bool ok = idx < BK * BNc / 4 && pix < p.P && c < p.x_C && (unsigned)hi < (unsigned)p.H &&     \
@@ -148,6 +159,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
       f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                               \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                               \
       xreg[r] = v;                                                                                        \
+      /* advance this row by BK pixels for the next tile */                                               \
+      int w2 = wo + BK, h2 = ho, n2 = n;                                                                  \
+      while (w2 >= p.Wo) { w2 -= p.Wo; ++h2; }                                                            \
+      while (h2 >= p.Ho) { h2 -= p.Ho; ++n2; }                                                            \
+      xr_wo[r] = w2; xr_ho[r] = h2; xr_n[r] = n2 < p.N ? n2 : 0;                                          \
     }                                                                                                     \
   }
 
@@ -270,16 +286,30 @@ static inline int grid_for(size_t work, int block = 256) {
 }
 
 struct WTile { int TM, TN, WM, WN; };
-// wgrad tiles: (couts x cins) per block
-static const WTile kWTiles[] = {{2, 2, 2, 2}, {1, 1, 2, 2}, {1, 1, 4, 1}, {3, 1, 1, 4}};  // 128x128, 64x64, 128x32, 96x128
+// wgrad tiles (couts x cins per block).  Family A: all 4 waves share the dY fragments, each owns 32
+// cins (BNc = 128, BMc = 32*TM exactly fits Cout up to 192).  Family B: cin tile 32 for tiny Cin.
+static const WTile kWTiles[] = {
+    {1, 1, 1, 4}, {2, 1, 1, 4}, {3, 1, 1, 4}, {4, 1, 1, 4}, {5, 1, 1, 4}, {6, 1, 1, 4},  // 0-5: 32..192 x 128
+    {2, 2, 2, 2},                                                                          // 6: 128 x 128
+    {1, 1, 4, 1}, {2, 1, 4, 1},                                                            // 7-8: 128/256 x 32
+    {1, 1, 2, 2},                                                                          // 9: 64 x 64
+};
 static int wt_bm(int i) { return 32 * kWTiles[i].TM * kWTiles[i].WM; }
 static int wt_bn(int i) { return 32 * kWTiles[i].TN * kWTiles[i].WN; }
 
 static int pick_wtile(int Cout, int Cin) {
-  if (Cin <= 32) return 2;
-  if (Cout <= 64 && Cin <= 64) return 1;
-  if (Cout % 128 != 0 && Cout % 96 == 0) return 3;
-  return 0;
+  if (Cin <= 32) return Cout > 128 ? 8 : 7;
+  if (Cout <= 64 && Cin <= 64) return 9;
+  const int tm = (Cout + 31) / 32;
+  if (tm <= 6) return tm - 1;           // exact cout fit, no padded rows
+  if (Cout % 128 == 0) return 6;
+  // large Cout: the family-A tile with the least padding
+  int best = 3, best_pad = 1 << 30;
+  for (int t = 3; t <= 6; ++t) {
+    const int bm = 32 * t, pad = (Cout + bm - 1) / bm * bm - Cout;
+    if (pad <= best_pad) { best_pad = pad; best = t - 1; }
+  }
+  return best;
 }
 
 }  // namespace hrv
@@ -398,12 +428,14 @@ extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, in
   p.S = S; p.ws = workspace;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = tiles * S;
+#define WG_CASE(I, A, B, Cc, D) \
+  case I: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p); break;
   switch (wt) {
-    case 0: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<2, 2, 2, 2>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
-    default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<3, 1, 1, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+    WG_CASE(0, 1, 1, 1, 4) WG_CASE(1, 2, 1, 1, 4) WG_CASE(2, 3, 1, 1, 4) WG_CASE(3, 4, 1, 1, 4) WG_CASE(4, 5, 1, 1, 4)
+    WG_CASE(5, 6, 1, 1, 4) WG_CASE(6, 2, 2, 2, 2) WG_CASE(7, 1, 1, 4, 1) WG_CASE(8, 2, 1, 4, 1)
+    default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p); break;
   }
+#undef WG_CASE
   int rc = check_launch("conv_wgrad_mfma_kernel");
   if (rc) return rc;
   const size_t total = (size_t)Cout * x_C_real * p.taps;
