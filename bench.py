@@ -74,7 +74,7 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.vgg import VGGLoss
     train = args.workload == "train_generator"
     B = args.batch or 4
-    opt = tg.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world)])
+    opt = tg.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world)] + (["--fp16"] if args.bf16 else []))
     torch.manual_seed(0)
     tocg = ConditionGenerator(opt, 4, 16, 13, ngf=96, norm_layer=nn.BatchNorm2d).to(dev).eval()
     gen = SPADEGenerator(opt, 9)
@@ -130,8 +130,9 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
         ach = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
         line = {"metric": metric, "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": args.workload + " 1024x768 fp32 ngf=64, random-init weights", "global_batch": B * world,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16 (generator; tocg+glue f32)" if args.bf16 else "f32", "data": "synthetic",
+                "config": {"workload": args.workload + " 1024x768 ngf=64, random-init weights", "global_batch": B * world,
                            "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
                 "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
                              "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
@@ -159,6 +160,7 @@ def main():
                          "shape in fp32 (4 img/GPU, G+D step incl. VGG, DP all-reduce); tryon_infer = end-to-end "
                          "test_generator.py step (configs[4] shape, fp32)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch for the non-default workloads")
+    ap.add_argument("--bf16", action="store_true", help="tryon_infer: run the SPADE generator on the bf16 engine")
     args = ap.parse_args()
 
     import torch

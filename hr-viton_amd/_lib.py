@@ -98,12 +98,17 @@ SYMBOLS = {
     "hrv_spectral_norm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "hrv_conv2d_workspace_bytes": (_i64, [C.POINTER(hrv_conv2d_t)]),
     "hrv_conv2d_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
+    "hrv_conv2d_packed_elems_bf16": (_i64, [_i32, _i32, _i32, _i32, _ip, _i32]),
+    "hrv_conv2d_pack_weight_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _vp]),
+    "hrv_conv2d_nhwc_bf16": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
     "hrv_conv2d_naive_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
     "hrv_tapsum_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _i32,
                                       _vp]),
     "hrv_instnorm_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "hrv_instnorm_stats_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
                                               _vp]),
+    "hrv_instnorm_stats_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
+                                               _vp]),
     "hrv_instnorm_apply_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32,
                                               _i32, _vp]),
     "hrv_avgpool3x3s2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
@@ -113,6 +118,8 @@ SYMBOLS = {
     "hrv_resize_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_occlusion_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
     "hrv_nchw_to_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_nchw_f32_to_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_nhwc_bf16_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,
                                                _vp, _i32, _i32, _vp, _i32, _i32, _vp]),

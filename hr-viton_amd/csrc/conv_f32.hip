@@ -65,6 +65,7 @@ struct ConvParams {
   int pad_w;   // horizontal padding (pad is the vertical one)
   int out_up;  // 1: replicate every result to its 2x2 block of a (2Ho x 2Wo) output
   int out_step, out_oh, out_ow, out_H, out_W;  // out_step 2: scatter to (2h+oh, 2w+ow) of an out_H x out_W output
+  int bf16;      // 1: sources / weights / residual / out / SPADE x are bf16 (accumulate + stats fp32)
   int res_mode;  // 0: + residual; 1: * (residual > 0 ? 1 : slope)   (activation derivative, backward)
   // SPADE epilogue (epi == 1)
   int epi;
@@ -95,9 +96,58 @@ __device__ __forceinline__ float res_combine(float v, float r, int mode, float s
   return mode == 0 ? v + r : v * (r > 0.f ? 1.f : slope);
 }
 
-template <int TM, int TN, int WM, int WN, int VAR>
-__global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) {
+// ---- element-type helpers: BF = activations / weights / residual / output are bf16 (fp32 accumulate,
+// fp32 scale/shift/statistics); the LDS tiles and the 16-byte gather are byte-identical in both modes
+// (a K-tile row is 64 bytes: 16 fp32 or 32 bf16 k-values).
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ float bf2f(unsigned short h) { return __builtin_bit_cast(float, (unsigned)h << 16); }
+__device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest even
+  unsigned u = __builtin_bit_cast(unsigned, f);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+template <bool BF>
+__device__ __forceinline__ f32x4 ld4e(const float* base, size_t idx) {
+  if constexpr (BF) {
+    const u16x4 h = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = bf2f(h[e]);
+    return v;
+  } else {
+    return *reinterpret_cast<const f32x4*>(base + idx);
+  }
+}
+template <bool BF>
+__device__ __forceinline__ void st4e(float* base, size_t idx, f32x4 v) {
+  if constexpr (BF) {
+    u16x4 h;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) h[e] = f2bf(v[e]);
+    *reinterpret_cast<u16x4*>(reinterpret_cast<unsigned short*>(base) + idx) = h;
+  } else {
+    *reinterpret_cast<f32x4*>(base + idx) = v;
+  }
+}
+template <bool BF>
+__device__ __forceinline__ float ld1e(const float* base, size_t idx) {
+  if constexpr (BF) return bf2f(reinterpret_cast<const unsigned short*>(base)[idx]);
+  else return base[idx];
+}
+template <bool BF>
+__device__ __forceinline__ void st1e(float* base, size_t idx, float v) {
+  if constexpr (BF) reinterpret_cast<unsigned short*>(base)[idx] = f2bf(v);
+  else base[idx] = v;
+}
+
+template <int TM, int TN, int WM, int WN, int VAR, bool BF>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
+  constexpr int ES = BF ? 2 : 4;     // element size in bytes
+  constexpr int EPG = 16 / ES;       // elements per 16-byte gather group
+  constexpr int BKE = 4 * EPG;       // k-values per K-tile row (64 bytes)
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int AR = BM / 64;                 // 16-byte A loads per thread per K-tile
@@ -186,7 +236,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
       s_co = sel ? p.src[q].coff : s_co;                                                                     \
       s_up = sel ? p.src[q].up_shift : s_up;                                                                 \
     }                                                                                                        \
-    const int c = it_c * BK + a_c4 * 4;                                                                      \
+    const int c = it_c * BKE + a_c4 * EPG;                                                                   \
     const bool c_ok = c < s_C;                                                                               \
     /* up_shift > 0: source is 2^up smaller (nearest upsample); < 0: 2^-up larger (nearest downsample) */    \
     const int sh_r = s_up > 0 ? s_up : 0, sh_l = s_up < 0 ? -s_up : 0;                                       \
@@ -200,11 +250,11 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
       const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);                              \
       const unsigned off =                                                                                   \
           ((unsigned)(a_n[r] * Hs + ((hic >> sh_r) << sh_l)) * Ws + ((wic >> sh_r) << sh_l)) * s_cs + s_co + cc; \
-      f32x4 v = *reinterpret_cast<const f32x4*>(s_ptr + off);                                                \
+      f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_ptr) + (size_t)off * ES);    \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                                  \
       a_reg[r] = v;                                                                                          \
     }                                                                                                        \
-    const float* wt = p.wp + ((size_t)(KTN)*p.CoutPad + n0) * BK;                                            \
+    const float* wt = p.wp + ((size_t)(KTN)*p.CoutPad + n0) * BK; /* 64-byte rows in both modes */            \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
       const int idx = tid + 256 * j;                                                                         \
       b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * 4) % 256 == 0 || idx < BN * 4 ? idx : 0) * 4);  \
@@ -256,14 +306,26 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
   acc[I][J] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x2f32(BV, AV, acc[I][J], 0, 0, 0)       \
                    : __builtin_amdgcn_mfma_f32_32x32x2f32(AV, BV, acc[I][J], 0, 0, 0);
 
-#define HRV_MMA_FRAGS()                                                       \
-  {                                                                           \
-    _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                          \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e)                         \
-            _Pragma("unroll") for (int i = 0; i < TM; ++i)                    \
-                _Pragma("unroll") for (int j = 0; j < TN; ++j) {              \
-      HRV_MMA1(i, j, fa[kq][i][e], fb[kq][j][e])                              \
-    }                                                                         \
+#define HRV_MMA_FRAGS()                                                                              \
+  {                                                                                                  \
+    if constexpr (BF) {                                                                              \
+      /* v_mfma_f32_32x32x16_bf16: lane half h supplies k = 8h..8h+7 of each 16-wide step */          \
+      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                               \
+          _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
+              _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
+        const bf16x8 av = __builtin_bit_cast(bf16x8, fa[kq][i]);                                     \
+        const bf16x8 bv = __builtin_bit_cast(bf16x8, fb[kq][j]);                                     \
+        acc[i][j] = SWAP ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[i][j], 0, 0, 0)       \
+                         : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);      \
+      }                                                                                              \
+    } else {                                                                                         \
+      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                               \
+          _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
+              _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
+                  _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
+        HRV_MMA1(i, j, fa[kq][i][e], fb[kq][j][e])                                                   \
+      }                                                                                              \
+    }                                                                                                \
   }
 
   f32x4 fa[2][TM], fb[2][TN];
@@ -284,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
       // followed by a slice of the gather's address arithmetic / load issue.
       __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
 #pragma unroll
-      for (int m = 0; m < 8 * TM * TN; ++m) {
+      for (int m = 0; m < (BF ? 2 : 8) * TM * TN; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
         if (m < AR + BR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -357,16 +419,16 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
           if (c_ok && pidx < p.M) {
             float v = acc[i][j][e] * sc + sh;
             const size_t opix = out_pixel(p, pidx);
-            if (p.res) v = res_combine(v, p.res[opix * p.res_cs + p.res_co + c], p.res_mode, p.slope);
+            if (p.res) v = res_combine(v, ld1e<BF>(p.res, opix * p.res_cs + p.res_co + c), p.res_mode, p.slope);
             v = apply_act(v, p.act, p.slope);
             if (!p.out_up) {
-              p.out[opix * p.out_cs + p.out_co + c] = v;
+              st1e<BF>(p.out, opix * p.out_cs + p.out_co + c, v);
             } else {
               const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
               const int h = rem / p.Wo, w = rem - h * p.Wo;
-              float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c;
-              o[0] = v; o[p.out_cs] = v;
-              o[(size_t)2 * p.Wo * p.out_cs] = v; o[(size_t)2 * p.Wo * p.out_cs + p.out_cs] = v;
+              const size_t o = (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c;
+              st1e<BF>(p.out, o, v); st1e<BF>(p.out, o + p.out_cs, v);
+              st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, v); st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, v);
             }
           }
         }
@@ -400,7 +462,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
               const int pidx = m0 + (wm * TM + i) * 32 + l31;
               if (c_ok && pidx < p.M) {
                 const int n = pidx / HWo;
-                f32x4 x = *reinterpret_cast<const f32x4*>(p.sx + (size_t)pidx * p.sx_cs + p.sx_co + c0);
+                f32x4 x = ld4e<BF>(p.sx, (size_t)pidx * p.sx_cs + p.sx_co + c0);
                 if (p.sz) {
                   const int rem = pidx - n * HWo;
                   const int h = rem / p.Wo, w = rem - h * p.Wo;
@@ -416,7 +478,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
                   v[e] = apply_act((x[e] - mu[e]) * rs[e] * g1[e] + bet, p.act, p.slope);
                 }
                 if (p.sg1p) *reinterpret_cast<f32x4*>(p.sg1p + (size_t)pidx * p.sC + c0) = g1;
-                *reinterpret_cast<f32x4*>(p.out + (size_t)pidx * p.out_cs + p.out_co + c0) = v;
+                st4e<BF>(p.out, (size_t)pidx * p.out_cs + p.out_co + c0, v);
               }
             }
           }
@@ -442,22 +504,22 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * sc[e] + sh[e];
             const size_t opix = out_pixel(p, pidx);
             if (p.res) {
-              const f32x4 r4 = *reinterpret_cast<const f32x4*>(p.res + opix * p.res_cs + p.res_co + c0);
+              const f32x4 r4 = ld4e<BF>(p.res, opix * p.res_cs + p.res_co + c0);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = res_combine(v[e], r4[e], p.res_mode, p.slope);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
             if (!p.out_up) {
-              *reinterpret_cast<f32x4*>(p.out + opix * p.out_cs + p.out_co + c0) = v;
+              st4e<BF>(p.out, opix * p.out_cs + p.out_co + c0, v);
             } else {
               const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
               const int h = rem / p.Wo, w = rem - h * p.Wo;
-              float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c0;
-              *reinterpret_cast<f32x4*>(o) = v;
-              *reinterpret_cast<f32x4*>(o + p.out_cs) = v;
-              *reinterpret_cast<f32x4*>(o + (size_t)2 * p.Wo * p.out_cs) = v;
-              *reinterpret_cast<f32x4*>(o + (size_t)2 * p.Wo * p.out_cs + p.out_cs) = v;
+              const size_t o = (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c0;
+              st4e<BF>(p.out, o, v);
+              st4e<BF>(p.out, o + p.out_cs, v);
+              st4e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, v);
+              st4e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, v);
             }
           }
         }
@@ -467,6 +529,7 @@ __global__ __launch_bounds__(256) void conv_f32_mfma_kernel(const ConvParams p) 
 }
 
 // Split-K second stage: fixed-order sum of the partial tiles + the standard epilogue.
+template <bool BF>
 __global__ void splitk_reduce_kernel(const ConvParams p) {
   const int C4 = (p.Cout + 3) / 4;
   const size_t total = (size_t)p.M * C4;
@@ -490,14 +553,14 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
       if (c >= p.Cout) break;
       float t = v[e] * (p.scale ? p.scale[c] : 1.f) + (p.shift ? p.shift[c] : 0.f);
       const size_t opix = out_pixel(p, pidx);
-      if (p.res) t = res_combine(t, p.res[opix * p.res_cs + p.res_co + c], p.res_mode, p.slope);
+      if (p.res) t = res_combine(t, ld1e<BF>(p.res, opix * p.res_cs + p.res_co + c), p.res_mode, p.slope);
       t = apply_act(t, p.act, p.slope);
       if (!p.out_up) {
-        p.out[opix * p.out_cs + p.out_co + c] = t;
+        st1e<BF>(p.out, opix * p.out_cs + p.out_co + c, t);
       } else {
-        float* o = p.out + (((size_t)on * 2 * p.Ho + 2 * oh) * 2 * p.Wo + 2 * ow) * p.out_cs + p.out_co + c;
-        o[0] = t; o[p.out_cs] = t;
-        o[(size_t)2 * p.Wo * p.out_cs] = t; o[(size_t)2 * p.Wo * p.out_cs + p.out_cs] = t;
+        const size_t o = (((size_t)on * 2 * p.Ho + 2 * oh) * 2 * p.Wo + 2 * ow) * p.out_cs + p.out_co + c;
+        st1e<BF>(p.out, o, t); st1e<BF>(p.out, o + p.out_cs, t);
+        st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, t); st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, t);
       }
     }
   }
@@ -577,7 +640,9 @@ static int pick_splitk(int nblk, int KT, bool allowed) {
   return s < 2 ? 1 : s;
 }
 
-static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
+static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, bool bf = false) {
+  const int cm = bf ? 8 : 4;     // channel granularity = one 16-byte gather group
+  const int bke = bf ? 32 : 16;  // k-values per K-tile
   HRV_REQUIRE(d != nullptr, "conv2d: null descriptor");
   HRV_REQUIRE(d->nsrc >= 1 && d->nsrc <= HRV_MAX_SRC, "conv2d: nsrc=%d out of range", d->nsrc);
   HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "conv2d: bad extent");
@@ -594,14 +659,15 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   HRV_REQUIRE(d->Cout > 0 && d->out != nullptr, "conv2d: bad output");
   HRV_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (int64_t)1 << 31, "conv2d: too many output pixels");
   memset(&p, 0, sizeof(p));
+  p.bf16 = bf ? 1 : 0;
   p.nsrc = d->nsrc;
   int chunks_total = 0;
   for (int i = 0; i < d->nsrc; ++i) {
     const hrv_src_t& s = d->src[i];
     HRV_REQUIRE(s.ptr != nullptr, "conv2d: src[%d] null", i);
-    HRV_REQUIRE(s.C > 0 && s.C % 4 == 0 && s.cstride % 4 == 0 && s.coff % 4 == 0 && s.coff + s.C <= s.cstride,
-                "conv2d: src[%d] channels C=%d cstride=%d coff=%d must be multiples of 4 and in range", i, s.C,
-                s.cstride, s.coff);
+    HRV_REQUIRE(s.C > 0 && s.C % cm == 0 && s.cstride % cm == 0 && s.coff % cm == 0 && s.coff + s.C <= s.cstride,
+                "conv2d: src[%d] channels C=%d cstride=%d coff=%d must be multiples of %d and in range", i, s.C,
+                s.cstride, s.coff, cm);
     HRV_REQUIRE(((uintptr_t)s.ptr & 15) == 0, "conv2d: src[%d] not 16-byte aligned", i);
     HRV_REQUIRE(s.up_shift >= -7 && s.up_shift <= 1 && (s.up_shift != 1 || (d->H % 2 == 0 && d->W % 2 == 0)),
                 "conv2d: src[%d] up_shift=%d out of range", i, s.up_shift);
@@ -619,7 +685,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
     p.src[i].coff = s.coff;
     p.src[i].up_shift = s.up_shift;
     p.src[i].pre_act = s.pre_act;
-    p.src[i].chunks = (s.C + BK - 1) / BK;
+    p.src[i].chunks = (s.C + bke - 1) / bke;
     chunks_total += p.src[i].chunks;
   }
   p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
@@ -684,7 +750,8 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed) {
   return HRV_OK;
 }
 
-// Product default variant; HRV_CONV_VARIANT (0..3) overrides it for A/B measurements.
+// Product default variant; HRV_CONV_VARIANT (0..3) overrides it for A/B measurements
+// (variants 2/3 = software-pipelined body exist for fp32 only).
 constexpr int kDefaultVariant = 1;
 
 template <int TM, int TN, int WM, int WN>
@@ -692,27 +759,51 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
   const int nblk = p.m_tiles * p.n_tiles * p.splitk;
   const char* ev = getenv("HRV_CONV_VARIANT");
   int var = ev ? atoi(ev) : kDefaultVariant;
+  const int esz = p.bf16 ? 2 : 4;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
-                      (((uintptr_t)p.out | (uintptr_t)p.res | (uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0;
+                      (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 &&
+                      (((uintptr_t)p.out | (uintptr_t)p.res) & (4 * esz - 1)) == 0;
   if (p.epi == 1) {
     if (TN % 2 != 0) { set_error("conv2d/spade: tile_cfg must have an even TN (cfg 0, 4, 6 or 7)"); return HRV_ERR_ARG; }
     var |= 1;  // the SPADE epilogue lives in the swapped-operand layout
   } else if (!vec_ok) {
     var &= ~1;  // scalar epilogue for odd channel counts / unaligned slices
   }
-  switch (var) {
-    case 0: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 0>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 1: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 1>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 2>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((conv_f32_mfma_kernel<TM, TN, WM, WN, 3>), dim3(nblk), dim3(256), 0, st, p); break;
-    default: set_error("conv2d: HRV_CONV_VARIANT=%d invalid", var); return HRV_ERR_ARG;
+  if (p.bf16) {
+    if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true>), dim3(nblk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true>), dim3(nblk), dim3(256), 0, st, p);
+  } else {
+    switch (var) {
+      case 0: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, false>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 1: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, false>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 2, false>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 3, false>), dim3(nblk), dim3(256), 0, st, p); break;
+      default: set_error("conv2d: HRV_CONV_VARIANT=%d invalid", var); return HRV_ERR_ARG;
+    }
   }
-  int rc = check_launch("conv_f32_mfma_kernel");
+  int rc = check_launch("conv_mfma_kernel");
   if (rc || p.splitk <= 1) return rc;
   const size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
   const size_t gsz = (total + 255) / 256;
-  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(gsz > 4096 ? 4096 : gsz)), dim3(256), 0, st, p);
+  const dim3 g((unsigned)(gsz > 4096 ? 4096 : gsz));
+  if (p.bf16) hipLaunchKernelGGL(splitk_reduce_kernel<true>, g, dim3(256), 0, st, p);
+  else hipLaunchKernelGGL(splitk_reduce_kernel<false>, g, dim3(256), 0, st, p);
   return check_launch("splitk_reduce_kernel");
+}
+
+static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
+  switch (tile_cfg) {
+    case 0: return launch_cfg<2, 2, 2, 2>(p, st);
+    case 1: return launch_cfg<1, 3, 4, 1>(p, st);
+    case 2: return launch_cfg<2, 3, 4, 1>(p, st);
+    case 3: return launch_cfg<2, 1, 4, 1>(p, st);
+    case 4: return launch_cfg<2, 2, 4, 1>(p, st);
+    case 5: return launch_cfg<1, 1, 4, 1>(p, st);
+    case 6: return launch_cfg<1, 2, 4, 1>(p, st);
+    case 7: return launch_cfg<4, 2, 2, 2>(p, st);
+  }
+  set_error("conv2d: tile_cfg=%d invalid", tile_cfg);
+  return HRV_ERR_ARG;
 }
 
 }  // namespace hrv
@@ -806,21 +897,71 @@ extern "C" int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d) {
 
 extern "C" int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {
   ConvParams p;
-  int rc = fill_params(d, p, true);
+  int rc = fill_params(d, p, true, false);
   if (rc) return rc;
-  hipStream_t st = (hipStream_t)stream;
-  switch (d->tile_cfg) {
-    case 0: return launch_cfg<2, 2, 2, 2>(p, st);
-    case 1: return launch_cfg<1, 3, 4, 1>(p, st);
-    case 2: return launch_cfg<2, 3, 4, 1>(p, st);
-    case 3: return launch_cfg<2, 1, 4, 1>(p, st);
-    case 4: return launch_cfg<2, 2, 4, 1>(p, st);
-    case 5: return launch_cfg<1, 1, 4, 1>(p, st);
-    case 6: return launch_cfg<1, 2, 4, 1>(p, st);
-    case 7: return launch_cfg<4, 2, 2, 2>(p, st);
+  return launch_any(d->tile_cfg, p, (hipStream_t)stream);
+}
+
+// bf16 storage (sources, packed weights, residual, SPADE x, output), fp32 accumulate / scale / shift /
+// statistics: v_mfma_f32_32x32x16_bf16.  Channel counts, strides and offsets are multiples of 8.
+extern "C" int hrv_conv2d_nhwc_bf16(const hrv_conv2d_t* d, hrv_stream_t stream) {
+  ConvParams p;
+  int rc = fill_params(d, p, true, true);
+  if (rc) return rc;
+  HRV_REQUIRE(!(d->spade && d->spade->g1p_out), "conv2d_bf16: g1p_out (training) is fp32-only");
+  return launch_any(d->tile_cfg, p, (hipStream_t)stream);
+}
+
+static inline unsigned short host_f2bf(float f) {
+  unsigned u;
+  memcpy(&u, &f, 4);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(u >> 16);
+}
+
+extern "C" int64_t hrv_conv2d_packed_elems_bf16(int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
+                                                int32_t tile_cfg) {
+  if (tile_cfg < 0 || tile_cfg >= kNumCfgs || nsrc < 1 || nsrc > HRV_MAX_SRC || !srcC) return -1;
+  const int bn = cfg_bn(tile_cfg);
+  const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
+  int64_t chunks = 0;
+  for (int i = 0; i < nsrc; ++i) chunks += (srcC[i] + 31) / 32;
+  return (int64_t)KH * KW * chunks * cpad * 32;
+}
+
+// HOST packer for the bf16 engine: [kt][CoutPad][32] bf16 (uint16), kt = (tap, source, 32-channel chunk)
+extern "C" int hrv_conv2d_pack_weight_bf16(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                           const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
+                                           uint16_t* out) {
+  HRV_REQUIRE(w && out && srcC && srcC_real, "pack_weight_bf16: null pointer");
+  HRV_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumCfgs, "pack_weight_bf16: bad tile_cfg %d", tile_cfg);
+  HRV_REQUIRE(nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_weight_bf16: bad nsrc");
+  const int bn = cfg_bn(tile_cfg);
+  const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
+  int cin_real = 0, chunks_total = 0;
+  for (int i = 0; i < nsrc; ++i) {
+    HRV_REQUIRE(srcC_real[i] > 0 && srcC_real[i] <= srcC[i] && srcC[i] % 8 == 0, "pack_weight_bf16: bad channel counts");
+    cin_real += srcC_real[i];
+    chunks_total += (srcC[i] + 31) / 32;
   }
-  set_error("conv2d: tile_cfg=%d invalid", d->tile_cfg);
-  return HRV_ERR_ARG;
+  const int64_t total = (int64_t)KH * KW * chunks_total * cpad * 32;
+  memset(out, 0, sizeof(uint16_t) * total);
+  const int64_t ostride = (int64_t)cin_real * KH * KW;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) {
+      int chunk0 = 0, cbase = 0;
+      for (int s = 0; s < nsrc; ++s) {
+        for (int c = 0; c < srcC_real[s]; ++c) {
+          const int64_t kt = (int64_t)(kh * KW + kw) * chunks_total + chunk0 + c / 32;
+          uint16_t* dst = out + (kt * cpad) * 32 + (c % 32);
+          const float* srcw = w + ((int64_t)(cbase + c) * KH + kh) * KW + kw;
+          for (int co = 0; co < Cout; ++co) dst[(int64_t)co * 32] = host_f2bf(srcw[co * ostride]);
+        }
+        chunk0 += (srcC[s] + 31) / 32;
+        cbase += srcC_real[s];
+      }
+    }
+  return HRV_OK;
 }
 
 extern "C" int hrv_conv2d_naive_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {

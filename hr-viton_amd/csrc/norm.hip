@@ -21,8 +21,19 @@ struct StatsParams {
   float* part;      // [N][NB][C4*4][2]
 };
 
+typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
+
+template <bool BF>
 __device__ __forceinline__ f32x4 stats_value(const StatsParams& p, int n, int pix, int g) {
-  f32x4 v = *reinterpret_cast<const f32x4*>(p.x + ((size_t)n * p.H * p.W + pix) * p.cs + p.co + g * 4);
+  f32x4 v;
+  const size_t idx = ((size_t)n * p.H * p.W + pix) * p.cs + p.co + g * 4;
+  if constexpr (BF) {
+    const u16x4 h = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.x) + idx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned)h[e] << 16);
+  } else {
+    v = *reinterpret_cast<const f32x4*>(p.x + idx);
+  }
   if (p.z) {
     const int h = pix / p.W, w = pix - h * p.W;
     const float zz = p.z[((size_t)n * p.W + w) * p.H + h];
@@ -31,6 +42,7 @@ __device__ __forceinline__ f32x4 stats_value(const StatsParams& p, int n, int pi
   return v;
 }
 
+template <bool BF>
 __global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams p) {
   __shared__ f32x4 red[2][256];
   const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
@@ -45,9 +57,9 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams
     const bool active = r < R && g < p.C4;
     f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
     if (active) {
-      const f32x4 K = stats_value(p, n, 0, g);  // shift: kills the cancellation in E[v^2]-E[v]^2
+      const f32x4 K = stats_value<BF>(p, n, 0, g);  // shift: kills the cancellation in E[v^2]-E[v]^2
       for (int px = p0 + r; px < p1; px += R) {
-        const f32x4 d = stats_value(p, n, px, g) - K;
+        const f32x4 d = stats_value<BF>(p, n, px, g) - K;
         s1 += d;
         s2 += d * d;
       }
@@ -71,6 +83,7 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams
   }
 }
 
+template <bool BF>
 __global__ void instnorm_finalize_kernel(const StatsParams p, float eps, float* __restrict__ mean,
                                          float* __restrict__ rstd) {
   const int C = p.C4 * 4;
@@ -83,7 +96,8 @@ __global__ void instnorm_finalize_kernel(const StatsParams p, float eps, float* 
     s1 += (double)src[0];
     s2 += (double)src[1];
   }
-  float K = p.x[(size_t)n * p.H * p.W * p.cs + p.co + c];
+  const size_t k0 = (size_t)n * p.H * p.W * p.cs + p.co + c;
+  float K = BF ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p.x)[k0] << 16) : p.x[k0];
   if (p.z) K += p.z[(size_t)n * p.W * p.H] * p.ns[c];
   const double cnt = (double)p.H * p.W;
   const double m = s1 / cnt;
@@ -157,28 +171,42 @@ extern "C" int64_t hrv_instnorm_workspace_elems(int32_t N, int32_t H, int32_t W,
   return (int64_t)N * nb * ((C + 3) / 4 * 4) * 2;
 }
 
-extern "C" int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
-                                           int32_t cstride, int32_t coff, const float* noise_z,
-                                           const float* noise_scale, float eps, float* workspace, float* mean,
-                                           float* rstd, hrv_stream_t stream) {
+template <bool BF>
+static int instnorm_stats_impl(const void* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
+                               const float* noise_z, const float* noise_scale, float eps, float* workspace, float* mean,
+                               float* rstd, hrv_stream_t stream) {
   HRV_REQUIRE(x && workspace && mean && rstd && N > 0 && H > 0 && W > 0, "instnorm_stats: bad args");
   HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && coff + C <= cstride,
               "instnorm_stats: channels must be multiples of 4 and in range");
   HRV_REQUIRE((noise_z == nullptr) == (noise_scale == nullptr), "instnorm_stats: noise_z and noise_scale go together");
-  HRV_REQUIRE((((uintptr_t)x | (uintptr_t)noise_scale) & 15) == 0, "instnorm_stats: 16-byte alignment");
+  HRV_REQUIRE((((uintptr_t)x) & (BF ? 7 : 15)) == 0 && (((uintptr_t)noise_scale) & 15) == 0, "instnorm_stats: alignment");
   StatsParams p;
-  p.x = x; p.N = N; p.H = H; p.W = W; p.C4 = C / 4; p.cs = cstride; p.co = coff;
+  p.x = (const float*)x; p.N = N; p.H = H; p.W = W; p.C4 = C / 4; p.cs = cstride; p.co = coff;
   p.z = noise_z; p.ns = noise_scale;
   const int HW = H * W;
   int nb = (HW + 511) / 512;
   p.NB = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
   p.part = workspace;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(instnorm_partial_kernel, dim3(p.NB, N), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(instnorm_partial_kernel<BF>, dim3(p.NB, N), dim3(256), 0, st, p);
   int rc = check_launch("instnorm_partial_kernel");
   if (rc) return rc;
-  hipLaunchKernelGGL(instnorm_finalize_kernel, dim3((N * C + 255) / 256), dim3(256), 0, st, p, eps, mean, rstd);
+  hipLaunchKernelGGL(instnorm_finalize_kernel<BF>, dim3((N * C + 255) / 256), dim3(256), 0, st, p, eps, mean, rstd);
   return check_launch("instnorm_finalize_kernel");
+}
+
+extern "C" int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                                           int32_t cstride, int32_t coff, const float* noise_z,
+                                           const float* noise_scale, float eps, float* workspace, float* mean,
+                                           float* rstd, hrv_stream_t stream) {
+  return instnorm_stats_impl<false>(x, N, H, W, C, cstride, coff, noise_z, noise_scale, eps, workspace, mean, rstd, stream);
+}
+
+extern "C" int hrv_instnorm_stats_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C,
+                                            int32_t cstride, int32_t coff, const float* noise_z,
+                                            const float* noise_scale, float eps, float* workspace, float* mean,
+                                            float* rstd, hrv_stream_t stream) {
+  return instnorm_stats_impl<true>(x, N, H, W, C, cstride, coff, noise_z, noise_scale, eps, workspace, mean, rstd, stream);
 }
 
 extern "C" int hrv_instnorm_apply_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,

@@ -47,6 +47,32 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, int co
   }
 }
 
+__global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ in, int N, int C, int HW,
+                                            unsigned short* __restrict__ out, int cs, int co) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const float* src = in + n * (size_t)C * HW + hw;
+    unsigned short* dst = out + i * cs + co;
+    for (int c = 0; c < C; ++c) {
+      unsigned u = __builtin_bit_cast(unsigned, src[(size_t)c * HW]);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      dst[c] = (unsigned short)(u >> 16);
+    }
+  }
+}
+
+__global__ void nhwc_bf16_to_nchw_f32_kernel(const unsigned short* __restrict__ in, int cs, int co, int N, int C, int HW,
+                                             float* __restrict__ out) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = i / HW, hw = i - n * HW;
+    const unsigned short* src = in + i * cs + co;
+    float* dst = out + n * (size_t)C * HW + hw;
+    for (int c = 0; c < C; ++c) dst[(size_t)c * HW] = __builtin_bit_cast(float, (unsigned)src[c] << 16);
+  }
+}
+
 // ---------------------------------------------------------------- bilinear
 // torch area_pixel_compute_source_index (align_corners=False, not cubic):
 //   src = max(ratio*(dst+0.5) - 0.5, 0); i0 = (int)src; i1 = i0 + (i0 < in-1); l1 = src - i0
@@ -250,6 +276,26 @@ extern "C" int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cstride,
                      in_coff, N, C, H * W, out);
   return check_launch("nhwc_to_nchw_kernel");
+}
+
+extern "C" int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, uint16_t* out,
+                                         int32_t out_cstride, int32_t out_coff, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nchw_f32_to_nhwc_bf16: bad args");
+  HRV_REQUIRE(out_coff >= 0 && out_coff + C <= out_cstride, "nchw_f32_to_nhwc_bf16: slice out of range");
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, C,
+                     H * W, out, out_cstride, out_coff);
+  return check_launch("nchw_f32_to_nhwc_bf16_kernel");
+}
+
+extern "C" int hrv_nhwc_bf16_to_nchw_f32(const uint16_t* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
+                                         int32_t H, int32_t W, float* out, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_bf16_to_nchw_f32: bad args");
+  HRV_REQUIRE(in_coff >= 0 && in_coff + C <= in_cstride, "nhwc_bf16_to_nchw_f32: slice out of range");
+  const size_t total = (size_t)N * H * W;
+  hipLaunchKernelGGL(nhwc_bf16_to_nchw_f32_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in,
+                     in_cstride, in_coff, N, C, H * W, out);
+  return check_launch("nhwc_bf16_to_nchw_f32_kernel");
 }
 
 extern "C" int hrv_resize_bilinear_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C,

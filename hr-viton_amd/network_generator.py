@@ -145,13 +145,13 @@ class SPADEResBlock(nn.Module):
 class _SpadePlan:
     """One SPADENorm on the HIP path: stats -> conv_shared(+ReLU) -> fused gamma||beta+modulate."""
 
-    def __init__(self, norm: SPADENorm, device, act: int, name: str):
+    def __init__(self, norm: SPADENorm, device, act: int, name: str, bf16: bool = False):
         cs = norm.conv_shared[0]
         self.label_nc = cs.in_channels
         self.shared = ConvLayer(cs.weight, [self.label_nc], device, shift=cs.bias, pad=1, act=ACT_RELU,
-                                name=name + ".conv_shared")
+                                name=name + ".conv_shared", bf16=bf16)
         self.mod = SpadeModulate(norm.conv_gamma.weight, norm.conv_gamma.bias, norm.conv_beta.weight,
-                                 norm.conv_beta.bias, norm.noise_scale, device, act, name + ".conv_gamma|beta")
+                                 norm.conv_beta.bias, norm.noise_scale, device, act, name + ".conv_gamma|beta", bf16=bf16)
 
     def __call__(self, x: Act, seg: Act, seg_shift: int, z: Optional[torch.Tensor]) -> Act:
         zz = z if (z is not None and self.mod.has_noise) else None
@@ -161,28 +161,29 @@ class _SpadePlan:
 
 
 class _BlockPlan:
-    def __init__(self, blk: SPADEResBlock, device, name: str):
+    def __init__(self, blk: SPADEResBlock, device, name: str, bf16: bool = False):
         self.learned = blk.learned_shortcut
-        self.n0 = _SpadePlan(blk.norm_0, device, ACT_LRELU, name + ".norm_0")
-        self.n1 = _SpadePlan(blk.norm_1, device, ACT_LRELU, name + ".norm_1")
+        self.bf16 = bf16
+        self.n0 = _SpadePlan(blk.norm_0, device, ACT_LRELU, name + ".norm_0", bf16)
+        self.n1 = _SpadePlan(blk.norm_1, device, ACT_LRELU, name + ".norm_1", bf16)
         s0, s1 = _sn_sigma(blk.conv_0), _sn_sigma(blk.conv_1)
         self.c0 = ConvLayer(_raw_weight(blk.conv_0), [blk.input_nc], device,
                             scale=torch.full((blk.middle_nc,), 1.0 / s0), shift=blk.conv_0.bias, pad=1,
-                            name=name + ".conv_0")
+                            name=name + ".conv_0", bf16=bf16)
         self.c1_scale = torch.full((blk.output_nc,), 1.0 / s1)
         self.c1_w, self.c1_b = _raw_weight(blk.conv_1), blk.conv_1.bias
         self.device, self.name, self.blk = device, name, blk
         self._c1 = {}
         if self.learned:
-            self.ns_ = _SpadePlan(blk.norm_s, device, ACT_NONE, name + ".norm_s")
+            self.ns_ = _SpadePlan(blk.norm_s, device, ACT_NONE, name + ".norm_s", bf16)
             ss = _sn_sigma(blk.conv_s)
             self.cs = ConvLayer(_raw_weight(blk.conv_s), [blk.input_nc], device,
-                                scale=torch.full((blk.output_nc,), 1.0 / ss), pad=0, name=name + ".conv_s")
+                                scale=torch.full((blk.output_nc,), 1.0 / ss), pad=0, name=name + ".conv_s", bf16=bf16)
 
     def conv1(self, act: int) -> ConvLayer:
         if act not in self._c1:
             self._c1[act] = ConvLayer(self.c1_w, [self.blk.middle_nc], self.device, scale=self.c1_scale,
-                                      shift=self.c1_b, pad=1, act=act, name=self.name + ".conv_1")
+                                      shift=self.c1_b, pad=1, act=act, name=self.name + ".conv_1", bf16=self.bf16)
         return self._c1[act]
 
     def __call__(self, x: Act, seg: Act, seg_shift: int, zs: Sequence[Optional[torch.Tensor]], out: Optional[Act],
@@ -245,17 +246,24 @@ class SPADEGenerator(BaseNetwork):
             names.append("up_4")
         return names
 
+    def _use_bf16(self) -> bool:
+        """The reference's ``--fp16`` (apex O1) switch selects the bf16-storage / fp32-accumulate engine
+        (no loss scaling needed); default fp32."""
+        return bool(getattr(self.param_opt, "fp16", False))
+
     def _build_plan(self, device):
-        P = {"blocks": [_BlockPlan(getattr(self, n), device, n) for n in self._blocks()]}
+        bf = self._use_bf16()
+        P = {"bf16": bf, "blocks": [_BlockPlan(getattr(self, n), device, n, bf) for n in self._blocks()]}
         P["stem"] = [ConvLayer(getattr(self, f"conv_{i}").weight, [self.input_nc], device,
-                               shift=getattr(self, f"conv_{i}").bias, pad=1, name=f"conv_{i}")
+                               shift=getattr(self, f"conv_{i}").bias, pad=1, name=f"conv_{i}", bf16=bf)
                      for i in range(len(P["blocks"]))]
         P["img"] = ConvLayer(self.conv_img.weight, [self.conv_img.in_channels], device, shift=self.conv_img.bias, pad=1,
-                             act=ACT_TANH, name="conv_img")
+                             act=ACT_TANH, name="conv_img", bf16=bf)
         return P
 
     def _get_plan(self, device):
-        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.WEIGHTS_EPOCH[0])
+        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.WEIGHTS_EPOCH[0],
+               self._use_bf16())
         if self._plan is None or self._plan_key != key:
             self._plan = self._build_plan(device)
             self._plan_key = key
@@ -290,8 +298,12 @@ class SPADEGenerator(BaseNetwork):
                              f"'{self.num_upsampling_layers}' (needs {self.sh << top}x{self.sw << top}; 'most' "
                              "needs H, W multiples of 128 -- see network_generator.py:207-218)")
         P = self._get_plan(x.device)
-        xin = ops.to_nhwc(x)       # [N,H,W,12] (9 real channels)
-        sg = seg if isinstance(seg, Act) else ops.to_nhwc(seg)      # [N,H,W,8]  (7 real channels)
+        bf = P["bf16"]
+        xin = ops.to_nhwc(x, bf16=bf)       # [N,H,W,12|16] (9 real channels)
+        if isinstance(seg, Act):
+            sg = seg if seg.bf16 == bf else ops.to_nhwc(ops.to_nchw(seg), bf16=bf)
+        else:
+            sg = ops.to_nhwc(seg, bf16=bf)  # [N,H,W,8]  (7 real channels)
         dev = x.device
 
         def draws(name, blk, h, w):
@@ -318,7 +330,7 @@ class SPADEGenerator(BaseNetwork):
                 cur = blk(cur, sg, shift, draws(name, blk, h, w), None, 0, ACT_LRELU)
             else:
                 nxt_c = getattr(self, names[j + 1]).input_nc
-                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)
+                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev, bf)
                 blk(cur, sg, shift, draws(name, blk, h, w), nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
                 cur = nxt
         img = P["img"]([cur])

@@ -27,6 +27,11 @@ def _ceil4(c: int) -> int:
     return (c + 3) // 4 * 4
 
 
+def _cpad(c: int, bf16: bool) -> int:
+    """Channel padding of an NHWC tensor: one 16-byte gather group (4 fp32 / 8 bf16 channels)."""
+    return (c + 7) // 8 * 8 if bf16 else (c + 3) // 4 * 4
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -35,8 +40,8 @@ def require_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise HrvError(f"{what}: tensor is on {t.device}; the MI355X path has no CPU fallback "
                        "(move inputs to cuda, reference semantics of opt.cuda=True)")
-    if t.dtype != torch.float32:
-        raise HrvError(f"{what}: expected float32, got {t.dtype}")
+    if t.dtype not in (torch.float32, torch.bfloat16):
+        raise HrvError(f"{what}: expected float32 (or bfloat16 inside the bf16 path), got {t.dtype}")
 
 
 @dataclass
@@ -55,43 +60,56 @@ class Act:
     @property
     def cstride(self): return self.t.shape[3]
     @property
+    def bf16(self):
+        return self.t.dtype == torch.bfloat16
+
+    @property
     def Cp(self):
-        """Channels the conv engine consumes (padded to a multiple of 4; pad channels are zero)."""
-        return _ceil4(self.C)
+        """Channels the conv engine consumes (padded to one 16-byte group; pad channels are zero)."""
+        return _cpad(self.C, self.bf16)
 
     def slice(self, c0: int, c: int) -> "Act":
         return Act(self.t, c, self.coff + c0)
 
 
-def alloc(N: int, H: int, W: int, C: int, device) -> Act:
-    cs = _ceil4(C)
+def alloc(N: int, H: int, W: int, C: int, device, bf16: bool = False) -> Act:
+    cs = _cpad(C, bf16)
+    dt = torch.bfloat16 if bf16 else torch.float32
     if cs == C:
-        t = torch.empty((N, H, W, cs), dtype=torch.float32, device=device)
+        t = torch.empty((N, H, W, cs), dtype=dt, device=device)
     else:  # pad channels must read as zero
-        t = torch.zeros((N, H, W, cs), dtype=torch.float32, device=device)
+        t = torch.zeros((N, H, W, cs), dtype=dt, device=device)
     return Act(t, C, 0)
 
 
-def to_nhwc(x: torch.Tensor, out: Optional[Act] = None) -> Act:
-    """NCHW (reference layout) -> NHWC Act.  hrv_nchw_to_nhwc_f32."""
+def to_nhwc(x: torch.Tensor, out: Optional[Act] = None, bf16: bool = False) -> Act:
+    """fp32 NCHW (reference layout) -> NHWC Act (fp32, or bf16 for the bf16 engine)."""
     require_cuda(x, "to_nhwc")
     x = x.contiguous()
     N, Cc, H, W = x.shape
     if out is None:
-        out = alloc(N, H, W, Cc, x.device)
+        out = alloc(N, H, W, Cc, x.device, bf16)
     lib = _lib.load()
-    _lib.check(lib.hrv_nchw_to_nhwc_f32(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
-                                        _stream()), "hrv_nchw_to_nhwc_f32")
+    if out.bf16:
+        _lib.check(lib.hrv_nchw_f32_to_nhwc_bf16(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
+                                                 _stream()), "hrv_nchw_f32_to_nhwc_bf16")
+    else:
+        _lib.check(lib.hrv_nchw_to_nhwc_f32(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
+                                            _stream()), "hrv_nchw_to_nhwc_f32")
     return out
 
 
 def to_nchw(a: Act, c0: int = 0, c: Optional[int] = None) -> torch.Tensor:
-    """NHWC Act (channel range) -> contiguous NCHW tensor.  hrv_nhwc_to_nchw_f32."""
+    """NHWC Act (channel range) -> contiguous fp32 NCHW tensor."""
     c = a.C - c0 if c is None else c
     out = torch.empty((a.N, c, a.H, a.W), dtype=torch.float32, device=a.t.device)
     lib = _lib.load()
-    _lib.check(lib.hrv_nhwc_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W, out.data_ptr(),
-                                        _stream()), "hrv_nhwc_to_nchw_f32")
+    if a.bf16:
+        _lib.check(lib.hrv_nhwc_bf16_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W,
+                                                 out.data_ptr(), _stream()), "hrv_nhwc_bf16_to_nchw_f32")
+    else:
+        _lib.check(lib.hrv_nhwc_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W, out.data_ptr(),
+                                            _stream()), "hrv_nhwc_to_nchw_f32")
     return out
 
 
@@ -162,14 +180,15 @@ class ConvLayer:
 
     def __init__(self, weight: torch.Tensor, src_real: Sequence[int], device, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1, act: int = ACT_NONE,
-                 slope: float = 0.2, name: str = "conv"):
+                 slope: float = 0.2, name: str = "conv", bf16: bool = False):
+        self.bf16 = bf16
         w = weight.detach().to("cpu", torch.float32).contiguous()
         self.Cout, cin, self.KH, self.KW = w.shape
         assert sum(src_real) == cin, (name, src_real, cin)
         assert 1 <= len(src_real) <= _lib.HRV_MAX_SRC
         self.w_cpu = w
         self.src_real = list(src_real)
-        self.src_pad = [_ceil4(c) for c in src_real]
+        self.src_pad = [_cpad(c, bf16) for c in src_real]
         self.device = device
         self.stride, self.pad, self.act, self.slope, self.name = stride, pad, act, slope, name
         self.scale = None if scale is None else scale.detach().to(device, torch.float32).contiguous()
@@ -183,12 +202,18 @@ class ConvLayer:
             n = len(self.src_pad)
             srcC = (C.c_int32 * n)(*self.src_pad)
             srcR = (C.c_int32 * n)(*self.src_real)
-            elems = lib.hrv_conv2d_packed_elems(self.Cout, self.KH, self.KW, n, srcC, cfg)
+            if self.bf16:
+                elems = lib.hrv_conv2d_packed_elems_bf16(self.Cout, self.KH, self.KW, n, srcC, cfg)
+                buf = torch.empty(max(elems, 1), dtype=torch.int16)
+                _lib.check(lib.hrv_conv2d_pack_weight_bf16(self.w_cpu.data_ptr(), self.Cout, self.KH, self.KW, n, srcC,
+                                                           srcR, cfg, buf.data_ptr()), "hrv_conv2d_pack_weight_bf16")
+            else:
+                elems = lib.hrv_conv2d_packed_elems(self.Cout, self.KH, self.KW, n, srcC, cfg)
+                buf = torch.empty(max(elems, 1), dtype=torch.float32)
+                _lib.check(lib.hrv_conv2d_pack_weight_f32(self.w_cpu.data_ptr(), self.Cout, self.KH, self.KW, n, srcC,
+                                                          srcR, cfg, buf.data_ptr()), "hrv_conv2d_pack_weight_f32")
             if elems <= 0:
                 raise HrvError(f"{self.name}: hrv_conv2d_packed_elems failed")
-            buf = torch.empty(elems, dtype=torch.float32)
-            _lib.check(lib.hrv_conv2d_pack_weight_f32(self.w_cpu.data_ptr(), self.Cout, self.KH, self.KW, n, srcC,
-                                                      srcR, cfg, buf.data_ptr()), "hrv_conv2d_pack_weight_f32")
             self._packed[cfg] = buf.to(self.device)
         return self._packed[cfg]
 
@@ -214,7 +239,8 @@ class ConvLayer:
         Ho, Wo = self.out_hw(H, W)
         oc = self.Cout if out_channels is None else out_channels
         if out is None:
-            out = alloc(N, Ho << out_up, Wo << out_up, oc, a0.t.device)
+            out = alloc(N, Ho << out_up, Wo << out_up, oc, a0.t.device, self.bf16)
+        assert out.bf16 == self.bf16 and all(a.bf16 == self.bf16 for a, _, _ in specs), (self.name, "dtype mix")
         d = _lib.hrv_conv2d_t()
         d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
@@ -255,7 +281,8 @@ class ConvLayer:
             if need > 0:
                 ws = _workspace(a0.t.device, need)
                 d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else lib.hrv_conv2d_nhwc_f32
+        fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else (lib.hrv_conv2d_nhwc_bf16 if self.bf16 else lib.hrv_conv2d_nhwc_f32)
+        assert not (naive and self.bf16), "the naive cross-check is fp32"
         with _Timed("conv", self.name, self.flops(N, Ho, Wo), 0):
             _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")
         return out
@@ -304,8 +331,9 @@ def instnorm_stats(a: Act, z: Optional[torch.Tensor] = None, noise_scale: Option
     rstd = torch.empty((a.N, Cp), dtype=torch.float32, device=dev)
     if z is not None:
         assert z.is_contiguous() and z.numel() == a.N * a.W * a.H and noise_scale.numel() == Cp
-    with _Timed("stats", "instnorm_stats", 0.0, 4.0 * a.N * a.H * a.W * Cp):
-        _lib.check(lib.hrv_instnorm_stats_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, Cp, a.cstride, a.coff,
+    fn = lib.hrv_instnorm_stats_nhwc_bf16 if a.bf16 else lib.hrv_instnorm_stats_nhwc_f32
+    with _Timed("stats", "instnorm_stats", 0.0, (2.0 if a.bf16 else 4.0) * a.N * a.H * a.W * Cp):
+        _lib.check(fn(a.t.data_ptr(), a.N, a.H, a.W, Cp, a.cstride, a.coff,
                                                    None if z is None else z.data_ptr(),
                                                    None if z is None else noise_scale.data_ptr(), eps,
                                                    ws.data_ptr(), mean.data_ptr(), rstd.data_ptr(), _stream()),
@@ -340,11 +368,12 @@ class SpadeModulate:
     """Fused conv_gamma || conv_beta (128 -> 2C, 3x3) whose epilogue applies
     IN(x + noise) * (1 + gamma) + beta (+ LeakyReLU): network_generator.py:101-122,170-171."""
 
-    def __init__(self, w_gamma, b_gamma, w_beta, b_beta, noise_scale, device, act: int, name: str):
+    def __init__(self, w_gamma, b_gamma, w_beta, b_beta, noise_scale, device, act: int, name: str, bf16: bool = False):
         wg = w_gamma.detach().to("cpu", torch.float32)
         wb = w_beta.detach().to("cpu", torch.float32)
+        self.bf16 = bf16
         self.Creal = wg.shape[0]
-        self.Cp = _ceil4(self.Creal)
+        self.Cp = _cpad(self.Creal, bf16)
         G = (self.Creal + 31) // 32
         hid, k = wg.shape[1], wg.shape[2]
         w = torch.zeros(G * 64, hid, k, k)
@@ -355,7 +384,7 @@ class SpadeModulate:
             w[g * 64 + 32: g * 64 + 32 + n] = wb[g * 32: g * 32 + n]
             b[g * 64: g * 64 + n] = b_gamma.detach().cpu().float()[g * 32: g * 32 + n]
             b[g * 64 + 32: g * 64 + 32 + n] = b_beta.detach().cpu().float()[g * 32: g * 32 + n]
-        self.conv = ConvLayer(w, [hid], device, shift=b, stride=1, pad=k // 2, act=act, name=name)
+        self.conv = ConvLayer(w, [hid], device, shift=b, stride=1, pad=k // 2, act=act, name=name, bf16=bf16)
         self.conv.flops_cout = 2 * self.Creal   # algorithmic (unpadded) gamma+beta columns
         self.cfg = 0 if (G % 2 == 0) else 6   # 128x128 tile when the pair count is even, else 128x64
         ns = torch.zeros(self.Cp)
@@ -375,7 +404,7 @@ class SpadeModulate:
         e.noise_z = z.data_ptr() if use_noise else None
         e.noise_scale = self.ns.data_ptr() if use_noise else None
         if out is None:
-            out = alloc(x.N, x.H, x.W, self.Creal, x.t.device)
+            out = alloc(x.N, x.H, x.W, self.Creal, x.t.device, self.bf16)
         return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=self.cfg)
 
 

@@ -257,6 +257,15 @@ int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* 
  * the workspace, fixed-order reduction + epilogue in a second kernel: deterministic). */
 int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d);
 int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream);
+/* bf16 storage / fp32 accumulate flavour of the same engine (v_mfma_f32_32x32x16_bf16): sources,
+ * packed weights, residual, the SPADE x tensor and the output are bf16 (uint16_t bit patterns);
+ * scale / shift / mean / rstd / noise stay fp32.  Channel counts, strides and offsets are multiples
+ * of 8 (one 16-byte gather group).  Same descriptor; w_packed from hrv_conv2d_pack_weight_bf16. */
+int64_t hrv_conv2d_packed_elems_bf16(int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
+                                     int32_t tile_cfg);
+int hrv_conv2d_pack_weight_bf16(const float* w_oihw, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, uint16_t* out);
+int hrv_conv2d_nhwc_bf16(const hrv_conv2d_t* d, hrv_stream_t stream);
 /* Same contract, one thread per output element, raw OIHW weights.  A device
  * side cross-check used by the tests to localise faults; never on the product
  * path. */
@@ -283,6 +292,9 @@ int64_t hrv_instnorm_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C)
 int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
                                 int32_t coff, const float* noise_z, const float* noise_scale, float eps,
                                 float* workspace, float* mean, float* rstd, hrv_stream_t stream);
+int hrv_instnorm_stats_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
+                                 int32_t coff, const float* noise_z, const float* noise_scale, float eps,
+                                 float* workspace, float* mean, float* rstd, hrv_stream_t stream);
 int hrv_instnorm_apply_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
                                 int32_t coff, const float* mean, const float* rstd, int32_t act, float act_slope,
                                 float* out, int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
@@ -324,6 +336,11 @@ int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32
                          int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
 int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
                          int32_t H, int32_t W, float* out, hrv_stream_t stream);
+/* fp32 NCHW (module boundary) <-> bf16 NHWC (inside the bf16 generator path) */
+int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, uint16_t* out,
+                              int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+int hrv_nhwc_bf16_to_nchw_f32(const uint16_t* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
+                              int32_t H, int32_t W, float* out, hrv_stream_t stream);
 
 /* ------------------------------------------------------------------------
  * Bilinear resize, align_corners=False (F.interpolate / nn.Upsample bilinear:

@@ -287,3 +287,63 @@ def test_conv_split_k(splitk):
             os.environ.pop("HRV_CONV_SPLITK", None)
         else:
             os.environ["HRV_CONV_SPLITK"] = old
+
+
+BF16_CASES = [
+    # name, cins, cout, k, stride, pad, H, W, extras
+    ("bf_3x3", [64], 96, 3, 1, 1, 16, 12, {"bias": True, "act": "relu"}),
+    ("bf_res", [32], 128, 3, 1, 1, 16, 12, {"bn": True, "res": True, "act": "lrelu"}),
+    ("bf_cat_up", [32, 16], 64, 3, 1, 1, 16, 12, {"bias": True, "up0": True}),
+    ("bf_1x1", [80], 32, 1, 1, 0, 12, 8, {"bn": True}),
+    ("bf_cin9", [9], 16, 3, 1, 1, 16, 8, {"bias": True}),
+    ("bf_img3", [32], 3, 3, 1, 1, 16, 12, {"bias": True, "act": "tanh"}),
+    ("bf_down", [8], 128, 3, 1, 1, 8, 6, {"bias": True, "act": "relu", "down0": 2}),
+    ("bf_smallM_splitk", [256], 256, 3, 1, 1, 4, 3, {"bias": True}),
+]
+
+
+@pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
+def test_conv_bf16_engine(case):
+    """bf16 storage / fp32 accumulate engine (v_mfma_f32_32x32x16_bf16) vs the fp32 oracle evaluated on the
+    bf16-rounded operands: what remains is accumulation order + the final bf16 rounding (2^-8 relative)."""
+    ops = _ops()
+    name, real, cout, k, stride, pad, H, W, ex = case
+    g = torch.Generator().manual_seed(sum(map(ord, name)))
+    N = 2
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    xs = []
+    for i, c in enumerate(real):
+        shp = (N, c, H // 2, W // 2) if (ex.get("up0") and i == 0) else \
+            ((N, c, H << ex["down0"], W << ex["down0"]) if (ex.get("down0") and i == 0) else (N, c, H, W))
+        xs.append(rb(torch.randn(*shp, generator=g)))
+    w = rb(torch.randn(cout, sum(real), k, k, generator=g) * (1.0 / (sum(real) * k * k) ** 0.5))
+    scale = (torch.rand(cout, generator=g) + 0.5) if ex.get("bn") else None
+    shift = torch.randn(cout, generator=g) * 0.3 if (ex.get("bn") or ex.get("bias")) else None
+    act = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}.get(ex.get("act"), ops.ACT_NONE)
+    full = []
+    for i, x in enumerate(xs):
+        if ex.get("up0") and i == 0:
+            x = x.repeat_interleave(2, 2).repeat_interleave(2, 3)
+        if ex.get("down0") and i == 0:
+            x = O.resize_nearest(x, (H, W))
+        full.append(x)
+    ref = F.conv2d(torch.cat(full, 1), w, None, stride=stride, padding=pad)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        ref = ref + shift.view(1, -1, 1, 1)
+    res = rb(torch.randn(ref.shape, generator=g)) if ex.get("res") else None
+    if res is not None:
+        ref = ref + res
+    ref = {ops.ACT_RELU: F.relu, ops.ACT_LRELU: lambda t: F.leaky_relu(t, 0.2), ops.ACT_TANH: torch.tanh,
+           ops.ACT_NONE: lambda t: t}[act](ref)
+    layer = ops.ConvLayer(w, real, "cuda", scale=scale, shift=shift, stride=stride, pad=pad, act=act, name=name, bf16=True)
+    srcs = []
+    for i, x in enumerate(xs):
+        up = 1 if (ex.get("up0") and i == 0) else (-ex["down0"] if (ex.get("down0") and i == 0) else 0)
+        srcs.append((ops.to_nhwc(x.cuda(), bf16=True), up, ops.ACT_NONE))
+    res_act = ops.to_nhwc(res.cuda(), bf16=True) if res is not None else None
+    o = layer(srcs, residual=res_act, H=H, W=W)
+    got = ops.to_nchw(o)
+    assert o.t.dtype == torch.bfloat16 and (o.t[..., cout:].float() == 0).all()
+    _assert_close("conv_bf16_" + name, got, ref, 1e-2)
