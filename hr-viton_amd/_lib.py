@@ -52,7 +52,7 @@ class hrv_conv2d_t(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("pad_w_plus1", C.c_int32), ("free_extent", C.c_int32), ("out_step", C.c_int32),
                 ("out_off_h", C.c_int32), ("out_off_w", C.c_int32), ("out_H", C.c_int32), ("out_W", C.c_int32),
-                ("res_mode", C.c_int32)]
+                ("res_mode", C.c_int32), ("mixed_flags", C.c_int32), ("_pad3", C.c_int32)]
 
 
 class hrv_flow_warp_t(C.Structure):

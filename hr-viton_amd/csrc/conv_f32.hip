@@ -65,7 +65,8 @@ struct ConvParams {
   int pad_w;   // horizontal padding (pad is the vertical one)
   int out_up;  // 1: replicate every result to its 2x2 block of a (2Ho x 2Wo) output
   int out_step, out_oh, out_ow, out_H, out_W;  // out_step 2: scatter to (2h+oh, 2w+ow) of an out_H x out_W output
-  int bf16;      // 1: sources / weights / residual / out / SPADE x are bf16 (accumulate + stats fp32)
+  int bf16;      // 1: sources / weights are bf16 (accumulate + stats fp32)
+  int out_f32, res_f32, sx_f32;  // bf16 mode: these tensors are fp32 instead of bf16
   int res_mode;  // 0: + residual; 1: * (residual > 0 ? 1 : slope)   (activation derivative, backward)
   // SPADE epilogue (epi == 1)
   int epi;
@@ -140,6 +141,30 @@ template <bool BF>
 __device__ __forceinline__ void st1e(float* base, size_t idx, float v) {
   if constexpr (BF) reinterpret_cast<unsigned short*>(base)[idx] = f2bf(v);
   else base[idx] = v;
+}
+
+// In bf16 mode the conv SOURCES and WEIGHTS are bf16 (compile time); the output, the residual and the
+// SPADE x tensor may each be bf16 or fp32 (run-time flags): tensors that feed an InstanceNorm (block
+// inputs / residual stream) stay fp32, tensors that only feed convolutions are bf16.
+template <bool BF>
+__device__ __forceinline__ f32x4 ld4rt(const float* base, size_t idx, int is_f32) {
+  if constexpr (BF) { if (!is_f32) return ld4e<true>(base, idx); }
+  return ld4e<false>(base, idx);
+}
+template <bool BF>
+__device__ __forceinline__ float ld1rt(const float* base, size_t idx, int is_f32) {
+  if constexpr (BF) { if (!is_f32) return ld1e<true>(base, idx); }
+  return ld1e<false>(base, idx);
+}
+template <bool BF>
+__device__ __forceinline__ void st4rt(float* base, size_t idx, f32x4 v, int is_f32) {
+  if constexpr (BF) { if (!is_f32) { st4e<true>(base, idx, v); return; } }
+  st4e<false>(base, idx, v);
+}
+template <bool BF>
+__device__ __forceinline__ void st1rt(float* base, size_t idx, float v, int is_f32) {
+  if constexpr (BF) { if (!is_f32) { st1e<true>(base, idx, v); return; } }
+  st1e<false>(base, idx, v);
 }
 
 template <int TM, int TN, int WM, int WN, int VAR, bool BF>
@@ -419,16 +444,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
           if (c_ok && pidx < p.M) {
             float v = acc[i][j][e] * sc + sh;
             const size_t opix = out_pixel(p, pidx);
-            if (p.res) v = res_combine(v, ld1e<BF>(p.res, opix * p.res_cs + p.res_co + c), p.res_mode, p.slope);
+            if (p.res) v = res_combine(v, ld1rt<BF>(p.res, opix * p.res_cs + p.res_co + c, p.res_f32), p.res_mode, p.slope);
             v = apply_act(v, p.act, p.slope);
             if (!p.out_up) {
-              st1e<BF>(p.out, opix * p.out_cs + p.out_co + c, v);
+              st1rt<BF>(p.out, opix * p.out_cs + p.out_co + c, v, p.out_f32);
             } else {
               const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
               const int h = rem / p.Wo, w = rem - h * p.Wo;
               const size_t o = (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c;
-              st1e<BF>(p.out, o, v); st1e<BF>(p.out, o + p.out_cs, v);
-              st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, v); st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, v);
+              st1rt<BF>(p.out, o, v, p.out_f32); st1rt<BF>(p.out, o + p.out_cs, v, p.out_f32);
+              st1rt<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, v, p.out_f32); st1rt<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, v, p.out_f32);
             }
           }
         }
@@ -462,7 +487,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
               const int pidx = m0 + (wm * TM + i) * 32 + l31;
               if (c_ok && pidx < p.M) {
                 const int n = pidx / HWo;
-                f32x4 x = ld4e<BF>(p.sx, (size_t)pidx * p.sx_cs + p.sx_co + c0);
+                f32x4 x = ld4rt<BF>(p.sx, (size_t)pidx * p.sx_cs + p.sx_co + c0, p.sx_f32);
                 if (p.sz) {
                   const int rem = pidx - n * HWo;
                   const int h = rem / p.Wo, w = rem - h * p.Wo;
@@ -478,7 +503,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                   v[e] = apply_act((x[e] - mu[e]) * rs[e] * g1[e] + bet, p.act, p.slope);
                 }
                 if (p.sg1p) *reinterpret_cast<f32x4*>(p.sg1p + (size_t)pidx * p.sC + c0) = g1;
-                st4e<BF>(p.out, (size_t)pidx * p.out_cs + p.out_co + c0, v);
+                st4rt<BF>(p.out, (size_t)pidx * p.out_cs + p.out_co + c0, v, p.out_f32);
               }
             }
           }
@@ -504,22 +529,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
             for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * sc[e] + sh[e];
             const size_t opix = out_pixel(p, pidx);
             if (p.res) {
-              const f32x4 r4 = ld4e<BF>(p.res, opix * p.res_cs + p.res_co + c0);
+              const f32x4 r4 = ld4rt<BF>(p.res, opix * p.res_cs + p.res_co + c0, p.res_f32);
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = res_combine(v[e], r4[e], p.res_mode, p.slope);
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
             if (!p.out_up) {
-              st4e<BF>(p.out, opix * p.out_cs + p.out_co + c0, v);
+              st4rt<BF>(p.out, opix * p.out_cs + p.out_co + c0, v, p.out_f32);
             } else {
               const int n = pidx / (p.Ho * p.Wo), rem = pidx - n * (p.Ho * p.Wo);
               const int h = rem / p.Wo, w = rem - h * p.Wo;
               const size_t o = (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + c0;
-              st4e<BF>(p.out, o, v);
-              st4e<BF>(p.out, o + p.out_cs, v);
-              st4e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, v);
-              st4e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, v);
+              st4rt<BF>(p.out, o, v, p.out_f32);
+              st4rt<BF>(p.out, o + p.out_cs, v, p.out_f32);
+              st4rt<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, v, p.out_f32);
+              st4rt<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, v, p.out_f32);
             }
           }
         }
@@ -553,14 +578,14 @@ __global__ void splitk_reduce_kernel(const ConvParams p) {
       if (c >= p.Cout) break;
       float t = v[e] * (p.scale ? p.scale[c] : 1.f) + (p.shift ? p.shift[c] : 0.f);
       const size_t opix = out_pixel(p, pidx);
-      if (p.res) t = res_combine(t, ld1e<BF>(p.res, opix * p.res_cs + p.res_co + c), p.res_mode, p.slope);
+      if (p.res) t = res_combine(t, ld1rt<BF>(p.res, opix * p.res_cs + p.res_co + c, p.res_f32), p.res_mode, p.slope);
       t = apply_act(t, p.act, p.slope);
       if (!p.out_up) {
-        st1e<BF>(p.out, opix * p.out_cs + p.out_co + c, t);
+        st1rt<BF>(p.out, opix * p.out_cs + p.out_co + c, t, p.out_f32);
       } else {
         const size_t o = (((size_t)on * 2 * p.Ho + 2 * oh) * 2 * p.Wo + 2 * ow) * p.out_cs + p.out_co + c;
-        st1e<BF>(p.out, o, t); st1e<BF>(p.out, o + p.out_cs, t);
-        st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, t); st1e<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, t);
+        st1rt<BF>(p.out, o, t, p.out_f32); st1rt<BF>(p.out, o + p.out_cs, t, p.out_f32);
+        st1rt<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs, t, p.out_f32); st1rt<BF>(p.out, o + (size_t)2 * p.Wo * p.out_cs + p.out_cs, t, p.out_f32);
       }
     }
   }
@@ -660,6 +685,9 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
   HRV_REQUIRE((int64_t)d->N * d->Ho * d->Wo < (int64_t)1 << 31, "conv2d: too many output pixels");
   memset(&p, 0, sizeof(p));
   p.bf16 = bf ? 1 : 0;
+  p.out_f32 = bf ? (d->mixed_flags & 1) : 1;
+  p.res_f32 = bf ? ((d->mixed_flags >> 1) & 1) : 1;
+  p.sx_f32 = bf ? ((d->mixed_flags >> 2) & 1) : 1;
   p.nsrc = d->nsrc;
   int chunks_total = 0;
   for (int i = 0; i < d->nsrc; ++i) {
@@ -759,10 +787,10 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
   const int nblk = p.m_tiles * p.n_tiles * p.splitk;
   const char* ev = getenv("HRV_CONV_VARIANT");
   int var = ev ? atoi(ev) : kDefaultVariant;
-  const int esz = p.bf16 ? 2 : 4;
+  const int oesz = p.out_f32 ? 4 : 2, resz = p.res_f32 ? 4 : 2;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
-                      (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 &&
-                      (((uintptr_t)p.out | (uintptr_t)p.res) & (4 * esz - 1)) == 0;
+                      (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (((uintptr_t)p.out) & (4 * oesz - 1)) == 0 &&
+                      (((uintptr_t)p.res) & (4 * resz - 1)) == 0;
   if (p.epi == 1) {
     if (TN % 2 != 0) { set_error("conv2d/spade: tile_cfg must have an even TN (cfg 0, 4, 6 or 7)"); return HRV_ERR_ARG; }
     var |= 1;  // the SPADE epilogue lives in the swapped-operand layout

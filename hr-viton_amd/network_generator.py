@@ -169,7 +169,7 @@ class _BlockPlan:
         s0, s1 = _sn_sigma(blk.conv_0), _sn_sigma(blk.conv_1)
         self.c0 = ConvLayer(_raw_weight(blk.conv_0), [blk.input_nc], device,
                             scale=torch.full((blk.middle_nc,), 1.0 / s0), shift=blk.conv_0.bias, pad=1,
-                            name=name + ".conv_0", bf16=bf16)
+                            name=name + ".conv_0", bf16=bf16, out_f32=True)   # dx feeds norm_1's InstanceNorm
         self.c1_scale = torch.full((blk.output_nc,), 1.0 / s1)
         self.c1_w, self.c1_b = _raw_weight(blk.conv_1), blk.conv_1.bias
         self.device, self.name, self.blk = device, name, blk
@@ -178,12 +178,16 @@ class _BlockPlan:
             self.ns_ = _SpadePlan(blk.norm_s, device, ACT_NONE, name + ".norm_s", bf16)
             ss = _sn_sigma(blk.conv_s)
             self.cs = ConvLayer(_raw_weight(blk.conv_s), [blk.input_nc], device,
-                                scale=torch.full((blk.output_nc,), 1.0 / ss), pad=0, name=name + ".conv_s", bf16=bf16)
+                                scale=torch.full((blk.output_nc,), 1.0 / ss), pad=0, name=name + ".conv_s", bf16=bf16,
+                                out_f32=True)
 
     def conv1(self, act: int) -> ConvLayer:
         if act not in self._c1:
+            # the block output is the next block's InstanceNorm input (fp32) -- except the last block,
+            # whose LeakyReLU'd output only feeds conv_img (bf16)
             self._c1[act] = ConvLayer(self.c1_w, [self.blk.middle_nc], self.device, scale=self.c1_scale,
-                                      shift=self.c1_b, pad=1, act=act, name=self.name + ".conv_1", bf16=self.bf16)
+                                      shift=self.c1_b, pad=1, act=act, name=self.name + ".conv_1", bf16=self.bf16,
+                                      out_f32=(act == ACT_NONE))
         return self._c1[act]
 
     def __call__(self, x: Act, seg: Act, seg_shift: int, zs: Sequence[Optional[torch.Tensor]], out: Optional[Act],
@@ -255,10 +259,10 @@ class SPADEGenerator(BaseNetwork):
         bf = self._use_bf16()
         P = {"bf16": bf, "blocks": [_BlockPlan(getattr(self, n), device, n, bf) for n in self._blocks()]}
         P["stem"] = [ConvLayer(getattr(self, f"conv_{i}").weight, [self.input_nc], device,
-                               shift=getattr(self, f"conv_{i}").bias, pad=1, name=f"conv_{i}", bf16=bf)
+                               shift=getattr(self, f"conv_{i}").bias, pad=1, name=f"conv_{i}", bf16=bf, out_f32=True)
                      for i in range(len(P["blocks"]))]
         P["img"] = ConvLayer(self.conv_img.weight, [self.conv_img.in_channels], device, shift=self.conv_img.bias, pad=1,
-                             act=ACT_TANH, name="conv_img", bf16=bf)
+                             act=ACT_TANH, name="conv_img", bf16=bf, out_f32=True)
         return P
 
     def _get_plan(self, device):
@@ -330,7 +334,7 @@ class SPADEGenerator(BaseNetwork):
                 cur = blk(cur, sg, shift, draws(name, blk, h, w), None, 0, ACT_LRELU)
             else:
                 nxt_c = getattr(self, names[j + 1]).input_nc
-                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev, bf)
+                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)     # residual stream / InstanceNorm input: fp32
                 blk(cur, sg, shift, draws(name, blk, h, w), nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
                 cur = nxt
         img = P["img"]([cur])

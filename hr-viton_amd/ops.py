@@ -180,8 +180,11 @@ class ConvLayer:
 
     def __init__(self, weight: torch.Tensor, src_real: Sequence[int], device, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1, act: int = ACT_NONE,
-                 slope: float = 0.2, name: str = "conv", bf16: bool = False):
+                 slope: float = 0.2, name: str = "conv", bf16: bool = False, out_f32: bool = False):
+        # bf16: sources + weights are bf16 (fp32 accumulate); out_f32: in bf16 mode the output is written
+        # as fp32 (tensors that feed an InstanceNorm stay fp32)
         self.bf16 = bf16
+        self.out_f32 = out_f32 or not bf16
         w = weight.detach().to("cpu", torch.float32).contiguous()
         self.Cout, cin, self.KH, self.KW = w.shape
         assert sum(src_real) == cin, (name, src_real, cin)
@@ -239,9 +242,11 @@ class ConvLayer:
         Ho, Wo = self.out_hw(H, W)
         oc = self.Cout if out_channels is None else out_channels
         if out is None:
-            out = alloc(N, Ho << out_up, Wo << out_up, oc, a0.t.device, self.bf16)
-        assert out.bf16 == self.bf16 and all(a.bf16 == self.bf16 for a, _, _ in specs), (self.name, "dtype mix")
+            out = alloc(N, Ho << out_up, Wo << out_up, oc, a0.t.device, self.bf16 and not self.out_f32)
+        assert all(a.bf16 == self.bf16 for a, _, _ in specs), (self.name, "conv sources must match the engine dtype")
+        assert self.bf16 or not out.bf16, (self.name, "fp32 engine writes fp32")
         d = _lib.hrv_conv2d_t()
+        mixed = (0 if out.bf16 else 1) | (0 if (residual is None or residual.bf16) else 2)
         d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
         d.KH, d.KW, d.stride, d.pad = self.KH, self.KW, self.stride, self.pad
         d.nsrc = len(specs)
@@ -276,6 +281,8 @@ class ConvLayer:
         d.out_up_shift = out_up
         if spade is not None:
             d.spade = C.pointer(spade)
+            mixed |= 4 if getattr(spade, "_x_f32", True) else 0
+        d.mixed_flags = mixed if self.bf16 else 0
         if not naive and spade is None:
             need = lib.hrv_conv2d_workspace_bytes(C.byref(d))
             if need > 0:
@@ -398,6 +405,7 @@ class SpadeModulate:
     def __call__(self, actv: Act, x: Act, mean, rstd, z: Optional[torch.Tensor], out: Optional[Act] = None) -> Act:
         assert x.C == self.Creal, (self.conv.name, x.C, self.Creal)
         e = _lib.hrv_spade_epi_t()
+        e._x_f32 = not x.bf16
         e.x, e.x_cstride, e.x_coff, e.C = x.t.data_ptr(), x.cstride, x.coff, self.Cp
         e.mean, e.rstd = mean.data_ptr(), rstd.data_ptr()
         use_noise = z is not None and self.has_noise

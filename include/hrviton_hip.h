@@ -135,6 +135,10 @@ typedef struct hrv_conv2d {
   int32_t res_mode;     /* 0: epilogue adds `residual`; 1: multiplies by the activation
                            derivative (residual > 0 ? 1 : act_slope) -- LeakyReLU/ReLU
                            backward fused into the data-gradient convolution             */
+  int32_t mixed_flags;  /* hrv_conv2d_nhwc_bf16 only: bit0 = `out` is fp32, bit1 = `residual` is
+                           fp32, bit2 = spade->x is fp32 (tensors that feed an InstanceNorm stay
+                           fp32; tensors that only feed convolutions are bf16)            */
+  int32_t _pad3;
 } hrv_conv2d_t;
 
 /* Tile configuration for (M = N*Ho*Wo output pixels, Cout): returns cfg id. */

@@ -39,7 +39,7 @@ def test_struct_layout_matches_c(lib):
     from hr_viton_amd import _lib
     # sizes implied by the C declarations (LP64): see include/hrviton_hip.h
     assert C.sizeof(_lib.hrv_src_t) == 32
-    assert C.sizeof(_lib.hrv_conv2d_t) == 40 + 4 * 32 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 16 + 32
+    assert C.sizeof(_lib.hrv_conv2d_t) == 40 + 4 * 32 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 8 + 16 + 32 + 8
     assert C.sizeof(_lib.hrv_spade_epi_t) == 8 + 16 + 32 + 8
     assert C.sizeof(_lib.hrv_flow_warp_t) == 8 + 24 + 8 + 16 + 16 + 8 + 8 + 8
 
