@@ -255,6 +255,31 @@ def _sn_weight(sd: SD, p: str) -> Tensor:
     return sd[p + ".weight"]
 
 
+# Emulation of the bf16 engine's rounding points: when QUANT["fn"] is set (e.g. lambda t:
+# t.bfloat16().float()) every convolution of the generator rounds its input and weight with it and
+# accumulates in fp32 -- exactly where the HIP bf16 path rounds (conv operands); InstanceNorm inputs,
+# statistics, biases and the residual stream stay fp32.
+QUANT = {"fn": None}
+
+
+def _qconv(x: Tensor, w: Tensor, b, **kw) -> Tensor:
+    q = QUANT["fn"]
+    if q is not None:
+        x, w = q(x), q(w)
+    return F.conv2d(x, w, b, **kw)
+
+
+def _qconv_sn(sd: SD, p: str, x: Tensor, b, **kw) -> Tensor:
+    """Spectral-normed conv.  The bf16 engine rounds weight_orig and applies 1/sigma in the fp32 epilogue."""
+    q = QUANT["fn"]
+    if q is None or p + ".weight_orig" not in sd:
+        return _qconv(x, _sn_weight(sd, p), b, **kw)
+    w = sd[p + ".weight_orig"]
+    sigma = spectral_sigma(w, sd[p + ".weight_u"], sd[p + ".weight_v"])
+    y = F.conv2d(q(x), q(w), None, **kw) / sigma
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
 def spade_norm(sd: SD, p: str, x: Tensor, seg: Tensor, z: Optional[Tensor]) -> Tensor:
     """SPADENorm.forward -- network_generator.py:101-122.  ``z`` is the
     [b,w,h,1] standard-normal draw of :104-107 (None => zeros, which is what a
@@ -263,9 +288,9 @@ def spade_norm(sd: SD, p: str, x: Tensor, seg: Tensor, z: Optional[Tensor]) -> T
         noise = (z * sd[p + ".noise_scale"]).transpose(1, 3)
         x = x + noise
     normalized = instance_norm(x)
-    actv = F.relu(F.conv2d(seg, sd[p + ".conv_shared.0.weight"], sd[p + ".conv_shared.0.bias"], padding=1))
-    gamma = F.conv2d(actv, sd[p + ".conv_gamma.weight"], sd[p + ".conv_gamma.bias"], padding=1)
-    beta = F.conv2d(actv, sd[p + ".conv_beta.weight"], sd[p + ".conv_beta.bias"], padding=1)
+    actv = F.relu(_qconv(seg, sd[p + ".conv_shared.0.weight"], sd[p + ".conv_shared.0.bias"], padding=1))
+    gamma = _qconv(actv, sd[p + ".conv_gamma.weight"], sd[p + ".conv_gamma.bias"], padding=1)
+    beta = _qconv(actv, sd[p + ".conv_beta.weight"], sd[p + ".conv_beta.bias"], padding=1)
     return normalized * (1 + gamma) + beta
 
 
@@ -277,13 +302,13 @@ def spade_resblock(sd: SD, p: str, x: Tensor, seg: Tensor, zs: Optional[Sequence
     zi = iter(zs) if zs is not None else None
     if learned:
         xs = spade_norm(sd, p + ".norm_s", x, seg, next(zi) if zi else None)
-        x_s = F.conv2d(xs, _sn_weight(sd, p + ".conv_s"), None)
+        x_s = _qconv_sn(sd, p + ".conv_s", xs, None)
     else:
         x_s = x
     dx = F.leaky_relu(spade_norm(sd, p + ".norm_0", x, seg, next(zi) if zi else None), 0.2)
-    dx = F.conv2d(dx, _sn_weight(sd, p + ".conv_0"), sd[p + ".conv_0.bias"], padding=1)
+    dx = _qconv_sn(sd, p + ".conv_0", dx, sd[p + ".conv_0.bias"], padding=1)
     dx = F.leaky_relu(spade_norm(sd, p + ".norm_1", dx, seg, next(zi) if zi else None), 0.2)
-    dx = F.conv2d(dx, _sn_weight(sd, p + ".conv_1"), sd[p + ".conv_1.bias"], padding=1)
+    dx = _qconv_sn(sd, p + ".conv_1", dx, sd[p + ".conv_1.bias"], padding=1)
     return x_s + dx
 
 
@@ -294,7 +319,7 @@ def spade_generator_forward(sd: SD, x: Tensor, seg: Tensor, fine_height: int, fi
     nup = {"normal": 5, "more": 6, "most": 7}[num_upsampling_layers]
     sh, sw = fine_height // 2 ** nup, fine_width // 2 ** nup
     samples = [resize_nearest(x, (sh * 2 ** i, sw * 2 ** i)) for i in range(8)]
-    feats = [F.conv2d(samples[i], sd[f"conv_{i}.weight"], sd[f"conv_{i}.bias"], padding=1) for i in range(8)]
+    feats = [_qconv(samples[i], sd[f"conv_{i}.weight"], sd[f"conv_{i}.bias"], padding=1) for i in range(8)]
 
     def up(t: Tensor) -> Tensor:
         return t.repeat_interleave(2, dim=2).repeat_interleave(2, dim=3)
@@ -314,7 +339,7 @@ def spade_generator_forward(sd: SD, x: Tensor, seg: Tensor, fine_height: int, fi
     if num_upsampling_layers == "most":
         h = up(h)
         h = blk("up_4", torch.cat((h, feats[7]), 1))
-    h = F.conv2d(F.leaky_relu(h, 0.2), sd["conv_img.weight"], sd["conv_img.bias"], padding=1)
+    h = _qconv(F.leaky_relu(h, 0.2), sd["conv_img.weight"], sd["conv_img.bias"], padding=1)
     return torch.tanh(h)
 
 
