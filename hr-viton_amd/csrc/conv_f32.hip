@@ -33,8 +33,7 @@ namespace hrv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int BK = 16;   // k-values per K-tile
-constexpr int LS = 20;   // LDS row stride in floats (16 + 4 pad, 80 B: 16-B aligned)
+constexpr int HOST_BK = 16;   // fp32 k-values per 64-byte K-tile row (host-side packing of the default tiles)
 
 struct SrcDev {
   const float* ptr;
@@ -167,16 +166,22 @@ __device__ __forceinline__ void st1rt(float* base, size_t idx, float v, int is_f
   st1e<false>(base, idx, v);
 }
 
-template <int TM, int TN, int WM, int WN, int VAR, bool BF>
+template <int TM, int TN, int WM, int WN, int VAR, bool BF, int RB = 64>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
+  static_assert(RB == 64 || RB == 128, "K-tile row = 64 or 128 bytes");
   constexpr int ES = BF ? 2 : 4;     // element size in bytes
   constexpr int EPG = 16 / ES;       // elements per 16-byte gather group
-  constexpr int BKE = 4 * EPG;       // k-values per K-tile row (64 bytes)
+  constexpr int GPR = RB / 16;       // 16-byte groups per K-tile row
+  constexpr int BKE = GPR * EPG;     // k-values per K-tile row
+  constexpr int LS = RB / 4 + 4;     // LDS row stride in floats (row + 16 B pad: conflict-free b128 reads)
+  constexpr int BK = RB / 4;         // floats per packed-weight row
+  constexpr int KQ = RB / 32;        // 32-byte fragment steps per row (2 lane-halves x 16 B)
+  constexpr int RPP = 256 / GPR;     // tile rows covered by one pass of the 256 threads
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
-  constexpr int AR = BM / 64;                 // 16-byte A loads per thread per K-tile
-  constexpr int BR = (BN * 4 + 255) / 256;    // 16-byte B loads per thread per K-tile
+  constexpr int AR = BM / RPP;                      // 16-byte A loads per thread per K-tile
+  constexpr int BR = (BN * GPR + 255) / 256;        // 16-byte B loads per thread per K-tile
   constexpr bool SWAP = (VAR & 1) != 0;
   constexpr bool PIPE = (VAR & 2) != 0;
   __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
@@ -198,13 +203,13 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   const int kt_end = (int)(((long long)p.KT * (ks + 1)) / p.splitk);
 
   // ---- per-thread gather coordinates (fixed for the whole K loop) ----
-  const int a_c4 = tid & 3;    // which 16-byte group of the 16-channel chunk
-  const int a_row = tid >> 2;  // + 64*r
+  const int a_c4 = tid % GPR;  // which 16-byte group of the K-tile row
+  const int a_row = tid / GPR; // + RPP*r
   int a_n[AR], a_hi0[AR], a_wi0[AR];
   bool a_ok[AR];
 #pragma unroll
   for (int r = 0; r < AR; ++r) {
-    const int pidx = m0 + a_row + 64 * r;
+    const int pidx = m0 + a_row + RPP * r;
     a_ok[r] = pidx < p.M;
     const int pp = a_ok[r] ? pidx : 0;
     const int n = pp / (p.Ho * p.Wo);
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const float* wt = p.wp + ((size_t)(KTN)*p.CoutPad + n0) * BK; /* 64-byte rows in both modes */            \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
       const int idx = tid + 256 * j;                                                                         \
-      b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * 4) % 256 == 0 || idx < BN * 4 ? idx : 0) * 4);  \
+      b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * GPR) % 256 == 0 || idx < BN * GPR ? idx : 0) * 4); \
     }                                                                                                        \
   }
 
@@ -307,11 +312,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     float* Asw = smem + (BUF) * (BM + BN) * LS;                                                         \
     float* Bsw = Asw + BM * LS;                                                                         \
     _Pragma("unroll") for (int r = 0; r < AR; ++r)                                                      \
-        *reinterpret_cast<f32x4*>(Asw + (a_row + 64 * r) * LS + a_c4 * 4) = a_reg[r];                   \
+        *reinterpret_cast<f32x4*>(Asw + (a_row + RPP * r) * LS + a_c4 * 4) = a_reg[r];                  \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                    \
       const int idx = tid + 256 * j;                                                                    \
-      if ((BN * 4) % 256 == 0 || idx < BN * 4)                                                          \
-        *reinterpret_cast<f32x4*>(Bsw + (idx >> 2) * LS + (idx & 3) * 4) = b_reg[j];                    \
+      if ((BN * GPR) % 256 == 0 || idx < BN * GPR)                                                      \
+        *reinterpret_cast<f32x4*>(Bsw + (idx / GPR) * LS + (idx % GPR) * 4) = b_reg[j];                 \
     }                                                                                                   \
   }
 
@@ -319,7 +324,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   {                                                                                                          \
     const float* As = smem + (BUF) * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;                    \
     const float* Bs = smem + (BUF) * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;          \
-    _Pragma("unroll") for (int kq = 0; kq < 2; ++kq) {                                                       \
+    _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {                                                      \
       _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[kq][i] =                                             \
           *reinterpret_cast<const f32x4*>(As + i * 32 * LS + kq * 8);                                        \
       _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[kq][j] =                                             \
@@ -335,7 +340,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   {                                                                                                  \
     if constexpr (BF) {                                                                              \
       /* v_mfma_f32_32x32x16_bf16: lane half h supplies k = 8h..8h+7 of each 16-wide step */          \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                               \
+      _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq)                                              \
           _Pragma("unroll") for (int i = 0; i < TM; ++i)                                             \
               _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                       \
         const bf16x8 av = __builtin_bit_cast(bf16x8, fa[kq][i]);                                     \
@@ -344,7 +349,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                          : __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);      \
       }                                                                                              \
     } else {                                                                                         \
-      _Pragma("unroll") for (int kq = 0; kq < 2; ++kq)                                               \
+      _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq)                                              \
           _Pragma("unroll") for (int e = 0; e < 4; ++e)                                              \
               _Pragma("unroll") for (int i = 0; i < TM; ++i)                                         \
                   _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                   \
@@ -353,7 +358,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }                                                                                                \
   }
 
-  f32x4 fa[2][TM], fb[2][TN];
+  f32x4 fa[KQ][TM], fb[KQ][TN];
 
   // prologue: fetch + stage the first K-tile of this block's range
   HRV_LOAD_TILE(kt_begin)
@@ -369,9 +374,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
       HRV_MMA_FRAGS()
       // scheduling recipe for this region: fragment reads first, then every MFMA is
       // followed by a slice of the gather's address arithmetic / load issue.
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * (TM + TN), 0);
+      __builtin_amdgcn_sched_group_barrier(0x100, KQ * (TM + TN), 0);
 #pragma unroll
-      for (int m = 0; m < (BF ? 2 : 8) * TM * TN; ++m) {
+      for (int m = 0; m < (BF ? 1 : 4) * KQ * TM * TN; ++m) {
         __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
         __builtin_amdgcn_sched_group_barrier(0x006, 4, 0);
         if (m < AR + BR) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
@@ -637,22 +642,26 @@ __global__ void conv_f32_naive_kernel(const ConvParams p, const float* __restric
 
 struct TileCfg {
   int TM, TN, WM, WN;
+  int RB;  // bytes per K-tile row: 64 (16 fp32 / 32 bf16 k-values) or 128 (bf16 engine only: 64 k-values)
 };
 // id -> (TM,TN,WM,WN); BM = 32*TM*WM, BN = 32*TN*WN
 static const TileCfg kCfgs[] = {
-    {2, 2, 2, 2},  // 0: 128 x 128
-    {1, 3, 4, 1},  // 1: 128 x 96
-    {2, 3, 4, 1},  // 2: 256 x 96
-    {2, 1, 4, 1},  // 3: 256 x 32
-    {2, 2, 4, 1},  // 4: 256 x 64
-    {1, 1, 4, 1},  // 5: 128 x 32
-    {1, 2, 4, 1},  // 6: 128 x 64
-    {4, 2, 2, 2},  // 7: 256 x 128
+    {2, 2, 2, 2, 64},   // 0: 128 x 128
+    {1, 3, 4, 1, 64},   // 1: 128 x 96
+    {2, 3, 4, 1, 64},   // 2: 256 x 96
+    {2, 1, 4, 1, 64},   // 3: 256 x 32
+    {2, 2, 4, 1, 64},   // 4: 256 x 64
+    {1, 1, 4, 1, 64},   // 5: 128 x 32
+    {1, 2, 4, 1, 64},   // 6: 128 x 64
+    {4, 2, 2, 2, 64},   // 7: 256 x 128
+    {2, 2, 2, 2, 128},  // 8: 128 x 128, 64 bf16 k-values per K-tile (bf16 engine only)
+    {1, 2, 4, 1, 128},  // 9: 128 x 64,  64 bf16 k-values per K-tile (bf16 engine only)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
 static int cfg_bm(int c) { return 32 * kCfgs[c].TM * kCfgs[c].WM; }
 static int cfg_bn(int c) { return 32 * kCfgs[c].TN * kCfgs[c].WN; }
+static int cfg_rb(int c) { return kCfgs[c].RB; }
 
 // Split-K factor for a launch that would otherwise leave most of the 256 CUs idle
 // (tocg levels 3-4 and the generator's 8x6..32x24 blocks: few pixels, K up to 9360).
@@ -667,8 +676,10 @@ static int pick_splitk(int nblk, int KT, bool allowed) {
 
 static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, bool bf = false) {
   const int cm = bf ? 8 : 4;     // channel granularity = one 16-byte gather group
-  const int bke = bf ? 32 : 16;  // k-values per K-tile
   HRV_REQUIRE(d != nullptr, "conv2d: null descriptor");
+  const int rb = (need_packed && d->tile_cfg >= 0 && d->tile_cfg < kNumCfgs) ? cfg_rb(d->tile_cfg) : 64;
+  HRV_REQUIRE(bf || rb == 64, "conv2d: tile_cfg=%d (128-byte K-tile rows) exists on the bf16 engine only", d->tile_cfg);
+  const int bke = rb / (bf ? 2 : 4);  // k-values per K-tile
   HRV_REQUIRE(d->nsrc >= 1 && d->nsrc <= HRV_MAX_SRC, "conv2d: nsrc=%d out of range", d->nsrc);
   HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0, "conv2d: bad extent");
   HRV_REQUIRE(d->KH > 0 && d->KW > 0 && d->stride > 0 && d->pad >= 0, "conv2d: bad kernel geometry");
@@ -782,7 +793,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
 // (variants 2/3 = software-pipelined body exist for fp32 only).
 constexpr int kDefaultVariant = 1;
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, int RB = 64>
 static int launch_cfg(const ConvParams& p, hipStream_t st) {
   const int nblk = p.m_tiles * p.n_tiles * p.splitk;
   const char* ev = getenv("HRV_CONV_VARIANT");
@@ -798,8 +809,11 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
     var &= ~1;  // scalar epilogue for odd channel counts / unaligned slices
   }
   if (p.bf16) {
-    if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true>), dim3(nblk), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true>), dim3(nblk), dim3(256), 0, st, p);
+    if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+  } else if constexpr (RB != 64) {
+    set_error("conv2d: 128-byte K-tile rows exist on the bf16 engine only");
+    return HRV_ERR_ARG;
   } else {
     switch (var) {
       case 0: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, false>), dim3(nblk), dim3(256), 0, st, p); break;
@@ -829,6 +843,8 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 5: return launch_cfg<1, 1, 4, 1>(p, st);
     case 6: return launch_cfg<1, 2, 4, 1>(p, st);
     case 7: return launch_cfg<4, 2, 2, 2>(p, st);
+    case 8: return launch_cfg<2, 2, 2, 2, 128>(p, st);
+    case 9: return launch_cfg<1, 2, 4, 1, 128>(p, st);
   }
   set_error("conv2d: tile_cfg=%d invalid", tile_cfg);
   return HRV_ERR_ARG;
@@ -864,7 +880,8 @@ extern "C" int hrv_conv2d_pick_tile(int64_t M, int32_t Cout) {
 
 extern "C" int64_t hrv_conv2d_packed_elems(int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
                                            int32_t tile_cfg) {
-  if (tile_cfg < 0 || tile_cfg >= kNumCfgs || nsrc < 1 || nsrc > HRV_MAX_SRC || !srcC) return -1;
+  if (tile_cfg < 0 || tile_cfg >= kNumCfgs || cfg_rb(tile_cfg) != 64 || nsrc < 1 || nsrc > HRV_MAX_SRC || !srcC) return -1;
+  constexpr int BK = HOST_BK;
   const int bn = cfg_bn(tile_cfg);
   const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
   int64_t chunks = 0;
@@ -876,8 +893,9 @@ extern "C" int hrv_conv2d_pack_weight_f32(const float* w, int32_t Cout, int32_t 
                                           const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
                                           float* out) {
   HRV_REQUIRE(w && out && srcC && srcC_real, "pack_weight: null pointer");
-  HRV_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumCfgs, "pack_weight: bad tile_cfg %d", tile_cfg);
+  HRV_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumCfgs && cfg_rb(tile_cfg) == 64, "pack_weight: bad tile_cfg %d", tile_cfg);
   HRV_REQUIRE(nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_weight: bad nsrc");
+  constexpr int BK = HOST_BK;
   const int bn = cfg_bn(tile_cfg);
   const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
   int cin_real = 0, chunks_total = 0;
@@ -913,8 +931,10 @@ extern "C" int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d) {
   const int64_t M = (int64_t)d->N * d->Ho * d->Wo;
   const int n_tiles = (d->Cout + bn - 1) / bn;
   const int m_tiles = (int)((M + bm - 1) / bm);
+  // K-tile count as the fp32 engine sees it (the bf16 engine has at most as many -> its split factor
+  // is never larger, so the workspace sized here always suffices)
   int chunks = 0;
-  for (int i = 0; i < d->nsrc && i < HRV_MAX_SRC; ++i) chunks += (d->src[i].C + BK - 1) / BK;
+  for (int i = 0; i < d->nsrc && i < HRV_MAX_SRC; ++i) chunks += (d->src[i].C + HOST_BK - 1) / HOST_BK;
   const int KT = d->KH * d->KW * chunks;
   const char* ev = getenv("HRV_CONV_SPLITK");
   int s = pick_splitk(m_tiles * n_tiles, KT, true);
@@ -953,11 +973,13 @@ extern "C" int64_t hrv_conv2d_packed_elems_bf16(int32_t Cout, int32_t KH, int32_
   const int bn = cfg_bn(tile_cfg);
   const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
   int64_t chunks = 0;
-  for (int i = 0; i < nsrc; ++i) chunks += (srcC[i] + 31) / 32;
-  return (int64_t)KH * KW * chunks * cpad * 32;
+  const int bke = cfg_rb(tile_cfg) / 2;
+  for (int i = 0; i < nsrc; ++i) chunks += (srcC[i] + bke - 1) / bke;
+  return (int64_t)KH * KW * chunks * cpad * bke;
 }
 
-// HOST packer for the bf16 engine: [kt][CoutPad][32] bf16 (uint16), kt = (tap, source, 32-channel chunk)
+// HOST packer for the bf16 engine: [kt][CoutPad][bke] bf16 (uint16), kt = (tap, source, bke-channel chunk),
+// bke = 32 (64-byte K-tile rows) or 64 (tile_cfg 8/9: 128-byte rows)
 extern "C" int hrv_conv2d_pack_weight_bf16(const float* w, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
                                            const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg,
                                            uint16_t* out) {
@@ -965,14 +987,15 @@ extern "C" int hrv_conv2d_pack_weight_bf16(const float* w, int32_t Cout, int32_t
   HRV_REQUIRE(tile_cfg >= 0 && tile_cfg < kNumCfgs, "pack_weight_bf16: bad tile_cfg %d", tile_cfg);
   HRV_REQUIRE(nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_weight_bf16: bad nsrc");
   const int bn = cfg_bn(tile_cfg);
+  const int bke = cfg_rb(tile_cfg) / 2;  // k-values per K-tile row
   const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
   int cin_real = 0, chunks_total = 0;
   for (int i = 0; i < nsrc; ++i) {
     HRV_REQUIRE(srcC_real[i] > 0 && srcC_real[i] <= srcC[i] && srcC[i] % 8 == 0, "pack_weight_bf16: bad channel counts");
     cin_real += srcC_real[i];
-    chunks_total += (srcC[i] + 31) / 32;
+    chunks_total += (srcC[i] + bke - 1) / bke;
   }
-  const int64_t total = (int64_t)KH * KW * chunks_total * cpad * 32;
+  const int64_t total = (int64_t)KH * KW * chunks_total * cpad * bke;
   memset(out, 0, sizeof(uint16_t) * total);
   const int64_t ostride = (int64_t)cin_real * KH * KW;
   for (int kh = 0; kh < KH; ++kh)
@@ -980,12 +1003,12 @@ extern "C" int hrv_conv2d_pack_weight_bf16(const float* w, int32_t Cout, int32_t
       int chunk0 = 0, cbase = 0;
       for (int s = 0; s < nsrc; ++s) {
         for (int c = 0; c < srcC_real[s]; ++c) {
-          const int64_t kt = (int64_t)(kh * KW + kw) * chunks_total + chunk0 + c / 32;
-          uint16_t* dst = out + (kt * cpad) * 32 + (c % 32);
+          const int64_t kt = (int64_t)(kh * KW + kw) * chunks_total + chunk0 + c / bke;
+          uint16_t* dst = out + (kt * cpad) * bke + (c % bke);
           const float* srcw = w + ((int64_t)(cbase + c) * KH + kh) * KW + kw;
-          for (int co = 0; co < Cout; ++co) dst[(int64_t)co * 32] = host_f2bf(srcw[co * ostride]);
+          for (int co = 0; co < Cout; ++co) dst[(int64_t)co * bke] = host_f2bf(srcw[co * ostride]);
         }
-        chunk0 += (srcC[s] + 31) / 32;
+        chunk0 += (srcC[s] + bke - 1) / bke;
         cbase += srcC_real[s];
       }
     }

@@ -302,8 +302,9 @@ BF16_CASES = [
 ]
 
 
+@pytest.mark.parametrize("cfg", [None, 8, 9], ids=["auto", "cfg8_rb128", "cfg9_rb128"])
 @pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
-def test_conv_bf16_engine(case):
+def test_conv_bf16_engine(case, cfg):
     """bf16 storage / fp32 accumulate engine (v_mfma_f32_32x32x16_bf16) vs the fp32 oracle evaluated on the
     bf16-rounded operands: what remains is accumulation order + the final bf16 rounding (2^-8 relative)."""
     ops = _ops()
@@ -343,7 +344,7 @@ def test_conv_bf16_engine(case):
         up = 1 if (ex.get("up0") and i == 0) else (-ex["down0"] if (ex.get("down0") and i == 0) else 0)
         srcs.append((ops.to_nhwc(x.cuda(), bf16=True), up, ops.ACT_NONE))
     res_act = ops.to_nhwc(res.cuda(), bf16=True) if res is not None else None
-    o = layer(srcs, residual=res_act, H=H, W=W)
+    o = layer(srcs, residual=res_act, H=H, W=W, cfg=cfg)
     got = ops.to_nchw(o)
     assert o.t.dtype == torch.bfloat16 and (o.t[..., cout:].float() == 0).all()
     _assert_close("conv_bf16_" + name, got, ref, 1e-2)

@@ -21,7 +21,21 @@ LAYERS = [
 ]
 
 
+BF_LAYERS = [
+    # SPADE-generator shapes of the bf16 engine
+    ("spade.gb 128->2x64 3x3 @1024x768", [128], 128, 3, 1, 1, 1, 1024, 768, False),
+    ("spade.gb 128->2x128 3x3 @512x384", [128], 256, 3, 1, 1, 1, 512, 384, False),
+    ("blk conv 256->256 3x3 @256x192", [256], 256, 3, 1, 1, 1, 256, 192, False),
+    ("blk conv 512->512 3x3 @128x96", [512], 512, 3, 1, 1, 1, 128, 96, False),
+    ("blk conv 1024->1024 3x3 @64x48", [1024], 1024, 3, 1, 1, 1, 64, 48, False),
+    ("blk conv 64->64 3x3 @1024x768", [64], 64, 3, 1, 1, 1, 1024, 768, False),
+]
+
+
 def main():
+    bf = os.environ.get("BF16", "0") == "1"
+    if bf:
+        LAYERS[:] = BF_LAYERS
     combos = [(int(c), int(v)) for c, v in (x.split(":") for x in os.environ.get(
         "COMBOS", "1:0,1:1,1:3,2:0,2:1,2:3,0:1,7:1").split(","))]
     rounds = int(os.environ.get("ROUNDS", "5"))
@@ -29,14 +43,15 @@ def main():
     sel = os.environ.get("LAYER_IDX")
     layers = LAYERS if sel is None else [LAYERS[int(i)] for i in sel.split(",")]
     for name, cins, cout, k, stride, pad, N, H, W, res in layers:
-        xs = [ops.to_nhwc(torch.randn(N, c, H, W, generator=g).cuda()) for c in cins]
+        xs = [ops.to_nhwc(torch.randn(N, c, H, W, generator=g).cuda(), bf16=bf) for c in cins]
         w = torch.randn(cout, sum(cins), k, k, generator=g) * 0.05
         sc = torch.rand(cout, generator=g) + 0.5
         sh = torch.randn(cout, generator=g)
-        layer = ops.ConvLayer(w, cins, "cuda", scale=sc, shift=sh, stride=stride, pad=pad, act=ops.ACT_RELU, name=name)
+        layer = ops.ConvLayer(w, cins, "cuda", scale=sc, shift=sh, stride=stride, pad=pad, act=ops.ACT_RELU, name=name,
+                               bf16=bf)
         Ho, Wo = layer.out_hw(H, W)
-        out = ops.alloc(N, Ho, Wo, cout, "cuda")
-        r = ops.alloc(N, Ho, Wo, cout, "cuda") if res else None
+        out = ops.alloc(N, Ho, Wo, cout, "cuda", bf16=bf)
+        r = ops.alloc(N, Ho, Wo, cout, "cuda", bf16=bf) if res else None
         if r is not None:
             r.t.normal_()
         flops = layer.flops(N, Ho, Wo)
