@@ -63,6 +63,15 @@ class hrv_flow_warp_t(C.Structure):
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("flow_up", C.c_void_p)]
 
 
+class hrv_flow_warp_bwd_t(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("src_cstride", C.c_int32), ("src_coff", C.c_int32), ("flow_up", C.c_void_p),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("norm_x", C.c_float), ("norm_y", C.c_float),
+                ("dout", C.c_void_p), ("dout_cstride", C.c_int32), ("dout_coff", C.c_int32),
+                ("dsrc", C.c_void_p), ("dsrc_cstride", C.c_int32), ("dsrc_coff", C.c_int32),
+                ("dflow", C.c_void_p), ("dflow_accumulate", C.c_int32), ("_pad", C.c_int32)]
+
+
 # every symbol include/hrviton_hip.h declares: (restype, argtypes)
 _i32, _i64, _f, _vp = C.c_int32, C.c_int64, C.c_float, C.c_void_p
 _ip = C.POINTER(C.c_int32)
@@ -124,6 +133,23 @@ SYMBOLS = {
     "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,
                                                _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "hrv_flow_warp_nhwc_f32": (C.c_int, [C.POINTER(hrv_flow_warp_t), _vp]),
+    "hrv_bn_finalize_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f, _i64, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp,
+                                      _vp, _vp]),
+    "hrv_affine_act_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _i32, _i32, _i32, _f, _vp, _i32,
+                                          _i32, _vp]),
+    "hrv_bn_bwd_workspace_elems": (_i64, [_i32]),
+    "hrv_bn_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp, _vp, _vp, _i32, _i32,
+                                      _i32, _vp, _vp, _i32, _vp]),
+    "hrv_resize_bilinear_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f, _vp, _i32, _i32,
+                                                   _i32, _i32, _i32, _vp]),
+    "hrv_flow_warp_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_flow_warp_bwd_t), _vp]),
+    "hrv_grid_sample_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
+    "hrv_grid_sample_nchw_bwd_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),
+    "hrv_softmax_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp]),
+    "hrv_softmax_nchw_bwd_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _vp, _vp]),
+    "hrv_cross_entropy_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _f, _vp, _vp, _vp, _vp]),
+    "hrv_tapsum_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
+    "hrv_tv_loss_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 
 _lib = None

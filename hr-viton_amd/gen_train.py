@@ -351,6 +351,34 @@ class DiscTrainPlan:
                 self.layers.append(("lrelu" if len(m) > 1 else "plain",
                                     TConv(first, first.stride[0], first.padding[0], f"{name}.model{n}")))
 
+    @classmethod
+    def from_sequential(cls, seq: nn.Sequential, name: str) -> "DiscTrainPlan":
+        """The tocg discriminator keeps one flattened nn.Sequential per scale (networks.py:389-393):
+        [conv, LReLU] + [conv, InstanceNorm2d, LReLU]* + [conv]."""
+        self = cls.__new__(cls)
+        self.D, self.layers = seq, []
+        mods = list(seq)
+        i = 0
+        while i < len(mods):
+            m = mods[i]
+            if not isinstance(m, nn.Conv2d):
+                raise NotImplementedError(f"hr-viton_amd tocg discriminator: unsupported layer {type(m).__name__} "
+                                          "(Ddropout / use_sigmoid / BatchNorm variants are not on the HIP path)")
+            tc = TConv(m, m.stride[0], m.padding[0], f"{name}.{i}")
+            nxt = mods[i + 1] if i + 1 < len(mods) else None
+            if isinstance(nxt, nn.InstanceNorm2d):
+                if nxt.affine or not isinstance(mods[i + 2], nn.LeakyReLU):
+                    raise NotImplementedError("hr-viton_amd tocg discriminator: InstanceNorm2d(affine=False) + LeakyReLU")
+                self.layers.append(("in", tc))
+                i += 3
+            elif isinstance(nxt, nn.LeakyReLU):
+                self.layers.append(("lrelu", tc))
+                i += 2
+            else:
+                self.layers.append(("plain", tc))
+                i += 1
+        return self
+
     def forward(self, a: Act, power_iteration: bool):
         feats, ctx = [], []
         for kind, conv in self.layers:

@@ -193,8 +193,12 @@ class ConditionGenerator(nn.Module):
         if upsample != "bilinear":
             raise NotImplementedError("HIP path implements upsample='bilinear' (the reference default)")
         if self.training:
-            raise NotImplementedError("hr-viton_amd ConditionGenerator: training-mode (batch-stat BatchNorm + "
-                                      "backward) HIP kernels are not built yet; call .eval()")
+            # batch-statistics BatchNorm + tape-recorded backward (train_condition.py:116,158)
+            from .cond_train import condition_train_forward
+            if not next(self.parameters()).is_cuda:
+                raise RuntimeError("hr-viton_amd ConditionGenerator: move the module to the GPU (.cuda()) first; "
+                                   "there is no CPU path")
+            return condition_train_forward(self, input1, input2)
         return self._forward_eval(input1, input2)
 
     @torch.no_grad()
@@ -245,6 +249,135 @@ class ConditionGenerator(nn.Module):
         warped_nchw = ops.to_nchw(warped_in)
         c = self.input1_nc
         return flow_list, seg_nchw, warped_nchw[:, :c - 1], warped_nchw[:, c - 1:]
+
+
+# ---------------------------------------------------------------------------------------------
+# Discriminator of the condition generator + its losses (networks.py:201-408, 427-453)
+# ---------------------------------------------------------------------------------------------
+from .vgg import VGGLoss, Vgg19  # noqa: E402,F401  (networks.py:201-251 live in vgg.py)
+
+
+class GANLoss(nn.Module):
+    """networks.GANLoss (networks.py:258-299): LSGAN = MSE against a constant 1 / 0 map of the LAST
+    tensor of every scale, summed over the scales.  One fused value+gradient kernel per scale."""
+
+    def __init__(self, use_lsgan=True, target_real_label=1.0, target_fake_label=0.0, tensor=torch.FloatTensor):
+        super().__init__()
+        if not use_lsgan:
+            raise NotImplementedError("hr-viton_amd networks.GANLoss implements use_lsgan=True (train_condition.py:124-126)")
+        self.real_label, self.fake_label = target_real_label, target_fake_label
+        self.real_label_var = self.fake_label_var = None
+        self.Tensor = tensor
+        from .losses import MSELoss
+        self.loss = MSELoss()
+
+    def get_target_tensor(self, input, target_is_real):
+        attr = "real_label_var" if target_is_real else "fake_label_var"
+        cur = getattr(self, attr)
+        if cur is None or cur.numel() != input.numel() or cur.device != input.device:
+            cur = torch.full(tuple(input.shape), self.real_label if target_is_real else self.fake_label,
+                             dtype=torch.float32, device=input.device)
+            setattr(self, attr, cur)
+        return cur
+
+    def __call__(self, input, target_is_real):
+        if isinstance(input[0], list):
+            total = 0
+            for scale in input:
+                pred = scale[-1]
+                total = total + self.loss(pred, self.get_target_tensor(pred, target_is_real))
+            return total
+        pred = input[-1]
+        return self.loss(pred, self.get_target_tensor(pred, target_is_real))
+
+
+class NLayerDiscriminator(nn.Module):
+    """Parameter container with the reference's module layout (networks.py:348-408)."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False, getIntermFeat=False,
+                 Ddropout=False, spectral=False):
+        super().__init__()
+        self.getIntermFeat, self.n_layers = getIntermFeat, n_layers
+        sn = nn.utils.spectral_norm if spectral else (lambda m: m)
+        kw, padw = 4, 2
+        groups = [[nn.Conv2d(input_nc, ndf, kw, 2, padw), nn.LeakyReLU(0.2, True)]]
+        nf = ndf
+        for _ in range(1, n_layers):
+            prev, nf = nf, min(nf * 2, 512)
+            g = [sn(nn.Conv2d(prev, nf, kw, 2, padw)), norm_layer(nf), nn.LeakyReLU(0.2, True)]
+            if Ddropout:
+                g.append(nn.Dropout(0.5))
+            groups.append(g)
+        prev, nf = nf, min(nf * 2, 512)
+        groups.append([nn.Conv2d(prev, nf, kw, 1, padw), norm_layer(nf), nn.LeakyReLU(0.2, True)])
+        groups.append([nn.Conv2d(nf, 1, kw, 1, padw)])
+        if use_sigmoid:
+            groups.append([nn.Sigmoid()])
+        if getIntermFeat:
+            for n, g in enumerate(groups):
+                setattr(self, "model" + str(n), nn.Sequential(*g))
+        else:
+            self.model = nn.Sequential(*[m for g in groups for m in g])
+
+    def forward(self, input):  # pragma: no cover
+        raise RuntimeError("hr-viton_amd NLayerDiscriminator is executed by MultiscaleDiscriminator's HIP plan")
+
+
+class MultiscaleDiscriminator(nn.Module):
+    """networks.MultiscaleDiscriminator (networks.py:302-346) on the HIP training kernels."""
+
+    def __init__(self, input_nc, ndf=64, n_layers=3, norm_layer=nn.BatchNorm2d, use_sigmoid=False, num_D=3,
+                 getIntermFeat=False, Ddownx2=False, Ddropout=False, spectral=False):
+        super().__init__()
+        self.num_D, self.n_layers, self.getIntermFeat, self.Ddownx2 = num_D, n_layers, getIntermFeat, Ddownx2
+        for i in range(num_D):
+            netD = NLayerDiscriminator(input_nc, ndf, n_layers, norm_layer, use_sigmoid, getIntermFeat, Ddropout,
+                                       spectral=spectral)
+            if getIntermFeat:
+                for j in range(n_layers + 2):
+                    setattr(self, "scale" + str(i) + "_layer" + str(j), getattr(netD, "model" + str(j)))
+            else:
+                setattr(self, "layer" + str(i), netD.model)
+        self.downsample = nn.AvgPool2d(3, stride=2, padding=[1, 1], count_include_pad=False)
+        self._hip_ok = (not getIntermFeat) and (not Ddropout) and (not spectral) and (not use_sigmoid)
+
+    def forward(self, input):
+        if not self._hip_ok:
+            raise NotImplementedError("hr-viton_amd tocg discriminator: getIntermFeat / Ddropout / spectral / use_sigmoid "
+                                      "variants are not on the HIP path (train_condition.py:484 defaults are)")
+        from .cond_train import cond_discriminator_forward
+        return cond_discriminator_forward(self, input)
+
+
+def weights_init(m):
+    """networks.py:427-433."""
+    name = m.__class__.__name__
+    if name.find("Conv2d") != -1:
+        m.weight.data.normal_(0.0, 0.02)
+    elif name.find("BatchNorm2d") != -1:
+        m.weight.data.normal_(1.0, 0.02)
+        m.bias.data.fill_(0)
+
+
+def get_norm_layer(norm_type="instance"):
+    import functools
+    if norm_type == "batch":
+        return functools.partial(nn.BatchNorm2d, affine=True)
+    if norm_type == "instance":
+        return functools.partial(nn.InstanceNorm2d, affine=False)
+    raise NotImplementedError("normalization layer [%s] is not found" % norm_type)
+
+
+def define_D(input_nc, ndf=64, n_layers_D=3, norm="instance", use_sigmoid=False, num_D=2, getIntermFeat=False,
+             gpu_ids=[], Ddownx2=False, Ddropout=False, spectral=False):
+    """networks.py:445-453."""
+    netD = MultiscaleDiscriminator(input_nc, ndf, n_layers_D, get_norm_layer(norm_type=norm), use_sigmoid, num_D,
+                                   getIntermFeat, Ddownx2, Ddropout, spectral=spectral)
+    if len(gpu_ids) > 0:
+        assert torch.cuda.is_available()
+        netD.cuda()
+    netD.apply(weights_init)
+    return netD
 
 
 def save_checkpoint(model, save_path, opt=None):

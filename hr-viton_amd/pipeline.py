@@ -106,3 +106,95 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
     opt_d.step()
     losses.update(d_losses)
     return losses, output_paired
+
+
+def remove_overlap(seg_out, warped_cm):
+    """train_condition.py:38-43 (same as test_generator.py:19-24)."""
+    assert len(warped_cm.shape) == 4
+    return warped_cm - (torch.cat([seg_out[:, 1:3, :, :], seg_out[:, 5:, :, :]], dim=1)).sum(dim=1, keepdim=True) * warped_cm
+
+
+def condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d, inputs: Dict[str, torch.Tensor],
+                         sync_g=None, sync_d=None):
+    """One iteration of train_condition.py:136-286 (the default `not G_D_seperate` order): tocg forward with
+    batch-statistics BatchNorm, warping / TV / interflow / cross-entropy / LSGAN losses, G step, D step.
+    The networks, warps, softmax, cross entropy, TV, L1, VGG and LSGAN terms run on the HIP kernels
+    (cond_train.py, functional.py, losses.py, vgg.py); torch only stitches the scalar sums and the
+    elementwise mask compositions.  ``inputs`` as produced by cp_dataset.py: cloth, cloth_mask,
+    parse_agnostic, densepose, parse_onehot (label indices [N,1,H,W]), parse (one-hot), pcm, parse_cloth."""
+    from . import functional as HF
+    from .networks import make_grid
+    c_paired = inputs["cloth"]
+    cm_paired = (inputs["cloth_mask"] > 0.5).to(torch.float32)                 # :140 without the numpy round trip
+    label_onehot, label, pcm, im_c = inputs["parse_onehot"], inputs["parse"], inputs["pcm"], inputs["parse_cloth"]
+    input1 = torch.cat([c_paired, cm_paired], 1)
+    input2 = torch.cat([inputs["parse_agnostic"], inputs["densepose"]], 1)
+    if sync_g is not None:
+        sync_g.begin()
+    if sync_d is not None:
+        sync_d.enabled = False          # D's gradients of loss_G are discarded by optimizer_D.zero_grad() (:284)
+    flow_list, fake_segmap, warped_cloth, warped_cm = tocg(input1, input2)      # :158
+    comp = getattr(opt, "clothmask_composition", "warp_grad")
+    if comp != "no_composition":                                               # :164-173
+        cloth_mask = torch.ones_like(fake_segmap.detach())
+        cloth_mask[:, 3:4, :, :] = (warped_cm.detach() > 0.5).to(torch.float32) if comp == "detach" else warped_cm
+        fake_segmap = fake_segmap * cloth_mask
+    if getattr(opt, "occlusion", False):                                       # :174-176
+        warped_cm = remove_overlap(HF.softmax(fake_segmap, dim=1), warped_cm)
+        warped_cloth = warped_cloth * warped_cm + torch.ones_like(warped_cloth) * (1 - warped_cm)
+    loss_l1_cloth = crit_l1(warped_cm, pcm)                                    # :184
+    use_vgg = crit_vgg is not None
+    loss_vgg = crit_vgg(warped_cloth, im_c) if use_vgg else torch.zeros((), device=c_paired.device)   # :185
+    loss_tv = 0
+    if getattr(opt, "edgeawaretv", "no_edge") != "no_edge":
+        raise NotImplementedError("hr-viton_amd condition_train_step: edgeawaretv='no_edge' (the default)")
+    for flow in (flow_list[-1:] if getattr(opt, "lasttvonly", False) else flow_list):   # :190-199
+        loss_tv = loss_tv + HF.tv_loss(flow)
+    N, _, iH, iW = c_paired.size()
+    if getattr(opt, "interflowloss", False):                                   # :235-248
+        soft_for_overlap = HF.softmax(fake_segmap, dim=1)
+        grid = make_grid(N, iH, iW).to(c_paired.device)
+        for i in range(len(flow_list) - 1):
+            flow = flow_list[i]
+            _, fH, fW, _ = flow.size()
+            flow = HF.interpolate(flow.permute(0, 3, 1, 2), size=c_paired.shape[2:], mode="bilinear").permute(0, 2, 3, 1)
+            flow_norm = torch.cat([flow[:, :, :, 0:1] / ((fW - 1.0) / 2.0), flow[:, :, :, 1:2] / ((fH - 1.0) / 2.0)], 3)
+            warped_cm_i = HF.grid_sample(cm_paired, flow_norm + grid, padding_mode="border")
+            warped_cm_i = remove_overlap(soft_for_overlap, warped_cm_i)
+            loss_l1_cloth = loss_l1_cloth + crit_l1(warped_cm_i, pcm) / (2 ** (4 - i))
+            if use_vgg:
+                warped_c_i = HF.grid_sample(c_paired, flow_norm + grid, padding_mode="border")
+                loss_vgg = loss_vgg + crit_vgg(warped_c_i, im_c) / (2 ** (4 - i))
+    CE_loss = HF.cross_entropy2d(fake_segmap, label_onehot.transpose(0, 1)[0].long())   # :252
+    losses = {"l1": loss_l1_cloth, "vgg": loss_vgg, "tv": loss_tv, "ce": CE_loss}
+    if getattr(opt, "no_GAN_loss", False):
+        loss_G = (10 * loss_l1_cloth + loss_vgg + opt.tvlambda * loss_tv) + (CE_loss * opt.CElamda)
+        opt_g.zero_grad()
+        loss_G.backward()
+        opt_g.step()
+        losses["loss_G"] = loss_G
+        return losses
+    fake_segmap_softmax = HF.softmax(fake_segmap, 1)                            # :260
+    pred_segmap = D(torch.cat((input1.detach(), input2.detach(), fake_segmap_softmax), dim=1))
+    loss_G_GAN = crit_gan(pred_segmap, True)
+    loss_G = (10 * loss_l1_cloth + loss_vgg + opt.tvlambda * loss_tv) + (CE_loss * opt.CElamda + loss_G_GAN * opt.GANlambda)
+    opt_g.zero_grad()
+    loss_G.backward()
+    opt_g.step()
+    # discriminator (:267-277,284-286).  InstanceNorm is per sample, so the fake and real batches share one
+    # launch sequence; the fake half repeats the G pass's forward on detached inputs, as the reference does.
+    if sync_d is not None:
+        sync_d.enabled = True
+        sync_d.begin()
+    both = torch.cat((torch.cat((input1, input2, fake_segmap_softmax.detach()), dim=1),
+                      torch.cat((input1, input2, label), dim=1)), dim=0)
+    pred = D(both)
+    pred_f = [[t[:N] for t in p] for p in pred]
+    pred_r = [[t[N:] for t in p] for p in pred]
+    loss_D_fake, loss_D_real = crit_gan(pred_f, False), crit_gan(pred_r, True)
+    loss_D = loss_D_fake + loss_D_real
+    opt_d.zero_grad()
+    loss_D.backward()
+    opt_d.step()
+    losses.update({"g_gan": loss_G_GAN, "loss_G": loss_G, "d_fake": loss_D_fake, "d_real": loss_D_real, "loss_D": loss_D})
+    return losses

@@ -314,3 +314,111 @@ def scale_(x: torch.Tensor, s_host: float = 1.0, s_dev: Optional[torch.Tensor] =
     _lib.check(lib.hrv_scale_f32(x.data_ptr(), x.numel(), s_host, None if s_dev is None else s_dev.data_ptr(), _stream()),
                "hrv_scale_f32")
     return x
+
+
+# ---------------------------------------------------------------------------------------------
+# condition-generator training kernels (cond_train.hip)
+# ---------------------------------------------------------------------------------------------
+class BNStats:
+    """Batch statistics of one training-mode BatchNorm2d call: per-channel vectors of ceil4(C) floats."""
+    __slots__ = ("mean", "rstd", "scale", "shift")
+
+    def __init__(self, mean, rstd, scale, shift):
+        self.mean, self.rstd, self.scale, self.shift = mean, rstd, scale, shift
+
+
+def bn_train_stats(x: Act, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], eps: float, momentum: float,
+                   running_mean: Optional[torch.Tensor], running_var: Optional[torch.Tensor]) -> BNStats:
+    """nn.BatchNorm2d in training mode over an NHWC Act: batch mean / biased var -> (scale, shift), and the
+    in-place running-statistics update (hrv_instnorm_stats + hrv_bn_finalize)."""
+    lib = _lib.load()
+    mean_nc, rstd_nc = ops.instnorm_stats(x, eps=eps)
+    dev, Cp = x.t.device, x.Cp
+    vec = torch.zeros((4, Cp), dtype=torch.float32, device=dev)
+    _lib.check(lib.hrv_bn_finalize_f32(mean_nc.data_ptr(), rstd_nc.data_ptr(), x.N, x.C, Cp, eps, x.H * x.W,
+                                       None if weight is None else weight.data_ptr(),
+                                       None if bias is None else bias.data_ptr(), eps, momentum,
+                                       None if running_mean is None else running_mean.data_ptr(),
+                                       None if running_var is None else running_var.data_ptr(),
+                                       vec[0].data_ptr(), vec[1].data_ptr(), vec[2].data_ptr(), vec[3].data_ptr(),
+                                       _stream()), "hrv_bn_finalize_f32")
+    return BNStats(vec[0], vec[1], vec[2], vec[3])
+
+
+def affine_act(x: Act, scale: torch.Tensor, shift: torch.Tensor, act: int = ACT_NONE, residual: Optional[Act] = None,
+               slope: float = 0.2, out: Optional[Act] = None) -> Act:
+    """out = act(x*scale[c] + shift[c] (+ residual)) -- hrv_affine_act_nhwc_f32."""
+    lib = _lib.load()
+    if out is None:
+        out = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
+    rp, rcs, rco = (None, 0, 0) if residual is None else (residual.t.data_ptr(), residual.cstride, residual.coff)
+    npix = x.N * x.H * x.W
+    with _Timed("apply", "bn_affine_act", 0.0, 4.0 * npix * x.Cp * (2 if residual is None else 3)):
+        _lib.check(lib.hrv_affine_act_nhwc_f32(x.t.data_ptr(), x.cstride, x.coff, x.Cp, npix, scale.data_ptr(),
+                                               shift.data_ptr(), rp, rcs, rco, act, slope, out.t.data_ptr(), out.cstride,
+                                               out.coff, _stream()), "hrv_affine_act_nhwc_f32")
+    return out
+
+
+def bn_bwd(dy: Act, x: Act, st: BNStats, dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor],
+           dx: Optional[Act] = None, dx_accumulate: bool = False) -> Act:
+    """Training-mode BatchNorm backward (hrv_bn_bwd_nhwc_f32).  ``x`` = the normalised conv output."""
+    lib = _lib.load()
+    if dx is None:
+        dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
+        dx_accumulate = False
+    ws = torch.empty(lib.hrv_bn_bwd_workspace_elems(x.C), dtype=torch.float32, device=x.t.device)
+    npix = x.N * x.H * x.W
+    with _Timed("norm_bwd", "bn_bwd", 0.0, 4.0 * npix * x.Cp * 5):
+        _lib.check(lib.hrv_bn_bwd_nhwc_f32(dy.t.data_ptr(), dy.cstride, dy.coff, x.t.data_ptr(), x.cstride, x.coff, x.C,
+                                           npix, st.mean.data_ptr(), st.rstd.data_ptr(), st.scale.data_ptr(),
+                                           ws.data_ptr(), dx.t.data_ptr(), dx.cstride, dx.coff,
+                                           1 if dx_accumulate else 0,
+                                           None if dgamma is None else dgamma.data_ptr(),
+                                           None if dbeta is None else dbeta.data_ptr(), 0, _stream()),
+                   "hrv_bn_bwd_nhwc_f32")
+    return dx
+
+
+def resize_bilinear_bwd(dy: Act, H: int, W: int, rh: float, rw: float, dx: Optional[Act] = None,
+                        accumulate: bool = False) -> Act:
+    """Adjoint of ops.resize_bilinear: dx[N,H,W,C] (+)= R^T dy."""
+    lib = _lib.load()
+    if dx is None:
+        dx = ops.alloc(dy.N, H, W, dy.C, dy.t.device)
+        accumulate = False
+    with _Timed("resize", "bilinear_bwd", 0.0, 4.0 * dy.N * dy.H * dy.W * dy.Cp * 2):
+        _lib.check(lib.hrv_resize_bilinear_bwd_nhwc_f32(dy.t.data_ptr(), dy.N, dy.H, dy.W, dy.Cp, dy.cstride, dy.coff,
+                                                        rh, rw, dx.t.data_ptr(), H, W, dx.cstride, dx.coff,
+                                                        1 if accumulate else 0, _stream()),
+                   "hrv_resize_bilinear_bwd_nhwc_f32")
+    return dx
+
+
+def resize_bilinear_bwd_dense(dy: torch.Tensor, H: int, W: int, rh: float, rw: float) -> torch.Tensor:
+    """Same adjoint on a dense [N,Ho,Wo,C] tensor of any C (the 2-channel flows)."""
+    lib = _lib.load()
+    N, Ho, Wo, Cc = dy.shape
+    dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.hrv_resize_bilinear_bwd_nhwc_f32(dy.data_ptr(), N, Ho, Wo, Cc, Cc, 0, rh, rw, dx.data_ptr(), H, W, Cc,
+                                                    0, 0, _stream()), "hrv_resize_bilinear_bwd_nhwc_f32")
+    return dx
+
+
+def flow_warp_bwd(src: Act, flow_up: torch.Tensor, norm_x: float, norm_y: float, dout: Act,
+                  dsrc: Optional[Act], dflow: Optional[torch.Tensor], dflow_accumulate: bool = False):
+    """Adjoint of ops.flow_warp.  ``dsrc`` (an accumulator Act, already initialised) receives the atomic
+    scatter; ``dflow`` [N,Ho,Wo,2] the gradient w.r.t. the upsampled un-normalised flow."""
+    lib = _lib.load()
+    d = _lib.hrv_flow_warp_bwd_t()
+    d.src, d.N, d.H, d.W, d.C = src.t.data_ptr(), src.N, src.H, src.W, src.Cp
+    d.src_cstride, d.src_coff = src.cstride, src.coff
+    d.flow_up, d.Ho, d.Wo = flow_up.data_ptr(), dout.H, dout.W
+    d.norm_x, d.norm_y = norm_x, norm_y
+    d.dout, d.dout_cstride, d.dout_coff = dout.t.data_ptr(), dout.cstride, dout.coff
+    if dsrc is not None:
+        d.dsrc, d.dsrc_cstride, d.dsrc_coff = dsrc.t.data_ptr(), dsrc.cstride, dsrc.coff
+    if dflow is not None:
+        d.dflow, d.dflow_accumulate = dflow.data_ptr(), 1 if dflow_accumulate else 0
+    with _Timed("warp", "flow_warp_bwd", 0.0, 4.0 * dout.N * dout.H * dout.W * dout.Cp * 6):
+        _lib.check(lib.hrv_flow_warp_bwd_nhwc_f32(C.byref(d), _stream()), "hrv_flow_warp_bwd_nhwc_f32")

@@ -384,6 +384,92 @@ typedef struct hrv_flow_warp {
 } hrv_flow_warp_t;
 int hrv_flow_warp_nhwc_f32(const hrv_flow_warp_t* d, hrv_stream_t stream);
 
+/* ------------------------------------------------------------------------
+ * Training of the condition generator (train_condition.py:113-286, tocg.train()).
+ *
+ * BatchNorm2d with batch statistics (networks.py:171-198 under train_condition.py:116):
+ *   bn_finalize : folds the per-sample (mean, rstd) of hrv_instnorm_stats_nhwc_f32
+ *                 (computed with eps_in) into batch mean / rstd (biased variance over
+ *                 N*H*W, eps), the affine y = scale*x + shift (scale = gamma*rstd) and
+ *                 nn.BatchNorm2d's running-statistics update (momentum, unbiased variance);
+ *                 running_* may be NULL.  Writes entries c < C only.
+ *   affine_act  : out = act(x*scale[c] + shift[c] (+ residual))   (BN apply + ReLU + skip)
+ *   bn_bwd      : dx (+)= scale*(dy - mean(dy) - xhat*mean(dy*xhat)), dgamma (+)= sum dy*xhat,
+ *                 dbeta (+)= sum dy; x is the convolution output the statistics were taken
+ *                 of.  mean / rstd / scale hold ceil4(C) floats (zero in the pad channels);
+ *                 workspace: hrv_bn_bwd_workspace_elems(C) floats.  Deterministic.
+ * ---------------------------------------------------------------------- */
+int hrv_bn_finalize_f32(const float* mean_nc, const float* rstd_nc, int32_t N, int32_t C, int32_t nc_stride,
+                        float eps_in, int64_t HW, const float* gamma, const float* beta, float eps, float momentum,
+                        float* running_mean, float* running_var, float* mean, float* rstd, float* scale, float* shift,
+                        hrv_stream_t stream);
+int hrv_affine_act_nhwc_f32(const float* x, int32_t x_cstride, int32_t x_coff, int32_t C, int64_t npix,
+                            const float* scale, const float* shift, const float* residual, int32_t res_cstride,
+                            int32_t res_coff, int32_t act, float act_slope, float* out, int32_t out_cstride,
+                            int32_t out_coff, hrv_stream_t stream);
+int64_t hrv_bn_bwd_workspace_elems(int32_t C);
+int hrv_bn_bwd_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, const float* x, int32_t x_cstride,
+                        int32_t x_coff, int32_t C, int64_t npix, const float* mean, const float* rstd, const float* scale,
+                        float* workspace, float* dx, int32_t dx_cstride, int32_t dx_coff, int32_t dx_accumulate,
+                        float* dgamma, float* dbeta, int32_t dgb_accumulate, hrv_stream_t stream);
+/* Adjoint of hrv_resize_bilinear_nhwc_f32 (F.interpolate / nn.Upsample backward,
+ * networks.py:130-133,150,181; train_condition.py:242): dx[N,H,W,C] (+)= R^T dy[N,Ho,Wo,C],
+ * gather form (deterministic).  Any C (an NCHW tensor is the C = 1 case with N*C planes). */
+int hrv_resize_bilinear_bwd_nhwc_f32(const float* dy, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dy_cstride,
+                                     int32_t dy_coff, float rh, float rw, float* dx, int32_t H, int32_t W,
+                                     int32_t dx_cstride, int32_t dx_coff, int32_t accumulate, hrv_stream_t stream);
+/* Adjoint of hrv_flow_warp_nhwc_f32 (F.grid_sample backward, networks.py:135,152): given the
+ * saved un-normalised flow at the output resolution (flow_up) and dout [N,Ho,Wo,C]:
+ *   dsrc  [N,H,W,C]   += scatter of the four bilinear taps (fp32 atomics; zero-init or an
+ *                        existing accumulator; may be NULL)
+ *   dflow [N,Ho,Wo,2] (+)= d/d flow_up (coordinate gradient x W/2 (H/2) / norm; zero where the
+ *                        sample position was clamped to the border, as torch does; may be NULL). */
+typedef struct hrv_flow_warp_bwd {
+  const float* src;
+  int32_t N, H, W, C;
+  int32_t src_cstride, src_coff;
+  const float* flow_up;
+  int32_t Ho, Wo;
+  float norm_x, norm_y;
+  const float* dout;
+  int32_t dout_cstride, dout_coff;
+  float* dsrc;
+  int32_t dsrc_cstride, dsrc_coff;
+  float* dflow;
+  int32_t dflow_accumulate;
+  int32_t _pad;
+} hrv_flow_warp_bwd_t;
+int hrv_flow_warp_bwd_nhwc_f32(const hrv_flow_warp_bwd_t* d, hrv_stream_t stream);
+/* F.grid_sample(input NCHW, grid [N,Ho,Wo,2], 'bilinear', padding_mode='border',
+ * align_corners=False) with an explicit grid, and its backward (train_condition.py:243-245;
+ * train_generator.py:237-238).  din (+= atomics, zero-init) and dgrid may each be NULL. */
+int hrv_grid_sample_nchw_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, const float* grid, int32_t Ho,
+                             int32_t Wo, float* out, hrv_stream_t stream);
+int hrv_grid_sample_nchw_bwd_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, const float* grid,
+                                 int32_t Ho, int32_t Wo, const float* dout, float* din, float* dgrid,
+                                 hrv_stream_t stream);
+/* torch.softmax(x, 1) on NCHW (train_condition.py:175,246,260) and its backward
+ * dx = y*(dy - sum_c dy*y); C <= 64. */
+int hrv_softmax_nchw_f32(const float* x, int32_t N, int32_t C, int64_t HW, float* y, hrv_stream_t stream);
+int hrv_softmax_nchw_bwd_f32(const float* y, const float* dy, int32_t N, int32_t C, int64_t HW, float* dx,
+                             hrv_stream_t stream);
+/* utils.cross_entropy2d (utils.py:29-42): mean over the valid pixels of logsumexp(x) - x[target]
+ * (targets outside [0,C) are ignored like ignore_index=250); loss_out[0] = loss, loss_out[1] =
+ * valid-pixel count; grad (optional, NCHW) = gscale*(softmax - onehot) -- the caller folds
+ * 1/count into gscale.  workspace: 1024 floats. */
+int hrv_cross_entropy_nchw_f32(const float* x, const int64_t* target, int32_t N, int32_t C, int64_t HW, float gscale,
+                               float* grad, float* workspace, float* loss_out, hrv_stream_t stream);
+/* Adjoint of hrv_tapsum_nhwc_f32 (the 768->2 flow_conv, networks.py:85-92, run as a
+ * taps-as-channels 1x1 convolution): dy[q][tap*Cout+co] = dout[q - off(tap)][co]; dy has
+ * ceil4(KH*KW*Cout) channels (padding zeroed). */
+int hrv_tapsum_bwd_nhwc_f32(const float* dout, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad,
+                            int32_t Cout, int32_t dout_cstride, float* dy, int32_t dy_cstride, hrv_stream_t stream);
+/* Flow total variation (train_condition.py:190-199) of one [N,H,W,2] flow:
+ * loss = mean|f[:,1:]-f[:,:-1]| + mean|f[:,:,1:]-f[:,:,:-1]|, grad = d loss / d f (optional).
+ * workspace: 1024 floats. */
+int hrv_tv_loss_f32(const float* flow, int32_t N, int32_t H, int32_t W, float* grad, float* workspace, float* loss_out,
+                    hrv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

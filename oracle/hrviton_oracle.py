@@ -152,7 +152,20 @@ def instance_norm(x: Tensor, eps: float = 1e-5) -> Tensor:
 # --------------------------------------------------------------------------
 
 
+# training mode of the tocg BatchNorms (train_condition.py:116 `tocg.train()`): batch statistics
+# (biased variance over N*H*W) normalise; "stats" records (batch mean, UNBIASED batch var) per
+# BatchNorm prefix = what nn.BatchNorm2d folds into running_mean / running_var with momentum 0.1.
+BN_TRAIN = {"on": False, "stats": {}}
+
+
 def _bn_eval(x: Tensor, sd: SD, p: str, eps: float = 1e-5) -> Tensor:
+    if BN_TRAIN["on"]:
+        mean = x.mean(dim=(0, 2, 3))
+        var = x.var(dim=(0, 2, 3), unbiased=False)
+        m = x.numel() // x.shape[1]
+        BN_TRAIN["stats"][p] = (mean.detach().clone(), (var * (m / max(m - 1, 1))).detach().clone())
+        xh = (x - mean.view(1, -1, 1, 1)) / torch.sqrt(var.view(1, -1, 1, 1) + eps)
+        return xh * sd[p + ".weight"].view(1, -1, 1, 1) + sd[p + ".bias"].view(1, -1, 1, 1)
     return F.batch_norm(x, sd[p + ".running_mean"], sd[p + ".running_var"],
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
 
@@ -498,3 +511,122 @@ def vgg_loss(sd: SD, x: Tensor, y: Tensor) -> Tensor:
     w = [1.0 / 32, 1.0 / 16, 1.0 / 8, 1.0 / 4, 1.0]
     fx, fy = vgg19_features(sd, x), vgg19_features(sd, y)
     return sum(w[i] * F.l1_loss(fx[i], fy[i].detach()) for i in range(5))
+
+
+# --------------------------------------------------------------------------
+# tocg training step (train_condition.py:113-286; config: --Ddownx2 --lasttvonly --interflowloss)
+# --------------------------------------------------------------------------
+
+
+def avgpool3x3s2(x: Tensor) -> Tensor:
+    """nn.AvgPool2d(3, stride=2, padding=[1,1], count_include_pad=False) -- networks.py:322."""
+    return F.avg_pool2d(x, 3, stride=2, padding=1, count_include_pad=False)
+
+
+def tocg_discriminator_forward(sd: SD, inp: Tensor, num_D: int = 2, n_layers: int = 3,
+                               Ddownx2: bool = False) -> List[List[Tensor]]:
+    """networks.MultiscaleDiscriminator.forward (getIntermFeat=False, InstanceNorm2d(affine=False), no
+    spectral norm, no dropout) -- networks.py:302-408.  Flattened nn.Sequential per scale `layer{k}`:
+    [conv4x4 s2, LReLU] + (n_layers-1) x [conv4x4 s2, IN, LReLU] + [conv4x4 s1, IN, LReLU] + [conv4x4 s1 -> 1],
+    every conv padded by ceil(3/2) = 2.  Scale i of the result uses `layer{num_D-1-i}` on the input
+    avg-pooled i (+1 with Ddownx2) times."""
+    result = []
+    x = avgpool3x3s2(inp) if Ddownx2 else inp
+    for i in range(num_D):
+        p = f"layer{num_D - 1 - i}"
+        h = F.leaky_relu(F.conv2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2, padding=2), 0.2)
+        idx = 2
+        for n in range(1, n_layers):
+            h = F.conv2d(h, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"], stride=2, padding=2)
+            h = F.leaky_relu(instance_norm(h), 0.2)
+            idx += 3
+        h = F.conv2d(h, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"], stride=1, padding=2)
+        h = F.leaky_relu(instance_norm(h), 0.2)
+        idx += 3
+        h = F.conv2d(h, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"], stride=1, padding=2)
+        result.append([h])
+        if i != num_D - 1:
+            x = avgpool3x3s2(x)
+    return result
+
+
+def lsgan_loss(preds: List[List[Tensor]], target_is_real: bool) -> Tensor:
+    """networks.GANLoss(use_lsgan=True).__call__ on a list of lists -- networks.py:258-299:
+    MSE of the last tensor of every scale against a constant 1 / 0 map, SUMMED over scales."""
+    total = 0
+    for p in preds:
+        x = p[-1]
+        total = total + F.mse_loss(x, torch.full_like(x, 1.0 if target_is_real else 0.0))
+    return total
+
+
+def cross_entropy2d(inp: Tensor, target: Tensor) -> Tensor:
+    """utils.py:29-42 with matching sizes: mean softmax cross entropy over N*H*W pixels
+    (ignore_index=250 never occurs: labels are 0..12)."""
+    n, c, h, w = inp.shape
+    return F.cross_entropy(inp.permute(0, 2, 3, 1).reshape(-1, c), target.reshape(-1), ignore_index=250)
+
+
+def tv_loss(flow: Tensor) -> Tensor:
+    """train_condition.py:190-199 on one [N,h,w,2] flow: mean |d/dy| + mean |d/dx|."""
+    return (flow[:, 1:] - flow[:, :-1]).abs().mean() + (flow[:, :, 1:] - flow[:, :, :-1]).abs().mean()
+
+
+def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict[str, Tensor],
+                           lasttvonly: bool = True, interflowloss: bool = True, occlusion: bool = False,
+                           Ddownx2: bool = True, composition: str = "warp_grad", tvlambda: float = 2.0,
+                           CElamda: float = 10.0, GANlambda: float = 1.0, num_D: int = 2):
+    """One iteration of train_condition.py:136-277 up to the two loss sums (the caller runs backward).
+    `batch`: cloth, cloth_mask (already binarised :140), parse_agnostic, densepose, parse_onehot (label
+    indices [N,1,H,W]), parse (one-hot 13), pcm, parse_cloth.  sd_vgg None drops the VGG terms
+    (torchvision weights are unavailable offline).  Returns a dict of the loss terms and tocg outputs."""
+    c_paired, cm_paired = batch["cloth"], batch["cloth_mask"]
+    input1 = torch.cat([c_paired, cm_paired], 1)
+    input2 = torch.cat([batch["parse_agnostic"], batch["densepose"]], 1)
+    label_onehot, label, pcm, im_c = batch["parse_onehot"], batch["parse"], batch["pcm"], batch["parse_cloth"]
+    BN_TRAIN["on"], BN_TRAIN["stats"] = True, {}
+    try:
+        flow_list, fake_segmap, warped_c, warped_cm = tocg_forward(sd_g, input1, input2)
+    finally:
+        BN_TRAIN["on"] = False
+    seg_raw = fake_segmap
+    warped_cm_onehot = (warped_cm.detach() > 0.5).float()
+    if composition != "no_composition":                                     # :164-173
+        mask = torch.ones_like(fake_segmap.detach())
+        mask[:, 3:4] = warped_cm_onehot if composition == "detach" else warped_cm
+        fake_segmap = fake_segmap * mask
+    if occlusion:                                                           # :174-176
+        warped_cm = remove_overlap(F.softmax(fake_segmap, dim=1), warped_cm)
+        warped_c = warped_c * warped_cm + torch.ones_like(warped_c) * (1 - warped_cm)
+    vgg = (lambda a, b: vgg_loss(sd_vgg, a, b)) if sd_vgg is not None else (lambda a, b: torch.zeros(()))
+    loss_l1 = F.l1_loss(warped_cm, pcm)                                     # :184
+    loss_vgg = vgg(warped_c, im_c)                                          # :185
+    loss_tv = 0
+    for flow in (flow_list[-1:] if lasttvonly else flow_list):              # :190-199
+        loss_tv = loss_tv + tv_loss(flow)
+    N, _, iH, iW = c_paired.shape
+    if interflowloss:                                                       # :235-248
+        for i in range(len(flow_list) - 1):
+            flow = flow_list[i]
+            _, fH, fW, _ = flow.shape
+            grid = make_grid(N, iH, iW)
+            flow = resize_bilinear(flow.permute(0, 3, 1, 2), size=(iH, iW)).permute(0, 2, 3, 1)
+            flow_norm = torch.cat([flow[..., 0:1] / ((fW - 1.0) / 2.0), flow[..., 1:2] / ((fH - 1.0) / 2.0)], 3)
+            w_c = grid_sample_bilinear_border(c_paired, flow_norm + grid)
+            w_cm = grid_sample_bilinear_border(cm_paired, flow_norm + grid)
+            w_cm = remove_overlap(F.softmax(fake_segmap, dim=1), w_cm)
+            loss_l1 = loss_l1 + F.l1_loss(w_cm, pcm) / (2 ** (4 - i))
+            loss_vgg = loss_vgg + vgg(w_c, im_c) / (2 ** (4 - i))
+    ce = cross_entropy2d(fake_segmap, label_onehot.transpose(0, 1)[0].long())   # :252
+    soft = torch.softmax(fake_segmap, 1)                                    # :260
+    pred = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), soft), 1), num_D, 3, Ddownx2)
+    loss_g_gan = lsgan_loss(pred, True)                                     # :264
+    pred_f = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), soft.detach()), 1), num_D,
+                                        3, Ddownx2)
+    pred_r = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), label), 1), num_D, 3, Ddownx2)
+    loss_d_fake, loss_d_real = lsgan_loss(pred_f, False), lsgan_loss(pred_r, True)
+    loss_G = (10 * loss_l1 + loss_vgg + tvlambda * loss_tv) + (ce * CElamda + loss_g_gan * GANlambda)   # :276
+    loss_D = loss_d_fake + loss_d_real                                      # :277
+    return {"loss_G": loss_G, "loss_D": loss_D, "l1": loss_l1, "vgg": loss_vgg, "tv": loss_tv, "ce": ce,
+            "g_gan": loss_g_gan, "d_fake": loss_d_fake, "d_real": loss_d_real, "flow_list": flow_list,
+            "fake_segmap": seg_raw, "warped_c": warped_c, "warped_cm": warped_cm, "bn_stats": dict(BN_TRAIN["stats"])}

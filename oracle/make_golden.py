@@ -215,5 +215,96 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
+def condstep():
+    """One tocg + D training iteration of the REAL reference (train_condition.py:136-286 re-composed on
+    CPU from the reference's own classes; config --Ddownx2 --lasttvonly --interflowloss, VGG terms
+    dropped: torchvision weights are unavailable).  Summaries only."""
+    import torch
+    import torch.nn as nn
+    import torch.nn.functional as F
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref_networks, _ = _import_reference()
+    from oracle.recipes import condstep_build
+    opt, tocg, D, b = condstep_build(ref_networks.ConditionGenerator, ref_networks.define_D)
+    tocg.train()
+    D.train()
+    crit = ref_networks.GANLoss(use_lsgan=True, tensor=torch.Tensor)
+    l1 = nn.L1Loss()
+    opt_G = torch.optim.Adam(tocg.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    opt_D = torch.optim.Adam(D.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    c, cm = b["cloth"], b["cloth_mask"]
+    in1, in2 = torch.cat([c, cm], 1), torch.cat([b["parse_agnostic"], b["densepose"]], 1)
+    flows, seg, w_c, w_cm = tocg(opt, in1, in2)
+    seg_raw = seg
+    mask = torch.ones_like(seg.detach())
+    mask[:, 3:4, :, :] = w_cm                       # clothmask_composition == 'warp_grad'
+    seg = seg * mask
+    loss_l1 = l1(w_cm, b["pcm"])
+    last = flows[-1]
+    loss_tv = torch.abs(last[:, 1:] - last[:, :-1]).mean() + torch.abs(last[:, :, 1:] - last[:, :, :-1]).mean()
+    N, _, iH, iW = c.size()
+
+    def rm_overlap(so, wcm):   # train_condition.py:38-43
+        return wcm - (torch.cat([so[:, 1:3], so[:, 5:]], dim=1)).sum(dim=1, keepdim=True) * wcm
+
+    for i in range(len(flows) - 1):
+        fl = flows[i]
+        _, fH, fW, _ = fl.size()
+        grid = ref_networks.make_grid(N, iH, iW, opt)
+        fl = F.interpolate(fl.permute(0, 3, 1, 2), size=c.shape[2:], mode="bilinear").permute(0, 2, 3, 1)
+        fn = torch.cat([fl[:, :, :, 0:1] / ((fW - 1.0) / 2.0), fl[:, :, :, 1:2] / ((fH - 1.0) / 2.0)], 3)
+        wcm_i = F.grid_sample(cm, fn + grid, padding_mode="border")
+        wcm_i = rm_overlap(F.softmax(seg, dim=1), wcm_i)
+        loss_l1 = loss_l1 + l1(wcm_i, b["pcm"]) / (2 ** (4 - i))
+    tgt = b["parse_onehot"].transpose(0, 1)[0].long()
+    ce = F.cross_entropy(seg.transpose(1, 2).transpose(2, 3).contiguous().view(-1, 13), tgt.view(-1), ignore_index=250)
+    soft = torch.softmax(seg, 1)
+    pred = D(torch.cat((in1.detach(), in2.detach(), soft), dim=1))
+    g_gan = crit(pred, True)
+    pred_f = D(torch.cat((in1.detach(), in2.detach(), soft.detach()), dim=1))
+    pred_r = D(torch.cat((in1.detach(), in2.detach(), b["parse"]), dim=1))
+    d_fake, d_real = crit(pred_f, False), crit(pred_r, True)
+    loss_G = (10 * loss_l1 + 2 * loss_tv) + (ce * 10 + g_gan * 1)
+    loss_D = d_fake + d_real
+    opt_G.zero_grad()
+    loss_G.backward()
+    g_summ = {n_: (p.grad.abs().max().item(), p.grad.sum().item(), p.grad.abs().sum().item())
+              for n_, p in tocg.named_parameters() if p.grad is not None}
+    samples = {k: dict(tocg.named_parameters())[k].grad.clone() for k in
+               ("ClothEncoder.0.scale.weight", "flow_conv.2.weight", "SegDecoder.4.block.1.weight",
+                "out_layer.block.4.bias", "conv1.1.bias")}
+    opt_G.step()
+    opt_D.zero_grad()
+    loss_D.backward()
+    d_summ = {n_: (p.grad.abs().max().item(), p.grad.sum().item(), p.grad.abs().sum().item())
+              for n_, p in D.named_parameters() if p.grad is not None}
+    samples_d = {k: dict(D.named_parameters())[k].grad.clone() for k in ("layer0.0.weight", "layer1.11.bias")}
+    opt_D.step()
+    sd = tocg.state_dict()
+    torch.save({"recipe": "oracle.recipes.condstep_build",
+                "losses": {"loss_G": loss_G.item(), "loss_D": loss_D.item(), "l1": loss_l1.item(), "tv": loss_tv.item(),
+                           "ce": ce.item(), "g_gan": g_gan.item(), "d_fake": d_fake.item(), "d_real": d_real.item()},
+                "fake_segmap": seg_raw.detach()[:, :, ::4, ::4].clone(), "flow_last": last.detach().clone(),
+                "warped_cm": w_cm.detach()[:, :, ::2, ::2].clone(),
+                "pred_shapes": [tuple(p[-1].shape) for p in pred],
+                "grad_summary_G": g_summ, "grad_summary_D": d_summ, "sample_grads_G": samples,
+                "sample_grads_D": samples_d,
+                "bn_after": {k: sd[k].clone() for k in ("ClothEncoder.0.block.1.running_mean",
+                                                        "ClothEncoder.0.block.1.running_var",
+                                                        "SegDecoder.4.block.4.running_var",
+                                                        "out_layer.block.1.num_batches_tracked")},
+                "param_after": {"flow_conv.4.bias": sd["flow_conv.4.bias"].clone(),
+                                "PoseEncoder.2.block.0.weight": sd["PoseEncoder.2.block.0.weight"].clone(),
+                                "D.layer1.0.bias": D.state_dict()["layer1.0.bias"].clone()}},
+               os.path.join(OUT, "condstep_ngf8_128x96.pt"))
+    print("condstep_ngf8_128x96.pt", os.path.getsize(os.path.join(OUT, "condstep_ngf8_128x96.pt")) // 1024, "KiB",
+          {k: round(v, 5) for k, v in {"G": loss_G.item(), "D": loss_D.item(), "ce": ce.item(), "tv": loss_tv.item(),
+                                       "l1": loss_l1.item(), "gan": g_gan.item()}.items()})
+
+
 if __name__ == "__main__":
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == "condstep":
+        condstep()
+    else:
+        main()
+        condstep()

@@ -42,3 +42,52 @@ def trainstep_build(gen_cls, dis_cls, cuda: bool = False):
         h, w = 2 << j, 1 << j
         noise[b] = [torch.randn(N, w, h, 1, generator=g) for _ in range(2 if b == "head_0" else 3)]
     return opt, gen, dis, x, seg, real, noise
+
+
+def condstep_opt(cuda: bool):
+    return Namespace(cuda=cuda, warp_feature="T1", out_layer="relu", semantic_nc=13, output_nc=13)
+
+
+def condstep_build(tocg_cls, define_D, cuda: bool = False):
+    """ConditionGenerator(ngf=8) + define_D(33 ch, Ddownx2, num_D=2) + one synthetic train_condition.py
+    batch (N=2, 128x96).  tocg keeps torch's default conv init with randomised BatchNorm affine terms
+    and non-trivial running statistics; D uses the reference's weights_init (N(0, 0.02)) scaled x2."""
+    opt = condstep_opt(cuda)
+    torch.manual_seed(31)
+    tocg = tocg_cls(opt, input1_nc=4, input2_nc=16, output_nc=13, ngf=8, norm_layer=torch.nn.BatchNorm2d)
+    D = define_D(input_nc=4 + 16 + 13, Ddownx2=True, Ddropout=False, n_layers_D=3, spectral=False, num_D=2)
+    g = torch.Generator().manual_seed(91)
+    with torch.no_grad():
+        for m in tocg.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.weight.copy_(1.0 + 0.3 * torch.randn(m.weight.shape, generator=g))
+                m.bias.copy_(0.2 * torch.randn(m.bias.shape, generator=g))
+                m.running_mean.copy_(0.1 * torch.randn(m.running_mean.shape, generator=g))
+                m.running_var.copy_(0.5 + torch.rand(m.running_var.shape, generator=g))
+        for name, p in tocg.named_parameters():
+            if name.startswith("flow_conv") and name.endswith("weight"):
+                p.mul_(0.3)   # keep the synthetic flows inside the image so the warps have gradients
+        for p in D.parameters():
+            p.copy_(0.02 * 2.0 * torch.randn(p.shape, generator=g))
+    N, H, W = 2, 128, 96
+    lab = torch.randint(0, 13, (N, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    parse = torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0)
+    agn = torch.randint(0, 13, (N, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
+    def smooth(c):
+        # low-frequency images: the warps' coordinate gradients are piecewise constant per source pixel,
+        # white noise would make every gradient comparison hinge on floor() flips at pixel borders
+        lo = torch.rand(N, c, H // 8, W // 8, generator=g) * 2 - 1
+        return torch.nn.functional.interpolate(lo, scale_factor=8, mode="bilinear", align_corners=False)
+
+    batch = {
+        "cloth": smooth(3),
+        "cloth_mask": (torch.rand(N, 1, H // 4, W // 4, generator=g) > 0.4).float().repeat_interleave(4, 2)
+        .repeat_interleave(4, 3),
+        "parse_agnostic": torch.zeros(N, 13, H, W).scatter_(1, agn, 1.0),
+        "densepose": smooth(3),
+        "parse_onehot": lab.float(),          # label indices [N,1,H,W] (cp_dataset.py 'parse_onehot')
+        "parse": parse,                       # one-hot 13
+        "pcm": (lab == 3).float(),            # parse cloth mask
+        "parse_cloth": smooth(3),
+    }
+    return opt, tocg, D, batch

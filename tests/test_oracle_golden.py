@@ -96,3 +96,62 @@ def test_training_step_restatement_matches_reference():
     for name, want in g["sample_grads"].items():
         t = (sd_d[name[2:]] if name.startswith("D.") else sd_g[name]).grad
         assert (t - want).abs().max() < 1e-2 * max(want.abs().max().item(), 1e-3 * gmax), name
+
+
+def _condstep_oracle():
+    """Shared by the CPU pin below and the GPU parity test: the oracle's train_condition.py step on the
+    recipe's weights (built through the product's parameter containers on the CPU)."""
+    from oracle.recipes import condstep_build
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import networks
+    opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D)
+    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k)
+            for k, v in tocg.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    res = O.condition_train_losses(sd_g, sd_d, None, batch)
+    return tocg, D, batch, sd_g, sd_d, res
+
+
+def test_condition_training_step_restatement_matches_reference():
+    """Oracle restatement of one train_condition.py iteration (batch-stat BatchNorm, flow warps, TV / CE /
+    LSGAN / interflow losses, autograd through all of it) vs summaries of the REAL reference's step."""
+    g = load_golden("condstep_ngf8_128x96.pt")
+    tocg, D, batch, sd_g, sd_d, r = _condstep_oracle()
+    for k, want in g["losses"].items():
+        got = r[{"loss_G": "loss_G", "loss_D": "loss_D", "l1": "l1", "tv": "tv", "ce": "ce", "g_gan": "g_gan",
+                 "d_fake": "d_fake", "d_real": "d_real"}[k]].item()
+        assert abs(got - want) < 2e-5 * max(1.0, abs(want)), (k, got, want)
+    _close(r["fake_segmap"][:, :, ::4, ::4], g["fake_segmap"], 2e-5)
+    _close(r["flow_list"][-1], g["flow_last"], 2e-5)
+    _close(r["warped_cm"][:, :, ::2, ::2], g["warped_cm"], 1e-4)
+    assert g["flow_last"].abs().max() > 0.3        # the warps are exercised
+    # generator gradients (sign() of the L1 terms makes them noisy at the 1e-3 level: scale-aware 1e-2)
+    r["loss_G"].backward(retain_graph=True)
+    gmax = max(v[0] for v in g["grad_summary_G"].values())
+    for name, (gm, gs, gas) in g["grad_summary_G"].items():
+        t = sd_g[name].grad
+        assert t is not None, name
+        assert abs(t.abs().max().item() - gm) < 1e-2 * max(gm, 1e-3 * gmax), (name, t.abs().max().item(), gm)
+        assert abs(t.abs().sum().item() - gas) < 1e-2 * max(gas, 1e-3 * gmax * t.numel()), (name, gas)
+    for name, want in g["sample_grads_G"].items():
+        assert (sd_g[name].grad - want).abs().max() < 1e-2 * max(want.abs().max().item(), 1e-3 * gmax), name
+    # discriminator gradients (optimizer_D.zero_grad() precedes loss_D.backward(): train_condition.py:284-286)
+    for v in sd_d.values():
+        v.grad = None
+    r["loss_D"].backward()
+    dmax = max(v[0] for v in g["grad_summary_D"].values())
+    for name, (gm, gs, gas) in g["grad_summary_D"].items():
+        t = sd_d[name].grad
+        assert abs(t.abs().max().item() - gm) < 1e-3 * max(gm, 1e-3 * dmax), (name, t.abs().max().item(), gm)
+    for name, want in g["sample_grads_D"].items():
+        assert (sd_d[name].grad - want).abs().max() < 1e-3 * max(want.abs().max().item(), 1e-3 * dmax), name
+    # running statistics after the step: momentum 0.1 on the recorded batch statistics
+    sd0 = tocg.state_dict()
+    for k, want in g["bn_after"].items():
+        if k.endswith("num_batches_tracked"):
+            assert int(want) == 1
+            continue
+        p, which = k.rsplit(".", 1)
+        mean, var_unb = r["bn_stats"][p]
+        new = 0.9 * sd0[k] + 0.1 * (mean if which == "running_mean" else var_unb)
+        _close(new, want, 1e-5)
