@@ -60,6 +60,79 @@ def build_model(torch, nn):
     return opt, m
 
 
+def _emit(args, torch, hdist, ops, rank, world, B, step, metric, workload, flops_per_img, train):
+    dt = hdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
+    ops.profile_begin()
+    step(0)
+    recs = ops.profile_end()
+    kinds = {}
+    for k, n, fl, by, ms in recs:
+        a = kinds.setdefault(k, [0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += fl
+    if args.dump_launches and rank == 0:
+        with open(args.dump_launches, "w") as f:
+            for k, n, fl, by, ms in recs:
+                f.write(f"{k:8s} {n:52s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s\n")
+    mf_ms = sum(v[1] for k, v in kinds.items() if k in ("conv", "wgrad"))
+    mf_fl = sum(v[2] for k, v in kinds.items() if k in ("conv", "wgrad"))
+    if rank == 0:
+        ach = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
+        line = {"metric": metric, "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": workload, "global_batch": B * world,
+                           "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
+                "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
+                             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                             "end_to_end_TFLOPs_vs_survey_work": round(B * flops_per_img / (dt / args.steps) / 1e12, 2)},
+                "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(kinds.items())},
+                "cpu_baseline": None}
+        print(json.dumps(line), flush=True)
+    import torch.distributed as tdist
+    if tdist.is_available() and tdist.is_initialized():
+        tdist.barrier()
+        tdist.destroy_process_group()
+
+
+def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
+    """BASELINE configs[2]: train_condition.py 1024x768 b=8 fp32 --Ddownx2 --lasttvonly --interflowloss."""
+    import train_condition as tc
+    from hr_viton_amd.gen_train import attach_grad_sync
+    from hr_viton_amd.losses import L1Loss
+    from hr_viton_amd.networks import ConditionGenerator, GANLoss, VGGLoss, define_D
+    from hr_viton_amd.optim import Adam
+    from hr_viton_amd.parallel import GradSync, broadcast_module
+    from hr_viton_amd.pipeline import condition_train_step
+    B = args.batch or 8
+    opt = tc.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world), "--fine_height", "1024", "--fine_width",
+                      "768", "--Ddownx2", "--lasttvonly", "--interflowloss"])
+    torch.manual_seed(0)
+    tocg = ConditionGenerator(opt, 4, 16, 13, ngf=96, norm_layer=nn.BatchNorm2d).to(dev).train()
+    D = define_D(input_nc=4 + 16 + 13, Ddownx2=True, Ddropout=False, n_layers_D=3, spectral=False, num_D=2).to(dev).train()
+    crit_vgg = VGGLoss(opt).to(dev)
+    for m in (tocg, D, crit_vgg):
+        broadcast_module(m)
+    sg = GradSync(tocg.parameters()) if world > 1 else None
+    sd = GradSync(D.parameters()) if world > 1 else None
+    for s_ in (sg, sd):
+        if s_ is not None:
+            attach_grad_sync(s_)
+    og = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999), grad_sync=sg)
+    od = Adam(D.parameters(), lr=opt.D_lr, betas=(0.5, 0.999), grad_sync=sd)
+    l1, gan = L1Loss(), GANLoss(use_lsgan=True)
+    batch = tc.synthetic_batch(opt, B, hdist.shard_seed(4321, rank), dev)
+
+    def step(_i):
+        condition_train_step(opt, tocg, D, l1, crit_vgg, gan, og, od, batch, sg, sd)
+    _emit(args, torch, hdist, ops, rank, world, B, step,
+          "1024x768 images/sec (train_condition.py step: tocg fwd/bwd with batch-stat BN, 5 VGG pairs, LSGAN D, Adam)",
+          "BASELINE configs[2]: train_condition.py 1024x768 fp32 --Ddownx2 --lasttvonly --interflowloss, ngf=96, "
+          "random-init weights", 13e12, True)
+
+
 def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     """Secondary workloads (not the driver's default bench): same timing contract, same JSON shape."""
     from argparse import Namespace
@@ -72,6 +145,8 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.parallel import GradSync, broadcast_module
     from hr_viton_amd.pipeline import generator_train_step, make_generator_inputs, tryon_step
     from hr_viton_amd.vgg import VGGLoss
+    if args.workload == "train_condition":
+        return cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev)
     train = args.workload == "train_generator"
     B = args.batch or 4
     opt = tg.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world)] + (["--fp16"] if args.bf16 else []))
@@ -155,7 +230,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(cores, 32))")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch table of one step to this file")
-    ap.add_argument("--workload", default="tocg_infer", choices=["tocg_infer", "train_generator", "tryon_infer"],
+    ap.add_argument("--workload", default="tocg_infer", choices=["tocg_infer", "train_generator", "tryon_infer", "train_condition"],
                     help="tocg_infer = BASELINE configs[1] (default, the driver's bench); train_generator = configs[3] "
                          "shape in fp32 (4 img/GPU, G+D step incl. VGG, DP all-reduce); tryon_infer = end-to-end "
                          "test_generator.py step (configs[4] shape, fp32)")

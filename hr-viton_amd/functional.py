@@ -149,7 +149,8 @@ class _CEFn(torch.autograd.Function):
     def forward(ctx, x, target):
         lib = _lib.load()
         x = _f32c(x, "cross_entropy2d(input)")
-        ops.require_cuda(target, "cross_entropy2d(target)")
+        if not target.is_cuda:
+            raise _lib.HrvError("cross_entropy2d(target): tensor is on the CPU; the MI355X path has no CPU fallback")
         target = target.contiguous().to(torch.int64)
         N, Cc, H, W = x.shape
         assert tuple(target.shape) == (N, H, W), "target must be [N,H,W] (sizes equal: utils.py:34-35 is not on the path)"

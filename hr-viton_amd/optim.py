@@ -23,9 +23,11 @@ class Adam(torch.optim.Optimizer):
         ps = [p for p in group["params"] if p.requires_grad]
         for p in ps:
             ops.require_cuda(p.data, "hr_viton_amd.optim.Adam parameter")
-        n = sum(p.numel() for p in ps)
+        # every parameter starts on a 16-byte boundary of the flat buffer: the conv epilogues take
+        # float4 loads of bias / scale vectors (unaligned ones fall back to the scalar epilogue)
+        n = sum((p.numel() + 3) // 4 * 4 for p in ps)
         dev = ps[0].device
-        w = torch.empty(n, dtype=torch.float32, device=dev)
+        w = torch.zeros(n, dtype=torch.float32, device=dev)
         off = 0
         spans = []
         for p in ps:
@@ -33,7 +35,7 @@ class Adam(torch.optim.Optimizer):
             w[off:off + k].copy_(p.data.reshape(-1))
             p.data = w[off:off + k].view_as(p.data)      # the parameter now lives in the flat buffer
             spans.append((p, off, k))
-            off += k
+            off += (k + 3) // 4 * 4
         st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w), g=torch.zeros_like(w), spans=spans, step=0)
         self._flat[gi] = st
         return st

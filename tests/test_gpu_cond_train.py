@@ -293,10 +293,10 @@ def test_condition_training_iteration_matches_oracle(with_vgg):
         def __init__(self, g):
             self.grad = g
 
-    # sign() of the L1 terms and floor() flips of the warps make G's gradients noisy: 2e-2 scale-aware
-    _compare_grads(_G(tocg, grads_g), {k: _W(g_grads[k]) for k in sd_g}, 2e-2,
+    # sign() of the L1 terms and floor() flips of the warps make G's gradients noisy: 5e-3 scale-aware (measured 4.6e-4)
+    _compare_grads(_G(tocg, grads_g), {k: _W(g_grads[k]) for k in sd_g}, 5e-3,
                    "tocg_vgg step" if with_vgg else "tocg step")
-    _compare_grads(_G(D, grads_d), {k: _W(v.grad) for k, v in sd_d.items()}, 1e-3,
+    _compare_grads(_G(D, grads_d), {k: _W(v.grad) for k, v in sd_d.items()}, 5e-4,
                    "tocgD_vgg step" if with_vgg else "tocgD step")
     # running statistics: momentum 0.1 on the oracle's recorded batch statistics
     mean, var_unb = r["bn_stats"]["ClothEncoder.0.block.1"]
