@@ -93,13 +93,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
 
-  int b = blockIdx.x;
-  const int s = b % p.S; b /= p.S;
-  const int tap = b % p.taps; b /= p.taps;
-  const int it = b % p.ci_tiles;
-  const int ct = b / p.ci_tiles;
-  const int kh = tap / p.KW, kw = tap - kh * p.KW;
-  const int co0 = ct * BMc, ci0 = it * BNc;
+  // Logical block id: slab-major (all tiles of one pixel slab are neighbours) and XCD-contiguous, so the
+  // blocks that stream the same dY / X pixels run at the same time behind the same L2.
+  int b = xcd_remap(blockIdx.x, p.co_tiles * p.ci_tiles * p.S);
+  const int it = b % p.ci_tiles; b /= p.ci_tiles;
+  const int ct = b % p.co_tiles;
+  const int s = b / p.co_tiles;
+  const int co0 = ct * BMc, col0 = it * BNc;   // columns = flattened (tap, ci): col = tap * x_C + ci
 
   const int ptiles = (p.P + BK - 1) / BK;
   const int t_begin = (int)(((long long)ptiles * s) / p.S);
@@ -107,6 +107,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
 
   const int sr = p.x_up > 0 ? p.x_up : 0, sl = p.x_up < 0 ? -p.x_up : 0;
   const int Hs = (p.H >> sr) << sl, Ws = (p.W >> sr) << sl;
+
+  // every X load of a thread has the same column group (256 % (BNc/4) == 0) -> one (tap, ci) per thread
+  static_assert(256 % (BNc / 4) == 0, "column group of a thread must not depend on the load index");
+  const int my_col = col0 + (tid % (BNc / 4)) * 4;
+  const bool col_ok = my_col < p.taps * p.x_C;
+  const int my_tap = col_ok ? my_col / p.x_C : 0;
+  const int my_ci = col_ok ? my_col - my_tap * p.x_C : 0;
+  const int kh = my_tap / p.KW, kw = my_tap - kh * p.KW;
 
   f32x4 yreg[YR], xreg[XR];
   // per-thread gather rows: pixel (n, ho, wo) of X-row r at the current tile, advanced by BK
@@ -146,16 +154,15 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
     }                                                                                                     \
     _Pragma("unroll") for (int r = 0; r < XR; ++r) {                                                      \
       const int idx = tid + 256 * r;                                                                      \
-      const int row = idx / (BNc / 4), c4 = idx - row * (BNc / 4);                                        \
+      const int row = idx / (BNc / 4);                                                                    \
       const int pix = (T)*BK + row;                                                                       \
       const int n = xr_n[r], ho = xr_ho[r], wo = xr_wo[r];                                                \
       const int hi = ho * p.stride - p.pad + kh, wi = wo * p.stride - p.pad + kw;                         \
-      const int c = ci0 + c4 * 4;                                                                         \
-      const bool ok = idx < BK * BNc / 4 && pix < p.P && c < p.x_C && (unsigned)hi < (unsigned)p.H &&     \
+      const bool ok = idx < BK * BNc / 4 && pix < p.P && col_ok && (unsigned)hi < (unsigned)p.H &&        \
                       (unsigned)wi < (unsigned)p.W;                                                       \
       const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);                           \
       const size_t off = ((size_t)(n * Hs + ((hic >> sr) << sl)) * Ws + ((wic >> sr) << sl)) * p.x_cs +   \
-                         p.x_co + (c < p.x_C ? c : 0);                                                    \
+                         p.x_co + my_ci;                                                                  \
       f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                               \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                               \
       xreg[r] = v;                                                                                        \
@@ -214,11 +221,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
 #undef WG_MMA
 
   // D[i = cout][j = cin]: col = lane&31 (cin), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
-  float* wsp = p.ws + ((size_t)s * p.taps + tap) * p.Cout * p.CinTot;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    const int ci = ci0 + (wn * TN + j) * 32 + l31;
+    const int col = col0 + (wn * TN + j) * 32 + l31;
+    if (col >= p.taps * p.x_C) continue;
+    const int tap = col / p.x_C, ci = col - tap * p.x_C;
     if (ci >= p.ci_real) continue;
+    float* wsp = p.ws + ((size_t)s * p.taps + tap) * p.Cout * p.CinTot;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -416,8 +425,9 @@ extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, in
   p.P = N * Ho * Wo; p.ci_base = ci_base; p.ci_real = x_C_real; p.CinTot = CinTot;
   const int wt = pick_wtile(Cout, x_C);
   const int bm = wt_bm(wt), bn = wt_bn(wt);
-  p.co_tiles = (Cout + bm - 1) / bm; p.ci_tiles = (x_C + bn - 1) / bn; p.taps = KH * KW;
-  const int tiles = p.co_tiles * p.ci_tiles * p.taps;
+  p.taps = KH * KW;
+  p.co_tiles = (Cout + bm - 1) / bm; p.ci_tiles = (p.taps * x_C + bn - 1) / bn;   // column tiles over (tap, ci)
+  const int tiles = p.co_tiles * p.ci_tiles;
   const int ptiles = (p.P + BK - 1) / BK;
   int S = (1024 + tiles - 1) / tiles;
   if (S > ptiles / 4) S = ptiles / 4;

@@ -48,6 +48,7 @@ class Vgg19(nn.Module):
             for p in self.parameters():
                 p.requires_grad = False
         self._plan = None
+        self._ycache = None
 
     def load_torchvision_state_dict(self, sd):
         """Accepts torchvision.models.vgg19().state_dict() (keys 'features.N.weight')."""
@@ -60,6 +61,7 @@ class Vgg19(nn.Module):
                         own[f"slice{k + 1}.{i}.{suf}"] = sd[key]
         self.load_state_dict(own, strict=True)
         self._plan = None
+        self._ycache = None
 
     def conv(self, idx: int) -> nn.Conv2d:
         for k, (a, b) in enumerate(_SLICES):
@@ -93,6 +95,18 @@ class Vgg19(nn.Module):
                 taps.append(out)
         return taps, saved
 
+    def target_features(self, y: torch.Tensor):
+        """Taps of the (detached, networks.py:250) target.  train_condition.py calls the criterion five times
+        per iteration with the SAME target tensor (:185,248): its features are computed once and reused while
+        the identical tensor object (same storage, same version counter) keeps being passed."""
+        c = getattr(self, "_ycache", None)
+        key = (y.data_ptr(), y._version, tuple(y.shape), ops.WEIGHTS_EPOCH[0])
+        if c is not None and c[0] is y and c[1] == key:
+            return c[2]
+        ty, _ = self.features(ops.to_nhwc(y), save=False)
+        self._ycache = (y, key, ty)
+        return ty
+
     def forward(self, X):
         with torch.no_grad():
             taps, _ = self.features(ops.to_nhwc(X), save=False)
@@ -104,8 +118,8 @@ class _VGGLossFn(torch.autograd.Function):
     def forward(ctx, vgg, weights, layids, x, y):
         ops.require_cuda(x, "VGGLoss(x)")
         need = ctx.needs_input_grad[3]
-        xa, ya = ops.to_nhwc(x), ops.to_nhwc(y)
-        ty, _ = vgg.features(ya, save=False)
+        xa = ops.to_nhwc(x)
+        ty = vgg.target_features(y)
         tx, saved = vgg.features(xa, save=need)
         loss = torch.zeros(1, dtype=torch.float32, device=x.device)
         grads: List[Optional[torch.Tensor]] = [None] * 5
