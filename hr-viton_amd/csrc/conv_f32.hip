@@ -38,6 +38,7 @@ constexpr int HOST_BK = 16;   // fp32 k-values per 64-byte K-tile row (host-side
 struct SrcDev {
   const float* ptr;
   int C, cstride, coff, up_shift, pre_act, chunks;
+  unsigned bytes;  // extent of the tensor in bytes (buffer resource of the LDS-DMA gather)
 };
 
 struct ConvParams {
@@ -67,6 +68,7 @@ struct ConvParams {
   int bf16;      // 1: sources / weights are bf16 (accumulate + stats fp32)
   int out_f32, res_f32, sx_f32;  // bf16 mode: these tensors are fp32 instead of bf16
   int res_mode;  // 0: + residual; 1: * (residual > 0 ? 1 : slope)   (activation derivative, backward)
+  unsigned w_bytes;       // size of the packed weight (LDS-DMA buffer resource; 0: LDS-DMA not usable)
   // SPADE epilogue (epi == 1)
   int epi;
   const float* sx;
@@ -166,6 +168,23 @@ __device__ __forceinline__ void st1rt(float* base, size_t idx, float v, int is_f
   st1e<false>(base, idx, v);
 }
 
+// LDS-DMA primitives.  The buffer-resource type and builtins exist in the device pass only; the host pass
+// (which still parses kernel bodies to emit launch stubs) sees inert stand-ins.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)bytes, 0x00020000);
+}
+// 16 bytes per lane: global[base + voff + soff] -> LDS[lds (wave-uniform) + 16*lane]; offsets past `bytes` store 0
+__device__ __forceinline__ void dma16(rsrc_t r, float* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+#else
+struct rsrc_t { int unused; };
+__device__ inline rsrc_t make_rsrc(const void*, unsigned) { return rsrc_t{0}; }
+__device__ inline void dma16(rsrc_t, float*, unsigned, unsigned) {}
+#endif
+
 template <int TM, int TN, int WM, int WN, int VAR, bool BF, int RB = 64>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   static_assert(WM * WN == 4, "4 waves per block");
@@ -174,7 +193,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   constexpr int EPG = 16 / ES;       // elements per 16-byte gather group
   constexpr int GPR = RB / 16;       // 16-byte groups per K-tile row
   constexpr int BKE = GPR * EPG;     // k-values per K-tile row
-  constexpr int LS = RB / 4 + 4;     // LDS row stride in floats (row + 16 B pad: conflict-free b128 reads)
+  constexpr bool GLDS = (VAR & 4) != 0;  // operands staged by LDS-DMA (global_load_lds_dwordx4), no register hop
+  static_assert(!GLDS || (BF && RB == 128), "the LDS-DMA variant exists for the bf16 engine with 128-byte rows");
+  // LDS row stride in floats.  Register-staged: row + 16 B pad (conflict-free b128 reads).  LDS-DMA: the
+  // image is lane-linear (dest = wave base + lane*16), so rows are dense and the 16-byte groups of a row
+  // are XOR-swizzled by ((row >> 1) & 7) on the SOURCE address and on the fragment read instead.
+  constexpr int LS = GLDS ? RB / 4 : RB / 4 + 4;
   constexpr int BK = RB / 4;         // floats per packed-weight row
   constexpr int KQ = RB / 32;        // 32-byte fragment steps per row (2 lane-halves x 16 B)
   constexpr int RPP = 256 / GPR;     // tile rows covered by one pass of the 256 threads
@@ -188,7 +212,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA bases stay scalar
   const int wm = wave / WN;
   const int wn = wave % WN;
 
@@ -219,6 +243,38 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     a_n[r] = n;
     a_hi0[r] = ho * p.stride - p.pad;
     a_wi0[r] = wo * p.stride - p.pad_w;
+  }
+
+  // LDS-DMA gather state: logical channel group of this thread (the swizzle term (row >> 1) & 7 does not
+  // depend on r: rows of one thread are RPP = 32 apart), pixel index of tap (0,0), per-row tap-validity
+  // bit mask, byte offset of the current (tap 0, source) run, constant weight-tile offsets.
+  [[maybe_unused]] const int g_ch = (a_c4 ^ ((a_row >> 1) & 7)) * EPG;
+  [[maybe_unused]] int a_pix[AR];
+  [[maybe_unused]] unsigned a_mask[AR], a_off[AR], b_voff[BR];
+  [[maybe_unused]] bool new_run = true;
+  [[maybe_unused]] const float* s_ptr = p.src[0].ptr;
+  [[maybe_unused]] int s_C = 0, s_cs = 0, s_co = 0, s_up = 0, s_chunks = 1;
+  [[maybe_unused]] unsigned s_bytes = 0;
+  [[maybe_unused]] rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
+  if constexpr (GLDS) {
+#pragma unroll
+    for (int r = 0; r < AR; ++r) {
+      a_pix[r] = (a_n[r] * p.H + a_hi0[r]) * p.W + a_wi0[r];
+      a_off[r] = 0;
+      unsigned m = 0;
+      if (p.KH * p.KW <= 32)
+        for (int t = 0; t < p.KH * p.KW; ++t) {
+          const int hi = a_hi0[r] + t / p.KW, wi = a_wi0[r] + t % p.KW;
+          m |= (a_ok[r] && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W) ? (1u << t) : 0u;
+        }
+      a_mask[r] = m;
+    }
+#pragma unroll
+    for (int j = 0; j < BR; ++j) {
+      const int idx = tid + 256 * j;
+      const int row = idx / GPR, slot = idx % GPR;
+      b_voff[j] = (unsigned)(row * RB + ((slot ^ ((row >> 1) & 7)) * 16));
+    }
   }
 
   // K-tile iterator state: (tap kh,kw) x (source s) x (chunk c), positioned at kt_begin
@@ -291,6 +347,83 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }                                                                                                        \
   }
 
+// ---- global -> LDS directly (LDS-DMA, `buffer_load_dwordx4 ... offen lds`) for K-tile KTN into buffer BUF.
+// Lane l of a wave-instruction lands at (wave-uniform base) + 16*l: the thread that owns LDS slot (row, slot)
+// fetches the logical 16-byte group slot ^ ((row >> 1) & 7) of that row.  Padding / out-of-range lanes pass
+// an offset beyond the buffer resource's num_records: the hardware range check writes ZEROS to LDS for them
+// (tools/probes/buffer_lds_oob.hip), so no zero page and no clamping.  Per K-tile VALU cost of the fast path
+// (sources without nearest up/down-sampling): one bit test + one add + one select per row; everything else
+// is wave-uniform (SALU) or hoisted to the start of a (tap, source) run.
+#define HRV_DMA_SRC()                                                                                        \
+  {                                                                                                          \
+    s_ptr = p.src[0].ptr; s_C = p.src[0].C; s_cs = p.src[0].cstride; s_co = p.src[0].coff;                   \
+    s_up = p.src[0].up_shift; s_bytes = p.src[0].bytes; s_chunks = p.src[0].chunks;                          \
+    _Pragma("unroll") for (int q = 1; q < HRV_MAX_SRC; ++q) {                                                \
+      const bool sel = it_s == q;                                                                            \
+      s_ptr = sel ? p.src[q].ptr : s_ptr;                                                                    \
+      s_C = sel ? p.src[q].C : s_C;                                                                          \
+      s_cs = sel ? p.src[q].cstride : s_cs;                                                                  \
+      s_co = sel ? p.src[q].coff : s_co;                                                                     \
+      s_up = sel ? p.src[q].up_shift : s_up;                                                                 \
+      s_bytes = sel ? p.src[q].bytes : s_bytes;                                                              \
+      s_chunks = sel ? p.src[q].chunks : s_chunks;                                                           \
+    }                                                                                                        \
+  }
+// iterator advance of the LDS-DMA loop: the current source's fields live in scalars and are reloaded only
+// when the source changes (never, for the single-source convolutions that dominate the path)
+#define HRV_DMA_ADVANCE()                                                                                    \
+  {                                                                                                          \
+    new_run = false;                                                                                         \
+    if (++it_c == s_chunks) {                                                                                \
+      it_c = 0;                                                                                              \
+      new_run = true;                                                                                        \
+      if (++it_s == p.nsrc) {                                                                                \
+        it_s = 0;                                                                                            \
+        if (++it_kw == p.KW) {                                                                               \
+          it_kw = 0;                                                                                         \
+          ++it_kh;                                                                                           \
+        }                                                                                                    \
+      }                                                                                                      \
+      if (p.nsrc > 1) HRV_DMA_SRC()                                                                          \
+    }                                                                                                        \
+  }
+#define HRV_DMA_TILE(KTN, BUF)                                                                               \
+  {                                                                                                          \
+    const rsrc_t a_rsrc = make_rsrc(s_ptr, s_bytes);                                                         \
+    float* Abuf = smem + (BUF) * (BM + BN) * LS;                                                             \
+    const bool c_ok = it_c * BKE + g_ch < s_C;                                                               \
+    if (s_up == 0 && p.KH * p.KW <= 32) {                                                                    \
+      if (new_run) {                                                                                         \
+        _Pragma("unroll") for (int r = 0; r < AR; ++r)                                                       \
+            a_off[r] = ((unsigned)a_pix[r] * (unsigned)s_cs + (unsigned)(s_co + g_ch)) * (unsigned)ES;       \
+      }                                                                                                      \
+      const unsigned delta = (unsigned)(((it_kh * p.W + it_kw) * s_cs + it_c * BKE) * ES);                   \
+      const int tap = it_kh * p.KW + it_kw;                                                                  \
+      _Pragma("unroll") for (int r = 0; r < AR; ++r) {                                                       \
+        const bool ok = c_ok && ((a_mask[r] >> tap) & 1u);                                                   \
+        const unsigned voff = ok ? a_off[r] + delta : 0xFFFFFFF0u;                                           \
+        dma16(a_rsrc, Abuf + (RPP * r + wave * (64 / GPR)) * LS, voff, 0u);                                  \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      const int sh_r = s_up > 0 ? s_up : 0, sh_l = s_up < 0 ? -s_up : 0;                                     \
+      const int Hs = (p.H >> sh_r) << sh_l, Ws = (p.W >> sh_r) << sh_l;                                      \
+      _Pragma("unroll") for (int r = 0; r < AR; ++r) {                                                       \
+        const int hi = a_hi0[r] + it_kh;                                                                     \
+        const int wi = a_wi0[r] + it_kw;                                                                     \
+        const bool ok = a_ok[r] && c_ok && (unsigned)hi < (unsigned)p.H && (unsigned)wi < (unsigned)p.W;     \
+        const unsigned off = ((unsigned)(a_n[r] * Hs + ((hi >> sh_r) << sh_l)) * Ws + ((wi >> sh_r) << sh_l)) * s_cs + \
+                             s_co + it_c * BKE + g_ch;                                                       \
+        const unsigned voff = ok ? off * ES : 0xFFFFFFF0u;                                                   \
+        dma16(a_rsrc, Abuf + (RPP * r + wave * (64 / GPR)) * LS, voff, 0u);                                  \
+      }                                                                                                      \
+    }                                                                                                        \
+    const unsigned w_soff = (unsigned)(((KTN)*p.CoutPad + n0) * RB);                                         \
+    float* Bbuf = Abuf + BM * LS;                                                                            \
+    _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
+      dma16(w_rsrc, Bbuf + ((256 * j + 64 * wave) / GPR) * LS, b_voff[j], w_soff);                           \
+    }                                                                                                        \
+  }
+
 #define HRV_ADVANCE_ITER()                                                                  \
   {                                                                                         \
     int chunks = p.src[0].chunks;                                                           \
@@ -322,13 +455,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
 #define HRV_READ_FRAGS(BUF)                                                                                  \
   {                                                                                                          \
-    const float* As = smem + (BUF) * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;                    \
-    const float* Bs = smem + (BUF) * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;          \
-    _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {                                                      \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[kq][i] =                                             \
-          *reinterpret_cast<const f32x4*>(As + i * 32 * LS + kq * 8);                                        \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[kq][j] =                                             \
-          *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + kq * 8);                                        \
+    if constexpr (GLDS) {                                                                                    \
+      /* rows are multiples of 32 apart: the swizzle term depends on l31 only */                             \
+      const int sw = (l31 >> 1) & 7;                                                                         \
+      const float* As = smem + (BUF) * (BM + BN) * LS + (wm * TM * 32 + l31) * LS;                           \
+      const float* Bs = smem + (BUF) * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS;                 \
+      _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {                                                    \
+        const int go = ((kq * 2 + lh) ^ sw) * 4;                                                             \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[kq][i] =                                           \
+            *reinterpret_cast<const f32x4*>(As + i * 32 * LS + go);                                          \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[kq][j] =                                           \
+            *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + go);                                          \
+      }                                                                                                      \
+    } else {                                                                                                 \
+      const float* As = smem + (BUF) * (BM + BN) * LS + (wm * TM * 32 + l31) * LS + lh * 4;                  \
+      const float* Bs = smem + (BUF) * (BM + BN) * LS + BM * LS + (wn * TN * 32 + l31) * LS + lh * 4;        \
+      _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {                                                    \
+        _Pragma("unroll") for (int i = 0; i < TM; ++i) fa[kq][i] =                                           \
+            *reinterpret_cast<const f32x4*>(As + i * 32 * LS + kq * 8);                                      \
+        _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[kq][j] =                                           \
+            *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + kq * 8);                                      \
+      }                                                                                                      \
     }                                                                                                        \
   }
 
@@ -360,6 +507,22 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   f32x4 fa[KQ][TM], fb[KQ][TN];
 
+  if constexpr (GLDS) {
+    static_assert((BN * GPR) % 256 == 0, "LDS-DMA B tile: every wave-instruction must be full");
+    HRV_DMA_SRC()
+    HRV_DMA_TILE(kt_begin, kt_begin & 1)
+    HRV_DMA_ADVANCE()
+    __syncthreads();   // carries vmcnt(0): the DMA has landed before any wave reads the tile
+    for (int kt = kt_begin; kt < kt_end - 1; ++kt) {
+      HRV_DMA_TILE(kt + 1, (kt + 1) & 1)   // in flight while tile kt is multiplied
+      HRV_DMA_ADVANCE()
+      HRV_READ_FRAGS(kt & 1)
+      HRV_MMA_FRAGS()
+      __syncthreads();
+    }
+    HRV_READ_FRAGS((kt_end - 1) & 1)
+    HRV_MMA_FRAGS()
+  } else {
   // prologue: fetch + stage the first K-tile of this block's range
   HRV_LOAD_TILE(kt_begin)
   HRV_ADVANCE_ITER()
@@ -393,7 +556,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   // last tile: nothing left to fetch
   HRV_READ_FRAGS((kt_end - 1) & 1)
   HRV_MMA_FRAGS()
+  }
 
+#undef HRV_DMA_TILE
+#undef HRV_DMA_SRC
+#undef HRV_DMA_ADVANCE
 #undef HRV_LOAD_TILE
 #undef HRV_ADVANCE_ITER
 #undef HRV_STORE_TILE
@@ -701,6 +868,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
   p.sx_f32 = bf ? ((d->mixed_flags >> 2) & 1) : 1;
   p.nsrc = d->nsrc;
   int chunks_total = 0;
+  bool dma_ok = bf && rb == 128;   // LDS-DMA staging: every operand must fit a 32-bit buffer resource
   for (int i = 0; i < d->nsrc; ++i) {
     const hrv_src_t& s = d->src[i];
     HRV_REQUIRE(s.ptr != nullptr, "conv2d: src[%d] null", i);
@@ -726,6 +894,12 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
     p.src[i].pre_act = s.pre_act;
     p.src[i].chunks = (s.C + bke - 1) / bke;
     chunks_total += p.src[i].chunks;
+    {
+      const int sr = s.up_shift > 0 ? s.up_shift : 0, sl = s.up_shift < 0 ? -s.up_shift : 0;
+      const int64_t bytes = (int64_t)d->N * ((d->H >> sr) << sl) * ((d->W >> sr) << sl) * s.cstride * (bf ? 2 : 4);
+      p.src[i].bytes = bytes < (int64_t)0xFFFFFFF0 ? (unsigned)bytes : 0u;
+      if (bytes >= (int64_t)0xFFFFFFF0) dma_ok = false;
+    }
   }
   p.N = d->N; p.H = d->H; p.W = d->W; p.Ho = d->Ho; p.Wo = d->Wo;
   p.KH = d->KH; p.KW = d->KW; p.stride = d->stride; p.pad = d->pad;
@@ -769,6 +943,10 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
     p.wp = (const float*)d->w_packed;
     p.n_tiles = (d->Cout + bn - 1) / bn;
     p.CoutPad = p.n_tiles * bn;
+    {
+      const int64_t wb = (int64_t)p.KT * p.CoutPad * rb;
+      p.w_bytes = (dma_ok && wb < (int64_t)0xFFFFFFF0) ? (unsigned)wb : 0u;
+    }
     p.m_tiles = (p.M + bm - 1) / bm;
     p.splitk = 1;
     const char* ev = getenv("HRV_CONV_SPLITK");   // 0 disables, N forces (A/B measurements)
@@ -809,8 +987,25 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
     var &= ~1;  // scalar epilogue for odd channel counts / unaligned slices
   }
   if (p.bf16) {
-    if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+    if constexpr (RB == 128 && (32 * TN * WN * 8) % 256 == 0) {
+      // 128-byte rows: LDS-DMA staging is the default for the 64-column tile (440-580 vs 350-370 TFLOP/s
+      // register-staged); the 128x128 tile measures the same either way (~470-505: both are bound by
+      // moving 32 KB per K-tile through the CU's texture path) and keeps the register pipeline.
+      // HRV_CONV_GLDS=0/1 forces it off/on (A/B measurements: profiles/r01_conv_bench_bf16_glds.txt).
+      const char* eg = getenv("HRV_CONV_GLDS");
+      const bool want = eg ? atoi(eg) != 0 : (32 * TN * WN == 64);
+      const bool glds = want && p.w_bytes != 0;
+      if (glds) {
+        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 5, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 4, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+      } else {
+        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+      }
+    } else {
+      if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+    }
   } else if constexpr (RB != 64) {
     set_error("conv2d: 128-byte K-tile rows exist on the bf16 engine only");
     return HRV_ERR_ARG;

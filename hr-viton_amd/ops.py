@@ -260,8 +260,10 @@ class ConvLayer:
         naive = os.environ.get("HRV_CONV_IMPL", "mfma") == "naive"
         if cfg is None:
             cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, self.Cout)
-            if self.bf16 and cfg == 0:
-                cfg = 8   # 128x128 tile with 128-byte K-tile rows: +15-20 % on MI355X (profiles/r01_conv_bench_bf16_rb.txt)
+            if self.bf16 and cfg in (0, 6):
+                # 128-byte K-tile rows: 128x128 tile +15-20 % (profiles/r01_conv_bench_bf16_rb.txt); the 128x64 tile
+                # additionally stages its operands by LDS-DMA (profiles/r01_conv_bench_bf16_glds.txt)
+                cfg = 8 if cfg == 0 else 9
         forced = os.environ.get("HRV_CONV_TILE") if spade is None else None
         if forced is not None:
             cfg = int(forced)
@@ -396,7 +398,7 @@ class SpadeModulate:
         self.conv = ConvLayer(w, [hid], device, shift=b, stride=1, pad=k // 2, act=act, name=name, bf16=bf16)
         self.conv.flops_cout = 2 * self.Creal   # algorithmic (unpadded) gamma+beta columns
         # 128x128 tile when the pair count is even (bf16: the 128-byte-row variant), else 128x64
-        self.cfg = (8 if bf16 else 0) if (G % 2 == 0) else 6
+        self.cfg = (8 if bf16 else 0) if (G % 2 == 0) else (9 if bf16 else 6)
         ns = torch.zeros(self.Cp)
         ns[: self.Creal] = noise_scale.detach().cpu().float()
         self.ns = ns.to(device)
