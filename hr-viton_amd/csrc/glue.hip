@@ -130,6 +130,35 @@ __global__ void resize_planes_kernel(const float* __restrict__ in, int planes, i
   }
 }
 
+
+// ---------------------------------------------------------------------------
+// Tap expansion (im2col of a narrow tensor): out[n,h,w, t*G + g] = 16-byte group g of the source pixel under
+// tap t = kh*KW + kw of a stride-1 'same' KHxKW window (zero outside), with the conv engine's nearest
+// down-sampling of the source folded in.  Turns the 7(8)-channel conv_shared 3x3 of every SPADENorm
+// (network_generator.py:97,113) into a 1x1 convolution over 72 dense channels: the label map is expanded
+// once per resolution and shared by the block's two or three norms.  Element-size agnostic (16-byte groups).
+// ---------------------------------------------------------------------------
+__global__ void tap_expand_kernel(const uint4* __restrict__ src, int N, int H, int W, int G, int scs16, int sco16,
+                                  int down, int KH, int KW, int pad, uint4* __restrict__ out) {
+  const int taps = KH * KW;
+  const size_t total = (size_t)N * H * W * taps * G;
+  const int Hs = H << down, Ws = W << down;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % G);
+    size_t t = i / G;
+    const int tap = (int)(t % taps);
+    const size_t pix = t / taps;
+    const int w = (int)(pix % W);
+    const size_t t2 = pix / W;
+    const int h = (int)(t2 % H);
+    const int n = (int)(t2 / H);
+    const int hh = h + tap / KW - pad, ww = w + tap % KW - pad;
+    uint4 v = make_uint4(0u, 0u, 0u, 0u);
+    if (hh >= 0 && hh < H && ww >= 0 && ww < W)
+      v = src[((size_t)(n * Hs + (hh << down)) * Ws + (ww << down)) * scs16 + sco16 + g];
+    out[i] = v;
+  }
+}
 }  // namespace hrv
 
 using namespace hrv;
@@ -187,4 +216,18 @@ extern "C" int hrv_resize_nchw_f32(const float* in, int32_t planes, int32_t H, i
   hipLaunchKernelGGL(resize_planes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, planes, H, W,
                      Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo, nearest, out);
   return check_launch("resize_planes_kernel");
+}
+
+extern "C" int hrv_tap_expand_nhwc(const void* src, int32_t N, int32_t H, int32_t W, int32_t group16_per_pixel,
+                                   int32_t src_stride16, int32_t src_off16, int32_t down_shift, int32_t KH, int32_t KW,
+                                   int32_t pad, void* out, hrv_stream_t stream) {
+  HRV_REQUIRE(src && out && N > 0 && H > 0 && W > 0 && group16_per_pixel > 0 && src_stride16 >= src_off16 + group16_per_pixel,
+              "tap_expand: bad args");
+  HRV_REQUIRE(KH > 0 && KW > 0 && KH == 2 * pad + 1 && KW == 2 * pad + 1 && down_shift >= 0 && down_shift <= 7,
+              "tap_expand: 'same' stride-1 window, down_shift in [0,7]");
+  HRV_REQUIRE((((uintptr_t)src | (uintptr_t)out) & 15) == 0, "tap_expand: 16-byte alignment");
+  const size_t total = (size_t)N * H * W * KH * KW * group16_per_pixel;
+  hipLaunchKernelGGL(tap_expand_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)src, N, H, W,
+                     group16_per_pixel, src_stride16, src_off16, down_shift, KH, KW, pad, (uint4*)out);
+  return check_launch("tap_expand_kernel");
 }

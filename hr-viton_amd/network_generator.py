@@ -148,16 +148,32 @@ class _SpadePlan:
     def __init__(self, norm: SPADENorm, device, act: int, name: str, bf16: bool = False):
         cs = norm.conv_shared[0]
         self.label_nc = cs.in_channels
-        self.shared = ConvLayer(cs.weight, [self.label_nc], device, shift=cs.bias, pad=1, act=ACT_RELU,
-                                name=name + ".conv_shared", bf16=bf16)
+        self.cs = cs      # conv_shared parameters: the owning block batches its norms' 3x3s into one 1x1 (see _BlockPlan)
         self.mod = SpadeModulate(norm.conv_gamma.weight, norm.conv_gamma.bias, norm.conv_beta.weight,
                                  norm.conv_beta.bias, norm.noise_scale, device, act, name + ".conv_gamma|beta", bf16=bf16)
 
-    def __call__(self, x: Act, seg: Act, seg_shift: int, z: Optional[torch.Tensor]) -> Act:
+    def __call__(self, x: Act, actv: Act, z: Optional[torch.Tensor]) -> Act:
         zz = z if (z is not None and self.mod.has_noise) else None
         mean, rstd = ops.instnorm_stats(x, zz, self.mod.ns if zz is not None else None)
-        actv = self.shared([(seg, -seg_shift, ACT_NONE)])
         return self.mod(actv, x, mean, rstd, zz)
+
+
+def _shared_1x1(norms, device, name: str, bf16: bool) -> ConvLayer:
+    """The conv_shared 3x3s (label_nc -> 128, + ReLU) of a block's norms as ONE 1x1 convolution over the
+    tap-expanded label map (ops.tap_expand: 9 taps x 8 padded channels = 72 dense inputs): the label map is
+    read once per block instead of 9 x (2 or 3) times, and no K-tile is 7/8 padding."""
+    ws, bs = [], []
+    for n_ in norms:
+        w = n_.cs.weight.detach().to("cpu", torch.float32)          # [128, C, 3, 3]
+        co, c, kh, kw = w.shape
+        cp = (c + 7) // 8 * 8 if bf16 else (c + 3) // 4 * 4
+        wt = torch.zeros(co, kh * kw, cp)
+        wt[:, :, :c] = w.permute(0, 2, 3, 1).reshape(co, kh * kw, c)   # tap-major, channel-minor (matches tap_expand)
+        ws.append(wt.reshape(co, kh * kw * cp, 1, 1))
+        bs.append(n_.cs.bias.detach().to("cpu", torch.float32))
+    w1 = torch.cat(ws, 0)
+    return ConvLayer(w1, [w1.shape[1]], device, shift=torch.cat(bs, 0), pad=0, act=ACT_RELU,
+                     name=name + ".conv_shared[x%d as 1x1 over taps]" % len(norms), bf16=bf16)
 
 
 class _BlockPlan:
@@ -180,6 +196,9 @@ class _BlockPlan:
             self.cs = ConvLayer(_raw_weight(blk.conv_s), [blk.input_nc], device,
                                 scale=torch.full((blk.output_nc,), 1.0 / ss), pad=0, name=name + ".conv_s", bf16=bf16,
                                 out_f32=True)
+        self.norms = ([self.ns_] if self.learned else []) + [self.n0, self.n1]
+        self.shared = _shared_1x1(self.norms, device, name, bf16)
+        self.nh = blk.norm_0.conv_shared[0].out_channels
 
     def conv1(self, act: int) -> ConvLayer:
         if act not in self._c1:
@@ -195,12 +214,16 @@ class _BlockPlan:
         """x_s + conv_1(lrelu(norm_1(conv_0(lrelu(norm_0(x)))))) -- network_generator.py:163-173.
         ``zs``: noise draws in the reference's call order (norm_s, norm_0, norm_1)."""
         zi = iter(zs)
+        # every norm of the block sees the same nearest-resized label map (network_generator.py:112-113)
+        actv_all = self.shared([ops.tap_expand(seg, seg_shift, 3)])
+        actv = [actv_all.slice(i * self.nh, self.nh) for i in range(len(self.norms))]
+        ai = iter(actv)
         if self.learned:
-            x_s = self.cs([self.ns_(x, seg, seg_shift, next(zi))])
+            x_s = self.cs([self.ns_(x, next(ai), next(zi))])
         else:
             x_s = x
-        dx = self.c0([self.n0(x, seg, seg_shift, next(zi))])
-        h1 = self.n1(dx, seg, seg_shift, next(zi))
+        dx = self.c0([self.n0(x, next(ai), next(zi))])
+        h1 = self.n1(dx, next(ai), next(zi))
         return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
 
 

@@ -421,6 +421,21 @@ class SpadeModulate:
         return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=self.cfg)
 
 
+def tap_expand(a: Act, down: int, k: int = 3) -> Act:
+    """hrv_tap_expand_nhwc: [N,Hs,Ws,C] (Hs = H << down) -> [N,H,W,k*k*Cp], tap-major (t*Cp + c), zero borders."""
+    lib = _lib.load()
+    es = 2 if a.bf16 else 4
+    Cp = a.Cp
+    assert (Cp * es) % 16 == 0 and (a.cstride * es) % 16 == 0 and (a.coff * es) % 16 == 0
+    H, W = a.H >> down, a.W >> down
+    out = torch.empty((a.N, H, W, k * k * Cp), dtype=a.t.dtype, device=a.t.device)
+    with _Timed("glue", "tap_expand", 0.0, float(out.numel() * es) * 1.2):
+        _lib.check(lib.hrv_tap_expand_nhwc(a.t.data_ptr(), a.N, H, W, Cp * es // 16, a.cstride * es // 16,
+                                           a.coff * es // 16, down, k, k, k // 2, out.data_ptr(), _stream()),
+                   "hrv_tap_expand_nhwc")
+    return Act(out, k * k * Cp)
+
+
 def resize_bilinear(a: Act, Ho: int, Wo: int, rh: float, rw: float, addend: Optional[Act] = None,
                     out: Optional[Act] = None) -> Act:
     """hrv_resize_bilinear_nhwc_f32: out = bilinear(a) (+ addend)."""

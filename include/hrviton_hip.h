@@ -384,6 +384,15 @@ typedef struct hrv_flow_warp {
 } hrv_flow_warp_t;
 int hrv_flow_warp_nhwc_f32(const hrv_flow_warp_t* d, hrv_stream_t stream);
 
+/* Tap expansion of a narrow NHWC tensor (im2col in 16-byte groups): out[n,h,w, t*G + g] = group g of the
+ * source pixel under tap t of a stride-1 'same' KHxKW window (zero outside the image); the source may be
+ * 2^down_shift larger (nearest down-sampling, F.interpolate(segmap, 'nearest'), network_generator.py:112).
+ * With it the 7-channel conv_shared 3x3 of every SPADENorm (network_generator.py:97,113) runs as a 1x1
+ * convolution over KH*KW*G*16 dense bytes per pixel.  Strides / offsets in 16-byte units; any element type. */
+int hrv_tap_expand_nhwc(const void* src, int32_t N, int32_t H, int32_t W, int32_t group16_per_pixel,
+                        int32_t src_stride16, int32_t src_off16, int32_t down_shift, int32_t KH, int32_t KW,
+                        int32_t pad, void* out, hrv_stream_t stream);
+
 /* ------------------------------------------------------------------------
  * Training of the condition generator (train_condition.py:113-286, tocg.train()).
  *
