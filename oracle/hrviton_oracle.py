@@ -630,3 +630,28 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
     return {"loss_G": loss_G, "loss_D": loss_D, "l1": loss_l1, "vgg": loss_vgg, "tv": loss_tv, "ce": ce,
             "g_gan": loss_g_gan, "d_fake": loss_d_fake, "d_real": loss_d_real, "flow_list": flow_list,
             "fake_segmap": seg_raw, "warped_c": warped_c, "warped_cm": warped_cm, "bn_stats": dict(BN_TRAIN["stats"])}
+
+
+def d_logit(pred: List[List[Tensor]]) -> Tensor:
+    """D_logit -- get_norm_const.py:60-64 (identical in test_condition.py)."""
+    score = 0
+    for p in pred:
+        score = score + p[-1].mean((1, 2, 3)) / 2
+    return score
+
+
+def rejection_logits(sd_g: SD, sd_d: SD, batch: Dict[str, Tensor], composition: str = "warp_grad",
+                     Ddownx2: bool = True, num_D: int = 2):
+    """get_norm_const.py:86-118 / test_condition.py:98-121 with tocg and D in eval mode:
+    (logit_real, logit_fake, composed fake_segmap)."""
+    input1 = torch.cat([batch["cloth"], batch["cloth_mask"]], 1)
+    input2 = torch.cat([batch["parse_agnostic"], batch["densepose"]], 1)
+    flow_list, fake_segmap, warped_c, warped_cm = tocg_forward(sd_g, input1, input2)
+    if composition != "no_composition":
+        mask = torch.ones_like(fake_segmap)
+        mask[:, 3:4] = (warped_cm > 0.5).float() if composition == "detach" else warped_cm
+        fake_segmap = fake_segmap * mask
+    soft = F.softmax(fake_segmap, dim=1)
+    real = tocg_discriminator_forward(sd_d, torch.cat((input1, input2, batch["parse"]), 1), num_D, 3, Ddownx2)
+    fake = tocg_discriminator_forward(sd_d, torch.cat((input1, input2, soft), 1), num_D, 3, Ddownx2)
+    return d_logit(real), d_logit(fake), fake_segmap

@@ -334,3 +334,29 @@ def test_condition_generator_train_mode_no_grad_and_eval_agree_with_oracle():
     _close("seg", gseg, seg, 1e-4)
     _close("warped_c", gwc, wc, 5e-4)
     _close("warped_cm", gwcm, wcm, 5e-4)
+
+
+def test_rejection_flow_matches_oracle():
+    """get_norm_const.py / test_condition.py: eval-mode tocg + D logits, odds, rejection score, misalign mask."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import networks, rejection
+    from oracle.recipes import condstep_build
+    opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D)
+    opt.clothmask_composition = "warp_grad"
+    sd_g = {k: v.detach().clone() for k, v in tocg.state_dict().items()}
+    sd_d = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    with torch.no_grad():
+        lr, lf, seg = O.rejection_logits(sd_g, sd_d, batch)
+    tocg.cuda().eval()
+    D.cuda().eval()
+    cb = {k: v.cuda() for k, v in batch.items()}
+    glr, glf = rejection.segmap_logits(opt, tocg, D, cb)
+    _close("logit_real", glr, lr, 1e-4)
+    _close("logit_fake", glf, lf, 1e-4)
+    want_const = max((l / (1 - l)) for l in torch.cat([lr, lf]).tolist())
+    got_const = rejection.get_const(opt, [cb], tocg, D)
+    assert abs(got_const - want_const) < 1e-3 * max(1.0, abs(want_const))
+    score, misalign, gseg, _, wcm1 = rejection.rejection_scores(opt, tocg, D, cb, got_const)
+    _close("score", score, (lf / (1 - lf)) / want_const, 1e-3)
+    _close("fake_segmap", gseg, seg, 1e-4)
+    assert misalign.shape == (2, 1, 128, 96) and misalign.min() >= 0
