@@ -77,11 +77,16 @@ def main(argv=None):
         load_checkpoint(tocg, opt.tocg_checkpoint, opt)
     tocg.to(dev)
     D.to(dev)
-    if not opt.synthetic:
-        raise SystemExit("no dataset code in this image: pass --synthetic (or put the reference's cp_dataset.py + "
-                         "torchvision on PYTHONPATH and extend main())")
-    length = opt.length or 4 * opt.batch_size
-    batches = (synthetic_batch(opt, opt.batch_size, 777 + i, dev) for i in range(length // opt.batch_size))
+    if opt.synthetic:
+        length = opt.length or 4 * opt.batch_size
+        batches = (synthetic_batch(opt, opt.batch_size, 777 + i, dev) for i in range(length // opt.batch_size))
+    else:
+        from hr_viton_amd.cp_dataset import CPDataLoader, CPDataset
+        from train_condition import disk_batch
+        ds = CPDataset(opt)
+        loader = CPDataLoader(opt, ds)
+        length = opt.length or len(ds)
+        batches = (disk_batch(loader.next_batch(), dev) for _ in range(length // opt.batch_size))
     print(get_const(opt, batches, tocg, D))
 
 

@@ -302,9 +302,72 @@ def condstep():
                                        "l1": loss_l1.item(), "gan": g_gan.item()}.items()})
 
 
+def dataset():
+    """One sample of the REAL reference CPDatasetTest (cp_dataset_test.py) on the synthetic on-disk data set
+    (hr_viton_amd.cp_dataset.write_synthetic_dataset, seed 0).  torchvision is absent: its three transforms are
+    supplied by a stub module built from the product's restatements (so THOSE are not pinned by this golden --
+    the label merging, the agnostic-person drawing, the mask threshold and the dictionary layout are)."""
+    import tempfile
+    import torch
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import cp_dataset as P
+    tvt = types.ModuleType("torchvision.transforms")
+
+    class Compose:
+        def __init__(self, ts):
+            self.ts = ts
+
+        def __call__(self, x):
+            for t in self.ts:
+                x = t(x)
+            return x
+
+    class ToTensor:
+        def __call__(self, img):
+            import numpy as np
+            a = np.asarray(img)
+            a = a[:, :, None] if a.ndim == 2 else a
+            return torch.from_numpy(a.transpose(2, 0, 1).copy()).float().div(255)
+
+    class Normalize:
+        def __init__(self, m, s):
+            self.m, self.s = torch.tensor(m).view(-1, 1, 1), torch.tensor(s).view(-1, 1, 1)
+
+        def __call__(self, t):
+            return (t - self.m) / self.s
+
+    class Resize:
+        def __init__(self, size, interpolation=2):
+            self.size, self.interp = size, interpolation
+
+        def __call__(self, img):
+            return P.resize_to_width(img, self.size, self.interp)
+
+    tvt.Compose, tvt.ToTensor, tvt.Normalize, tvt.Resize = Compose, ToTensor, Normalize, Resize
+    tv = sys.modules.setdefault("torchvision", types.ModuleType("torchvision"))
+    tv.transforms = tvt
+    sys.modules["torchvision.transforms"] = tvt
+    _import_reference()
+    sys.path.insert(0, REF)
+    import cp_dataset_test as ref_ds  # noqa
+    sys.path.pop(0)
+    with tempfile.TemporaryDirectory() as root:
+        P.write_synthetic_dataset(root, n=2, seed=0)
+        opt = Namespace(dataroot=root, datamode="test", data_list="test_pairs.txt", fine_height=64, fine_width=48,
+                        semantic_nc=13)
+        item = ref_ds.CPDatasetTest(opt)[1]
+    keep = {k: (v if not isinstance(v, dict) else dict(v)) for k, v in item.items()}
+    torch.save({"recipe": "hr_viton_amd.cp_dataset.write_synthetic_dataset(root, n=2, seed=0); CPDatasetTest(opt)[1], "
+                          "fine 64x48", "item": keep}, os.path.join(OUT, "cpdataset_item1_64x48.pt"))
+    print("cpdataset_item1_64x48.pt", os.path.getsize(os.path.join(OUT, "cpdataset_item1_64x48.pt")) // 1024, "KiB")
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "condstep":
         condstep()
+    elif len(sys.argv) > 1 and sys.argv[1] == "dataset":
+        dataset()
     else:
         main()
         condstep()
+        dataset()

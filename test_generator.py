@@ -135,11 +135,8 @@ def main(argv=None):
     if opt.synthetic > 0:
         batches = synthetic_batches(opt, opt.synthetic)
     else:
-        try:
-            from cp_dataset_test import CPDatasetTest, CPDataLoader  # the reference's dataset code, on PYTHONPATH
-        except Exception as e:  # noqa: BLE001
-            raise SystemExit("no dataset code available (%s): put the reference's cp_dataset_test.py (and torchvision) on "
-                             "PYTHONPATH, or pass --synthetic N" % e)
+        # the reference's on-disk VITON-HD layout through the torchvision-free pipeline (hr_viton_amd.cp_dataset)
+        from hr_viton_amd.cp_dataset import CPDataLoader, CPDatasetTest
         batches = CPDataLoader(opt, CPDatasetTest(opt)).data_loader
     tocg = ConditionGenerator(opt, input1_nc=4, input2_nc=opt.semantic_nc + 3, output_nc=opt.output_nc,
                               ngf=opt.tocg_ngf, norm_layer=nn.BatchNorm2d)

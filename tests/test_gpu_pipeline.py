@@ -123,3 +123,34 @@ def test_tryon_step_end_to_end_vs_oracle():
     # a flipped label changes the SPADE input locally; everything else must agree closely
     assert (err > 1e-3).float().mean().item() < 1e-3, f"{(err > 1e-3).float().mean().item()} of output pixels off by >1e-3"
     assert err.median() < 1e-5
+
+
+def test_entry_scripts_on_disk_dataset(tmp_path):
+    """BASELINE configs[0] plumbing on the HIP path: test_generator.py over a synthetic VITON-HD-layout data set
+    on disk (256x192, 'more', batch 1, random-init tocg + generator, 4 pairs) through the torchvision-free
+    pipeline, then two train_condition.py iterations on the same tree; the outputs are JPEG bytes under .png names
+    (utils.py:93-109)."""
+    import sys
+    from PIL import Image
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.cp_dataset import write_synthetic_dataset
+    import test_generator as tg
+    import train_condition as tc
+    root = str(tmp_path / "data")
+    write_synthetic_dataset(root, n=4, seed=1)
+    write_synthetic_dataset(root, n=4, datamode="train", list_name="train_pairs.txt", seed=2)
+    out = str(tmp_path / "out")
+    torch.manual_seed(0)
+    tg.main(["--dataroot", root, "--datamode", "test", "--data_list", "test_pairs.txt", "--fine_height", "256",
+             "--fine_width", "192", "--num_upsampling_layers", "more", "-b", "1", "-j", "0", "--random_init_tocg",
+             "--gen_checkpoint", "", "--tocg_ngf", "16", "--ngf", "8", "--output_dir", out, "--datasetting", "unpaired"])
+    files = sorted(f for f in __import__("os").listdir(out))
+    assert len(files) == 4 and all(f.endswith(".png") for f in files), files
+    im = Image.open(__import__("os").path.join(out, files[0]))
+    assert im.format == "JPEG" and im.size == (192, 256)
+    ck = str(tmp_path / "ck")
+    tc.main(["--dataroot", root, "--datamode", "train", "--data_list", "train_pairs.txt", "-b", "2", "-j", "0",
+             "--Ddownx2", "--lasttvonly", "--interflowloss", "--max_steps", "2", "--display_count", "1", "--ngf", "8",
+             "--checkpoint_dir", ck, "--name", "t", "--shuffle"])
+    sd = torch.load(__import__("os").path.join(ck, "t", "tocg_final.pth"), map_location="cpu")
+    assert "ClothEncoder.0.block.1.running_mean" in sd and int(sd["out_layer.block.1.num_batches_tracked"]) == 2

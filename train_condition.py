@@ -116,6 +116,24 @@ def synthetic_batch(opt, n, seed, device):
     return {k: v.to(device) for k, v in b.items()}
 
 
+def _rank_loader(opt, per_rank, rank, world):
+    """CPDataset over the reference's on-disk layout; every rank draws its own shuffled stream of per_rank samples."""
+    import copy
+    from hr_viton_amd.cp_dataset import CPDataLoader, CPDataset
+    o = copy.copy(opt)
+    o.batch_size = per_rank
+    torch.manual_seed(hdist.shard_seed(97, rank))     # the sampler's permutation differs per rank
+    return CPDataLoader(o, CPDataset(o))
+
+
+def disk_batch(inputs, device):
+    """cp_dataset.py batch -> the flat dictionary condition_train_step takes (train_condition.py:136-153)."""
+    return {"cloth": inputs["cloth"]["paired"].to(device), "cloth_mask": inputs["cloth_mask"]["paired"].to(device),
+            "parse_agnostic": inputs["parse_agnostic"].to(device), "densepose": inputs["densepose"].to(device),
+            "parse_onehot": inputs["parse_onehot"].to(device), "parse": inputs["parse"].to(device),
+            "pcm": inputs["pcm"].to(device), "parse_cloth": inputs["parse_cloth"].to(device)}
+
+
 def main(argv=None):
     opt = get_opt(argv)
     rank, local_rank, world = hdist.init_from_env()
@@ -152,18 +170,21 @@ def main(argv=None):
             attach_grad_sync(s)
     opt_g = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999), grad_sync=sync_g)
     opt_d = Adam(D.parameters(), lr=opt.D_lr, betas=(0.5, 0.999), grad_sync=sync_d)
+    loader = None
     if not opt.synthetic:
-        raise SystemExit("no dataset code in this image: pass --synthetic (or put the reference's cp_dataset.py + "
-                         "torchvision on PYTHONPATH and extend main())")
+        loader = _rank_loader(opt, per_rank, rank, world)
     last = opt.keep_step if not opt.max_steps else min(opt.keep_step, opt.load_step + opt.max_steps)
     for step in range(opt.load_step, last):
         t0 = time.time()
-        batch = synthetic_batch(opt, per_rank, hdist.shard_seed(4321 + step * 89, rank), dev)
+        if loader is None:
+            batch = synthetic_batch(opt, per_rank, hdist.shard_seed(4321 + step * 89, rank), dev)
+        else:
+            batch = disk_batch(loader.next_batch(), dev)
         losses = condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d, batch, sync_g, sync_d)
         if (step + 1) % opt.display_count == 0 and rank == 0:
             torch.cuda.synchronize()
             t = time.time() - t0
-            f = lambda k: float(losses[k]) if k in losses else 0.0  # noqa: E731
+            f = lambda k: float(losses[k].detach()) if k in losses and torch.is_tensor(losses[k]) else float(losses.get(k, 0.0))  # noqa: E731
             print("step: %8d, time: %.3f\nloss G: %.4f, L1_cloth loss: %.4f, VGG loss: %.4f, TV loss: %.4f CE: %.4f, "
                   "G GAN: %.4f\nloss D: %.4f, D real: %.4f, D fake: %.4f"
                   % (step + 1, t, f("loss_G"), f("l1"), f("vgg"), f("tv"), f("ce"), f("g_gan"), f("loss_D"), f("d_real"),

@@ -165,15 +165,26 @@ def main(argv=None):
     sched_g = torch.optim.lr_scheduler.LambdaLR(opt_g, lr_lambda=lam)
     sched_d = torch.optim.lr_scheduler.LambdaLR(opt_d, lr_lambda=lam)
 
+    loader = None
     if not opt.synthetic:
-        raise SystemExit("no dataset code in this image: pass --synthetic (or put the reference's cp_dataset.py + "
-                         "torchvision on PYTHONPATH and extend main())")
+        import copy
+        from hr_viton_amd.cp_dataset import CPDataLoader, CPDataset
+        o = copy.copy(opt)
+        o.batch_size = per_rank
+        torch.manual_seed(hdist.shard_seed(97, rank))
+        loader = CPDataLoader(o, CPDataset(o))
     last = opt.keep_step + opt.decay_step
     if opt.max_steps:
         last = min(last, opt.load_step + opt.max_steps)
     for step in range(opt.load_step, last):
         t0 = time.time()
-        batch = synthetic_batch(opt, per_rank, hdist.shard_seed(1234 + step * 97, rank), dev)
+        if loader is None:
+            batch = synthetic_batch(opt, per_rank, hdist.shard_seed(1234 + step * 97, rank), dev)
+        else:
+            raw = loader.next_batch()                                  # train_generator.py:194-212
+            batch = {"cloth": raw["cloth"]["paired"].to(dev), "cloth_mask": raw["cloth_mask"]["paired"].to(dev),
+                     "parse_agnostic": raw["parse_agnostic"].to(dev), "densepose": raw["densepose"].to(dev),
+                     "agnostic": raw["agnostic"].to(dev), "image": raw["image"].to(dev)}
         x, parse7 = make_generator_inputs(opt, tocg, batch)
         losses, _ = generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, crit_vgg, opt_g, opt_d, x,
                                          parse7, batch["image"], sync_g, sync_d)
