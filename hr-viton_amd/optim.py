@@ -62,3 +62,42 @@ class Adam(torch.optim.Optimizer):
                         st["step"], world_scale)
         ops.WEIGHTS_EPOCH[0] += 1      # cached inference plans (packed weights) are stale now
         return loss
+
+    # ------------------------------------------------------------------ (de)serialisation
+    def state_dict(self):
+        """torch.optim.Adam-compatible state_dict: per-parameter ``step`` / ``exp_avg`` / ``exp_avg_sq`` cut out
+        of the flat moment buffers (an extension: the reference saves weights only)."""
+        state, groups, idx = {}, [], 0
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi)
+            spans = {id(p): (off, k) for p, off, k in st["spans"]} if st else {}
+            ids = []
+            for p in group["params"]:
+                if st and id(p) in spans:
+                    off, k = spans[id(p)]
+                    state[idx] = {"step": torch.tensor(float(st["step"])),
+                                  "exp_avg": st["m"][off:off + k].view_as(p).clone(),
+                                  "exp_avg_sq": st["v"][off:off + k].view_as(p).clone()}
+                ids.append(idx)
+                idx += 1
+            g = {k: v for k, v in group.items() if k != "params"}
+            g["params"] = ids
+            groups.append(g)
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        idx = 0
+        for gi, (group, saved) in enumerate(zip(self.param_groups, sd["param_groups"])):
+            for k, v in saved.items():
+                if k != "params":
+                    group[k] = tuple(v) if k == "betas" else v
+            st = self._flat.get(gi) or self._setup(gi, group)
+            spans = {id(p): (off, k) for p, off, k in st["spans"]}
+            for p in group["params"]:
+                ent = sd["state"].get(idx)
+                if ent is not None and id(p) in spans:
+                    off, k = spans[id(p)]
+                    st["m"][off:off + k].copy_(ent["exp_avg"].reshape(-1).to(st["m"].device))
+                    st["v"][off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(st["v"].device))
+                    st["step"] = int(ent["step"])
+                idx += 1

@@ -230,8 +230,10 @@ def _vgg_pair(seed=5):
     return crit, sd
 
 
-@pytest.mark.parametrize("with_vgg", [False, True], ids=["novgg", "vgg"])
-def test_condition_training_iteration_matches_oracle(with_vgg):
+@pytest.mark.parametrize("with_vgg,comp,occl", [(False, "warp_grad", False), (True, "warp_grad", False),
+                                                (False, "detach", True), (False, "no_composition", False)],
+                         ids=["novgg", "vgg", "detach_occlusion", "no_composition"])
+def test_condition_training_iteration_matches_oracle(with_vgg, comp, occl):
     """train_condition.py:136-286 (--Ddownx2 --lasttvonly --interflowloss) on the HIP path vs the oracle:
     the eight loss terms, every tocg / D parameter gradient, running statistics, one Adam update."""
     import hr_viton_amd  # noqa: F401
@@ -240,13 +242,13 @@ def test_condition_training_iteration_matches_oracle(with_vgg):
     from hr_viton_amd.optim import Adam
     from oracle.recipes import condstep_build
     opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D)
-    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, True, False, "warp_grad"
+    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, True, occl, comp
     opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
     crit_vgg, sd_vgg = _vgg_pair() if with_vgg else (None, None)
     sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k)
             for k, v in tocg.state_dict().items()}
     sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
-    r = O.condition_train_losses(sd_g, sd_d, sd_vgg, batch)
+    r = O.condition_train_losses(sd_g, sd_d, sd_vgg, batch, occlusion=occl, composition=comp)
     r["loss_G"].backward(retain_graph=True)
     g_grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in sd_g.items()}
     for v in sd_d.values():
@@ -278,7 +280,7 @@ def test_condition_training_iteration_matches_oracle(with_vgg):
     losses = pipeline.condition_train_step(opt, tocg, D, L1Loss(), crit_vgg, networks.GANLoss(use_lsgan=True), opt_g,
                                            opt_d, cb)
     for k in ("l1", "vgg", "tv", "ce", "g_gan", "loss_G", "d_fake", "d_real", "loss_D"):
-        want, got = float(r[k]), float(losses[k])
+        want, got = float(r[k].detach()), float(losses[k].detach())
         assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (k, got, want)
 
     class _G:   # adapters: _compare_grads walks named_parameters() and reads .grad
@@ -295,9 +297,9 @@ def test_condition_training_iteration_matches_oracle(with_vgg):
 
     # sign() of the L1 terms and floor() flips of the warps make G's gradients noisy: 5e-3 scale-aware (measured 4.6e-4)
     _compare_grads(_G(tocg, grads_g), {k: _W(g_grads[k]) for k in sd_g}, 5e-3,
-                   "tocg_vgg step" if with_vgg else "tocg step")
+                   ("tocg_vgg step" if with_vgg else "tocg step") if comp == "warp_grad" else f"tocg_{comp} step")
     _compare_grads(_G(D, grads_d), {k: _W(v.grad) for k, v in sd_d.items()}, 5e-4,
-                   "tocgD_vgg step" if with_vgg else "tocgD step")
+                   ("tocgD_vgg step" if with_vgg else "tocgD step") if comp == "warp_grad" else f"tocgD_{comp} step")
     # running statistics: momentum 0.1 on the oracle's recorded batch statistics
     mean, var_unb = r["bn_stats"]["ClothEncoder.0.block.1"]
     _close("running_mean", tocg.ClothEncoder[0].block[1].running_mean, 0.9 * rm_before + 0.1 * mean, 1e-5)
