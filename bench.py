@@ -61,6 +61,8 @@ def build_model(torch, nn):
 
 
 def _emit(args, torch, hdist, ops, rank, world, B, step, metric, workload, flops_per_img, train):
+    mixed = bool(getattr(args, "bf16", False))
+    peak = 2500.0 if mixed else PEAK_F32_MFMA_TFLOPS
     dt = hdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
     ops.profile_begin()
     step(0)
@@ -81,12 +83,13 @@ def _emit(args, torch, hdist, ops, rank, world, B, step, metric, workload, flops
         ach = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
         line = {"metric": metric, "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "bf16 MFMA operands, f32 storage/accumulate" if mixed else "f32", "data": "synthetic",
                 "config": {"workload": workload, "global_batch": B * world,
                            "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
                 "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
-                             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
+                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                             "frac": round(ach / peak, 4), "traffic": None,
                              "end_to_end_TFLOPs_vs_survey_work": round(B * flops_per_img / (dt / args.steps) / 1e12, 2)},
                 "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(kinds.items())},
                 "cpu_baseline": None}
@@ -108,7 +111,10 @@ def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.pipeline import condition_train_step
     B = args.batch or 8
     opt = tc.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world), "--fine_height", "1024", "--fine_width",
-                      "768", "--Ddownx2", "--lasttvonly", "--interflowloss"])
+                      "768", "--Ddownx2", "--lasttvonly", "--interflowloss"] + (["--fp16"] if args.bf16 else []))
+    if args.bf16:
+        from hr_viton_amd import train_ops as _T
+        _T.MMA_BF16[0] = True
     torch.manual_seed(0)
     tocg = ConditionGenerator(opt, 4, 16, 13, ngf=96, norm_layer=nn.BatchNorm2d).to(dev).train()
     D = define_D(input_nc=4 + 16 + 13, Ddownx2=True, Ddropout=False, n_layers_D=3, spectral=False, num_D=2).to(dev).train()
@@ -157,6 +163,9 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     gen.to(dev)
     batch = tg.synthetic_batch(opt, B, hdist.shard_seed(1234, rank), dev)
     if train:
+        if args.bf16:
+            from hr_viton_amd import train_ops as _T
+            _T.MMA_BF16[0] = True      # mixed precision: bf16 matrix cores over fp32 tensors
         dis = MultiscaleDiscriminator(opt)
         dis.init_weights("xavier", 0.02)
         dis.to(dev).train()
@@ -185,41 +194,12 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
             tryon_step(opt, tocg, gen, batch)
         metric = "1024x768 try-on images/sec (test_generator.py step: tocg@256x192 + glue + SPADE generator)"
         flops_per_img = 1.73e12
-    dt = hdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
-    ops.profile_begin()
-    step(0)
-    recs = ops.profile_end()
-    kinds = {}
-    for k, n, fl, by, ms in recs:
-        a = kinds.setdefault(k, [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += ms
-        a[2] += fl
-    if args.dump_launches and rank == 0:
-        with open(args.dump_launches, "w") as f:
-            for k, n, fl, by, ms in recs:
-                f.write(f"{k:8s} {n:52s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s\n")
-    mf_ms = sum(v[1] for k, v in kinds.items() if k in ("conv", "wgrad"))
-    mf_fl = sum(v[2] for k, v in kinds.items() if k in ("conv", "wgrad"))
-    if rank == 0:
-        ach = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        line = {"metric": metric, "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16 (generator; tocg+glue f32)" if args.bf16 else "f32", "data": "synthetic",
-                "config": {"workload": args.workload + " 1024x768 ngf=64, random-init weights", "global_batch": B * world,
-                           "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
-                "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
-                             "achieved": round(ach, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                             "frac": round(ach / PEAK_F32_MFMA_TFLOPS, 4), "traffic": None,
-                             "end_to_end_TFLOPs_vs_survey_work": round(B * flops_per_img / (dt / args.steps) / 1e12, 2)},
-                "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(kinds.items())},
-                "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
-    import torch.distributed as tdist
-    if tdist.is_available() and tdist.is_initialized():
-        tdist.barrier()
-        tdist.destroy_process_group()
+    if train:
+        _emit(args, torch, hdist, ops, rank, world, B, step, metric, "train_generator 1024x768 ngf=64, random-init weights",
+              flops_per_img, True)
+    else:
+        _emit(args, torch, hdist, ops, rank, world, B, step, metric, "tryon_infer 1024x768 ngf=64, random-init weights"
+              + (" (bf16 storage in the generator; tocg + glue f32)" if args.bf16 else ""), flops_per_img, False)
 
 
 def main():

@@ -33,15 +33,18 @@ struct PackParams {
   int rows, rows_pad;    // output rows (Cout or CinTot) and their padded count
   float wscale;
   const float* sigma;    // optional device scalar: weights are divided by sigma[0] (spectral norm)
-  float* out;            // [KHp*KWp*chunks_total][rows_pad][16]
+  float* out;            // [KHp*KWp*chunks_total][rows_pad][bke]  (fp32, or bf16 when `bf16`)
+  int bke;               // k-values per packed row: 16 (fp32 engine), 32 / 64 (bf16 engine, 64- / 128-byte rows)
+  int bf16;
 };
 
 __global__ void pack_weight_kernel(const PackParams p) {
-  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  const int BKp = p.bke;
+  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BKp;
   const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % BK);
-    const size_t t = i / BK;
+    const int k = (int)(i % BKp);
+    const size_t t = i / BKp;
     const int row = (int)(t % p.rows_pad);
     const int kt = (int)(t / p.rows_pad);
     const int tap = kt / p.chunks_total, chunk = kt - tap * p.chunks_total;
@@ -53,7 +56,7 @@ __global__ void pack_weight_kernel(const PackParams p) {
 #pragma unroll
       for (int q = 1; q < HRV_MAX_SRC; ++q)
         if (q < p.nsrc && chunk >= p.src_chunk0[q]) s = q;
-      const int c = (chunk - p.src_chunk0[s]) * BK + k;  // channel within source s
+      const int c = (chunk - p.src_chunk0[s]) * BKp + k;  // channel within source s
       if (c < p.src_creal[s]) {
         const int cc = p.src_cbase[s] + c;
         const int co = p.transposed ? cc : row;
@@ -61,7 +64,13 @@ __global__ void pack_weight_kernel(const PackParams p) {
         v = p.w[(((size_t)co * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
       }
     }
-    p.out[i] = v;
+    if (p.bf16) {  // round to nearest even
+      unsigned u = __builtin_bit_cast(unsigned, v);
+      u += 0x7fffu + ((u >> 16) & 1u);
+      reinterpret_cast<unsigned short*>(p.out)[i] = (unsigned short)(u >> 16);
+    } else {
+      p.out[i] = v;
+    }
   }
 }
 
@@ -238,6 +247,199 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
   }
 }
 
+// ------------------------------------------------------------------ wgrad, bf16 matrix cores over fp32 tensors
+// Mixed-precision training: dY and X stay fp32 in HBM; they are rounded to bf16 (v_cvt_pk_bf16_f32) while being
+// staged and multiplied by v_mfma_f32_32x32x16_bf16 (fp32 accumulate).  That MFMA wants 8 consecutive k-values
+// (= pixels here) per lane, but NHWC is pixel-major, so each load task covers a QUAD of 4 consecutive pixels x 4
+// channels: the 4x4 block is transposed in registers for free and every channel's 4 pixels go to LDS as one
+// 8-byte store into a [channel][pixel] image (row = 32 pixels = 64 B + 16 B pad -> conflict-free b128 fragment
+// reads).  Needs Wo % 4 == 0 (a quad never straddles an image row); the caller falls back to the fp32 kernel
+// otherwise (the odd-sized PatchGAN maps).
+typedef __bf16 bf16x8w __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2w __attribute__((ext_vector_type(2)));
+typedef float f32x2w __attribute__((ext_vector_type(2)));
+constexpr int BKP = 32;      // pixels per K-tile
+constexpr int LKP = 40;      // LDS row stride in bf16 elements (32 + 8 pad)
+
+__device__ __forceinline__ unsigned pk_bf16(float a, float b) {
+  const f32x2w v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2w));
+}
+
+template <int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams p) {
+  constexpr int BMc = 32 * TM * WM;  // couts per block
+  constexpr int BNc = 32 * TN * WN;  // (tap, cin) columns per block
+  constexpr int YG = BMc / 4, XG = BNc / 4;             // channel groups per pixel
+  constexpr int YT = (8 * YG + 255) / 256;              // quad tasks per thread per K-tile
+  constexpr int XT = (8 * XG + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BMc + BNc) * LKP];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int l31 = lane & 31, lh = lane >> 5;
+
+  int b = xcd_remap(blockIdx.x, p.co_tiles * p.ci_tiles * p.S);
+  const int it = b % p.ci_tiles; b /= p.ci_tiles;
+  const int ct = b % p.co_tiles;
+  const int s = b / p.co_tiles;
+  const int co0 = ct * BMc, col0 = it * BNc;
+
+  const int ptiles = (p.P + BKP - 1) / BKP;
+  const int t_begin = (int)(((long long)ptiles * s) / p.S);
+  const int t_end = (int)(((long long)ptiles * (s + 1)) / p.S);
+  const int sr = p.x_up > 0 ? p.x_up : 0, sl = p.x_up < 0 ? -p.x_up : 0;
+  const int Hs = (p.H >> sr) << sl, Ws = (p.W >> sr) << sl;
+
+  // X tasks: task = (quad q in 0..7, column group g); every task of a thread has its own (tap, ci)
+  int xq[XT], xtap_kh[XT], xtap_kw[XT], xci[XT], xn[XT], xho[XT], xwo[XT];
+  bool xcol_ok[XT];
+#pragma unroll
+  for (int r = 0; r < XT; ++r) {
+    const int task = tid + 256 * r;
+    const int g = task % XG;
+    xq[r] = task / XG;
+    const int col = col0 + g * 4;
+    xcol_ok[r] = task < 8 * XG && col < p.taps * p.x_C;
+    const int tap = xcol_ok[r] ? col / p.x_C : 0;
+    xci[r] = xcol_ok[r] ? col - tap * p.x_C : 0;
+    xtap_kh[r] = tap / p.KW;
+    xtap_kw[r] = tap - xtap_kh[r] * p.KW;
+    const int pix = t_begin * BKP + xq[r] * 4;
+    const int pp = pix < p.P ? pix : 0;
+    xn[r] = pp / (p.Ho * p.Wo);
+    const int rem = pp - xn[r] * (p.Ho * p.Wo);
+    xho[r] = rem / p.Wo;
+    xwo[r] = rem - xho[r] * p.Wo;
+  }
+  f32x4 yreg[YT][4], xreg[XT][4];
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+#define WB_LOAD(T)                                                                                        \
+  {                                                                                                       \
+    _Pragma("unroll") for (int r = 0; r < YT; ++r) {                                                      \
+      const int task = tid + 256 * r;                                                                     \
+      const int g = task % YG, q = task / YG;                                                             \
+      const int c = co0 + g * 4;                                                                          \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+        const int pix = (T)*BKP + q * 4 + j;                                                              \
+        const bool ok = task < 8 * YG && pix < p.P && c < p.Cout;                                         \
+        const size_t off = ok ? (size_t)pix * p.dy_cs + p.dy_co + c : (size_t)p.dy_co;                    \
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + off);                                            \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = (ok && c + e < p.Cout) ? v[e] : 0.f;         \
+        yreg[r][j] = v;                                                                                   \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < XT; ++r) {                                                      \
+      const int n = xn[r], ho = xho[r], wo = xwo[r];                                                      \
+      const int hi = ho * p.stride - p.pad + xtap_kh[r];                                                  \
+      const bool row_ok = xcol_ok[r] && (unsigned)hi < (unsigned)p.H;                                     \
+      const int hic = min(max(hi, 0), p.H - 1);                                                           \
+      const size_t rowoff = (size_t)(n * Hs + ((hic >> sr) << sl)) * Ws;                                  \
+      _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
+        const int pix = (T)*BKP + xq[r] * 4 + j;                                                          \
+        const int wi = (wo + j) * p.stride - p.pad + xtap_kw[r];                                          \
+        const bool ok = row_ok && pix < p.P && (unsigned)wi < (unsigned)p.W;                              \
+        const int wic = min(max(wi, 0), p.W - 1);                                                         \
+        const size_t off = (rowoff + ((wic >> sr) << sl)) * p.x_cs + p.x_co + xci[r];                     \
+        f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                             \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                             \
+        xreg[r][j] = v;                                                                                   \
+      }                                                                                                   \
+      /* advance the quad by BKP pixels for the next tile (Wo % 4 == 0: it stays inside one image row) */ \
+      int w2 = wo + BKP, h2 = ho, n2 = n;                                                                 \
+      while (w2 >= p.Wo) { w2 -= p.Wo; ++h2; }                                                            \
+      while (h2 >= p.Ho) { h2 -= p.Ho; ++n2; }                                                            \
+      xwo[r] = w2; xho[r] = h2; xn[r] = n2 < p.N ? n2 : 0;                                                \
+    }                                                                                                     \
+  }
+
+// registers -> LDS: channel-major rows, the quad's 4 pixels of one channel as one 8-byte store
+#define WB_STORE(BUF)                                                                                     \
+  {                                                                                                       \
+    unsigned short* Ys = smem + (BUF) * (BMc + BNc) * LKP;                                                \
+    unsigned short* Xs = Ys + BMc * LKP;                                                                  \
+    _Pragma("unroll") for (int r = 0; r < YT; ++r) {                                                      \
+      const int task = tid + 256 * r;                                                                     \
+      const int g = task % YG, q = task / YG;                                                             \
+      if (task < 8 * YG) {                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+          uint2 w2;                                                                                       \
+          w2.x = pk_bf16(yreg[r][0][e], yreg[r][1][e]);                                                   \
+          w2.y = pk_bf16(yreg[r][2][e], yreg[r][3][e]);                                                   \
+          *reinterpret_cast<uint2*>(Ys + (g * 4 + e) * LKP + q * 4) = w2;                                 \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+    _Pragma("unroll") for (int r = 0; r < XT; ++r) {                                                      \
+      const int task = tid + 256 * r;                                                                     \
+      const int g = task % XG;                                                                            \
+      if (task < 8 * XG) {                                                                                \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
+          uint2 w2;                                                                                       \
+          w2.x = pk_bf16(xreg[r][0][e], xreg[r][1][e]);                                                   \
+          w2.y = pk_bf16(xreg[r][2][e], xreg[r][3][e]);                                                   \
+          *reinterpret_cast<uint2*>(Xs + (g * 4 + e) * LKP + xq[r] * 4) = w2;                             \
+        }                                                                                                 \
+      }                                                                                                   \
+    }                                                                                                     \
+  }
+
+#define WB_MMA(BUF)                                                                                       \
+  {                                                                                                       \
+    const unsigned short* Ys = smem + (BUF) * (BMc + BNc) * LKP + (wm * TM * 32 + l31) * LKP + lh * 8;    \
+    const unsigned short* Xs = smem + (BUF) * (BMc + BNc) * LKP + BMc * LKP + (wn * TN * 32 + l31) * LKP + lh * 8; \
+    _Pragma("unroll") for (int ks = 0; ks < BKP / 16; ++ks) {                                             \
+      bf16x8w a[TM], bb[TN];                                                                              \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
+          a[i] = *reinterpret_cast<const bf16x8w*>(Ys + i * 32 * LKP + ks * 16);                          \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
+          bb[j] = *reinterpret_cast<const bf16x8w*>(Xs + j * 32 * LKP + ks * 16);                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
+          _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);       \
+    }                                                                                                     \
+  }
+
+  if (t_begin < t_end) {
+    WB_LOAD(t_begin)
+    WB_STORE(t_begin & 1)
+    __syncthreads();
+    for (int t = t_begin; t < t_end - 1; ++t) {
+      WB_LOAD(t + 1)
+      WB_MMA(t & 1)
+      WB_STORE((t + 1) & 1)
+      __syncthreads();
+    }
+    WB_MMA((t_end - 1) & 1)
+  }
+#undef WB_LOAD
+#undef WB_STORE
+#undef WB_MMA
+
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = col0 + (wn * TN + j) * 32 + l31;
+    if (col >= p.taps * p.x_C) continue;
+    const int tap = col / p.x_C, ci = col - tap * p.x_C;
+    if (ci >= p.ci_real) continue;
+    float* wsp = p.ws + ((size_t)s * p.taps + tap) * p.Cout * p.CinTot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+        if (co < p.Cout) wsp[(size_t)co * p.CinTot + p.ci_base + ci] = acc[i][j][e];
+      }
+  }
+}
+
 // dW[co][ci][tap] (torch OIHW) (+)= sum_s ws[s][tap][co][ci], for ci in [ci_base, ci_base+ci_real)
 __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int taps, int Cout, int CinTot, int ci_base,
                                     int ci_real, float* __restrict__ dw, int accumulate) {
@@ -325,12 +527,11 @@ static int pick_wtile(int Cout, int Cin) {
 
 using namespace hrv;
 
-extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW,
-                                              int32_t nsrc, const int32_t* srcC, const int32_t* srcC_real,
-                                              int32_t tile_cfg, int32_t mode, int32_t stride, int32_t pad,
-                                              int32_t phase_a, int32_t phase_b, float wscale,
-                                              const float* sigma_dev, float* out_dev, int32_t* out_geom,
-                                              hrv_stream_t stream) {
+static int pack_weight_dev_impl(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
+                                int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
+                                const float* sigma_dev, void* out_dev, int32_t* out_geom, hrv_stream_t stream,
+                                const int BK, const int as_bf16) {
   HRV_REQUIRE(w_oihw_dev && out_dev && srcC && srcC_real && nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_dev: bad args");
   const int bn = hrv_conv2d_tile_bn(tile_cfg);
   HRV_REQUIRE(bn > 0, "pack_dev: bad tile_cfg %d", tile_cfg);
@@ -338,7 +539,8 @@ extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t C
   HRV_REQUIRE(KH <= 8 && KW <= 8, "pack_dev: kernel too large");
   PackParams p;
   memset(&p, 0, sizeof(p));
-  p.w = w_oihw_dev; p.Cout = Cout; p.KH = KH; p.KW = KW; p.wscale = wscale; p.sigma = sigma_dev; p.out = out_dev;
+  p.w = w_oihw_dev; p.Cout = Cout; p.KH = KH; p.KW = KW; p.wscale = wscale; p.sigma = sigma_dev; p.out = (float*)out_dev;
+  p.bke = BK; p.bf16 = as_bf16;
   int cin = 0;
   for (int i = 0; i < nsrc; ++i) cin += srcC_real[i];
   p.CinTot = cin;
@@ -397,6 +599,29 @@ extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t C
   return check_launch("pack_weight_kernel");
 }
 
+extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW,
+                                              int32_t nsrc, const int32_t* srcC, const int32_t* srcC_real,
+                                              int32_t tile_cfg, int32_t mode, int32_t stride, int32_t pad,
+                                              int32_t phase_a, int32_t phase_b, float wscale,
+                                              const float* sigma_dev, float* out_dev, int32_t* out_geom,
+                                              hrv_stream_t stream) {
+  return pack_weight_dev_impl(w_oihw_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, stride, pad, phase_a,
+                              phase_b, wscale, sigma_dev, out_dev, out_geom, stream, 16, 0);
+}
+
+// bf16 packing for the bf16 matrix-core engine ([kt][rows_pad][64] bf16 for the 128-byte-row tiles cfg 8/9,
+// [..][32] for the 64-byte-row tiles); same modes / geometry output (out_geom[7] counts bf16 elements).
+extern "C" int hrv_conv2d_pack_weight_dev_bf16(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW,
+                                               int32_t nsrc, const int32_t* srcC, const int32_t* srcC_real,
+                                               int32_t tile_cfg, int32_t mode, int32_t stride, int32_t pad,
+                                               int32_t phase_a, int32_t phase_b, float wscale,
+                                               const float* sigma_dev, uint16_t* out_dev, int32_t* out_geom,
+                                               hrv_stream_t stream) {
+  const int bke = (tile_cfg == 8 || tile_cfg == 9) ? 64 : 32;
+  return pack_weight_dev_impl(w_oihw_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, stride, pad, phase_a,
+                              phase_b, wscale, sigma_dev, out_dev, out_geom, stream, bke, 1);
+}
+
 extern "C" int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P) {
   // upper bound on S is 256 slabs
   const int64_t ptiles = (P + BK - 1) / BK;
@@ -405,12 +630,11 @@ extern "C" int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot
   return S * KH * KW * (int64_t)Cout * CinTot * (int64_t)sizeof(float);
 }
 
-extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
-                                         const float* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
-                                         int32_t x_up_shift, int32_t x_C_real, int32_t ci_base, int32_t CinTot,
-                                         int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
-                                         int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes,
-                                         float* dw_oihw, int32_t accumulate, hrv_stream_t stream) {
+static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x, int32_t x_C,
+                      int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real, int32_t ci_base,
+                      int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
+                      int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes, float* dw_oihw,
+                      int32_t accumulate, hrv_stream_t stream, const bool mma_bf16) {
   HRV_REQUIRE(dy && x && workspace && dw_oihw, "wgrad: null pointer");
   HRV_REQUIRE(Cout > 0 && x_C > 0 && x_C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 && dy_cstride % 4 == 0 &&
                   dy_coff % 4 == 0 && x_C_real > 0 && x_C_real <= x_C && ci_base >= 0 && ci_base + x_C_real <= CinTot,
@@ -428,7 +652,8 @@ extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, in
   p.taps = KH * KW;
   p.co_tiles = (Cout + bm - 1) / bm; p.ci_tiles = (p.taps * x_C + bn - 1) / bn;   // column tiles over (tap, ci)
   const int tiles = p.co_tiles * p.ci_tiles;
-  const int ptiles = (p.P + BK - 1) / BK;
+  HRV_REQUIRE(!mma_bf16 || Wo % 4 == 0, "wgrad (bf16 matrix cores): Wo must be a multiple of 4 (got %d)", Wo);
+  const int ptiles = mma_bf16 ? (p.P + BKP - 1) / BKP : (p.P + BK - 1) / BK;
   int S = (1024 + tiles - 1) / tiles;
   if (S > ptiles / 4) S = ptiles / 4;
   if (S > 256) S = 256;
@@ -438,12 +663,18 @@ extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, in
   p.S = S; p.ws = workspace;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = tiles * S;
-#define WG_CASE(I, A, B, Cc, D) \
-  case I: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p); break;
+#define WG_CASE(I, A, B, Cc, D)                                                                                   \
+  case I:                                                                                                         \
+    if (mma_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p);     \
+    else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p);              \
+    break;
   switch (wt) {
     WG_CASE(0, 1, 1, 1, 4) WG_CASE(1, 2, 1, 1, 4) WG_CASE(2, 3, 1, 1, 4) WG_CASE(3, 4, 1, 1, 4) WG_CASE(4, 5, 1, 1, 4)
     WG_CASE(5, 6, 1, 1, 4) WG_CASE(6, 2, 2, 2, 2) WG_CASE(7, 1, 1, 4, 1) WG_CASE(8, 2, 1, 4, 1)
-    default: hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p); break;
+    default:
+      if (mma_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p);
+      else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p);
+      break;
   }
 #undef WG_CASE
   int rc = check_launch("conv_wgrad_mfma_kernel");
@@ -452,6 +683,29 @@ extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, in
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, workspace, S, p.taps, Cout, CinTot,
                      ci_base, x_C_real, dw_oihw, accumulate);
   return check_launch("wgrad_reduce_kernel");
+}
+
+extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+                                         const float* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
+                                         int32_t x_up_shift, int32_t x_C_real, int32_t ci_base, int32_t CinTot,
+                                         int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
+                                         int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes,
+                                         float* dw_oihw, int32_t accumulate, hrv_stream_t stream) {
+  return wgrad_impl(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base, CinTot, N, H,
+                    W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, stream, false);
+}
+
+// Same contract on the bf16 matrix cores (operands rounded to bf16 while staged, fp32 accumulate): the weight
+// gradient of mixed-precision training.  Requires Wo % 4 == 0.
+extern "C" int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+                                                 const float* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
+                                                 int32_t x_up_shift, int32_t x_C_real, int32_t ci_base, int32_t CinTot,
+                                                 int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH,
+                                                 int32_t KW, int32_t stride, int32_t pad, float* workspace,
+                                                 int64_t workspace_bytes, float* dw_oihw, int32_t accumulate,
+                                                 hrv_stream_t stream) {
+  return wgrad_impl(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base, CinTot, N, H,
+                    W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, stream, true);
 }
 
 extern "C" int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,

@@ -67,6 +67,7 @@ struct ConvParams {
   int out_step, out_oh, out_ow, out_H, out_W;  // out_step 2: scatter to (2h+oh, 2w+ow) of an out_H x out_W output
   int bf16;      // 1: sources / weights are bf16 (accumulate + stats fp32)
   int out_f32, res_f32, sx_f32;  // bf16 mode: these tensors are fp32 instead of bf16
+  int src_f32;   // bf16 mode: the conv SOURCES are fp32 and are rounded to bf16 while being staged
   int res_mode;  // 0: + residual; 1: * (residual > 0 ? 1 : slope)   (activation derivative, backward)
   unsigned w_bytes;       // size of the packed weight (LDS-DMA buffer resource; 0: LDS-DMA not usable)
   // SPADE epilogue (epi == 1)
@@ -110,6 +111,19 @@ __device__ __forceinline__ unsigned short f2bf(float f) {  // round to nearest e
   u += 0x7fffu + ((u >> 16) & 1u);
   return (unsigned short)(u >> 16);
 }
+// 8 fp32 -> 8 bf16 (round to nearest even, v_cvt_pk_bf16_f32), returned as the 16 raw bytes of one LDS group
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 pack_bf16x8(f32x4 lo, f32x4 hi) {
+  f32x4 r;
+  const f32x2 p0 = {lo[0], lo[1]}, p1 = {lo[2], lo[3]}, p2 = {hi[0], hi[1]}, p3 = {hi[2], hi[3]};
+  r[0] = __builtin_bit_cast(float, __builtin_convertvector(p0, bf16x2));
+  r[1] = __builtin_bit_cast(float, __builtin_convertvector(p1, bf16x2));
+  r[2] = __builtin_bit_cast(float, __builtin_convertvector(p2, bf16x2));
+  r[3] = __builtin_bit_cast(float, __builtin_convertvector(p3, bf16x2));
+  return r;
+}
+
 template <bool BF>
 __device__ __forceinline__ f32x4 ld4e(const float* base, size_t idx) {
   if constexpr (BF) {
@@ -195,6 +209,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   constexpr int BKE = GPR * EPG;     // k-values per K-tile row
   constexpr bool GLDS = (VAR & 4) != 0;  // operands staged by LDS-DMA (global_load_lds_dwordx4), no register hop
   static_assert(!GLDS || (BF && RB == 128), "the LDS-DMA variant exists for the bf16 engine with 128-byte rows");
+  // bf16 matrix cores over fp32 tensors (mixed-precision TRAINING, the reference's --fp16 / apex O1 role): the
+  // gather loads 8 fp32 channels (two float4s) per 16-byte LDS group and rounds them with v_cvt_pk_bf16_f32;
+  // weights are packed as bf16; accumulation, epilogue, residual and output stay fp32.
+  constexpr bool SF = (VAR & 8) != 0;
+  static_assert(!SF || (BF && !GLDS), "fp32-source variant: bf16 MFMA, register-staged");
   // LDS row stride in floats.  Register-staged: row + 16 B pad (conflict-free b128 reads).  LDS-DMA: the
   // image is lane-linear (dest = wave base + lane*16), so rows are dense and the 16-byte groups of a row
   // are XOR-swizzled by ((row >> 1) & 7) on the SOURCE address and on the fragment read instead.
@@ -336,9 +355,21 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
       const int hic = min(max(hi, 0), p.H - 1), wic = min(max(wi, 0), p.W - 1);                              \
       const unsigned off =                                                                                   \
           ((unsigned)(a_n[r] * Hs + ((hic >> sh_r) << sh_l)) * Ws + ((wic >> sh_r) << sh_l)) * s_cs + s_co + cc; \
-      f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_ptr) + (size_t)off * ES);    \
-      _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                                  \
-      a_reg[r] = v;                                                                                          \
+      if constexpr (SF) {                                                                                    \
+        const float* g = s_ptr + off;                                                                        \
+        const bool ok2 = ok && (c + 4 < s_C);                                                                \
+        f32x4 lo = *reinterpret_cast<const f32x4*>(g);                                                       \
+        f32x4 hi4 = *reinterpret_cast<const f32x4*>(g + (ok2 ? 4 : 0));                                      \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                      \
+          lo[e] = ok ? lo[e] : 0.f;                                                                          \
+          hi4[e] = ok2 ? hi4[e] : 0.f;                                                                       \
+        }                                                                                                    \
+        a_reg[r] = pack_bf16x8(lo, hi4);                                                                     \
+      } else {                                                                                               \
+        f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(s_ptr) + (size_t)off * ES);  \
+        _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                                \
+        a_reg[r] = v;                                                                                        \
+      }                                                                                                      \
     }                                                                                                        \
     const float* wt = p.wp + ((size_t)(KTN)*p.CoutPad + n0) * BK; /* 64-byte rows in both modes */            \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
@@ -842,7 +873,8 @@ static int pick_splitk(int nblk, int KT, bool allowed) {
 }
 
 static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, bool bf = false) {
-  const int cm = bf ? 8 : 4;     // channel granularity = one 16-byte gather group
+  const bool srcf = bf && d && ((d->mixed_flags >> 3) & 1);   // fp32 sources rounded to bf16 in the gather
+  const int cm = (bf && !srcf) ? 8 : 4;     // channel granularity = one 16-byte gather group
   HRV_REQUIRE(d != nullptr, "conv2d: null descriptor");
   const int rb = (need_packed && d->tile_cfg >= 0 && d->tile_cfg < kNumCfgs) ? cfg_rb(d->tile_cfg) : 64;
   HRV_REQUIRE(bf || rb == 64, "conv2d: tile_cfg=%d (128-byte K-tile rows) exists on the bf16 engine only", d->tile_cfg);
@@ -866,9 +898,12 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
   p.out_f32 = bf ? (d->mixed_flags & 1) : 1;
   p.res_f32 = bf ? ((d->mixed_flags >> 1) & 1) : 1;
   p.sx_f32 = bf ? ((d->mixed_flags >> 2) & 1) : 1;
+  p.src_f32 = srcf ? 1 : 0;
+  HRV_REQUIRE(!srcf || (rb == 128 && p.out_f32 && p.res_f32 && p.sx_f32),
+              "conv2d: fp32-source bf16 mode needs a 128-byte-row tile (cfg 8/9) and fp32 out/residual/x (mixed_flags 15)");
   p.nsrc = d->nsrc;
   int chunks_total = 0;
-  bool dma_ok = bf && rb == 128;   // LDS-DMA staging: every operand must fit a 32-bit buffer resource
+  bool dma_ok = bf && rb == 128 && !srcf;   // LDS-DMA staging: every operand must fit a 32-bit buffer resource
   for (int i = 0; i < d->nsrc; ++i) {
     const hrv_src_t& s = d->src[i];
     HRV_REQUIRE(s.ptr != nullptr, "conv2d: src[%d] null", i);
@@ -896,7 +931,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
     chunks_total += p.src[i].chunks;
     {
       const int sr = s.up_shift > 0 ? s.up_shift : 0, sl = s.up_shift < 0 ? -s.up_shift : 0;
-      const int64_t bytes = (int64_t)d->N * ((d->H >> sr) << sl) * ((d->W >> sr) << sl) * s.cstride * (bf ? 2 : 4);
+      const int64_t bytes = (int64_t)d->N * ((d->H >> sr) << sl) * ((d->W >> sr) << sl) * s.cstride * ((bf && !srcf) ? 2 : 4);
       p.src[i].bytes = bytes < (int64_t)0xFFFFFFF0 ? (unsigned)bytes : 0u;
       if (bytes >= (int64_t)0xFFFFFFF0) dma_ok = false;
     }
@@ -995,7 +1030,10 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
       const char* eg = getenv("HRV_CONV_GLDS");
       const bool want = eg ? atoi(eg) != 0 : (32 * TN * WN == 64);
       const bool glds = want && p.w_bytes != 0;
-      if (glds) {
+      if (p.src_f32) {
+        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 9, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 8, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+      } else if (glds) {
         if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 5, true, RB>), dim3(nblk), dim3(256), 0, st, p);
         else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 4, true, RB>), dim3(nblk), dim3(256), 0, st, p);
       } else {
@@ -1151,7 +1189,8 @@ extern "C" int hrv_conv2d_nhwc_bf16(const hrv_conv2d_t* d, hrv_stream_t stream) 
   ConvParams p;
   int rc = fill_params(d, p, true, true);
   if (rc) return rc;
-  HRV_REQUIRE(!(d->spade && d->spade->g1p_out), "conv2d_bf16: g1p_out (training) is fp32-only");
+  HRV_REQUIRE(!(d->spade && d->spade->g1p_out) || p.src_f32,
+              "conv2d_bf16: g1p_out (training) needs the fp32-source mode (mixed_flags bit 3)");
   return launch_any(d->tile_cfg, p, (hipStream_t)stream);
 }
 

@@ -130,7 +130,9 @@ class SpadeT:
         bc = torch.zeros(self.G * 64, device=dev)
         bc.index_copy_(0, self.rows_g, n.conv_gamma.bias.data)
         bc.index_copy_(0, self.rows_b, n.conv_beta.bias.data)
-        packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], self.cfg, 0, 1, 1)
+        mb = T.MMA_BF16[0]     # mixed precision: bf16 matrix cores over the fp32 actv, fp32 epilogue
+        cfg = ((8 if self.G % 2 == 0 else 9) if mb else self.cfg)
+        packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], cfg, 0, 1, 1, bf16=mb)
         out = ops.alloc(x.N, x.H, x.W, self.C, dev)
         g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev)
         e = ops._lib.hrv_spade_epi_t()
@@ -147,14 +149,16 @@ class SpadeT:
         d.nsrc = 1
         s = d.src[0]
         s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = actv.t.data_ptr(), self.hid, actv.cstride, 0, 0, 0, self.hid
-        d.w_packed, d.Cout, d.tile_cfg = packed.data_ptr(), self.G * 64, self.cfg
+        d.w_packed, d.Cout, d.tile_cfg = packed.data_ptr(), self.G * 64, cfg
+        d.mixed_flags = 15 if mb else 0
         d.shift = bc.data_ptr()
         d.act, d.act_slope = self.act, 0.2
         d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
         d.spade = C.pointer(e)
         fl = 2.0 * x.N * x.H * x.W * 2 * self.C * self.hid * 9
         with ops._Timed("conv", self.name + ".conv_gamma|beta", fl, 0):
-            ops._lib.check(lib.hrv_conv2d_nhwc_f32(C.byref(d), ops._stream()), "hrv_conv2d_nhwc_f32[spade]")
+            fn = lib.hrv_conv2d_nhwc_bf16 if mb else lib.hrv_conv2d_nhwc_f32
+            ops._lib.check(fn(C.byref(d), ops._stream()), "hrv_conv2d_nhwc_%s[spade]" % ("bf16" if mb else "f32"))
         ctx = dict(x=x, seg=seg, seg_shift=seg_shift, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv,
                    g1p=Act(g1p, self.C), out=out)
         return out, ctx

@@ -12,9 +12,22 @@ from . import _lib, ops
 from .ops import ACT_NONE, Act, _ceil4, _stream, _Timed, _workspace
 
 
+# Mixed-precision training switch (the reference's --fp16 / apex-O1 role): when on, every training
+# convolution (forward and data gradient) rounds its fp32 operands to bf16 while staging them and runs on
+# v_mfma_f32_32x32x16_bf16 with fp32 accumulation; all tensors in HBM, the epilogues, the normalisations,
+# the losses and the optimizer stay fp32.  The weight gradient has its own switch-aware kernel.
+MMA_BF16 = [False]
+
+
+def _bf16_tile(cout: int) -> int:
+    """128-byte-row tile of the bf16 engine with the least column padding (cfg 8: 128 columns, cfg 9: 64)."""
+    p64, p128 = (cout + 63) // 64 * 64, (cout + 127) // 128 * 128
+    return 8 if p128 <= p64 else 9
+
+
 def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
                     stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0,
-                    sigma: Optional[torch.Tensor] = None):
+                    sigma: Optional[torch.Tensor] = None, bf16: bool = False):
     """hrv_conv2d_pack_weight_dev_f32.  ``w``: OIHW fp32 on the device.  Returns (packed, geom)
     with geom = (KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, elems)."""
     lib = _lib.load()
@@ -27,22 +40,23 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     bn = lib.hrv_conv2d_tile_bn(cfg)
     rows = Cout if mode == 0 else cin
     rows_pad = (rows + bn - 1) // bn * bn
-    chunks = sum((c + 15) // 16 for c in src_pad) if mode == 0 else (_ceil4(Cout) + 15) // 16
-    buf = torch.empty(KH * KW * chunks * rows_pad * 16, dtype=torch.float32, device=w.device)
+    bke = (64 if cfg in (8, 9) else 32) if bf16 else 16
+    chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
+    buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
     geom = (C.c_int32 * 8)()
-    _lib.check(lib.hrv_conv2d_pack_weight_dev_f32(w.data_ptr(), Cout, KH, KW, n, srcC, srcR, cfg, mode, stride, pad,
-                                                  phase[0], phase[1], wscale,
-                                                  None if sigma is None else sigma.data_ptr(), buf.data_ptr(), geom,
-                                                  _stream()),
-               "hrv_conv2d_pack_weight_dev_f32")
+    fn = lib.hrv_conv2d_pack_weight_dev_bf16 if bf16 else lib.hrv_conv2d_pack_weight_dev_f32
+    _lib.check(fn(w.data_ptr(), Cout, KH, KW, n, srcC, srcR, cfg, mode, stride, pad, phase[0], phase[1], wscale,
+                  None if sigma is None else sigma.data_ptr(), buf.data_ptr(), geom, _stream()),
+               "hrv_conv2d_pack_weight_dev_" + ("bf16" if bf16 else "f32"))
     return buf, tuple(geom)
 
 
 def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_h, pad_w, out: Act, scale=None,
                 shift=None, residual: Optional[Act] = None, res_mode: int = 0, act: int = ACT_NONE, slope: float = 0.2,
                 free_extent: int = 0, out_step: int = 0, out_off=(0, 0), out_hw=(0, 0), out_up: int = 0,
-                name: str = "conv", flops: float = 0.0):
-    """Raw launch of hrv_conv2d_nhwc_f32 with an explicit, already packed weight."""
+                name: str = "conv", flops: float = 0.0, mma_bf16: bool = False, spade=None):
+    """Raw launch of hrv_conv2d_nhwc_f32 (or, with ``mma_bf16``, of the bf16 matrix-core engine over the same
+    fp32 tensors: mixed_flags 15) with an explicit, already packed weight."""
     lib = _lib.load()
     d = _lib.hrv_conv2d_t()
     d.N, d.H, d.W, d.Ho, d.Wo = N, H, W, Ho, Wo
@@ -69,8 +83,13 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
     if need > 0:
         ws = _workspace(out.t.device, need)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+    if spade is not None:
+        d.spade = C.pointer(spade)
+    if mma_bf16:
+        d.mixed_flags = 15
     with _Timed("conv", name, flops, 0):
-        _lib.check(lib.hrv_conv2d_nhwc_f32(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{name}]")
+        fn = lib.hrv_conv2d_nhwc_bf16 if mma_bf16 else lib.hrv_conv2d_nhwc_f32
+        _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_{'bf16' if mma_bf16 else 'f32'}[{name}]")
     return out
 
 
@@ -84,15 +103,18 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     N = a0.N
     H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
-    cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
+    mb = MMA_BF16[0]
+    cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
-    packed, _ = pack_weight_dev(w, [_ceil4(c) for c in real], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma)
+    packed, _ = pack_weight_dev(w, [_ceil4(c) for c in real], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
+                                bf16=mb)
     if out is None:
         out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     return _run_engine([(a, up, a.C) for a, up in srcs], packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad, pad,
-                       out, shift=shift, residual=residual, act=act, slope=slope, out_up=out_up, name=name, flops=fl)
+                       out, shift=shift, residual=residual, act=act, slope=slope, out_up=out_up, name=name, flops=fl,
+                       mma_bf16=mb)
 
 
 def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
@@ -106,13 +128,14 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
     assert dy.C == Cout
     if out is None:
         out = ops.alloc(N, H, W, cin, dy.t.device)
-    cfg = lib.hrv_conv2d_pick_tile(N * H * W, cin)
+    mb = MMA_BF16[0]
+    cfg = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * H * W, cin)
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     if stride == 1:
-        packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma)
+        packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
-                    residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl)
+                    residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl, mma_bf16=mb)
         return out
     assert stride == 2, "data gradient implemented for stride 1 and 2"
     for a in range(2):
@@ -120,11 +143,11 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
             Hp, Wp = (H - a + 1) // 2, (W - b + 1) // 2
             if Hp <= 0 or Wp <= 0:
                 continue
-            cfg_p = lib.hrv_conv2d_pick_tile(N * Hp * Wp, cin)
-            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale, sigma)
+            cfg_p = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * Hp * Wp, cin)
+            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale, sigma, bf16=mb)
             _run_engine([(dy, 0, Cout)], packed, cin, cfg_p, N, Ho, Wo, Hp, Wp, g[0], g[1], 1, g[2], g[3], out,
                         residual=act_mask, res_mode=res_mode, slope=slope, free_extent=1, out_step=2, out_off=(a, b),
-                        out_hw=(H, W), name=f"{name}[phase {a}{b}]", flops=fl / 4)
+                        out_hw=(H, W), name=f"{name}[phase {a}{b}]", flops=fl / 4, mma_bf16=mb)
     return out
 
 
@@ -138,8 +161,10 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     need = lib.hrv_conv2d_wgrad_workspace_bytes(Cout, cin_tot, KH, KW, N * Ho * Wo)
     ws = _workspace(dy.t.device, need)
     fl = 2.0 * N * Ho * Wo * Cout * x.C * KH * KW
+    # mixed precision: bf16 matrix cores (needs Wo % 4 == 0; the odd-sized PatchGAN maps keep the fp32 kernel)
+    fn = lib.hrv_conv2d_wgrad_bf16mma_nhwc_f32 if (MMA_BF16[0] and Wo % 4 == 0) else lib.hrv_conv2d_wgrad_nhwc_f32
     with _Timed("wgrad", name, fl, 0):
-        _lib.check(lib.hrv_conv2d_wgrad_nhwc_f32(dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp,
+        _lib.check(fn(dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp,
                                                  x.cstride, x.coff, x_up, x.C, ci_base, cin_tot, N, H, W, Ho, Wo, KH, KW,
                                                  stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
                                                  1 if accumulate else 0, _stream()), "hrv_conv2d_wgrad_nhwc_f32")

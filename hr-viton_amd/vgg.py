@@ -87,7 +87,13 @@ class Vgg19(nn.Module):
                 if save:
                     saved.append(("pool", cur))
                 cur = pooled
-            out = layers[idx]([cur])
+            if T.MMA_BF16[0]:
+                # mixed-precision training: bf16 matrix cores over the fp32 activations (device-packed weights)
+                m = self.conv(idx)
+                out = T.conv_forward_dev(m.weight.data, [(cur, 0)], 1, 1, shift=m.bias.data, act=ACT_RELU,
+                                         name=f"vgg.features.{idx}")
+            else:
+                out = layers[idx]([cur])
             if save:
                 saved.append(("conv", idx, cur, out))
             cur = out

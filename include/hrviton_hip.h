@@ -135,9 +135,10 @@ typedef struct hrv_conv2d {
   int32_t res_mode;     /* 0: epilogue adds `residual`; 1: multiplies by the activation
                            derivative (residual > 0 ? 1 : act_slope) -- LeakyReLU/ReLU
                            backward fused into the data-gradient convolution             */
-  int32_t mixed_flags;  /* hrv_conv2d_nhwc_bf16 only: bit0 = `out` is fp32, bit1 = `residual` is
-                           fp32, bit2 = spade->x is fp32 (tensors that feed an InstanceNorm stay
-                           fp32; tensors that only feed convolutions are bf16)            */
+  int32_t mixed_flags;  /* hrv_conv2d_nhwc_bf16 only: bit0 = `out` is fp32, bit1 = `residual` is fp32,
+                           bit2 = the SPADE `x` is fp32 (tensors that feed an InstanceNorm stay fp32),
+                           bit3 = the conv SOURCES are fp32 and are rounded to bf16 while staged
+                           (mixed-precision training; needs bits 0-2 and a 128-byte-row tile) */
   int32_t _pad3;
 } hrv_conv2d_t;
 
@@ -177,8 +178,22 @@ int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_
                                    const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
                                    int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
                                    const float* sigma_dev, float* out_dev, int32_t* out_geom, hrv_stream_t stream);
+/* Same packing, rounded to bf16, for the bf16 matrix-core engine (hrv_conv2d_nhwc_bf16): rows of 64 k-values
+ * for the 128-byte-row tiles (tile_cfg 8/9), 32 otherwise.  Used by mixed-precision training, where the
+ * activations stay fp32 in HBM (hrv_conv2d_t.mixed_flags bit 3) and only the MFMA operands are bf16. */
+int hrv_conv2d_pack_weight_dev_bf16(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                    const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
+                                    int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
+                                    const float* sigma_dev, uint16_t* out_dev, int32_t* out_geom, hrv_stream_t stream);
 int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P);
 int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
+                              int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
+                              int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
+                              int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,
+                              int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, hrv_stream_t stream);
+/* Same contract with the operands rounded to bf16 while staged and multiplied on v_mfma_f32_32x32x16_bf16 (fp32
+ * accumulate): the weight gradient of mixed-precision training.  Requires Wo % 4 == 0. */
+int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
                               int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
                               int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                               int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,

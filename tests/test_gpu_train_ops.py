@@ -277,3 +277,66 @@ def test_training_state_checkpoint_resumes_exactly(tmp_path):
         step(m2, o2, s2, k)
     for a, b in zip(m1.parameters(), m2.parameters()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("case", [("c3x3", [24], 40, 3, 1, 1, 12, 10), ("cat", [16, 8], 130, 3, 1, 1, 8, 12),
+                                  ("s2_4x4", [12], 20, 4, 2, 2, 13, 9), ("c1x1", [72], 64, 1, 1, 0, 8, 8),
+                                  ("in4", [4], 16, 3, 2, 1, 16, 12)], ids=lambda c: c[0])
+def test_mixed_precision_conv_forward_and_dgrad(case):
+    """T.MMA_BF16: bf16 matrix cores over fp32 tensors (fp32 accumulate / epilogue).  Reference: fp32 conv of the
+    bf16-ROUNDED operands (the only rounding the mode introduces), tolerance = accumulation-order noise."""
+    ops, T = _mods()
+    name, cins, cout, k, stride, pad, H, W = case
+    g = torch.Generator().manual_seed(len(name) + cout)
+    N = 2
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    xs = [torch.randn(N, c, H, W, generator=g) for c in cins]
+    w = torch.randn(cout, sum(cins), k, k, generator=g) * (1.0 / (sum(cins) * k * k) ** 0.5)
+    b = torch.randn(cout, generator=g) * 0.1
+    x = torch.cat(xs, 1)
+    ref = F.conv2d(rb(x), rb(w), b, stride=stride, padding=pad)
+    dy = torch.randn(ref.shape, generator=g)
+    dx_ref = torch.nn.grad.conv2d_input(x.shape, rb(w), rb(dy), stride=stride, padding=pad)
+    T.MMA_BF16[0] = True
+    try:
+        srcs = [(ops.to_nhwc(t.cuda()), 0) for t in xs]
+        out = T.conv_forward_dev(w.cuda(), srcs, stride, pad, shift=b.cuda(), name=name)
+        dx = T.conv_dgrad(ops.to_nhwc(dy.cuda()), w.cuda(), H, W, stride, pad, name=name + ".dgrad")
+    finally:
+        T.MMA_BF16[0] = False
+    assert out.t.dtype == torch.float32
+    got, gdx = ops.to_nchw(out).cpu(), ops.to_nchw(dx).cpu()
+    assert (got - ref).abs().max() <= 2e-5 * ref.abs().max() + 1e-5, (got - ref).abs().max()
+    assert (gdx - dx_ref).abs().max() <= 2e-5 * dx_ref.abs().max() + 1e-5, (gdx - dx_ref).abs().max()
+    # and it IS a different rounding than the fp32 engine (the bf16 operands lose ~3 decimal digits)
+    full = F.conv2d(x, w, b, stride=stride, padding=pad)
+    assert (got - full).abs().max() > 1e-4 * full.abs().max()
+
+
+@pytest.mark.parametrize("case", [("w3x3", 24, 40, 3, 1, 1, 12, 12), ("wcat_base", 16, 130, 3, 1, 1, 8, 16),
+                                  ("ws2", 12, 96, 4, 2, 1, 16, 24), ("w1x1", 72, 192, 1, 1, 0, 8, 8),
+                                  ("wtiny", 4, 16, 3, 2, 1, 16, 24), ("wup", 8, 32, 3, 1, 1, 8, 8)], ids=lambda c: c[0])
+def test_mixed_precision_wgrad(case):
+    """hrv_conv2d_wgrad_bf16mma_nhwc_f32 (quad-transposed staging, v_mfma_f32_32x32x16_bf16) vs the fp32 weight
+    gradient of the bf16-rounded operands."""
+    ops, T = _mods()
+    name, cin, cout, k, stride, pad, H, W = case
+    g = torch.Generator().manual_seed(len(name) + cout)
+    N = 2
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    up = 1 if name == "wup" else 0
+    x = torch.randn(N, cin, H >> up, W >> up, generator=g)
+    xf = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else x
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    assert Wo % 4 == 0
+    dy = torch.randn(N, cout, Ho, Wo, generator=g)
+    ref = torch.nn.grad.conv2d_weight(rb(xf), (cout, cin + 5, k, k)[:1] + (cin,) + (k, k), rb(dy), stride=stride, padding=pad)
+    dw = torch.zeros(cout, cin + 8, k, k, device="cuda")       # the source sits at ci_base 4 of a wider Cin axis
+    T.MMA_BF16[0] = True
+    try:
+        T.conv_wgrad(ops.to_nhwc(dy.cuda()), ops.to_nhwc(x.cuda()), up, 4, cin + 8, k, k, stride, pad, dw, name=name)
+    finally:
+        T.MMA_BF16[0] = False
+    got = dw[:, 4:4 + cin].cpu()
+    assert (got - ref).abs().max() <= 3e-5 * ref.abs().max() + 1e-5, ((got - ref).abs().max(), ref.abs().max())
+    assert dw[:, :4].abs().max() == 0 and dw[:, 4 + cin:].abs().max() == 0

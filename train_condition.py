@@ -137,6 +137,9 @@ def disk_batch(inputs, device):
 def main(argv=None):
     opt = get_opt(argv)
     rank, local_rank, world = hdist.init_from_env()
+    if opt.fp16:
+        from hr_viton_amd import train_ops as _T
+        _T.MMA_BF16[0] = True      # bf16 matrix cores for the training convolutions (fp32 storage / accumulate)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     assert opt.batch_size % world == 0, "Batch size %d must be a multiple of # GPUs %d." % (opt.batch_size, world)

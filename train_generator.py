@@ -7,7 +7,9 @@ on the MI355X-native hot path.
     hold identical weights; gradients are bucket-all-reduced on RCCL during the backward
     (hr_viton_amd.parallel.GradSync) instead of the reference's nn.DataParallel wrapper.
   * ``-b`` is the GLOBAL batch like the reference (split over ranks, train_generator.py:124-126).
-  * ``--fp16`` is accepted; this round's kernels are fp32 (bf16 engine: next round).
+  * ``--fp16``: mixed precision like the reference's apex O1 -- every training convolution (forward, data and
+    weight gradient) runs on the bf16 matrix cores over fp32 tensors (hr_viton_amd.train_ops.MMA_BF16);
+    normalisations, losses, the optimizer and everything in HBM stay fp32.
   * ``--synthetic`` feeds VITON-HD-shaped random batches (no dataset / torchvision in this image);
     tensorboard / LPIPS evaluation blocks (train_generator.py:364-584) are out of scope.
 Bug-fixes of the reference call sites: tocg(input1, input2) arity, load_checkpoint arity,
@@ -118,6 +120,9 @@ def synthetic_batch(opt, n, seed, device):
 def main(argv=None):
     opt = get_opt(argv)
     rank, local_rank, world = hdist.init_from_env()
+    if opt.fp16:
+        from hr_viton_amd import train_ops as _T
+        _T.MMA_BF16[0] = True      # bf16 matrix cores for the training convolutions (fp32 storage / accumulate)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     assert opt.batch_size % world == 0, "Batch size %d must be a multiple of # GPUs %d." % (opt.batch_size, world)
