@@ -63,5 +63,5 @@ def load_training_state(path, modules, optimizers=None, schedulers=None):
     if blob["rng"]["cuda"] is not None and torch.cuda.is_available():
         torch.cuda.set_rng_state(blob["rng"]["cuda"])
     from . import ops
-    ops.WEIGHTS_EPOCH[0] += 1
+    ops.WEIGHTS_EPOCH[0] += 1       # load_state_dict's copy_ bumps every tensor's _version: cached plans rebuild
     return blob["step"], blob["extra"]

@@ -22,7 +22,7 @@ import torch.nn as nn
 
 from . import _lib, ops
 from . import train_ops as T
-from .gen_train import DiscTrainPlan, Grads, TConv, _acc
+from .gen_train import DiscTrainPlan, Grads, TConv, _acc, grad_buffer
 from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Act, _stream
 
 
@@ -133,8 +133,8 @@ def bn_act(tape: Tape, bn: nn.BatchNorm2d, x: Var, act: int, residual: Optional[
         if act != ACT_NONE:
             T.act_bwd_(d, out.a, act, 0.2)
         dev = d.t.device
-        dg = torch.empty(x.a.C, dtype=torch.float32, device=dev) if bn.affine else None
-        db = torch.empty(x.a.C, dtype=torch.float32, device=dev) if bn.affine else None
+        dg = grad_buffer(bn.weight) if bn.affine else None
+        db = grad_buffer(bn.bias) if bn.affine else None
         dx = T.bn_bwd(d, x.a, st, dg, db)
         if bn.affine:
             _acc(tape.grads, bn.weight, dg)

@@ -33,9 +33,35 @@ def attach_grad_sync(sync):
         GRAD_SYNC[p] = sync
 
 
+# ``p._hrv_flat_grad``: the parameter's slot in the fused optimizer's flat gradient buffer (optim.Adam sets the
+# attribute at its first step).  Backward plans produce a gradient directly in that slot and hand it over as ``p.grad``: no autograd
+# accumulation copy, no gather copy in the optimizer (~1000 tiny copy launches per iteration otherwise).
+def flat_grad_slot(p: nn.Parameter) -> Optional[torch.Tensor]:
+    return getattr(p, "_hrv_flat_grad", None)
+
+
+def grad_buffer(p: nn.Parameter) -> torch.Tensor:
+    """Where the gradient of ``p`` should be written: its flat-buffer slot when it is free this iteration."""
+    v = flat_grad_slot(p)
+    if v is not None and p.grad is None:
+        return v
+    return torch.empty_like(p.data)
+
+
 def _acc(grads: Grads, p: nn.Parameter, g: torch.Tensor):
-    assert p not in grads, "each parameter is used once per forward on this path"
-    grads[p] = g
+    v = flat_grad_slot(p)
+    if v is not None:
+        if p.grad is None:
+            if g.data_ptr() != v.data_ptr():
+                v.copy_(g.reshape(v.shape))
+            p.grad = v
+            g = v
+        else:                       # a second contribution before the optimizer step (e.g. D(fake), D(real))
+            p.grad.add_(g.reshape(p.grad.shape))
+            g = p.grad
+    else:
+        assert p not in grads, "each parameter is used once per forward on this path"
+        grads[p] = g
     s = GRAD_SYNC.get(p)
     if s is not None:
         s.on_grad(p, g)
@@ -78,19 +104,19 @@ class TConv:
         w = self.wparam.data
         Cout, cin, KH, KW = w.shape
         if need_w:
-            G = torch.empty_like(w)
+            G = torch.empty_like(w) if self.spectral else grad_buffer(self.wparam)
             base = 0
             for a, up in srcs:
                 T.conv_wgrad(dy, a, up, base, cin, KH, KW, self.stride, self.pad, G, name=self.name + ".wgrad")
                 base += a.C
             if self.spectral:
-                dwo = torch.empty_like(w)
+                dwo = grad_buffer(self.wparam)
                 T.spectral_grad(G, w, self.u, self.v, self.sigma, dwo)
                 _acc(grads, self.wparam, dwo)
             else:
                 _acc(grads, self.wparam, G)
             if self.bparam is not None:
-                _acc(grads, self.bparam, T.colsum(dy))
+                _acc(grads, self.bparam, T.colsum(dy, out=grad_buffer(self.bparam)))
         if not need_dx:
             return None
         a0, up0 = srcs[0]
@@ -173,7 +199,7 @@ class SpadeT:
                              noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dx=dx,
                              dx_accumulate=dx_accumulate, dnoise_scale=dns)
         if dns is not None:
-            _acc(grads, n.noise_scale, dns[:C_].clone())
+            _acc(grads, n.noise_scale, dns[:C_])
         else:
             _acc(grads, n.noise_scale, torch.zeros(C_, device=dev))
         # gamma/beta convs: one conv with Wcat = [Wgamma ; Wbeta] over dgb = [dgamma | dbeta]
@@ -183,11 +209,13 @@ class SpadeT:
         wcat[Cp:Cp + C_] = n.conv_beta.weight.data
         dwcat = torch.empty_like(wcat)
         T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad")
-        _acc(grads, n.conv_gamma.weight, dwcat[:C_].clone())
-        _acc(grads, n.conv_beta.weight, dwcat[Cp:Cp + C_].clone())
+        direct = flat_grad_slot(n.conv_gamma.weight) is not None
+        keep = (lambda t: t) if direct else (lambda t: t.clone())     # slices are copied into the flat slots by _acc
+        _acc(grads, n.conv_gamma.weight, keep(dwcat[:C_]))
+        _acc(grads, n.conv_beta.weight, keep(dwcat[Cp:Cp + C_]))
         db = T.colsum(dgb)
-        _acc(grads, n.conv_gamma.bias, db[:C_].clone())
-        _acc(grads, n.conv_beta.bias, db[Cp:Cp + C_].clone())
+        _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
+        _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
         # d actv, with the ReLU derivative of conv_shared fused (slope 0)
         dact = T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, name=self.name + ".gb.dgrad")
         self.shared.backward(dact, [(ctx["seg"], -ctx["seg_shift"])], grads, need_dx=False)

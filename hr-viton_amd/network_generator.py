@@ -289,7 +289,7 @@ class SPADEGenerator(BaseNetwork):
         return P
 
     def _get_plan(self, device):
-        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.WEIGHTS_EPOCH[0],
+        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.weights_epoch(self.parameters()),
                self._use_bf16())
         if self._plan is None or self._plan_key != key:
             self._plan = self._build_plan(device)
@@ -435,7 +435,7 @@ class NLayerDiscriminator(BaseNetwork):
         return plan
 
     def _get_plan(self, device):
-        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.WEIGHTS_EPOCH[0])
+        key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.weights_epoch(self.parameters()))
         if self._plan is None or self._plan_key != key:
             self._plan = self._build_plan(device)
             self._plan_key = key

@@ -173,7 +173,7 @@ class ConditionGenerator(nn.Module):
         return P
 
     def _get_plan(self, device):
-        key = (str(device), self._state_version(), ops.WEIGHTS_EPOCH[0])
+        key = (str(device), self._state_version(), ops.weights_epoch(self.parameters()))
         if self._plan is None or self._plan_key != key:
             self._plan = self._build_plan(device)
             self._plan_key = key

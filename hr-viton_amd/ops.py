@@ -20,7 +20,14 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, HrvError  # noqa: F40
 
 # bumped by hr_viton_amd.optim.Adam.step(): the fused Adam kernel writes parameters through raw
 # pointers (no torch version-counter bump), so cached inference plans key on this as well
-WEIGHTS_EPOCH = [0]
+WEIGHTS_EPOCH = [0]     # global step counter of the fused optimizers (per-iteration caches key on it)
+
+
+def weights_epoch(tensors) -> int:
+    """Sum of the per-parameter update counters the fused Adam maintains (``_hrv_epoch``): the fused step writes
+    parameters through raw pointers, which torch's ``_version`` does not see.  A cached plan of a module that no
+    optimizer touches (the frozen tocg inside train_generator.py) therefore stays valid across steps."""
+    return sum(getattr(t, "_hrv_epoch", 0) for t in tensors)
 
 
 def _ceil4(c: int) -> int:

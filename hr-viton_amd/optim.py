@@ -38,6 +38,9 @@ class Adam(torch.optim.Optimizer):
             off += (k + 3) // 4 * 4
         st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w), g=torch.zeros_like(w), spans=spans, step=0)
         self._flat[gi] = st
+        # the backward plans write gradients straight into these slots (gen_train.grad_buffer / _acc)
+        for p, off, k in spans:
+            p._hrv_flat_grad = st["g"][off:off + k].view_as(p.data)
         return st
 
     @torch.no_grad()
@@ -50,17 +53,21 @@ class Adam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             st = self._flat.get(gi) or self._setup(gi, group)
             g = st["g"]
+            base = g.data_ptr()
             for p, off, k in st["spans"]:
                 src = self.grad_sync.grad_of(p) if self.grad_sync is not None else p.grad
                 if src is None:
                     g[off:off + k].zero_()               # torch's Adam skips it; a zero gradient is a no-op here
-                else:
+                elif src.data_ptr() != base + 4 * off:   # already produced in place by the backward plan otherwise
                     g[off:off + k].copy_(src.reshape(-1))
             st["step"] += 1
             b1, b2 = group["betas"]
             T.adam_step(st["w"], g, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                         st["step"], world_scale)
-        ops.WEIGHTS_EPOCH[0] += 1      # cached inference plans (packed weights) are stale now
+        for group in self.param_groups:          # cached inference plans of THESE parameters are stale now
+            for p in group["params"]:
+                p._hrv_epoch = getattr(p, "_hrv_epoch", 0) + 1
+        ops.WEIGHTS_EPOCH[0] += 1
         return loss
 
     # ------------------------------------------------------------------ (de)serialisation
