@@ -121,13 +121,13 @@ def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     crit_vgg = VGGLoss(opt).to(dev)
     for m in (tocg, D, crit_vgg):
         broadcast_module(m)
-    sg = GradSync(tocg.parameters()) if world > 1 else None
-    sd = GradSync(D.parameters()) if world > 1 else None
+    og = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999))
+    od = Adam(D.parameters(), lr=opt.D_lr, betas=(0.5, 0.999))
+    sg = og.make_grad_sync() if world > 1 else None
+    sd = od.make_grad_sync() if world > 1 else None
     for s_ in (sg, sd):
         if s_ is not None:
             attach_grad_sync(s_)
-    og = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999), grad_sync=sg)
-    od = Adam(D.parameters(), lr=opt.D_lr, betas=(0.5, 0.999), grad_sync=sd)
     l1, gan = L1Loss(), GANLoss(use_lsgan=True)
     batch = tc.synthetic_batch(opt, B, hdist.shard_seed(4321, rank), dev)
 
@@ -173,13 +173,13 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
         crit_vgg = VGGLoss(opt).to(dev)
         for m in (gen, dis, crit_vgg):
             broadcast_module(m)
-        sg = GradSync(gen.parameters()) if world > 1 else None
-        sd = GradSync(dis.parameters()) if world > 1 else None
+        og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9))
+        od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9))
+        sg = og.make_grad_sync() if world > 1 else None
+        sd = od.make_grad_sync() if world > 1 else None
         for s_ in (sg, sd):
             if s_ is not None:
                 attach_grad_sync(s_)
-        og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9), grad_sync=sg)
-        od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9), grad_sync=sd)
         cg, cf = GANLoss("hinge"), L1Loss()
 
         def step(_i):

@@ -43,6 +43,16 @@ class Adam(torch.optim.Optimizer):
             p._hrv_flat_grad = st["g"][off:off + k].view_as(p.data)
         return st
 
+    def make_grad_sync(self, bucket_mb: float = 64.0, process_group=None):
+        """Data-parallel gradient synchronisation that all-reduces contiguous slices of THIS optimizer's flat
+        gradient buffer in place (parallel.GradSync): the backward plans write each gradient into its slot, the
+        bucket collectives run on the buffer itself, the fused step reads it -- zero gradient copies."""
+        from .parallel import GradSync
+        assert len(self.param_groups) == 1, "one parameter group per fused optimizer"
+        st = self._flat.get(0) or self._setup(0, self.param_groups[0])
+        self.grad_sync = GradSync(None, bucket_mb, process_group, flat=st["g"], spans=st["spans"])
+        return self.grad_sync
+
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None

@@ -17,32 +17,57 @@ import torch.distributed as dist
 
 
 class GradSync:
-    def __init__(self, params, bucket_mb: float = 64.0, process_group=None):
-        self.params = [p for p in params if p.requires_grad]
+    def __init__(self, params, bucket_mb: float = 64.0, process_group=None, flat: Optional[torch.Tensor] = None,
+                 spans=None):
+        """``flat`` / ``spans`` ([(param, offset, numel)] in buffer order): reduce IN PLACE on the fused optimizer's
+        flat gradient buffer (optim.Adam.make_grad_sync) -- the backward plans already produce every gradient in
+        its slot there, so a bucket is a contiguous slice of that buffer and nothing is copied on either side of
+        the collective.  Without them the buckets own their storage and gradients are copied in (stand-alone use)."""
         self.pg = process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.enabled = True
         cap = int(bucket_mb * (1 << 20) / 4)
-        # backward produces gradients roughly in reverse registration order
-        order = list(reversed(self.params))
         self.buckets: List[dict] = []
-        cur, cur_n = [], 0
-        for p in order:
-            if cur and cur_n + p.numel() > cap:
-                self.buckets.append(dict(params=cur, n=cur_n))
-                cur, cur_n = [], 0
-            cur.append(p)
-            cur_n += p.numel()
-        if cur:
-            self.buckets.append(dict(params=cur, n=cur_n))
         self.where: Dict[torch.nn.Parameter, tuple] = {}
-        for bi, b in enumerate(self.buckets):
-            dev = b["params"][0].device
-            b["flat"] = torch.zeros(b["n"], dtype=torch.float32, device=dev)
-            off = 0
-            for p in b["params"]:
-                self.where[p] = (bi, off, p.numel())
-                off += p.numel()
+        if flat is not None:
+            self.params = [p for p, _, _ in spans]
+            # contiguous ranges of the flat buffer, cut back to front: backward finishes the LAST parameters first,
+            # so the highest range completes (and is all-reduced) first
+            ranges, hi, n = [], len(spans), 0
+            for i in range(len(spans) - 1, -1, -1):
+                n += spans[i][2]
+                if n > cap and hi - i > 1:
+                    ranges.append((i + 1, hi))
+                    hi, n = i + 1, spans[i][2]
+            ranges.append((0, hi))
+            for lo, hi in ranges:
+                a = spans[lo][1]
+                bnd = spans[hi - 1][1] + spans[hi - 1][2]
+                b = dict(params=[sp[0] for sp in spans[lo:hi]], n=bnd - a, flat=flat[a:bnd])
+                for p, off, k in spans[lo:hi]:
+                    self.where[p] = (len(self.buckets), off - a, k)
+                self.buckets.append(b)
+        else:
+            self.params = [p for p in params if p.requires_grad]
+            # backward produces gradients roughly in reverse registration order
+            order = list(reversed(self.params))
+            cur, cur_n = [], 0
+            for p in order:
+                if cur and cur_n + p.numel() > cap:
+                    self.buckets.append(dict(params=cur, n=cur_n))
+                    cur, cur_n = [], 0
+                cur.append(p)
+                cur_n += p.numel()
+            if cur:
+                self.buckets.append(dict(params=cur, n=cur_n))
+            for bi, b in enumerate(self.buckets):
+                dev = b["params"][0].device
+                b["flat"] = torch.zeros(b["n"], dtype=torch.float32, device=dev)
+                off = 0
+                for p in b["params"]:
+                    self.where[p] = (bi, off, p.numel())
+                    off += p.numel()
+        for b in self.buckets:
             b["pending"] = set(b["params"])
             b["handle"] = None
         self.begin()
@@ -67,7 +92,9 @@ class GradSync:
             return
         bi, off, k = self.where[p]
         b = self.buckets[bi]
-        b["flat"][off:off + k].copy_(g.reshape(-1))
+        slot = b["flat"][off:off + k]
+        if g.data_ptr() != slot.data_ptr():     # in-place mode: the plan already wrote the gradient here
+            slot.copy_(g.reshape(-1))
         b["seen"].add(p)
         b["pending"].discard(p)
         if not b["pending"] and b["handle"] is None:

@@ -17,15 +17,15 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, inplace=False):
     try:
-        _worker_body(rank, world, port, q)
+        _worker_body(rank, world, port, q, inplace)
     except Exception as e:  # noqa: BLE001 -- surface the failure instead of a queue timeout
         import traceback
         q.put((rank, "ERROR: " + traceback.format_exc()))
 
 
-def _worker_body(rank, world, port, q):
+def _worker_body(rank, world, port, q, inplace=False):
     sys.path.insert(0, ROOT)
     os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                       MASTER_PORT=str(port))
@@ -40,7 +40,21 @@ def _worker_body(rank, world, port, q):
     net = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 100), torch.nn.Linear(100, 7))
     broadcast_module(net)                           # ... and are made identical
     w0 = net[0].weight.detach().clone()
-    sync = GradSync(net.parameters(), bucket_mb=0.1)   # ~26k floats per bucket -> several buckets
+    if inplace:
+        # what optim.Adam.make_grad_sync sets up on the GPU: one flat gradient buffer (16-byte aligned slots), every
+        # parameter knows its slot, buckets are contiguous slices of the buffer reduced in place
+        plist = list(net.parameters())
+        offs, n = [], 0
+        for p in plist:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(n)
+        spans = [(p, o, p.numel()) for p, o in zip(plist, offs)]
+        for p, o, k in spans:
+            p._hrv_flat_grad = flat[o:o + k].view_as(p.data)
+        sync = GradSync(None, bucket_mb=0.1, flat=flat, spans=spans)
+    else:
+        sync = GradSync(net.parameters(), bucket_mb=0.1)   # ~26k floats per bucket -> several buckets
     attach_grad_sync(sync)
     assert len(sync.buckets) >= 2
     params = list(net.parameters())
@@ -49,9 +63,19 @@ def _worker_body(rank, world, port, q):
     grads = {}
     # the "backward plan": gradients appear in reverse order; the last Linear's bias is unused
     for p in reversed(params[:-1]):
-        _acc(grads, p, torch.full_like(p, float(rank + 1)))
+        if inplace:
+            from hr_viton_amd.gen_train import grad_buffer
+            g = grad_buffer(p)                      # the plan writes the gradient straight into the flat slot
+            assert g.data_ptr() == p._hrv_flat_grad.data_ptr()
+            g.fill_(float(rank + 1))
+            _acc(grads, p, g)
+            assert p.grad is not None and p.grad.data_ptr() == g.data_ptr() and p not in grads
+        else:
+            _acc(grads, p, torch.full_like(p, float(rank + 1)))
         fired_early.append(sum(1 for b in sync.buckets if b["handle"] is not None))
     sync.wait()
+    if inplace:     # the reduced values ARE the flat buffer: nothing was copied out of or into it
+        assert all(sync.grad_of(p).data_ptr() == p._hrv_flat_grad.data_ptr() for p in params[:-1])
     ok = all(torch.allclose(sync.grad_of(p), torch.full_like(p, 3.0)) for p in params[:-1])   # 1 + 2 summed
     unused = sync.grad_of(params[-1])
     q.put((rank, bool(ok), unused is None, fired_early[-1] >= 1 and fired_early[0] == 0 or len(sync.buckets) == 1,
@@ -62,11 +86,15 @@ def _worker_body(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_gradsync_world2_gloo():
+import pytest  # noqa: E402
+
+
+@pytest.mark.parametrize("inplace", [False, True], ids=["own_buckets", "inplace_flat_buffer"])
+def test_gradsync_world2_gloo(inplace):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q, inplace)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted(q.get(timeout=120) for _ in range(2))

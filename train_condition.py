@@ -166,13 +166,13 @@ def main(argv=None):
             crit_vgg.vgg.load_torchvision_state_dict(torch.load(opt.vgg_weights, map_location="cpu"))
         crit_vgg.to(dev)
         broadcast_module(crit_vgg)
-    sync_g = GradSync(tocg.parameters()) if world > 1 else None
-    sync_d = GradSync(D.parameters()) if world > 1 else None
+    opt_g = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999))
+    opt_d = Adam(D.parameters(), lr=opt.D_lr, betas=(0.5, 0.999))
+    sync_g = opt_g.make_grad_sync() if world > 1 else None
+    sync_d = opt_d.make_grad_sync() if world > 1 else None
     for s in (sync_g, sync_d):
         if s is not None:
             attach_grad_sync(s)
-    opt_g = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999), grad_sync=sync_g)
-    opt_d = Adam(D.parameters(), lr=opt.D_lr, betas=(0.5, 0.999), grad_sync=sync_d)
     loader = None
     if not opt.synthetic:
         loader = _rank_loader(opt, per_rank, rank, world)

@@ -159,13 +159,14 @@ def main(argv=None):
         crit_vgg.to(dev)
         broadcast_module(crit_vgg)
 
-    sync_g = GradSync(generator.parameters()) if world > 1 else None
-    sync_d = GradSync(discriminator.parameters()) if world > 1 else None
+    opt_g = Adam(generator.parameters(), lr=opt.G_lr, betas=(0.0, 0.9))
+    opt_d = Adam(discriminator.parameters(), lr=opt.D_lr, betas=(0.0, 0.9))
+    # in-place bucketed all-reduce on the optimizers' flat gradient buffers, fired from inside the backward
+    sync_g = opt_g.make_grad_sync() if world > 1 else None
+    sync_d = opt_d.make_grad_sync() if world > 1 else None
     for s in (sync_g, sync_d):
         if s is not None:
             attach_grad_sync(s)
-    opt_g = Adam(generator.parameters(), lr=opt.G_lr, betas=(0.0, 0.9), grad_sync=sync_g)
-    opt_d = Adam(discriminator.parameters(), lr=opt.D_lr, betas=(0.0, 0.9), grad_sync=sync_d)
     lam = lambda step: 1.0 - max(0, step * 1000 + opt.load_step - opt.keep_step) / float(opt.decay_step + 1)  # noqa: E731
     sched_g = torch.optim.lr_scheduler.LambdaLR(opt_g, lr_lambda=lam)
     sched_d = torch.optim.lr_scheduler.LambdaLR(opt_d, lr_lambda=lam)
