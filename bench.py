@@ -107,7 +107,7 @@ def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.losses import L1Loss
     from hr_viton_amd.networks import ConditionGenerator, GANLoss, VGGLoss, define_D
     from hr_viton_amd.optim import Adam
-    from hr_viton_amd.parallel import GradSync, broadcast_module
+    from hr_viton_amd.parallel import broadcast_module
     from hr_viton_amd.pipeline import condition_train_step
     B = args.batch or 8
     opt = tc.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world), "--fine_height", "1024", "--fine_width",
@@ -148,7 +148,7 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.network_generator import MultiscaleDiscriminator, SPADEGenerator
     from hr_viton_amd.networks import ConditionGenerator
     from hr_viton_amd.optim import Adam
-    from hr_viton_amd.parallel import GradSync, broadcast_module
+    from hr_viton_amd.parallel import broadcast_module
     from hr_viton_amd.pipeline import generator_train_step, make_generator_inputs, tryon_step
     from hr_viton_amd.vgg import VGGLoss
     if args.workload == "train_condition":

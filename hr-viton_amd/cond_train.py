@@ -15,7 +15,7 @@ running_mean / running_var / num_batches_tracked are updated in place like nn.Ba
 """
 from __future__ import annotations
 
-from typing import Callable, Dict, List, Optional, Sequence, Tuple
+from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
 import torch.nn as nn
@@ -23,7 +23,7 @@ import torch.nn as nn
 from . import _lib, ops
 from . import train_ops as T
 from .gen_train import DiscTrainPlan, Grads, TConv, _acc, grad_buffer
-from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Act, _stream
+from .ops import ACT_NONE, ACT_RELU, Act, _stream
 
 
 class Var:

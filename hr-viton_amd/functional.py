@@ -13,7 +13,7 @@ csrc/cond_train.hip / csrc/glue.hip through the C ABI.  No CPU fallback.
 """
 from __future__ import annotations
 
-from typing import Optional, Sequence, Tuple, Union
+from typing import Optional, Sequence, Union
 
 import torch
 

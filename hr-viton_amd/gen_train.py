@@ -23,14 +23,17 @@ from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, Act, _ceil4
 Grads = Dict[nn.Parameter, torch.Tensor]
 
 
-# parameter -> GradSync: the backward plan reports every finished gradient so its bucket's
-# all-reduce can start while the rest of the backward is still running (parallel.py)
-GRAD_SYNC: Dict[nn.Parameter, object] = {}
-
-
+# ``p._hrv_grad_sync``: the GradSync a parameter reports to -- the backward plan announces every finished
+# gradient so its bucket's all-reduce can start while the rest of the backward is still running (parallel.py)
 def attach_grad_sync(sync):
     for p in sync.params:
-        GRAD_SYNC[p] = sync
+        p._hrv_grad_sync = sync
+
+
+def detach_grad_sync(params):
+    for p in params:
+        if hasattr(p, "_hrv_grad_sync"):
+            del p._hrv_grad_sync
 
 
 # ``p._hrv_flat_grad``: the parameter's slot in the fused optimizer's flat gradient buffer (optim.Adam sets the
@@ -62,7 +65,7 @@ def _acc(grads: Grads, p: nn.Parameter, g: torch.Tensor):
     else:
         assert p not in grads, "each parameter is used once per forward on this path"
         grads[p] = g
-    s = GRAD_SYNC.get(p)
+    s = getattr(p, "_hrv_grad_sync", None)
     if s is not None:
         s.on_grad(p, g)
 

@@ -5,9 +5,7 @@ merge, high-resolution cloth warp, occlusion handling.  No host round trips (the
 reference's ``.cpu().numpy() > 0.5`` becomes a device-side compare)."""
 from __future__ import annotations
 
-import ctypes as C
-import math
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

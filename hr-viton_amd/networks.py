@@ -16,13 +16,13 @@ There is no CPU fallback: CPU tensors raise (ops.require_cuda).
 from __future__ import annotations
 
 import os
-from typing import List, Optional
+from typing import List
 
 import torch
 import torch.nn as nn
 
 from . import ops
-from .ops import ACT_NONE, ACT_RELU, Act, ConvLayer, TapConvLayer
+from .ops import ACT_RELU, Act, ConvLayer, TapConvLayer
 
 
 class ResBlock(nn.Module):

@@ -4,7 +4,6 @@ first step; gradients are gathered into a flat buffer (or taken from a ``GradSyn
 buckets).  LambdaLR and friends work unchanged (it is a torch.optim.Optimizer)."""
 from __future__ import annotations
 
-from typing import Optional
 
 import torch
 

@@ -4,7 +4,7 @@ weight gradient, bias gradient.  Everything is NHWC fp32 ``Act`` views like ops.
 from __future__ import annotations
 
 import ctypes as C
-from typing import List, Optional, Sequence, Tuple
+from typing import Optional, Sequence, Tuple
 
 import torch
 

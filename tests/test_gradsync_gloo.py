@@ -33,7 +33,7 @@ def _worker_body(rank, world, port, q, inplace=False):
     import torch.distributed as dist
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd import dist as hdist
-    from hr_viton_amd.gen_train import GRAD_SYNC, _acc, attach_grad_sync
+    from hr_viton_amd.gen_train import _acc, attach_grad_sync, detach_grad_sync
     from hr_viton_amd.parallel import GradSync, broadcast_module
     hdist.init_from_env("gloo")
     torch.manual_seed(rank)                         # replicas start different ...
@@ -80,8 +80,7 @@ def _worker_body(rank, world, port, q, inplace=False):
     unused = sync.grad_of(params[-1])
     q.put((rank, bool(ok), unused is None, fired_early[-1] >= 1 and fired_early[0] == 0 or len(sync.buckets) == 1,
            float(w0.sum()), sync.world))
-    for p in params:
-        GRAD_SYNC.pop(p, None)
+    detach_grad_sync(params)
     dist.barrier()
     dist.destroy_process_group()
 

@@ -33,7 +33,7 @@ from hr_viton_amd.losses import L1Loss  # noqa: E402
 from hr_viton_amd.networks import (ConditionGenerator, GANLoss, VGGLoss, define_D, load_checkpoint,  # noqa: E402
                                    save_checkpoint)
 from hr_viton_amd.optim import Adam  # noqa: E402
-from hr_viton_amd.parallel import GradSync, broadcast_module  # noqa: E402
+from hr_viton_amd.parallel import broadcast_module  # noqa: E402
 from hr_viton_amd.pipeline import condition_train_step  # noqa: E402
 
 

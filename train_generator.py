@@ -35,7 +35,7 @@ from hr_viton_amd.losses import GANLoss, L1Loss  # noqa: E402
 from hr_viton_amd.network_generator import MultiscaleDiscriminator, SPADEGenerator  # noqa: E402
 from hr_viton_amd.networks import ConditionGenerator  # noqa: E402
 from hr_viton_amd.optim import Adam  # noqa: E402
-from hr_viton_amd.parallel import GradSync, broadcast_module  # noqa: E402
+from hr_viton_amd.parallel import broadcast_module  # noqa: E402
 from hr_viton_amd.pipeline import generator_train_step, make_generator_inputs  # noqa: E402
 from hr_viton_amd.vgg import VGGLoss  # noqa: E402
 
