@@ -87,6 +87,8 @@ struct WgradParams {
   int CinTot;
   int co_tiles, ci_tiles, taps, S;
   float* ws;        // [S][taps][Cout][CinTot]  (only this source's ci range is written)
+  float* bias_ws;   // [S][Cout] partial column sums of dY (bias gradient), or null: computed as one extra
+                    // "ones" column right after the (tap, ci) columns -- same MFMAs, same fixed reduction order
 };
 
 template <int TM, int TN, int WM, int WN>
@@ -120,7 +122,9 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
   // every X load of a thread has the same column group (256 % (BNc/4) == 0) -> one (tap, ci) per thread
   static_assert(256 % (BNc / 4) == 0, "column group of a thread must not depend on the load index");
   const int my_col = col0 + (tid % (BNc / 4)) * 4;
-  const bool col_ok = my_col < p.taps * p.x_C;
+  const int NT = p.taps * p.x_C;
+  const bool ones_col = p.bias_ws != nullptr && my_col == NT;   // this thread's 4 columns are (1, 0, 0, 0)
+  const bool col_ok = my_col < NT;
   const int my_tap = col_ok ? my_col / p.x_C : 0;
   const int my_ci = col_ok ? my_col - my_tap * p.x_C : 0;
   const int kh = my_tap / p.KW, kw = my_tap - kh * p.KW;
@@ -174,6 +178,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
                          p.x_co + my_ci;                                                                  \
       f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                               \
       _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                               \
+      if (ones_col) v[0] = (idx < BK * BNc / 4 && pix < p.P) ? 1.f : 0.f;                                 \
       xreg[r] = v;                                                                                        \
       /* advance this row by BK pixels for the next tile */                                               \
       int w2 = wo + BK, h2 = ho, n2 = n;                                                                  \
@@ -233,6 +238,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_mfma_kernel(const WgradParams 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col0 + (wn * TN + j) * 32 + l31;
+    if (col == p.taps * p.x_C && p.bias_ws) {   // the ones column: sum over this slab's pixels of dY[:, co]
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+          if (co < p.Cout) p.bias_ws[(size_t)s * p.Cout + co] = acc[i][j][e];
+        }
+      continue;
+    }
     if (col >= p.taps * p.x_C) continue;
     const int tap = col / p.x_C, ci = col - tap * p.x_C;
     if (ci >= p.ci_real) continue;
@@ -293,13 +308,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
 
   // X tasks: task = (quad q in 0..7, column group g); every task of a thread has its own (tap, ci)
   int xq[XT], xtap_kh[XT], xtap_kw[XT], xci[XT], xn[XT], xho[XT], xwo[XT];
-  bool xcol_ok[XT];
+  bool xcol_ok[XT], xones[XT];
 #pragma unroll
   for (int r = 0; r < XT; ++r) {
     const int task = tid + 256 * r;
     const int g = task % XG;
     xq[r] = task / XG;
     const int col = col0 + g * 4;
+    xones[r] = p.bias_ws != nullptr && task < 8 * XG && col == p.taps * p.x_C;
     xcol_ok[r] = task < 8 * XG && col < p.taps * p.x_C;
     const int tap = xcol_ok[r] ? col / p.x_C : 0;
     xci[r] = xcol_ok[r] ? col - tap * p.x_C : 0;
@@ -350,6 +366,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
         const size_t off = (rowoff + ((wic >> sr) << sl)) * p.x_cs + p.x_co + xci[r];                     \
         f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                             \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                             \
+        if (xones[r]) v[0] = pix < p.P ? 1.f : 0.f;                                                       \
         xreg[r][j] = v;                                                                                   \
       }                                                                                                   \
       /* advance the quad by BKP pixels for the next tile (Wo % 4 == 0: it stays inside one image row) */ \
@@ -426,6 +443,16 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int col = col0 + (wn * TN + j) * 32 + l31;
+    if (col == p.taps * p.x_C && p.bias_ws) {   // the ones column: bias-gradient partial of this slab
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const int co = co0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+          if (co < p.Cout) p.bias_ws[(size_t)s * p.Cout + co] = acc[i][j][e];
+        }
+      continue;
+    }
     if (col >= p.taps * p.x_C) continue;
     const int tap = col / p.x_C, ci = col - tap * p.x_C;
     if (ci >= p.ci_real) continue;
@@ -454,6 +481,16 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int tap
     float* dst = dw + ((size_t)co * CinTot + ci_base + ci) * taps + tap;
     *dst = accumulate ? *dst + sum : sum;
   }
+}
+
+// db[co] (+)= sum_s bias_ws[s][co]   (fixed order)
+__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bws, int S, int Cout, float* __restrict__ db,
+                                         int accumulate) {
+  const int co = blockIdx.x * blockDim.x + threadIdx.x;
+  if (co >= Cout) return;
+  float sum = 0.f;
+  for (int s = 0; s < S; ++s) sum += bws[(size_t)s * Cout + co];
+  db[co] = accumulate ? db[co] + sum : sum;
 }
 
 // ------------------------------------------------------------------ column sums (bias gradient)
@@ -627,14 +664,15 @@ extern "C" int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot
   const int64_t ptiles = (P + BK - 1) / BK;
   int64_t S = ptiles / 4 < 1 ? 1 : ptiles / 4;
   if (S > 256) S = 256;
-  return S * KH * KW * (int64_t)Cout * CinTot * (int64_t)sizeof(float);
+  return (S * KH * KW * (int64_t)Cout * CinTot + 256 * (int64_t)Cout) * (int64_t)sizeof(float);   // + bias partials
 }
 
 static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x, int32_t x_C,
                       int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real, int32_t ci_base,
                       int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
                       int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes, float* dw_oihw,
-                      int32_t accumulate, hrv_stream_t stream, const bool mma_bf16) {
+                      int32_t accumulate, float* dbias, int32_t dbias_accumulate, hrv_stream_t stream,
+                      const bool mma_bf16) {
   HRV_REQUIRE(dy && x && workspace && dw_oihw, "wgrad: null pointer");
   HRV_REQUIRE(Cout > 0 && x_C > 0 && x_C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 && dy_cstride % 4 == 0 &&
                   dy_coff % 4 == 0 && x_C_real > 0 && x_C_real <= x_C && ci_base >= 0 && ci_base + x_C_real <= CinTot,
@@ -650,7 +688,8 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   const int wt = pick_wtile(Cout, x_C);
   const int bm = wt_bm(wt), bn = wt_bn(wt);
   p.taps = KH * KW;
-  p.co_tiles = (Cout + bm - 1) / bm; p.ci_tiles = (p.taps * x_C + bn - 1) / bn;   // column tiles over (tap, ci)
+  // column tiles over (tap, ci) (+ the "ones" column group of the fused bias gradient)
+  p.co_tiles = (Cout + bm - 1) / bm; p.ci_tiles = (p.taps * x_C + (dbias ? 4 : 0) + bn - 1) / bn;
   const int tiles = p.co_tiles * p.ci_tiles;
   HRV_REQUIRE(!mma_bf16 || Wo % 4 == 0, "wgrad (bf16 matrix cores): Wo must be a multiple of 4 (got %d)", Wo);
   const int ptiles = mma_bf16 ? (p.P + BKP - 1) / BKP : (p.P + BK - 1) / BK;
@@ -658,9 +697,10 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   if (S > ptiles / 4) S = ptiles / 4;
   if (S > 256) S = 256;
   if (S < 1) S = 1;
-  const int64_t need = (int64_t)S * p.taps * Cout * CinTot * (int64_t)sizeof(float);
+  const int64_t need = ((int64_t)S * p.taps * Cout * CinTot + (dbias ? (int64_t)S * Cout : 0)) * (int64_t)sizeof(float);
   HRV_REQUIRE(workspace_bytes >= need, "wgrad: workspace too small (%lld < %lld)", (long long)workspace_bytes, (long long)need);
   p.S = S; p.ws = workspace;
+  p.bias_ws = dbias ? workspace + (size_t)S * p.taps * Cout * CinTot : nullptr;
   hipStream_t st = (hipStream_t)stream;
   const int nblk = tiles * S;
 #define WG_CASE(I, A, B, Cc, D)                                                                                   \
@@ -682,7 +722,11 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   const size_t total = (size_t)Cout * x_C_real * p.taps;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, workspace, S, p.taps, Cout, CinTot,
                      ci_base, x_C_real, dw_oihw, accumulate);
-  return check_launch("wgrad_reduce_kernel");
+  rc = check_launch("wgrad_reduce_kernel");
+  if (rc || !dbias) return rc;
+  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Cout + 127) / 128), dim3(128), 0, st, p.bias_ws, S, Cout, dbias,
+                     dbias_accumulate);
+  return check_launch("wgrad_bias_reduce_kernel");
 }
 
 extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
@@ -690,9 +734,11 @@ extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, in
                                          int32_t x_up_shift, int32_t x_C_real, int32_t ci_base, int32_t CinTot,
                                          int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
                                          int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes,
-                                         float* dw_oihw, int32_t accumulate, hrv_stream_t stream) {
+                                         float* dw_oihw, int32_t accumulate, float* dbias, int32_t dbias_accumulate,
+                                         hrv_stream_t stream) {
   return wgrad_impl(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base, CinTot, N, H,
-                    W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, stream, false);
+                    W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, dbias,
+                    dbias_accumulate, stream, false);
 }
 
 // Same contract on the bf16 matrix cores (operands rounded to bf16 while staged, fp32 accumulate): the weight
@@ -703,9 +749,10 @@ extern "C" int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cst
                                                  int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH,
                                                  int32_t KW, int32_t stride, int32_t pad, float* workspace,
                                                  int64_t workspace_bytes, float* dw_oihw, int32_t accumulate,
-                                                 hrv_stream_t stream) {
+                                                 float* dbias, int32_t dbias_accumulate, hrv_stream_t stream) {
   return wgrad_impl(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base, CinTot, N, H,
-                    W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, stream, true);
+                    W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, dbias,
+                    dbias_accumulate, stream, true);
 }
 
 extern "C" int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,

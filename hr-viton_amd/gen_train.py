@@ -108,9 +108,12 @@ class TConv:
         Cout, cin, KH, KW = w.shape
         if need_w:
             G = torch.empty_like(w) if self.spectral else grad_buffer(self.wparam)
+            db = grad_buffer(self.bparam) if self.bparam is not None else None
             base = 0
             for a, up in srcs:
-                T.conv_wgrad(dy, a, up, base, cin, KH, KW, self.stride, self.pad, G, name=self.name + ".wgrad")
+                # the bias gradient rides along with the first source as a ones-column of the same MFMA reduction
+                T.conv_wgrad(dy, a, up, base, cin, KH, KW, self.stride, self.pad, G, name=self.name + ".wgrad",
+                             dbias=db if base == 0 else None)
                 base += a.C
             if self.spectral:
                 dwo = grad_buffer(self.wparam)
@@ -118,8 +121,8 @@ class TConv:
                 _acc(grads, self.wparam, dwo)
             else:
                 _acc(grads, self.wparam, G)
-            if self.bparam is not None:
-                _acc(grads, self.bparam, T.colsum(dy, out=grad_buffer(self.bparam)))
+            if db is not None:
+                _acc(grads, self.bparam, db)
         if not need_dx:
             return None
         a0, up0 = srcs[0]
@@ -211,12 +214,12 @@ class SpadeT:
         wcat[:C_] = n.conv_gamma.weight.data
         wcat[Cp:Cp + C_] = n.conv_beta.weight.data
         dwcat = torch.empty_like(wcat)
-        T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad")
+        db = torch.empty(2 * Cp, device=dev)
+        T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad", dbias=db)
         direct = flat_grad_slot(n.conv_gamma.weight) is not None
         keep = (lambda t: t) if direct else (lambda t: t.clone())     # slices are copied into the flat slots by _acc
         _acc(grads, n.conv_gamma.weight, keep(dwcat[:C_]))
         _acc(grads, n.conv_beta.weight, keep(dwcat[Cp:Cp + C_]))
-        db = T.colsum(dgb)
         _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
         _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
         # d actv, with the ReLU derivative of conv_shared fused (slope 0)

@@ -152,8 +152,10 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
 
 
 def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, KW: int, stride: int, pad: int,
-               dw: torch.Tensor, accumulate: bool = False, name: str = "wgrad"):
-    """dW[:, ci_base:ci_base+x.C] (+)= wgrad(dY, x) -- hrv_conv2d_wgrad_nhwc_f32.  ``dw``: OIHW fp32 device."""
+               dw: torch.Tensor, accumulate: bool = False, name: str = "wgrad", dbias: Optional[torch.Tensor] = None,
+               dbias_accumulate: bool = False):
+    """dW[:, ci_base:ci_base+x.C] (+)= wgrad(dY, x) -- hrv_conv2d_wgrad_nhwc_f32.  ``dw``: OIHW fp32 device.
+    ``dbias`` ([Cout], optional): the bias gradient, fused as a ones-column of the same reduction."""
     lib = _lib.load()
     N, Ho, Wo, Cout = dy.N, dy.H, dy.W, dy.C
     H, W = (x.H << x_up, x.W << x_up) if x_up >= 0 else (x.H >> -x_up, x.W >> -x_up)
@@ -167,7 +169,8 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
         _lib.check(fn(dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp,
                                                  x.cstride, x.coff, x_up, x.C, ci_base, cin_tot, N, H, W, Ho, Wo, KH, KW,
                                                  stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
-                                                 1 if accumulate else 0, _stream()), "hrv_conv2d_wgrad_nhwc_f32")
+                                                 1 if accumulate else 0, None if dbias is None else dbias.data_ptr(),
+                                                 1 if dbias_accumulate else 0, _stream()), "hrv_conv2d_wgrad_nhwc_f32")
 
 
 def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:

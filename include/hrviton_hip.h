@@ -190,14 +190,18 @@ int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_co
                               int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
                               int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                               int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,
-                              int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, hrv_stream_t stream);
-/* Same contract with the operands rounded to bf16 while staged and multiplied on v_mfma_f32_32x32x16_bf16 (fp32
+                              int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, float* dbias,
+                              int32_t dbias_accumulate, hrv_stream_t stream);
+/* dbias (optional, [Cout]): the bias gradient sum_pixels dY[:, co], fused as one extra "ones" column of the same
+ * MFMA reduction (no second pass over dY; deterministic).  Pass it with the FIRST source of a concatenation only.
+ * Same contract with the operands rounded to bf16 while staged and multiplied on v_mfma_f32_32x32x16_bf16 (fp32
  * accumulate): the weight gradient of mixed-precision training.  Requires Wo % 4 == 0. */
 int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
                               int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
                               int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo,
                               int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,
-                              int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, hrv_stream_t stream);
+                              int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, float* dbias,
+                              int32_t dbias_accumulate, hrv_stream_t stream);
 int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,
                         int64_t workspace_bytes, float* out, int32_t accumulate, hrv_stream_t stream);
 

@@ -340,3 +340,32 @@ def test_mixed_precision_wgrad(case):
     got = dw[:, 4:4 + cin].cpu()
     assert (got - ref).abs().max() <= 3e-5 * ref.abs().max() + 1e-5, ((got - ref).abs().max(), ref.abs().max())
     assert dw[:, :4].abs().max() == 0 and dw[:, 4 + cin:].abs().max() == 0
+
+
+@pytest.mark.parametrize("mixed", [False, True], ids=["fp32", "bf16mma"])
+@pytest.mark.parametrize("cin,cout,k", [(128, 48, 3), (24, 130, 3), (64, 64, 1)], ids=["exact_fit_extra_tile", "free_slot", "1x1"])
+def test_wgrad_fused_bias_gradient(mixed, cin, cout, k):
+    """dbias = sum over pixels of dY, produced by the weight-gradient kernel itself as a ones-column of the same
+    MFMA reduction (also when taps*Cin exactly fills the column tiles and the column needs a tile of its own)."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(cin + cout)
+    N, H, W = 2, 8, 12
+    x = torch.randn(N, cin, H, W, generator=g)
+    dy = torch.randn(N, cout, H, W, generator=g)
+    rb = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mixed else (lambda t: t)
+    want_w = torch.nn.grad.conv2d_weight(rb(x), (cout, cin, k, k), rb(dy), stride=1, padding=k // 2)
+    want_b = rb(dy).sum((0, 2, 3))
+    dw = torch.empty(cout, cin, k, k, device="cuda")
+    db = torch.full((cout,), 7.0, device="cuda")
+    T.MMA_BF16[0] = mixed
+    try:
+        T.conv_wgrad(ops.to_nhwc(dy.cuda()), ops.to_nhwc(x.cuda()), 0, 0, cin, k, k, 1, k // 2, dw, dbias=db)
+        db2 = db.clone()
+        T.conv_wgrad(ops.to_nhwc(dy.cuda()), ops.to_nhwc(x.cuda()), 0, 0, cin, k, k, 1, k // 2, dw, dbias=db2,
+                     dbias_accumulate=True)
+    finally:
+        T.MMA_BF16[0] = False
+    tol = 3e-5
+    assert (dw.cpu() - want_w).abs().max() <= tol * want_w.abs().max() + 1e-5
+    assert (db.cpu() - want_b).abs().max() <= tol * want_b.abs().max() + 1e-5
+    assert (db2.cpu() - 2 * want_b).abs().max() <= 2 * tol * want_b.abs().max() + 1e-5
