@@ -433,11 +433,17 @@ class DiscTrainPlan:
             a = f
         return feats, ctx
 
-    def backward(self, ctx, dfeats: List[Optional[Act]], grads: Grads, need_dx: bool) -> Optional[Act]:
+    def backward(self, ctx, dfeats: List[Optional[Act]], grads: Grads, need_dx: bool, rows: Optional[int] = None) -> Optional[Act]:
+        """``rows``: only the first ``rows`` samples of the batch carry a gradient (the fake half in the
+        generator step: the real half is a detached target) -- every saved tensor is cut to that prefix."""
+        def cut(a):
+            if rows is None or a is None:
+                return a
+            return Act(a.t[:rows], a.C, a.coff) if isinstance(a, Act) else a[:rows]
         d_next: Optional[Act] = None   # gradient flowing back into feats[i] from layer i+1
         for i in range(len(self.layers) - 1, -1, -1):
             kind, conv = self.layers[i]
-            c = ctx[i]
+            c = {k: cut(v) for k, v in ctx[i].items()}
             d = dfeats[i]
             if d is None and d_next is None:
                 continue
@@ -473,12 +479,14 @@ class MultiscaleDTrainPlan:
                 a = ops.avgpool3x3s2(a)
         return feats_all, dict(ctxs=ctxs, inputs=inputs)
 
-    def backward(self, ctx, dfeats_all, need_dx: bool):
+    def backward(self, ctx, dfeats_all, need_dx: bool, rows: Optional[int] = None):
         grads: Grads = {}
         d_in_next: Optional[Act] = None
         for k in range(len(self.plans) - 1, -1, -1):
             a = ctx["inputs"][k]
-            d_a = self.plans[k].backward(ctx["ctxs"][k], dfeats_all[k], grads, need_dx)
+            if rows is not None:
+                a = Act(a.t[:rows], a.C, a.coff)
+            d_a = self.plans[k].backward(ctx["ctxs"][k], dfeats_all[k], grads, need_dx, rows)
             if need_dx:
                 if d_a is None:
                     d_a = Act(torch.zeros_like(a.t), a.C)
@@ -488,33 +496,91 @@ class MultiscaleDTrainPlan:
         return grads, d_in_next
 
 
+def _nchw_view(f: Act) -> torch.Tensor:
+    """NHWC activation as an NCHW tensor: a zero-copy channels-last view when no channel padding is involved."""
+    if f.coff == 0 and f.C == f.cstride:
+        return f.t.permute(0, 3, 1, 2)
+    return ops.to_nchw(f)
+
+
+def _nhwc_act(d: torch.Tensor, C: int) -> Act:
+    """Incoming NCHW gradient as an NHWC Act: zero-copy when it is channels-last (as the HIP losses return it)."""
+    if d.dim() == 4 and d.shape[1] == _ceil4(C) == C and d.is_contiguous(memory_format=torch.channels_last) \
+            and not d.is_contiguous():
+        return Act(d.permute(0, 2, 3, 1), C)
+    return ops.to_nhwc(d.contiguous())
+
+
 class _DiscFn(torch.autograd.Function):
+    """outputs: per scale, per layer the feature map -- or, with ``split``, its fake (first) half and its real
+    (second) half as two outputs, so the training script needs no torch slicing and the backward sees directly
+    which half carries a gradient (generator step: the fake half only -> half-batch backward)."""
+
     @staticmethod
-    def forward(ctx, msd, plan, inp, *params):
+    def forward(ctx, msd, plan, inp, split, *params):
         feats_all, saved = plan.forward(inp, power_iteration=True)
-        ctx.plan, ctx.saved, ctx.params = plan, saved, params
+        ctx.plan, ctx.saved, ctx.params, ctx.split = plan, saved, params, split
         ctx.shapes = [[(f.N, f.H, f.W, f.C) for f in fs] for fs in feats_all]
-        outs = tuple(ops.to_nchw(f) for fs in feats_all for f in fs)
-        return outs
+        ctx.in_shape = tuple(inp.shape)
+        outs = []
+        for fs in feats_all:
+            for f in fs:
+                v = _nchw_view(f)
+                if split:
+                    h = v.shape[0] // 2
+                    outs += [v[:h], v[h:]]
+                else:
+                    outs.append(v)
+        return tuple(outs)
 
     @staticmethod
     def backward(ctx, *d_outs):
         it = iter(d_outs)
-        dfeats_all = []
-        for fs in ctx.shapes:
-            row = []
-            for _ in fs:
-                d = next(it)
-                row.append(None if d is None else ops.to_nhwc(d.contiguous()))
-            dfeats_all.append(row)
+        dfeats_all, rows = [], None
+        if ctx.split:
+            pairs = [[(next(it), next(it)) for _ in fs] for fs in ctx.shapes]
+            only_fake = all(dr is None for fs in pairs for _, dr in fs)
+            half = ctx.shapes[0][0][0] // 2
+            rows = half if only_fake else None
+            for fs, shp in zip(pairs, ctx.shapes):
+                row = []
+                for (df, dr), (n, h, w, c) in zip(fs, shp):
+                    if df is None and dr is None:
+                        row.append(None)
+                    elif only_fake:
+                        row.append(_nhwc_act(df, c))
+                    else:   # both halves (discriminator step: hinge terms on the last, tiny, maps)
+                        full = ops.alloc(n, h, w, c, (df if df is not None else dr).device)
+                        full.t.zero_()
+                        if df is not None:
+                            T.add_slice(_nhwc_act(df, c), Act(full.t[:half], c), False)
+                        if dr is not None:
+                            T.add_slice(_nhwc_act(dr, c), Act(full.t[half:], c), False)
+                        row.append(full)
+                dfeats_all.append(row)
+        else:
+            for fs in ctx.shapes:
+                row = []
+                for (n, h, w, c) in fs:
+                    d = next(it)
+                    row.append(None if d is None else _nhwc_act(d, c))
+                dfeats_all.append(row)
         need_dx = ctx.needs_input_grad[2]
-        grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx)
+        grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx, rows)
         ctx.saved = None
-        d_inp = ops.to_nchw(d_in) if (need_dx and d_in is not None) else None
-        return (None, None, d_inp) + tuple(grads.get(p) for p in ctx.params)
+        d_inp = None
+        if need_dx and d_in is not None:
+            d_inp = ops.to_nchw(d_in)
+            if rows is not None:      # the real half of the input gets a zero gradient
+                full = torch.zeros(ctx.in_shape, dtype=d_inp.dtype, device=d_inp.device)
+                full[:rows] = d_inp
+                d_inp = full
+        return (None, None, d_inp, None) + tuple(grads.get(p) for p in ctx.params)
 
 
-def discriminator_train_forward(msd: nn.Module, inp: torch.Tensor):
+def discriminator_train_forward(msd: nn.Module, inp: torch.Tensor, split: bool = False):
+    """``split``: the batch is [fake ; real] (train_generator.py:283-295); returns (pred_fake, pred_real), each a
+    list (scales) of lists (layers), as zero-copy halves of the feature maps."""
     ops.require_cuda(inp, "MultiscaleDiscriminator.forward")
     plan = getattr(msd, "_train_plan", None)
     if plan is None:
@@ -523,11 +589,19 @@ def discriminator_train_forward(msd: nn.Module, inp: torch.Tensor):
     nD = len(plan.plans)
     if not torch.is_grad_enabled():
         feats_all, _ = plan.forward(inp, power_iteration=True)
-        flat = [ops.to_nchw(f) for fs in feats_all for f in fs]
+        flat = []
+        for fs in feats_all:
+            for f in fs:
+                v = _nchw_view(f)
+                flat += [v[: v.shape[0] // 2], v[v.shape[0] // 2:]] if split else [v]
     else:
-        flat = list(_DiscFn.apply(msd, plan, inp, *params))
-    per = len(flat) // nD
-    result = [flat[k * per:(k + 1) * per] for k in range(nD)]
-    if msd.no_ganFeat_loss:
-        result = [[r[-1]] for r in result]
-    return result
+        flat = list(_DiscFn.apply(msd, plan, inp, split, *params))
+
+    def group(seq):
+        per = len(seq) // nD
+        res = [seq[k * per:(k + 1) * per] for k in range(nD)]
+        return [[r[-1]] for r in res] if msd.no_ganFeat_loss else res
+
+    if split:
+        return group(flat[0::2]), group(flat[1::2])
+    return group(flat)

@@ -15,8 +15,15 @@ class _LossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, a, b, mode):
         ops.require_cuda(a, "loss")
-        ac = a.contiguous()
-        bc = None if b is None else b.detach().contiguous()
+        # elementwise + full reduction: any dense layout works as long as both operands share it (the
+        # discriminator hands out channels-last views of its NHWC feature maps -- no NCHW copy)
+        cl = torch.channels_last
+        if a.dim() == 4 and not a.is_contiguous() and a.is_contiguous(memory_format=cl) and \
+                (b is None or (b.shape == a.shape and b.is_contiguous(memory_format=cl))):
+            ac, bc = a, (None if b is None else b.detach())
+        else:
+            ac = a.contiguous()
+            bc = None if b is None else b.detach().contiguous()
         n = ac.numel()
         out = torch.zeros(1, dtype=torch.float32, device=a.device)
         grad = T.loss(ac, bc, mode, 1.0 / n, 1.0 / n, out, accumulate=False, want_grad=ctx.needs_input_grad[0])

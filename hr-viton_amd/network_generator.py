@@ -469,11 +469,13 @@ class MultiscaleDiscriminator(BaseNetwork):
     def downsample(self, input):
         raise RuntimeError("executed inside forward() by hrv_avgpool3x3s2_nhwc_f32")
 
-    def forward(self, input):
-        """List (scales) of lists (layers) of NCHW tensors -- network_generator.py:306-316."""
+    def forward(self, input, split: bool = False):
+        """List (scales) of lists (layers) of NCHW tensors -- network_generator.py:306-316.  ``split=True`` (an
+        extension for the [fake ; real] batches of train_generator.py:283-295) returns (pred_fake, pred_real)."""
         if self.training:
             from .gen_train import discriminator_train_forward
-            return discriminator_train_forward(self, input)
+            return discriminator_train_forward(self, input, split)
+        assert not split, "split is a training-mode option"
         ops.require_cuda(input, "MultiscaleDiscriminator.forward")
         result = []
         with torch.no_grad():

@@ -71,9 +71,7 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
     output_paired = generator(x, parse7)
     fake_concat = torch.cat((parse_nchw, output_paired), dim=1)
     real_concat = torch.cat((parse_nchw, im), dim=1)
-    pred = discriminator(torch.cat((fake_concat, real_concat), dim=0))
-    pred_fake = [[t[: t.size(0) // 2] for t in p] for p in pred]
-    pred_real = [[t[t.size(0) // 2:] for t in p] for p in pred]
+    pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)   # :283-295
     losses = {"GAN": crit_gan(pred_fake, True, for_discriminator=False)}
     if not getattr(opt, "no_ganFeat_loss", False):
         num_D = len(pred_fake)
@@ -95,9 +93,7 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
     with torch.no_grad():
         output = generator(x, parse7)       # new noise, post-update weights (:327-330)
     fake_concat = torch.cat((parse_nchw, output), dim=1)
-    pred = discriminator(torch.cat((fake_concat, real_concat), dim=0))
-    pred_fake = [[t[: t.size(0) // 2] for t in p] for p in pred]
-    pred_real = [[t[t.size(0) // 2:] for t in p] for p in pred]
+    pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)
     d_losses = {"D_Fake": crit_gan(pred_fake, False, for_discriminator=True),
                 "D_Real": crit_gan(pred_real, True, for_discriminator=True)}
     loss_dis = sum(d_losses.values()).mean()

@@ -249,3 +249,55 @@ def test_mixed_precision_generator_step_tracks_fp32():
         assert cos > 0.93 and 0.85 < ratio < 1.15, (n, cos, ratio)
     assert sum(coss) / len(coss) > 0.98, sum(coss) / len(coss)
     assert worst < 0.9999999     # the bf16 path really ran
+
+
+def test_split_discriminator_path_equals_sliced_path():
+    """D(x, split=True) (zero-copy fake / real halves, half-batch backward when only the fake half carries a
+    gradient) against the reference-style `pred = D(x); pred_fake = t[:N]` composition: same losses, same
+    generator gradients, same discriminator gradients in the D step."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.losses import GANLoss, L1Loss
+
+    def run(split):
+        opt, gen, D, x, seg, real, noise = _setup(seed=5)
+        gen.cuda().train()
+        D.cuda().train()
+        segc, realc = seg.cuda(), real.cuda()
+        fake = gen(x.cuda(), segc, noise=noise)
+        both = torch.cat([torch.cat([segc, fake], 1), torch.cat([segc, realc], 1)], 0)
+        if split:
+            pf, pr = D(both, split=True)
+        else:
+            pred = D(both)
+            pf = [[t[: t.size(0) // 2] for t in p] for p in pred]
+            pr = [[t[t.size(0) // 2:] for t in p] for p in pred]
+        l = GANLoss("hinge")(pf, True, for_discriminator=False)
+        for i in range(2):
+            for j in range(len(pf[i]) - 1):
+                l = l + L1Loss()(pf[i][j], pr[i][j].detach()) * 10.0 / 2
+        l.mean().backward()
+        gg = {n: p.grad.detach().cpu().clone() for n, p in gen.named_parameters() if p.grad is not None}
+        for p in D.parameters():
+            p.grad = None
+        # discriminator step on detached images: both halves carry a (hinge) gradient
+        both_d = both.detach()
+        if split:
+            pf, pr = D(both_d, split=True)
+        else:
+            pred = D(both_d)
+            pf = [[t[: t.size(0) // 2] for t in p] for p in pred]
+            pr = [[t[t.size(0) // 2:] for t in p] for p in pred]
+        ld = GANLoss("hinge")(pf, False, for_discriminator=True) + GANLoss("hinge")(pr, True, for_discriminator=True)
+        ld.mean().backward()
+        gd = {n: p.grad.detach().cpu().clone() for n, p in D.named_parameters() if p.grad is not None}
+        return float(l.mean()), float(ld.mean()), gg, gd
+
+    l0, d0, gg0, gd0 = run(False)
+    l1, d1, gg1, gd1 = run(True)
+    assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)) and abs(d0 - d1) < 1e-5 * max(1.0, abs(d0))
+    gm = max(v.abs().max().item() for v in gg0.values())
+    for n in gg0:
+        assert (gg0[n] - gg1[n]).abs().max() <= 1e-4 * max(gg0[n].abs().max().item(), 1e-3 * gm), n
+    dm = max(v.abs().max().item() for v in gd0.values())
+    for n in gd0:
+        assert (gd0[n] - gd1[n]).abs().max() <= 1e-4 * max(gd0[n].abs().max().item(), 1e-3 * dm), n
