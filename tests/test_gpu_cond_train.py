@@ -362,3 +362,85 @@ def test_rejection_flow_matches_oracle():
     _close("score", score, (lf / (1 - lf)) / want_const, 1e-3)
     _close("fake_segmap", gseg, seg, 1e-4)
     assert misalign.shape == (2, 1, 128, 96) and misalign.min() >= 0
+
+
+def test_three_training_iterations_against_the_oracle():
+    """Three consecutive train_condition.py iterations on the HIP path (from the second one on the gradients are
+    produced straight in the fused Adam's flat buffer; BatchNorm running statistics carry over).  Free-running
+    trajectories of two fp32 implementations separate quickly under Adam (its update is ~lr*sign(g): elements
+    whose gradient is round-off noise around zero step the other way, and the warps' floor() flips feed that
+    back), so each iteration is compared at the SAME weights: the oracle is re-synchronised to the HIP weights,
+    then takes its own torch.optim.Adam step with its own (continuing) moments.  Checked per iteration: both
+    losses, every tocg gradient, and the weights after the step."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import networks, pipeline
+    from hr_viton_amd.losses import L1Loss
+    from hr_viton_amd.optim import Adam
+    from oracle.recipes import condstep_build
+    opt, tocg, D, batch0 = condstep_build(networks.ConditionGenerator, networks.define_D)
+    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, True, False, "warp_grad"
+    opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
+    g = torch.Generator().manual_seed(7)
+    batches = []
+    for s_ in range(3):      # vary the images, keep the label maps
+        b = dict(batch0)
+        for k in ("cloth", "densepose", "parse_cloth"):
+            b[k] = (batch0[k] + 0.2 * F.interpolate(torch.randn(2, 3, 16, 12, generator=g), scale_factor=8, mode="bilinear")
+                    ).clamp(-1, 1)
+        batches.append(b)
+    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k)
+            for k, v in tocg.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    og = torch.optim.Adam([v for v in sd_g.values() if v.requires_grad], lr=2e-4, betas=(0.5, 0.999))
+    od = torch.optim.Adam(list(sd_d.values()), lr=2e-4, betas=(0.5, 0.999))
+    tocg.cuda().train()
+    D.cuda().train()
+    hg = Adam(tocg.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    hd = Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    crit_gan = networks.GANLoss(use_lsgan=True)
+    for it, b in enumerate(batches):
+        with torch.no_grad():                      # same starting point for this iteration
+            for k, v in tocg.state_dict().items():
+                sd_g[k].copy_(v.cpu())
+            for k, v in D.state_dict().items():
+                sd_d[k].copy_(v.cpu())
+        r = O.condition_train_losses(sd_g, sd_d, None, b)
+        og.zero_grad()
+        od.zero_grad()
+        r["loss_G"].backward(retain_graph=True)
+        want_g = {k: v.grad.clone() for k, v in sd_g.items() if v.grad is not None}
+        og.step()
+        od.zero_grad()
+        r["loss_D"].backward()
+        od.step()
+        cap = {}
+        real_step = hg.step
+
+        def capture():
+            cap.update({n: p.grad.detach().cpu().clone() for n, p in tocg.named_parameters() if p.grad is not None})
+            return real_step()
+
+        hg.step = capture
+        losses = pipeline.condition_train_step(opt, tocg, D, L1Loss(), None, crit_gan, hg, hd,
+                                               {k: v.cuda() for k, v in b.items()})
+        hg.step = real_step
+        if it > 0:      # the in-place path: the gradient IS its slot of the optimizer's flat buffer
+            p0 = tocg.conv1[1].bias
+            assert p0.grad is not None and p0.grad.data_ptr() == p0._hrv_flat_grad.data_ptr()
+        for k in ("loss_G", "loss_D"):
+            assert abs(float(losses[k].detach()) - float(r[k].detach())) < 1e-4 * max(1.0, abs(float(r[k].detach()))), (it, k)
+        gmax = max(v.abs().max().item() for v in want_g.values())
+        for k, w in want_g.items():
+            err = (cap[k] - w).abs().max().item()
+            assert err < 5e-3 * max(w.abs().max().item(), 1e-3 * gmax), (it, k, err)
+        sd_h = tocg.state_dict()
+        off = tot = 0
+        for k, v in sd_g.items():
+            if v.requires_grad:
+                d = (sd_h[k].detach().cpu() - v.detach()).abs()
+                off += (d > 2e-5).sum().item()
+                tot += d.numel()
+        assert off / tot < 5e-3, (it, off, tot)     # a tenth of one Adam step; the rest are sign flips of ~0 gradients
+        mean, var_unb = r["bn_stats"]["SegDecoder.4.block.4"]
+        _close("running_var", sd_h["SegDecoder.4.block.4.running_var"],
+               0.9 * sd_g["SegDecoder.4.block.4.running_var"] + 0.1 * var_unb, 1e-4)
