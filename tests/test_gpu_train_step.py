@@ -301,3 +301,82 @@ def test_split_discriminator_path_equals_sliced_path():
     dm = max(v.abs().max().item() for v in gd0.values())
     for n in gd0:
         assert (gd0[n] - gd1[n]).abs().max() <= 1e-4 * max(gd0[n].abs().max().item(), 1e-3 * dm), n
+
+
+def test_second_generator_iteration_on_the_flat_gradient_path():
+    """pipeline.generator_train_step twice: in the second iteration every generator / discriminator gradient is
+    produced directly in its slot of the fused Adam's flat buffer (spectral-norm dW_orig, SPADE gamma/beta slices,
+    fused bias columns).  The oracle is synchronised to the HIP weights (incl. the power-iterated u, v) before that
+    iteration and fed the same SPADE noise; compared: the generator-step losses and every generator gradient."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, pipeline
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    from hr_viton_amd.optim import Adam
+    opt, gen, D, x, seg, real, noise = _setup(seed=9, wmul=8.0)
+    opt.lambda_feat, opt.lambda_vgg, opt.no_vgg_loss = 10.0, 10.0, True
+    gen.cuda().train()
+    D.cuda().train()
+    og = Adam(gen.parameters(), lr=1e-4, betas=(0.0, 0.9))
+    od = Adam(D.parameters(), lr=4e-4, betas=(0.0, 0.9))
+    xc, realc = x.cuda(), real.cuda()
+    parse7 = ops.to_nhwc(seg.cuda())
+    blocks = list(noise.keys())
+    real_randn = torch.randn
+    fed = {}
+
+    def feed_randn(*size, **kw):
+        # SPADENorm noise draws ([b, w, h, 1], network_generator.py:104-107): recorded so the oracle can replay them
+        if len(size) == 4 and size[3] == 1:
+            z = real_randn(*size, **kw)
+            fed.setdefault("z", []).append(z.detach().cpu())
+            return z
+        return real_randn(*size, **kw)
+
+    cap = {}
+    for it in range(2):
+        fed.clear()
+        # the weights (and u, v) this iteration starts from, on the CPU for the oracle
+        sd_g, sd_d = ({k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith(("weight_u", "weight_v")))
+                       for k, v in m.state_dict().items()} for m in (gen, D))
+        real_step = og.step
+
+        def capture():
+            cap.clear()
+            cap.update({n: p.grad.detach().cpu().clone() for n, p in gen.named_parameters() if p.grad is not None})
+            return real_step()
+
+        og.step = capture
+        torch.randn = feed_randn
+        try:
+            losses, _ = pipeline.generator_train_step(opt, gen, D, GANLoss("hinge"), L1Loss(), None, og, od, xc, parse7, realc)
+        finally:
+            torch.randn = real_randn
+            og.step = real_step
+    # oracle replay of the SECOND iteration's generator step
+    zs = fed["z"]
+    per_block = {b: (3 if getattr(gen, b).learned_shortcut else 2) for b in blocks}
+    n_g = sum(per_block.values())
+    it_z = iter(zs[:n_g])                                     # the first n_g draws belong to the G-step forward
+    onoise = {b: [next(it_z) for _ in range(per_block[b])] for b in blocks}
+    O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+    try:
+        fake = O.spade_generator_forward(sd_g, x, seg, opt.fine_height, opt.fine_width, "most", noise=onoise)
+        pred = O.gen_discriminator_forward(sd_d, torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0))
+    finally:
+        O.SN_TRAIN["on"] = False
+    pf, pr = O.split_fake_real(pred)
+    l_gan, l_feat = O.hinge_loss(pf, True, False), O.feat_match_loss(pf, pr, 10.0)
+    (l_gan + l_feat).backward()
+    assert abs(float(losses["GAN"]) - l_gan.item()) < 2e-4 * max(1.0, abs(l_gan.item()))
+    assert abs(float(losses["GAN_Feat"]) - l_feat.item()) < 2e-4 * max(1.0, abs(l_feat.item()))
+    p0 = gen.up_4.conv_0.weight_orig
+    assert p0.grad is None or p0.grad.data_ptr() == p0._hrv_flat_grad.data_ptr()
+    gmax = max(v.grad.abs().max().item() for v in sd_g.values() if v.grad is not None)
+    rows = []
+    for n, p in gen.named_parameters():
+        w = sd_g[n].grad
+        if w is None:
+            continue
+        rows.append(((cap[n] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), n))
+    rows.sort(reverse=True)
+    assert rows[0][0] < 1e-2, rows[:5]
