@@ -40,10 +40,10 @@ def make_inputs(torch, n, seed, device):
     return input1.to(device), input2.to(device)
 
 
-def build_model(torch, nn):
+def build_model(torch, nn, mixed=False):
     from argparse import Namespace
     from hr_viton_amd.networks import ConditionGenerator
-    opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu")
+    opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu", fp16=mixed)
     torch.manual_seed(0)
     m = ConditionGenerator(opt, 4, 16, 13, ngf=NGF, norm_layer=nn.BatchNorm2d)
     g = torch.Generator().manual_seed(5)
@@ -231,7 +231,7 @@ def main():
     if args.workload != "tocg_infer":
         return other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev)
 
-    opt, model = build_model(torch, nn)
+    opt, model = build_model(torch, nn, mixed=args.bf16)   # --bf16: bf16 MFMA operands over fp32 tensors (not the default)
     sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
     model.to(dev)
     i1, i2 = make_inputs(torch, BATCH, hdist.shard_seed(1234, rank), dev)
@@ -268,9 +268,12 @@ def main():
         with open(tp) as f:
             tj = json.load(f)
         traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
-    roofline = {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel (all tile configs)",
-                "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+    peak = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS
+    if args.bf16:
+        traffic, traffic_src = None, None      # the committed PMC passes are of the fp32 default
+    roofline = {"bound": "mfma", "kernel": "hrv::conv_mfma_kernel (all tile configs)",
+                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
                 "traffic_unit": "HBM bytes per conv launch (average over the step's launches)", "traffic_source": traffic_src,
                 "algorithmic_flops_per_launch": conv_flops / max(1, len(conv)),
                 "launches_per_step": len(conv), "flops_per_step": conv_flops,
@@ -308,7 +311,7 @@ def main():
         line = {"metric": "1024x768 try-on images/sec (ConditionGenerator inference: flow+seg+grid_sample)",
                 "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA operands, f32 storage/accumulate" if args.bf16 else "f32", "data": "synthetic",
                 "config": {"workload": "BASELINE configs[1]: ConditionGenerator inference 1024x768 batch=4/GPU "
                                        "fp32, ngf=96, random-init weights",
                            "global_batch": BATCH * world, "height": H, "width": W, "parallelism": f"dp{world}-replicas"},

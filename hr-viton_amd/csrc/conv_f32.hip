@@ -1225,7 +1225,8 @@ extern "C" int hrv_conv2d_pack_weight_bf16(const float* w, int32_t Cout, int32_t
   const int64_t cpad = (int64_t)((Cout + bn - 1) / bn) * bn;
   int cin_real = 0, chunks_total = 0;
   for (int i = 0; i < nsrc; ++i) {
-    HRV_REQUIRE(srcC_real[i] > 0 && srcC_real[i] <= srcC[i] && srcC[i] % 8 == 0, "pack_weight_bf16: bad channel counts");
+    // multiples of 8 for bf16 tensors; multiples of 4 when the sources are fp32 tensors rounded in the gather
+    HRV_REQUIRE(srcC_real[i] > 0 && srcC_real[i] <= srcC[i] && srcC[i] % 4 == 0, "pack_weight_bf16: bad channel counts");
     cin_real += srcC_real[i];
     chunks_total += (srcC[i] + bke - 1) / bke;
   }

@@ -187,10 +187,15 @@ class ConvLayer:
 
     def __init__(self, weight: torch.Tensor, src_real: Sequence[int], device, scale: Optional[torch.Tensor] = None,
                  shift: Optional[torch.Tensor] = None, stride: int = 1, pad: int = 1, act: int = ACT_NONE,
-                 slope: float = 0.2, name: str = "conv", bf16: bool = False, out_f32: bool = False):
+                 slope: float = 0.2, name: str = "conv", bf16: bool = False, out_f32: bool = False,
+                 mma_bf16: bool = False):
         # bf16: sources + weights are bf16 (fp32 accumulate); out_f32: in bf16 mode the output is written
         # as fp32 (tensors that feed an InstanceNorm stay fp32)
+        # mma_bf16: every tensor stays fp32, only the matrix-core operands are rounded to bf16 while staged
+        # (hrv_conv2d_t.mixed_flags bit 3) -- the inference counterpart of train_ops.MMA_BF16
+        assert not (bf16 and mma_bf16)
         self.bf16 = bf16
+        self.mixed = mma_bf16
         self.out_f32 = out_f32 or not bf16
         w = weight.detach().to("cpu", torch.float32).contiguous()
         self.Cout, cin, self.KH, self.KW = w.shape
@@ -212,7 +217,7 @@ class ConvLayer:
             n = len(self.src_pad)
             srcC = (C.c_int32 * n)(*self.src_pad)
             srcR = (C.c_int32 * n)(*self.src_real)
-            if self.bf16:
+            if self.bf16 or self.mixed:
                 elems = lib.hrv_conv2d_packed_elems_bf16(self.Cout, self.KH, self.KW, n, srcC, cfg)
                 buf = torch.empty(max(elems, 1), dtype=torch.int16)
                 _lib.check(lib.hrv_conv2d_pack_weight_bf16(self.w_cpu.data_ptr(), self.Cout, self.KH, self.KW, n, srcC,
@@ -267,11 +272,13 @@ class ConvLayer:
         naive = os.environ.get("HRV_CONV_IMPL", "mfma") == "naive"
         if cfg is None:
             cfg = lib.hrv_conv2d_pick_tile(N * Ho * Wo, self.Cout)
+            if self.mixed:      # 128-byte-row tile with the least column padding (cfg 8: 128 columns, 9: 64)
+                cfg = 8 if (self.Cout + 127) // 128 * 128 <= (self.Cout + 63) // 64 * 64 else 9
             if self.bf16 and cfg in (0, 6):
                 # 128-byte K-tile rows: 128x128 tile +15-20 % (profiles/r01_conv_bench_bf16_rb.txt); the 128x64 tile
                 # additionally stages its operands by LDS-DMA (profiles/r01_conv_bench_bf16_glds.txt)
                 cfg = 8 if cfg == 0 else 9
-        forced = os.environ.get("HRV_CONV_TILE") if spade is None else None
+        forced = os.environ.get("HRV_CONV_TILE") if (spade is None and not self.mixed) else None
         if forced is not None:
             cfg = int(forced)
         d.Cout, d.tile_cfg = self.Cout, cfg
@@ -293,14 +300,15 @@ class ConvLayer:
         if spade is not None:
             d.spade = C.pointer(spade)
             mixed |= 4 if getattr(spade, "_x_f32", True) else 0
-        d.mixed_flags = mixed if self.bf16 else 0
+        d.mixed_flags = 15 if self.mixed else (mixed if self.bf16 else 0)
         if not naive and spade is None:
             need = lib.hrv_conv2d_workspace_bytes(C.byref(d))
             if need > 0:
                 ws = _workspace(a0.t.device, need)
                 d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else (lib.hrv_conv2d_nhwc_bf16 if self.bf16 else lib.hrv_conv2d_nhwc_f32)
-        assert not (naive and self.bf16), "the naive cross-check is fp32"
+        engine_bf16 = self.bf16 or self.mixed
+        fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else (lib.hrv_conv2d_nhwc_bf16 if engine_bf16 else lib.hrv_conv2d_nhwc_f32)
+        assert not (naive and engine_bf16), "the naive cross-check is fp32"
         with _Timed("conv", self.name, self.flops(N, Ho, Wo), 0):
             _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")
         return out
@@ -311,14 +319,15 @@ class TapConvLayer:
     a 1x1 convolution with KH*KW*Cout tap-channels on the MFMA engine + hrv_tapsum_nhwc_f32."""
 
     def __init__(self, weight: torch.Tensor, src_real: Sequence[int], device, bias: Optional[torch.Tensor] = None,
-                 name: str = "tapconv"):
+                 name: str = "tapconv", mma_bf16: bool = False):
         w = weight.detach().to("cpu", torch.float32)
         self.Cout, cin, self.KH, self.KW = w.shape
         assert self.KH == self.KW and self.KH % 2 == 1
         self.pad = self.KH // 2
         # [co][c][kh][kw] -> [(kh*KW+kw)*Cout + co][c][1][1]
         w1 = w.permute(2, 3, 0, 1).reshape(self.KH * self.KW * self.Cout, cin, 1, 1).contiguous()
-        self.inner = ConvLayer(w1, src_real, device, stride=1, pad=0, name=name + "[taps-as-channels 1x1]")
+        self.inner = ConvLayer(w1, src_real, device, stride=1, pad=0, name=name + "[taps-as-channels 1x1]",
+                               mma_bf16=mma_bf16)
         self.bias = None if bias is None else bias.detach().to(device, torch.float32).contiguous()
         self.name = name
 

@@ -130,3 +130,28 @@ def test_tocg_full_size_properties():
     assert a[3].min() >= 0.0 and a[3].max() <= 1.0          # warped mask stays in [0,1]
     assert a[2].min() >= i1[:, :3].min() - 1e-6 and a[2].max() <= i1[:, :3].max() + 1e-6
     assert (a[1] >= 0).all()                                  # out_layer='relu' ends in ReLU
+
+
+def test_mixed_precision_inference_tracks_fp32():
+    """opt.fp16 (test_generator.py --fp16): bf16 matrix-core operands over fp32 tensors (flow heads stay fp32).
+    Against the fp32 HIP path on the same weights: flows / logits within the stated bf16 tolerance, labels agree."""
+    from argparse import Namespace
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.networks import ConditionGenerator
+    g = load_golden("tocg_ngf8_96x64.pt")
+
+    def run(fp16):
+        opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu", fp16=fp16)
+        m = ConditionGenerator(opt, 4, 16, 13, ngf=8, norm_layer=torch.nn.BatchNorm2d)
+        m.load_state_dict(g["state_dict"])
+        m.cuda().eval()
+        return m(opt, g["input1"].cuda(), g["input2"].cuda())
+
+    f32, f16 = run(False), run(True)
+    for a, b in zip(f16[0], f32[0]):
+        assert (a - b).abs().max() <= 3e-2 * b.abs().max() + 1e-3
+    seg16, seg32 = f16[1], f32[1]
+    assert (seg16 - seg32).abs().max() <= 3e-2 * seg32.abs().max()
+    assert (seg16 - seg32).abs().mean() > 1e-6          # it is a different rounding
+    agree = (seg16.argmax(1) == seg32.argmax(1)).float().mean().item()
+    assert agree > 0.98, agree
