@@ -155,6 +155,7 @@ SYMBOLS = {
     "hrv_cross_entropy_nchw_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i64, _f, _vp, _vp, _vp, _vp]),
     "hrv_tapsum_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "hrv_tap_expand_nhwc": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_mul_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "hrv_tv_loss_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 

@@ -381,7 +381,7 @@ class CondDPlan:
         outs, ctxs, inputs = [], [], []
         for i, p in enumerate(self.plans):
             inputs.append(a)
-            feats, c = p.forward(a, power_iteration=True)
+            feats, c = p.forward(a, power_iteration=self.msd.training)   # torch's spectral_norm iterates in train() only
             outs.append(feats[-1])
             ctxs.append((c, len(feats)))
             if i != len(self.plans) - 1:

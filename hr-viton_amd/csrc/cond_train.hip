@@ -77,6 +77,12 @@ __global__ void affine_act_kernel(const float* __restrict__ x, int xcs, int xco,
   }
 }
 
+// out = x * m   (dropout: m holds 0 or 1/(1-p); also its backward d *= m)
+__global__ void mul_kernel(const float* __restrict__ x, const float* __restrict__ m, size_t n4, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x)
+    *reinterpret_cast<f32x4*>(out + i * 4) = ld4(x + i * 4) * ld4(m + i * 4);
+}
+
 // BatchNorm backward, stage 1: per block partial sums over its pixel range of
 //   s1[c] = sum dy, s2[c] = sum dy * (x - mean[c]) * rstd[c]
 __global__ __launch_bounds__(256) void bn_bwd_partial_kernel(const float* __restrict__ dy, int dcs, int dco,
@@ -752,4 +758,11 @@ extern "C" int hrv_tapsum_bwd_nhwc_f32(const float* dout, int32_t N, int32_t H, 
   hipLaunchKernelGGL(tapsum_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, N, H, W, KH, KW,
                      pad, Cout, dout_cstride, dy, dy_cstride, ycp);
   return check_launch("tapsum_bwd_kernel");
+}
+
+extern "C" int hrv_mul_f32(const float* x, const float* m, int64_t n, float* out, hrv_stream_t stream) {
+  HRV_REQUIRE(x && m && out && n > 0 && n % 4 == 0 && (((uintptr_t)x | (uintptr_t)m | (uintptr_t)out) & 15) == 0,
+              "mul: n must be a multiple of 4 and the pointers 16-byte aligned");
+  hipLaunchKernelGGL(mul_kernel, dim3(grid_for((size_t)n / 4)), dim3(256), 0, (hipStream_t)stream, x, m, (size_t)n / 4, out);
+  return check_launch("mul_kernel");
 }

@@ -373,6 +373,10 @@ def generator_train_forward(gen: nn.Module, x: torch.Tensor, seg, noise=None) ->
 # ----------------------------------------------------------------------------
 # PatchGAN (network_generator.py:250-316)
 # ----------------------------------------------------------------------------
+# test hook: dropout keep-masks (already scaled by 1/(1-p), NCHW or NHWC) consumed in call order instead of fresh draws
+DROP_MASKS: List[torch.Tensor] = []
+
+
 class DiscTrainPlan:
     """One NLayerDiscriminator: conv0+lrelu, [SNconv, IN, lrelu] x (n_layers-1), conv_last."""
 
@@ -407,8 +411,15 @@ class DiscTrainPlan:
             if isinstance(nxt, nn.InstanceNorm2d):
                 if nxt.affine or not isinstance(mods[i + 2], nn.LeakyReLU):
                     raise NotImplementedError("hr-viton_amd tocg discriminator: InstanceNorm2d(affine=False) + LeakyReLU")
-                self.layers.append(("in", tc))
-                i += 3
+                drop = mods[i + 3] if i + 3 < len(mods) and isinstance(mods[i + 3], nn.Dropout) else None
+                if drop is not None:       # --Ddropout (networks.py:363-368)
+                    self.layers.append(("in_drop", tc))
+                    self.drop_p = drop.p
+                    self.drop_mod = drop
+                    i += 4
+                else:
+                    self.layers.append(("in", tc))
+                    i += 3
             elif isinstance(nxt, nn.LeakyReLU):
                 self.layers.append(("lrelu", tc))
                 i += 2
@@ -421,11 +432,22 @@ class DiscTrainPlan:
         feats, ctx = [], []
         for kind, conv in self.layers:
             conv.prepare(power_iteration)
-            if kind == "in":
+            if kind in ("in", "in_drop"):
                 c = conv.forward([(a, 0)])
                 mean, rstd = ops.instnorm_stats(c)
                 f = ops.instnorm_apply(c, mean, rstd, ACT_LRELU, 0.2)
-                ctx.append(dict(src=a, c=c, mean=mean, rstd=rstd, f=f))
+                entry = dict(src=a, c=c, mean=mean, rstd=rstd, f=f)
+                if kind == "in_drop" and self.drop_mod.training:
+                    # nn.Dropout(p): keep mask scaled by 1/(1-p); DROP_MASKS lets a test inject the draws
+                    if DROP_MASKS:
+                        m = DROP_MASKS.pop(0).to(f.t.device)
+                        m = m.permute(0, 2, 3, 1).contiguous() if m.shape != f.t.shape else m
+                    else:
+                        m = torch.empty_like(f.t).bernoulli_(1.0 - self.drop_p).mul_(1.0 / (1.0 - self.drop_p))
+                    f = Act(f.t.clone(), f.C)          # f (pre-dropout) is kept for the LeakyReLU derivative
+                    T.mul_(f, m)
+                    entry["mask"] = m
+                ctx.append(entry)
             else:
                 f = conv.forward([(a, 0)], act=ACT_LRELU if kind == "lrelu" else ACT_NONE)
                 ctx.append(dict(src=a, f=f))
@@ -451,7 +473,9 @@ class DiscTrainPlan:
                 d = d_next
             elif d_next is not None:
                 T.add_slice(d_next, d, True)
-            if kind == "in":
+            if kind in ("in", "in_drop"):
+                if c.get("mask") is not None:
+                    T.mul_(d, c["mask"])
                 d_c, _ = T.norm_bwd(c["c"], c["mean"], c["rstd"], d, act=ACT_LRELU, slope=0.2, out=c["f"])
             elif kind == "lrelu":
                 T.act_bwd_(d, c["f"], ACT_LRELU, 0.2)

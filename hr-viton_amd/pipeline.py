@@ -142,10 +142,23 @@ def condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d
     use_vgg = crit_vgg is not None
     loss_vgg = crit_vgg(warped_cloth, im_c) if use_vgg else torch.zeros((), device=c_paired.device)   # :185
     loss_tv = 0
-    if getattr(opt, "edgeawaretv", "no_edge") != "no_edge":
-        raise NotImplementedError("hr-viton_amd condition_train_step: edgeawaretv='no_edge' (the default)")
-    for flow in (flow_list[-1:] if getattr(opt, "lasttvonly", False) else flow_list):   # :190-199
-        loss_tv = loss_tv + HF.tv_loss(flow)
+    edge = getattr(opt, "edgeawaretv", "no_edge")
+    if edge == "no_edge":
+        for flow in (flow_list[-1:] if getattr(opt, "lasttvonly", False) else flow_list):   # :190-199
+            loss_tv = loss_tv + HF.tv_loss(flow)
+    else:
+        # edge-aware TV (:200-229): |d flow| weighted by exp(-150 |d mask|) of the warped cloth mask resized to the
+        # flow's resolution.  The resize runs on the HIP kernel; the weighting is elementwise glue on flow-sized maps.
+        levels = [4] if edge == "last_only" else list(range(5))
+        for i in levels:
+            flow = flow_list[i]
+            wcd = HF.interpolate(warped_cm, size=flow.shape[1:3], mode="bilinear").permute(0, 2, 3, 1)
+            y_tv = torch.abs(flow[:, 1:, :, :] - flow[:, :-1, :, :]) * torch.exp(-150 * torch.abs(wcd[:, 1:] - wcd[:, :-1]))
+            x_tv = torch.abs(flow[:, :, 1:, :] - flow[:, :, :-1, :]) * torch.exp(-150 * torch.abs(wcd[:, :, 1:] - wcd[:, :, :-1]))
+            scale = 1.0 if edge == "last_only" else 1.0 / (2 ** (4 - i))
+            loss_tv = loss_tv + y_tv.mean() * scale + x_tv.mean() * scale
+        if getattr(opt, "add_lasttv", False):
+            loss_tv = loss_tv + HF.tv_loss(flow_list[-1])
     N, _, iH, iW = c_paired.size()
     if getattr(opt, "interflowloss", False):                                   # :235-248
         soft_for_overlap = HF.softmax(fake_segmap, dim=1)
@@ -182,6 +195,10 @@ def condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d
     if sync_d is not None:
         sync_d.enabled = True
         sync_d.begin()
+    if getattr(opt, "G_D_seperate", False):                                   # :296-300 -- D sees the UPDATED generator
+        with torch.no_grad():
+            _, fake_segmap_new, _, _ = tocg(input1, input2)
+        fake_segmap_softmax = HF.softmax(fake_segmap_new, 1)
     both = torch.cat((torch.cat((input1, input2, fake_segmap_softmax.detach()), dim=1),
                       torch.cat((input1, input2, label), dim=1)), dim=0)
     pred = D(both)

@@ -451,3 +451,11 @@ def flow_warp_bwd(src: Act, flow_up: torch.Tensor, norm_x: float, norm_y: float,
         d.dflow, d.dflow_accumulate = dflow.data_ptr(), 1 if dflow_accumulate else 0
     with _Timed("warp", "flow_warp_bwd", 0.0, 4.0 * dout.N * dout.H * dout.W * dout.Cp * 6):
         _lib.check(lib.hrv_flow_warp_bwd_nhwc_f32(C.byref(d), _stream()), "hrv_flow_warp_bwd_nhwc_f32")
+
+
+def mul_(x: Act, m: torch.Tensor) -> Act:
+    """x *= m in place over the whole (dense) buffer -- hrv_mul_f32 (dropout mask, forward and backward)."""
+    lib = _lib.load()
+    assert x.t.is_contiguous() and m.shape == x.t.shape and m.is_contiguous()
+    _lib.check(lib.hrv_mul_f32(x.t.data_ptr(), m.data_ptr(), x.t.numel(), x.t.data_ptr(), _stream()), "hrv_mul_f32")
+    return x

@@ -492,6 +492,9 @@ int hrv_cross_entropy_nchw_f32(const float* x, const int64_t* target, int32_t N,
  * ceil4(KH*KW*Cout) channels (padding zeroed). */
 int hrv_tapsum_bwd_nhwc_f32(const float* dout, int32_t N, int32_t H, int32_t W, int32_t KH, int32_t KW, int32_t pad,
                             int32_t Cout, int32_t dout_cstride, float* dy, int32_t dy_cstride, hrv_stream_t stream);
+/* out = x * m elementwise (dense buffers, n % 4 == 0): nn.Dropout(0.5) of the tocg discriminator with the keep
+ * mask pre-scaled by 1/(1-p) (networks.py:363-368), forward and backward. */
+int hrv_mul_f32(const float* x, const float* m, int64_t n, float* out, hrv_stream_t stream);
 /* Flow total variation (train_condition.py:190-199) of one [N,H,W,2] flow:
  * loss = mean|f[:,1:]-f[:,:-1]| + mean|f[:,:,1:]-f[:,:,:-1]|, grad = d loss / d f (optional).
  * workspace: 1024 floats. */

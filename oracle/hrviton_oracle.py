@@ -524,7 +524,7 @@ def avgpool3x3s2(x: Tensor) -> Tensor:
 
 
 def tocg_discriminator_forward(sd: SD, inp: Tensor, num_D: int = 2, n_layers: int = 3,
-                               Ddownx2: bool = False) -> List[List[Tensor]]:
+                               Ddownx2: bool = False, drop_masks: Optional[List[Tensor]] = None) -> List[List[Tensor]]:
     """networks.MultiscaleDiscriminator.forward (getIntermFeat=False, InstanceNorm2d(affine=False), no
     spectral norm, no dropout) -- networks.py:302-408.  Flattened nn.Sequential per scale `layer{k}`:
     [conv4x4 s2, LReLU] + (n_layers-1) x [conv4x4 s2, IN, LReLU] + [conv4x4 s1, IN, LReLU] + [conv4x4 s1 -> 1],
@@ -537,9 +537,14 @@ def tocg_discriminator_forward(sd: SD, inp: Tensor, num_D: int = 2, n_layers: in
         h = F.leaky_relu(F.conv2d(x, sd[p + ".0.weight"], sd[p + ".0.bias"], stride=2, padding=2), 0.2)
         idx = 2
         for n in range(1, n_layers):
-            h = F.conv2d(h, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"], stride=2, padding=2)
+            w = _sn_weight(sd, f"{p}.{idx}") if f"{p}.{idx}.weight_orig" in sd else sd[f"{p}.{idx}.weight"]
+            h = F.conv2d(h, w, sd[f"{p}.{idx}.bias"], stride=2, padding=2)
             h = F.leaky_relu(instance_norm(h), 0.2)
             idx += 3
+            if drop_masks is not None:     # --Ddropout: nn.Dropout(0.5) after the activation (networks.py:363-368);
+                # the keep masks (already x 1/(1-p)) are supplied: a list consumed in call order, or a callable shape -> mask
+                h = h * (drop_masks(tuple(h.shape)) if callable(drop_masks) else drop_masks.pop(0))
+                idx += 1
         h = F.conv2d(h, sd[f"{p}.{idx}.weight"], sd[f"{p}.{idx}.bias"], stride=1, padding=2)
         h = F.leaky_relu(instance_norm(h), 0.2)
         idx += 3
@@ -575,7 +580,8 @@ def tv_loss(flow: Tensor) -> Tensor:
 def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict[str, Tensor],
                            lasttvonly: bool = True, interflowloss: bool = True, occlusion: bool = False,
                            Ddownx2: bool = True, composition: str = "warp_grad", tvlambda: float = 2.0,
-                           CElamda: float = 10.0, GANlambda: float = 1.0, num_D: int = 2):
+                           CElamda: float = 10.0, GANlambda: float = 1.0, num_D: int = 2, drop_masks=None,
+                           edgeawaretv: str = "no_edge", add_lasttv: bool = False):
     """One iteration of train_condition.py:136-277 up to the two loss sums (the caller runs backward).
     `batch`: cloth, cloth_mask (already binarised :140), parse_agnostic, densepose, parse_onehot (label
     indices [N,1,H,W]), parse (one-hot 13), pcm, parse_cloth.  sd_vgg None drops the VGG terms
@@ -602,8 +608,19 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
     loss_l1 = F.l1_loss(warped_cm, pcm)                                     # :184
     loss_vgg = vgg(warped_c, im_c)                                          # :185
     loss_tv = 0
-    for flow in (flow_list[-1:] if lasttvonly else flow_list):              # :190-199
-        loss_tv = loss_tv + tv_loss(flow)
+    if edgeawaretv == "no_edge":
+        for flow in (flow_list[-1:] if lasttvonly else flow_list):          # :190-199
+            loss_tv = loss_tv + tv_loss(flow)
+    else:                                                                   # :200-229
+        for i in ([4] if edgeawaretv == "last_only" else range(5)):
+            flow = flow_list[i]
+            wcd = resize_bilinear(warped_cm, size=tuple(flow.shape[1:3])).permute(0, 2, 3, 1)
+            y_tv = (flow[:, 1:] - flow[:, :-1]).abs() * torch.exp(-150 * (wcd[:, 1:] - wcd[:, :-1]).abs())
+            x_tv = (flow[:, :, 1:] - flow[:, :, :-1]).abs() * torch.exp(-150 * (wcd[:, :, 1:] - wcd[:, :, :-1]).abs())
+            sc = 1.0 if edgeawaretv == "last_only" else 1.0 / (2 ** (4 - i))
+            loss_tv = loss_tv + y_tv.mean() * sc + x_tv.mean() * sc
+        if add_lasttv:
+            loss_tv = loss_tv + tv_loss(flow_list[-1])
     N, _, iH, iW = c_paired.shape
     if interflowloss:                                                       # :235-248
         for i in range(len(flow_list) - 1):
@@ -619,11 +636,14 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
             loss_vgg = loss_vgg + vgg(w_c, im_c) / (2 ** (4 - i))
     ce = cross_entropy2d(fake_segmap, label_onehot.transpose(0, 1)[0].long())   # :252
     soft = torch.softmax(fake_segmap, 1)                                    # :260
-    pred = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), soft), 1), num_D, 3, Ddownx2)
+    dm = drop_masks or {}
+    pred = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), soft), 1), num_D, 3, Ddownx2,
+                                      dm.get("g"))
     loss_g_gan = lsgan_loss(pred, True)                                     # :264
     pred_f = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), soft.detach()), 1), num_D,
-                                        3, Ddownx2)
-    pred_r = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), label), 1), num_D, 3, Ddownx2)
+                                        3, Ddownx2, dm.get("f"))
+    pred_r = tocg_discriminator_forward(sd_d, torch.cat((input1.detach(), input2.detach(), label), 1), num_D, 3, Ddownx2,
+                                        dm.get("r"))
     loss_d_fake, loss_d_real = lsgan_loss(pred_f, False), lsgan_loss(pred_r, True)
     loss_G = (10 * loss_l1 + loss_vgg + tvlambda * loss_tv) + (ce * CElamda + loss_g_gan * GANlambda)   # :276
     loss_D = loss_d_fake + loss_d_real                                      # :277

@@ -230,10 +230,12 @@ def _vgg_pair(seed=5):
     return crit, sd
 
 
-@pytest.mark.parametrize("with_vgg,comp,occl", [(False, "warp_grad", False), (True, "warp_grad", False),
-                                                (False, "detach", True), (False, "no_composition", False)],
-                         ids=["novgg", "vgg", "detach_occlusion", "no_composition"])
-def test_condition_training_iteration_matches_oracle(with_vgg, comp, occl):
+@pytest.mark.parametrize("with_vgg,comp,occl,edge", [(False, "warp_grad", False, "no_edge"), (True, "warp_grad", False, "no_edge"),
+                                                     (False, "detach", True, "no_edge"),
+                                                     (False, "no_composition", False, "no_edge"),
+                                                     (False, "warp_grad", False, "weighted")],
+                         ids=["novgg", "vgg", "detach_occlusion", "no_composition", "edgeaware_weighted_addlast"])
+def test_condition_training_iteration_matches_oracle(with_vgg, comp, occl, edge):
     """train_condition.py:136-286 (--Ddownx2 --lasttvonly --interflowloss) on the HIP path vs the oracle:
     the eight loss terms, every tocg / D parameter gradient, running statistics, one Adam update."""
     import hr_viton_amd  # noqa: F401
@@ -243,12 +245,14 @@ def test_condition_training_iteration_matches_oracle(with_vgg, comp, occl):
     from oracle.recipes import condstep_build
     opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D)
     opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, True, occl, comp
+    opt.edgeawaretv, opt.add_lasttv = edge, edge != "no_edge"
     opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
     crit_vgg, sd_vgg = _vgg_pair() if with_vgg else (None, None)
     sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k)
             for k, v in tocg.state_dict().items()}
     sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
-    r = O.condition_train_losses(sd_g, sd_d, sd_vgg, batch, occlusion=occl, composition=comp)
+    r = O.condition_train_losses(sd_g, sd_d, sd_vgg, batch, occlusion=occl, composition=comp, edgeawaretv=edge,
+                                 add_lasttv=edge != "no_edge")
     r["loss_G"].backward(retain_graph=True)
     g_grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in sd_g.items()}
     for v in sd_d.values():
@@ -297,9 +301,11 @@ def test_condition_training_iteration_matches_oracle(with_vgg, comp, occl):
 
     # sign() of the L1 terms and floor() flips of the warps make G's gradients noisy: 5e-3 scale-aware (measured 4.6e-4)
     _compare_grads(_G(tocg, grads_g), {k: _W(g_grads[k]) for k in sd_g}, 5e-3,
-                   ("tocg_vgg step" if with_vgg else "tocg step") if comp == "warp_grad" else f"tocg_{comp} step")
+                   ("tocg_vgg step" if with_vgg else "tocg step") if (comp == "warp_grad" and edge == "no_edge")
+                   else f"tocg_{comp}_{edge} step")
     _compare_grads(_G(D, grads_d), {k: _W(v.grad) for k, v in sd_d.items()}, 5e-4,
-                   ("tocgD_vgg step" if with_vgg else "tocgD step") if comp == "warp_grad" else f"tocgD_{comp} step")
+                   ("tocgD_vgg step" if with_vgg else "tocgD step") if (comp == "warp_grad" and edge == "no_edge")
+                   else f"tocgD_{comp}_{edge} step")
     # running statistics: momentum 0.1 on the oracle's recorded batch statistics
     mean, var_unb = r["bn_stats"]["ClothEncoder.0.block.1"]
     _close("running_mean", tocg.ClothEncoder[0].block[1].running_mean, 0.9 * rm_before + 0.1 * mean, 1e-5)
@@ -444,3 +450,124 @@ def test_three_training_iterations_against_the_oracle():
         mean, var_unb = r["bn_stats"]["SegDecoder.4.block.4"]
         _close("running_var", sd_h["SegDecoder.4.block.4.running_var"],
                0.9 * sd_g["SegDecoder.4.block.4.running_var"] + 0.1 * var_unb, 1e-4)
+
+
+def test_discriminator_dropout_and_spectral_variants_match_oracle():
+    """--Ddropout (the reference README's training command) and --spectral of the tocg discriminator: one
+    condition-training iteration with the dropout keep-masks recorded from the oracle run and replayed on the HIP
+    path (gen_train.DROP_MASKS); losses and all D gradients."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import gen_train, networks, pipeline
+    from hr_viton_amd.losses import L1Loss
+    from hr_viton_amd.optim import Adam
+    from oracle.recipes import condstep_build
+
+    def define_D(**kw):
+        kw.update(Ddropout=True, spectral=True)
+        return networks.define_D(**kw)
+
+    opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, define_D)
+    assert any(isinstance(m, torch.nn.Dropout) for m in D.modules()) and any(k.endswith("weight_orig") for k in D.state_dict())
+    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, False, False, "warp_grad"
+    opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
+    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k)
+            for k, v in tocg.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(v.is_floating_point() and not k.endswith(("weight_u", "weight_v")))
+            for k, v in D.state_dict().items()}
+    gm = torch.Generator().manual_seed(17)
+    rec = {"g": [], "f": [], "r": []}
+
+    def drawer(key):
+        def f(shape):
+            m = (torch.rand(shape, generator=gm) < 0.5).float() * 2.0
+            rec[key].append(m)
+            return m
+        return f
+
+    O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+    try:
+        r = O.condition_train_losses(sd_g, sd_d, None, batch, interflowloss=False,
+                                     drop_masks={k: drawer(k) for k in rec})
+    finally:
+        O.SN_TRAIN["on"] = False
+    r["loss_G"].backward(retain_graph=True)
+    for v in sd_d.values():
+        v.grad = None
+    r["loss_D"].backward()
+    tocg.cuda().train()
+    D.cuda().train()
+    og = Adam(tocg.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    od = Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    grads_d = {}
+    step_d = od.step
+
+    def sdd():
+        grads_d.update({n: p.grad.detach().cpu().clone() for n, p in D.named_parameters() if p.grad is not None})
+        return step_d()
+
+    od.step = sdd
+    gen_train.DROP_MASKS[:] = rec["g"] + [torch.cat([a, b], 0) for a, b in zip(rec["f"], rec["r"])]
+    try:
+        losses = pipeline.condition_train_step(opt, tocg, D, L1Loss(), None, networks.GANLoss(use_lsgan=True), og, od,
+                                               {k: v.cuda() for k, v in batch.items()})
+    finally:
+        assert not gen_train.DROP_MASKS, "every recorded mask must have been consumed"
+        gen_train.DROP_MASKS[:] = []
+    for k in ("g_gan", "d_fake", "d_real", "loss_G", "loss_D"):
+        want, got = float(r[k].detach()), float(losses[k].detach())
+        assert abs(got - want) < 2e-4 * max(1.0, abs(want)), (k, got, want)
+    dmax = max(v.grad.abs().max().item() for v in sd_d.values() if v.grad is not None)
+    for n, gq in grads_d.items():
+        w = sd_d[n].grad
+        assert (gq - w).abs().max().item() < 2e-3 * max(w.abs().max().item(), 1e-3 * dmax), n
+    # eval mode: dropout is the identity (test_condition.py / get_norm_const.py use D.eval())
+    D.eval()
+    with torch.no_grad():
+        a = D(torch.randn(1, 33, 64, 48, device="cuda"))
+        b = D(torch.randn(1, 33, 64, 48, device="cuda") * 0 + 0.1)
+    assert a[0][0].shape == b[0][0].shape
+
+
+def test_g_d_separate_ordering_uses_the_updated_generator():
+    """--G_D_seperate (train_condition.py:287-310): the D step sees fake maps of the generator AFTER its Adam
+    step, recomputed in training mode under no_grad and WITHOUT the cloth-mask composition.  Oracle: G step with
+    torch Adam, forward of the updated weights, LSGAN terms."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import networks, pipeline
+    from hr_viton_amd.losses import L1Loss
+    from hr_viton_amd.optim import Adam
+    from oracle.recipes import condstep_build
+    opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D)
+    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, False, False, "warp_grad"
+    opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss, opt.G_D_seperate = 2.0, 10.0, 1.0, False, True
+    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k)
+            for k, v in tocg.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    og = torch.optim.Adam([v for v in sd_g.values() if v.requires_grad], lr=2e-4, betas=(0.5, 0.999))
+    r = O.condition_train_losses(sd_g, sd_d, None, batch, interflowloss=False)
+    og.zero_grad()
+    r["loss_G"].backward()
+    og.step()
+    in1 = torch.cat([batch["cloth"], batch["cloth_mask"]], 1)
+    in2 = torch.cat([batch["parse_agnostic"], batch["densepose"]], 1)
+    O.BN_TRAIN["on"], O.BN_TRAIN["stats"] = True, {}
+    try:
+        with torch.no_grad():
+            _, seg_new, _, _ = O.tocg_forward(sd_g, in1, in2)
+    finally:
+        O.BN_TRAIN["on"] = False
+    soft = torch.softmax(seg_new, 1)
+    with torch.no_grad():
+        want_f = O.lsgan_loss(O.tocg_discriminator_forward(sd_d, torch.cat((in1, in2, soft), 1), 2, 3, True), False)
+        want_r = O.lsgan_loss(O.tocg_discriminator_forward(sd_d, torch.cat((in1, in2, batch["parse"]), 1), 2, 3, True), True)
+    tocg.cuda().train()
+    D.cuda().train()
+    hg = Adam(tocg.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    hd = Adam(D.parameters(), lr=2e-4, betas=(0.5, 0.999))
+    losses = pipeline.condition_train_step(opt, tocg, D, L1Loss(), None, networks.GANLoss(use_lsgan=True), hg, hd,
+                                           {k: v.cuda() for k, v in batch.items()})
+    assert abs(float(losses["d_fake"].detach()) - float(want_f)) < 2e-3 * max(1.0, float(want_f))
+    assert abs(float(losses["d_real"].detach()) - float(want_r)) < 2e-4 * max(1.0, float(want_r))
+    # and it differs from the default ordering's D loss (pre-update fake maps)
+    assert abs(float(r["d_fake"].detach()) - float(want_f)) > 1e-6
+    assert int(tocg.out_layer.block[1].num_batches_tracked) == 2     # two training-mode forwards

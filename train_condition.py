@@ -11,8 +11,7 @@ kernels (hr_viton_amd.cond_train, .functional, .losses, .vgg); one iteration is
     on RCCL during the backward (hr_viton_amd.parallel.GradSync).
   * ``--synthetic`` feeds VITON-HD-shaped random batches (no dataset / torchvision in this image);
     the tensorboard / validation-IoU blocks (train_condition.py:311-418) are out of scope.
-  * not on the HIP path (raise NotImplementedError): --Ddropout, --spectral, --edgeawaretv != no_edge,
-    --G_D_seperate, --upsample nearest, --warp_feature encoder, --out_layer conv.
+  * not on the HIP path (raise NotImplementedError): --upsample nearest, --warp_feature encoder, --out_layer conv.
 """
 import argparse
 import os
@@ -95,8 +94,8 @@ def get_opt(argv=None):
     p.add_argument("--no_vgg_loss", action="store_true", help="drop the VGG terms (train_condition.py always has them)")
     p.add_argument("--vgg_weights", type=str, default="", help="torchvision vgg19 state_dict (.pth); random init if absent")
     opt = p.parse_args(argv)
-    if opt.G_D_seperate or opt.upsample != "bilinear":
-        raise NotImplementedError("hr-viton_amd train_condition: --G_D_seperate / --upsample nearest are not on the HIP path")
+    if opt.upsample != "bilinear":
+        raise NotImplementedError("hr-viton_amd train_condition: --upsample nearest is not on the HIP path")
     return opt
 
 
