@@ -60,6 +60,22 @@ def make_parse(fake_segmap: torch.Tensor, warped_cm: torch.Tensor, fine_height: 
     return gauss, labels, parse7
 
 
+def parse_from_scores(scores: torch.Tensor, want_labels: bool = False):
+    """argmax over 13 classes -> one-hot -> 13->7 merge of an NCHW score / one-hot map (the --GT branch of
+    train_generator.py:253-274: ``fake_parse = parse_GT.argmax(dim=1)``).  Returns (labels or None, parse7 Act)."""
+    lib = _lib.load()
+    ops.require_cuda(scores, "parse_from_scores")
+    N, Cn, H, W = scores.shape
+    assert Cn == 13
+    a = ops.to_nhwc(scores)
+    labels = torch.empty((N, 1, H, W), dtype=torch.int64, device=scores.device) if want_labels else None
+    parse7 = Act(torch.empty((N, H, W, 8), dtype=torch.float32, device=scores.device), 7)
+    _lib.check(lib.hrv_parse_argmax_nhwc_f32(a.t.data_ptr(), a.cstride, 13, N * H * W,
+                                             None if labels is None else labels.data_ptr(), parse7.t.data_ptr(), 8,
+                                             ops._stream()), "hrv_parse_argmax_nhwc_f32")
+    return labels, parse7
+
+
 def hires_warp(flow_last: torch.Tensor, clothes: torch.Tensor, cloth_mask: torch.Tensor,
                norm_x: float = (96 - 1.0) / 2.0, norm_y: float = (128 - 1.0) / 2.0) -> Act:
     """test_generator.py:206-213: up-sample the last flow to the cloth size (size= resize), normalise

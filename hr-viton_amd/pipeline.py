@@ -41,6 +41,12 @@ def tryon_step(opt, tocg, generator, inputs: Dict[str, torch.Tensor], noise=None
 def make_generator_inputs(opt, tocg, inputs: Dict[str, torch.Tensor]):
     """train_generator.py:201-275 (the no_grad block): frozen tocg at 256x192 -> parse glue ->
     high-resolution cloth warp.  Returns (x [N,9,H,W], parse7 Act)."""
+    if getattr(opt, "GT", False):
+        # --GT (train_generator.py:253-256): ground-truth parse map and ground-truth warped cloth, no tocg
+        with torch.no_grad():
+            _, parse7 = glue.parse_from_scores(inputs["parse"])
+            x = torch.cat((inputs["agnostic"], inputs["densepose"], inputs["parse_cloth"]), dim=1)
+        return x, parse7
     with torch.no_grad():
         c_paired, pose, agnostic = inputs["cloth"], inputs["densepose"], inputs["agnostic"]
         H, W = opt.fine_height, opt.fine_width

@@ -235,8 +235,11 @@ def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, g
          accumulate: bool = True, want_grad: bool = True) -> Optional[torch.Tensor]:
     """hrv_loss_f32 over flat contiguous tensors: loss_out[0] (+)= lscale*sum(l); returns grad (same shape as a)."""
     lib = _lib.load()
-    dense = a.is_contiguous() or (a.dim() == 4 and a.is_contiguous(memory_format=torch.channels_last))
-    assert dense and (b is None or (b.shape == a.shape and b.stride() == a.stride())), "loss: operands must share one dense layout"
+    cl = torch.channels_last
+    ok = a.is_contiguous() and (b is None or (b.shape == a.shape and b.is_contiguous()))
+    ok = ok or (a.dim() == 4 and a.is_contiguous(memory_format=cl) and
+                (b is None or (b.shape == a.shape and b.is_contiguous(memory_format=cl))))
+    assert ok, "loss: operands must share one dense layout (strides of size-1 dims do not matter)"
     grad = torch.empty_like(a) if want_grad else None
     ws = _workspace(a.device, 4096)
     _lib.check(lib.hrv_loss_f32(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), mode, lscale, gscale,

@@ -154,3 +154,22 @@ def test_entry_scripts_on_disk_dataset(tmp_path):
              "--checkpoint_dir", ck, "--name", "t", "--shuffle"])
     sd = torch.load(__import__("os").path.join(ck, "t", "tocg_final.pth"), map_location="cpu")
     assert "ClothEncoder.0.block.1.running_mean" in sd and int(sd["out_layer.block.1.num_batches_tracked"]) == 2
+
+
+def test_gt_branch_of_generator_inputs():
+    """--GT (train_generator.py:253-274): parse7 = merge(one-hot(argmax(parse_GT))), x = cat(agnostic, pose, parse_cloth)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, pipeline
+    g = torch.Generator().manual_seed(2)
+    N, H, W = 2, 64, 48
+    lab = torch.randint(0, 13, (N, 1, H, W), generator=g)
+    inputs = {"parse": torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0).cuda(),
+              "agnostic": torch.rand(N, 3, H, W, generator=g).cuda(), "densepose": torch.rand(N, 3, H, W, generator=g).cuda(),
+              "parse_cloth": torch.rand(N, 3, H, W, generator=g).cuda()}
+    x, parse7 = pipeline.make_generator_inputs(Namespace(GT=True), None, inputs)
+    want = torch.zeros(N, 7, H, W)
+    for i, src in O.PARSE_MERGE.items():
+        for l in src:
+            want[:, i] += (lab[:, 0] == l).float()
+    assert torch.equal(ops.to_nchw(parse7).cpu(), want)
+    assert torch.equal(x.cpu(), torch.cat([inputs["agnostic"], inputs["densepose"], inputs["parse_cloth"]], 1).cpu())

@@ -112,9 +112,10 @@ def synthetic_batch(opt, n, seed, device):
     H, W = opt.fine_height, opt.fine_width
     lab = torch.randint(0, 13, (n, 1, H // 32, W // 32), generator=g).repeat_interleave(32, 2).repeat_interleave(32, 3)
     u = lambda c: (torch.rand(n, c, H, W, generator=g) * 2 - 1).to(device)  # noqa: E731
+    onehot = torch.zeros(n, 13, H, W).scatter_(1, lab, 1.0).to(device)
     return {"cloth": u(3), "cloth_mask": (torch.rand(n, 1, H, W, generator=g) > 0.4).float().to(device),
-            "parse_agnostic": torch.zeros(n, 13, H, W).scatter_(1, lab, 1.0).to(device), "densepose": u(3),
-            "agnostic": u(3), "image": u(3)}
+            "parse_agnostic": onehot, "densepose": u(3), "agnostic": u(3), "image": u(3),
+            "parse": onehot, "parse_cloth": u(3)}
 
 
 def main(argv=None):
@@ -190,7 +191,8 @@ def main(argv=None):
             raw = loader.next_batch()                                  # train_generator.py:194-212
             batch = {"cloth": raw["cloth"]["paired"].to(dev), "cloth_mask": raw["cloth_mask"]["paired"].to(dev),
                      "parse_agnostic": raw["parse_agnostic"].to(dev), "densepose": raw["densepose"].to(dev),
-                     "agnostic": raw["agnostic"].to(dev), "image": raw["image"].to(dev)}
+                     "agnostic": raw["agnostic"].to(dev), "image": raw["image"].to(dev),
+                     "parse": raw["parse"].to(dev), "parse_cloth": raw["parse_cloth"].to(dev)}
         x, parse7 = make_generator_inputs(opt, tocg, batch)
         losses, _ = generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, crit_vgg, opt_g, opt_d, x,
                                          parse7, batch["image"], sync_g, sync_d)
