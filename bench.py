@@ -224,10 +224,12 @@ def main():
     from hr_viton_amd import dist as hdist
     from hr_viton_amd import ops
 
-    rank, local_rank, world = hdist.init_from_env("nccl" if args.gpus > 1 else None)
+    rank, local_rank, world = hdist.init_from_env()      # nccl (= RCCL) unless HRV_DIST_BACKEND overrides it
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    ndev = torch.cuda.device_count()
+    local_dev = local_rank % ndev        # == local_rank on a real node; lets a 1-GPU box smoke-test the N>1 logic
+    torch.cuda.set_device(local_dev)
+    dev = torch.device("cuda", local_dev)
     if args.workload != "tocg_infer":
         return other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev)
 

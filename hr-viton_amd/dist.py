@@ -30,7 +30,7 @@ def init_from_env(backend: Optional[str] = None) -> Tuple[int, int, int]:
             # HRV_DIST_BACKEND=gloo: two ranks sharing one GPU in the DP tests (RCCL refuses duplicate devices)
             backend = os.environ.get("HRV_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
-            torch.cuda.set_device(local_rank)
+            torch.cuda.set_device(local_rank % max(1, torch.cuda.device_count()))
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, local_rank, world
 
