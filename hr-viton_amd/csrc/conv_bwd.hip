@@ -654,7 +654,7 @@ extern "C" int hrv_conv2d_pack_weight_dev_bf16(const float* w_oihw_dev, int32_t 
                                                int32_t phase_a, int32_t phase_b, float wscale,
                                                const float* sigma_dev, uint16_t* out_dev, int32_t* out_geom,
                                                hrv_stream_t stream) {
-  const int bke = (tile_cfg == 8 || tile_cfg == 9) ? 64 : 32;
+  const int bke = (tile_cfg >= 8 && tile_cfg <= 11) ? 64 : 32;
   return pack_weight_dev_impl(w_oihw_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, stride, pad, phase_a,
                               phase_b, wscale, sigma_dev, out_dev, out_geom, stream, bke, 1);
 }

@@ -854,6 +854,8 @@ static const TileCfg kCfgs[] = {
     {4, 2, 2, 2, 64},   // 7: 256 x 128
     {2, 2, 2, 2, 128},  // 8: 128 x 128, 64 bf16 k-values per K-tile (bf16 engine only)
     {1, 2, 4, 1, 128},  // 9: 128 x 64,  64 bf16 k-values per K-tile (bf16 engine only)
+    {4, 2, 2, 2, 128},  // 10: 256 x 128 (wave tile 128 x 64: 32 MFMAs per K-tile), LDS-DMA, 96 KB LDS, 1 block / CU
+    {2, 4, 2, 2, 128},  // 11: 128 x 256 (wave tile 64 x 128)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1028,7 +1030,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
       // moving 32 KB per K-tile through the CU's texture path) and keeps the register pipeline.
       // HRV_CONV_GLDS=0/1 forces it off/on (A/B measurements: profiles/r01_conv_bench_bf16_glds.txt).
       const char* eg = getenv("HRV_CONV_GLDS");
-      const bool want = eg ? atoi(eg) != 0 : (32 * TN * WN == 64);
+      const bool want = eg ? atoi(eg) != 0 : (32 * TN * WN == 64 || TM * TN >= 8);
       const bool glds = want && p.w_bytes != 0;
       if (p.src_f32) {
         if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 9, true, RB>), dim3(nblk), dim3(256), 0, st, p);
@@ -1078,6 +1080,8 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 7: return launch_cfg<4, 2, 2, 2>(p, st);
     case 8: return launch_cfg<2, 2, 2, 2, 128>(p, st);
     case 9: return launch_cfg<1, 2, 4, 1, 128>(p, st);
+    case 10: return launch_cfg<4, 2, 2, 2, 128>(p, st);
+    case 11: return launch_cfg<2, 4, 2, 2, 128>(p, st);
   }
   set_error("conv2d: tile_cfg=%d invalid", tile_cfg);
   return HRV_ERR_ARG;

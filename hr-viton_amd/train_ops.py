@@ -40,7 +40,7 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     bn = lib.hrv_conv2d_tile_bn(cfg)
     rows = Cout if mode == 0 else cin
     rows_pad = (rows + bn - 1) // bn * bn
-    bke = (64 if cfg in (8, 9) else 32) if bf16 else 16
+    bke = (64 if 8 <= cfg <= 11 else 32) if bf16 else 16
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
     buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
     geom = (C.c_int32 * 8)()
