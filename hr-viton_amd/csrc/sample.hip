@@ -25,25 +25,52 @@ static inline int grid_for(size_t work, int block = 256) {
 }
 
 // ---------------------------------------------------------------- layout
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ in, int N, int C, int HW, float* __restrict__ out,
-                                    int cs, int co) {
-  const size_t total = (size_t)N * HW;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = i / HW, hw = i - n * HW;
-    const float* src = in + n * (size_t)C * HW + hw;
-    float* dst = out + i * cs + co;
-    for (int c = 0; c < C; ++c) dst[c] = src[(size_t)c * HW];
+// Layout converters at the module boundary: LDS-tiled transposes.  A block moves 64 pixels x up to 64 channels:
+// the NCHW side is accessed plane by plane with 64 consecutive pixels per wave (coalesced), the NHWC side as the
+// contiguous run of the tile's pixels (coalesced); the [64][65] LDS tile absorbs the stride change.
+constexpr int LT_P = 64, LT_C = 64;
+
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, int N, int C, int HW,
+                                                           float* __restrict__ out, int cs, int co) {
+  __shared__ float tile[LT_P][LT_C + 1];
+  const int tiles_per_img = (HW + LT_P - 1) / LT_P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, p0 = (t - n * tiles_per_img) * LT_P;
+    const int np = min(LT_P, HW - p0);
+    for (int c0 = 0; c0 < C; c0 += LT_C) {
+      const int nc = min(LT_C, C - c0);
+      for (int c = wave; c < nc; c += 4)
+        if (lane < np) tile[lane][c] = in[((size_t)n * C + c0 + c) * HW + p0 + lane];
+      __syncthreads();
+      for (int i = threadIdx.x; i < np * nc; i += 256) {
+        const int p = i / nc, c = i - p * nc;
+        out[((size_t)n * HW + p0 + p) * cs + co + c0 + c] = tile[p][c];
+      }
+      __syncthreads();
+    }
   }
 }
 
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, int co, int N, int C, int HW,
-                                    float* __restrict__ out) {
-  const size_t total = (size_t)N * HW;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const size_t n = i / HW, hw = i - n * HW;
-    const float* src = in + i * cs + co;
-    float* dst = out + n * (size_t)C * HW + hw;
-    for (int c = 0; c < C; ++c) dst[(size_t)c * HW] = src[c];
+__global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restrict__ in, int cs, int co, int N, int C,
+                                                           int HW, float* __restrict__ out) {
+  __shared__ float tile[LT_P][LT_C + 1];
+  const int tiles_per_img = (HW + LT_P - 1) / LT_P;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int t = blockIdx.x; t < N * tiles_per_img; t += gridDim.x) {
+    const int n = t / tiles_per_img, p0 = (t - n * tiles_per_img) * LT_P;
+    const int np = min(LT_P, HW - p0);
+    for (int c0 = 0; c0 < C; c0 += LT_C) {
+      const int nc = min(LT_C, C - c0);
+      for (int i = threadIdx.x; i < np * nc; i += 256) {
+        const int p = i / nc, c = i - p * nc;
+        tile[p][c] = in[((size_t)n * HW + p0 + p) * cs + co + c0 + c];
+      }
+      __syncthreads();
+      for (int c = wave; c < nc; c += 4)
+        if (lane < np) out[((size_t)n * C + c0 + c) * HW + p0 + lane] = tile[lane][c];
+      __syncthreads();
+    }
   }
 }
 
@@ -263,8 +290,10 @@ extern "C" int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32
   HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
   HRV_REQUIRE(out_coff >= 0 && out_coff + C <= out_cstride, "nchw_to_nhwc: slice out of range");
   const size_t total = (size_t)N * H * W;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, C, H * W,
-                     out, out_cstride, out_coff);
+  (void)total;
+  const size_t tiles = (size_t)N * (((size_t)H * W + LT_P - 1) / LT_P);
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)(tiles > 16384 ? 16384 : tiles)), dim3(256), 0,
+                     (hipStream_t)stream, in, N, C, H * W, out, out_cstride, out_coff);
   return check_launch("nchw_to_nhwc_kernel");
 }
 
@@ -273,8 +302,10 @@ extern "C" int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t
   HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nhwc_to_nchw: bad args");
   HRV_REQUIRE(in_coff >= 0 && in_coff + C <= in_cstride, "nhwc_to_nchw: slice out of range");
   const size_t total = (size_t)N * H * W;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, in_cstride,
-                     in_coff, N, C, H * W, out);
+  (void)total;
+  const size_t tiles = (size_t)N * (((size_t)H * W + LT_P - 1) / LT_P);
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3((unsigned)(tiles > 16384 ? 16384 : tiles)), dim3(256), 0,
+                     (hipStream_t)stream, in, in_cstride, in_coff, N, C, H * W, out);
   return check_launch("nhwc_to_nchw_kernel");
 }
 

@@ -34,7 +34,8 @@ BF_LAYERS = [
 
 def main():
     bf = os.environ.get("BF16", "0") == "1"
-    if bf:
+    mixed = os.environ.get("MIXED", "0") == "1"      # bf16 MFMA operands over fp32 tensors (training / --fp16 tocg)
+    if bf or mixed:
         LAYERS[:] = BF_LAYERS
     combos = [(int(c), int(v)) for c, v in (x.split(":") for x in os.environ.get(
         "COMBOS", "1:0,1:1,1:3,2:0,2:1,2:3,0:1,7:1").split(","))]
@@ -48,7 +49,7 @@ def main():
         sc = torch.rand(cout, generator=g) + 0.5
         sh = torch.randn(cout, generator=g)
         layer = ops.ConvLayer(w, cins, "cuda", scale=sc, shift=sh, stride=stride, pad=pad, act=ops.ACT_RELU, name=name,
-                               bf16=bf)
+                               bf16=bf, mma_bf16=mixed)
         Ho, Wo = layer.out_hw(H, W)
         out = ops.alloc(N, Ho, Wo, cout, "cuda", bf16=bf)
         r = ops.alloc(N, Ho, Wo, cout, "cuda", bf16=bf) if res else None
@@ -64,7 +65,7 @@ def main():
                 os.environ["HRV_CONV_VARIANT"] = str(var)
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
-                layer(xs, out=out, residual=r)
+                layer(xs, out=out, residual=r, cfg=cfg if mixed else None)
                 e.record()
                 torch.cuda.synchronize()
                 if rd > 0:
