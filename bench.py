@@ -63,7 +63,7 @@ def build_model(torch, nn, mixed=False):
 def _emit(args, torch, hdist, ops, rank, world, B, step, metric, workload, flops_per_img, train):
     mixed = bool(getattr(args, "bf16", False))
     peak = 2500.0 if mixed else PEAK_F32_MFMA_TFLOPS
-    dt = hdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
+    dt = hdist.timed_steps(getattr(args, "_timed", None) or step, args.steps, args.warmup, torch.cuda.synchronize)
     ops.profile_begin()
     step(0)
     recs = ops.profile_end()
@@ -85,7 +85,8 @@ def _emit(args, torch, hdist, ops, rank, world, B, step, metric, workload, flops
                 "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                 "dtype": "bf16 MFMA operands, f32 storage/accumulate" if mixed else "f32", "data": "synthetic",
-                "config": {"workload": workload, "global_batch": B * world,
+                "config": {"workload": workload + (" [hipGraph replay]" if getattr(args, "_timed", None) else ""),
+                           "global_batch": B * world,
                            "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
                 "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
                              "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
@@ -192,6 +193,9 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
 
         def step(_i):
             tryon_step(opt, tocg, gen, batch)
+        if args.graph:
+            from hr_viton_amd.graph import graphed_tryon
+            args._timed = (lambda g: (lambda _i: g(batch)))(graphed_tryon(opt, tocg, gen, batch))
         metric = "1024x768 try-on images/sec (test_generator.py step: tocg@256x192 + glue + SPADE generator)"
         flops_per_img = 1.73e12
     if train:
@@ -216,6 +220,8 @@ def main():
                          "test_generator.py step (configs[4] shape, fp32)")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch for the non-default workloads")
     ap.add_argument("--bf16", action="store_true", help="tryon_infer: run the SPADE generator on the bf16 engine")
+    ap.add_argument("--graph", action="store_true", help="inference workloads: replay the step as one captured hipGraph "
+                                                         "(hr_viton_amd.graph); the per-launch roofline leg stays eager")
     args = ap.parse_args()
 
     import torch
@@ -242,7 +248,15 @@ def main():
     def step(_i):
         model(opt, i1, i2)
 
-    dt = hdist.timed_steps(step, args.steps, args.warmup, torch.cuda.synchronize)
+    timed = step
+    if args.graph:
+        from hr_viton_amd.graph import graphed_condition
+        g = graphed_condition(opt, model, i1, i2)
+        feed = {"input1": i1, "input2": i2}
+
+        def timed(_i):
+            g(feed)
+    dt = hdist.timed_steps(timed, args.steps, args.warmup, torch.cuda.synchronize)
     images = BATCH * world * args.steps
     value = images / dt
 
@@ -315,7 +329,7 @@ def main():
                 "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
                 "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA operands, f32 storage/accumulate" if args.bf16 else "f32", "data": "synthetic",
                 "config": {"workload": "BASELINE configs[1]: ConditionGenerator inference 1024x768 batch=4/GPU "
-                                       "fp32, ngf=96, random-init weights",
+                                       "fp32, ngf=96, random-init weights" + (" [hipGraph replay]" if args.graph else ""),
                            "global_batch": BATCH * world, "height": H, "width": W, "parallelism": f"dp{world}-replicas"},
                 "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
         print(json.dumps(line), flush=True)

@@ -1180,22 +1180,82 @@ extern "C" int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d) {
   return s > 1 ? (int64_t)s * M * n_tiles * bn * (int64_t)sizeof(float) : 0;
 }
 
-extern "C" int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {
+static int conv2d_one(const hrv_conv2d_t* d, hipStream_t stream, bool bf) {
   ConvParams p;
-  int rc = fill_params(d, p, true, false);
+  int rc = fill_params(d, p, true, bf);
   if (rc) return rc;
-  return launch_any(d->tile_cfg, p, (hipStream_t)stream);
+  if (bf)
+    HRV_REQUIRE(!(d->spade && d->spade->g1p_out) || p.src_f32,
+                "conv2d_bf16: g1p_out (training) needs the fp32-source mode (mixed_flags bit 3)");
+  return launch_any(d->tile_cfg, p, stream);
 }
 
-// bf16 storage (sources, packed weights, residual, SPADE x, output), fp32 accumulate / scale / shift /
-// statistics: v_mfma_f32_32x32x16_bf16.  Channel counts, strides and offsets are multiples of 8.
+// The gather addresses a source with 32-bit element offsets.  A batch whose largest source exceeds 2^32 elements
+// (serving batches: 16 x 1024x768 x 384 channels) is issued as consecutive launches over sub-batches of whole
+// images -- convolution rows never cross an image, so only the base pointers move.  Forward geometry only.
+static int conv2d_any(const hrv_conv2d_t* d, hipStream_t stream, bool bf) {
+  HRV_REQUIRE(d != nullptr, "conv2d: null descriptor");
+  HRV_REQUIRE(d->nsrc >= 1 && d->nsrc <= HRV_MAX_SRC && d->N > 0 && d->H > 0 && d->W > 0, "conv2d: bad geometry");
+  int64_t per_img = 0;
+  for (int i = 0; i < d->nsrc; ++i) {
+    const hrv_src_t& s = d->src[i];
+    const int sr = s.up_shift > 0 ? s.up_shift : 0, sl = s.up_shift < 0 ? -s.up_shift : 0;
+    const int64_t e = (int64_t)((d->H >> sr) << sl) * ((d->W >> sr) << sl) * s.cstride;
+    per_img = e > per_img ? e : per_img;
+  }
+  const int64_t out_px = (int64_t)d->Ho * d->Wo;
+  // HRV_CONV_MAX_BATCH caps the images per launch so that the tests can exercise the sub-batch path on small tensors
+  const int64_t lim = (int64_t)1 << 32;
+  int64_t cap = d->N;
+  if (const char* e = getenv("HRV_CONV_MAX_BATCH")) {
+    const long long v = atoll(e);
+    if (v > 0 && v < cap) cap = v;
+  }
+  const bool fits = cap == d->N && d->N * per_img < lim && d->N * out_px < ((int64_t)1 << 31);
+  const bool plain_fwd = d->out_step <= 1 && d->free_extent == 0 && d->res_mode == 0;
+  if (fits || !plain_fwd || per_img <= 0 || out_px <= 0) return conv2d_one(d, stream, bf);
+  int64_t nb = (lim - 1) / per_img;
+  const int64_t nb2 = (((int64_t)1 << 31) - 1) / out_px;
+  nb = nb < nb2 ? nb : nb2;
+  nb = nb < cap ? nb : cap;
+  HRV_REQUIRE(nb >= 1, "conv2d: one image alone exceeds the 32-bit gather range");
+  const bool srcf = bf && (d->mixed_flags & 8);
+  const size_t es_src = bf && !srcf ? 2 : 4, es_out = bf && !(d->mixed_flags & 1) ? 2 : 4;
+  const size_t es_res = bf && !(d->mixed_flags & 2) ? 2 : 4, es_x = bf && !(d->mixed_flags & 4) ? 2 : 4;
+  const int64_t out_img_px = ((int64_t)d->Ho << d->out_up_shift) * ((int64_t)d->Wo << d->out_up_shift);
+  for (int64_t n0 = 0; n0 < d->N; n0 += nb) {
+    hrv_conv2d_t c = *d;
+    hrv_spade_epi_t e;
+    c.N = (int32_t)((d->N - n0) < nb ? (d->N - n0) : nb);
+    for (int i = 0; i < d->nsrc; ++i) {
+      const hrv_src_t& s = d->src[i];
+      const int sr = s.up_shift > 0 ? s.up_shift : 0, sl = s.up_shift < 0 ? -s.up_shift : 0;
+      const int64_t img = (int64_t)((d->H >> sr) << sl) * ((d->W >> sr) << sl) * s.cstride;
+      c.src[i].ptr = (const char*)s.ptr + (size_t)(n0 * img) * es_src;
+    }
+    c.out = (char*)d->out + (size_t)(n0 * out_img_px * d->out_cstride) * es_out;
+    if (d->residual) c.residual = (const char*)d->residual + (size_t)(n0 * out_px * d->res_cstride) * es_res;
+    if (d->spade) {
+      e = *d->spade;
+      e.x = (const float*)((const char*)e.x + (size_t)(n0 * out_px * e.x_cstride) * es_x);
+      e.mean += n0 * e.C;
+      e.rstd += n0 * e.C;
+      if (e.noise_z) e.noise_z += n0 * out_px;
+      if (e.g1p_out) e.g1p_out += n0 * out_px * e.C;
+      c.spade = &e;
+    }
+    const int rc = conv2d_one(&c, stream, bf);
+    if (rc) return rc;
+  }
+  return HRV_OK;
+}
+
+extern "C" int hrv_conv2d_nhwc_f32(const hrv_conv2d_t* d, hrv_stream_t stream) {
+  return conv2d_any(d, (hipStream_t)stream, false);
+}
+
 extern "C" int hrv_conv2d_nhwc_bf16(const hrv_conv2d_t* d, hrv_stream_t stream) {
-  ConvParams p;
-  int rc = fill_params(d, p, true, true);
-  if (rc) return rc;
-  HRV_REQUIRE(!(d->spade && d->spade->g1p_out) || p.src_f32,
-              "conv2d_bf16: g1p_out (training) needs the fp32-source mode (mixed_flags bit 3)");
-  return launch_any(d->tile_cfg, p, (hipStream_t)stream);
+  return conv2d_any(d, (hipStream_t)stream, true);
 }
 
 static inline unsigned short host_f2bf(float f) {

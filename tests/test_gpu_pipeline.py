@@ -173,3 +173,54 @@ def test_gt_branch_of_generator_inputs():
             want[:, i] += (lab[:, 0] == l).float()
     assert torch.equal(ops.to_nchw(parse7).cpu(), want)
     assert torch.equal(x.cpu(), torch.cat([inputs["agnostic"], inputs["densepose"], inputs["parse_cloth"]], 1).cpu())
+
+
+def test_hipgraph_replay_is_bit_identical_to_eager():
+    """hr_viton_amd.graph: the captured try-on step (tocg -> glue -> generator) replays the same launches, so the
+    outputs are bit-identical to an eager call on the same inputs -- also after the inputs change (static-buffer
+    refresh), and the integer label map is exact."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.graph import graphed_condition, graphed_tryon
+    from hr_viton_amd.network_generator import SPADEGenerator
+    from hr_viton_amd.networks import ConditionGenerator
+    from hr_viton_amd.ops import HrvError
+    from hr_viton_amd.pipeline import tryon_step
+    H, W = 256, 192
+    opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu", norm_G="spectralaliasinstance", gen_semantic_nc=7,
+                    ngf=8, num_upsampling_layers="more", fine_height=H, fine_width=W, occlusion=True,
+                    clothmask_composition="warp_grad")
+    torch.manual_seed(0)
+    tocg = ConditionGenerator(opt, 4, 16, 13, ngf=16, norm_layer=nn.BatchNorm2d).cuda().eval()
+    gen = SPADEGenerator(opt, 9)
+    gen.init_weights("xavier", 0.02)
+    gen.cuda().eval()          # noise_scale is zero at init: the SPADE noise draw does not reach the output
+
+    def batch(seed, N=2):
+        g = torch.Generator().manual_seed(seed)
+        lab = torch.randint(0, 13, (N, 1, H // 32, W // 32), generator=g).repeat_interleave(32, 2).repeat_interleave(32, 3)
+        b = {"cloth": torch.rand(N, 3, H, W, generator=g) * 2 - 1, "cloth_mask": (torch.rand(N, 1, H, W, generator=g) > 0.4).float(),
+             "parse_agnostic": torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0), "densepose": torch.rand(N, 3, H, W, generator=g) * 2 - 1,
+             "agnostic": torch.rand(N, 3, H, W, generator=g) * 2 - 1}
+        return {k: v.cuda() for k, v in b.items()}
+
+    b0, b1 = batch(0), batch(1)
+    g = graphed_tryon(opt, tocg, gen, b0)
+    for b in (b0, b1, b0):
+        want = tryon_step(opt, tocg, gen, b)
+        got = g(b)
+        for k in ("output", "warped_cloth", "warped_clothmask", "fake_segmap"):
+            assert torch.equal(got[k], want[k]), k
+        assert torch.equal(got["fake_parse"], want["fake_parse"])
+        for fg, fw in zip(got["flow_list"], want["flow_list"]):
+            assert torch.equal(fg, fw)
+    assert g.replays == 3
+    with pytest.raises(HrvError):
+        g({k: v[:1] for k, v in b0.items()})          # a new shape needs a new capture
+    with pytest.raises(HrvError):
+        graphed_condition(opt, tocg, torch.zeros(1, 4, H, W), torch.zeros(1, 16, H, W))   # host tensors: no CPU path
+    # the condition generator alone
+    i1, i2 = torch.randn(2, 4, H, W, device="cuda"), torch.randn(2, 16, H, W, device="cuda")
+    gc = graphed_condition(opt, tocg, i1, i2)
+    want = tocg(opt, i1, i2)
+    got = gc({"input1": i1, "input2": i2})
+    assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and torch.equal(got[0][-1], want[0][-1])
