@@ -95,6 +95,9 @@ SYMBOLS = {
     "hrv_conv2d_wgrad_bf16mma_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                                     _i64, _vp, _i32, _vp, _i32, _vp]),
+    "hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                          _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                          _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
     "hrv_colsum_nhwc_f32": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hrv_norm_bwd_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "hrv_spade_norm_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), _vp]),

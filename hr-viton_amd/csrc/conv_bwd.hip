@@ -87,6 +87,7 @@ struct WgradParams {
   int CinTot;
   int co_tiles, ci_tiles, taps, S;
   float* ws;        // [S][taps][Cout][CinTot]  (only this source's ci range is written)
+  int x_bf16;       // bf16-MMA kernel only: X is stored as bf16 (a tensor only matrix cores read: same rounding, half the bytes)
   float* bias_ws;   // [S][Cout] partial column sums of dY (bias gradient), or null: computed as one extra
                     // "ones" column right after the (tap, ci) columns -- same MFMAs, same fixed reduction order
 };
@@ -281,7 +282,7 @@ __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2w));
 }
 
-template <int TM, int TN, int WM, int WN>
+template <int TM, int TN, int WM, int WN, bool XB = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams p) {
   constexpr int BMc = 32 * TM * WM;  // couts per block
   constexpr int BNc = 32 * TN * WN;  // (tap, cin) columns per block
@@ -364,7 +365,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
         const bool ok = row_ok && pix < p.P && (unsigned)wi < (unsigned)p.W;                              \
         const int wic = min(max(wi, 0), p.W - 1);                                                         \
         const size_t off = (rowoff + ((wic >> sr) << sl)) * p.x_cs + p.x_co + xci[r];                     \
-        f32x4 v = *reinterpret_cast<const f32x4*>(p.x + off);                                             \
+        f32x4 v;                                                                                          \
+        if constexpr (XB) {                                                                               \
+          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.x) + off); \
+          v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u); \
+          v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u); \
+        } else {                                                                                          \
+          v = *reinterpret_cast<const f32x4*>(p.x + off);                                                 \
+        }                                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = ok ? v[e] : 0.f;                             \
         if (xones[r]) v[0] = pix < p.P ? 1.f : 0.f;                                                       \
         xreg[r][j] = v;                                                                                   \
@@ -672,7 +680,7 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
                       int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
                       int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes, float* dw_oihw,
                       int32_t accumulate, float* dbias, int32_t dbias_accumulate, hrv_stream_t stream,
-                      const bool mma_bf16) {
+                      const bool mma_bf16, const bool x_bf16 = false) {
   HRV_REQUIRE(dy && x && workspace && dw_oihw, "wgrad: null pointer");
   HRV_REQUIRE(Cout > 0 && x_C > 0 && x_C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 && dy_cstride % 4 == 0 &&
                   dy_coff % 4 == 0 && x_C_real > 0 && x_C_real <= x_C && ci_base >= 0 && ci_base + x_C_real <= CinTot,
@@ -685,6 +693,8 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   p.x = x; p.x_C = x_C; p.x_cs = x_cstride; p.x_co = x_coff; p.x_up = x_up_shift;
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.P = N * Ho * Wo; p.ci_base = ci_base; p.ci_real = x_C_real; p.CinTot = CinTot;
+  p.x_bf16 = x_bf16 ? 1 : 0;
+  HRV_REQUIRE(!x_bf16 || mma_bf16, "wgrad: a bf16 X exists for the bf16 matrix-core kernel only");
   const int wt = pick_wtile(Cout, x_C);
   const int bm = wt_bm(wt), bn = wt_bn(wt);
   p.taps = KH * KW;
@@ -705,7 +715,8 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   const int nblk = tiles * S;
 #define WG_CASE(I, A, B, Cc, D)                                                                                   \
   case I:                                                                                                         \
-    if (mma_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p);     \
+    if (mma_bf16 && x_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D, true>), dim3(nblk), dim3(256), 0, st, p); \
+    else if (mma_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p); \
     else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p);              \
     break;
   switch (wt) {
@@ -753,6 +764,22 @@ extern "C" int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cst
   return wgrad_impl(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base, CinTot, N, H,
                     W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, dbias,
                     dbias_accumulate, stream, true);
+}
+
+// Same again with X stored as bf16 (``x`` points at bf16 elements; x_C / x_cstride / x_coff in elements, multiples
+// of 4): activations that only matrix cores read (ReLU(conv_shared(seg)), the SPADE-modulated conv inputs) are
+// kept in bf16 by the mixed-precision training plan -- the MMA operand is the same bf16 value either way.
+extern "C" int hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+                                                       const void* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
+                                                       int32_t x_up_shift, int32_t x_C_real, int32_t ci_base,
+                                                       int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho,
+                                                       int32_t Wo, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                                       float* workspace, int64_t workspace_bytes, float* dw_oihw,
+                                                       int32_t accumulate, float* dbias, int32_t dbias_accumulate,
+                                                       hrv_stream_t stream) {
+  return wgrad_impl(dy, dy_cstride, dy_coff, Cout, (const float*)x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base,
+                    CinTot, N, H, W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, dbias,
+                    dbias_accumulate, stream, true, true);
 }
 
 extern "C" int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,

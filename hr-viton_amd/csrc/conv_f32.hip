@@ -901,8 +901,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
   p.res_f32 = bf ? ((d->mixed_flags >> 1) & 1) : 1;
   p.sx_f32 = bf ? ((d->mixed_flags >> 2) & 1) : 1;
   p.src_f32 = srcf ? 1 : 0;
-  HRV_REQUIRE(!srcf || (rb == 128 && p.out_f32 && p.res_f32 && p.sx_f32),
-              "conv2d: fp32-source bf16 mode needs a 128-byte-row tile (cfg 8/9) and fp32 out/residual/x (mixed_flags 15)");
+  HRV_REQUIRE(!srcf || rb == 128, "conv2d: fp32-source bf16 mode needs a 128-byte-row tile (cfg 8/9)");
   p.nsrc = d->nsrc;
   int chunks_total = 0;
   bool dma_ok = bf && rb == 128 && !srcf;   // LDS-DMA staging: every operand must fit a 32-bit buffer resource
@@ -1184,9 +1183,6 @@ static int conv2d_one(const hrv_conv2d_t* d, hipStream_t stream, bool bf) {
   ConvParams p;
   int rc = fill_params(d, p, true, bf);
   if (rc) return rc;
-  if (bf)
-    HRV_REQUIRE(!(d->spade && d->spade->g1p_out) || p.src_f32,
-                "conv2d_bf16: g1p_out (training) needs the fp32-source mode (mixed_flags bit 3)");
   return launch_any(d->tile_cfg, p, stream);
 }
 

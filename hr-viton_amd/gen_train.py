@@ -96,11 +96,11 @@ class TConv:
             self.u, self.v = self.conv.weight_u.clone(), self.conv.weight_v.clone()
 
     def forward(self, srcs: Sequence[Tuple[Act, int]], act: int = ACT_NONE, residual: Optional[Act] = None,
-                out: Optional[Act] = None, out_up: int = 0, slope: float = 0.2) -> Act:
+                out: Optional[Act] = None, out_up: int = 0, slope: float = 0.2, out_bf16: bool = False) -> Act:
         b = self.bparam
         return T.conv_forward_dev(self.wparam.data, srcs, self.stride, self.pad, sigma=self.sigma,
                                   shift=None if b is None else b.data, residual=residual, act=act, slope=slope, out=out,
-                                  out_up=out_up, name=self.name)
+                                  out_up=out_up, name=self.name, out_bf16=out_bf16)
 
     def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
                  act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True) -> Optional[Act]:
@@ -147,14 +147,21 @@ class SpadeT:
         rows_g = torch.tensor([g * 64 + l for g in range(G) for l in range(32) if g * 32 + l < self.C], device=dev)
         self.rows_g, self.rows_b = rows_g, rows_g + 32
 
-    def forward(self, x: Act, seg: Act, seg_shift: int, z: Optional[torch.Tensor]):
+    def shared_as_1x1(self) -> Tuple[torch.Tensor, torch.Tensor, int]:
+        """conv_shared's 3x3 weight as a 1x1 over the tap-expanded label map (ops.tap_expand: tap-major, channel-
+        minor, channels padded to one 16-byte group): ([hid, 9*cp, 1, 1], bias, cp)."""
+        w = self.shared.wparam.data                       # [hid, label_nc, 3, 3]
+        co, c, kh, kw = w.shape
+        return w.permute(0, 2, 3, 1), self.shared.bparam.data, c
+
+    def forward(self, x: Act, actv: Act, z: Optional[torch.Tensor]):
         n = self.norm
         dev = x.t.device
         ns = torch.zeros(self.Cp, device=dev)
         ns[: self.C] = n.noise_scale.data
         zz = z  # the noise term is always applied in training (noise_scale is a learnable parameter)
         mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
-        actv = self.shared.forward([(seg, -seg_shift)], act=ACT_RELU)
+        mb = T.MMA_BF16[0]     # mixed precision: bf16 matrix cores, fp32 epilogue / statistics / x
         # combined (gamma32 | beta32) weight / bias for the fused modulate epilogue (device gather)
         wc = torch.zeros((self.G * 64, self.hid, 3, 3), device=dev)
         wc.index_copy_(0, self.rows_g, n.conv_gamma.weight.data)
@@ -162,7 +169,6 @@ class SpadeT:
         bc = torch.zeros(self.G * 64, device=dev)
         bc.index_copy_(0, self.rows_g, n.conv_gamma.bias.data)
         bc.index_copy_(0, self.rows_b, n.conv_beta.bias.data)
-        mb = T.MMA_BF16[0]     # mixed precision: bf16 matrix cores over the fp32 actv, fp32 epilogue
         cfg = ((8 if self.G % 2 == 0 else 9) if mb else self.cfg)
         packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], cfg, 0, 1, 1, bf16=mb)
         out = ops.alloc(x.N, x.H, x.W, self.C, dev)
@@ -180,9 +186,10 @@ class SpadeT:
         d.KH, d.KW, d.stride, d.pad = 3, 3, 1, 1
         d.nsrc = 1
         s = d.src[0]
-        s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = actv.t.data_ptr(), self.hid, actv.cstride, 0, 0, 0, self.hid
+        s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = (actv.t.data_ptr(), self.hid, actv.cstride,
+                                                                          actv.coff, 0, 0, self.hid)
         d.w_packed, d.Cout, d.tile_cfg = packed.data_ptr(), self.G * 64, cfg
-        d.mixed_flags = 15 if mb else 0
+        d.mixed_flags = (7 if actv.bf16 else 15) if mb else 0
         d.shift = bc.data_ptr()
         d.act, d.act_slope = self.act, 0.2
         d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
@@ -191,11 +198,12 @@ class SpadeT:
         with ops._Timed("conv", self.name + ".conv_gamma|beta", fl, 0):
             fn = lib.hrv_conv2d_nhwc_bf16 if mb else lib.hrv_conv2d_nhwc_f32
             ops._lib.check(fn(C.byref(d), ops._stream()), "hrv_conv2d_nhwc_%s[spade]" % ("bf16" if mb else "f32"))
-        ctx = dict(x=x, seg=seg, seg_shift=seg_shift, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv,
-                   g1p=Act(g1p, self.C), out=out)
+        ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C), out=out)
         return out, ctx
 
-    def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool) -> Act:
+    def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool, dact: Act) -> Act:
+        """``dact``: this norm's slice of the block-wide d(actv) tensor (the block back-propagates its norms'
+        conv_shared together, BlockT.backward)."""
         n = self.norm
         C_, Cp = self.C, self.Cp
         dev = dout.t.device
@@ -223,8 +231,7 @@ class SpadeT:
         _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
         _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
         # d actv, with the ReLU derivative of conv_shared fused (slope 0)
-        dact = T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, name=self.name + ".gb.dgrad")
-        self.shared.backward(dact, [(ctx["seg"], -ctx["seg_shift"])], grads, need_dx=False)
+        T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad")
         return dx
 
 
@@ -243,18 +250,65 @@ class BlockT:
     def convs(self):
         return [self.c0, self.c1] + ([self.cs] if self.learned else [])
 
+    def norms(self):
+        return ([self.ns_] if self.learned else []) + [self.n0, self.n1]
+
+    def shared_forward(self, seg: Act, seg_shift: int):
+        """The conv_shared 3x3s (label_nc -> 128, + ReLU) of the block's norms as ONE 1x1 convolution over the
+        tap-expanded label map (ops.tap_expand: 9 taps x 8 padded channels = 72 dense inputs): the label map is
+        read once per block and no K-tile is 7/8 padding (the 3x3 form spends 9 K-tiles on 8 channels each).
+        Mixed precision: the one-hot map is exact in bf16, and actv is read by matrix cores only (the gamma|beta
+        conv, its weight gradient, the sign mask of its data gradient) -- both are stored in bf16 there; levels
+        whose width is not a multiple of 4 take the fp32 weight-gradient kernel and stay fp32."""
+        norms = self.norms()
+        mb = T.MMA_BF16[0] and (seg.W >> seg_shift) % 4 == 0
+        sg = seg
+        if mb and seg.coff == 0 and seg.cstride == 8:
+            sg = getattr(seg, "_as_bf16", None)          # one cast per step, shared by the blocks
+            if sg is None:
+                sg = seg._as_bf16 = Act(seg.t.to(torch.bfloat16), seg.C)
+        mb = mb and sg.bf16
+        segx = ops.tap_expand(sg, seg_shift, 3)
+        cp = sg.Cp
+        ws, bs = [], []
+        for n_ in norms:
+            w, b, c = n_.shared_as_1x1()
+            wt = torch.zeros((w.shape[0], 9, cp), device=w.device)
+            wt[:, :, :c] = w.reshape(w.shape[0], 9, c)
+            ws.append(wt.reshape(w.shape[0], 9 * cp, 1, 1))
+            bs.append(b)
+        hid = norms[0].hid
+        actv_all = T.conv_forward_dev(torch.cat(ws, 0), [(segx, 0)], 1, 0, shift=torch.cat(bs, 0), act=ACT_RELU,
+                                      out_bf16=mb, name=self.name + ".conv_shared[x%d as 1x1 over taps]" % len(norms))
+        return segx, [actv_all.slice(hid * i, hid) for i in range(len(norms))]
+
+    def shared_backward(self, segx: Act, dact_all: Act, grads: Grads):
+        norms = self.norms()
+        hid, cp = norms[0].hid, segx.C // 9
+        dw = torch.empty((hid * len(norms), segx.C, 1, 1), device=dact_all.t.device)
+        db = torch.empty(hid * len(norms), device=dact_all.t.device)
+        T.conv_wgrad(dact_all, segx, 0, 0, segx.C, 1, 1, 1, 0, dw, name=self.name + ".conv_shared.wgrad", dbias=db)
+        for i, n_ in enumerate(norms):
+            c = n_.shared.wparam.shape[1]
+            g = dw[hid * i:hid * (i + 1)].reshape(hid, 9, cp)[:, :, :c].permute(0, 2, 1).reshape(hid, c, 3, 3)
+            _acc(grads, n_.shared.wparam, g.contiguous())
+            _acc(grads, n_.shared.bparam, db[hid * i:hid * (i + 1)].clone())
+
     def forward(self, x: Act, seg: Act, seg_shift: int, zs, out: Optional[Act], out_up: int, out_act: int):
         zi = iter(zs)
         ctx = {"x": x}
+        segx, actvs = self.shared_forward(seg, seg_shift)
+        ai = iter(actvs)
+        ctx["segx"] = segx
         if self.learned:
-            hs, ctx["ns"] = self.ns_.forward(x, seg, seg_shift, next(zi))
+            hs, ctx["ns"] = self.ns_.forward(x, next(ai), next(zi))
             x_s = self.cs.forward([(hs, 0)])
             ctx["hs"] = hs
         else:
             x_s = x
-        h0, ctx["n0"] = self.n0.forward(x, seg, seg_shift, next(zi))
+        h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi))
         dx = self.c0.forward([(h0, 0)])
-        h1, ctx["n1"] = self.n1.forward(dx, seg, seg_shift, next(zi))
+        h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi))
         o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up)
         ctx.update(h0=h0, h1=h1)
         return o, ctx
@@ -262,15 +316,20 @@ class BlockT:
     def backward(self, ctx, d_out: Act, grads: Grads) -> Act:
         """d_out: gradient w.r.t. the block's PRE-activation output (x_s + conv_1(...)) at block resolution."""
         x = ctx["x"]
+        norms = self.norms()
+        hid = norms[0].hid
+        dact_all = ops.alloc(x.N, x.H, x.W, hid * len(norms), x.t.device)
+        k0 = 1 if self.learned else 0          # slice order = norms(): [norm_s,] norm_0, norm_1
         d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads)
-        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False)
+        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid))
         d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads)
-        d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False)
+        d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False, dact_all.slice(hid * k0, hid))
         if self.learned:
             d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads)
-            self.ns_.backward(ctx["ns"], d_hs, grads, d_x, True)
+            self.ns_.backward(ctx["ns"], d_hs, grads, d_x, True, dact_all.slice(0, hid))
         else:
             T.add_slice(d_out, d_x, True)
+        self.shared_backward(ctx["segx"], dact_all, grads)
         return d_x
 
 

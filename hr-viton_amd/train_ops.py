@@ -63,10 +63,12 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
     d.KH, d.KW, d.stride, d.pad = KH, KW, stride, pad_h
     d.pad_w_plus1 = pad_w + 1
     d.nsrc = len(srcs)
+    src_bf16 = srcs[0][0].bf16
     for i, (a, up, creal) in enumerate(srcs):
         s = d.src[i]
-        s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = (a.t.data_ptr(), _ceil4(creal), a.cstride,
-                                                                          a.coff, up, 0, creal)
+        assert a.bf16 == src_bf16, f"{name}: the sources of one convolution share one storage type"
+        s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = (a.t.data_ptr(), ops._cpad(creal, a.bf16),
+                                                                          a.cstride, a.coff, up, 0, creal)
     d.w_packed = w_packed.data_ptr()
     d.Cout, d.tile_cfg = Cout, cfg
     d.scale = None if scale is None else scale.data_ptr()
@@ -86,7 +88,12 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
     if spade is not None:
         d.spade = C.pointer(spade)
     if mma_bf16:
-        d.mixed_flags = 15
+        # storage types of the tensors around the bf16 matrix cores: fp32 unless a tensor is one that only
+        # matrix cores read (kept in bf16: same operand bits, half the bytes, LDS-DMA staging)
+        d.mixed_flags = ((0 if out.bf16 else 1) | (0 if (residual is not None and residual.bf16) else 2) | 4 |
+                         (0 if src_bf16 else 8))
+    else:
+        assert not (src_bf16 or out.bf16 or (residual is not None and residual.bf16)), f"{name}: bf16 tensors need MMA_BF16"
     with _Timed("conv", name, flops, 0):
         fn = lib.hrv_conv2d_nhwc_bf16 if mma_bf16 else lib.hrv_conv2d_nhwc_f32
         _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_{'bf16' if mma_bf16 else 'f32'}[{name}]")
@@ -95,8 +102,10 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
 
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
-                     slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv") -> Act:
-    """Forward convolution with device-resident, per-step packed weights.  ``srcs``: (Act, up_shift)."""
+                     slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
+                     out_bf16: bool = False) -> Act:
+    """Forward convolution with device-resident, per-step packed weights.  ``srcs``: (Act, up_shift).
+    ``out_bf16`` (mixed precision only): store the result in bf16 -- for tensors that only matrix cores read."""
     lib = _lib.load()
     Cout, cin, KH, KW = w.shape
     a0, up0 = srcs[0]
@@ -107,10 +116,10 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
-    packed, _ = pack_weight_dev(w, [_ceil4(c) for c in real], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
+    packed, _ = pack_weight_dev(w, [a.Cp for a, _ in srcs], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
                                 bf16=mb)
     if out is None:
-        out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device)
+        out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device, bf16=out_bf16 and mb)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     return _run_engine([(a, up, a.C) for a, up in srcs], packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad, pad,
                        out, shift=shift, residual=residual, act=act, slope=slope, out_up=out_up, name=name, flops=fl,
@@ -165,6 +174,9 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     fl = 2.0 * N * Ho * Wo * Cout * x.C * KH * KW
     # mixed precision: bf16 matrix cores (needs Wo % 4 == 0; the odd-sized PatchGAN maps keep the fp32 kernel)
     fn = lib.hrv_conv2d_wgrad_bf16mma_nhwc_f32 if (MMA_BF16[0] and Wo % 4 == 0) else lib.hrv_conv2d_wgrad_nhwc_f32
+    if x.bf16:
+        assert MMA_BF16[0] and Wo % 4 == 0, f"{name}: a bf16 activation needs the bf16 matrix-core weight gradient"
+        fn = lib.hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32
     with _Timed("wgrad", name, fl, 0):
         _lib.check(fn(dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp,
                                                  x.cstride, x.coff, x_up, x.C, ci_base, cin_tot, N, H, W, Ho, Wo, KH, KW,

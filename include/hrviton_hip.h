@@ -138,7 +138,7 @@ typedef struct hrv_conv2d {
   int32_t mixed_flags;  /* hrv_conv2d_nhwc_bf16 only: bit0 = `out` is fp32, bit1 = `residual` is fp32,
                            bit2 = the SPADE `x` is fp32 (tensors that feed an InstanceNorm stay fp32),
                            bit3 = the conv SOURCES are fp32 and are rounded to bf16 while staged
-                           (mixed-precision training; needs bits 0-2 and a 128-byte-row tile) */
+                           (mixed-precision training; needs a 128-byte-row tile, cfg 8/9) */
   int32_t _pad3;
 } hrv_conv2d_t;
 
@@ -202,6 +202,14 @@ int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cstride, int32
                               int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,
                               int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, float* dbias,
                               int32_t dbias_accumulate, hrv_stream_t stream);
+/* Same again with X stored as bf16 (`x` points at bf16 elements; counts in elements, multiples of 4): tensors
+ * that only matrix cores read are kept in bf16 by the mixed-precision training plan (same MMA operand bits). */
+int hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+                              const void* x, int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift,
+                              int32_t x_C_real, int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W,
+                              int32_t Ho, int32_t Wo, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                              float* workspace, int64_t workspace_bytes, float* dw_oihw, int32_t accumulate,
+                              float* dbias, int32_t dbias_accumulate, hrv_stream_t stream);
 int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,
                         int64_t workspace_bytes, float* out, int32_t accumulate, hrv_stream_t stream);
 
