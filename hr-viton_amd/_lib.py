@@ -37,7 +37,8 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dgb", C.c_void_p), ("dgb_cstride", C.c_int32), ("dgb_coff", C.c_int32),
                 ("dx", C.c_void_p), ("dx_cstride", C.c_int32), ("dx_coff", C.c_int32),
                 ("dx_accumulate", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
-                ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p)]
+                ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p),
+                ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32)]
 
 
 class hrv_conv2d_t(C.Structure):
@@ -95,9 +96,9 @@ SYMBOLS = {
     "hrv_conv2d_wgrad_bf16mma_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
                                                     _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp,
                                                     _i64, _vp, _i32, _vp, _i32, _vp]),
-    "hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
-                                                          _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
-                                                          _vp, _i64, _vp, _i32, _vp, _i32, _vp]),
+    "hrv_conv2d_wgrad_bf16mma_st_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                       _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
+                                                       _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),
     "hrv_colsum_nhwc_f32": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hrv_norm_bwd_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "hrv_spade_norm_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), _vp]),

@@ -277,23 +277,36 @@ typedef float f32x2w __attribute__((ext_vector_type(2)));
 constexpr int BKP = 32;      // pixels per K-tile
 constexpr int LKP = 40;      // LDS row stride in bf16 elements (32 + 8 pad)
 
+__device__ __forceinline__ f32x4 widen_bf16x4(uint2 u) {   // 4 stored bf16 -> the same values as fp32
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+  v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+  return v;
+}
+
 __device__ __forceinline__ unsigned pk_bf16(float a, float b) {
   const f32x2w v = {a, b};
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2w));
 }
 
-template <int TM, int TN, int WM, int WN, bool XB = false>
+template <int TM, int TN, int WM, int WN, bool XB = false, bool YB = false>
 __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams p) {
   constexpr int BMc = 32 * TM * WM;  // couts per block
   constexpr int BNc = 32 * TN * WN;  // (tap, cin) columns per block
-  constexpr int YG = BMc / 4, XG = BNc / 4;             // channel groups per pixel
+  // 4 channels per load task: 16 bytes of fp32, or 8 bytes of a bf16-STORED operand (XB / YB) widened in
+  // registers.  (Measured: 8-channel / 16-byte packed tasks with a v_perm_b32 transpose halve the loads in flight
+  // per thread and run 25 % SLOWER -- this kernel is bound by global-load latency, not by VALU or bytes.)
+  constexpr int YC = 4, XC = 4;
+  constexpr int YG = BMc / YC, XG = BNc / XC;           // channel groups per pixel
   constexpr int YT = (8 * YG + 255) / 256;              // quad tasks per thread per K-tile
   constexpr int XT = (8 * XG + 255) / 256;
+  constexpr int XOFF = 0;
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BMc + BNc) * LKP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
+  const int xtid = (tid + XOFF) & 255;
 
   int b = xcd_remap(blockIdx.x, p.co_tiles * p.ci_tiles * p.S);
   const int it = b % p.ci_tiles; b /= p.ci_tiles;
@@ -312,10 +325,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
   bool xcol_ok[XT], xones[XT];
 #pragma unroll
   for (int r = 0; r < XT; ++r) {
-    const int task = tid + 256 * r;
+    const int task = xtid + 256 * r;
     const int g = task % XG;
     xq[r] = task / XG;
-    const int col = col0 + g * 4;
+    const int col = col0 + g * XC;
     xones[r] = p.bias_ws != nullptr && task < 8 * XG && col == p.taps * p.x_C;
     xcol_ok[r] = task < 8 * XG && col < p.taps * p.x_C;
     const int tap = xcol_ok[r] ? col / p.x_C : 0;
@@ -329,6 +342,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
     xho[r] = rem / p.Wo;
     xwo[r] = rem - xho[r] * p.Wo;
   }
+  // staging registers: [task][pixel of the quad] = one 16-byte load (4 fp32 or 8 packed bf16 channels)
   f32x4 yreg[YT][4], xreg[XT][4];
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -343,12 +357,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
     _Pragma("unroll") for (int r = 0; r < YT; ++r) {                                                      \
       const int task = tid + 256 * r;                                                                     \
       const int g = task % YG, q = task / YG;                                                             \
-      const int c = co0 + g * 4;                                                                          \
+      const int c = co0 + g * YC;                                                                         \
       _Pragma("unroll") for (int j = 0; j < 4; ++j) {                                                     \
         const int pix = (T)*BKP + q * 4 + j;                                                              \
         const bool ok = task < 8 * YG && pix < p.P && c < p.Cout;                                         \
         const size_t off = ok ? (size_t)pix * p.dy_cs + p.dy_co + c : (size_t)p.dy_co;                    \
-        f32x4 v = *reinterpret_cast<const f32x4*>(p.dy + off);                                            \
+        f32x4 v;                                                                                          \
+        if constexpr (YB) {                                                                               \
+          v = widen_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.dy) + off)); \
+        } else {                                                                                          \
+          v = *reinterpret_cast<const f32x4*>(p.dy + off);                                                \
+        }                                                                                                 \
         _Pragma("unroll") for (int e = 0; e < 4; ++e) v[e] = (ok && c + e < p.Cout) ? v[e] : 0.f;         \
         yreg[r][j] = v;                                                                                   \
       }                                                                                                   \
@@ -367,9 +386,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
         const size_t off = (rowoff + ((wic >> sr) << sl)) * p.x_cs + p.x_co + xci[r];                     \
         f32x4 v;                                                                                          \
         if constexpr (XB) {                                                                               \
-          const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.x) + off); \
-          v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u); \
-          v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u); \
+          v = widen_bf16x4(*reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(p.x) + off)); \
         } else {                                                                                          \
           v = *reinterpret_cast<const f32x4*>(p.x + off);                                                 \
         }                                                                                                 \
@@ -385,7 +402,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
     }                                                                                                     \
   }
 
-// registers -> LDS: channel-major rows, the quad's 4 pixels of one channel as one 8-byte store
+// one operand's quad (4 pixels x CG channels, REG[j] = pixel j) -> LDS: channel-major rows, the quad's 4 pixels
+// of one channel as one 8-byte store
+#define WB_STORE_QUAD(REG, DST, CH0, Q)                                                                   \
+  {                                                                                                       \
+    _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
+      uint2 w2;                                                                                           \
+      w2.x = pk_bf16(REG[0][e], REG[1][e]);                                                               \
+      w2.y = pk_bf16(REG[2][e], REG[3][e]);                                                               \
+      *reinterpret_cast<uint2*>(DST + ((CH0) + e) * LKP + (Q)*4) = w2;                                    \
+    }                                                                                                     \
+  }
 #define WB_STORE(BUF)                                                                                     \
   {                                                                                                       \
     unsigned short* Ys = smem + (BUF) * (BMc + BNc) * LKP;                                                \
@@ -393,26 +420,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
     _Pragma("unroll") for (int r = 0; r < YT; ++r) {                                                      \
       const int task = tid + 256 * r;                                                                     \
       const int g = task % YG, q = task / YG;                                                             \
-      if (task < 8 * YG) {                                                                                \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-          uint2 w2;                                                                                       \
-          w2.x = pk_bf16(yreg[r][0][e], yreg[r][1][e]);                                                   \
-          w2.y = pk_bf16(yreg[r][2][e], yreg[r][3][e]);                                                   \
-          *reinterpret_cast<uint2*>(Ys + (g * 4 + e) * LKP + q * 4) = w2;                                 \
-        }                                                                                                 \
-      }                                                                                                   \
+      if (task < 8 * YG) WB_STORE_QUAD(yreg[r], Ys, g * YC, q)                                        \
     }                                                                                                     \
     _Pragma("unroll") for (int r = 0; r < XT; ++r) {                                                      \
-      const int task = tid + 256 * r;                                                                     \
+      const int task = xtid + 256 * r;                                                                    \
       const int g = task % XG;                                                                            \
-      if (task < 8 * XG) {                                                                                \
-        _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                   \
-          uint2 w2;                                                                                       \
-          w2.x = pk_bf16(xreg[r][0][e], xreg[r][1][e]);                                                   \
-          w2.y = pk_bf16(xreg[r][2][e], xreg[r][3][e]);                                                   \
-          *reinterpret_cast<uint2*>(Xs + (g * 4 + e) * LKP + xq[r] * 4) = w2;                             \
-        }                                                                                                 \
-      }                                                                                                   \
+      if (task < 8 * XG) WB_STORE_QUAD(xreg[r], Xs, g * XC, xq[r])                                    \
     }                                                                                                     \
   }
 
@@ -446,6 +459,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
   }
 #undef WB_LOAD
 #undef WB_STORE
+#undef WB_STORE_QUAD
 #undef WB_MMA
 
 #pragma unroll
@@ -680,7 +694,7 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
                       int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
                       int32_t stride, int32_t pad, float* workspace, int64_t workspace_bytes, float* dw_oihw,
                       int32_t accumulate, float* dbias, int32_t dbias_accumulate, hrv_stream_t stream,
-                      const bool mma_bf16, const bool x_bf16 = false) {
+                      const bool mma_bf16, const bool x_bf16 = false, const bool dy_bf16 = false) {
   HRV_REQUIRE(dy && x && workspace && dw_oihw, "wgrad: null pointer");
   HRV_REQUIRE(Cout > 0 && x_C > 0 && x_C % 4 == 0 && x_cstride % 4 == 0 && x_coff % 4 == 0 && dy_cstride % 4 == 0 &&
                   dy_coff % 4 == 0 && x_C_real > 0 && x_C_real <= x_C && ci_base >= 0 && ci_base + x_C_real <= CinTot,
@@ -694,7 +708,8 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   p.N = N; p.H = H; p.W = W; p.Ho = Ho; p.Wo = Wo; p.KH = KH; p.KW = KW; p.stride = stride; p.pad = pad;
   p.P = N * Ho * Wo; p.ci_base = ci_base; p.ci_real = x_C_real; p.CinTot = CinTot;
   p.x_bf16 = x_bf16 ? 1 : 0;
-  HRV_REQUIRE(!x_bf16 || mma_bf16, "wgrad: a bf16 X exists for the bf16 matrix-core kernel only");
+  HRV_REQUIRE(!(x_bf16 || dy_bf16) || mma_bf16, "wgrad: bf16-stored operands exist for the bf16 matrix-core kernel only");
+  HRV_REQUIRE(!dy_bf16 || x_bf16, "wgrad: storage_flags 1 (bf16 dY with fp32 X) is not built");
   const int wt = pick_wtile(Cout, x_C);
   const int bm = wt_bm(wt), bn = wt_bn(wt);
   p.taps = KH * KW;
@@ -715,17 +730,18 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   const int nblk = tiles * S;
 #define WG_CASE(I, A, B, Cc, D)                                                                                   \
   case I:                                                                                                         \
-    if (mma_bf16 && x_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D, true>), dim3(nblk), dim3(256), 0, st, p); \
+    if (mma_bf16 && dy_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D, true, true>), dim3(nblk), dim3(256), 0, st, p); \
+    else if (mma_bf16 && x_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D, true>), dim3(nblk), dim3(256), 0, st, p); \
     else if (mma_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p); \
     else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<A, B, Cc, D>), dim3(nblk), dim3(256), 0, st, p);              \
     break;
   switch (wt) {
     WG_CASE(0, 1, 1, 1, 4) WG_CASE(1, 2, 1, 1, 4) WG_CASE(2, 3, 1, 1, 4) WG_CASE(3, 4, 1, 1, 4) WG_CASE(4, 5, 1, 1, 4)
     WG_CASE(5, 6, 1, 1, 4) WG_CASE(6, 2, 2, 2, 2) WG_CASE(7, 1, 1, 4, 1) WG_CASE(8, 2, 1, 4, 1)
+    WG_CASE(9, 1, 1, 2, 2)
     default:
-      if (mma_bf16) hipLaunchKernelGGL((conv_wgrad_bf16_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((conv_wgrad_mfma_kernel<1, 1, 2, 2>), dim3(nblk), dim3(256), 0, st, p);
-      break;
+      set_error("wgrad: unknown tile %d", wt);
+      return HRV_ERR_ARG;
   }
 #undef WG_CASE
   int rc = check_launch("conv_wgrad_mfma_kernel");
@@ -766,20 +782,21 @@ extern "C" int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cst
                     dbias_accumulate, stream, true);
 }
 
-// Same again with X stored as bf16 (``x`` points at bf16 elements; x_C / x_cstride / x_coff in elements, multiples
-// of 4): activations that only matrix cores read (ReLU(conv_shared(seg)), the SPADE-modulated conv inputs) are
-// kept in bf16 by the mixed-precision training plan -- the MMA operand is the same bf16 value either way.
-extern "C" int hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
-                                                       const void* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
-                                                       int32_t x_up_shift, int32_t x_C_real, int32_t ci_base,
-                                                       int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho,
-                                                       int32_t Wo, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
-                                                       float* workspace, int64_t workspace_bytes, float* dw_oihw,
-                                                       int32_t accumulate, float* dbias, int32_t dbias_accumulate,
-                                                       hrv_stream_t stream) {
-  return wgrad_impl(dy, dy_cstride, dy_coff, Cout, (const float*)x, x_C, x_cstride, x_coff, x_up_shift, x_C_real, ci_base,
-                    CinTot, N, H, W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw, accumulate, dbias,
-                    dbias_accumulate, stream, true, true);
+// Same again with bf16-STORED operands (storage_flags bit0: dY, bit1: X; element counts): activations and
+// gradients that only matrix cores read (ReLU(conv_shared(seg)), the expanded label map, [dgamma|dbeta]) are kept
+// in bf16 by the mixed-precision training plan -- the MMA operand is the same bf16 value either way.
+extern "C" int hrv_conv2d_wgrad_bf16mma_st_nhwc_f32(const void* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+                                                    const void* x, int32_t x_C, int32_t x_cstride, int32_t x_coff,
+                                                    int32_t x_up_shift, int32_t x_C_real, int32_t ci_base,
+                                                    int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho,
+                                                    int32_t Wo, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
+                                                    float* workspace, int64_t workspace_bytes, float* dw_oihw,
+                                                    int32_t accumulate, float* dbias, int32_t dbias_accumulate,
+                                                    int32_t storage_flags, hrv_stream_t stream) {
+  HRV_REQUIRE(storage_flags >= 0 && storage_flags <= 3, "wgrad: storage_flags");
+  return wgrad_impl((const float*)dy, dy_cstride, dy_coff, Cout, (const float*)x, x_C, x_cstride, x_coff, x_up_shift,
+                    x_C_real, ci_base, CinTot, N, H, W, Ho, Wo, KH, KW, stride, pad, workspace, workspace_bytes, dw_oihw,
+                    accumulate, dbias, dbias_accumulate, stream, true, (storage_flags & 2) != 0, (storage_flags & 1) != 0);
 }
 
 extern "C" int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,

@@ -41,9 +41,21 @@ struct NormBwdParams {
   float* dgb; int dgb_cs, dgb_co;            // nullable; [.., 2C]: dgamma at [0,C), dbeta at [C,2C)
   int N, H, W, C4, act; float slope;
   int NB; float* part;                       // [N][NB][C][2]
+  int dgb_bf16, out_bf16;                    // storage of dgb / out: bf16 when only matrix cores (and this mask) read them
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 ld4_bf16(const void* base, size_t elem) {
+  const uint2 u = *reinterpret_cast<const uint2*>(reinterpret_cast<const unsigned short*>(base) + elem);
+  f32x4 v;
+  v[0] = __builtin_bit_cast(float, u.x << 16); v[1] = __builtin_bit_cast(float, u.x & 0xFFFF0000u);
+  v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
+  return v;
+}
+typedef __bf16 bf16x4t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void st4_bf16(void* base, size_t elem, f32x4 v) {
+  *reinterpret_cast<bf16x4t*>(reinterpret_cast<unsigned short*>(base) + elem) = __builtin_convertvector(v, bf16x4t);
+}
 
 __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParams p) {
   __shared__ f32x4 red[2][256];
@@ -70,7 +82,8 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
         const f32x4 nh = (v - mu) * rs;
         f32x4 dpre = ld4(p.dout + pix * p.do_cs + p.do_co + g * 4);
         if (p.act != HRV_ACT_NONE) {
-          const f32x4 o = ld4(p.out + pix * p.out_cs + p.out_co + g * 4);
+          const size_t oe = pix * p.out_cs + p.out_co + g * 4;
+          const f32x4 o = p.out_bf16 ? ld4_bf16(p.out, oe) : ld4(p.out + oe);
 #pragma unroll
           for (int e = 0; e < 4; ++e) dpre[e] *= dact(o[e], p.act, p.slope);
         }
@@ -78,8 +91,14 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
         if (p.g1p) dnh *= ld4(p.g1p + pix * p.g_cs + p.g_co + g * 4);
         *reinterpret_cast<f32x4*>(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) = dnh;
         if (p.dgb) {
-          *reinterpret_cast<f32x4*>(p.dgb + pix * p.dgb_cs + p.dgb_co + g * 4) = dpre * nh;
-          *reinterpret_cast<f32x4*>(p.dgb + pix * p.dgb_cs + p.dgb_co + C + g * 4) = dpre;
+          const size_t ge = pix * p.dgb_cs + p.dgb_co + g * 4;
+          if (p.dgb_bf16) {
+            st4_bf16(p.dgb, ge, dpre * nh);
+            st4_bf16(p.dgb, ge + C, dpre);
+          } else {
+            *reinterpret_cast<f32x4*>(p.dgb + ge) = dpre * nh;
+            *reinterpret_cast<f32x4*>(p.dgb + ge + C) = dpre;
+          }
         }
         s1 += dnh;
         s2 += dnh * nh;
@@ -498,6 +517,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   p.dnh = d->dnh; p.dn_cs = d->dnh_cstride; p.dn_co = d->dnh_coff;
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;
+  p.dgb_bf16 = d->dgb_bf16; p.out_bf16 = d->out_bf16;
   hipLaunchKernelGGL(norm_bwd_stage1_kernel, dim3(nb, d->N), dim3(256), 0, st, p);
   int rc = check_launch("norm_bwd_stage1_kernel");
   if (rc) return rc;

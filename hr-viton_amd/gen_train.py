@@ -211,7 +211,8 @@ class SpadeT:
         dx, dgb = T.norm_bwd(ctx["x"], ctx["mean"], ctx["rstd"], dout, act=self.act, slope=0.2,
                              out=ctx["out"] if self.act != ACT_NONE else None, g1p=ctx["g1p"], z=ctx["z"],
                              noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dx=dx,
-                             dx_accumulate=dx_accumulate, dnoise_scale=dns)
+                             dx_accumulate=dx_accumulate, dnoise_scale=dns,
+                             dgb_bf16=ctx["actv"].bf16)   # [dgamma|dbeta] feeds matrix cores only (gb.wgrad, gb.dgrad)
         if dns is not None:
             _acc(grads, n.noise_scale, dns[:C_])
         else:

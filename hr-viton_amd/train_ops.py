@@ -174,15 +174,17 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     fl = 2.0 * N * Ho * Wo * Cout * x.C * KH * KW
     # mixed precision: bf16 matrix cores (needs Wo % 4 == 0; the odd-sized PatchGAN maps keep the fp32 kernel)
     fn = lib.hrv_conv2d_wgrad_bf16mma_nhwc_f32 if (MMA_BF16[0] and Wo % 4 == 0) else lib.hrv_conv2d_wgrad_nhwc_f32
-    if x.bf16:
-        assert MMA_BF16[0] and Wo % 4 == 0, f"{name}: a bf16 activation needs the bf16 matrix-core weight gradient"
-        fn = lib.hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32
+    args = (dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp, x.cstride, x.coff, x_up, x.C, ci_base,
+            cin_tot, N, H, W, Ho, Wo, KH, KW, stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
+            1 if accumulate else 0, None if dbias is None else dbias.data_ptr(), 1 if dbias_accumulate else 0)
     with _Timed("wgrad", name, fl, 0):
-        _lib.check(fn(dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp,
-                                                 x.cstride, x.coff, x_up, x.C, ci_base, cin_tot, N, H, W, Ho, Wo, KH, KW,
-                                                 stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
-                                                 1 if accumulate else 0, None if dbias is None else dbias.data_ptr(),
-                                                 1 if dbias_accumulate else 0, _stream()), "hrv_conv2d_wgrad_nhwc_f32")
+        if x.bf16 or dy.bf16:
+            assert MMA_BF16[0] and Wo % 4 == 0, f"{name}: bf16-stored operands need the bf16 matrix-core weight gradient"
+            assert x.bf16, f"{name}: bf16 dY with an fp32 X is not built"
+            _lib.check(lib.hrv_conv2d_wgrad_bf16mma_st_nhwc_f32(*args, (1 if dy.bf16 else 0) | 2, _stream()),
+                       "hrv_conv2d_wgrad_bf16mma_st_nhwc_f32")
+        else:
+            _lib.check(fn(*args, _stream()), "hrv_conv2d_wgrad_nhwc_f32")
 
 
 def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
@@ -204,8 +206,10 @@ def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False)
 def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int = ACT_NONE, slope: float = 0.2,
              out: Optional[Act] = None, g1p: Optional[Act] = None, z: Optional[torch.Tensor] = None,
              noise_scale: Optional[torch.Tensor] = None, want_dgb: bool = False, dx: Optional[Act] = None,
-             dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False):
-    """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None)."""
+             dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False,
+             dgb_bf16: bool = False):
+    """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None).  ``dgb_bf16``: store
+    [dgamma | dbeta] in bf16 (mixed precision: only the gamma|beta conv's matrix-core backward reads it)."""
     lib = _lib.load()
     N, H, W, Cp = x.N, x.H, x.W, x.Cp
     dev = x.t.device
@@ -213,7 +217,8 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
         dx = ops.alloc(N, H, W, x.C, dev)
         dx_accumulate = False
     dnh = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
-    dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.float32, device=dev), 2 * Cp) if want_dgb else None
+    dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.bfloat16 if dgb_bf16 else torch.float32, device=dev),
+              2 * Cp) if want_dgb else None
     ws = torch.empty(lib.hrv_norm_bwd_workspace_elems(N, H, W, Cp), dtype=torch.float32, device=dev)
     d = _lib.hrv_norm_bwd_t()
     d.N, d.H, d.W, d.C = N, H, W, Cp
@@ -223,12 +228,14 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
     d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
     if out is not None:
         d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+        d.out_bf16 = 1 if out.bf16 else 0
     if g1p is not None:
         d.g1p, d.g1p_cstride, d.g1p_coff = g1p.t.data_ptr(), g1p.cstride, g1p.coff
     d.dout, d.dout_cstride, d.dout_coff = dout.t.data_ptr(), dout.cstride, dout.coff
     d.dnh, d.dnh_cstride, d.dnh_coff = dnh.data_ptr(), Cp, 0
     if dgb is not None:
         d.dgb, d.dgb_cstride, d.dgb_coff = dgb.t.data_ptr(), 2 * Cp, 0
+        d.dgb_bf16 = 1 if dgb.bf16 else 0
     d.dx, d.dx_cstride, d.dx_coff = dx.t.data_ptr(), dx.cstride, dx.coff
     d.dx_accumulate = 1 if dx_accumulate else 0
     d.act, d.act_slope = act, slope

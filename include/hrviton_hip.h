@@ -202,14 +202,15 @@ int hrv_conv2d_wgrad_bf16mma_nhwc_f32(const float* dy, int32_t dy_cstride, int32
                               int32_t KH, int32_t KW, int32_t stride, int32_t pad, float* workspace,
                               int64_t workspace_bytes, float* dw_oihw, int32_t accumulate, float* dbias,
                               int32_t dbias_accumulate, hrv_stream_t stream);
-/* Same again with X stored as bf16 (`x` points at bf16 elements; counts in elements, multiples of 4): tensors
- * that only matrix cores read are kept in bf16 by the mixed-precision training plan (same MMA operand bits). */
-int hrv_conv2d_wgrad_bf16mma_xbf16_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
+/* Same again with bf16-STORED operands: storage_flags bit0 = `dy` points at bf16 elements, bit1 = `x` does
+ * (counts in elements, multiples of 4).  Tensors that only matrix cores read are kept in bf16 by the
+ * mixed-precision training plan (same MMA operand bits, half the bytes).  Supported: 0, 2 (x), 3 (both). */
+int hrv_conv2d_wgrad_bf16mma_st_nhwc_f32(const void* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,
                               const void* x, int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift,
                               int32_t x_C_real, int32_t ci_base, int32_t CinTot, int32_t N, int32_t H, int32_t W,
                               int32_t Ho, int32_t Wo, int32_t KH, int32_t KW, int32_t stride, int32_t pad,
                               float* workspace, int64_t workspace_bytes, float* dw_oihw, int32_t accumulate,
-                              float* dbias, int32_t dbias_accumulate, hrv_stream_t stream);
+                              float* dbias, int32_t dbias_accumulate, int32_t storage_flags, hrv_stream_t stream);
 int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, int32_t coff, float* workspace,
                         int64_t workspace_bytes, float* out, int32_t accumulate, hrv_stream_t stream);
 
@@ -238,6 +239,8 @@ typedef struct hrv_norm_bwd {
   int32_t dns_accumulate;
   float* dnoise_scale;                                 /* [C], nullable */
   float* workspace;
+  int32_t dgb_bf16;   /* 1: `dgb` is stored as bf16 (element strides/offsets): a tensor only matrix cores read */
+  int32_t out_bf16;   /* 1: `out` is stored as bf16 (only its sign is used here)                              */
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);

@@ -369,3 +369,57 @@ def test_wgrad_fused_bias_gradient(mixed, cin, cout, k):
     assert (dw.cpu() - want_w).abs().max() <= tol * want_w.abs().max() + 1e-5
     assert (db.cpu() - want_b).abs().max() <= tol * want_b.abs().max() + 1e-5
     assert (db2.cpu() - 2 * want_b).abs().max() <= 2 * tol * want_b.abs().max() + 1e-5
+
+
+@pytest.mark.parametrize("case", [("gb", 128, 64, 3, 1, 16, 24), ("shared1x1", 72, 384, 1, 0, 8, 16),
+                                  ("sliced", 40, 24, 3, 1, 8, 12)], ids=lambda c: c[0])
+@pytest.mark.parametrize("dy_bf16", [False, True], ids=["dy_f32", "dy_bf16"])
+def test_mixed_precision_bf16_stored_operands_are_bit_identical(case, dy_bf16):
+    """Tensors that only matrix cores read may be STORED in bf16 by the mixed-precision plan (actv, the expanded
+    label map, [dgamma|dbeta]).  The MMA operand bits are then the same as when the fp32 tensor is rounded while
+    staged, so every consumer -- forward conv, data gradient (bf16 source / bf16 sign mask), weight gradient incl.
+    the fused bias column (hrv_conv2d_wgrad_bf16mma_st_nhwc_f32, packed staging) -- gives BIT-IDENTICAL results."""
+    ops, T = _mods()
+    name, cin, cout, k, pad, H, W = case
+    g = torch.Generator().manual_seed(cin + cout)
+    N = 2
+    # values already representable in bf16: the two storage forms hold the same numbers
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g)).cuda()
+    dy = rb(torch.randn(N, cout, H, W, generator=g)).cuda()
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).cuda()
+    mask = rb(torch.randn(N, cin, H, W, generator=g)).cuda()
+
+    def as_act(t, bf, wide=False):
+        if not wide:
+            return ops.to_nhwc(t, bf16=bf)
+        # a channel slice of a wider tensor (the block-wide actv / d(actv) tensors)
+        C_ = t.shape[1]
+        full = ops.alloc(t.shape[0], t.shape[2], t.shape[3], C_ + 16, t.device, bf16=bf)
+        full.t.zero_()
+        ops.to_nhwc(t, out=full.slice(8, C_))
+        return full.slice(8, C_)
+
+    wide = name == "sliced"
+    outs = {}
+    T.MMA_BF16[0] = True
+    try:
+        for bf in (False, True):
+            xa = as_act(x, bf, wide)
+            dya = as_act(dy, bf and dy_bf16, wide)
+            fwd = T.conv_forward_dev(w, [(xa, 0)], 1, pad, name=name)
+            dx = T.conv_dgrad(dya, w, H, W, 1, pad, act_mask=as_act(mask, bf, wide), slope=0.2, name=name + ".dgrad")
+            dw = torch.zeros(cout, cin + 8, k, k, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            if dya.bf16 and not xa.bf16:
+                continue
+            T.conv_wgrad(dya, xa, 0, 8, cin + 8, k, k, 1, pad, dw, name=name + ".wgrad", dbias=db)
+            outs[bf] = (ops.to_nchw(fwd), ops.to_nchw(dx), dw, db)
+    finally:
+        T.MMA_BF16[0] = False
+    for what, a, b in zip(("forward", "dgrad", "wgrad", "dbias"), outs[False], outs[True]):
+        assert torch.equal(a, b), (what, (a - b).abs().max().item())
+    ref = torch.nn.grad.conv2d_weight(x.cpu(), (cout, cin, k, k), dy.cpu(), stride=1, padding=pad)
+    got = outs[True][2][:, 8:8 + cin].cpu()
+    assert (got - ref).abs().max() <= 3e-5 * ref.abs().max() + 1e-5
+    assert (outs[True][3].cpu() - dy.cpu().sum((0, 2, 3))).abs().max() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item()
