@@ -339,6 +339,100 @@ __global__ __launch_bounds__(256) void flow_warp_bwd_kernel(const WarpBwdParams 
   }
 }
 
+// d(src) of the warp, LDS-privatised.  The scatter-add above issues 4 fp32 atomics per (output pixel, channel);
+// at 8 x 512x384 x 96 channels that is 600 M L2 atomics (31 ms).  Flows are smooth, so the samples of a 16x16
+// output tile land in a compact source window: a block accumulates its tile (one 16-channel chunk) into an LDS
+// window of up to 24x24 source pixels with ds_add_f32, then flushes only the touched cells with one global
+// atomic each -- the windows of neighbouring tiles overlap, so the flush stays atomic, but a cell receives ~1
+// global atomic per tile instead of one per contributing output pixel.  A tile whose samples do not fit the
+// window (large local flow gradients) falls back to direct global atomics; the result is the same sum either way.
+constexpr int WT = 16;                 // output tile edge
+constexpr int WB = 24;                 // source window edge
+constexpr int WCH = 16;                // channels per block
+constexpr int WCELLS = WB * WB + 1;    // +1: odd row stride between channel planes
+
+__global__ __launch_bounds__(256) void flow_warp_dsrc_tiled_kernel(const WarpBwdParams p, int tiles_x, int tiles_y) {
+  __shared__ float acc[WCH][WCELLS];
+  __shared__ int red[4][4];
+  const int tid = threadIdx.x;
+  int b = blockIdx.x;
+  const int txi = b % tiles_x; b /= tiles_x;
+  const int tyi = b % tiles_y;
+  const int n = b / tiles_y;
+  const int c0 = blockIdx.y * WCH;                       // first channel of this block
+  const int wo = txi * WT + (tid & (WT - 1)), ho = tyi * WT + (tid >> 4);
+  const bool live = wo < p.Wo && ho < p.Ho;
+  const size_t pp = live ? ((size_t)n * p.Ho + ho) * p.Wo + wo : 0;
+  const float fx = p.flow_up[pp * 2], fy = p.flow_up[pp * 2 + 1];
+  const float gx = fx / p.norm_x + lin_m1_1b(live ? wo : 0, p.Wo, p.step_x);
+  const float gy = fy / p.norm_y + lin_m1_1b(live ? ho : 0, p.Ho, p.step_y);
+  float ix = ((gx + 1.f) * (float)p.W - 1.f) / 2.f;
+  float iy = ((gy + 1.f) * (float)p.H - 1.f) / 2.f;
+  ix = fminf(fmaxf(ix, 0.f), (float)(p.W - 1));
+  iy = fminf(fmaxf(iy, 0.f), (float)(p.H - 1));
+  const float x0f = floorf(ix), y0f = floorf(iy);
+  const int x0 = (int)x0f, y0 = (int)y0f;
+  const float wx1 = ix - x0f, wx0 = (x0f + 1.f) - ix;
+  const float wy1 = iy - y0f, wy0 = (y0f + 1.f) - iy;
+  const bool vx1 = x0 + 1 < p.W, vy1 = y0 + 1 < p.H;
+  // window = bounding box of the tile's taps
+  int mnx = live ? x0 : 0x7fffffff, mny = live ? y0 : 0x7fffffff;
+  int mxx = live ? x0 + (vx1 ? 1 : 0) : -1, mxy = live ? y0 + (vy1 ? 1 : 0) : -1;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    mnx = min(mnx, __shfl_xor(mnx, o)); mny = min(mny, __shfl_xor(mny, o));
+    mxx = max(mxx, __shfl_xor(mxx, o)); mxy = max(mxy, __shfl_xor(mxy, o));
+  }
+  if ((tid & 63) == 0) { red[tid >> 6][0] = mnx; red[tid >> 6][1] = mny; red[tid >> 6][2] = mxx; red[tid >> 6][3] = mxy; }
+  for (int i = tid; i < WCH * WCELLS; i += 256) (&acc[0][0])[i] = 0.f;
+  __syncthreads();
+  const int bx0 = min(min(red[0][0], red[1][0]), min(red[2][0], red[3][0]));
+  const int by0 = min(min(red[0][1], red[1][1]), min(red[2][1], red[3][1]));
+  const int bx1 = max(max(red[0][2], red[1][2]), max(red[2][2], red[3][2]));
+  const int by1 = max(max(red[0][3], red[1][3]), max(red[2][3], red[3][3]));
+  const bool fits = bx1 - bx0 < WB && by1 - by0 < WB;    // block-uniform
+  const int nch = min(WCH, p.C4 * 4 - c0);               // channels of this chunk (multiple of 4)
+  const size_t base = (size_t)n * p.H * p.W;
+  if (live) {
+    const int cell = (y0 - by0) * WB + (x0 - bx0);
+    const size_t o00 = base + (size_t)y0 * p.W + x0;
+    const float w00 = wx0 * wy0, w01 = wx1 * wy0, w10 = wx0 * wy1, w11 = wx1 * wy1;
+    for (int c = 0; c < nch; c += 4) {
+      const f32x4 d = ld4(p.dout + pp * p.dcs + p.dco + c0 + c);
+      if (fits) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float* a = &acc[c + e][cell];
+          atomicAdd(a, d[e] * w00);
+          if (vx1) atomicAdd(a + 1, d[e] * w01);
+          if (vy1) atomicAdd(a + WB, d[e] * w10);
+          if (vx1 && vy1) atomicAdd(a + WB + 1, d[e] * w11);
+        }
+      } else {
+        float* gb = p.dsrc + p.gco + c0 + c;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          unsafeAtomicAdd(gb + o00 * p.gcs + e, d[e] * w00);
+          if (vx1) unsafeAtomicAdd(gb + (o00 + 1) * p.gcs + e, d[e] * w01);
+          if (vy1) unsafeAtomicAdd(gb + (o00 + p.W) * p.gcs + e, d[e] * w10);
+          if (vx1 && vy1) unsafeAtomicAdd(gb + (o00 + p.W + 1) * p.gcs + e, d[e] * w11);
+        }
+      }
+    }
+  }
+  if (!fits) return;
+  __syncthreads();
+  // flush: lanes run over (cell, channel) with the channel fastest -> 64-byte runs per source pixel
+  const int ww = bx1 - bx0 + 1, wh = by1 - by0 + 1;
+  for (int i = tid; i < ww * wh * nch; i += 256) {
+    const int c = i % nch, cellc = i / nch;
+    const int cy = cellc / ww, cx = cellc - cy * ww;
+    const float v = acc[c][cy * WB + cx];
+    if (v != 0.f)
+      unsafeAtomicAdd(p.dsrc + (base + (size_t)(by0 + cy) * p.W + bx0 + cx) * p.gcs + p.gco + c0 + c, v);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // F.grid_sample(input NCHW, grid [N,Ho,Wo,2], bilinear, border, align_corners=False) with an
 // explicit grid and its backward (train_condition.py:243-245; few channels: cloth 3, mask 1).
@@ -679,6 +773,17 @@ extern "C" int hrv_flow_warp_bwd_nhwc_f32(const hrv_flow_warp_bwd_t* d, hrv_stre
   p.dsrc = d->dsrc; p.gcs = d->dsrc_cstride; p.gco = d->dsrc_coff;
   p.dflow = d->dflow; p.dflow_accumulate = d->dflow_accumulate;
   const size_t npix = (size_t)d->N * d->Ho * d->Wo;
+  // wide tensors: d(src) by the LDS-privatised tile kernel, d(flow) (a gather, no atomics) by the per-pixel kernel
+  const char* ev = getenv("HRV_WARP_BWD_TILED");
+  const bool tiled = p.dsrc && d->C >= 16 && (!ev || atoi(ev) != 0);
+  if (tiled) {
+    const int tx = (d->Wo + WT - 1) / WT, ty = (d->Ho + WT - 1) / WT;
+    hipLaunchKernelGGL(flow_warp_dsrc_tiled_kernel, dim3((unsigned)(tx * ty * d->N), (unsigned)((d->C + WCH - 1) / WCH)),
+                       dim3(256), 0, (hipStream_t)stream, p, tx, ty);
+    const int rc = check_launch("flow_warp_dsrc_tiled_kernel");
+    if (rc || !p.dflow) return rc;
+    p.dsrc = nullptr;
+  }
   hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(grid_for(npix * 16)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("flow_warp_bwd_kernel");
 }

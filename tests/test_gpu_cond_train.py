@@ -94,16 +94,20 @@ def _smooth(g, N, C, H, W, f=4):
     return F.interpolate(lo, scale_factor=f, mode="bilinear", align_corners=False)
 
 
-def test_flow_warp_adjoint():
-    """d_src (atomic scatter) and d_flow_prev (coordinate gradient through normalise + x2 upsample) of the fused
-    warp vs autograd through the oracle's composition (networks.py:133-135)."""
+@pytest.mark.parametrize("case", [("per_pixel", 8, 8, 6, 1.5), ("tiled", 24, 20, 18, 1.5), ("tiled_c40", 40, 12, 20, 0.7),
+                                  ("tiled_window_overflow", 16, 24, 20, 9.0)], ids=lambda c: c[0])
+def test_flow_warp_adjoint(case):
+    """d_src (atomic scatter; >= 16 channels: LDS-privatised 16x16 tiles with a 24x24 source window, direct global
+    atomics for tiles whose samples do not fit it) and d_flow_prev (coordinate gradient through normalise + x2
+    upsample) of the fused warp vs autograd through the oracle's composition (networks.py:133-135)."""
     ops = _ops()
     from hr_viton_amd import train_ops as T
     g = torch.Generator().manual_seed(5)
-    N, C, fh, fw = 2, 8, 8, 6
-    Ho, Wo = 16, 12
+    _, C, fh, fw, amp = case
+    N = 2
+    Ho, Wo = 2 * fh, 2 * fw
     src = _smooth(g, N, C, Ho, Wo).requires_grad_(True)
-    flow = (torch.randn(N, fh, fw, 2, generator=g) * 1.5).requires_grad_(True)   # some samples leave the image
+    flow = (torch.randn(N, fh, fw, 2, generator=g) * amp).requires_grad_(True)   # some samples leave the image
     nx, ny = (Wo / 2 - 1.0) / 2.0, (Ho / 2 - 1.0) / 2.0
     fup = O.resize_bilinear(flow.permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1)
     fn = torch.cat([fup[..., 0:1] / nx, fup[..., 1:2] / ny], 3)
