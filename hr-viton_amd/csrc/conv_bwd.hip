@@ -404,13 +404,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
 
 // one operand's quad (4 pixels x CG channels, REG[j] = pixel j) -> LDS: channel-major rows, the quad's 4 pixels
 // of one channel as one 8-byte store
+// LDS image: row = channel, 32 pixels (64 B) + 16 B pad.  The quad slot inside a row is XOR-swizzled with
+// 2*((row >> 4) & 3): without it the 32 channel groups of a wave hit 4 bank groups with their 8-byte stores
+// (8-way conflict: SQ_LDS_BANK_CONFLICT was 76 % of SQ_LDS_IDX_ACTIVE, profiles/r01_pmc_wgrad_bf16.txt); with it
+// 2-way, the floor for a 512-byte wave store (270 -> 317 TFLOP/s on the gamma|beta shape).  The swizzle is even,
+// so the two quads of one b128 fragment read stay adjacent and in order.
 #define WB_STORE_QUAD(REG, DST, CH0, Q)                                                                   \
   {                                                                                                       \
+    const int qs = ((Q) ^ ((((CH0) >> 4) & 3) * 2)) * 4;   /* CH0 % 4 == 0: all 4 rows share the swizzle */ \
     _Pragma("unroll") for (int e = 0; e < 4; ++e) {                                                       \
       uint2 w2;                                                                                           \
       w2.x = pk_bf16(REG[0][e], REG[1][e]);                                                               \
       w2.y = pk_bf16(REG[2][e], REG[3][e]);                                                               \
-      *reinterpret_cast<uint2*>(DST + ((CH0) + e) * LKP + (Q)*4) = w2;                                    \
+      *reinterpret_cast<uint2*>(DST + ((CH0) + e) * LKP + qs) = w2;                                       \
     }                                                                                                     \
   }
 #define WB_STORE(BUF)                                                                                     \
@@ -431,14 +437,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
 
 #define WB_MMA(BUF)                                                                                       \
   {                                                                                                       \
-    const unsigned short* Ys = smem + (BUF) * (BMc + BNc) * LKP + (wm * TM * 32 + l31) * LKP + lh * 8;    \
-    const unsigned short* Xs = smem + (BUF) * (BMc + BNc) * LKP + BMc * LKP + (wn * TN * 32 + l31) * LKP + lh * 8; \
+    const int yrow = wm * TM * 32 + l31, xrow = wn * TN * 32 + l31;                                       \
+    const unsigned short* Ys = smem + (BUF) * (BMc + BNc) * LKP + yrow * LKP;                             \
+    const unsigned short* Xs = smem + (BUF) * (BMc + BNc) * LKP + BMc * LKP + xrow * LKP;                 \
     _Pragma("unroll") for (int ks = 0; ks < BKP / 16; ++ks) {                                             \
       bf16x8w a[TM], bb[TN];                                                                              \
-      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
-          a[i] = *reinterpret_cast<const bf16x8w*>(Ys + i * 32 * LKP + ks * 16);                          \
-      _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                      \
-          bb[j] = *reinterpret_cast<const bf16x8w*>(Xs + j * 32 * LKP + ks * 16);                         \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i) {                                                    \
+        const int sw = (((yrow + i * 32) >> 4) & 3) * 2;                                                  \
+        a[i] = *reinterpret_cast<const bf16x8w*>(Ys + i * 32 * LKP + ((lh * 2 + ks * 4) ^ sw) * 4);       \
+      }                                                                                                   \
+      _Pragma("unroll") for (int j = 0; j < TN; ++j) {                                                    \
+        const int sw = (((xrow + j * 32) >> 4) & 3) * 2;                                                  \
+        bb[j] = *reinterpret_cast<const bf16x8w*>(Xs + j * 32 * LKP + ((lh * 2 + ks * 4) ^ sw) * 4);      \
+      }                                                                                                   \
       _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                      \
           _Pragma("unroll") for (int j = 0; j < TN; ++j)                                                  \
               acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], bb[j], acc[i][j], 0, 0, 0);       \
