@@ -294,19 +294,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
   constexpr int BMc = 32 * TM * WM;  // couts per block
   constexpr int BNc = 32 * TN * WN;  // (tap, cin) columns per block
   // 4 channels per load task: 16 bytes of fp32, or 8 bytes of a bf16-STORED operand (XB / YB) widened in
-  // registers.  (Measured: 8-channel / 16-byte packed tasks with a v_perm_b32 transpose halve the loads in flight
-  // per thread and run 25 % SLOWER -- this kernel is bound by global-load latency, not by VALU or bytes.)
+  // registers.  (Measured: 8-channel / 16-byte packed tasks with a v_perm_b32 transpose leave half the block's
+  // threads without staging work and run 25 % SLOWER; see DESIGN.md 6c for the PMC picture of this kernel.)
   constexpr int YC = 4, XC = 4;
   constexpr int YG = BMc / YC, XG = BNc / XC;           // channel groups per pixel
   constexpr int YT = (8 * YG + 255) / 256;              // quad tasks per thread per K-tile
   constexpr int XT = (8 * XG + 255) / 256;
-  constexpr int XOFF = 0;
   __shared__ __attribute__((aligned(16))) unsigned short smem[2 * (BMc + BNc) * LKP];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int l31 = lane & 31, lh = lane >> 5;
-  const int xtid = (tid + XOFF) & 255;
 
   int b = xcd_remap(blockIdx.x, p.co_tiles * p.ci_tiles * p.S);
   const int it = b % p.ci_tiles; b /= p.ci_tiles;
@@ -325,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
   bool xcol_ok[XT], xones[XT];
 #pragma unroll
   for (int r = 0; r < XT; ++r) {
-    const int task = xtid + 256 * r;
+    const int task = tid + 256 * r; 
     const int g = task % XG;
     xq[r] = task / XG;
     const int col = col0 + g * XC;
@@ -429,7 +427,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
       if (task < 8 * YG) WB_STORE_QUAD(yreg[r], Ys, g * YC, q)                                        \
     }                                                                                                     \
     _Pragma("unroll") for (int r = 0; r < XT; ++r) {                                                      \
-      const int task = xtid + 256 * r;                                                                    \
+      const int task = tid + 256 * r;                                                                     \
       const int g = task % XG;                                                                            \
       if (task < 8 * XG) WB_STORE_QUAD(xreg[r], Xs, g * XC, xq[r])                                    \
     }                                                                                                     \
