@@ -200,8 +200,13 @@ __device__ inline void dma16(rsrc_t, float*, unsigned, unsigned) {}
 #endif
 
 template <int TM, int TN, int WM, int WN, int VAR, bool BF, int RB = 64>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
-  static_assert(WM * WN == 4, "4 waves per block");
+__global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma_kernel(const ConvParams p) {
+  static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 MMA waves per block");
+  constexpr int NT = 64 * WM * WN;   // threads that share the gather / the MMA wave grid
+  // VAR bit 5: wave specialisation.  The block carries WM*WN extra LOADER waves: they issue every LDS-DMA
+  // instruction and wait for it, the MMA waves only read fragments and issue MFMAs -- a wave that issues its own
+  // DMA cannot issue MFMAs meanwhile (in-order issue; ~100 cycles per DMA instruction inside an MFMA stream).
+  constexpr bool SPEC = (VAR & 32) != 0;
   static_assert(RB == 64 || RB == 128, "K-tile row = 64 or 128 bytes");
   constexpr int ES = BF ? 2 : 4;     // element size in bytes
   constexpr int EPG = 16 / ES;       // elements per 16-byte gather group
@@ -220,18 +225,25 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
   constexpr int LS = GLDS ? RB / 4 : RB / 4 + 4;
   constexpr int BK = RB / 4;         // floats per packed-weight row
   constexpr int KQ = RB / 32;        // 32-byte fragment steps per row (2 lane-halves x 16 B)
-  constexpr int RPP = 256 / GPR;     // tile rows covered by one pass of the 256 threads
+  constexpr int RPP = NT / GPR;      // tile rows covered by one pass of the block's threads
   constexpr int BM = 32 * TM * WM;
   constexpr int BN = 32 * TN * WN;
   constexpr int AR = BM / RPP;                      // 16-byte A loads per thread per K-tile
-  constexpr int BR = (BN * GPR + 255) / 256;        // 16-byte B loads per thread per K-tile
+  constexpr int BR = (BN * GPR + NT - 1) / NT;      // 16-byte B loads per thread per K-tile
   constexpr bool SWAP = (VAR & 1) != 0;
   constexpr bool PIPE = (VAR & 2) != 0;
-  __shared__ __attribute__((aligned(16))) float smem[2 * (BM + BN) * LS];
+  // VAR bit 4 (LDS-DMA only): THREE K-tile stages in LDS -- two tiles' DMA stay in flight across a fence-less
+  // barrier (counted vmcnt), so the load latency is hidden inside the block instead of by a second resident block
+  constexpr int ST = (VAR & 16) ? 3 : 2;
+  static_assert(ST == 2 || GLDS, "the 3-stage pipeline exists for the LDS-DMA variant");
+  static_assert(!SPEC || ST == 3, "wave specialisation rides on the 3-stage LDS-DMA pipeline");
+  __shared__ __attribute__((aligned(16))) float smem[ST * (BM + BN) * LS];
 
-  const int tid = threadIdx.x;
+  // loader waves mirror the MMA waves' thread ids: the gather distribution below is written for NT threads
+  const int tid = SPEC ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform (SGPR): LDS-DMA bases stay scalar
+  [[maybe_unused]] const bool loader = SPEC && __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) >= WM * WN;
   const int wm = wave / WN;
   const int wn = wave % WN;
 
@@ -290,7 +302,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 #pragma unroll
     for (int j = 0; j < BR; ++j) {
-      const int idx = tid + 256 * j;
+      const int idx = tid + NT * j;
       const int row = idx / GPR, slot = idx % GPR;
       b_voff[j] = (unsigned)(row * RB + ((slot ^ ((row >> 1) & 7)) * 16));
     }
@@ -373,8 +385,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }                                                                                                        \
     const float* wt = p.wp + ((size_t)(KTN)*p.CoutPad + n0) * BK; /* 64-byte rows in both modes */            \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
-      const int idx = tid + 256 * j;                                                                         \
-      b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * GPR) % 256 == 0 || idx < BN * GPR ? idx : 0) * 4); \
+      const int idx = tid + NT * j;                                                                          \
+      b_reg[j] = *reinterpret_cast<const f32x4*>(wt + ((BN * GPR) % NT == 0 || idx < BN * GPR ? idx : 0) * 4);  \
     }                                                                                                        \
   }
 
@@ -451,7 +463,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const unsigned w_soff = (unsigned)(((KTN)*p.CoutPad + n0) * RB);                                         \
     float* Bbuf = Abuf + BM * LS;                                                                            \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                         \
-      dma16(w_rsrc, Bbuf + ((256 * j + 64 * wave) / GPR) * LS, b_voff[j], w_soff);                           \
+      dma16(w_rsrc, Bbuf + ((NT * j + 64 * wave) / GPR) * LS, b_voff[j], w_soff);                            \
     }                                                                                                        \
   }
 
@@ -478,8 +490,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     _Pragma("unroll") for (int r = 0; r < AR; ++r)                                                      \
         *reinterpret_cast<f32x4*>(Asw + (a_row + RPP * r) * LS + a_c4 * 4) = a_reg[r];                  \
     _Pragma("unroll") for (int j = 0; j < BR; ++j) {                                                    \
-      const int idx = tid + 256 * j;                                                                    \
-      if ((BN * GPR) % 256 == 0 || idx < BN * GPR)                                                      \
+      const int idx = tid + NT * j;                                                                     \
+      if ((BN * GPR) % NT == 0 || idx < BN * GPR)                                                       \
         *reinterpret_cast<f32x4*>(Bsw + (idx / GPR) * LS + (idx % GPR) * 4) = b_reg[j];                 \
     }                                                                                                   \
   }
@@ -538,8 +550,60 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 
   f32x4 fa[KQ][TM], fb[KQ][TN];
 
-  if constexpr (GLDS) {
-    static_assert((BN * GPR) % 256 == 0, "LDS-DMA B tile: every wave-instruction must be full");
+  if constexpr (GLDS && ST == 3) {
+    static_assert((BN * GPR) % NT == 0, "LDS-DMA B tile: every wave-instruction must be full");
+    // every wave issues exactly AR + BR DMA instructions per K-tile (masked lanes use out-of-range offsets), so
+    // "tile k+1 has landed, tile k+2 may still fly" is s_waitcnt vmcnt(AR + BR).  gfx9 encoding: vmcnt[3:0] in
+    // bits 3:0, vmcnt[5:4] in bits 15:14, expcnt (bits 6:4) and lgkmcnt (bits 11:8) at their maxima = no wait.
+    constexpr int NDMA = AR + BR;
+    static_assert(NDMA < 64, "vmcnt is a 6-bit counter");
+    constexpr int WAIT_ONE = (NDMA & 15) | (7 << 4) | (0 << 8) | ((NDMA >> 4) << 14);   // vmcnt(NDMA) lgkmcnt(0)
+    constexpr int WAIT_ALL = 0 | (7 << 4) | (0 << 8);                                   // vmcnt(0) lgkmcnt(0)
+    constexpr int WAIT_LDS = 0x3F | (7 << 4) | (0 << 8) | (3 << 14);                    // lgkmcnt(0) only
+    const bool dma_wave = !SPEC || loader, mma_wave = !SPEC || !loader;
+    const bool two = kt_begin + 1 < kt_end;
+    if (dma_wave) {
+      HRV_DMA_SRC()
+      HRV_DMA_TILE(kt_begin, 0)
+      HRV_DMA_ADVANCE()
+      if (two) {
+        HRV_DMA_TILE(kt_begin + 1, 1)
+        HRV_DMA_ADVANCE()
+        __builtin_amdgcn_s_waitcnt(WAIT_ONE);
+      } else {
+        __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+      }
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int rb = 0, wb = 2;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+      const bool more = kt + 2 < kt_end;
+      if (dma_wave && more) {
+        HRV_DMA_TILE(kt + 2, wb)   // buffer wb was read in iteration kt-1: every wave passed that barrier
+        HRV_DMA_ADVANCE()
+      }
+      if (mma_wave) {
+        HRV_READ_FRAGS(rb)
+        HRV_MMA_FRAGS()
+      }
+      if (kt + 1 < kt_end) {
+        asm volatile("" ::: "memory");
+        if (dma_wave) {
+          if (more) __builtin_amdgcn_s_waitcnt(WAIT_ONE);
+          else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+        } else {
+          __builtin_amdgcn_s_waitcnt(WAIT_LDS);   // this wave's fragment reads are done before the buffer is refilled
+        }
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      rb = rb == 2 ? 0 : rb + 1;
+      wb = wb == 2 ? 0 : wb + 1;
+    }
+    if (SPEC && loader) return;   // the epilogue belongs to the MMA waves (no barrier after this point)
+  } else if constexpr (GLDS) {
+    static_assert((BN * GPR) % NT == 0, "LDS-DMA B tile: every wave-instruction must be full");
     HRV_DMA_SRC()
     HRV_DMA_TILE(kt_begin, kt_begin & 1)
     HRV_DMA_ADVANCE()
@@ -856,6 +920,10 @@ static const TileCfg kCfgs[] = {
     {1, 2, 4, 1, 128},  // 9: 128 x 64,  64 bf16 k-values per K-tile (bf16 engine only)
     {4, 2, 2, 2, 128},  // 10: 256 x 128 (wave tile 128 x 64: 32 MFMAs per K-tile), LDS-DMA, 96 KB LDS, 1 block / CU
     {2, 4, 2, 2, 128},  // 11: 128 x 256 (wave tile 64 x 128)
+    {2, 2, 4, 2, 128},  // 12: 256 x 128 with EIGHT waves (wave tile 64 x 64, two waves per SIMD), LDS-DMA, 96 KB LDS
+    {2, 2, 4, 2, 128},  // 13: the same tile with THREE LDS stages (144 KB): two tiles' DMA in flight per block
+    {4, 2, 2, 2, 128},  // 14: 256 x 128, 4 MMA waves (wave tile 128 x 64) + 4 LOADER waves, three LDS stages
+    {2, 2, 2, 2, 128},  // 15: 128 x 128, 4 MMA waves (wave tile 64 x 64) + 4 LOADER waves, three LDS stages (96 KB)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1032,28 +1100,28 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
       const bool want = eg ? atoi(eg) != 0 : (32 * TN * WN == 64 || TM * TN >= 8);
       const bool glds = want && p.w_bytes != 0;
       if (p.src_f32) {
-        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 9, true, RB>), dim3(nblk), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 8, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 9, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 8, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
       } else if (glds) {
-        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 5, true, RB>), dim3(nblk), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 4, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 5, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 4, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
       } else {
-        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(256), 0, st, p);
-        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+        if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
+        else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
       }
     } else {
-      if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(256), 0, st, p);
-      else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(256), 0, st, p);
+      if (var & 1) hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
+      else hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, true, RB>), dim3(nblk), dim3(64 * WM * WN), 0, st, p);
     }
   } else if constexpr (RB != 64) {
     set_error("conv2d: 128-byte K-tile rows exist on the bf16 engine only");
     return HRV_ERR_ARG;
   } else {
     switch (var) {
-      case 0: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, false>), dim3(nblk), dim3(256), 0, st, p); break;
-      case 1: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, false>), dim3(nblk), dim3(256), 0, st, p); break;
-      case 2: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 2, false>), dim3(nblk), dim3(256), 0, st, p); break;
-      case 3: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 3, false>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 0: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 0, false>), dim3(nblk), dim3(64 * WM * WN), 0, st, p); break;
+      case 1: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 1, false>), dim3(nblk), dim3(64 * WM * WN), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 2, false>), dim3(nblk), dim3(64 * WM * WN), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, 3, false>), dim3(nblk), dim3(64 * WM * WN), 0, st, p); break;
       default: set_error("conv2d: HRV_CONV_VARIANT=%d invalid", var); return HRV_ERR_ARG;
     }
   }
@@ -1064,6 +1132,34 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
   const dim3 g((unsigned)(gsz > 4096 ? 4096 : gsz));
   if (p.bf16) hipLaunchKernelGGL(splitk_reduce_kernel<true>, g, dim3(256), 0, st, p);
   else hipLaunchKernelGGL(splitk_reduce_kernel<false>, g, dim3(256), 0, st, p);
+  return check_launch("splitk_reduce_kernel");
+}
+
+// Eight-wave LDS-DMA tiles (cfg 12/13): bf16 storage only (sources, weights); no register-staged fallback is
+// instantiated for them.
+template <int TM, int TN, int WM, int WN, bool ST3, bool SPECW = false>
+static int launch_cfg8w(const ConvParams& p, hipStream_t st) {
+  const int nblk = p.m_tiles * p.n_tiles * p.splitk;
+  const int oesz = p.out_f32 ? 4 : 2, resz = p.res_f32 ? 4 : 2;
+  const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
+                      (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (((uintptr_t)p.out) & (4 * oesz - 1)) == 0 &&
+                      (((uintptr_t)p.res) & (4 * resz - 1)) == 0;
+  if (!p.bf16 || p.src_f32 || p.w_bytes == 0) {
+    set_error("conv2d: tile_cfg 12/13 (eight-wave LDS-DMA) needs bf16-stored sources within the 32-bit buffer range");
+    return HRV_ERR_ARG;
+  }
+  constexpr int V = 4 | (ST3 ? 16 : 0) | (SPECW ? 32 : 0);
+  constexpr int NTB = 64 * WM * WN * (SPECW ? 2 : 1);
+  if (vec_ok || p.epi == 1)   // swapped-operand vector epilogue (the SPADE epilogue lives there)
+    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, V | 1, true, 128>), dim3(nblk), dim3(NTB), 0, st, p);
+  else                        // scalar epilogue for odd channel counts / unaligned slices
+    hipLaunchKernelGGL((conv_mfma_kernel<TM, TN, WM, WN, V, true, 128>), dim3(nblk), dim3(NTB), 0, st, p);
+  int rc = check_launch("conv_mfma_kernel");
+  if (rc || p.splitk <= 1) return rc;
+  const size_t total = (size_t)p.M * ((p.Cout + 3) / 4);
+  const size_t gsz = (total + 255) / 256;
+  const dim3 g((unsigned)(gsz > 4096 ? 4096 : gsz));
+  hipLaunchKernelGGL(splitk_reduce_kernel<true>, g, dim3(256), 0, st, p);
   return check_launch("splitk_reduce_kernel");
 }
 
@@ -1081,6 +1177,10 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 9: return launch_cfg<1, 2, 4, 1, 128>(p, st);
     case 10: return launch_cfg<4, 2, 2, 2, 128>(p, st);
     case 11: return launch_cfg<2, 4, 2, 2, 128>(p, st);
+    case 12: return launch_cfg8w<2, 2, 4, 2, false>(p, st);
+    case 13: return launch_cfg8w<2, 2, 4, 2, true>(p, st);
+    case 14: return launch_cfg8w<4, 2, 2, 2, true, true>(p, st);
+    case 15: return launch_cfg8w<2, 2, 2, 2, true, true>(p, st);
   }
   set_error("conv2d: tile_cfg=%d invalid", tile_cfg);
   return HRV_ERR_ARG;

@@ -302,7 +302,9 @@ BF16_CASES = [
 ]
 
 
-@pytest.mark.parametrize("cfg", [None, 8, 9, 10, 11], ids=["auto", "cfg8_rb128", "cfg9_rb128", "cfg10_256x128", "cfg11_128x256"])
+@pytest.mark.parametrize("cfg", [None, 8, 9, 10, 11, 12, 13, 14, 15],
+                         ids=["auto", "cfg8_rb128", "cfg9_rb128", "cfg10_256x128", "cfg11_128x256", "cfg12_8waves",
+                              "cfg13_8waves_3stage", "cfg14_loader_waves_256x128", "cfg15_loader_waves_128x128"])
 @pytest.mark.parametrize("case", BF16_CASES, ids=[c[0] for c in BF16_CASES])
 def test_conv_bf16_engine(case, cfg):
     """bf16 storage / fp32 accumulate engine (v_mfma_f32_32x32x16_bf16) vs the fp32 oracle evaluated on the
