@@ -237,7 +237,17 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   constexpr int ST = (VAR & 16) ? 3 : 2;
   static_assert(ST == 2 || GLDS, "the 3-stage pipeline exists for the LDS-DMA variant");
   static_assert(!SPEC || ST == 3, "wave specialisation rides on the 3-stage LDS-DMA pipeline");
-  __shared__ __attribute__((aligned(16))) float smem[ST * (BM + BN) * LS];
+  // VAR bit 6: PATCH mode for 3x3 stride-1 'same' convolutions over ONE bf16 source with Cin % 128 == 0.  The
+  // implicit-GEMM gather re-reads every activation pixel from L2 once per tap (9x); here the block's 16x16 output
+  // pixels are a 2-D tile whose 18x18 halo patch (128 channels) is DMA'd into LDS ONCE per 128-channel chunk and
+  // all 9 taps x 2 K-tiles read their A fragments from it -- only the weight tiles stream (3 LDS stages, counted
+  // vmcnt).  L2 -> LDS bytes per block tile drop from 18 x 48 KB to 81 KB + 18 x 16 KB (2.3x fewer).
+  constexpr bool PATCH = (VAR & 64) != 0;
+  static_assert(!PATCH || (GLDS && ST == 3 && !SPEC && BM == 256 && BN == 128 && NT == 512),
+                "patch mode: 8 waves, 256 (16x16) x 128 tile, LDS-DMA, 3 weight stages");
+  constexpr int PW = 18, PPIX = PW * PW;      // halo patch, pixels
+  constexpr int PFL = 64;                     // floats per patch pixel (128 bf16 channels)
+  __shared__ __attribute__((aligned(16))) float smem[PATCH ? (PPIX * PFL + 3 * BN * LS) : ST * (BM + BN) * LS];
 
   // loader waves mirror the MMA waves' thread ids: the gather distribution below is written for NT threads
   const int tid = SPEC ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;
@@ -254,6 +264,24 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   const int nt = lid - mt * p.n_tiles;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
+  // patch mode: mt = (image, tile row, tile column) of a 16x16 output tile
+  [[maybe_unused]] int pt_n = 0, pt_y0 = 0, pt_x0 = 0;
+  if constexpr (PATCH) {
+    const int tx = (p.W + 15) >> 4, ty = (p.H + 15) >> 4;
+    pt_n = mt / (tx * ty);
+    const int r = mt - pt_n * (tx * ty);
+    pt_y0 = (r / tx) << 4;
+    pt_x0 = (r % tx) << 4;
+  }
+  // GEMM row of this block -> output pixel index (>= p.M: no such pixel)
+  auto row2pix = [&](int row) -> int {
+    if constexpr (PATCH) {
+      const int y = pt_y0 + (row >> 4), x = pt_x0 + (row & 15);
+      return (y < p.H && x < p.W) ? (pt_n * p.H + y) * p.W + x : p.M;
+    } else {
+      return m0 + row;
+    }
+  };
   const int kt_begin = (int)(((long long)p.KT * ks) / p.splitk);
   const int kt_end = (int)(((long long)p.KT * (ks + 1)) / p.splitk);
 
@@ -550,7 +578,94 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
 
   f32x4 fa[KQ][TM], fb[KQ][TN];
 
-  if constexpr (GLDS && ST == 3) {
+  if constexpr (PATCH) {
+    // ---- patch mode main loop (see the VAR bit 6 note above)
+    float* patch = smem;
+    float* bst = smem + PPIX * PFL;                        // 3 weight stages of BN rows x 128 B
+    const SrcDev& S = p.src[0];
+    const rsrc_t a_rsrc = make_rsrc(S.ptr, S.bytes);
+    const int c64 = S.C >> 6;                              // 64-channel K-tiles per tap
+    const int nchunk = S.C >> 7;                           // 128-channel patch chunks
+    const int KTOT = 18 * nchunk;                          // weight tiles in patch order: chunk, tap, half
+    constexpr int NB = BR;                                 // weight DMA instructions per wave per K-tile
+    constexpr int WAIT_B1 = (NB & 15) | (7 << 4) | (0 << 8) | ((NB >> 4) << 14);   // vmcnt(NB) lgkmcnt(0)
+    constexpr int WAIT_0 = 0 | (7 << 4) | (0 << 8);                                // vmcnt(0) lgkmcnt(0)
+    // one DMA instruction = 4 consecutive halo pixels x 16 groups of 8 channels; instruction t of wave w is
+    // t*8 + w (81 instructions per patch).  The 16-byte groups of a pixel are XOR-swizzled by (hx & 15) on the
+    // SOURCE side, which makes the tap-shifted b128 fragment reads of 16 horizontally adjacent pixels bank-disjoint
+#define HRV_PATCH_DMA(CHUNK)                                                                               \
+    {                                                                                                      \
+      for (int t = wave; t < PPIX / 4; t += NT / 64) {                                                     \
+        const int P = 4 * t + (lane >> 4), s16 = lane & 15;                                                \
+        const int hy = P / PW, hx = P - hy * PW;                                                           \
+        const int y = pt_y0 - 1 + hy, x = pt_x0 - 1 + hx;                                                  \
+        const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;                        \
+        const int g = s16 ^ (hx & 15);                                                                     \
+        const unsigned off = ((unsigned)((pt_n * p.H + y) * p.W + x) * (unsigned)S.cstride +               \
+                              (unsigned)(S.coff + (CHUNK)*128 + g * 8)) * 2u;                              \
+        dma16(a_rsrc, patch + t * 256, ok ? off : 0xFFFFFFF0u, 0u);                                        \
+      }                                                                                                    \
+    }
+#define HRV_PATCH_KT(Q) ((((Q) % 18) >> 1) * c64 + ((Q) / 18) * 2 + ((Q)&1))
+#define HRV_PATCH_BDMA(Q, BUF)                                                                             \
+    {                                                                                                      \
+      const unsigned w_soff = (unsigned)((HRV_PATCH_KT(Q) * p.CoutPad + n0) * RB);                         \
+      float* Bbuf = bst + (BUF)*BN * LS;                                                                   \
+      _Pragma("unroll") for (int j = 0; j < BR; ++j)                                                       \
+          dma16(w_rsrc, Bbuf + ((NT * j + 64 * wave) / GPR) * LS, b_voff[j], w_soff);                      \
+    }
+    HRV_PATCH_DMA(0)
+    HRV_PATCH_BDMA(0, 0)
+    if (KTOT > 1) {
+      HRV_PATCH_BDMA(1, 1)
+      __builtin_amdgcn_s_waitcnt(WAIT_B1);
+    } else {
+      __builtin_amdgcn_s_waitcnt(WAIT_0);
+    }
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int rb = 0, wb = 2;
+    for (int q = 0; q < KTOT; ++q) {
+      const bool more = q + 2 < KTOT;
+      if (more) HRV_PATCH_BDMA(q + 2, wb)
+      {
+        const int rem = q % 18, tap = rem >> 1, half = rem & 1;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        const int sw = (l31 >> 1) & 7;
+        const float* Bs = bst + rb * BN * LS + (wn * TN * 32 + l31) * LS;
+        _Pragma("unroll") for (int kq = 0; kq < KQ; ++kq) {
+          _Pragma("unroll") for (int i = 0; i < TM; ++i) {
+            const int r = (wm * TM + i) * 32 + l31;
+            const int hx = (r & 15) + kw;
+            const int pix = ((r >> 4) + kh) * PW + hx;
+            fa[kq][i] = *reinterpret_cast<const f32x4*>(patch + pix * PFL + (((half * 8 + kq * 2 + lh) ^ (hx & 15)) * 4));
+          }
+          _Pragma("unroll") for (int j = 0; j < TN; ++j) fb[kq][j] =
+              *reinterpret_cast<const f32x4*>(Bs + j * 32 * LS + (((kq * 2 + lh) ^ sw) * 4));
+        }
+      }
+      HRV_MMA_FRAGS()
+      if (q + 1 < KTOT) {
+        asm volatile("" ::: "memory");
+        if (more) __builtin_amdgcn_s_waitcnt(WAIT_B1);
+        else __builtin_amdgcn_s_waitcnt(WAIT_0);
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if ((q + 1) % 18 == 0) {
+          // next 128-channel chunk: every wave has passed the barrier, the patch is free
+          HRV_PATCH_DMA((q + 1) / 18)
+          __builtin_amdgcn_s_waitcnt(WAIT_0);
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
+      }
+      rb = rb == 2 ? 0 : rb + 1;
+      wb = wb == 2 ? 0 : wb + 1;
+    }
+#undef HRV_PATCH_DMA
+#undef HRV_PATCH_KT
+#undef HRV_PATCH_BDMA
+  } else if constexpr (GLDS && ST == 3) {
     static_assert((BN * GPR) % NT == 0, "LDS-DMA B tile: every wave-instruction must be full");
     // every wave issues exactly AR + BR DMA instructions per K-tile (masked lanes use out-of-range offsets), so
     // "tile k+1 has landed, tile k+2 may still fly" is s_waitcnt vmcnt(AR + BR).  gfx9 encoding: vmcnt[3:0] in
@@ -671,7 +786,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
         if (SWAP) {
-          const int pidx = m0 + (wm * TM + i) * 32 + l31;
+          const int pidx = row2pix((wm * TM + i) * 32 + l31);
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int c0 = n0 + (wn * TN + j) * 32 + 8 * g + 4 * lh;
@@ -686,7 +801,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
           const int c = n0 + (wn * TN + j) * 32 + l31;
 #pragma unroll
           for (int e = 0; e < 16; ++e) {
-            const int pidx = m0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+            const int pidx = row2pix((wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2));
             if (pidx < p.M) wsp[(size_t)pidx * p.CoutPad + c] = acc[i][j][e];
           }
         }
@@ -704,10 +819,10 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
       const float sh = (c_ok && p.shift) ? p.shift[c] : 0.f;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
-        const int prow0 = m0 + (wm * TM + i) * 32 + 4 * lh;
+        const int prow0 = (wm * TM + i) * 32 + 4 * lh;
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const int pidx = prow0 + (e & 3) + 8 * (e >> 2);
+          const int pidx = row2pix(prow0 + (e & 3) + 8 * (e >> 2));
           if (c_ok && pidx < p.M) {
             float v = acc[i][j][e] * sc + sh;
             const size_t opix = out_pixel(p, pidx);
@@ -751,7 +866,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
             const f32x4 ns4 = p.sns ? *reinterpret_cast<const f32x4*>(p.sns + cs) : (f32x4)(0.f);
 #pragma unroll
             for (int i = 0; i < TM; ++i) {
-              const int pidx = m0 + (wm * TM + i) * 32 + l31;
+              const int pidx = row2pix((wm * TM + i) * 32 + l31);
               if (c_ok && pidx < p.M) {
                 const int n = pidx / HWo;
                 f32x4 x = ld4rt<BF>(p.sx, (size_t)pidx * p.sx_cs + p.sx_co + c0, p.sx_f32);
@@ -789,7 +904,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
         const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cs) : (f32x4)(0.f);
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-          const int pidx = m0 + (wm * TM + i) * 32 + l31;
+          const int pidx = row2pix((wm * TM + i) * 32 + l31);
           if (c_ok && pidx < p.M) {
             f32x4 v;
 #pragma unroll
@@ -924,6 +1039,7 @@ static const TileCfg kCfgs[] = {
     {2, 2, 4, 2, 128},  // 13: the same tile with THREE LDS stages (144 KB): two tiles' DMA in flight per block
     {4, 2, 2, 2, 128},  // 14: 256 x 128, 4 MMA waves (wave tile 128 x 64) + 4 LOADER waves, three LDS stages
     {2, 2, 2, 2, 128},  // 15: 128 x 128, 4 MMA waves (wave tile 64 x 64) + 4 LOADER waves, three LDS stages (96 KB)
+    {2, 2, 4, 2, 128},  // 16: PATCH mode -- 16x16-pixel x 128-column tile, 18x18 halo patch resident in LDS (3x3 s1 only)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1163,6 +1279,37 @@ static int launch_cfg8w(const ConvParams& p, hipStream_t st) {
   return check_launch("splitk_reduce_kernel");
 }
 
+// cfg 16: patch mode (VAR bit 6).  3x3, stride 1, pad 1 ('same'), ONE bf16-stored source with C % 128 == 0 read at its
+// own resolution, bf16 packed weights, no split-K, no strided scatter.
+static bool patch_eligible(const ConvParams& p) {
+  return p.bf16 && !p.src_f32 && p.nsrc == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.pad_w == 1 &&
+         p.Ho == p.H && p.Wo == p.W && p.src[0].up_shift == 0 && p.src[0].C % 128 == 0 && p.src[0].bytes != 0 &&
+         p.w_bytes != 0 && p.out_step != 2 && p.CoutPad % 128 == 0;
+}
+
+static int launch_patch(const ConvParams& p0, hipStream_t st) {
+  if (!patch_eligible(p0)) {
+    set_error("conv2d: tile_cfg 16 (patch mode) needs a 3x3 stride-1 'same' convolution over one bf16-stored source with "
+              "C %% 128 == 0");
+    return HRV_ERR_ARG;
+  }
+  ConvParams p = p0;
+  p.splitk = 1;
+  p.m_tiles = p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16);
+  p.n_tiles = p.CoutPad / 128;
+  const int nblk = p.m_tiles * p.n_tiles;
+  const int oesz = p.out_f32 ? 4 : 2, resz = p.res_f32 ? 4 : 2;
+  const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
+                      (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (((uintptr_t)p.out) & (4 * oesz - 1)) == 0 &&
+                      (((uintptr_t)p.res) & (4 * resz - 1)) == 0;
+  constexpr int V = 4 | 16 | 64;
+  if (vec_ok || p.epi == 1)
+    hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 4, 2, V | 1, true, 128>), dim3(nblk), dim3(512), 0, st, p);
+  else
+    hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 4, 2, V, true, 128>), dim3(nblk), dim3(512), 0, st, p);
+  return check_launch("conv_mfma_kernel[patch]");
+}
+
 static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
   switch (tile_cfg) {
     case 0: return launch_cfg<2, 2, 2, 2>(p, st);
@@ -1181,6 +1328,7 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 13: return launch_cfg8w<2, 2, 4, 2, true>(p, st);
     case 14: return launch_cfg8w<4, 2, 2, 2, true, true>(p, st);
     case 15: return launch_cfg8w<2, 2, 2, 2, true, true>(p, st);
+    case 16: return launch_patch(p, st);
   }
   set_error("conv2d: tile_cfg=%d invalid", tile_cfg);
   return HRV_ERR_ARG;

@@ -39,6 +39,21 @@ def _cpad(c: int, bf16: bool) -> int:
     return (c + 7) // 8 * 8 if bf16 else (c + 3) // 4 * 4
 
 
+def patch_tile_ok(bf16_sources: bool, KH: int, KW: int, stride: int, pad: int, nsrc: int, up: int, C: int, cols: int,
+                  N: int, H: int, W: int) -> bool:
+    """tile_cfg 16 (conv_f32.hip, VAR bit 6): 3x3 stride-1 'same' convolution over ONE bf16-stored source with
+    C % 128 == 0 whose 16x16-pixel tiles keep their halo patch resident in LDS.  Chosen when the 128-column tiles
+    waste little (``cols`` = GEMM columns) and there are enough tiles to fill the chip (else the gather tiles with
+    split-K win).  Measured 585-600 vs 410-520 TFLOP/s on the SPADE shapes."""
+    if not (bf16_sources and KH == 3 and KW == 3 and stride == 1 and pad == 1 and nsrc == 1 and up == 0 and
+            C % 128 == 0 and os.environ.get("HRV_CONV_PATCH", "1") != "0"):
+        return False
+    cp = (cols + 127) // 128 * 128
+    if cp - cols > 32:
+        return False
+    return N * ((H + 15) // 16) * ((W + 15) // 16) * (cp // 128) >= 256
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -278,6 +293,9 @@ class ConvLayer:
                 # 128-byte K-tile rows: 128x128 tile +15-20 % (profiles/r01_conv_bench_bf16_rb.txt); the 128x64 tile
                 # additionally stages its operands by LDS-DMA (profiles/r01_conv_bench_bf16_glds.txt)
                 cfg = 8 if cfg == 0 else 9
+            if self.bf16 and patch_tile_ok(True, self.KH, self.KW, self.stride, self.pad, len(specs), up0,
+                                           self.src_pad[0], self.Cout, N, H, W):
+                cfg = 16
         forced = os.environ.get("HRV_CONV_TILE") if (spade is None and not self.mixed) else None
         if forced is not None:
             cfg = int(forced)
@@ -434,7 +452,10 @@ class SpadeModulate:
         e.noise_scale = self.ns.data_ptr() if use_noise else None
         if out is None:
             out = alloc(x.N, x.H, x.W, self.Creal, x.t.device, self.bf16)
-        return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=self.cfg)
+        cfg = self.cfg
+        if self.bf16 and patch_tile_ok(True, 3, 3, 1, 1, 1, 0, actv.Cp, self.conv.Cout, x.N, x.H, x.W):
+            cfg = 16
+        return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=cfg)
 
 
 def tap_expand(a: Act, down: int, k: int = 3) -> Act:

@@ -40,7 +40,7 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     bn = lib.hrv_conv2d_tile_bn(cfg)
     rows = Cout if mode == 0 else cin
     rows_pad = (rows + bn - 1) // bn * bn
-    bke = (64 if 8 <= cfg <= 11 else 32) if bf16 else 16
+    bke = (64 if cfg >= 8 else 32) if bf16 else 16
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
     buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
     geom = (C.c_int32 * 8)()
@@ -114,6 +114,8 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     mb = MMA_BF16[0]
     cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
+    if mb and ops.patch_tile_ok(a0.bf16, KH, KW, stride, pad, len(srcs), up0, a0.Cp, Cout, N, H, W):
+        cfg = 16       # bf16-stored source: the halo patch stays in LDS (ops.patch_tile_ok)
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
     packed, _ = pack_weight_dev(w, [a.Cp for a, _ in srcs], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
@@ -142,6 +144,8 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     if stride == 1:
+        if mb and ops.patch_tile_ok(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) and (Ho, Wo) == (H, W):
+            cfg = 16   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
         packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
                     residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl, mma_bf16=mb)

@@ -273,3 +273,34 @@ def test_conv_sub_batch_launches_are_bit_identical(monkeypatch, bf16):
         got = m(x, seg)
         assert torch.equal(got, want), cap
     assert (want[0] - want[1]).abs().max() > 1e-3      # the images do differ: a wrong base pointer would show
+
+
+@pytest.mark.parametrize("C,H,W", [(64, 32, 48), (128, 20, 24), (96, 16, 16)])
+def test_spade_modulate_patch_mode_matches_gather_tiles(C, H, W):
+    """The fused gamma|beta + modulate epilogue on tile_cfg 16 (LDS-resident halo patch) vs the same layer on the
+    gather tile it replaces (cfg 8): same operands, same epilogue, only the fp32 summation order may differ."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C + H)
+    N, hid = 2, 128
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    wg, wb = rb(torch.randn(C, hid, 3, 3, generator=g) * 0.03), rb(torch.randn(C, hid, 3, 3, generator=g) * 0.03)
+    bg, bb = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    ns = torch.randn(C, generator=g) * 0.3
+    x = torch.randn(N, C, H, W, generator=g)
+    actv = rb(torch.relu(torch.randn(N, hid, H, W, generator=g)))
+    z = torch.randn(N, W, H, 1, generator=g).cuda().contiguous()
+    mod = ops.SpadeModulate(wg, bg, wb, bb, ns, "cuda", ops.ACT_LRELU, "mod", bf16=True)
+    xa = ops.to_nhwc(x.cuda())                       # the normalised tensor stays fp32 (feeds InstanceNorm)
+    aa = ops.to_nhwc(actv.cuda(), bf16=True)
+    mean, rstd = ops.instnorm_stats(xa, z, mod.ns)
+    outs = {}
+    for cfg in (8, 16):
+        mod.cfg = cfg
+        outs[cfg] = ops.to_nchw(mod(aa, xa, mean, rstd, z)).float()
+    # oracle: IN(x + noise) * (1 + gamma) + beta with gamma/beta = conv(actv)
+    v = x + (z.cpu() * ns).transpose(1, 3)
+    nh = (v - v.mean((2, 3), keepdim=True)) / torch.sqrt(v.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
+    want = F.leaky_relu(nh * (1 + F.conv2d(actv, wg, bg, padding=1)) + F.conv2d(actv, wb, bb, padding=1), 0.2)
+    for cfg in (8, 16):
+        assert _rel(outs[cfg].cpu(), want) < 1e-2, (cfg, _rel(outs[cfg].cpu(), want))
+    assert (outs[8] - outs[16]).abs().max() <= 2 ** -7 * want.abs().max()

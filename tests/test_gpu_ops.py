@@ -350,3 +350,53 @@ def test_conv_bf16_engine(case, cfg):
     got = ops.to_nchw(o)
     assert o.t.dtype == torch.bfloat16 and (o.t[..., cout:].float() == 0).all()
     _assert_close("conv_bf16_" + name, got, ref, 1e-2)
+
+
+@pytest.mark.parametrize("case", [("p128", 128, 128, 32, 48, {}),
+                                  ("p128_res_relu_f32out", 128, 256, 20, 24, {"res": True, "act": "relu", "bias": True}),
+                                  ("p256_partial_tiles", 256, 128, 18, 40, {"bn": True}),
+                                  ("p384_cout100", 384, 100, 16, 16, {"bias": True, "act": "lrelu"})],
+                         ids=lambda c: c[0])
+def test_conv_bf16_patch_mode(case):
+    """tile_cfg 16: 3x3 stride-1 convolutions whose 16x16-pixel tile keeps its 18x18 halo patch resident in LDS (the
+    activation is read from L2 once instead of once per tap).  Same math as the gather tiles: vs the fp32 oracle on
+    the bf16-rounded operands, and vs cfg 8 (bit-identical for Cin = 128, where the K order is the same)."""
+    ops = _ops()
+    name, cin, cout, H, W, ex = case
+    g = torch.Generator().manual_seed(cin + cout + H)
+    N = 2
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g))
+    w = rb(torch.randn(cout, cin, 3, 3, generator=g) * (1.0 / (cin * 9) ** 0.5))
+    scale = (torch.rand(cout, generator=g) + 0.5) if ex.get("bn") else None
+    shift = torch.randn(cout, generator=g) * 0.3 if (ex.get("bn") or ex.get("bias")) else None
+    act = {"relu": ops.ACT_RELU, "lrelu": ops.ACT_LRELU}.get(ex.get("act"), ops.ACT_NONE)
+    ref = F.conv2d(x, w, None, padding=1)
+    if scale is not None:
+        ref = ref * scale.view(1, -1, 1, 1)
+    if shift is not None:
+        ref = ref + shift.view(1, -1, 1, 1)
+    res = rb(torch.randn(ref.shape, generator=g)) if ex.get("res") else None
+    if res is not None:
+        ref = ref + res
+    ref = {ops.ACT_RELU: F.relu, ops.ACT_LRELU: lambda t: F.leaky_relu(t, 0.2), ops.ACT_NONE: lambda t: t}[act](ref)
+    f32out = "f32out" in name
+    layer = ops.ConvLayer(w, [cin], "cuda", scale=scale, shift=shift, pad=1, act=act, name=name, bf16=True, out_f32=f32out)
+    xa = ops.to_nhwc(x.cuda(), bf16=True)
+    ra = ops.to_nhwc(res.cuda(), bf16=True) if res is not None else None
+    outs = {}
+    for cfg in (8, 16):
+        o = layer([(xa, 0, ops.ACT_NONE)], residual=ra, cfg=cfg)
+        assert o.t.dtype == (torch.float32 if f32out else torch.bfloat16)
+        outs[cfg] = ops.to_nchw(o)
+        _assert_close(f"conv_bf16_patch_{name}_cfg{cfg}", outs[cfg], ref, 1e-2 if not f32out else 2e-5)
+    d = (outs[8] - outs[16]).abs()
+    os.makedirs("gpurun_out", exist_ok=True)
+    with open("gpurun_out/patch_mode_diff.txt", "a") as f:
+        f.write(f"{name}: max|cfg8-cfg16|={d.max().item():.3e} differing={int((d > 0).sum())}/{d.numel()} "
+                f"max|ref|={ref.abs().max().item():.3f}\n")
+    assert d.max() <= 2 ** -7 * ref.abs().max()
+    # not eligible: patch mode refuses instead of computing something else
+    bad = ops.ConvLayer(rb(torch.randn(64, 96, 3, 3, generator=g)), [96], "cuda", pad=1, name="bad", bf16=True)
+    with pytest.raises(Exception):
+        bad([(ops.to_nhwc(torch.zeros(1, 96, 16, 16).cuda(), bf16=True), 0, ops.ACT_NONE)], cfg=16)
