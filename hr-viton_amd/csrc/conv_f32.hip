@@ -243,11 +243,15 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   // all 9 taps x 2 K-tiles read their A fragments from it -- only the weight tiles stream (3 LDS stages, counted
   // vmcnt).  L2 -> LDS bytes per block tile drop from 18 x 48 KB to 81 KB + 18 x 16 KB (2.3x fewer).
   constexpr bool PATCH = (VAR & 64) != 0;
-  static_assert(!PATCH || (GLDS && ST == 3 && !SPEC && BM == 256 && BN == 128 && NT == 512),
-                "patch mode: 8 waves, 256 (16x16) x 128 tile, LDS-DMA, 3 weight stages");
-  constexpr int PW = 18, PPIX = PW * PW;      // halo patch, pixels
+  static_assert(!PATCH || (GLDS && !SPEC && ((BM == 256 && BN == 128 && NT == 512 && ST == 3) ||
+                                            (BM == 128 && (BN == 128 || BN == 64) && NT == 256 && ST == 2))),
+                "patch mode: 16x16 pixels x 128 columns with 8 waves and 3 weight stages (132 KB LDS, one block per "
+                "CU), or 8x16 pixels with 4 waves and 2 weight stages (78 KB: two blocks per CU overlap each "
+                "other's patch load and epilogue; 128 or 64 columns)");
+  constexpr int TH = BM / 16;                 // tile rows (pixels); tile width is 16
+  constexpr int PW = 18, PPIX = (TH + 2) * PW;   // halo patch, pixels
   constexpr int PFL = 64;                     // floats per patch pixel (128 bf16 channels)
-  __shared__ __attribute__((aligned(16))) float smem[PATCH ? (PPIX * PFL + 3 * BN * LS) : ST * (BM + BN) * LS];
+  __shared__ __attribute__((aligned(16))) float smem[PATCH ? (PPIX * PFL + ST * BN * LS) : ST * (BM + BN) * LS];
 
   // loader waves mirror the MMA waves' thread ids: the gather distribution below is written for NT threads
   const int tid = SPEC ? (int)(threadIdx.x & (NT - 1)) : (int)threadIdx.x;
@@ -267,10 +271,10 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   // patch mode: mt = (image, tile row, tile column) of a 16x16 output tile
   [[maybe_unused]] int pt_n = 0, pt_y0 = 0, pt_x0 = 0;
   if constexpr (PATCH) {
-    const int tx = (p.W + 15) >> 4, ty = (p.H + 15) >> 4;
+    const int tx = (p.W + 15) >> 4, ty = (p.H + TH - 1) / TH;
     pt_n = mt / (tx * ty);
     const int r = mt - pt_n * (tx * ty);
-    pt_y0 = (r / tx) << 4;
+    pt_y0 = (r / tx) * TH;
     pt_x0 = (r % tx) << 4;
   }
   // GEMM row of this block -> output pixel index (>= p.M: no such pixel)
@@ -581,7 +585,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   if constexpr (PATCH) {
     // ---- patch mode main loop (see the VAR bit 6 note above)
     float* patch = smem;
-    float* bst = smem + PPIX * PFL;                        // 3 weight stages of BN rows x 128 B
+    float* bst = smem + PPIX * PFL;                        // ST weight stages of BN rows x 128 B
     const SrcDev& S = p.src[0];
     const rsrc_t a_rsrc = make_rsrc(S.ptr, S.bytes);
     const int c64 = S.C >> 6;                              // 64-channel K-tiles per tap
@@ -616,7 +620,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
     }
     HRV_PATCH_DMA(0)
     HRV_PATCH_BDMA(0, 0)
-    if (KTOT > 1) {
+    if (ST == 3 && KTOT > 1) {
       HRV_PATCH_BDMA(1, 1)
       __builtin_amdgcn_s_waitcnt(WAIT_B1);
     } else {
@@ -624,10 +628,10 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
-    int rb = 0, wb = 2;
+    int rb = 0, wb = ST - 1;
     for (int q = 0; q < KTOT; ++q) {
-      const bool more = q + 2 < KTOT;
-      if (more) HRV_PATCH_BDMA(q + 2, wb)
+      const bool more = q + ST - 1 < KTOT;
+      if (more) HRV_PATCH_BDMA(q + ST - 1, wb)
       {
         const int rem = q % 18, tap = rem >> 1, half = rem & 1;
         const int kh = tap / 3, kw = tap - kh * 3;
@@ -647,7 +651,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
       HRV_MMA_FRAGS()
       if (q + 1 < KTOT) {
         asm volatile("" ::: "memory");
-        if (more) __builtin_amdgcn_s_waitcnt(WAIT_B1);
+        if (ST == 3 && more) __builtin_amdgcn_s_waitcnt(WAIT_B1);
         else __builtin_amdgcn_s_waitcnt(WAIT_0);
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
@@ -659,8 +663,8 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
           asm volatile("" ::: "memory");
         }
       }
-      rb = rb == 2 ? 0 : rb + 1;
-      wb = wb == 2 ? 0 : wb + 1;
+      rb = rb == ST - 1 ? 0 : rb + 1;
+      wb = wb == ST - 1 ? 0 : wb + 1;
     }
 #undef HRV_PATCH_DMA
 #undef HRV_PATCH_KT
@@ -1040,6 +1044,8 @@ static const TileCfg kCfgs[] = {
     {4, 2, 2, 2, 128},  // 14: 256 x 128, 4 MMA waves (wave tile 128 x 64) + 4 LOADER waves, three LDS stages
     {2, 2, 2, 2, 128},  // 15: 128 x 128, 4 MMA waves (wave tile 64 x 64) + 4 LOADER waves, three LDS stages (96 KB)
     {2, 2, 4, 2, 128},  // 16: PATCH mode -- 16x16-pixel x 128-column tile, 18x18 halo patch resident in LDS (3x3 s1 only)
+    {2, 2, 2, 2, 128},  // 17: PATCH mode -- 8x16-pixel x 128-column tile, 10x18 halo patch, two blocks per CU
+    {1, 2, 4, 1, 128},  // 18: PATCH mode -- 8x16-pixel x 64-column tile (column counts that are odd multiples of 64)
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -1284,29 +1290,32 @@ static int launch_cfg8w(const ConvParams& p, hipStream_t st) {
 static bool patch_eligible(const ConvParams& p) {
   return p.bf16 && !p.src_f32 && p.nsrc == 1 && p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.pad_w == 1 &&
          p.Ho == p.H && p.Wo == p.W && p.src[0].up_shift == 0 && p.src[0].C % 128 == 0 && p.src[0].bytes != 0 &&
-         p.w_bytes != 0 && p.out_step != 2 && p.CoutPad % 128 == 0;
+         p.w_bytes != 0 && p.out_step != 2;
 }
 
+template <int TMP, int TNP, int WMP, int WNP, int STV>
 static int launch_patch(const ConvParams& p0, hipStream_t st) {
-  if (!patch_eligible(p0)) {
-    set_error("conv2d: tile_cfg 16 (patch mode) needs a 3x3 stride-1 'same' convolution over one bf16-stored source with "
+  constexpr int BNP = 32 * TNP * WNP;
+  if (!patch_eligible(p0) || p0.CoutPad % BNP != 0) {
+    set_error("conv2d: tile_cfg 16-18 (patch mode) needs a 3x3 stride-1 'same' convolution over one bf16-stored source with "
               "C %% 128 == 0");
     return HRV_ERR_ARG;
   }
   ConvParams p = p0;
   p.splitk = 1;
-  p.m_tiles = p.N * ((p.H + 15) / 16) * ((p.W + 15) / 16);
-  p.n_tiles = p.CoutPad / 128;
+  constexpr int THP = TMP * WMP * 32 / 16;   // tile rows: BM / 16
+  p.m_tiles = p.N * ((p.H + THP - 1) / THP) * ((p.W + 15) / 16);
+  p.n_tiles = p.CoutPad / BNP;
   const int nblk = p.m_tiles * p.n_tiles;
   const int oesz = p.out_f32 ? 4 : 2, resz = p.res_f32 ? 4 : 2;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
                       (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (((uintptr_t)p.out) & (4 * oesz - 1)) == 0 &&
                       (((uintptr_t)p.res) & (4 * resz - 1)) == 0;
-  constexpr int V = 4 | 16 | 64;
+  constexpr int V = 4 | STV | 64;
   if (vec_ok || p.epi == 1)
-    hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 4, 2, V | 1, true, 128>), dim3(nblk), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TMP, TNP, WMP, WNP, V | 1, true, 128>), dim3(nblk), dim3(64 * WMP * WNP), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<2, 2, 4, 2, V, true, 128>), dim3(nblk), dim3(512), 0, st, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TMP, TNP, WMP, WNP, V, true, 128>), dim3(nblk), dim3(64 * WMP * WNP), 0, st, p);
   return check_launch("conv_mfma_kernel[patch]");
 }
 
@@ -1328,7 +1337,9 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 13: return launch_cfg8w<2, 2, 4, 2, true>(p, st);
     case 14: return launch_cfg8w<4, 2, 2, 2, true, true>(p, st);
     case 15: return launch_cfg8w<2, 2, 2, 2, true, true>(p, st);
-    case 16: return launch_patch(p, st);
+    case 16: return launch_patch<2, 2, 4, 2, 16>(p, st);
+    case 17: return launch_patch<2, 2, 2, 2, 0>(p, st);
+    case 18: return launch_patch<1, 2, 4, 1, 0>(p, st);
   }
   set_error("conv2d: tile_cfg=%d invalid", tile_cfg);
   return HRV_ERR_ARG;

@@ -39,19 +39,31 @@ def _cpad(c: int, bf16: bool) -> int:
     return (c + 7) // 8 * 8 if bf16 else (c + 3) // 4 * 4
 
 
-def patch_tile_ok(bf16_sources: bool, KH: int, KW: int, stride: int, pad: int, nsrc: int, up: int, C: int, cols: int,
-                  N: int, H: int, W: int) -> bool:
-    """tile_cfg 16 (conv_f32.hip, VAR bit 6): 3x3 stride-1 'same' convolution over ONE bf16-stored source with
-    C % 128 == 0 whose 16x16-pixel tiles keep their halo patch resident in LDS.  Chosen when the 128-column tiles
-    waste little (``cols`` = GEMM columns) and there are enough tiles to fill the chip (else the gather tiles with
-    split-K win).  Measured 585-600 vs 410-520 TFLOP/s on the SPADE shapes."""
+def patch_tile(bf16_sources: bool, KH: int, KW: int, stride: int, pad: int, nsrc: int, up: int, C: int, cols: int,
+               N: int, H: int, W: int) -> int:
+    """Patch-mode tile of the conv engine (conv_f32.hip, VAR bit 6) for this layer, or 0.  Patch mode: 3x3 stride-1
+    'same' convolution over ONE bf16-stored source with C % 128 == 0; the 8x16-pixel tile keeps its 10x18 halo
+    patch resident in LDS and only the weight tiles stream (the implicit-GEMM gather re-reads every activation
+    pixel from L2 once per tap).  tile_cfg 17: 128 columns, 18: 64 columns (column counts that are odd multiples
+    of 64 -- the SPADE gamma|beta convs of the 80/144/272-channel blocks).  Needs enough tiles to fill the chip
+    (else the gather tiles with split-K win).  HRV_CONV_PATCH=0 disables it, =16 selects the 16x16-pixel tile."""
+    env = os.environ.get("HRV_CONV_PATCH", "1")
     if not (bf16_sources and KH == 3 and KW == 3 and stride == 1 and pad == 1 and nsrc == 1 and up == 0 and
-            C % 128 == 0 and os.environ.get("HRV_CONV_PATCH", "1") != "0"):
-        return False
-    cp = (cols + 127) // 128 * 128
-    if cp - cols > 32:
-        return False
-    return N * ((H + 15) // 16) * ((W + 15) // 16) * (cp // 128) >= 256
+            C % 128 == 0 and env != "0"):
+        return 0
+    c64 = (cols + 63) // 64
+    if c64 * 64 - cols > 32:
+        return 0
+    wide = c64 % 2 == 0
+    if N * ((H + 7) // 8) * ((W + 15) // 16) * (c64 // 2 if wide else c64) < 512:
+        return 0
+    if env == "16" and wide:
+        return 16
+    return 17 if wide else 18
+
+
+def patch_tile_ok(*a) -> bool:
+    return patch_tile(*a) != 0
 
 
 def _stream() -> int:
@@ -293,9 +305,9 @@ class ConvLayer:
                 # 128-byte K-tile rows: 128x128 tile +15-20 % (profiles/r01_conv_bench_bf16_rb.txt); the 128x64 tile
                 # additionally stages its operands by LDS-DMA (profiles/r01_conv_bench_bf16_glds.txt)
                 cfg = 8 if cfg == 0 else 9
-            if self.bf16 and patch_tile_ok(True, self.KH, self.KW, self.stride, self.pad, len(specs), up0,
-                                           self.src_pad[0], self.Cout, N, H, W):
-                cfg = 16
+            pt = patch_tile(self.bf16, self.KH, self.KW, self.stride, self.pad, len(specs), up0, self.src_pad[0],
+                            self.Cout, N, H, W)
+            cfg = pt or cfg
         forced = os.environ.get("HRV_CONV_TILE") if (spade is None and not self.mixed) else None
         if forced is not None:
             cfg = int(forced)
@@ -453,8 +465,7 @@ class SpadeModulate:
         if out is None:
             out = alloc(x.N, x.H, x.W, self.Creal, x.t.device, self.bf16)
         cfg = self.cfg
-        if self.bf16 and patch_tile_ok(True, 3, 3, 1, 1, 1, 0, actv.Cp, self.conv.Cout, x.N, x.H, x.W):
-            cfg = 16
+        cfg = patch_tile(self.bf16, 3, 3, 1, 1, 1, 0, actv.Cp, self.conv.Cout, x.N, x.H, x.W) or cfg
         return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=cfg)
 
 

@@ -114,8 +114,8 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     mb = MMA_BF16[0]
     cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
-    if mb and ops.patch_tile_ok(a0.bf16, KH, KW, stride, pad, len(srcs), up0, a0.Cp, Cout, N, H, W):
-        cfg = 16       # bf16-stored source: the halo patch stays in LDS (ops.patch_tile_ok)
+    if mb:                 # bf16-stored source: the halo patch stays in LDS (ops.patch_tile)
+        cfg = ops.patch_tile(a0.bf16, KH, KW, stride, pad, len(srcs), up0, a0.Cp, Cout, N, H, W) or cfg
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
     packed, _ = pack_weight_dev(w, [a.Cp for a, _ in srcs], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
@@ -144,8 +144,8 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     if stride == 1:
-        if mb and ops.patch_tile_ok(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) and (Ho, Wo) == (H, W):
-            cfg = 16   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
+        if mb and (Ho, Wo) == (H, W):   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
+            cfg = ops.patch_tile(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) or cfg
         packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
                     residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl, mma_bf16=mb)

@@ -294,13 +294,18 @@ def test_spade_modulate_patch_mode_matches_gather_tiles(C, H, W):
     aa = ops.to_nhwc(actv.cuda(), bf16=True)
     mean, rstd = ops.instnorm_stats(xa, z, mod.ns)
     outs = {}
-    for cfg in (8, 16):
+    import os
+    for cfg in (8, 16, 17):
         mod.cfg = cfg
-        outs[cfg] = ops.to_nchw(mod(aa, xa, mean, rstd, z)).float()
+        os.environ["HRV_CONV_PATCH"] = "0" if cfg == 8 else str(cfg)     # the layer picks its patch tile from this
+        try:
+            outs[cfg] = ops.to_nchw(mod(aa, xa, mean, rstd, z)).float()
+        finally:
+            os.environ.pop("HRV_CONV_PATCH", None)
     # oracle: IN(x + noise) * (1 + gamma) + beta with gamma/beta = conv(actv)
     v = x + (z.cpu() * ns).transpose(1, 3)
     nh = (v - v.mean((2, 3), keepdim=True)) / torch.sqrt(v.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
     want = F.leaky_relu(nh * (1 + F.conv2d(actv, wg, bg, padding=1)) + F.conv2d(actv, wb, bb, padding=1), 0.2)
-    for cfg in (8, 16):
+    for cfg in (8, 16, 17):
         assert _rel(outs[cfg].cpu(), want) < 1e-2, (cfg, _rel(outs[cfg].cpu(), want))
-    assert (outs[8] - outs[16]).abs().max() <= 2 ** -7 * want.abs().max()
+        assert (outs[8] - outs[cfg]).abs().max() <= 2 ** -7 * want.abs().max()

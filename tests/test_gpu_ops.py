@@ -358,8 +358,8 @@ def test_conv_bf16_engine(case, cfg):
                                   ("p384_cout100", 384, 100, 16, 16, {"bias": True, "act": "lrelu"})],
                          ids=lambda c: c[0])
 def test_conv_bf16_patch_mode(case):
-    """tile_cfg 16: 3x3 stride-1 convolutions whose 16x16-pixel tile keeps its 18x18 halo patch resident in LDS (the
-    activation is read from L2 once instead of once per tap).  Same math as the gather tiles: vs the fp32 oracle on
+    """tile_cfg 16 / 17 / 18: 3x3 stride-1 convolutions whose pixel tile (16x16, 8x16 x 128 columns, 8x16 x 64 columns)
+    keeps its halo patch resident in LDS (the activation is read from L2 once instead of once per tap).  Same math as the gather tiles: vs the fp32 oracle on
     the bf16-rounded operands, and vs cfg 8 (bit-identical for Cin = 128, where the K order is the same)."""
     ops = _ops()
     name, cin, cout, H, W, ex = case
@@ -385,11 +385,13 @@ def test_conv_bf16_patch_mode(case):
     xa = ops.to_nhwc(x.cuda(), bf16=True)
     ra = ops.to_nhwc(res.cuda(), bf16=True) if res is not None else None
     outs = {}
-    for cfg in (8, 16):
+    for cfg in (8, 16, 17, 18):
         o = layer([(xa, 0, ops.ACT_NONE)], residual=ra, cfg=cfg)
         assert o.t.dtype == (torch.float32 if f32out else torch.bfloat16)
         outs[cfg] = ops.to_nchw(o)
         _assert_close(f"conv_bf16_patch_{name}_cfg{cfg}", outs[cfg], ref, 1e-2 if not f32out else 2e-5)
+    assert (outs[8] - outs[17]).abs().max() <= 2 ** -7 * ref.abs().max()
+    assert (outs[8] - outs[18]).abs().max() <= 2 ** -7 * ref.abs().max()
     d = (outs[8] - outs[16]).abs()
     os.makedirs("gpurun_out", exist_ok=True)
     with open("gpurun_out/patch_mode_diff.txt", "a") as f:
