@@ -58,25 +58,21 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams
     f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
     if (active) {
       const f32x4 K = stats_value<BF>(p, n, 0, g);  // shift: kills the cancellation in E[v^2]-E[v]^2
-      // four independent chains: four 16-byte loads in flight per thread (one chain is latency-bound: 1.3 TB/s)
-      f32x4 t1[4], t2[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { t1[u] = (f32x4)(0.f); t2[u] = (f32x4)(0.f); }
+      // four 16-byte loads in flight per thread (one load per iteration is latency-bound: 1.3 TB/s); the sums keep
+      // ONE chain in pixel order, so the result is bit-identical to the plain loop
       int px = p0 + r;
       for (; px + 3 * R < p1; px += 4 * R) {
         f32x4 d[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) d[u] = stats_value<BF>(p, n, px + u * R, g) - K;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) { t1[u] += d[u]; t2[u] += d[u] * d[u]; }
+        for (int u = 0; u < 4; ++u) { s1 += d[u]; s2 += d[u] * d[u]; }
       }
       for (; px < p1; px += R) {
         const f32x4 d = stats_value<BF>(p, n, px, g) - K;
-        t1[0] += d;
-        t2[0] += d * d;
+        s1 += d;
+        s2 += d * d;
       }
-      s1 = (t1[0] + t1[1]) + (t1[2] + t1[3]);
-      s2 = (t2[0] + t2[1]) + (t2[2] + t2[3]);
     }
     red[0][t] = s1;
     red[1][t] = s2;

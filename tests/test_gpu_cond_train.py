@@ -4,6 +4,8 @@ EVERY parameter gradient, BatchNorm running statistics, Adam update) against the
 tests/test_oracle_golden.py pins to the real reference's step."""
 from argparse import Namespace
 
+import os
+
 import pytest
 import torch
 import torch.nn.functional as F
@@ -440,9 +442,15 @@ def test_three_training_iterations_against_the_oracle():
         for k in ("loss_G", "loss_D"):
             assert abs(float(losses[k].detach()) - float(r[k].detach())) < 1e-4 * max(1.0, abs(float(r[k].detach()))), (it, k)
         gmax = max(v.abs().max().item() for v in want_g.values())
-        for k, w in want_g.items():
-            err = (cap[k] - w).abs().max().item()
-            assert err < 5e-3 * max(w.abs().max().item(), 1e-3 * gmax), (it, k, err)
+        errs = sorted(((cap[k] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), k) for k, w in want_g.items())
+        os.makedirs("gpurun_out", exist_ok=True)
+        with open("gpurun_out/grad_diag_tocg_3iter.txt", "a" if it else "w") as f:
+            f.write(f"# iteration {it}: relative gradient error (max-abs / max|want|), worst 8 of {len(errs)}; median "
+                    f"{errs[len(errs) // 2][0]:.2e}\n" + "".join(f"{e:.3e} {k}\n" for e, k in errs[-8:]))
+        # This configuration is sensitive to last-bit changes upstream of the warps (a different summation order in
+        # the BatchNorm statistics moved the median from 1e-4 to 3e-3): the statistics kernel keeps its sums in
+        # pixel order for that reason.
+        assert errs[-1][0] < 5e-3, (it, errs[-1])
         sd_h = tocg.state_dict()
         off = tot = 0
         for k, v in sd_g.items():
