@@ -1459,8 +1459,11 @@ static int conv2d_any(const hrv_conv2d_t* d, hipStream_t stream, bool bf) {
     per_img = e > per_img ? e : per_img;
   }
   const int64_t out_px = (int64_t)d->Ho * d->Wo;
-  // HRV_CONV_MAX_BATCH caps the images per launch so that the tests can exercise the sub-batch path on small tensors
-  const int64_t lim = (int64_t)1 << 32;
+  // HRV_CONV_MAX_BATCH caps the images per launch so that the tests can exercise the sub-batch path on small tensors.
+  // The limit is on BYTES (the LDS-DMA staging addresses a source through a 32-bit buffer resource; the patch-mode
+  // tiles have no other staging), which also keeps the element offsets of the register-staged gather in range.
+  const bool srcf0 = bf && (d->mixed_flags & 8);
+  const int64_t lim = (int64_t)0xFFFFFFF0 / ((bf && !srcf0) ? 2 : 4);
   int64_t cap = d->N;
   if (const char* e = getenv("HRV_CONV_MAX_BATCH")) {
     const long long v = atoll(e);
