@@ -138,3 +138,46 @@ def test_cpu_tensors_raise():
     from hr_viton_amd import ops
     with pytest.raises(ops.HrvError):
         ops.to_nhwc(torch.zeros(1, 4, 8, 8))
+
+
+def test_tile_table_and_new_struct_fields(lib):
+    """Tile ids 8-18 (128-byte K-tile rows of the bf16 engine incl. the 8-wave, loader-wave and patch-mode tiles):
+    column / row extents the packers and the Python planners rely on; the structs that gained fields."""
+    from hr_viton_amd import _lib
+    want = {8: (128, 128), 9: (128, 64), 10: (256, 128), 11: (128, 256), 12: (256, 128), 13: (256, 128), 14: (256, 128),
+            15: (128, 128), 16: (256, 128), 17: (128, 128), 18: (128, 64)}
+    for cfg, (bm, bn) in want.items():
+        assert (lib.hrv_conv2d_tile_bm(cfg), lib.hrv_conv2d_tile_bn(cfg)) == (bm, bn), cfg
+    assert lib.hrv_conv2d_tile_bn(19) == -1
+    d = _lib.hrv_norm_bwd_t()
+    assert hasattr(d, "dgb_bf16") and hasattr(d, "out_bf16") and d.dgb_bf16 == 0 and d.out_bf16 == 0
+    # a descriptor that asks for the patch tile without being a 3x3 'same' bf16 convolution is refused, not rerouted
+    c = _lib.hrv_conv2d_t()
+    c.tile_cfg = 17
+    assert lib.hrv_conv2d_nhwc_bf16(C.byref(c), None) == -1
+
+
+def test_patch_tile_selection():
+    """ops.patch_tile: which layers take the LDS-resident-patch tiles (no GPU needed: pure host logic)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops
+    pt = ops.patch_tile
+    # SPADE gamma|beta convs of the released 1024x768 generator, batch 4: C = 64 -> 128 columns, C = 80 -> 192
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 128, 4, 1024, 768) == 17
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768) == 18
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 2112, 4, 8, 6) == 0          # the 8x6 head: too few tiles to fill the chip
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 2112, 4, 32, 24) == 18       # 33 column tiles x 32 pixel tiles
+    assert pt(True, 3, 3, 1, 1, 1, 0, 1024, 1024, 4, 64, 48) == 17
+    # not a 3x3 stride-1 'same' conv / fp32 engine / several sources / resampled source / C % 128 / padded columns
+    assert pt(True, 1, 1, 1, 0, 1, 0, 128, 128, 4, 1024, 768) == 0
+    assert pt(True, 3, 3, 2, 1, 1, 0, 128, 128, 4, 1024, 768) == 0
+    assert pt(False, 3, 3, 1, 1, 1, 0, 128, 128, 4, 1024, 768) == 0
+    assert pt(True, 3, 3, 1, 1, 2, 0, 128, 128, 4, 1024, 768) == 0
+    assert pt(True, 3, 3, 1, 1, 1, 1, 128, 128, 4, 1024, 768) == 0
+    assert pt(True, 3, 3, 1, 1, 1, 0, 80, 128, 4, 1024, 768) == 0
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 13, 4, 1024, 768) == 0
+    os.environ["HRV_CONV_PATCH"] = "0"
+    try:
+        assert pt(True, 3, 3, 1, 1, 1, 0, 128, 128, 4, 1024, 768) == 0
+    finally:
+        del os.environ["HRV_CONV_PATCH"]
