@@ -897,6 +897,71 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
       }
       return;
     }
+    // Dense outputs: the finished 32-pixel x 32-channel tile goes through a per-wave LDS scratch so that the global
+    // stores run along the channels (128-byte runs per pixel for fp32, 64 for bf16) instead of 16 / 8 bytes per lane
+    // at the pixel stride -- the stores of the wide memory-bound layers (conv_shared: 384 columns, K = 72) were 8-byte
+    // pieces 768 bytes apart.  Pad channels are never written (a slice may sit inside a wider tensor).
+    constexpr int SCR = 36;                                  // scratch row stride in floats (32 + 4: conflict-free)
+    const bool bf_out = BF && !p.out_f32;
+    const bool lds_store = !SPEC && !p.out_up && p.out_step != 2 && ((uintptr_t)p.out & 15) == 0 &&
+                           (!bf_out || ((p.Cout | p.out_cs | p.out_co) & 7) == 0);
+    if (lds_store) {
+      static_assert(sizeof(smem) >= (size_t)(NT / 64) * 32 * SCR * 4, "epilogue scratch must fit the operand stages");
+      __syncthreads();                                       // every wave is done reading the operand stages
+      float* scr = smem + wave * (32 * SCR);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int cj = n0 + (wn * TN + j) * 32;              // first channel of this 32-column tile
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int pidx = row2pix((wm * TM + i) * 32 + l31);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = cj + 8 * g + 4 * lh;
+            const bool c_ok = c0 < p.Cout;
+            const int cs = c_ok ? c0 : 0;
+            const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cs) : (f32x4)(1.f);
+            const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cs) : (f32x4)(0.f);
+            f32x4 v = (f32x4)(0.f);
+            if (c_ok && pidx < p.M) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * sc[e] + sh[e];
+              if (p.res) {
+                const f32x4 r4 = ld4rt<BF>(p.res, (size_t)pidx * p.res_cs + p.res_co + c0, p.res_f32);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = res_combine(v[e], r4[e], p.res_mode, p.slope);
+              }
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], p.act, p.slope);
+            }
+            *reinterpret_cast<f32x4*>(scr + l31 * SCR + 8 * g + 4 * lh) = v;
+          }
+          // same wave wrote and reads: LDS operations of a wave complete in order (the compiler waits lgkmcnt)
+          if (bf_out) {
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {                    // 32 pixels x 4 chunks of 8 channels
+              const int t = lane + 64 * k, px = t >> 2, kk = t & 3;
+              const int po = row2pix((wm * TM + i) * 32 + px);
+              const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + px * SCR + kk * 8);
+              const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + px * SCR + kk * 8 + 4);
+              if (po < p.M && cj + kk * 8 < p.Cout)
+                *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)po * p.out_cs + p.out_co + cj + kk * 8) =
+                    pack_bf16x8(lo, hi);
+            }
+          } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                    // 32 pixels x 8 chunks of 4 channels
+              const int t = lane + 64 * k, px = t >> 3, kk = t & 7;
+              const int po = row2pix((wm * TM + i) * 32 + px);
+              const f32x4 v = *reinterpret_cast<const f32x4*>(scr + px * SCR + kk * 4);
+              if (po < p.M && cj + kk * 4 < p.Cout)
+                *reinterpret_cast<f32x4*>(p.out + (size_t)po * p.out_cs + p.out_co + cj + kk * 4) = v;
+            }
+          }
+        }
+      }
+      return;
+    }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
 #pragma unroll

@@ -305,6 +305,10 @@ class ConvLayer:
                 # 128-byte K-tile rows: 128x128 tile +15-20 % (profiles/r01_conv_bench_bf16_rb.txt); the 128x64 tile
                 # additionally stages its operands by LDS-DMA (profiles/r01_conv_bench_bf16_glds.txt)
                 cfg = 8 if cfg == 0 else 9
+            if self.bf16 and self.KH == 1 and self.KW == 1 and sum(self.src_pad) <= 128 and self.Cout % 64 == 0:
+                # one or two K-tiles (conv_shared as a 1x1 over the 72 expanded taps): the block is all prologue and
+                # epilogue, so the small 128x64 tile with 64-byte rows wins on resident blocks (0.39 vs 0.48 ms)
+                cfg = 6
             pt = patch_tile(self.bf16, self.KH, self.KW, self.stride, self.pad, len(specs), up0, self.src_pad[0],
                             self.Cout, N, H, W)
             cfg = pt or cfg

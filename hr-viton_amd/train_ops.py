@@ -115,6 +115,8 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     mb = MMA_BF16[0]
     cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
     if mb:                 # bf16-stored source: the halo patch stays in LDS (ops.patch_tile)
+        if KH == 1 and KW == 1 and a0.bf16 and len(srcs) == 1 and a0.Cp <= 128 and Cout % 64 == 0:
+            cfg = 6        # one or two K-tiles: the small tile with 64-byte rows keeps more blocks resident
         cfg = ops.patch_tile(a0.bf16, KH, KW, stride, pad, len(srcs), up0, a0.Cp, Cout, N, H, W) or cfg
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)

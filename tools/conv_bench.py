@@ -29,6 +29,7 @@ BF_LAYERS = [
     ("blk conv 512->512 3x3 @128x96", [512], 512, 3, 1, 1, 1, 128, 96, False),
     ("blk conv 1024->1024 3x3 @64x48", [1024], 1024, 3, 1, 1, 1, 64, 48, False),
     ("blk conv 64->64 3x3 @1024x768", [64], 64, 3, 1, 1, 1, 1024, 768, False),
+    ("conv_shared x3 as 1x1 over taps 72->384 @1024x768", [72], 384, 1, 1, 0, 1, 1024, 768, False),
 ]
 
 
