@@ -1,24 +1,32 @@
 #!/usr/bin/env python3
 """bench.py -- the hot path's throughput on MI355X (driver contract).
 
-Workload (BASELINE.json configs[1]): ConditionGenerator inference, 1024x768,
-batch 4 per GPU, fp32, random-init ngf=96 weights (+ randomised BatchNorm
-statistics), synthetic VITON-HD-shaped inputs already resident in HBM.  A "step"
-is one forward pass of the hot path (flow pyramid + seg logits + grid_sample
-warps) over one batch.  N>1: one process per GPU (torch.distributed.run), each
-rank owns its own batch (independent images => no data-path collective, "weak"
-scaling); value = images all ranks processed / max-over-ranks time.
+Default workload = the HEADLINE, BASELINE.json configs[3] (SURVEY.md 8d "config #4"): one iteration of
+train_generator.py:279-360 at 1024x768, 4 images per GPU, mixed precision (bf16 matrix cores, fp32 accumulate):
+frozen tocg@256x192 + parse glue, SPADE generator forward/backward, multi-scale PatchGAN on [fake; real] twice,
+VGG19 + feature-matching + hinge losses, fused Adam on both networks; DP all-reduce of the gradients for N > 1.
+A "step" is that whole iteration over one synthetic batch already resident in HBM.  N>1: one process per GPU
+(torch.distributed.run, backend nccl = RCCL), weak scaling; value = images of all ranks / max-over-ranks time.
 
 Extra objects on the JSON line:
-  roofline     -- the dominant kernel family (implicit-GEMM fp32 MFMA conv):
-                  algorithmic conv FLOPs of one step / summed per-launch HIP-event
-                  durations of the conv launches of one step, vs 157.3 TFLOP/s.
-  cpu_baseline -- the oracle (CPU restatement of the reference) timed on this
-                  box's host cores on a bounded sample (1 image, 1 forward).
+  roofline     -- north-star definition: algorithmic FLOPs of the SPADE-generator 3x3 convolutions
+                  (forward, data gradient, weight gradient) / the summed HIP-event durations of exactly those launches,
+                  against the 2.5 PFLOP/s dense bf16 MFMA peak; `whole_step_conv_family` is the same ratio over every
+                  convolution launch of the iteration; `hbm_kinds` prices the HBM-bound launch kinds in GB/s against
+                  6.3 TB/s; `traffic` = HBM bytes per conv launch from the committed rocprofv3 PMC passes of this
+                  command (profiles/, tools/profile_traffic.sh) next to `algorithmic_bytes_per_launch`.
+  cpu_baseline -- the oracle's whole iteration (oracle/step_check.py) on this box's host cores at 256x192 'more'
+                  (BASELINE.md section 4), 1 warm-up + 3 timed, median.
+  parity       -- generator half of the iteration at 512x384 ngf=64 against torch autograd over the oracle: image,
+                  loss terms, every parameter gradient (fp32 engine), and the same with the bf16 engine.
+  extra        -- BASELINE configs[4] (tryon_infer bf16, 16 img/GPU) and configs[1] (tocg inference fp32, with the
+                  argmax index check) measured in the same run.
+Other workloads: --workload tocg_infer | tryon_infer | train_condition (same JSON shape).
 """
 import argparse
 import json
 import os
+import re
 import sys
 import time
 
@@ -26,26 +34,75 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
-H, W, BATCH, NGF = 1024, 768, 4, 96
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # dense bf16 (the 5 PF headline figure includes 2:1 sparsity)
+HBM_ACHIEVABLE_GBPS = 6300.0   # MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy (8.0 TB/s spec)
+H, W = 1024, 768
+
+# launches of the SPADE generator that are 3x3 convolutions (network_generator.py:98-99,117-121,141-143,184-186,201):
+# conv_shared / gamma|beta / conv_0 / conv_1 of every block, the stems conv_0..7 and conv_img; conv_s is 1x1
+_GEN = re.compile(r"^(head_0|G_middle_\d|up_\d|conv_\d+|conv_img)(\.|\[|$)")
 
 
-def make_inputs(torch, n, seed, device):
-    g = torch.Generator().manual_seed(seed)
-    input1 = torch.cat([torch.rand(n, 3, H, W, generator=g) * 2 - 1,
-                        (torch.rand(n, 1, H, W, generator=g) > 0.5).float()], 1)
-    lab = torch.randint(0, 13, (n, 1, H, W), generator=g)
-    input2 = torch.cat([torch.zeros(n, 13, H, W).scatter_(1, lab, 1.0),
-                        torch.rand(n, 3, H, W, generator=g) * 2 - 1], 1)
-    return input1.to(device), input2.to(device)
+def is_spade_gen_3x3(kind, name):
+    return kind in ("conv", "wgrad") and _GEN.match(name) is not None and ".conv_s" not in name
 
 
-def build_model(torch, nn, mixed=False):
+def summarize(recs, peak_tflops):
+    """recs: [(kind, name, flops, bytes, ms)] of ONE step -> roofline pieces."""
+    kinds = {}
+    for k, n, fl, by, ms in recs:
+        a = kinds.setdefault(k, [0, 0.0, 0.0, 0.0])
+        a[0] += 1
+        a[1] += ms
+        a[2] += fl
+        a[3] += by
+    mm = [r for r in recs if r[0] in ("conv", "wgrad")]
+    sp = [r for r in mm if is_spade_gen_3x3(r[0], r[1])]
+
+    def agg(rows):
+        ms = sum(r[4] for r in rows)
+        fl = sum(r[2] for r in rows)
+        ach = fl / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        return {"launches": len(rows), "ms_per_step": round(ms, 3), "flops_per_step": fl, "achieved": round(ach, 2),
+                "frac": round(ach / peak_tflops, 4)}
+    hbm = {}
+    for k, (n, ms, fl, by) in sorted(kinds.items()):
+        if k in ("conv", "wgrad") or by <= 0 or ms <= 0:
+            continue
+        gbps = by / (ms * 1e-3) / 1e9
+        hbm[k] = {"launches": n, "ms": round(ms, 3), "GBps": round(gbps, 1), "frac_of_6.3TBps": round(gbps / HBM_ACHIEVABLE_GBPS, 3)}
+    conv_bytes = sum(r[3] for r in mm)
+    return {"kinds": kinds, "spade": agg(sp), "all": agg(mm), "hbm": hbm,
+            "conv_alg_bytes_per_launch": conv_bytes / max(1, len(mm)), "conv_launches": len(mm),
+            "top": sorted(mm, key=lambda r: -r[4])[:6]}
+
+
+def dump_launches(path, recs):
+    with open(path, "w") as f:
+        for k, n, fl, by, ms in recs:
+            f.write(f"{k:8s} {n:52s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s  "
+                    f"{by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s\n")
+
+
+def load_traffic(tag):
+    """HBM bytes per conv launch from the committed PMC passes of this command (cannot be read in-process)."""
+    for rnd in ("r02", "r01"):
+        tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{tag}.json")
+        if os.path.exists(tp):
+            with open(tp) as f:
+                tj = json.load(f)
+            return tj.get("hbm_bytes_per_launch"), f"profiles/{os.path.basename(tp)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+    return None, None
+
+
+# ------------------------------------------------------------------------------------------------- workloads
+def build_tocg(torch, nn, mixed=False, ngf=96):
     from argparse import Namespace
     from hr_viton_amd.networks import ConditionGenerator
     opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu", fp16=mixed)
     torch.manual_seed(0)
-    m = ConditionGenerator(opt, 4, 16, 13, ngf=NGF, norm_layer=nn.BatchNorm2d)
+    m = ConditionGenerator(opt, 4, 16, 13, ngf=ngf, norm_layer=nn.BatchNorm2d)
     g = torch.Generator().manual_seed(5)
     with torch.no_grad():
         for mod in m.modules():
@@ -60,49 +117,63 @@ def build_model(torch, nn, mixed=False):
     return opt, m
 
 
-def _emit(args, torch, hdist, ops, rank, world, B, step, metric, workload, flops_per_img, train):
-    mixed = bool(getattr(args, "bf16", False))
-    peak = 2500.0 if mixed else PEAK_F32_MFMA_TFLOPS
-    dt = hdist.timed_steps(getattr(args, "_timed", None) or step, args.steps, args.warmup, torch.cuda.synchronize)
-    ops.profile_begin()
-    step(0)
-    recs = ops.profile_end()
-    kinds = {}
-    for k, n, fl, by, ms in recs:
-        a = kinds.setdefault(k, [0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += ms
-        a[2] += fl
-    if args.dump_launches and rank == 0:
-        with open(args.dump_launches, "w") as f:
-            for k, n, fl, by, ms in recs:
-                f.write(f"{k:8s} {n:52s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s\n")
-    mf_ms = sum(v[1] for k, v in kinds.items() if k in ("conv", "wgrad"))
-    mf_fl = sum(v[2] for k, v in kinds.items() if k in ("conv", "wgrad"))
-    if rank == 0:
-        ach = mf_fl / (mf_ms * 1e-3) / 1e12 if mf_ms > 0 else 0.0
-        line = {"metric": metric, "value": round(B * world * args.steps / dt, 3), "unit": "images/s", "n_gpus": world,
-                "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 2),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                "dtype": "bf16 MFMA operands, f32 storage/accumulate" if mixed else "f32", "data": "synthetic",
-                "config": {"workload": workload + (" [hipGraph replay]" if getattr(args, "_timed", None) else ""),
-                           "global_batch": B * world,
-                           "parallelism": f"dp{world}" + ("-allreduce" if train else "-replicas")},
-                "roofline": {"bound": "mfma", "kernel": "hrv::conv_f32_mfma_kernel + hrv::conv_wgrad_mfma_kernel",
-                             "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
-                             "frac": round(ach / peak, 4), "traffic": None,
-                             "end_to_end_TFLOPs_vs_survey_work": round(B * flops_per_img / (dt / args.steps) / 1e12, 2)},
-                "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(kinds.items())},
-                "cpu_baseline": None}
-        print(json.dumps(line), flush=True)
-    import torch.distributed as tdist
-    if tdist.is_available() and tdist.is_initialized():
-        tdist.barrier()
-        tdist.destroy_process_group()
+def tocg_inputs(torch, n, seed, device):
+    g = torch.Generator().manual_seed(seed)
+    input1 = torch.cat([torch.rand(n, 3, H, W, generator=g) * 2 - 1,
+                        (torch.rand(n, 1, H, W, generator=g) > 0.5).float()], 1)
+    lab = torch.randint(0, 13, (n, 1, H, W), generator=g)
+    input2 = torch.cat([torch.zeros(n, 13, H, W).scatter_(1, lab, 1.0),
+                        torch.rand(n, 3, H, W, generator=g) * 2 - 1], 1)
+    return input1.to(device), input2.to(device)
 
 
-def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
+def wl_tocg_infer(ctx, mixed, B):
+    """BASELINE configs[1]: ConditionGenerator inference 1024x768 b=4 fp32 (flow + seg + grid_sample)."""
+    torch, nn = ctx["torch"], ctx["nn"]
+    B = B or 4
+    opt, model = build_tocg(torch, nn, mixed)
+    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    model.to(ctx["dev"])
+    i1, i2 = tocg_inputs(torch, B, ctx["hdist"].shard_seed(1234, ctx["rank"]), ctx["dev"])
+
+    def step(_i):
+        model(opt, i1, i2)
+
+    def parity():
+        """configs[1] outputs vs the oracle at 1024x768 (1 image): max-rel errors and the argmax label map -- every
+        mismatching pixel's top-2 logit margin is reported in ulps of the logit."""
+        from oracle import hrviton_oracle as O
+        c1, c2 = i1[:1].cpu(), i2[:1].cpu()
+        torch.set_num_threads(ctx["cpu_threads"])
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            want = O.tocg_forward(sd_cpu, c1, c2)
+        cdt = time.perf_counter() - t0
+        got = model(opt, i1[:1], i2[:1])
+
+        def rel(a, b):
+            return float(((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12)).item())
+        seg_g, seg_w = got[1].cpu(), want[1]
+        lab_g, lab_w = seg_g.argmax(1), seg_w.argmax(1)
+        bad = (lab_g != lab_w)
+        top2 = seg_w.topk(2, dim=1).values
+        margin = (top2[:, 0] - top2[:, 1])[bad]
+        ulp = torch.abs(top2[:, 0][bad]).clamp_min(1e-30)
+        ulps = (margin / (ulp * 2.0 ** -23)).tolist()
+        return {"oracle_forward_s": round(cdt, 2), "flow_last_max_rel_err": rel(got[0][-1], want[0][-1]),
+                "seg_max_rel_err": rel(seg_g, seg_w), "warped_cloth_max_rel_err": rel(got[2], want[2]),
+                "argmax_mismatch_pixels": int(bad.sum().item()), "pixels": int(lab_w.numel()),
+                "mismatch_top2_margin_ulps_of_logit": [round(u, 1) for u in ulps[:16]],
+                "mismatch_top2_margin_max_abs": float(margin.max().item()) if margin.numel() else 0.0}
+    return dict(step=step, B=B, train=False, parity=parity, flops_per_img=1.468e12,
+                metric="1024x768 try-on images/sec (ConditionGenerator inference: flow+seg+grid_sample)",
+                workload="BASELINE configs[1]: ConditionGenerator inference 1024x768 fp32, ngf=96, random-init weights",
+                traffic_tag="tocg_infer")
+
+
+def wl_train_condition(ctx, mixed, B):
     """BASELINE configs[2]: train_condition.py 1024x768 b=8 fp32 --Ddownx2 --lasttvonly --interflowloss."""
+    torch, nn, dev, world, rank = ctx["torch"], ctx["nn"], ctx["dev"], ctx["world"], ctx["rank"]
     import train_condition as tc
     from hr_viton_amd.gen_train import attach_grad_sync
     from hr_viton_amd.losses import L1Loss
@@ -110,12 +181,11 @@ def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.optim import Adam
     from hr_viton_amd.parallel import broadcast_module
     from hr_viton_amd.pipeline import condition_train_step
-    B = args.batch or 8
+    B = B or 8
     opt = tc.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world), "--fine_height", "1024", "--fine_width",
-                      "768", "--Ddownx2", "--lasttvonly", "--interflowloss"] + (["--fp16"] if args.bf16 else []))
-    if args.bf16:
-        from hr_viton_amd import train_ops as _T
-        _T.MMA_BF16[0] = True
+                      "768", "--Ddownx2", "--lasttvonly", "--interflowloss"] + (["--fp16"] if mixed else []))
+    from hr_viton_amd import train_ops as _T
+    _T.MMA_BF16[0] = bool(mixed)
     torch.manual_seed(0)
     tocg = ConditionGenerator(opt, 4, 16, 13, ngf=96, norm_layer=nn.BatchNorm2d).to(dev).train()
     D = define_D(input_nc=4 + 16 + 13, Ddownx2=True, Ddropout=False, n_layers_D=3, spectral=False, num_D=2).to(dev).train()
@@ -130,19 +200,19 @@ def cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
         if s_ is not None:
             attach_grad_sync(s_)
     l1, gan = L1Loss(), GANLoss(use_lsgan=True)
-    batch = tc.synthetic_batch(opt, B, hdist.shard_seed(4321, rank), dev)
+    batch = tc.synthetic_batch(opt, B, ctx["hdist"].shard_seed(4321, rank), dev)
 
     def step(_i):
         condition_train_step(opt, tocg, D, l1, crit_vgg, gan, og, od, batch, sg, sd)
-    _emit(args, torch, hdist, ops, rank, world, B, step,
-          "1024x768 images/sec (train_condition.py step: tocg fwd/bwd with batch-stat BN, 5 VGG pairs, LSGAN D, Adam)",
-          "BASELINE configs[2]: train_condition.py 1024x768 fp32 --Ddownx2 --lasttvonly --interflowloss, ngf=96, "
-          "random-init weights", 13e12, True)
+    return dict(step=step, B=B, train=True, parity=None, flops_per_img=13.2e12,
+                metric="1024x768 images/sec (train_condition.py step: tocg fwd/bwd with batch-stat BN, 5 VGG pairs, LSGAN D, Adam)",
+                workload="BASELINE configs[2]: train_condition.py 1024x768 --Ddownx2 --lasttvonly --interflowloss, ngf=96, "
+                         "random-init weights", traffic_tag="train_condition")
 
 
-def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
-    """Secondary workloads (not the driver's default bench): same timing contract, same JSON shape."""
-    from argparse import Namespace
+def wl_generator(ctx, mixed, B, train):
+    """train=True: BASELINE configs[3] (headline); False: configs[4] (end-to-end test_generator.py step)."""
+    torch, nn, dev, world, rank = ctx["torch"], ctx["nn"], ctx["dev"], ctx["world"], ctx["rank"]
     import train_generator as tg
     from hr_viton_amd.gen_train import attach_grad_sync
     from hr_viton_amd.losses import GANLoss, L1Loss
@@ -152,21 +222,16 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
     from hr_viton_amd.parallel import broadcast_module
     from hr_viton_amd.pipeline import generator_train_step, make_generator_inputs, tryon_step
     from hr_viton_amd.vgg import VGGLoss
-    if args.workload == "train_condition":
-        return cond_workload(args, torch, nn, hdist, ops, rank, local_rank, world, dev)
-    train = args.workload == "train_generator"
-    B = args.batch or 4
-    opt = tg.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world)] + (["--fp16"] if args.bf16 else []))
+    from hr_viton_amd import train_ops as _T
+    B = B or (4 if train else 16)
+    opt = tg.get_opt(["--name", "bench", "--synthetic", "-b", str(B * world)] + (["--fp16"] if mixed else []))
     torch.manual_seed(0)
     tocg = ConditionGenerator(opt, 4, 16, 13, ngf=96, norm_layer=nn.BatchNorm2d).to(dev).eval()
     gen = SPADEGenerator(opt, 9)
     gen.init_weights("xavier", 0.02)
     gen.to(dev)
-    batch = tg.synthetic_batch(opt, B, hdist.shard_seed(1234, rank), dev)
+    batch = tg.synthetic_batch(opt, B, ctx["hdist"].shard_seed(1234, rank), dev)
     if train:
-        if args.bf16:
-            from hr_viton_amd import train_ops as _T
-            _T.MMA_BF16[0] = True      # mixed precision: bf16 matrix cores over fp32 tensors
         dis = MultiscaleDiscriminator(opt)
         dis.init_weights("xavier", 0.02)
         dis.to(dev).train()
@@ -184,26 +249,100 @@ def other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev):
         cg, cf = GANLoss("hinge"), L1Loss()
 
         def step(_i):
+            _T.MMA_BF16[0] = bool(mixed)     # (another workload of this process may have switched it)
             x, parse7 = make_generator_inputs(opt, tocg, batch)
             generator_train_step(opt, gen, dis, cg, cf, crit_vgg, og, od, x, parse7, batch["image"], sg, sd)
-        metric = "1024x768 try-on images/sec (train_generator.py step: tocg+glue, G fwd/bwd, D fwd/bwd x2, VGG, Adam)"
-        flops_per_img = 8.8e12
-    else:
-        gen.eval()
 
-        def step(_i):
-            tryon_step(opt, tocg, gen, batch)
-        if args.graph:
-            from hr_viton_amd.graph import graphed_tryon
-            args._timed = (lambda g: (lambda _i: g(batch)))(graphed_tryon(opt, tocg, gen, batch))
-        metric = "1024x768 try-on images/sec (test_generator.py step: tocg@256x192 + glue + SPADE generator)"
-        flops_per_img = 1.73e12
-    if train:
-        _emit(args, torch, hdist, ops, rank, world, B, step, metric, "train_generator 1024x768 ngf=64, random-init weights",
-              flops_per_img, True)
-    else:
-        _emit(args, torch, hdist, ops, rank, world, B, step, metric, "tryon_infer 1024x768 ngf=64, random-init weights"
-              + (" (bf16 storage in the generator; tocg + glue f32)" if args.bf16 else ""), flops_per_img, False)
+        def parity():
+            from oracle import step_check
+            gp = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(gp, exist_ok=True)
+            f32 = step_check.compare_generator_step(512, 384, 64, 64, 1, mixed=False, cpu_threads=ctx["cpu_threads"],
+                                                    table_path=os.path.join(gp, "bench_grad_parity_gen_f32.txt"))
+            out = {"fp32_engine_vs_oracle": f32,
+                   "tolerance_fp32": "image / losses 1e-3 rel (north star); per-parameter gradients 1e-2 of max(|g|, 1e-3 module max)"}
+            if mixed:
+                out["bf16_engine_vs_oracle"] = step_check.compare_generator_step(
+                    512, 384, 64, 64, 1, mixed=True, cpu_threads=ctx["cpu_threads"],
+                    table_path=os.path.join(gp, "bench_grad_parity_gen_bf16.txt"))
+                out["tolerance_bf16"] = ("operands carry 8 mantissa bits: image mean-abs 2e-2, loss terms 2e-2 rel, gradient "
+                                         "cosine >= 0.93 on every sizeable parameter")
+            return out
+
+        def cpu_baseline():
+            from oracle import step_check
+            r = step_check.cpu_train_generator_step(256, 192, 64, 64, 1, "more", repeats=3, warmup=1, threads=ctx["cpu_threads"])
+            return {"value": round(r["images_per_s"], 4), "unit": "images/s", "cores": ctx["cpu_threads"], "kind": "port",
+                    "sample": "oracle/step_check.cpu_train_generator_step: the whole train_generator.py iteration (G fwd/bwd, "
+                              "PatchGAN x2, VGG + feat + hinge, Adam x2) on torch-CPU fp32, 1 image 256x192 'more' ngf=64 "
+                              "(BASELINE.md section 4), 1 warm-up + 3 timed, median",
+                    "seconds_per_step": round(r["seconds_per_step_median"], 3),
+                    "scaled_to_1024x768_images_per_s": round(r["images_per_s"] / 16.0, 5),
+                    "scaling_note": "x1/16 by pixel count (conv work is linear in pixels; 'most' adds up_4 on top, so this "
+                                    "over-states the CPU)"}
+        return dict(step=step, B=B, train=True, parity=parity, cpu_baseline=cpu_baseline, flops_per_img=8.8e12,
+                    metric="1024x768 try-on images/sec (train_generator.py step: tocg+glue, G fwd/bwd, D fwd/bwd x2, VGG, Adam)",
+                    workload="BASELINE configs[3] (SURVEY 8d config #4, headline): train_generator.py 1024x768, "
+                             f"{B} img/GPU, " + ("--fp16 (bf16 MFMA operands, fp32 accumulate)" if mixed else "fp32") +
+                             ", SPADE ngf=64 'most' + multiscale-D + VGG/feat-match, random-init weights",
+                    traffic_tag="train_generator")
+    gen.eval()
+
+    def step(_i):
+        tryon_step(opt, tocg, gen, batch)
+    timed = None
+    if ctx["args"].graph:
+        from hr_viton_amd.graph import graphed_tryon
+        timed = (lambda g: (lambda _i: g(batch)))(graphed_tryon(opt, tocg, gen, batch))
+    return dict(step=step, timed=timed, B=B, train=False, parity=None, flops_per_img=1.73e12,
+                metric="1024x768 try-on images/sec (test_generator.py step: tocg@256x192 + glue + SPADE generator)",
+                workload=f"BASELINE configs[4]: end-to-end test_generator.py step 1024x768, {B} img/GPU, ngf=64, random-init "
+                         "weights" + (" (bf16 storage in the generator; tocg + glue f32)" if mixed else " fp32") +
+                         (" [hipGraph replay]" if timed else ""), traffic_tag="tryon_infer")
+
+
+def make_workload(ctx, name, mixed, B):
+    if name == "tocg_infer":
+        return wl_tocg_infer(ctx, mixed, B)
+    if name == "train_condition":
+        return wl_train_condition(ctx, mixed, B)
+    return wl_generator(ctx, mixed, B, train=(name == "train_generator"))
+
+
+def measure(ctx, wl, steps, warmup, mixed, dump=None):
+    """Timed region (driver contract) + one extra profiled step with per-launch HIP events."""
+    torch, hdist, ops = ctx["torch"], ctx["hdist"], ctx["ops"]
+    dt = hdist.timed_steps(wl.get("timed") or wl["step"], steps, warmup, torch.cuda.synchronize)
+    ops.profile_begin()
+    wl["step"](0)
+    recs = ops.profile_end()
+    if dump and ctx["rank"] == 0:
+        dump_launches(dump, recs)
+    peak = PEAK_BF16_MFMA_TFLOPS if mixed else PEAK_F32_MFMA_TFLOPS
+    s = summarize(recs, peak)
+    B, world = wl["B"], ctx["world"]
+    res = {"value": round(B * world * steps / dt, 3), "ms_per_step": round(dt / steps * 1e3, 3), "peak": peak,
+           "summary": s, "dt": dt}
+    return res
+
+
+def roofline_obj(wl, res, north_star):
+    s = res["summary"]
+    head = s["spade"] if north_star else s["all"]
+    traffic, src = load_traffic(wl["traffic_tag"])
+    return {"bound": "mfma",
+            "kernel": ("hrv::conv_mfma_kernel / conv_wgrad_* over the SPADE-generator 3x3 convolutions (fwd+dgrad+wgrad)"
+                       if north_star else "hrv::conv_mfma_kernel / conv_wgrad_* (every convolution launch of the step)"),
+            "achieved": head["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": head["frac"],
+            "launches_per_step": head["launches"], "ms_per_step": head["ms_per_step"],
+            "algorithmic_flops_per_launch": head["flops_per_step"] / max(1, head["launches"]),
+            "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (average over the step's conv launches)",
+            "traffic_source": src, "algorithmic_bytes_per_launch": round(s["conv_alg_bytes_per_launch"], 1),
+            "whole_step_conv_family": s["all"],
+            "end_to_end_TFLOPs_vs_survey_work": round(wl["B"] * wl["flops_per_img"] / (res["dt"] / res["steps"]) / 1e12, 2),
+            "hbm_kinds": s["hbm"],
+            "slowest_launches": [{"name": r[1], "ms": round(r[4], 3), "TFLOPs": round(r[2] / (r[4] * 1e-3) / 1e12, 1)}
+                                 for r in s["top"]]}
 
 
 def main():
@@ -211,18 +350,20 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU baseline (0 = min(cores, 32))")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the CPU legs (cpu_baseline, parity)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the configs[4] / configs[1] sub-measurements")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU legs (0 = min(cores, 32))")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch table of one step to this file")
-    ap.add_argument("--workload", default="tocg_infer", choices=["tocg_infer", "train_generator", "tryon_infer", "train_condition"],
-                    help="tocg_infer = BASELINE configs[1] (default, the driver's bench); train_generator = configs[3] "
-                         "shape in fp32 (4 img/GPU, G+D step incl. VGG, DP all-reduce); tryon_infer = end-to-end "
-                         "test_generator.py step (configs[4] shape, fp32)")
-    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch for the non-default workloads")
-    ap.add_argument("--bf16", action="store_true", help="tryon_infer: run the SPADE generator on the bf16 engine")
-    ap.add_argument("--graph", action="store_true", help="inference workloads: replay the step as one captured hipGraph "
-                                                         "(hr_viton_amd.graph); the per-launch roofline leg stays eager")
+    ap.add_argument("--workload", default="train_generator",
+                    choices=["train_generator", "tryon_infer", "tocg_infer", "train_condition"],
+                    help="train_generator = BASELINE configs[3], the headline (default); tryon_infer = configs[4]; "
+                         "tocg_infer = configs[1]; train_condition = configs[2]")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0: the config's own)")
+    ap.add_argument("--bf16", action="store_true", help="bf16 matrix cores (default for train_generator / tryon_infer)")
+    ap.add_argument("--fp32", action="store_true", help="fp32 engine (default for tocg_infer / train_condition)")
+    ap.add_argument("--graph", action="store_true", help="tryon_infer: replay the step as one captured hipGraph")
     args = ap.parse_args()
+    mixed = (args.workload in ("train_generator", "tryon_infer") or args.bf16) and not args.fp32
 
     import torch
     import torch.nn as nn
@@ -236,105 +377,62 @@ def main():
     local_dev = local_rank % ndev        # == local_rank on a real node; lets a 1-GPU box smoke-test the N>1 logic
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    if args.workload != "tocg_infer":
-        return other_workloads(args, torch, nn, hdist, ops, rank, local_rank, world, dev)
-
-    opt, model = build_model(torch, nn, mixed=args.bf16)   # --bf16: bf16 MFMA operands over fp32 tensors (not the default)
-    sd_cpu = {k: v.detach().clone() for k, v in model.state_dict().items()}
-    model.to(dev)
-    i1, i2 = make_inputs(torch, BATCH, hdist.shard_seed(1234, rank), dev)
-    torch.cuda.synchronize()
-
-    def step(_i):
-        model(opt, i1, i2)
-
-    timed = step
-    if args.graph:
-        from hr_viton_amd.graph import graphed_condition
-        g = graphed_condition(opt, model, i1, i2)
-        feed = {"input1": i1, "input2": i2}
-
-        def timed(_i):
-            g(feed)
-    dt = hdist.timed_steps(timed, args.steps, args.warmup, torch.cuda.synchronize)
-    images = BATCH * world * args.steps
-    value = images / dt
-
-    # ---- roofline leg: per-launch HIP events (torch's current stream IS the launch stream)
-    ops.profile_begin()
-    step(0)
-    recs = ops.profile_end()
-    if args.dump_launches and rank == 0:
-        with open(args.dump_launches, "w") as f:
-            for k, n, fl, by, ms in recs:
-                f.write(f"{k:8s} {n:44s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s  "
-                        f"{by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s\n")
-    conv = [r for r in recs if r[0] == "conv"]
-    conv_flops = sum(r[2] for r in conv)
-    conv_ms = sum(r[4] for r in conv)
-    other_ms = sum(r[4] for r in recs if r[0] != "conv")
-    other_bytes = sum(r[3] for r in recs if r[0] != "conv")
-    achieved = conv_flops / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    top = sorted(conv, key=lambda r: -r[4])[:5]
-    # HBM traffic cannot be read from inside the process: it comes from the committed rocprofv3 PMC
-    # passes of this same command (profiles/, see tools/profile_pmc.sh), per conv launch.
-    traffic, traffic_src = None, None
-    tp = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tp):
-        with open(tp) as f:
-            tj = json.load(f)
-        traffic, traffic_src = tj.get("hbm_bytes_per_launch"), "profiles/r01_pmc_traffic.json (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE)"
-    peak = 2500.0 if args.bf16 else PEAK_F32_MFMA_TFLOPS
-    if args.bf16:
-        traffic, traffic_src = None, None      # the committed PMC passes are of the fp32 default
-    roofline = {"bound": "mfma", "kernel": "hrv::conv_mfma_kernel (all tile configs)",
-                "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                "frac": round(achieved / peak, 4), "traffic": traffic,
-                "traffic_unit": "HBM bytes per conv launch (average over the step's launches)", "traffic_source": traffic_src,
-                "algorithmic_flops_per_launch": conv_flops / max(1, len(conv)),
-                "launches_per_step": len(conv), "flops_per_step": conv_flops,
-                "conv_ms_per_step": round(conv_ms, 3),
-                "hbm_kernels_ms_per_step": round(other_ms, 3),
-                "hbm_kernels_GBps": round(other_bytes / (other_ms * 1e-3) / 1e9, 1) if other_ms > 0 else None,
-                "slowest_launches": [{"name": r[1], "ms": round(r[4], 3),
-                                      "TFLOPs": round(r[2] / (r[4] * 1e-3) / 1e12, 1)} for r in top]}
-
-    cpu_baseline = None
-    parity = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import hrviton_oracle as O
-        c1, c2 = i1[:1].cpu(), i2[:1].cpu()
-        # all 256 host threads of the GPU box are slower than 32 on this shape (oversubscribed oneDNN)
-        torch.set_num_threads(args.cpu_threads or min(os.cpu_count() or 1, 32))
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            want = O.tocg_forward(sd_cpu, c1, c2)
-        cdt = time.perf_counter() - t0
-        cpu_baseline = {"value": round(1.0 / cdt, 4), "unit": "images/s", "cores": torch.get_num_threads(),
-                        "kind": "port", "sample": "1 image 1024x768, one forward of oracle.tocg_forward "
-                        "(torch CPU fp32 restatement of networks.py:98-159), no warm-up"}
-        got = model(opt, i1[:1], i2[:1])
-
-        def rel(a, b):
-            return float(((a.cpu() - b).abs().max() / b.abs().max().clamp_min(1e-12)).item())
-
-        lab_g, lab_w = got[1].cpu().argmax(1), want[1].argmax(1)
-        parity = {"flow_last_max_rel_err": rel(got[0][-1], want[0][-1]), "seg_max_rel_err": rel(got[1], want[1]),
-                  "warped_cloth_max_rel_err": rel(got[2], want[2]),
-                  "argmax_mismatch_pixels": int((lab_g != lab_w).sum().item()), "pixels": int(lab_w.numel())}
-
-    if rank == 0:
-        line = {"metric": "1024x768 try-on images/sec (ConditionGenerator inference: flow+seg+grid_sample)",
-                "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps,
-                "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                "scaling": "weak", "vs_baseline": None, "dtype": "bf16 MFMA operands, f32 storage/accumulate" if args.bf16 else "f32", "data": "synthetic",
-                "config": {"workload": "BASELINE configs[1]: ConditionGenerator inference 1024x768 batch=4/GPU "
-                                       "fp32, ngf=96, random-init weights" + (" [hipGraph replay]" if args.graph else ""),
-                           "global_batch": BATCH * world, "height": H, "width": W, "parallelism": f"dp{world}-replicas"},
-                "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity}
-        print(json.dumps(line), flush=True)
-
     import torch.distributed as tdist
+    ctx = dict(torch=torch, nn=nn, hdist=hdist, ops=ops, rank=rank, world=world, dev=dev, args=args,
+               cpu_threads=args.cpu_threads or min(os.cpu_count() or 1, 32))
+
+    wl = make_workload(ctx, args.workload, mixed, args.batch)
+    res = measure(ctx, wl, args.steps, args.warmup, mixed, args.dump_launches)
+    res["steps"] = args.steps
+    s = res["summary"]
+    line = None
+    if rank == 0:
+        line = {"metric": wl["metric"], "value": res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None,
+                "dtype": "bf16 MFMA operands (matrix-core-only tensors stored bf16), f32 accumulate / norms / optimizer" if mixed else "f32",
+                "data": "synthetic",
+                "config": {"workload": wl["workload"], "global_batch": wl["B"] * world, "height": H, "width": W,
+                           "parallelism": f"dp{world}" + ("-allreduce" if wl["train"] else "-replicas"),
+                           "dist_backend": tdist.get_backend() if tdist.is_initialized() else "none (single process)",
+                           "rccl_ranks": tdist.get_world_size() if tdist.is_initialized() else 1},
+                "roofline": roofline_obj(wl, res, north_star=(args.workload in ("train_generator", "tryon_infer"))),
+                "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(s["kinds"].items())},
+                "cpu_baseline": None, "parity": None}
+    cpu_legs = rank == 0 and world == 1 and not args.no_cpu_baseline
+    if cpu_legs:
+        torch.set_num_threads(ctx["cpu_threads"])
+        if wl.get("cpu_baseline"):
+            line["cpu_baseline"] = wl["cpu_baseline"]()
+        if wl.get("parity"):
+            line["parity"] = wl["parity"]()
+    if rank == 0 and world == 1 and not args.no_extras and args.workload == "train_generator":
+        # the other two measured configurations of BASELINE.json, same process, after the headline's timed region
+        extra = {}
+        del wl
+        torch.cuda.empty_cache()
+        for key, name, mx, st in (("config5_tryon_infer_bf16_b16", "tryon_infer", True, 5),
+                                  ("config2_tocg_infer_f32_b4", "tocg_infer", False, 10)):
+            from hr_viton_amd import train_ops as _T
+            _T.MMA_BF16[0] = False
+            w2 = make_workload(ctx, name, mx, 0)
+            r2 = measure(ctx, w2, st, 2, mx)
+            r2["steps"] = st
+            e = {"metric": w2["metric"], "value": r2["value"], "unit": "images/s", "ms_per_step": r2["ms_per_step"],
+                 "steps": st, "warmup": 2, "workload": w2["workload"], "batch": w2["B"],
+                 "roofline": roofline_obj(w2, r2, north_star=(name == "tryon_infer"))}
+            if cpu_legs and w2.get("parity"):
+                e["parity"] = w2["parity"]()
+            extra[key] = e
+            del w2
+            torch.cuda.empty_cache()
+        line["extra"] = extra
+    elif cpu_legs and args.workload == "tocg_infer" and line["parity"] is not None:
+        p = line["parity"]
+        line["cpu_baseline"] = {"value": round(1.0 / p["oracle_forward_s"], 4), "unit": "images/s", "cores": ctx["cpu_threads"],
+                                "kind": "port", "sample": "1 image 1024x768, one forward of oracle.tocg_forward"}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if tdist.is_available() and tdist.is_initialized():
         tdist.barrier()
         tdist.destroy_process_group()

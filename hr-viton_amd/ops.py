@@ -70,6 +70,13 @@ def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
 
+def act_bytes(a, C: Optional[int] = None) -> float:
+    """Algorithmic HBM bytes of one pass over the logical channels of an NHWC view (padding not counted)."""
+    if a is None:
+        return 0.0
+    return float(a.N * a.H * a.W * (a.C if C is None else C) * (2 if a.bf16 else 4))
+
+
 def require_cuda(t: torch.Tensor, what: str):
     if not t.is_cuda:
         raise HrvError(f"{what}: tensor is on {t.device}; the MI355X path has no CPU fallback "
@@ -124,12 +131,13 @@ def to_nhwc(x: torch.Tensor, out: Optional[Act] = None, bf16: bool = False) -> A
     if out is None:
         out = alloc(N, H, W, Cc, x.device, bf16)
     lib = _lib.load()
-    if out.bf16:
-        _lib.check(lib.hrv_nchw_f32_to_nhwc_bf16(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
-                                                 _stream()), "hrv_nchw_f32_to_nhwc_bf16")
-    else:
-        _lib.check(lib.hrv_nchw_to_nhwc_f32(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
-                                            _stream()), "hrv_nchw_to_nhwc_f32")
+    with _Timed("layout", "nchw_to_nhwc", 0.0, 4.0 * x.numel() + act_bytes(out, Cc)):
+        if out.bf16:
+            _lib.check(lib.hrv_nchw_f32_to_nhwc_bf16(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
+                                                     _stream()), "hrv_nchw_f32_to_nhwc_bf16")
+        else:
+            _lib.check(lib.hrv_nchw_to_nhwc_f32(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
+                                                _stream()), "hrv_nchw_to_nhwc_f32")
     return out
 
 
@@ -138,12 +146,13 @@ def to_nchw(a: Act, c0: int = 0, c: Optional[int] = None) -> torch.Tensor:
     c = a.C - c0 if c is None else c
     out = torch.empty((a.N, c, a.H, a.W), dtype=torch.float32, device=a.t.device)
     lib = _lib.load()
-    if a.bf16:
-        _lib.check(lib.hrv_nhwc_bf16_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W,
-                                                 out.data_ptr(), _stream()), "hrv_nhwc_bf16_to_nchw_f32")
-    else:
-        _lib.check(lib.hrv_nhwc_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W, out.data_ptr(),
-                                            _stream()), "hrv_nhwc_to_nchw_f32")
+    with _Timed("layout", "nhwc_to_nchw", 0.0, 4.0 * out.numel() + act_bytes(a, c)):
+        if a.bf16:
+            _lib.check(lib.hrv_nhwc_bf16_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W,
+                                                     out.data_ptr(), _stream()), "hrv_nhwc_bf16_to_nchw_f32")
+        else:
+            _lib.check(lib.hrv_nhwc_to_nchw_f32(a.t.data_ptr(), a.cstride, a.coff + c0, a.N, c, a.H, a.W, out.data_ptr(),
+                                                _stream()), "hrv_nhwc_to_nchw_f32")
     return out
 
 
@@ -343,7 +352,13 @@ class ConvLayer:
         engine_bf16 = self.bf16 or self.mixed
         fn = lib.hrv_conv2d_naive_nhwc_f32 if naive else (lib.hrv_conv2d_nhwc_bf16 if engine_bf16 else lib.hrv_conv2d_nhwc_f32)
         assert not (naive and engine_bf16), "the naive cross-check is fp32"
-        with _Timed("conv", self.name, self.flops(N, Ho, Wo), 0):
+        # algorithmic bytes: every source once, the output once (x4 for the fused 2x upsample store), the residual /
+        # SPADE x once, the weights once
+        nbytes = (sum(act_bytes(a) for a, _, _ in specs) + act_bytes(out) + act_bytes(residual) +
+                  self.Cout * sum(self.src_real) * self.KH * self.KW * (2 if engine_bf16 else 4))
+        if spade is not None:
+            nbytes += N * Ho * Wo * oc * (4 if getattr(spade, "_x_f32", True) else 2)
+        with _Timed("conv", self.name, self.flops(N, Ho, Wo), nbytes):
             _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")
         return out
 

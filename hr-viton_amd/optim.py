@@ -54,7 +54,10 @@ class Adam(torch.optim.Optimizer):
 
     @torch.no_grad()
     def step(self, closure=None):
-        loss = closure() if closure is not None else None
+        loss = None
+        if closure is not None:
+            with torch.enable_grad():            # like torch.optim: the closure may call backward()
+                loss = closure()
         world_scale = 1.0
         if self.grad_sync is not None:
             self.grad_sync.wait()
@@ -63,16 +66,25 @@ class Adam(torch.optim.Optimizer):
             st = self._flat.get(gi) or self._setup(gi, group)
             g = st["g"]
             base = g.data_ptr()
+            skipped = []
             for p, off, k in st["spans"]:
                 src = self.grad_sync.grad_of(p) if self.grad_sync is not None else p.grad
                 if src is None:
-                    g[off:off + k].zero_()               # torch's Adam skips it; a zero gradient is a no-op here
+                    # torch's Adam SKIPS a parameter without a gradient (weight, moments and weight decay untouched): the
+                    # fused launch covers the whole flat buffer, so the span is snapshotted here and restored below
+                    g[off:off + k].zero_()
+                    skipped.append((off, k, st["w"][off:off + k].clone(), st["m"][off:off + k].clone(),
+                                    st["v"][off:off + k].clone()))
                 elif src.data_ptr() != base + 4 * off:   # already produced in place by the backward plan otherwise
                     g[off:off + k].copy_(src.reshape(-1))
             st["step"] += 1
             b1, b2 = group["betas"]
             T.adam_step(st["w"], g, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
                         st["step"], world_scale)
+            for off, k, w0, m0, v0 in skipped:
+                st["w"][off:off + k].copy_(w0)
+                st["m"][off:off + k].copy_(m0)
+                st["v"][off:off + k].copy_(v0)
         for group in self.param_groups:          # cached inference plans of THESE parameters are stale now
             for p in group["params"]:
                 p._hrv_epoch = getattr(p, "_hrv_epoch", 0) + 1

@@ -94,7 +94,9 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
                          (0 if src_bf16 else 8))
     else:
         assert not (src_bf16 or out.bf16 or (residual is not None and residual.bf16)), f"{name}: bf16 tensors need MMA_BF16"
-    with _Timed("conv", name, flops, 0):
+    nbytes = (sum(ops.act_bytes(a, creal) for a, _, creal in srcs) + ops.act_bytes(out, Cout) * (4 if out_up else 1) +
+              ops.act_bytes(residual, Cout) + float(Cout) * sum(c for _, _, c in srcs) * KH * KW * (2 if mma_bf16 else 4))
+    with _Timed("conv", name, flops, nbytes):
         fn = lib.hrv_conv2d_nhwc_bf16 if mma_bf16 else lib.hrv_conv2d_nhwc_f32
         _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_{'bf16' if mma_bf16 else 'f32'}[{name}]")
     return out
@@ -183,7 +185,8 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     args = (dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp, x.cstride, x.coff, x_up, x.C, ci_base,
             cin_tot, N, H, W, Ho, Wo, KH, KW, stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
             1 if accumulate else 0, None if dbias is None else dbias.data_ptr(), 1 if dbias_accumulate else 0)
-    with _Timed("wgrad", name, fl, 0):
+    nbytes = ops.act_bytes(dy) + ops.act_bytes(x) + 4.0 * Cout * x.C * KH * KW
+    with _Timed("wgrad", name, fl, nbytes):
         if x.bf16 or dy.bf16:
             assert MMA_BF16[0] and Wo % 4 == 0, f"{name}: bf16-stored operands need the bf16 matrix-core weight gradient"
             assert x.bf16, f"{name}: bf16 dY with an fp32 X is not built"
@@ -267,9 +270,10 @@ def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, g
     assert ok, "loss: operands must share one dense layout (strides of size-1 dims do not matter)"
     grad = torch.empty_like(a) if want_grad else None
     ws = _workspace(a.device, 4096)
-    _lib.check(lib.hrv_loss_f32(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), mode, lscale, gscale,
-                                None if grad is None else grad.data_ptr(), ws.data_ptr(), loss_out.data_ptr(),
-                                1 if accumulate else 0, _stream()), "hrv_loss_f32")
+    with _Timed("loss", "loss_f32", 0.0, 4.0 * a.numel() * (1 + (b is not None) + (grad is not None))):
+        _lib.check(lib.hrv_loss_f32(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), mode, lscale, gscale,
+                                    None if grad is None else grad.data_ptr(), ws.data_ptr(), loss_out.data_ptr(),
+                                    1 if accumulate else 0, _stream()), "hrv_loss_f32")
     return grad
 
 
@@ -279,9 +283,10 @@ def downsum2x2(dhi: Act, dlo: Optional[Act] = None, accumulate: bool = False) ->
     if dlo is None:
         dlo = ops.alloc(dhi.N, Hl, Wl, dhi.C, dhi.t.device)
         accumulate = False
-    _lib.check(lib.hrv_downsum2x2_nhwc_f32(dhi.t.data_ptr(), dhi.N, Hl, Wl, dhi.Cp, dhi.cstride, dhi.coff,
-                                           dlo.t.data_ptr(), dlo.cstride, dlo.coff, 1 if accumulate else 0, _stream()),
-               "hrv_downsum2x2_nhwc_f32")
+    with _Timed("ew", "downsum2x2", 0.0, ops.act_bytes(dhi) * (1.25 + (0.25 if accumulate else 0))):
+        _lib.check(lib.hrv_downsum2x2_nhwc_f32(dhi.t.data_ptr(), dhi.N, Hl, Wl, dhi.Cp, dhi.cstride, dhi.coff,
+                                               dlo.t.data_ptr(), dlo.cstride, dlo.coff, 1 if accumulate else 0, _stream()),
+                   "hrv_downsum2x2_nhwc_f32")
     return dlo
 
 
@@ -290,9 +295,10 @@ def avgpool3x3s2_bwd(dy: Act, H: int, W: int, dx: Optional[Act] = None, accumula
     if dx is None:
         dx = ops.alloc(dy.N, H, W, dy.C, dy.t.device)
         accumulate = False
-    _lib.check(lib.hrv_avgpool3x3s2_bwd_nhwc_f32(dy.t.data_ptr(), dy.N, H, W, dy.Cp, dy.cstride, dy.coff,
-                                                 dx.t.data_ptr(), dx.cstride, dx.coff, 1 if accumulate else 0,
-                                                 _stream()), "hrv_avgpool3x3s2_bwd_nhwc_f32")
+    with _Timed("pool", "avgpool3x3s2_bwd", 0.0, ops.act_bytes(dy) + ops.act_bytes(dx) * (2 if accumulate else 1)):
+        _lib.check(lib.hrv_avgpool3x3s2_bwd_nhwc_f32(dy.t.data_ptr(), dy.N, H, W, dy.Cp, dy.cstride, dy.coff,
+                                                     dx.t.data_ptr(), dx.cstride, dx.coff, 1 if accumulate else 0,
+                                                     _stream()), "hrv_avgpool3x3s2_bwd_nhwc_f32")
     return dx
 
 
@@ -300,24 +306,27 @@ def maxpool2x2(x: Act) -> Act:
     lib = _lib.load()
     assert x.coff == 0 and x.cstride == x.Cp
     y = ops.alloc(x.N, x.H // 2, x.W // 2, x.C, x.t.device)
-    _lib.check(lib.hrv_maxpool2x2_nhwc_f32(x.t.data_ptr(), x.N, x.H, x.W, x.Cp, y.t.data_ptr(), _stream()),
-               "hrv_maxpool2x2_nhwc_f32")
+    with _Timed("pool", "maxpool2x2", 0.0, ops.act_bytes(x) * 1.25):
+        _lib.check(lib.hrv_maxpool2x2_nhwc_f32(x.t.data_ptr(), x.N, x.H, x.W, x.Cp, y.t.data_ptr(), _stream()),
+                   "hrv_maxpool2x2_nhwc_f32")
     return y
 
 
 def maxpool2x2_bwd(x: Act, dy: Act) -> Act:
     lib = _lib.load()
     dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
-    _lib.check(lib.hrv_maxpool2x2_bwd_nhwc_f32(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(),
-                                               _stream()), "hrv_maxpool2x2_bwd_nhwc_f32")
+    with _Timed("pool", "maxpool2x2_bwd", 0.0, ops.act_bytes(x) * 2.25):
+        _lib.check(lib.hrv_maxpool2x2_bwd_nhwc_f32(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(),
+                                                   _stream()), "hrv_maxpool2x2_bwd_nhwc_f32")
     return dx
 
 
 def adam_step(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, lr: float, beta1: float, beta2: float,
               eps: float, weight_decay: float, step: int, grad_scale: float = 1.0):
     lib = _lib.load()
-    _lib.check(lib.hrv_adam_f32(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), lr, beta1, beta2, eps,
-                                weight_decay, step, grad_scale, _stream()), "hrv_adam_f32")
+    with _Timed("adam", "adam_f32", 0.0, 28.0 * w.numel()):     # read w, g, m, v; write w, m, v
+        _lib.check(lib.hrv_adam_f32(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), lr, beta1, beta2, eps,
+                                    weight_decay, step, grad_scale, _stream()), "hrv_adam_f32")
 
 
 def spectral_sigma(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, power_iterations: int,
@@ -347,7 +356,8 @@ def spectral_grad(G: torch.Tensor, w_orig: torch.Tensor, u: torch.Tensor, v: tor
 def tanh_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     lib = _lib.load()
     out = torch.empty_like(dy)
-    _lib.check(lib.hrv_tanh_bwd_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), out.data_ptr(), _stream()), "hrv_tanh_bwd_f32")
+    with _Timed("ew", "tanh_bwd", 0.0, 12.0 * dy.numel()):
+        _lib.check(lib.hrv_tanh_bwd_f32(dy.data_ptr(), y.data_ptr(), dy.numel(), out.data_ptr(), _stream()), "hrv_tanh_bwd_f32")
     return out
 
 
@@ -355,15 +365,17 @@ def add_slice(a: Act, out: Act, accumulate: bool):
     """out (+)= a over a's channels (both views may be channel slices)."""
     lib = _lib.load()
     assert (a.N, a.H, a.W) == (out.N, out.H, out.W) and a.Cp <= out.cstride - out.coff
-    _lib.check(lib.hrv_add_slice_nhwc_f32(a.t.data_ptr(), a.cstride, a.coff, out.t.data_ptr(), out.cstride, out.coff, a.Cp,
-                                          a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc_f32")
+    with _Timed("ew", "add_slice", 0.0, ops.act_bytes(a) * (3 if accumulate else 2)):
+        _lib.check(lib.hrv_add_slice_nhwc_f32(a.t.data_ptr(), a.cstride, a.coff, out.t.data_ptr(), out.cstride, out.coff, a.Cp,
+                                              a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc_f32")
 
 
 def act_bwd_(d: Act, y: Act, act: int, slope: float = 0.2):
     """d *= act'(y) in place."""
     lib = _lib.load()
-    _lib.check(lib.hrv_act_bwd_nhwc_f32(d.t.data_ptr(), d.cstride, d.coff, y.t.data_ptr(), y.cstride, y.coff, d.Cp,
-                                        d.N * d.H * d.W, act, slope, _stream()), "hrv_act_bwd_nhwc_f32")
+    with _Timed("ew", "act_bwd", 0.0, ops.act_bytes(d) * 2 + ops.act_bytes(y, d.C)):
+        _lib.check(lib.hrv_act_bwd_nhwc_f32(d.t.data_ptr(), d.cstride, d.coff, y.t.data_ptr(), y.cstride, y.coff, d.Cp,
+                                            d.N * d.H * d.W, act, slope, _stream()), "hrv_act_bwd_nhwc_f32")
 
 
 def scale_(x: torch.Tensor, s_host: float = 1.0, s_dev: Optional[torch.Tensor] = None) -> torch.Tensor:

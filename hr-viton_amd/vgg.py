@@ -70,10 +70,14 @@ class Vgg19(nn.Module):
         raise KeyError(idx)
 
     def plan(self, device):
-        if self._plan is None or self._plan[0] != str(device):
+        # keyed like the tocg / generator plans: any in-place weight write (load_state_dict, a broadcast, the fused
+        # Adam's raw-pointer update) invalidates the host-packed weights
+        ps = list(self.parameters())
+        key = (str(device), tuple(p._version for p in ps), ops.weights_epoch(ps))
+        if self._plan is None or self._plan[0] != key:
             layers = {idx: ConvLayer(self.conv(idx).weight, [cin], device, shift=self.conv(idx).bias, pad=1, act=ACT_RELU,
                                      name=f"vgg.features.{idx}") for idx, cin, cout in _CONVS}
-            self._plan = (str(device), layers)
+            self._plan = (key, layers)
         return self._plan[1]
 
     def features(self, x: Act, save: bool):

@@ -1,0 +1,196 @@
+"""Checker for one train_generator.py iteration (train_generator.py:279-360): the product classes on the
+MI355X against torch autograd over the CPU restatement (hrviton_oracle.py), at any size the CPU can afford.
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/ and by bench.py's parity / cpu_baseline legs, never by the
+product package.  Three entry points:
+
+* ``build``            one deterministic (generator, PatchGAN, VGG criterion, batch, SPADE noise) recipe;
+* ``compare_generator_step``  G-step losses, the generated image and EVERY parameter gradient, HIP vs oracle
+                       (fp32: reassociation only; ``mixed=True``: bf16 matrix-core operands, stated tolerance);
+* ``cpu_train_generator_step``  the whole iteration (G step + D step + Adam) on the oracle, for the CPU baseline.
+"""
+from __future__ import annotations
+
+import time
+from argparse import Namespace
+from typing import Dict, List, Optional
+
+import torch
+
+from . import hrviton_oracle as O
+
+
+def build(H: int, W: int, ngf: int, ndf: int, N: int, seed: int = 0, wmul: float = 8.0, layers: str = "most"):
+    """SPADEGenerator(ngf, ``layers``) + MultiscaleDiscriminator(ndf) with the reference's xavier(0.02) init, the
+    non-spectral weights scaled by ``wmul`` (a random-init generator is otherwise ~linear), random biases and
+    noise_scale; one synthetic batch (x [N,9,H,W], one-hot 7-class blobs, real image) and the SPADE noise."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.network_generator import MultiscaleDiscriminator, SPADEGenerator
+    from hr_viton_amd.vgg import VGGLoss
+    opt = Namespace(cuda=True, norm_G="spectralaliasinstance", gen_semantic_nc=7, ngf=ngf, num_upsampling_layers=layers,
+                    fine_height=H, fine_width=W, ndf=ndf, norm_D="spectralinstance", n_layers_D=3, num_D=2,
+                    no_ganFeat_loss=False, lambda_feat=10.0, lambda_vgg=10.0, no_vgg_loss=False)
+    torch.manual_seed(seed)
+    gen = SPADEGenerator(opt, 9)
+    gen.init_weights("xavier", 0.02)
+    D = MultiscaleDiscriminator(opt)
+    D.init_weights("xavier", 0.02)
+    vgg = VGGLoss(Namespace(cuda=False))
+    g = torch.Generator().manual_seed(seed + 1)
+    with torch.no_grad():
+        for n_, p in list(gen.named_parameters()) + list(D.named_parameters()):
+            if n_.endswith("noise_scale"):
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+            elif n_.endswith("weight") or n_.endswith("weight_orig"):
+                p.mul_(wmul)
+            elif n_.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    x = torch.rand(N, 9, H, W, generator=g) * 2 - 1
+    b = 16 if H % 16 == 0 and W % 16 == 0 else 1
+    lab = torch.randint(0, 7, (N, 1, H // b, W // b), generator=g).repeat_interleave(b, 2).repeat_interleave(b, 3)
+    seg = torch.zeros(N, 7, H, W).scatter_(1, lab, 1.0)
+    real = torch.rand(N, 3, H, W, generator=g) * 2 - 1
+    noise = {}
+    for j, name in enumerate(gen._blocks()):
+        h, w = gen.sh << j, gen.sw << j
+        k = 3 if getattr(gen, name).learned_shortcut else 2
+        noise[name] = [torch.randn(N, w, h, 1, generator=g) for _ in range(k)]
+    return opt, gen, D, vgg, x, seg, real, noise
+
+
+def oracle_sd(mod) -> Dict[str, torch.Tensor]:
+    return {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith(("weight_u", "weight_v")))
+            for k, v in mod.state_dict().items()}
+
+
+def oracle_generator_losses(opt, sd_g, sd_d, sd_vgg, x, seg, real, noise):
+    """Generator half of the iteration (train_generator.py:279-314) on the oracle; spectral norm in training mode
+    (one power iteration per forward, like torch)."""
+    O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+    try:
+        fake = O.spade_generator_forward(sd_g, x, seg, opt.fine_height, opt.fine_width, opt.num_upsampling_layers,
+                                         noise=noise)
+        pred = O.gen_discriminator_forward(sd_d, torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0))
+    finally:
+        O.SN_TRAIN["on"] = False
+    pf, pr = O.split_fake_real(pred)
+    losses = {"GAN": O.hinge_loss(pf, True, False), "GAN_Feat": O.feat_match_loss(pf, pr, opt.lambda_feat)}
+    if sd_vgg is not None:
+        losses["VGG"] = O.vgg_loss(sd_vgg, fake, real) * opt.lambda_vgg
+    return fake, losses
+
+
+def _grad_table(mod, sd):
+    """[(rel_err, abs_err, |want|max, name)] per parameter; rel = abs / max(|want|max, 1e-3 x the module's largest
+    gradient magnitude): analytically-zero gradients (a bias in front of an InstanceNorm) are pure round-off."""
+    gmax = max((sd[n].grad.abs().max().item() for n, _ in mod.named_parameters() if sd[n].grad is not None), default=1.0)
+    rows = []
+    for name, p in mod.named_parameters():
+        want = sd[name].grad
+        if want is None or p.grad is None:
+            continue
+        got = p.grad.detach().float().cpu()
+        aerr = (got - want).abs().max().item()
+        cos = torch.nn.functional.cosine_similarity(got.flatten(), want.flatten(), dim=0).item() if want.numel() > 1 else 1.0
+        rows.append((aerr / max(want.abs().max().item(), 1e-3 * gmax), aerr, want.abs().max().item(), cos, name))
+    rows.sort(reverse=True)
+    return rows, gmax
+
+
+def compare_generator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: int = 1, seed: int = 0, wmul: float = 8.0,
+                           mixed: bool = False, with_vgg: bool = True, table_path: Optional[str] = None,
+                           cpu_threads: int = 0) -> dict:
+    """Runs the generator half of one iteration on cuda:0 (product classes) and on the CPU oracle with identical
+    weights, inputs and SPADE noise.  Returns max-rel errors of the image and the loss terms, the worst / median
+    per-parameter gradient error and cosine, and optionally writes the per-parameter table."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import train_ops as T
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    if cpu_threads:
+        torch.set_num_threads(cpu_threads)
+    opt, gen, D, vgg, x, seg, real, noise = build(H, W, ngf, ndf, N, seed, wmul)
+    sd_g, sd_d = oracle_sd(gen), oracle_sd(D)
+    sd_vgg = {k: v.detach().clone() for k, v in vgg.vgg.state_dict().items()} if with_vgg else None
+    t0 = time.perf_counter()
+    fake, losses = oracle_generator_losses(opt, sd_g, sd_d, sd_vgg, x, seg, real, noise)
+    sum(losses.values()).backward()
+    t_oracle = time.perf_counter() - t0
+    gen.cuda().train()
+    D.cuda().train()
+    vgg.cuda()
+    T.MMA_BF16[0] = mixed
+    try:
+        xc, sc, rc = x.cuda(), seg.cuda(), real.cuda()
+        out = gen(xc, sc, noise={k: [z.cuda() for z in v] for k, v in noise.items()})
+        pf, pr = D(torch.cat([torch.cat([sc, out], 1), torch.cat([sc, rc], 1)], 0), split=True)
+        got = {"GAN": GANLoss("hinge")(pf, True, for_discriminator=False)}
+        feat = 0
+        for i in range(len(pf)):
+            for j in range(len(pf[i]) - 1):
+                feat = feat + L1Loss()(pf[i][j], pr[i][j].detach()) * opt.lambda_feat / len(pf)
+        got["GAN_Feat"] = feat
+        if with_vgg:
+            got["VGG"] = vgg(out, rc) * opt.lambda_vgg
+        sum(got.values()).mean().backward()
+        torch.cuda.synchronize()
+    finally:
+        T.MMA_BF16[0] = False
+    rows_g, gmax = _grad_table(gen, sd_g)
+    rel = lambda a, b: float(((a.detach().float().cpu() - b.detach()).abs().max() / b.detach().abs().max().clamp_min(1e-12)))  # noqa: E731
+    rep = {"size": f"{N}x{H}x{W} ngf={ngf}", "mixed": mixed, "oracle_fwd_bwd_s": round(t_oracle, 2),
+           "image_max_rel_err": rel(out, fake),
+           "image_mean_abs_err": float((out.detach().cpu() - fake.detach()).abs().mean()),
+           "loss_rel_err": {k: abs(float(got[k]) - float(losses[k])) / max(1.0, abs(float(losses[k]))) for k in losses},
+           "losses_oracle": {k: float(v) for k, v in losses.items()},
+           "grad_worst_rel_err": rows_g[0][0], "grad_worst_name": rows_g[0][4],
+           "grad_median_rel_err": rows_g[len(rows_g) // 2][0],
+           "grad_min_cosine": min(r[3] for r in rows_g if r[2] > 1e-2 * gmax and not r[4].endswith("noise_scale")),
+           "n_params_compared": len(rows_g)}
+    if table_path:
+        with open(table_path, "w") as f:
+            f.write(f"# generator step {rep['size']} mixed={mixed}: rel_err abs_err |want|max cosine name "
+                    f"(module max grad {gmax:.3e})\n")
+            for r in rows_g:
+                f.write("%.3e %.3e %.3e %.6f %s\n" % r)
+    return rep
+
+
+def cpu_train_generator_step(H: int = 256, W: int = 192, ngf: int = 64, ndf: int = 64, N: int = 1, layers: str = "more",
+                             repeats: int = 3, warmup: int = 1, threads: int = 0) -> dict:
+    """The whole train_generator.py iteration on the oracle (CPU): G forward, PatchGAN on [fake; real], hinge +
+    feature-matching + VGG losses, backward, Adam; then the D half (no_grad G forward, PatchGAN, hinge, backward,
+    Adam).  1 warm-up + ``repeats`` timed iterations, median -- BASELINE.md section 4."""
+    if threads:
+        torch.set_num_threads(threads)
+    opt, gen, D, vgg, x, seg, real, noise = build(H, W, ngf, ndf, N, 0, 8.0, layers)
+    sd_g, sd_d = oracle_sd(gen), oracle_sd(D)
+    sd_vgg = {k: v.detach().clone() for k, v in vgg.vgg.state_dict().items()}
+    pg = [v for v in sd_g.values() if v.requires_grad]
+    pd = [v for v in sd_d.values() if v.requires_grad]
+    og = torch.optim.Adam(pg, lr=1e-4, betas=(0.0, 0.9))
+    od = torch.optim.Adam(pd, lr=4e-4, betas=(0.0, 0.9))
+    times: List[float] = []
+    for it in range(warmup + repeats):
+        t0 = time.perf_counter()
+        _, losses = oracle_generator_losses(opt, sd_g, sd_d, sd_vgg, x, seg, real, noise)
+        og.zero_grad()
+        od.zero_grad()
+        sum(losses.values()).backward()
+        og.step()
+        O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+        try:
+            with torch.no_grad():
+                fake = O.spade_generator_forward(sd_g, x, seg, H, W, layers, noise=noise)
+            pred = O.gen_discriminator_forward(sd_d, torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0))
+        finally:
+            O.SN_TRAIN["on"] = False
+        pf, pr = O.split_fake_real(pred)
+        ld = O.hinge_loss(pf, False, True) + O.hinge_loss(pr, True, True)
+        od.zero_grad()
+        ld.backward()
+        od.step()
+        if it >= warmup:
+            times.append(time.perf_counter() - t0)
+    times.sort()
+    med = times[len(times) // 2]
+    return {"seconds_per_step_median": med, "images_per_s": N / med, "times": times, "size": (N, H, W), "layers": layers}

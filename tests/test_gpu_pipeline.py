@@ -151,7 +151,7 @@ def test_entry_scripts_on_disk_dataset(tmp_path):
     ck = str(tmp_path / "ck")
     tc.main(["--dataroot", root, "--datamode", "train", "--data_list", "train_pairs.txt", "-b", "2", "-j", "0",
              "--Ddownx2", "--lasttvonly", "--interflowloss", "--max_steps", "2", "--display_count", "1", "--ngf", "8",
-             "--checkpoint_dir", ck, "--name", "t", "--shuffle"])
+             "--checkpoint_dir", ck, "--name", "t", "--shuffle", "--vgg_random_init"])
     sd = torch.load(__import__("os").path.join(ck, "t", "tocg_final.pth"), map_location="cpu")
     assert "ClothEncoder.0.block.1.running_mean" in sd and int(sd["out_layer.block.1.num_batches_tracked"]) == 2
 

@@ -92,7 +92,10 @@ def get_opt(argv=None):
     p.add_argument("--max_steps", type=int, default=0, help="stop after this many steps (0: keep_step)")
     p.add_argument("--ngf", type=int, default=96)
     p.add_argument("--no_vgg_loss", action="store_true", help="drop the VGG terms (train_condition.py always has them)")
-    p.add_argument("--vgg_weights", type=str, default="", help="torchvision vgg19 state_dict (.pth); random init if absent")
+    p.add_argument("--vgg_weights", type=str, default="", help="torchvision vgg19 state_dict (.pth): the reference's models.vgg19(pretrained=True) weights")
+    p.add_argument("--vgg_random_init", action="store_true",
+                   help="plumbing / bench runs only: a RANDOMLY initialised VGG19 in the perceptual loss (no network here to "
+                        "download the pretrained weights); implied by --synthetic")
     opt = p.parse_args(argv)
     if opt.upsample != "bilinear":
         raise NotImplementedError("hr-viton_amd train_condition: --upsample nearest is not on the HIP path")
@@ -163,6 +166,15 @@ def main(argv=None):
         crit_vgg = VGGLoss(opt)
         if opt.vgg_weights:
             crit_vgg.vgg.load_torchvision_state_dict(torch.load(opt.vgg_weights, map_location="cpu"))
+        elif opt.vgg_random_init or opt.synthetic:
+            if rank == 0:
+                print("WARNING: VGGLoss runs on a RANDOMLY initialised VGG19 (--vgg_random_init / --synthetic): the "
+                      "perceptual term is not the reference's objective; pass --vgg_weights for real training.", flush=True)
+        else:
+            # the reference builds models.vgg19(pretrained=True) (networks.py:204); silently optimising random features
+            # would be a different objective
+            raise SystemExit("VGGLoss needs the pretrained torchvision vgg19 weights: pass --vgg_weights <state_dict.pth>, "
+                             "or --no_vgg_loss, or --vgg_random_init for plumbing runs")
         crit_vgg.to(dev)
         broadcast_module(crit_vgg)
     opt_g = Adam(tocg.parameters(), lr=opt.G_lr, betas=(0.5, 0.999))
