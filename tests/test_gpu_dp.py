@@ -90,3 +90,94 @@ def test_two_rank_condition_training_keeps_replicas_identical():
     assert moved0 > 1e-5 and moved0 == moved1
     assert all(map(lambda v: v == v and abs(v) < 1e6, (lg0, ld0, lg1, ld1)))
     assert lg0 != lg1                                   # the ranks really saw different data
+
+
+def _gen_worker(rank, world, port, q):
+    """Two ranks of train_generator.py's iteration (G step + D step): SPADE generator + PatchGAN, spectral norm in
+    training mode (one power iteration per forward on every rank -- u, v are buffers, never all-reduced), per-rank
+    data and SPADE noise, gradients summed by GradSync from inside the backward plans, fused Adam."""
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port), HRV_DIST_BACKEND="gloo")
+        from argparse import Namespace
+        import torch.distributed as dist
+        import hr_viton_amd  # noqa: F401
+        from hr_viton_amd import dist as hdist
+        from hr_viton_amd import ops
+        from hr_viton_amd.gen_train import attach_grad_sync
+        from hr_viton_amd.losses import GANLoss, L1Loss
+        from hr_viton_amd.network_generator import MultiscaleDiscriminator, SPADEGenerator
+        from hr_viton_amd.optim import Adam
+        from hr_viton_amd.parallel import broadcast_module
+        from hr_viton_amd.pipeline import generator_train_step
+        hdist.init_from_env()
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+        H, W = 256, 128
+        opt = Namespace(cuda=True, norm_G="spectralaliasinstance", gen_semantic_nc=7, ngf=8, num_upsampling_layers="most",
+                        fine_height=H, fine_width=W, ndf=8, norm_D="spectralinstance", n_layers_D=3, num_D=2,
+                        no_ganFeat_loss=False, lambda_feat=10.0, lambda_vgg=10.0, no_vgg_loss=True)
+        torch.manual_seed(200 + rank)                   # replicas start different (weights AND u, v); broadcast equalises
+        gen = SPADEGenerator(opt, 9)
+        gen.init_weights("xavier", 0.02)
+        dis = MultiscaleDiscriminator(opt)
+        dis.init_weights("xavier", 0.02)
+        gen.to(dev).train()
+        dis.to(dev).train()
+        broadcast_module(gen)
+        broadcast_module(dis)
+        og = Adam(gen.parameters(), lr=1e-4, betas=(0.0, 0.9))
+        od = Adam(dis.parameters(), lr=4e-4, betas=(0.0, 0.9))
+        sg, sd = og.make_grad_sync(bucket_mb=0.25), od.make_grad_sync(bucket_mb=4.0)
+        attach_grad_sync(sg)
+        attach_grad_sync(sd)
+        assert len(sg.buckets) >= 2
+        w0 = torch.cat([p.detach().flatten() for p in gen.parameters()]).clone()
+        losses = None
+        for step in range(2):
+            g = torch.Generator().manual_seed(1000 + 10 * step + rank)     # a different sample per rank
+            x = (torch.rand(1, 9, H, W, generator=g) * 2 - 1).to(dev)
+            lab = torch.randint(0, 7, (1, 1, H // 16, W // 16), generator=g).repeat_interleave(16, 2).repeat_interleave(16, 3)
+            seg = torch.zeros(1, 7, H, W).scatter_(1, lab, 1.0).to(dev)
+            real = (torch.rand(1, 3, H, W, generator=g) * 2 - 1).to(dev)
+            torch.manual_seed(77 + rank + step)                            # per-rank SPADE noise draws
+            losses, _ = generator_train_step(opt, gen, dis, GANLoss("hinge"), L1Loss(), None, og, od, x, ops.to_nhwc(seg),
+                                             real, sg, sd)
+        torch.cuda.synchronize()
+        wg = torch.cat([p.detach().flatten() for p in gen.parameters()])
+        wd = torch.cat([p.detach().flatten() for p in dis.parameters()])
+        uv = torch.cat([b.detach().flatten() for n, b in list(gen.named_buffers()) + list(dis.named_buffers())
+                        if n.endswith(("weight_u", "weight_v"))])
+        sums = torch.stack([t.double().sum() for t in (wg, wd, uv)] + [t.double().abs().sum() for t in (wg, wd, uv)]).cpu()
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        q.put((rank, [t.tolist() for t in gathered], float((wg - w0).abs().max()), float(losses["GAN_Feat"].detach()),
+               float(losses["D_Fake"].detach())))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc()))
+
+
+def test_two_rank_generator_training_keeps_replicas_identical():
+    """train_generator.py's DP iteration (train_generator.py:171-178 -> one process per GPU + gradient all-reduce):
+    after two iterations on different per-rank data the generator, the PatchGAN AND the spectral-norm (u, v)
+    buffers are bitwise identical on both ranks."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert len(r) == 5, r
+    (_, g0, moved0, lf0, ld0), (_, g1, moved1, lf1, ld1) = res
+    assert g0 == g1 and g0[0] == g0[1], ("replica checksums (G weights, D weights, spectral u/v) differ", g0, g1)
+    assert moved0 > 1e-6 and moved0 == moved1
+    assert all(map(lambda v: v == v and abs(v) < 1e6, (lf0, ld0, lf1, ld1)))
+    assert lf0 != lf1                                   # the ranks really saw different data
