@@ -388,14 +388,14 @@ class CondDPlan:
                 a = ops.avgpool3x3s2(a)
         return outs, dict(ctxs=ctxs, inputs=inputs, full=full)
 
-    def backward(self, saved, d_outs: List[Optional[Act]], need_dx: bool):
+    def backward(self, saved, d_outs: List[Optional[Act]], need_dx: bool, need_w: bool = True):
         grads: Grads = {}
         d_next: Optional[Act] = None
         for i in range(len(self.plans) - 1, -1, -1):
             a = saved["inputs"][i]
             c, nfe = saved["ctxs"][i]
             dfeats = [None] * (nfe - 1) + [d_outs[i]]
-            d_a = self.plans[i].backward(c, dfeats, grads, need_dx) if d_outs[i] is not None else None
+            d_a = self.plans[i].backward(c, dfeats, grads, need_dx, need_w=need_w) if d_outs[i] is not None else None
             if need_dx:
                 if d_a is None:
                     d_a = Act(torch.zeros_like(a.t), a.C)
@@ -413,13 +413,15 @@ class _CondDFn(torch.autograd.Function):
     def forward(ctx, plan, inp, *params):
         outs, saved = plan.forward(inp)
         ctx.plan, ctx.saved, ctx.params = plan, saved, params
+        # loss_G's gradients w.r.t. the discriminator are discarded by optimizer_D.zero_grad() (train_condition.py:284)
+        ctx.need_w = not getattr(plan.msd, "_hrv_discard_param_grads", False)
         return tuple(ops.to_nchw(o) for o in outs)
 
     @staticmethod
     def backward(ctx, *d_outs):
         need_dx = ctx.needs_input_grad[1]
         d_acts = [None if d is None else ops.to_nhwc(d.contiguous()) for d in d_outs]
-        grads, d_in = ctx.plan.backward(ctx.saved, d_acts, need_dx)
+        grads, d_in = ctx.plan.backward(ctx.saved, d_acts, need_dx, ctx.need_w)
         ctx.saved = None
         return (None, ops.to_nchw(d_in) if (need_dx and d_in is not None) else None) + \
             tuple(grads.get(p) for p in ctx.params)

@@ -698,6 +698,13 @@ extern "C" int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot
   return (S * KH * KW * (int64_t)Cout * CinTot + 256 * (int64_t)Cout) * (int64_t)sizeof(float);   // + bias partials
 }
 
+namespace hrv {
+// wgrad_tr.hip: LDS-DMA + transposing-read weight gradient for bf16-stored operands (1: launched, 0: shape not served)
+int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, int x_C, int x_cs, int x_co, int x_C_real,
+                 int ci_base, int CinTot, int N, int H, int W, int KH, int KW, int pad, float* workspace,
+                 long long workspace_bytes, float* dbias, int dbias_accumulate, hipStream_t st, int* S_out);
+}
+
 static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x, int32_t x_C,
                       int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real, int32_t ci_base,
                       int32_t CinTot, int32_t N, int32_t H, int32_t W, int32_t Ho, int32_t Wo, int32_t KH, int32_t KW,
@@ -719,6 +726,18 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   p.x_bf16 = x_bf16 ? 1 : 0;
   HRV_REQUIRE(!(x_bf16 || dy_bf16) || mma_bf16, "wgrad: bf16-stored operands exist for the bf16 matrix-core kernel only");
   HRV_REQUIRE(!dy_bf16 || x_bf16, "wgrad: storage_flags 1 (bf16 dY with fp32 X) is not built");
+  if (mma_bf16 && x_bf16 && dy_bf16 && stride == 1 && Ho == H && Wo == W && x_up_shift == 0) {
+    int S2 = 0;
+    const int r = wgrad_tr_try(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_C_real, ci_base, CinTot, N, H, W,
+                               KH, KW, pad, workspace, workspace_bytes, dbias, dbias_accumulate, (hipStream_t)stream, &S2);
+    if (r < 0) return r;
+    if (r == 1) {
+      const size_t total = (size_t)Cout * x_C_real * KH * KW;
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, workspace, S2,
+                         KH * KW, Cout, CinTot, ci_base, x_C_real, dw_oihw, accumulate);
+      return check_launch("wgrad_reduce_kernel");
+    }
+  }
   const int wt = pick_wtile(Cout, x_C);
   const int bm = wt_bm(wt), bn = wt_bn(wt);
   p.taps = KH * KW;

@@ -1,0 +1,414 @@
+// Weight gradient of a stride-1 'same' convolution whose operands are STORED in bf16 (mixed-precision training:
+// dY = [dgamma|dbeta] / d(conv out), X = actv / a SPADE-modulated activation -- tensors only matrix cores read):
+//
+//     dW[co][tap][ci] = sum_p dY[p][co] * X[p + tap][ci]            (reference: autograd of nn.Conv2d,
+//                                                                     network_generator.py:98-99,117-121,141-143)
+//
+// The bf16 MFMA wants 8 consecutive k (= PIXELS here) per lane, but NHWC is pixel-major.  conv_wgrad_bf16_kernel
+// (conv_bwd.hip) transposes quads in registers: 26 VALU instructions per MFMA, MFMA-busy 13 %
+// (profiles/r01_pmc_wgrad_bf16.txt).  This kernel has NO VALU in the staging path:
+//   * both operands travel global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds) in their natural [pixel][channel]
+//     order: a tile is one image-row segment of 64 pixels, so dY is ONE contiguous run and X (with its KW-1 halo
+//     pixels) another; 3-4 stages in flight with counted vmcnt across a fence-less s_barrier;
+//   * fragments are read with ds_read_b64_tr_b16: 16 lanes fetch a [4 pixels][16 channels] block and receive it
+//     transposed -- lane j holds channel j's 4 pixels, i.e. half an MFMA operand.  Every lane passes its own address,
+//     so a tap is just a pixel offset into the X patch (no im2col, no per-tap restaging);
+//   * a block owns a (cout tile) x (one kernel row: KW taps x 32*XC input channels) tile of dW and keeps it in
+//     registers (TM x TN x 16 accumulators per lane) while it streams its slab of the image; the kernel rows /
+//     cout tiles of one slab are neighbouring blocks of one XCD (they re-read the same dY rows out of L2).
+// LDS rows shorter than 256 bytes are padded to (4 mod 8) 16-byte slots (pad slots are DMA'd as zeros by out-of-range
+// offsets); rows of 256 bytes and more are dense.
+// Partial sums go to the same [S][tap][Cout][CinTot] workspace as the other weight-gradient kernels (fixed-order
+// reduce => deterministic).
+#include "hrv_common.h"
+
+namespace hrv {
+
+typedef float wt_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 wt_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short wt_s16x4 __attribute__((ext_vector_type(4)));
+typedef short wt_s16x8 __attribute__((ext_vector_type(8)));
+
+struct WgradTrParams {
+  const void* dy; int dy_cs, dy_co, Cout;
+  const void* x; int x_cs, x_co, x_C;       // x_C: channels of this source, multiple of 8
+  int N, H, W, KH, KW, pad;
+  int CinTot, ci_base, ci_real;
+  int co_tiles, col_tiles, S;               // col tile = (kernel row kh, group range)
+  int gpt;                                  // 32-channel groups per tap = ceil(x_C / 32)
+  int tiles_per_row, n_tiles;               // 64-pixel row segments
+  float* ws;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __amdgpu_buffer_rsrc_t wt_rsrc_t;
+__device__ __forceinline__ wt_rsrc_t wt_make_rsrc(const void* base) {
+  // every out-of-image lane is masked explicitly (voffset = 0xFFFFFFF0 >= num_records => the DMA writes zeros);
+  // in-range voffsets are small, the tile position travels in the (unchecked) scalar offset
+  return __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)0x7FFFFFF0, 0x00020000);
+}
+__device__ __forceinline__ void wt_dma16(wt_rsrc_t r, unsigned char* lds, unsigned voff, unsigned soff) {
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ wt_s16x4 wt_tr_read(const unsigned char* lds) {
+  typedef __attribute__((address_space(3))) wt_s16x4 lds_v;
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v*)lds);
+}
+#else
+struct wt_rsrc_t { int unused; };
+__device__ inline wt_rsrc_t wt_make_rsrc(const void*) { return wt_rsrc_t{0}; }
+__device__ inline void wt_dma16(wt_rsrc_t, unsigned char*, unsigned, unsigned) {}
+__device__ inline wt_s16x4 wt_tr_read(const unsigned char*) { return wt_s16x4{0, 0, 0, 0}; }
+#endif
+
+constexpr int wt_pad_slots(int s) { return s + ((4 - (s & 7)) & 7); }   // next count == 4 (mod 8)
+
+// TM x 32 couts and TN groups (of 32 (tap, ci) columns) per wave; WM x WN waves; XC = 32-channel chunks of X a block stages
+template <int TM, int TN, int WM, int WN, int XC>
+__global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams p) {
+  static_assert(WM * WN == 4, "4 waves");
+  constexpr int TW = 64;                          // pixels per tile
+  // LDS rows: dense [pixel][channel].  tools/probes/tr_read_probe.hip: linear 256-byte rows read as fast as padded
+  // ones with ds_read_b64_tr_b16 (XOR-swizzled rows are slower), so rows of >= 256 bytes stay unpadded; shorter rows
+  // are padded to (4 mod 8) slots so that four consecutive pixel rows spread over the four 64-byte bank quarters
+  constexpr int RDY = 4 * TM * WM >= 16 ? 4 * TM * WM : wt_pad_slots(4 * TM * WM);   // 16-byte slots per dY pixel row
+  constexpr int RX = 4 * XC >= 16 ? 4 * XC : wt_pad_slots(4 * XC);                   // 16-byte slots per X patch pixel
+  constexpr int PXMAX = TW + 2;                   // patch pixels (KW <= 3)
+  constexpr int NDY = RDY;                        // dY DMA instructions per tile (64 pixels x RDY slots / 64 lanes)
+  static_assert(NDY % 4 == 0, "dY instructions split evenly over the waves");
+  constexpr int NDYW = NDY / 4;
+  constexpr int NX = (PXMAX * RX + 63) / 64;      // X DMA instructions per tile
+  constexpr int NXW = (NX + 3) / 4;               // per wave (the last ones may repeat instruction NX-1: benign)
+  constexpr int DYB = NDY * 1024, XB = NX * 1024, STAGE = DYB + XB;
+  constexpr int NS = (163840 / STAGE) >= 4 ? 4 : (163840 / STAGE);
+  static_assert(NS >= 2, "at least two stages must fit the 160 KB LDS");
+  constexpr int NPW = NDYW + NXW;                 // DMA instructions per wave per stage
+  static_assert(NPW * (NS - 2) < 64, "vmcnt is a 6-bit counter");
+  constexpr int WAIT_RUN = ((NPW * (NS - 2)) & 15) | (7 << 4) | (0 << 8) | (((NPW * (NS - 2)) >> 4) << 14);
+  constexpr int WAIT_ALL = 0 | (7 << 4) | (0 << 8);
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int g = lane >> 4, i16 = lane & 15, l31 = lane & 31, lh = lane >> 5;
+
+  // logical block id: slab-major, the (cout tile, column tile) jobs of one slab are neighbours on one XCD
+  int b = xcd_remap(blockIdx.x, p.co_tiles * p.col_tiles * p.S);
+  const int ct = b % p.col_tiles; b /= p.col_tiles;
+  const int cot = b % p.co_tiles;
+  const int s = b / p.co_tiles;
+  const int co0 = cot * (32 * TM * WM);
+  constexpr int NGB = WN * TN;                    // column groups of this block
+  const int gidx0 = ct * NGB;                     // first global group (tap-major: tap * gpt + chunk)
+  const int tap0 = gidx0 / p.gpt;
+  const int kh = tap0 / p.KW;
+  const int chunk_lo = (NGB >= p.gpt) ? 0 : gidx0 % p.gpt;   // first 32-channel chunk staged (whole taps: all of them)
+
+  const int t_begin = (int)(((long long)p.n_tiles * s) / p.S);
+  const int t_end = (int)(((long long)p.n_tiles * (s + 1)) / p.S);
+
+  // ---- DMA lane constants
+  const wt_rsrc_t dy_rsrc = wt_make_rsrc((const char*)p.dy + ((size_t)p.dy_co + co0) * 2);
+  // X base shifted back by `pad` pixels: patch pixel 0 is image column x0 - pad (masked when outside the row)
+  const wt_rsrc_t x_rsrc = wt_make_rsrc((const char*)p.x + ((long long)p.x_co + chunk_lo * 32 - (long long)p.pad * p.x_cs) * 2);
+  unsigned dy_voff[NDYW];
+  int dy_p[NDYW];
+#pragma unroll
+  for (int q = 0; q < NDYW; ++q) {
+    const int slot = 64 * (wave + 4 * q) + lane;
+    const int pp = slot / RDY, sl = slot - pp * RDY;
+    const bool ok = sl < 4 * TM * WM && co0 + 8 * sl < p.Cout;
+    dy_p[q] = ok ? pp : 1 << 20;                                   // pixel of the tile (>= any width: never valid)
+    dy_voff[q] = (unsigned)((pp * p.dy_cs + 8 * sl) * 2);
+  }
+  unsigned x_voff[NXW];
+  int x_p[NXW];
+  const int px_used = TW + p.KW - 1;
+#pragma unroll
+  for (int q = 0; q < NXW; ++q) {
+    int j = wave + 4 * q;
+    j = j < NX ? j : NX - 1;
+    const int slot = 64 * j + lane;
+    const int pp = slot / RX, sl = slot - pp * RX;
+    const bool ok = pp < px_used && sl < 4 * XC && (chunk_lo * 32 + 8 * sl) < p.x_C;
+    x_p[q] = ok ? pp : 1 << 20;
+    x_voff[q] = (unsigned)((pp * p.x_cs + 8 * sl) * 2);
+  }
+
+  // ---- fragment lane constants (bytes inside a stage)
+  //  a (dY): pixel 8*(g>>1) + (i16>>2) (+4 for the second read, +16 per k-step), channels wm*TM*32 + 16*(g&1) + 4*(i16&3) (+32 per tm)
+  const int a_base = (8 * (g >> 1) + (i16 >> 2)) * (RDY * 16) + (wm * TM * 32 + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
+  int b_base[TN], b_tap[TN], b_chunk[TN];
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int gi = gidx0 + wn * TN + j;
+    const int tap = gi / p.gpt, chunk = gi - tap * p.gpt;
+    const int kw = tap - kh * p.KW;
+    b_tap[j] = tap; b_chunk[j] = chunk;
+    b_base[j] = DYB + (8 * (g >> 1) + (i16 >> 2) + kw) * (RX * 16) + ((chunk - chunk_lo) * 32 + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
+  }
+
+  wt_f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // tile t -> (image row r = n*H + y, segment xt)
+  auto issue = [&](int t, int buf) {
+    const int r = t / p.tiles_per_row, xt = t - r * p.tiles_per_row;
+    const int x0 = xt * TW;
+    const int n = r / p.H, y = r - n * p.H;
+    unsigned char* sb = smem + buf * STAGE;
+    {
+      const unsigned soff = (unsigned)(((size_t)r * p.W + x0) * (size_t)p.dy_cs * 2);
+      const int lim = p.W - x0;                                    // valid pixels of this segment
+#pragma unroll
+      for (int q = 0; q < NDYW; ++q)
+        wt_dma16(dy_rsrc, sb + (wave + 4 * q) * 1024, dy_p[q] < lim ? dy_voff[q] : 0xFFFFFFF0u, soff);
+    }
+    {
+      const int yy = y + kh - p.pad;
+      const bool row_ok = (unsigned)yy < (unsigned)p.H;
+      const int yc = row_ok ? yy : y;
+      const unsigned soff = (unsigned)((((size_t)n * p.H + yc) * p.W + x0) * (size_t)p.x_cs * 2);
+      const int lo = p.pad - x0, hi = p.W - x0 + p.pad;            // patch pixel pp is image column x0 - pad + pp
+#pragma unroll
+      for (int q = 0; q < NXW; ++q) {
+        int j = wave + 4 * q;
+        j = j < NX ? j : NX - 1;
+        const bool ok = row_ok && x_p[q] >= lo && x_p[q] < hi;
+        wt_dma16(x_rsrc, sb + DYB + j * 1024, ok ? x_voff[q] : 0xFFFFFFF0u, soff);
+      }
+    }
+  };
+
+  // ---- fragment reads: inline asm (the ds_read_tr16 builtin makes hipcc wait vmcnt(0) for every pending LDS-DMA before
+  // the first read of a k-step, which serialises the pipeline; plain asm reads are invisible to that pass), so the
+  // LDS counter is managed by hand: reads of k-step k+1 are issued in two halves around the MFMAs of k-step k,
+  // "lgkmcnt(half)" at the top of a step says the CURRENT step's fragments have all landed (LDS returns in order).
+  constexpr int NR = 2 * (TM + TN);                 // tr reads per k-step
+  constexpr int NH1 = NR / 2, NH2 = NR - NH1;
+  static_assert(NH1 <= 15, "lgkmcnt is a 4-bit counter");
+  constexpr int KSTEPS = TW / 16;
+  static_assert(KSTEPS % 2 == 0, "fragment sets alternate by k-step parity");
+  wt_s16x4 fr[2][NR];                               // [set][read]: reads 2i, 2i+1 = a[i] (lo, hi); 2TM + 2j, +1 = b[j]
+  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
+#define WT_READ(DST, ADDR, OFF) asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(OFF) : "memory")
+  // reads [R0, R1) of k-step KS of the stage at byte address SB (a VGPR base per operand) into set SET
+#define WT_READS(SET, KS, R0, R1, ABASE, BBASE)                                                            \
+  {                                                                                                        \
+    _Pragma("unroll") for (int r = (R0); r < (R1); ++r) {                                                  \
+      if (r < 2 * TM) {                                                                                    \
+        const int i = r >> 1, hi = r & 1;                                                                  \
+        WT_READ(fr[SET][r], ABASE, (KS) * (16 * RDY * 16) + i * 64 + hi * (4 * RDY * 16));                 \
+      } else {                                                                                             \
+        const int j = (r - 2 * TM) >> 1, hi = r & 1;                                                       \
+        WT_READ(fr[SET][r], BBASE[j], (KS) * (16 * RX * 16) + hi * (4 * RX * 16));                         \
+      }                                                                                                    \
+    }                                                                                                      \
+  }
+#define WT_FRAG(SET, R) __builtin_bit_cast(wt_bf16x8, __builtin_shufflevector(fr[SET][2 * (R)], fr[SET][2 * (R) + 1], 0, 1, 2, 3, 4, 5, 6, 7))
+  // MFMAs [M0, M1) of the TM x TN grid (row-major) on set SET
+#define WT_MMAS(SET, M0, M1)                                                                               \
+  {                                                                                                        \
+    _Pragma("unroll") for (int m = (M0); m < (M1); ++m) {                                                  \
+      const int i = m / TN, j = m - i * TN;                                                                \
+      acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WT_FRAG(SET, i), WT_FRAG(SET, TM + j), acc[i][j], 0, 0, 0); \
+    }                                                                                                      \
+  }
+  constexpr int WAIT_H1 = 0x3F | (7 << 4) | (NH1 << 8) | (3 << 14);    // lgkmcnt(NH1), vmcnt untouched
+  constexpr int WAIT_L0 = 0x3F | (7 << 4) | (0 << 8) | (3 << 14);      // lgkmcnt(0)
+
+  if (t_begin < t_end) {
+    // prologue: NS-1 tiles in flight, the first one landed
+#pragma unroll
+    for (int q = 0; q < NS - 1; ++q)
+      if (t_begin + q < t_end) issue(t_begin + q, q);
+    if (t_begin + NS - 1 <= t_end) __builtin_amdgcn_s_waitcnt(WAIT_RUN);
+    else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    int rb = 0, wb = NS - 1;
+    unsigned a_addr = lds0 + (unsigned)a_base;
+    unsigned b_addr[TN];
+#pragma unroll
+    for (int j = 0; j < TN; ++j) b_addr[j] = lds0 + (unsigned)b_base[j];
+    WT_READS(0, 0, 0, NR, a_addr, b_addr)                 // first k-step of the first tile
+    for (int t = t_begin; t < t_end; ++t) {
+      const bool more = t + NS - 1 < t_end;
+      if (more) issue(t + NS - 1, wb);      // that buffer was read in tile t-1: every wave passed the barrier after its reads
+      const int nb = rb == NS - 1 ? 0 : rb + 1;
+      const unsigned a_next = lds0 + (unsigned)(a_base + nb * STAGE);
+      unsigned b_next[TN];
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b_next[j] = lds0 + (unsigned)(b_base[j] + nb * STAGE);
+#pragma unroll
+      for (int ks = 0; ks < KSTEPS; ++ks) {
+        const int cur = ks & 1, nxt = cur ^ 1;
+        if (ks + 1 < KSTEPS) {
+          WT_READS(nxt, ks + 1, 0, NH1, a_addr, b_addr)
+          __builtin_amdgcn_s_waitcnt(WAIT_H1);             // set `cur` has landed
+        } else {
+          // last k-step of the tile: every LDS read of this tile has been issued; once they are back the stage is
+          // free, and tile t+1 must have landed before its first fragments are fetched
+          if (t + 1 < t_end) {
+            if (more) __builtin_amdgcn_s_waitcnt(WAIT_RUN);   // lgkmcnt(0) + this wave's DMA of tile t+1
+            else __builtin_amdgcn_s_waitcnt(WAIT_ALL);
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            WT_READS(nxt, 0, 0, NH1, a_next, b_next)
+            __builtin_amdgcn_s_waitcnt(WAIT_H1);
+          } else {
+            __builtin_amdgcn_s_waitcnt(WAIT_L0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        WT_MMAS(cur, 0, (TM * TN) / 2)
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 1 < KSTEPS) {
+          WT_READS(nxt, ks + 1, NH1, NR, a_addr, b_addr)
+        } else if (t + 1 < t_end) {
+          WT_READS(nxt, 0, NH1, NR, a_next, b_next)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        WT_MMAS(cur, (TM * TN) / 2, TM * TN)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      a_addr = a_next;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) b_addr[j] = b_next[j];
+      rb = nb;
+      wb = wb == NS - 1 ? 0 : wb + 1;
+    }
+  }
+#undef WT_READ
+#undef WT_READS
+#undef WT_FRAG
+#undef WT_MMAS
+
+  // D[i = cout][j = ci]: col = lane&31 (ci), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
+  const int taps = p.KH * p.KW;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int ci = b_chunk[j] * 32 + l31;
+    if (b_tap[j] >= taps || ci >= p.ci_real) continue;
+    float* wsp = p.ws + ((size_t)s * taps + b_tap[j]) * p.Cout * p.CinTot;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const int co = co0 + (wm * TM + i) * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);
+        if (co < p.Cout) wsp[(size_t)co * p.CinTot + p.ci_base + ci] = acc[i][j][e];
+      }
+  }
+}
+
+// column sums of a bf16 [P][cs] tensor (bias gradient next to the kernel above), two deterministic stages
+__global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned short* __restrict__ x, long long P, int C,
+                                                                  int cs, int co, int NB, float* __restrict__ part) {
+  // block b sums pixels [P*b/NB, P*(b+1)/NB); thread (pr, c8): 8 channels of every (256/groups)-th pixel
+  const int groups = (C + 7) / 8;
+  const int per = 256 / groups;                     // pixel lanes per block (host guarantees groups <= 256)
+  const int c8 = threadIdx.x % groups, pr = threadIdx.x / groups;
+  const long long p0 = P * blockIdx.x / NB, p1 = P * (blockIdx.x + 1) / NB;
+  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  if (pr < per)
+    for (long long q = p0 + pr; q < p1; q += per) {
+      const uint4 v = *reinterpret_cast<const uint4*>(x + q * cs + co + c8 * 8);
+      const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        sum[2 * k] += __builtin_bit_cast(float, w[k] << 16);
+        sum[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xFFFF0000u);
+      }
+    }
+  __shared__ float red[256 * 8];
+#pragma unroll
+  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sum[k];
+  __syncthreads();
+  if (threadIdx.x < groups * 8) {
+    const int gq = threadIdx.x / 8, k = threadIdx.x % 8;
+    float t = 0.f;
+    for (int r = 0; r < per; ++r) t += red[(r * groups + gq) * 8 + k];   // fixed order
+    if (gq * 8 + k < C) part[(size_t)blockIdx.x * C + gq * 8 + k] = t;
+  }
+}
+
+__global__ void colsum_bf16_final_kernel(const float* __restrict__ part, int NB, int C, float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float t = 0.f;
+  for (int b = 0; b < NB; ++b) t += part[(size_t)b * C + c];
+  out[c] = accumulate ? out[c] + t : t;
+}
+
+// Host side.  Returns 1 when the kernel was launched (partials in `workspace`, *S_out slabs), 0 when the shape is
+// not one it serves (the caller falls back to conv_wgrad_bf16_kernel), < 0 on error.
+int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, int x_C, int x_cs, int x_co, int x_C_real,
+                 int ci_base, int CinTot, int N, int H, int W, int KH, int KW, int pad, float* workspace,
+                 long long workspace_bytes, float* dbias, int dbias_accumulate, hipStream_t st, int* S_out) {
+  const char* env = getenv("HRV_WGRAD_TR");
+  if (env && env[0] == '0') return 0;
+  if (KW < 1 || KW > 3 || KH != KW || pad != KH / 2) return 0;
+  if ((Cout | dy_cs | dy_co | x_cs | x_co | x_C) & 7) return 0;                  // 16-byte DMA granules
+  const long long P = (long long)N * H * W;
+  if (P < 32768 || W < 32) return 0;                                              // low-resolution levels: weight-bound, old kernel
+  if (P * dy_cs * 2 >= 0x7FF00000LL || P * x_cs * 2 >= 0x7FF00000LL) return 0;    // 31-bit scalar offsets
+  const int gpt = (x_C + 31) / 32;
+  if (gpt != 4) return 0;                        // instantiated: 128-channel sources (the SPADE gamma|beta convolutions)
+  WgradTrParams p;
+  p.dy = dy; p.dy_cs = dy_cs; p.dy_co = dy_co; p.Cout = Cout;
+  p.x = x; p.x_cs = x_cs; p.x_co = x_co; p.x_C = x_C;
+  p.N = N; p.H = H; p.W = W; p.KH = KH; p.KW = KW; p.pad = pad;
+  p.CinTot = CinTot; p.ci_base = ci_base; p.ci_real = x_C_real;
+  p.gpt = gpt;
+  p.co_tiles = (Cout + 159) / 160;
+  const int tm = (((Cout + p.co_tiles - 1) / p.co_tiles) + 31) / 32;             // 1..5
+  const int NGB = 12;                                                              // WN 4 x TN 3
+  if ((KW * gpt) % NGB != 0) return 0;                                             // a block = whole taps of ONE kernel row
+  p.col_tiles = KH * KW * gpt / NGB;
+  p.tiles_per_row = (W + 63) / 64;
+  p.n_tiles = N * H * p.tiles_per_row;
+  const int jobs = p.co_tiles * p.col_tiles;
+  int S = (256 + jobs - 1) / jobs;                                                 // one block per CU
+  if (S > p.n_tiles / 8) S = p.n_tiles / 8;
+  if (S > 256) S = 256;
+  if (S < 1) S = 1;
+  const long long need = ((long long)S * KH * KW * Cout * CinTot + 256LL * Cout) * 4;
+  if (workspace_bytes < need) {
+    set_error("wgrad_tr: workspace too small (%lld < %lld)", workspace_bytes, need);
+    return HRV_ERR_ARG;
+  }
+  p.S = S; p.ws = workspace;
+  const int nblk = jobs * S;
+  switch (tm) {
+    case 1: hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 2: hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 3: hipLaunchKernelGGL((conv_wgrad_tr_kernel<3, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 4: hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+    case 5: hipLaunchKernelGGL((conv_wgrad_tr_kernel<5, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
+    default: return 0;
+  }
+  int rc = check_launch("conv_wgrad_tr_kernel");
+  if (rc) return rc;
+  if (dbias) {
+    float* part = workspace + (size_t)S * KH * KW * Cout * CinTot;
+    if ((Cout + 7) / 8 > 256) { set_error("wgrad_tr: bias gradient supports Cout <= 2048"); return HRV_ERR_ARG; }
+    hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(256), dim3(256), 0, st, (const unsigned short*)dy, P, Cout, dy_cs,
+                       dy_co, 256, part);
+    rc = check_launch("colsum_bf16_partial_kernel");
+    if (rc) return rc;
+    hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((Cout + 127) / 128), dim3(128), 0, st, part, 256, Cout, dbias,
+                       dbias_accumulate);
+    rc = check_launch("colsum_bf16_final_kernel");
+    if (rc) return rc;
+  }
+  *S_out = S;
+  return 1;
+}
+
+}  // namespace hrv

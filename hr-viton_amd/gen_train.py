@@ -519,7 +519,8 @@ class DiscTrainPlan:
             a = f
         return feats, ctx
 
-    def backward(self, ctx, dfeats: List[Optional[Act]], grads: Grads, need_dx: bool, rows: Optional[int] = None) -> Optional[Act]:
+    def backward(self, ctx, dfeats: List[Optional[Act]], grads: Grads, need_dx: bool, rows: Optional[int] = None,
+                 need_w: bool = True) -> Optional[Act]:
         """``rows``: only the first ``rows`` samples of the batch carry a gradient (the fake half in the
         generator step: the real half is a detached target) -- every saved tensor is cut to that prefix."""
         def cut(a):
@@ -546,7 +547,7 @@ class DiscTrainPlan:
                 d_c = d
             else:
                 d_c = d
-            d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx))
+            d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx), need_w=need_w)
         return d_next
 
 
@@ -567,14 +568,14 @@ class MultiscaleDTrainPlan:
                 a = ops.avgpool3x3s2(a)
         return feats_all, dict(ctxs=ctxs, inputs=inputs)
 
-    def backward(self, ctx, dfeats_all, need_dx: bool, rows: Optional[int] = None):
+    def backward(self, ctx, dfeats_all, need_dx: bool, rows: Optional[int] = None, need_w: bool = True):
         grads: Grads = {}
         d_in_next: Optional[Act] = None
         for k in range(len(self.plans) - 1, -1, -1):
             a = ctx["inputs"][k]
             if rows is not None:
                 a = Act(a.t[:rows], a.C, a.coff)
-            d_a = self.plans[k].backward(ctx["ctxs"][k], dfeats_all[k], grads, need_dx, rows)
+            d_a = self.plans[k].backward(ctx["ctxs"][k], dfeats_all[k], grads, need_dx, rows, need_w)
             if need_dx:
                 if d_a is None:
                     d_a = Act(torch.zeros_like(a.t), a.C)
@@ -608,6 +609,10 @@ class _DiscFn(torch.autograd.Function):
     def forward(ctx, msd, plan, inp, split, *params):
         feats_all, saved = plan.forward(inp, power_iteration=True)
         ctx.plan, ctx.saved, ctx.params, ctx.split = plan, saved, params, split
+        # generator step: the discriminator's own parameter gradients of loss_G are thrown away by the training script
+        # (optimizer_dis.zero_grad() before the D backward, train_generator.py:354) -- the weight / bias gradient
+        # kernels and the spectral-norm transform are skipped when the caller says so (pipeline.generator_train_step)
+        ctx.need_w = not getattr(msd, "_hrv_discard_param_grads", False)
         ctx.shapes = [[(f.N, f.H, f.W, f.C) for f in fs] for fs in feats_all]
         ctx.in_shape = tuple(inp.shape)
         outs = []
@@ -654,7 +659,7 @@ class _DiscFn(torch.autograd.Function):
                     row.append(None if d is None else _nhwc_act(d, c))
                 dfeats_all.append(row)
         need_dx = ctx.needs_input_grad[2]
-        grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx, rows)
+        grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx, rows, ctx.need_w)
         ctx.saved = None
         d_inp = None
         if need_dx and d_in is not None:

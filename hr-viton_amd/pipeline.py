@@ -77,7 +77,11 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
     output_paired = generator(x, parse7)
     fake_concat = torch.cat((parse_nchw, output_paired), dim=1)
     real_concat = torch.cat((parse_nchw, im), dim=1)
-    pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)   # :283-295
+    discriminator._hrv_discard_param_grads = True      # :354 zeroes D's gradients of loss_gen before they are ever used
+    try:
+        pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)   # :283-295
+    finally:
+        discriminator._hrv_discard_param_grads = False
     losses = {"GAN": crit_gan(pred_fake, True, for_discriminator=False)}
     if not getattr(opt, "no_ganFeat_loss", False):
         num_D = len(pred_fake)
@@ -190,7 +194,11 @@ def condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d
         losses["loss_G"] = loss_G
         return losses
     fake_segmap_softmax = HF.softmax(fake_segmap, 1)                            # :260
-    pred_segmap = D(torch.cat((input1.detach(), input2.detach(), fake_segmap_softmax), dim=1))
+    D._hrv_discard_param_grads = True                   # optimizer_D.zero_grad() (:284) discards them
+    try:
+        pred_segmap = D(torch.cat((input1.detach(), input2.detach(), fake_segmap_softmax), dim=1))
+    finally:
+        D._hrv_discard_param_grads = False
     loss_G_GAN = crit_gan(pred_segmap, True)
     loss_G = (10 * loss_l1_cloth + loss_vgg + opt.tvlambda * loss_tv) + (CE_loss * opt.CElamda + loss_G_GAN * opt.GANlambda)
     opt_g.zero_grad()

@@ -98,8 +98,16 @@ def _grad_table(mod, sd):
 
 
 def compare_generator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: int = 1, seed: int = 0, wmul: float = 8.0,
-                           mixed: bool = False, with_vgg: bool = True, table_path: Optional[str] = None,
-                           cpu_threads: int = 0) -> dict:
+                           mixed=False, with_vgg: bool = True, table_path: Optional[str] = None,
+                           cpu_threads: int = 0):
+    """``mixed``: False / True, or a tuple of engines, e.g. (False, True): ONE oracle pass, one HIP pass per engine,
+    returns {engine: report} (the CPU pass dominates the cost)."""
+    if isinstance(mixed, (tuple, list)):
+        return _compare(H, W, ngf, ndf, N, seed, wmul, tuple(mixed), with_vgg, table_path, cpu_threads)
+    return _compare(H, W, ngf, ndf, N, seed, wmul, (mixed,), with_vgg, table_path, cpu_threads)[mixed]
+
+
+def _compare(H, W, ngf, ndf, N, seed, wmul, engines, with_vgg, table_path, cpu_threads) -> dict:
     """Runs the generator half of one iteration on cuda:0 (product classes) and on the CPU oracle with identical
     weights, inputs and SPADE noise.  Returns max-rel errors of the image and the loss terms, the worst / median
     per-parameter gradient error and cosine, and optionally writes the per-parameter table."""
@@ -118,6 +126,24 @@ def compare_generator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: int 
     gen.cuda().train()
     D.cuda().train()
     vgg.cuda()
+    sd0_g = {k: v.detach().clone() for k, v in gen.state_dict().items()}       # u, v are advanced by every forward
+    sd0_d = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    reports = {}
+    for mixed in engines:
+        gen.load_state_dict(sd0_g)
+        D.load_state_dict(sd0_d)
+        for p_ in list(gen.parameters()) + list(D.parameters()):
+            p_.grad = None
+        reports[mixed] = _hip_pass(opt, gen, D, vgg, x, seg, real, noise, mixed, with_vgg, losses, fake, sd_g, N, H, W, ngf,
+                                   t_oracle, None if table_path is None else
+                                   (table_path if len(engines) == 1 else table_path.replace(".txt", "_bf16.txt" if mixed else "_f32.txt")))
+    return reports
+
+
+def _hip_pass(opt, gen, D, vgg, x, seg, real, noise, mixed, with_vgg, losses, fake, sd_g, N, H, W, ngf, t_oracle, table_path):
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import train_ops as T
+    from hr_viton_amd.losses import GANLoss, L1Loss
     T.MMA_BF16[0] = mixed
     try:
         xc, sc, rc = x.cuda(), seg.cuda(), real.cuda()

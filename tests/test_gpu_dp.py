@@ -21,9 +21,19 @@ def _free_port():
     return p
 
 
+def _watchdog(tag, rank):
+    """a hung rank writes its Python stacks to gpurun_out/ instead of dying silently with the parent's timeout"""
+    import faulthandler
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    f = open(os.path.join(ROOT, "gpurun_out", f"dp_{tag}_rank{rank}_stacks.txt"), "w")
+    faulthandler.dump_traceback_later(90, repeat=False, file=f, exit=False)
+    return f
+
+
 def _worker(rank, world, port, q):
     try:
         sys.path.insert(0, ROOT)
+        _wd = _watchdog("cond", rank)
         os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port), HRV_DIST_BACKEND="gloo")
         import torch.distributed as dist
@@ -80,7 +90,7 @@ def test_two_rank_condition_training_keeps_replicas_identical():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=150) for _ in range(2))
     for p in procs:
         p.join(60)
     for r in res:
@@ -100,6 +110,7 @@ def _gen_worker(rank, world, port, q):
         sys.path.insert(0, ROOT)
         os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
                           MASTER_PORT=str(port), HRV_DIST_BACKEND="gloo")
+        _wd = _watchdog("gen", rank)
         from argparse import Namespace
         import torch.distributed as dist
         import hr_viton_amd  # noqa: F401
@@ -171,7 +182,7 @@ def test_two_rank_generator_training_keeps_replicas_identical():
     procs = [ctx.Process(target=_gen_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    res = sorted(q.get(timeout=300) for _ in range(2))
+    res = sorted(q.get(timeout=150) for _ in range(2))
     for p in procs:
         p.join(60)
     for r in res:

@@ -423,3 +423,52 @@ def test_mixed_precision_bf16_stored_operands_are_bit_identical(case, dy_bf16):
     got = outs[True][2][:, 8:8 + cin].cpu()
     assert (got - ref).abs().max() <= 3e-5 * ref.abs().max() + 1e-5
     assert (outs[True][3].cpu() - dy.cpu().sum((0, 2, 3))).abs().max() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item()
+
+
+@pytest.mark.parametrize("case", [("gb_up4", 160, 1, 128, 256, False), ("gb_norm1", 64, 2, 136, 128, False),
+                                  ("gb_up3_two_cout_tiles", 288, 1, 352, 96, False), ("sliced_partial_row", 128, 1, 260, 160, True)],
+                         ids=lambda c: c[0])
+def test_wgrad_tr_kernel_bf16_stored_operands(case, monkeypatch):
+    """conv_wgrad_tr_kernel (wgrad_tr.hip: LDS-DMA staging + ds_read_b64_tr_b16 fragments, bf16-STORED dY and X, 128-channel
+    source = the SPADE gamma|beta convolutions) vs torch's conv2d_weight on the same bf16-representable operands (fp32
+    accumulation: only the summation order differs) and vs the register-transposing kernel it replaces (HRV_WGRAD_TR=0).
+    Covers: one / two cout tiles, a row width that is not a multiple of the 64-pixel tile (masked tail, 96 and 160),
+    image-border rows and columns (zero padding by out-of-range DMA offsets), channel slices of wider tensors, the bias
+    gradient."""
+    ops, T = _mods()
+    name, cout, N, H, W, wide = case
+    cin, k, pad = 128, 3, 1
+    g = torch.Generator().manual_seed(cout + H)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g))
+    dy = rb(torch.randn(N, cout, H, W, generator=g) * (torch.rand(N, cout, H, W, generator=g) > 0.3))
+
+    def as_act(t):
+        if not wide:
+            return ops.to_nhwc(t.cuda(), bf16=True)
+        C_ = t.shape[1]
+        full = ops.alloc(t.shape[0], t.shape[2], t.shape[3], C_ + 24, "cuda", bf16=True)
+        full.t.normal_()                                      # neighbours of the slice must not leak in
+        ops.to_nhwc(t.cuda(), out=full.slice(16, C_))
+        return full.slice(16, C_)
+
+    res = {}
+    T.MMA_BF16[0] = True
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("HRV_WGRAD_TR", mode)
+            dw = torch.full((cout, cin + 8, k, k), 7.0, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            T.conv_wgrad(as_act(dy), as_act(x), 0, 8, cin + 8, k, k, 1, pad, dw, name=name, dbias=db)
+            torch.cuda.synchronize()
+            res[mode] = (dw.cpu(), db.cpu())
+    finally:
+        T.MMA_BF16[0] = False
+    ref = torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dy, stride=1, padding=pad)
+    scale = ref.abs().max().item()
+    got = res["1"][0]
+    assert torch.equal(got[:, :8], torch.full((cout, 8, k, k), 7.0)), "columns outside [ci_base, ci_base+C) must stay untouched"
+    assert (got[:, 8:] - ref).abs().max().item() <= 3e-5 * scale + 1e-5, (got[:, 8:] - ref).abs().max().item() / scale
+    assert (got[:, 8:] - res["0"][0][:, 8:]).abs().max().item() <= 6e-5 * scale
+    dbr = dy.sum((0, 2, 3))
+    assert (res["1"][1] - dbr).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item()
