@@ -46,4 +46,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// Launch geometry shared by the per-(sample, channel) reduction kernels (InstanceNorm statistics, SPADE / InstanceNorm
+// backward): grid = (pixel slabs, samples, channel chunks).  A block covers <= NORM_GCAP groups of 4 channels, so the
+// 1040-channel / 64x48-pixel levels of the generator spread over 5 x 24 x N blocks instead of 6 x N (they ran at
+// 50-200 GB/s), and slabs are >= 128 pixels (fixed-order second stage over <= 256 slab partials).
+constexpr int NORM_GCAP = 64;
+inline int norm_slabs(int HW) {
+  int nb = (HW + 127) / 128;
+  return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+}
+inline int norm_chunks(int C4) { return (C4 + NORM_GCAP - 1) / NORM_GCAP; }
+
 }  // namespace hrv

@@ -49,11 +49,11 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams
   const int HW = p.H * p.W;
   const int PB = (HW + p.NB - 1) / p.NB;
   const int p0 = b * PB, p1 = min(p0 + PB, HW);
-  const int GB = p.C4 < 256 ? p.C4 : 256;  // channel groups handled per pass
-  const int R = 256 / GB;                  // pixel rows in flight per pass
+  const int GB = p.C4 < NORM_GCAP ? p.C4 : NORM_GCAP;   // channel groups of this block (blockIdx.z picks the chunk)
+  const int R = 256 / GB;                  // pixel rows in flight
   const int r = t / GB, gl = t - r * GB;
-  for (int g0 = 0; g0 < p.C4; g0 += GB) {
-    const int g = g0 + gl;
+  {
+    const int g = blockIdx.z * GB + gl;
     const bool active = r < R && g < p.C4;
     f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
     if (active) {
@@ -89,7 +89,6 @@ __global__ __launch_bounds__(256) void instnorm_partial_kernel(const StatsParams
         dst[2 * e + 1] = s2[e];
       }
     }
-    __syncthreads();
   }
 }
 
@@ -184,10 +183,7 @@ using namespace hrv;
 
 extern "C" int64_t hrv_instnorm_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
-  const int HW = H * W;
-  int nb = (HW + 511) / 512;
-  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
-  return (int64_t)N * nb * ((C + 3) / 4 * 4) * 2;
+  return (int64_t)N * norm_slabs(H * W) * ((C + 3) / 4 * 4) * 2;
 }
 
 template <bool BF>
@@ -202,12 +198,10 @@ static int instnorm_stats_impl(const void* x, int32_t N, int32_t H, int32_t W, i
   StatsParams p;
   p.x = (const float*)x; p.N = N; p.H = H; p.W = W; p.C4 = C / 4; p.cs = cstride; p.co = coff;
   p.z = noise_z; p.ns = noise_scale;
-  const int HW = H * W;
-  int nb = (HW + 511) / 512;
-  p.NB = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  p.NB = norm_slabs(H * W);
   p.part = workspace;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(instnorm_partial_kernel<BF>, dim3(p.NB, N), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(instnorm_partial_kernel<BF>, dim3(p.NB, N, norm_chunks(p.C4)), dim3(256), 0, st, p);
   int rc = check_launch("instnorm_partial_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(instnorm_finalize_kernel<BF>, dim3((N * C + 3) / 4), dim3(256), 0, st, p, eps, mean, rstd);

@@ -63,11 +63,11 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
   const int HW = p.H * p.W, C = p.C4 * 4;
   const int PB = (HW + p.NB - 1) / p.NB;
   const int p0 = b * PB, p1 = min(p0 + PB, HW);
-  const int GB = p.C4 < 256 ? p.C4 : 256;
+  const int GB = p.C4 < NORM_GCAP ? p.C4 : NORM_GCAP;   // channel groups of this block (blockIdx.z picks the chunk)
   const int R = 256 / GB;
   const int r = t / GB, gl = t - r * GB;
-  for (int g0 = 0; g0 < p.C4; g0 += GB) {
-    const int g = g0 + gl;
+  {
+    const int g = blockIdx.z * GB + gl;
     f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f);
     if (r < R && g < p.C4) {
       const f32x4 mu = ld4(p.mean + (size_t)n * C + g * 4), rs = ld4(p.rstd + (size_t)n * C + g * 4);
@@ -113,7 +113,6 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
 #pragma unroll
       for (int e = 0; e < 4; ++e) { dst[2 * e] = s1[e]; dst[2 * e + 1] = s2[e]; }
     }
-    __syncthreads();
   }
 }
 
@@ -151,11 +150,11 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
   const int HW = p.H * p.W, C = p.C4 * 4;
   const int PB = (HW + p.NB - 1) / p.NB;
   const int p0 = b * PB, p1 = min(p0 + PB, HW);
-  const int GB = p.C4 < 256 ? p.C4 : 256;
+  const int GB = p.C4 < NORM_GCAP ? p.C4 : NORM_GCAP;
   const int R = 256 / GB;
   const int r = t / GB, gl = t - r * GB;
-  for (int g0 = 0; g0 < p.C4; g0 += GB) {
-    const int g = g0 + gl;
+  {
+    const int g = blockIdx.z * GB + gl;
     f32x4 sz = (f32x4)(0.f);
     if (r < R && g < p.C4) {
       const size_t sc = (size_t)n * C + g * 4;
@@ -185,7 +184,6 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
         for (int rr = 1; rr < R; ++rr) sz += red[rr * GB + gl];
         *reinterpret_cast<f32x4*>(p.part + ((size_t)n * p.NB + b) * C + g * 4) = sz;
       }
-      __syncthreads();
     }
   }
 }
@@ -489,8 +487,7 @@ using namespace hrv;
 
 extern "C" int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;
-  int nb = (H * W + 511) / 512;
-  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  const int nb = norm_slabs(H * W);
   return (int64_t)N * nb * ((C + 3) / 4 * 4) * 2 + (int64_t)N * ((C + 3) / 4 * 4) * 2;
 }
 
@@ -503,8 +500,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
                 d->dout_coff | d->dnh_cstride | d->dnh_coff | d->dgb_cstride | d->dgb_coff | d->dx_cstride | d->dx_coff) & 3) == 0,
               "norm_bwd: strides/offsets must be multiples of 4");
   const int HW = d->H * d->W, C = d->C;
-  int nb = (HW + 511) / 512;
-  nb = nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  const int nb = norm_slabs(HW);
   float* part = d->workspace;
   float* m1 = part + (size_t)d->N * nb * C * 2;
   float* m2 = m1 + (size_t)d->N * C;
@@ -518,7 +514,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;
   p.dgb_bf16 = d->dgb_bf16; p.out_bf16 = d->out_bf16;
-  hipLaunchKernelGGL(norm_bwd_stage1_kernel, dim3(nb, d->N), dim3(256), 0, st, p);
+  hipLaunchKernelGGL(norm_bwd_stage1_kernel, dim3(nb, d->N, norm_chunks(C / 4)), dim3(256), 0, st, p);
   int rc = check_launch("norm_bwd_stage1_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((d->N * C + 255) / 256), dim3(256), 0, st, part, d->N, nb, C, HW, m1, m2);
@@ -530,7 +526,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff;
   q.dx = d->dx; q.dx_cs = d->dx_cstride; q.dx_co = d->dx_coff; q.accumulate = d->dx_accumulate;
   q.N = d->N; q.H = d->H; q.W = d->W; q.C4 = C / 4; q.NB = nb; q.part = part;  // partials are free again
-  hipLaunchKernelGGL(norm_bwd_stage2_kernel, dim3(nb, d->N), dim3(256), 0, st, q);
+  hipLaunchKernelGGL(norm_bwd_stage2_kernel, dim3(nb, d->N, norm_chunks(C / 4)), dim3(256), 0, st, q);
   rc = check_launch("norm_bwd_stage2_kernel");
   if (rc) return rc;
   if (d->noise_z && d->dnoise_scale) {

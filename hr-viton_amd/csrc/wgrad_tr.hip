@@ -108,10 +108,14 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   const int t_begin = (int)(((long long)p.n_tiles * s) / p.S);
   const int t_end = (int)(((long long)p.n_tiles * (s + 1)) / p.S);
 
-  // ---- DMA lane constants
-  const wt_rsrc_t dy_rsrc = wt_make_rsrc((const char*)p.dy + ((size_t)p.dy_co + co0) * 2);
-  // X base shifted back by `pad` pixels: patch pixel 0 is image column x0 - pad (masked when outside the row)
-  const wt_rsrc_t x_rsrc = wt_make_rsrc((const char*)p.x + ((long long)p.x_co + chunk_lo * 32 - (long long)p.pad * p.x_cs) * 2);
+  // ---- DMA lane constants.  The buffer resources are based at the first image row of this block's slab (64-bit
+  // pointer arithmetic once per block), so the per-tile scalar offsets stay small whatever the tensor size (the
+  // 384-channel actv tensor of up_4 is 2.4 GB).
+  const int r_base = t_begin / p.tiles_per_row;                    // global row index n*H + y of the slab's first tile
+  const wt_rsrc_t dy_rsrc = wt_make_rsrc((const char*)p.dy + ((long long)r_base * p.W * p.dy_cs + p.dy_co + co0) * 2);
+  // X base shifted back by `pad` rows and `pad` pixels: patch pixel 0 of a tile is image column x0 - pad, its row may
+  // be row - pad (both masked when outside the image; the address is never dereferenced then)
+  const wt_rsrc_t x_rsrc = wt_make_rsrc((const char*)p.x + (((long long)(r_base - p.pad) * p.W - p.pad) * p.x_cs + p.x_co + chunk_lo * 32) * 2);
   unsigned dy_voff[NDYW];
   int dy_p[NDYW];
 #pragma unroll
@@ -164,7 +168,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
     const int n = r / p.H, y = r - n * p.H;
     unsigned char* sb = smem + buf * STAGE;
     {
-      const unsigned soff = (unsigned)(((size_t)r * p.W + x0) * (size_t)p.dy_cs * 2);
+      const unsigned soff = (unsigned)(((r - r_base) * p.W + x0) * p.dy_cs * 2);
       const int lim = p.W - x0;                                    // valid pixels of this segment
 #pragma unroll
       for (int q = 0; q < NDYW; ++q)
@@ -174,7 +178,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
       const int yy = y + kh - p.pad;
       const bool row_ok = (unsigned)yy < (unsigned)p.H;
       const int yc = row_ok ? yy : y;
-      const unsigned soff = (unsigned)((((size_t)n * p.H + yc) * p.W + x0) * (size_t)p.x_cs * 2);
+      const unsigned soff = (unsigned)(((n * p.H + yc - (r_base - p.pad)) * p.W + x0) * p.x_cs * 2);
       const int lo = p.pad - x0, hi = p.W - x0 + p.pad;            // patch pixel pp is image column x0 - pad + pp
 #pragma unroll
       for (int q = 0; q < NXW; ++q) {
@@ -330,11 +334,11 @@ __global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned
 #pragma unroll
   for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sum[k];
   __syncthreads();
-  if (threadIdx.x < groups * 8) {
-    const int gq = threadIdx.x / 8, k = threadIdx.x % 8;
+  for (int c = threadIdx.x; c < groups * 8; c += 256) {                    // (up to 2048 channels: more than one pass)
+    const int gq = c / 8, k = c % 8;
     float t = 0.f;
     for (int r = 0; r < per; ++r) t += red[(r * groups + gq) * 8 + k];   // fixed order
-    if (gq * 8 + k < C) part[(size_t)blockIdx.x * C + gq * 8 + k] = t;
+    if (c < C) part[(size_t)blockIdx.x * C + c] = t;
   }
 }
 
@@ -357,7 +361,6 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   if ((Cout | dy_cs | dy_co | x_cs | x_co | x_C) & 7) return 0;                  // 16-byte DMA granules
   const long long P = (long long)N * H * W;
   if (P < 32768 || W < 32) return 0;                                              // low-resolution levels: weight-bound, old kernel
-  if (P * dy_cs * 2 >= 0x7FF00000LL || P * x_cs * 2 >= 0x7FF00000LL) return 0;    // 31-bit scalar offsets
   const int gpt = (x_C + 31) / 32;
   if (gpt != 4) return 0;                        // instantiated: 128-channel sources (the SPADE gamma|beta convolutions)
   WgradTrParams p;
@@ -378,6 +381,9 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   if (S > p.n_tiles / 8) S = p.n_tiles / 8;
   if (S > 256) S = 256;
   if (S < 1) S = 1;
+  // per-tile scalar offsets are relative to the slab's first row: the slab's extent must fit 31 bits
+  const long long slab_rows = p.n_tiles / S / p.tiles_per_row + 4;
+  if (slab_rows * W * (long long)(dy_cs > x_cs ? dy_cs : x_cs) * 2 >= 0x7FF00000LL) return 0;
   const long long need = ((long long)S * KH * KW * Cout * CinTot + 256LL * Cout) * 4;
   if (workspace_bytes < need) {
     set_error("wgrad_tr: workspace too small (%lld < %lld)", workspace_bytes, need);
