@@ -16,8 +16,8 @@
 //   * a block owns a (cout tile) x (one kernel row: KW taps x 32*XC input channels) tile of dW and keeps it in
 //     registers (TM x TN x 16 accumulators per lane) while it streams its slab of the image; the kernel rows /
 //     cout tiles of one slab are neighbouring blocks of one XCD (they re-read the same dY rows out of L2).
-// LDS rows shorter than 256 bytes are padded to (4 mod 8) 16-byte slots (pad slots are DMA'd as zeros by out-of-range
-// offsets); rows of 256 bytes and more are dense.
+// LDS rows are padded to (4 mod 8) 16-byte slots so the four pixel rows of a transposing read fall into the four
+// 64-byte bank quarters (pad slots are DMA'd as zeros by out-of-range offsets).
 // Partial sums go to the same [S][tap][Cout][CinTot] workspace as the other weight-gradient kernels (fixed-order
 // reduce => deterministic).
 #include "hrv_common.h"
@@ -68,11 +68,13 @@ template <int TM, int TN, int WM, int WN, int XC>
 __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TW = 64;                          // pixels per tile
-  // LDS rows: dense [pixel][channel].  tools/probes/tr_read_probe.hip: linear 256-byte rows read as fast as padded
-  // ones with ds_read_b64_tr_b16 (XOR-swizzled rows are slower), so rows of >= 256 bytes stay unpadded; shorter rows
-  // are padded to (4 mod 8) slots so that four consecutive pixel rows spread over the four 64-byte bank quarters
-  constexpr int RDY = 4 * TM * WM >= 16 ? 4 * TM * WM : wt_pad_slots(4 * TM * WM);   // 16-byte slots per dY pixel row
-  constexpr int RX = 4 * XC >= 16 ? 4 * XC : wt_pad_slots(4 * XC);                   // 16-byte slots per X patch pixel
+  // LDS rows [pixel][channel], padded to (4 mod 8) 16-byte slots: a transposing read of a 32-lane group touches 4
+  // pixel rows x 64 bytes, and banks are (address / 4) mod 64, so the four rows must start in four different 64-byte
+  // quarters of the 256-byte bank line.  Measured on dense 256-byte X rows (profiles/r02_pmc_wgrad_tr.txt, first
+  // build): SQ_LDS_BANK_CONFLICT = 53 % of SQ_LDS_IDX_ACTIVE = exactly the 4-way conflict of the 6 X reads per k-step
+  // next to 10 conflict-free dY reads on 320-byte rows.
+  constexpr int RDY = wt_pad_slots(4 * TM * WM);  // 16-byte slots per dY pixel row
+  constexpr int RX = wt_pad_slots(4 * XC);        // 16-byte slots per X patch pixel
   constexpr int PXMAX = TW + 2;                   // patch pixels (KW <= 3)
   constexpr int NDY = RDY;                        // dY DMA instructions per tile (64 pixels x RDY slots / 64 lanes)
   static_assert(NDY % 4 == 0, "dY instructions split evenly over the waves");
@@ -377,7 +379,16 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   p.tiles_per_row = (W + 63) / 64;
   p.n_tiles = N * H * p.tiles_per_row;
   const int jobs = p.co_tiles * p.col_tiles;
-  int S = (256 + jobs - 1) / jobs;                                                 // one block per CU
+  // one block per CU (a block owns 126-152 KB of LDS): the grid must NOT exceed the CU count, or the surplus blocks
+  // run as a second round on an otherwise idle chip (first build: 258 blocks, kernel time 2x the wave lifetime)
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  int S = n_cu / jobs;
   if (S > p.n_tiles / 8) S = p.n_tiles / 8;
   if (S > 256) S = 256;
   if (S < 1) S = 1;
