@@ -507,8 +507,20 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int tap
     const size_t t = i / ci_real;
     const int tap = (int)(t % taps);
     const int co = (int)(t / taps);
+    // eight independent loads in flight (the slab partials are megabytes apart: one load per iteration is pure
+    // latency), summed in slab order -- the result does not depend on the unrolling
+    const float* src = ws + ((size_t)tap * Cout + co) * CinTot + ci_base + ci;
+    const size_t sstride = (size_t)taps * Cout * CinTot;
     float sum = 0.f;
-    for (int s = 0; s < S; ++s) sum += ws[(((size_t)s * taps + tap) * Cout + co) * CinTot + ci_base + ci];
+    int s = 0;
+    for (; s + 8 <= S; s += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = src[(size_t)(s + u) * sstride];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) sum += v[u];
+    }
+    for (; s < S; ++s) sum += src[(size_t)s * sstride];
     float* dst = dw + ((size_t)co * CinTot + ci_base + ci) * taps + tap;
     *dst = accumulate ? *dst + sum : sum;
   }

@@ -38,6 +38,7 @@ struct WgradTrParams {
   int gpt;                                  // 32-channel groups per tap = ceil(x_C / 32)
   int tiles_per_row, n_tiles;               // 64-pixel row segments
   float* ws;
+  float* bias_ws;                           // [S][Cout] column sums of dY (bias gradient), or null
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -163,6 +164,20 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
+  // Bias gradient = column sums of dY: one extra MFMA per k-step against a constant B fragment whose column 0 is all
+  // ones (D[co][0] = sum_k dY[k][co]).  The TM cout tiles of a slab are spread over the 4 waves of its kernel-row
+  // blocks (wave w of the kh block takes tile kh*4 + w), so no wave carries more than one extra MFMA per 15.
+  const int bias_i = (p.bias_ws != nullptr && ct < 3) ? ct * 4 + wave : -1;      // wave-uniform
+  wt_f32x16 acc_b;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc_b[e] = 0.f;
+  wt_bf16x8 ones;
+  {
+    const short one = l31 == 0 ? (short)0x3F80 : (short)0;
+    const wt_s16x8 o8 = {one, one, one, one, one, one, one, one};
+    ones = __builtin_bit_cast(wt_bf16x8, o8);
+  }
+
   // tile t -> (image row r = n*H + y, segment xt)
   auto issue = [&](int t, int buf) {
     const int r = t / p.tiles_per_row, xt = t - r * p.tiles_per_row;
@@ -224,6 +239,10 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
     _Pragma("unroll") for (int m = (M0); m < (M1); ++m) {                                                  \
       const int i = m / TN, j = m - i * TN;                                                                \
       acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WT_FRAG(SET, i), WT_FRAG(SET, TM + j), acc[i][j], 0, 0, 0); \
+    }                                                                                                      \
+    if ((M1) == TM * TN) {                                                                                 \
+      _Pragma("unroll") for (int i = 0; i < TM; ++i)                                                       \
+        if (bias_i == i) acc_b = __builtin_amdgcn_mfma_f32_32x32x16_bf16(WT_FRAG(SET, i), ones, acc_b, 0, 0, 0); \
     }                                                                                                      \
   }
   constexpr int WAIT_H1 = 0x3F | (7 << 4) | (NH1 << 8) | (3 << 14);    // lgkmcnt(NH1), vmcnt untouched
@@ -298,6 +317,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
 
   // D[i = cout][j = ci]: col = lane&31 (ci), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) (cout)
   const int taps = p.KH * p.KW;
+  if (bias_i >= 0 && bias_i < TM && l31 == 0) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int co = co0 + bias_i * 32 + 4 * lh + (e & 3) + 8 * (e >> 2);      // WM == 1: tile i covers couts co0 + 32 i ..
+      if (co < p.Cout) p.bias_ws[(size_t)s * p.Cout + co] = acc_b[e];
+    }
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int ci = b_chunk[j] * 32 + l31;
@@ -313,37 +339,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   }
 }
 
-// column sums of a bf16 [P][cs] tensor (bias gradient next to the kernel above), two deterministic stages
-__global__ __launch_bounds__(256) void colsum_bf16_partial_kernel(const unsigned short* __restrict__ x, long long P, int C,
-                                                                  int cs, int co, int NB, float* __restrict__ part) {
-  // block b sums pixels [P*b/NB, P*(b+1)/NB); thread (pr, c8): 8 channels of every (256/groups)-th pixel
-  const int groups = (C + 7) / 8;
-  const int per = 256 / groups;                     // pixel lanes per block (host guarantees groups <= 256)
-  const int c8 = threadIdx.x % groups, pr = threadIdx.x / groups;
-  const long long p0 = P * blockIdx.x / NB, p1 = P * (blockIdx.x + 1) / NB;
-  float sum[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  if (pr < per)
-    for (long long q = p0 + pr; q < p1; q += per) {
-      const uint4 v = *reinterpret_cast<const uint4*>(x + q * cs + co + c8 * 8);
-      const unsigned w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        sum[2 * k] += __builtin_bit_cast(float, w[k] << 16);
-        sum[2 * k + 1] += __builtin_bit_cast(float, w[k] & 0xFFFF0000u);
-      }
-    }
-  __shared__ float red[256 * 8];
-#pragma unroll
-  for (int k = 0; k < 8; ++k) red[threadIdx.x * 8 + k] = sum[k];
-  __syncthreads();
-  for (int c = threadIdx.x; c < groups * 8; c += 256) {                    // (up to 2048 channels: more than one pass)
-    const int gq = c / 8, k = c % 8;
-    float t = 0.f;
-    for (int r = 0; r < per; ++r) t += red[(r * groups + gq) * 8 + k];   // fixed order
-    if (c < C) part[(size_t)blockIdx.x * C + c] = t;
-  }
-}
-
+// bias gradient, second stage: fixed-order sum of the per-slab column sums the kernel above wrote
 __global__ void colsum_bf16_final_kernel(const float* __restrict__ part, int NB, int C, float* __restrict__ out, int accumulate) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
@@ -401,6 +397,7 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
     return HRV_ERR_ARG;
   }
   p.S = S; p.ws = workspace;
+  p.bias_ws = dbias ? workspace + (size_t)S * KH * KW * Cout * CinTot : nullptr;     // [S][Cout], written by the kh blocks
   const int nblk = jobs * S;
   switch (tm) {
     case 1: hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
@@ -413,13 +410,7 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   int rc = check_launch("conv_wgrad_tr_kernel");
   if (rc) return rc;
   if (dbias) {
-    float* part = workspace + (size_t)S * KH * KW * Cout * CinTot;
-    if ((Cout + 7) / 8 > 256) { set_error("wgrad_tr: bias gradient supports Cout <= 2048"); return HRV_ERR_ARG; }
-    hipLaunchKernelGGL(colsum_bf16_partial_kernel, dim3(256), dim3(256), 0, st, (const unsigned short*)dy, P, Cout, dy_cs,
-                       dy_co, 256, part);
-    rc = check_launch("colsum_bf16_partial_kernel");
-    if (rc) return rc;
-    hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((Cout + 127) / 128), dim3(128), 0, st, part, 256, Cout, dbias,
+    hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((Cout + 127) / 128), dim3(128), 0, st, p.bias_ws, S, Cout, dbias,
                        dbias_accumulate);
     rc = check_launch("colsum_bf16_final_kernel");
     if (rc) return rc;

@@ -171,7 +171,7 @@ class SpadeT:
         bc.index_copy_(0, self.rows_b, n.conv_beta.bias.data)
         cfg = ((8 if self.G % 2 == 0 else 9) if mb else self.cfg)
         if mb:                 # bf16 actv: each tile's halo patch stays in LDS (ops.patch_tile)
-            cfg = ops.patch_tile(actv.bf16, 3, 3, 1, 1, 1, 0, self.hid, self.G * 64, x.N, x.H, x.W) or cfg
+            cfg = ops.patch_tile(actv.bf16, 3, 3, 1, 1, 1, 0, self.hid, self.G * 64, x.N, x.H, x.W, wide=True) or cfg
         packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], cfg, 0, 1, 1, bf16=mb)
         out = ops.alloc(x.N, x.H, x.W, self.C, dev)
         g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev)

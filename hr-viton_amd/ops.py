@@ -40,7 +40,7 @@ def _cpad(c: int, bf16: bool) -> int:
 
 
 def patch_tile(bf16_sources: bool, KH: int, KW: int, stride: int, pad: int, nsrc: int, up: int, C: int, cols: int,
-               N: int, H: int, W: int) -> int:
+               N: int, H: int, W: int, wide: bool = False) -> int:
     """Patch-mode tile of the conv engine (conv_f32.hip, VAR bit 6) for this layer, or 0.  Patch mode: 3x3 stride-1
     'same' convolution over ONE bf16-stored source with C % 128 == 0; the 8x16-pixel tile keeps its 10x18 halo
     patch resident in LDS and only the weight tiles stream (the implicit-GEMM gather re-reads every activation
@@ -51,6 +51,12 @@ def patch_tile(bf16_sources: bool, KH: int, KW: int, stride: int, pad: int, nsrc
     if not (bf16_sources and KH == 3 and KW == 3 and stride == 1 and pad == 1 and nsrc == 1 and up == 0 and
             C % 128 == 0 and env != "0"):
         return 0
+    # tile_cfg 19 (conv_patchw.hip): 16x16-pixel tiles x up to 192 columns per block, one block per CU, weights
+    # streamed once per 256 pixels through 3 LDS stages -- when there is at least one tile per CU.  HRV_CONV_PATCHW=0
+    # falls back to the 8x16 tiles below.
+    # (``wide``: the caller's epilogue is one conv_patchw.hip implements -- the SPADE modulate sites)
+    if wide and os.environ.get("HRV_CONV_PATCHW", "1") != "0" and N * ((H + 15) // 16) * ((W + 15) // 16) >= 256:
+        return 19
     c64 = (cols + 63) // 64
     if c64 * 64 - cols > 32:
         return 0
@@ -484,7 +490,7 @@ class SpadeModulate:
         if out is None:
             out = alloc(x.N, x.H, x.W, self.Creal, x.t.device, self.bf16)
         cfg = self.cfg
-        cfg = patch_tile(self.bf16, 3, 3, 1, 1, 1, 0, actv.Cp, self.conv.Cout, x.N, x.H, x.W) or cfg
+        cfg = patch_tile(self.bf16, 3, 3, 1, 1, 1, 0, actv.Cp, self.conv.Cout, x.N, x.H, x.W, wide=True) or cfg
         return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=cfg)
 
 

@@ -145,10 +145,10 @@ def test_tile_table_and_new_struct_fields(lib):
     column / row extents the packers and the Python planners rely on; the structs that gained fields."""
     from hr_viton_amd import _lib
     want = {8: (128, 128), 9: (128, 64), 10: (256, 128), 11: (128, 256), 12: (256, 128), 13: (256, 128), 14: (256, 128),
-            15: (128, 128), 16: (256, 128), 17: (128, 128), 18: (128, 64)}
+            15: (128, 128), 16: (256, 128), 17: (128, 128), 18: (128, 64), 19: (256, 64)}
     for cfg, (bm, bn) in want.items():
         assert (lib.hrv_conv2d_tile_bm(cfg), lib.hrv_conv2d_tile_bn(cfg)) == (bm, bn), cfg
-    assert lib.hrv_conv2d_tile_bn(19) == -1
+    assert lib.hrv_conv2d_tile_bn(20) == -1
     d = _lib.hrv_norm_bwd_t()
     assert hasattr(d, "dgb_bf16") and hasattr(d, "out_bf16") and d.dgb_bf16 == 0 and d.out_bf16 == 0
     # a descriptor that asks for the patch tile without being a 3x3 'same' bf16 convolution is refused, not rerouted
@@ -176,6 +176,12 @@ def test_patch_tile_selection():
     assert pt(True, 3, 3, 1, 1, 1, 1, 128, 128, 4, 1024, 768) == 0
     assert pt(True, 3, 3, 1, 1, 1, 0, 80, 128, 4, 1024, 768) == 0
     assert pt(True, 3, 3, 1, 1, 1, 0, 128, 13, 4, 1024, 768) == 0
+    # wide patch tiles (conv_patchw.hip, tile_cfg 19): only where the caller's epilogue exists there (SPADE sites) and
+    # there is at least one 16x16 tile per CU
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 19
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 576, 4, 256, 192, wide=True) == 19
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 1088, 4, 128, 96, wide=True) == 18     # 192 tiles: the 8x16 tiles
+    assert pt(False, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 0
     os.environ["HRV_CONV_PATCH"] = "0"
     try:
         assert pt(True, 3, 3, 1, 1, 1, 0, 128, 128, 4, 1024, 768) == 0

@@ -309,3 +309,39 @@ def test_spade_modulate_patch_mode_matches_gather_tiles(C, H, W):
     for cfg in (8, 16, 17):
         assert _rel(outs[cfg].cpu(), want) < 1e-2, (cfg, _rel(outs[cfg].cpu(), want))
         assert (outs[8] - outs[cfg]).abs().max() <= 2 ** -7 * want.abs().max()
+
+
+@pytest.mark.parametrize("C,N,H,W,out_bf16", [(80, 1, 272, 256, False), (32, 1, 256, 256, True), (144, 2, 128, 256, False),
+                                              (64, 1, 250, 264, True)])
+def test_spade_modulate_wide_patch_tiles(C, N, H, W, out_bf16, monkeypatch):
+    """tile_cfg 19 (conv_patchw.hip: 16x16-pixel tiles x up to 192 columns per block, 3-stage weight stream, asm-pipelined
+    fragment reads) for the fused gamma|beta + modulate: 192 / 64 / 192+128 / 128 columns, tile rows and columns that
+    overhang the image, fp32 and bf16 outputs, the (1+gamma) side output of the training path -- vs the oracle formula on
+    the same bf16-representable operands and vs the 8x16 patch tiles it replaces (only the fp32 summation order differs)."""
+    ops = _ops()
+    import ctypes
+    g = torch.Generator().manual_seed(C + H)
+    hid = 128
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    wg, wb = rb(torch.randn(C, hid, 3, 3, generator=g) * 0.03), rb(torch.randn(C, hid, 3, 3, generator=g) * 0.03)
+    bg, bb = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    ns = torch.randn(C, generator=g) * 0.3
+    x = torch.randn(N, C, H, W, generator=g)
+    actv = rb(torch.relu(torch.randn(N, hid, H, W, generator=g)))
+    z = torch.randn(N, W, H, 1, generator=g).cuda().contiguous()
+    mod = ops.SpadeModulate(wg, bg, wb, bb, ns, "cuda", ops.ACT_LRELU, "mod", bf16=True)
+    xa = ops.to_nhwc(x.cuda())
+    aa = ops.to_nhwc(actv.cuda(), bf16=True)
+    mean, rstd = ops.instnorm_stats(xa, z, mod.ns)
+    assert ops.patch_tile(True, 3, 3, 1, 1, 1, 0, hid, mod.conv.Cout, N, H, W, wide=True) == 19
+    outs = {}
+    for wide in ("1", "0"):
+        monkeypatch.setenv("HRV_CONV_PATCHW", wide)
+        out = ops.alloc(N, H, W, C, "cuda", bf16=out_bf16)
+        outs[wide] = ops.to_nchw(mod(aa, xa, mean, rstd, z, out=out)).float().cpu()
+    v = x + (z.cpu() * ns).transpose(1, 3)
+    nh = (v - v.mean((2, 3), keepdim=True)) / torch.sqrt(v.var((2, 3), unbiased=False, keepdim=True) + 1e-5)
+    want = F.leaky_relu(nh * (1 + F.conv2d(actv, wg, bg, padding=1)) + F.conv2d(actv, wb, bb, padding=1), 0.2)
+    tol = 1e-2 if out_bf16 else 2e-4
+    assert _rel(outs["1"], want) < tol, _rel(outs["1"], want)
+    assert (outs["1"] - outs["0"]).abs().max() <= (2 ** -7 if out_bf16 else 1e-4) * want.abs().max()
