@@ -174,13 +174,17 @@ class SpadeT:
             cfg = ops.patch_tile(actv.bf16, 3, 3, 1, 1, 1, 0, self.hid, self.G * 64, x.N, x.H, x.W, wide=True) or cfg
         packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], cfg, 0, 1, 1, bf16=mb)
         out = ops.alloc(x.N, x.H, x.W, self.C, dev)
-        g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev)
+        # (1 + gamma) is only read by the backward: the no_grad forward of the discriminator step (train_generator.py:
+        # 327-330) does not write it (252 MB per image and norm at up_4)
+        save = torch.is_grad_enabled()
+        g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev) if save else None
         e = ops._lib.hrv_spade_epi_t()
         e.x, e.x_cstride, e.x_coff, e.C = x.t.data_ptr(), x.cstride, x.coff, self.Cp
         e.mean, e.rstd = mean.data_ptr(), rstd.data_ptr()
         if zz is not None:
             e.noise_z, e.noise_scale = zz.data_ptr(), ns.data_ptr()
-        e.g1p_out = g1p.data_ptr()
+        if save:
+            e.g1p_out = g1p.data_ptr()
         import ctypes as C
         lib = ops._lib.load()
         d = ops._lib.hrv_conv2d_t()
@@ -197,12 +201,12 @@ class SpadeT:
         d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
         d.spade = C.pointer(e)
         fl = 2.0 * x.N * x.H * x.W * 2 * self.C * self.hid * 9
-        nbytes = (ops.act_bytes(actv) + 2 * ops.act_bytes(x) + ops.act_bytes(out) +
+        nbytes = (ops.act_bytes(actv) + (2 if save else 1) * ops.act_bytes(x) + ops.act_bytes(out) +
                   2.0 * self.C * self.hid * 9 * (2 if mb else 4))     # actv, x, out, 1+gamma, weights
         with ops._Timed("conv", self.name + ".conv_gamma|beta", fl, nbytes):
             fn = lib.hrv_conv2d_nhwc_bf16 if mb else lib.hrv_conv2d_nhwc_f32
             ops._lib.check(fn(C.byref(d), ops._stream()), "hrv_conv2d_nhwc_%s[spade]" % ("bf16" if mb else "f32"))
-        ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C), out=out)
+        ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)
         return out, ctx
 
     def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool, dact: Act) -> Act:

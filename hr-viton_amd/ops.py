@@ -52,10 +52,11 @@ def patch_tile(bf16_sources: bool, KH: int, KW: int, stride: int, pad: int, nsrc
             C % 128 == 0 and env != "0"):
         return 0
     # tile_cfg 19 (conv_patchw.hip): 16x16-pixel tiles x up to 192 columns per block, one block per CU, weights
-    # streamed once per 256 pixels through 3 LDS stages -- when there is at least one tile per CU.  HRV_CONV_PATCHW=0
-    # falls back to the 8x16 tiles below.
+    # streamed once per 256 pixels through 3 LDS stages.  Opt-in (HRV_CONV_PATCHW=1): measured in the training step
+    # it is 5-10 % SLOWER than the 8x16 tiles below (up_4 gamma|beta 2.42 vs 2.25 ms) -- with one block per CU nothing
+    # overlaps the SPADE epilogue's 246 KB of loads/stores per tile, which the two resident blocks of cfg 17/18 hide.
     # (``wide``: the caller's epilogue is one conv_patchw.hip implements -- the SPADE modulate sites)
-    if wide and os.environ.get("HRV_CONV_PATCHW", "1") != "0" and N * ((H + 15) // 16) * ((W + 15) // 16) >= 256:
+    if wide and os.environ.get("HRV_CONV_PATCHW", "0") != "0" and N * ((H + 15) // 16) * ((W + 15) // 16) >= 256:
         return 19
     c64 = (cols + 63) // 64
     if c64 * 64 - cols > 32:

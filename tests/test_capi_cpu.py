@@ -178,10 +178,15 @@ def test_patch_tile_selection():
     assert pt(True, 3, 3, 1, 1, 1, 0, 128, 13, 4, 1024, 768) == 0
     # wide patch tiles (conv_patchw.hip, tile_cfg 19): only where the caller's epilogue exists there (SPADE sites) and
     # there is at least one 16x16 tile per CU
-    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 19
-    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 576, 4, 256, 192, wide=True) == 19
-    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 1088, 4, 128, 96, wide=True) == 18     # 192 tiles: the 8x16 tiles
-    assert pt(False, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 0
+    assert pt(True, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 18     # opt-in
+    os.environ["HRV_CONV_PATCHW"] = "1"
+    try:
+        assert pt(True, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 19
+        assert pt(True, 3, 3, 1, 1, 1, 0, 128, 576, 4, 256, 192, wide=True) == 19
+        assert pt(True, 3, 3, 1, 1, 1, 0, 128, 1088, 4, 128, 96, wide=True) == 18     # 192 tiles: the 8x16 tiles
+        assert pt(False, 3, 3, 1, 1, 1, 0, 128, 192, 4, 1024, 768, wide=True) == 0
+    finally:
+        del os.environ["HRV_CONV_PATCHW"]
     os.environ["HRV_CONV_PATCH"] = "0"
     try:
         assert pt(True, 3, 3, 1, 1, 1, 0, 128, 128, 4, 1024, 768) == 0

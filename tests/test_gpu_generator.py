@@ -333,6 +333,7 @@ def test_spade_modulate_wide_patch_tiles(C, N, H, W, out_bf16, monkeypatch):
     xa = ops.to_nhwc(x.cuda())
     aa = ops.to_nhwc(actv.cuda(), bf16=True)
     mean, rstd = ops.instnorm_stats(xa, z, mod.ns)
+    monkeypatch.setenv("HRV_CONV_PATCHW", "1")
     assert ops.patch_tile(True, 3, 3, 1, 1, 1, 0, hid, mod.conv.Cout, N, H, W, wide=True) == 19
     outs = {}
     for wide in ("1", "0"):
