@@ -140,6 +140,7 @@ struct NormBwd2Params {
   const float* mean; const float* rstd; const float* m1; const float* m2;
   const float* dnh; int dn_cs, dn_co;
   float* dx; int dx_cs, dx_co; int accumulate;
+  int dx_bf16;
   int N, H, W, C4;
   int NB; float* part;  // [N][NB][C] (only when z != NULL)
 };
@@ -172,9 +173,13 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
         const f32x4 nh = (v - mu) * rs;
         f32x4 d = rs * (ld4(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) - a1 - nh * a2);
         sz += d * zz;
-        float* o = p.dx + pix * p.dx_cs + p.dx_co + g * 4;
-        if (p.accumulate) d += ld4(o);
-        *reinterpret_cast<f32x4*>(o) = d;
+        if (p.dx_bf16) {
+          st4_bf16(p.dx, pix * p.dx_cs + p.dx_co + g * 4, d);
+        } else {
+          float* o = p.dx + pix * p.dx_cs + p.dx_co + g * 4;
+          if (p.accumulate) d += ld4(o);
+          *reinterpret_cast<f32x4*>(o) = d;
+        }
       }
     }
     if (p.z) {
@@ -294,6 +299,10 @@ __global__ void downsum2x2_kernel(const float* __restrict__ dhi, int N, int Hl, 
     const int n = (int)(t / Hl);
     const float* s = dhi + (((size_t)n * 2 * Hl + 2 * h) * 2 * Wl + 2 * w) * hcs + hco + g * 4;
     f32x4 v = ld4(s) + ld4(s + hcs) + ld4(s + (size_t)2 * Wl * hcs) + ld4(s + (size_t)2 * Wl * hcs + hcs);
+    if (accumulate == 2) {      // bf16 result (element strides): a gradient only matrix cores read
+      st4_bf16(dlo, pix * lcs + lco + g * 4, v);
+      continue;
+    }
     float* o = dlo + pix * lcs + lco + g * 4;
     if (accumulate) v += ld4(o);
     *reinterpret_cast<f32x4*>(o) = v;
@@ -525,6 +534,8 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   q.mean = d->mean; q.rstd = d->rstd; q.m1 = m1; q.m2 = m2;
   q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff;
   q.dx = d->dx; q.dx_cs = d->dx_cstride; q.dx_co = d->dx_coff; q.accumulate = d->dx_accumulate;
+  q.dx_bf16 = d->dx_bf16;
+  HRV_REQUIRE(!(d->dx_bf16 && d->dx_accumulate), "norm_bwd: a bf16 dx cannot be accumulated into");
   q.N = d->N; q.H = d->H; q.W = d->W; q.C4 = C / 4; q.NB = nb; q.part = part;  // partials are free again
   hipLaunchKernelGGL(norm_bwd_stage2_kernel, dim3(nb, d->N, norm_chunks(C / 4)), dim3(256), 0, st, q);
   rc = check_launch("norm_bwd_stage2_kernel");

@@ -64,8 +64,10 @@ __device__ inline wt_s16x4 wt_tr_read(const unsigned char*) { return wt_s16x4{0,
 
 constexpr int wt_pad_slots(int s) { return s + ((4 - (s & 7)) & 7); }   // next count == 4 (mod 8)
 
-// TM x 32 couts and TN groups (of 32 (tap, ci) columns) per wave; WM x WN waves; XC = 32-channel chunks of X a block stages
-template <int TM, int TN, int WM, int WN, int XC>
+// TM x 32 couts and TN groups (of 32 (tap, ci) columns) per wave; WM x WN waves; XC = 32-channel chunks of X a block
+// stages; PR = image rows of the X patch: 1 (all groups of a block lie in ONE kernel row: the 128-channel sources) or
+// KH (a block covers every tap: the thin convolutions of the 1024x768 level, 32..96 channels on either side).
+template <int TM, int TN, int WM, int WN, int XC, int PR>
 __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams p) {
   static_assert(WM * WN == 4, "4 waves");
   constexpr int TW = 64;                          // pixels per tile
@@ -80,7 +82,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   constexpr int NDY = RDY;                        // dY DMA instructions per tile (64 pixels x RDY slots / 64 lanes)
   static_assert(NDY % 4 == 0, "dY instructions split evenly over the waves");
   constexpr int NDYW = NDY / 4;
-  constexpr int NX = (PXMAX * RX + 63) / 64;      // X DMA instructions per tile
+  constexpr int NX = (PR * PXMAX * RX + 63) / 64; // X DMA instructions per tile
   constexpr int NXW = (NX + 3) / 4;               // per wave (the last ones may repeat instruction NX-1: benign)
   constexpr int DYB = NDY * 1024, XB = NX * 1024, STAGE = DYB + XB;
   constexpr int NS = (163840 / STAGE) >= 4 ? 4 : (163840 / STAGE);
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   constexpr int NGB = WN * TN;                    // column groups of this block
   const int gidx0 = ct * NGB;                     // first global group (tap-major: tap * gpt + chunk)
   const int tap0 = gidx0 / p.gpt;
-  const int kh = tap0 / p.KW;
+  const int kh = PR == 1 ? tap0 / p.KW : 0;       // first kernel row of the patch
   const int chunk_lo = (NGB >= p.gpt) ? 0 : gidx0 % p.gpt;   // first 32-channel chunk staged (whole taps: all of them)
 
   const int t_begin = (int)(((long long)p.n_tiles * s) / p.S);
@@ -130,17 +132,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
     dy_voff[q] = (unsigned)((pp * p.dy_cs + 8 * sl) * 2);
   }
   unsigned x_voff[NXW];
-  int x_p[NXW];
+  int x_p[NXW], x_row[NXW];
   const int px_used = TW + p.KW - 1;
 #pragma unroll
   for (int q = 0; q < NXW; ++q) {
     int j = wave + 4 * q;
     j = j < NX ? j : NX - 1;
     const int slot = 64 * j + lane;
-    const int pp = slot / RX, sl = slot - pp * RX;
-    const bool ok = pp < px_used && sl < 4 * XC && (chunk_lo * 32 + 8 * sl) < p.x_C;
+    const int pq = slot / RX, sl = slot - pq * RX;                  // patch pixel (row-major over PR rows), slot
+    const int prow = pq / PXMAX, pp = pq - prow * PXMAX;
+    const bool ok = prow < PR && pp < px_used && sl < 4 * XC && (chunk_lo * 32 + 8 * sl) < p.x_C;
     x_p[q] = ok ? pp : 1 << 20;
-    x_voff[q] = (unsigned)((pp * p.x_cs + 8 * sl) * 2);
+    x_row[q] = prow < PR ? prow : 0;
+    x_voff[q] = (unsigned)(((prow * p.W + pp) * p.x_cs + 8 * sl) * 2);
   }
 
   // ---- fragment lane constants (bytes inside a stage)
@@ -151,9 +155,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   for (int j = 0; j < TN; ++j) {
     const int gi = gidx0 + wn * TN + j;
     const int tap = gi / p.gpt, chunk = gi - tap * p.gpt;
-    const int kw = tap - kh * p.KW;
+    const int tc = tap < p.KH * p.KW ? tap : 0;                     // groups past the last tap are computed on tap 0 and dropped
+    const int khj = tc / p.KW, kw = tc - khj * p.KW;
     b_tap[j] = tap; b_chunk[j] = chunk;
-    b_base[j] = DYB + (8 * (g >> 1) + (i16 >> 2) + kw) * (RX * 16) + ((chunk - chunk_lo) * 32 + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
+    b_base[j] = DYB + ((khj - kh) * PXMAX + 8 * (g >> 1) + (i16 >> 2) + kw) * (RX * 16) +
+                ((chunk - chunk_lo) * 32 + 16 * (g & 1) + 4 * (i16 & 3)) * 2;
   }
 
   wt_f32x16 acc[TM][TN];
@@ -192,16 +198,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
         wt_dma16(dy_rsrc, sb + (wave + 4 * q) * 1024, dy_p[q] < lim ? dy_voff[q] : 0xFFFFFFF0u, soff);
     }
     {
-      const int yy = y + kh - p.pad;
-      const bool row_ok = (unsigned)yy < (unsigned)p.H;
-      const int yc = row_ok ? yy : y;
-      const unsigned soff = (unsigned)(((n * p.H + yc - (r_base - p.pad)) * p.W + x0) * p.x_cs * 2);
+      // patch row `prow` is image row y + kh + prow - pad of this sample; the scalar offset points at patch row 0
+      // (never negative: the resource base sits `pad` rows before the slab), invalid rows / columns are masked per lane
+      unsigned rowmask = 0;
+#pragma unroll
+      for (int pr = 0; pr < PR; ++pr) rowmask |= ((unsigned)(y + kh + pr - p.pad) < (unsigned)p.H) ? (1u << pr) : 0u;
+      const unsigned soff = (unsigned)(((r + kh - r_base) * p.W + x0) * p.x_cs * 2);
       const int lo = p.pad - x0, hi = p.W - x0 + p.pad;            // patch pixel pp is image column x0 - pad + pp
 #pragma unroll
       for (int q = 0; q < NXW; ++q) {
         int j = wave + 4 * q;
         j = j < NX ? j : NX - 1;
-        const bool ok = row_ok && x_p[q] >= lo && x_p[q] < hi;
+        const bool ok = ((rowmask >> x_row[q]) & 1u) && x_p[q] >= lo && x_p[q] < hi;
         wt_dma16(x_rsrc, sb + DYB + j * 1024, ok ? x_voff[q] : 0xFFFFFFF0u, soff);
       }
     }
@@ -360,20 +368,28 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   const long long P = (long long)N * H * W;
   if (P < 32768 || W < 32) return 0;                                              // low-resolution levels: weight-bound, old kernel
   const int gpt = (x_C + 31) / 32;
-  if (gpt != 4) return 0;                        // instantiated: 128-channel sources (the SPADE gamma|beta convolutions)
+  const int taps = KH * KW;
   WgradTrParams p;
   p.dy = dy; p.dy_cs = dy_cs; p.dy_co = dy_co; p.Cout = Cout;
   p.x = x; p.x_cs = x_cs; p.x_co = x_co; p.x_C = x_C;
   p.N = N; p.H = H; p.W = W; p.KH = KH; p.KW = KW; p.pad = pad;
   p.CinTot = CinTot; p.ci_base = ci_base; p.ci_real = x_C_real;
   p.gpt = gpt;
-  p.co_tiles = (Cout + 159) / 160;
-  const int tm = (((Cout + p.co_tiles - 1) / p.co_tiles) + 31) / 32;             // 1..5
-  const int NGB = 12;                                                              // WN 4 x TN 3
-  if ((KW * gpt) % NGB != 0) return 0;                                             // a block = whole taps of ONE kernel row
-  p.col_tiles = KH * KW * gpt / NGB;
   p.tiles_per_row = (W + 63) / 64;
   p.n_tiles = N * H * p.tiles_per_row;
+  // shape classes:  0 = 128-channel source, a block = the KW taps of one kernel row x all 128 channels x <= 160 couts
+  //                 1..3 = thin layers (<= 32 couts, <= 96 source channels): a block = every tap x every channel
+  int cls = -1, tm = 0;
+  if (gpt == 4 && KW == 3) {
+    cls = 0;
+    p.co_tiles = (Cout + 159) / 160;
+    tm = (((Cout + p.co_tiles - 1) / p.co_tiles) + 31) / 32;                     // 1..5
+    p.col_tiles = KH * KW * gpt / 12;                                              // WN 4 x TN 3 groups per block
+  } else if (Cout <= 32 && taps * gpt <= 28 && gpt <= 3) {
+    cls = gpt == 3 ? (taps == 1 ? 3 : 1) : (gpt == 1 && taps == 9 ? 2 : -1);
+    p.co_tiles = 1; p.col_tiles = 1; tm = 1;
+  }
+  if (cls < 0) return 0;
   const int jobs = p.co_tiles * p.col_tiles;
   // one block per CU (a block owns 126-152 KB of LDS): the grid must NOT exceed the CU count, or the surplus blocks
   // run as a second round on an otherwise idle chip (first build: 258 blocks, kernel time 2x the wave lifetime)
@@ -389,7 +405,7 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   if (S > 256) S = 256;
   if (S < 1) S = 1;
   // per-tile scalar offsets are relative to the slab's first row: the slab's extent must fit 31 bits
-  const long long slab_rows = p.n_tiles / S / p.tiles_per_row + 4;
+  const long long slab_rows = p.n_tiles / S / p.tiles_per_row + 4 + KH;
   if (slab_rows * W * (long long)(dy_cs > x_cs ? dy_cs : x_cs) * 2 >= 0x7FF00000LL) return 0;
   const long long need = ((long long)S * KH * KW * Cout * CinTot + 256LL * Cout) * 4;
   if (workspace_bytes < need) {
@@ -399,13 +415,21 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   p.S = S; p.ws = workspace;
   p.bias_ws = dbias ? workspace + (size_t)S * KH * KW * Cout * CinTot : nullptr;     // [S][Cout], written by the kh blocks
   const int nblk = jobs * S;
-  switch (tm) {
-    case 1: hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 2: hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 3: hipLaunchKernelGGL((conv_wgrad_tr_kernel<3, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 4: hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
-    case 5: hipLaunchKernelGGL((conv_wgrad_tr_kernel<5, 3, 1, 4, 4>), dim3(nblk), dim3(256), 0, st, p); break;
-    default: return 0;
+  if (cls == 0) {
+    switch (tm) {
+      case 1: hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 3, 1, 4, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 2: hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 3, 1, 4, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 3: hipLaunchKernelGGL((conv_wgrad_tr_kernel<3, 3, 1, 4, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 4: hipLaunchKernelGGL((conv_wgrad_tr_kernel<4, 3, 1, 4, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+      case 5: hipLaunchKernelGGL((conv_wgrad_tr_kernel<5, 3, 1, 4, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
+      default: return 0;
+    }
+  } else if (cls == 1) {      // 3x3 over <= 96 channels: 27 groups -> 4 waves x 7
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 7, 1, 4, 3, 3>), dim3(nblk), dim3(256), 0, st, p);
+  } else if (cls == 2) {      // 3x3 over 32 channels: 9 groups -> 4 waves x 3
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 3, 1, 4, 1, 3>), dim3(nblk), dim3(256), 0, st, p);
+  } else {                    // 1x1 over <= 96 channels: 3 groups -> 4 waves x 1
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 1, 1, 4, 3, 1>), dim3(nblk), dim3(256), 0, st, p);
   }
   int rc = check_launch("conv_wgrad_tr_kernel");
   if (rc) return rc;

@@ -103,7 +103,7 @@ class TConv:
                                   out_up=out_up, name=self.name, out_bf16=out_bf16)
 
     def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
-                 act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True) -> Optional[Act]:
+                 act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True, dx_bf16: bool = False) -> Optional[Act]:
         w = self.wparam.data
         Cout, cin, KH, KW = w.shape
         if need_w:
@@ -128,7 +128,7 @@ class TConv:
         a0, up0 = srcs[0]
         H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
         return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope,
-                            name=self.name + ".dgrad")
+                            name=self.name + ".dgrad", out_bf16=dx_bf16)
 
 
 class SpadeT:
@@ -173,7 +173,10 @@ class SpadeT:
         if mb:                 # bf16 actv: each tile's halo patch stays in LDS (ops.patch_tile)
             cfg = ops.patch_tile(actv.bf16, 3, 3, 1, 1, 1, 0, self.hid, self.G * 64, x.N, x.H, x.W, wide=True) or cfg
         packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], cfg, 0, 1, 1, bf16=mb)
-        out = ops.alloc(x.N, x.H, x.W, self.C, dev)
+        # mixed precision: the modulated activation is read by matrix cores only (conv_0 / conv_1 / conv_s, their weight
+        # gradients) and as the sign mask of its own LeakyReLU -- stored in bf16 (same operand bits as rounding while
+        # staging, half the bytes); widths that are not a multiple of 4 keep the fp32 weight-gradient kernel and fp32
+        out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=mb and actv.bf16 and self.C % 8 == 0)
         # (1 + gamma) is only read by the backward: the no_grad forward of the discriminator step (train_generator.py:
         # 327-330) does not write it (252 MB per image and norm at up_4)
         save = torch.is_grad_enabled()
@@ -195,7 +198,7 @@ class SpadeT:
         s.ptr, s.C, s.cstride, s.coff, s.up_shift, s.pre_act, s.C_real = (actv.t.data_ptr(), self.hid, actv.cstride,
                                                                           actv.coff, 0, 0, self.hid)
         d.w_packed, d.Cout, d.tile_cfg = packed.data_ptr(), self.G * 64, cfg
-        d.mixed_flags = (7 if actv.bf16 else 15) if mb else 0
+        d.mixed_flags = ((7 if actv.bf16 else 15) & ~(1 if out.bf16 else 0)) if mb else 0
         d.shift = bc.data_ptr()
         d.act, d.act_slope = self.act, 0.2
         d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
@@ -209,7 +212,8 @@ class SpadeT:
         ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)
         return out, ctx
 
-    def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool, dact: Act) -> Act:
+    def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool, dact: Act,
+                 dx_bf16: bool = False) -> Act:
         """``dact``: this norm's slice of the block-wide d(actv) tensor (the block back-propagates its norms'
         conv_shared together, BlockT.backward)."""
         n = self.norm
@@ -220,7 +224,8 @@ class SpadeT:
                              out=ctx["out"] if self.act != ACT_NONE else None, g1p=ctx["g1p"], z=ctx["z"],
                              noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dx=dx,
                              dx_accumulate=dx_accumulate, dnoise_scale=dns,
-                             dgb_bf16=ctx["actv"].bf16)   # [dgamma|dbeta] feeds matrix cores only (gb.wgrad, gb.dgrad)
+                             dgb_bf16=ctx["actv"].bf16,   # [dgamma|dbeta] feeds matrix cores only (gb.wgrad, gb.dgrad)
+                             dx_bf16=dx_bf16 and ctx["actv"].bf16)
         if dns is not None:
             _acc(grads, n.noise_scale, dns[:C_])
         else:
@@ -258,6 +263,11 @@ class BlockT:
 
     def convs(self):
         return [self.c0, self.c1] + ([self.cs] if self.learned else [])
+
+    def wants_bf16_dout(self, ctx) -> bool:
+        """d(block output) may be stored in bf16: learned shortcut (no fp32 residual add of the gradient) and this level's
+        conv inputs are bf16 (so the weight-gradient kernel takes bf16 on both sides)."""
+        return bool(self.learned and ctx["h1"].bf16 and ctx["hs"].bf16 and self.c1.conv.out_channels % 8 == 0)
 
     def norms(self):
         return ([self.ns_] if self.learned else []) + [self.n0, self.n1]
@@ -318,7 +328,9 @@ class BlockT:
         h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi))
         dx = self.c0.forward([(h0, 0)])
         h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi))
-        o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up)
+        # the last block's activated output only feeds conv_img (matrix cores + the sign mask of its data gradient)
+        o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up,
+                            out_bf16=out is None and h1.bf16 and self.c1.conv.out_channels % 8 == 0)
         ctx.update(h0=h0, h1=h1)
         return o, ctx
 
@@ -330,7 +342,9 @@ class BlockT:
         dact_all = ops.alloc(x.N, x.H, x.W, hid * len(norms), x.t.device)
         k0 = 1 if self.learned else 0          # slice order = norms(): [norm_s,] norm_0, norm_1
         d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads)
-        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid))
+        # d(conv_0 output) is read by conv_0's weight / data gradient only: bf16 when the mixed-precision plan stores
+        # that level's matrix-core tensors in bf16
+        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid), dx_bf16=True)
         d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads)
         d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False, dact_all.slice(hid * k0, hid))
         if self.learned:
@@ -396,7 +410,10 @@ class GeneratorTrainPlan:
         dimg = ops.to_nhwc(d_img.contiguous())
         dpre = Act(T.tanh_bwd(dimg.t, img.t), 3)
         # conv_img reads lrelu(x_last): its dgrad carries that LeakyReLU's derivative
-        d_cur = self.img.backward(dpre, [(ctx["last"], 0)], grads, act_mask=ctx["last"], slope=0.2)
+        # the gradient of a learned-shortcut block's output is read by conv_1's and conv_s's backward only (matrix
+        # cores): stored in bf16 when that block's activations are (BlockT.wants_bf16_dout)
+        d_cur = self.img.backward(dpre, [(ctx["last"], 0)], grads, act_mask=ctx["last"], slope=0.2,
+                                  dx_bf16=self.blocks[-1].wants_bf16_dout(ctx["blocks"][-1]))
         xin = ctx["xin"]
         for j in range(len(self.names) - 1, -1, -1):
             blk, c = self.blocks[j], ctx["blocks"][j]
@@ -406,7 +423,7 @@ class GeneratorTrainPlan:
                 self.stems[0].backward(d_x, [(xin, -c["shift"])], grads, need_dx=False)
             else:
                 self.stems[j].backward(d_x.slice(cin - 16, 16), [(xin, -c["shift"])], grads, need_dx=False)
-                d_cur = T.downsum2x2(d_x.slice(0, cin - 16))
+                d_cur = T.downsum2x2(d_x.slice(0, cin - 16), out_bf16=self.blocks[j - 1].wants_bf16_dout(ctx["blocks"][j - 1]))
         return grads
 
 

@@ -134,16 +134,16 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
 
 def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
                sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
-               name: str = "dgrad") -> Act:
+               name: str = "dgrad", out_bf16: bool = False) -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
     activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x)."""
     lib = _lib.load()
     Cout, cin, KH, KW = w.shape
     N, Ho, Wo = dy.N, dy.H, dy.W
     assert dy.C == Cout
-    if out is None:
-        out = ops.alloc(N, H, W, cin, dy.t.device)
     mb = MMA_BF16[0]
+    if out is None:
+        out = ops.alloc(N, H, W, cin, dy.t.device, bf16=out_bf16 and mb and cin % 8 == 0 and stride == 1)
     cfg = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * H * W, cin)
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
@@ -216,14 +216,15 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
              out: Optional[Act] = None, g1p: Optional[Act] = None, z: Optional[torch.Tensor] = None,
              noise_scale: Optional[torch.Tensor] = None, want_dgb: bool = False, dx: Optional[Act] = None,
              dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False,
-             dgb_bf16: bool = False):
+             dgb_bf16: bool = False, dx_bf16: bool = False):
     """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None).  ``dgb_bf16``: store
     [dgamma | dbeta] in bf16 (mixed precision: only the gamma|beta conv's matrix-core backward reads it)."""
     lib = _lib.load()
     N, H, W, Cp = x.N, x.H, x.W, x.Cp
     dev = x.t.device
     if dx is None:
-        dx = ops.alloc(N, H, W, x.C, dev)
+        # ``dx_bf16``: the gradient of a convolution OUTPUT that only that convolution's backward reads (matrix cores)
+        dx = ops.alloc(N, H, W, x.C, dev, bf16=dx_bf16 and x.C % 8 == 0)
         dx_accumulate = False
     dnh = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
     dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.bfloat16 if dgb_bf16 else torch.float32, device=dev),
@@ -247,6 +248,8 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
         d.dgb_bf16 = 1 if dgb.bf16 else 0
     d.dx, d.dx_cstride, d.dx_coff = dx.t.data_ptr(), dx.cstride, dx.coff
     d.dx_accumulate = 1 if dx_accumulate else 0
+    d.dx_bf16 = 1 if dx.bf16 else 0
+    assert not (dx.bf16 and dx_accumulate)
     d.act, d.act_slope = act, slope
     d.dns_accumulate = 1 if dns_accumulate else 0
     d.dnoise_scale = None if dnoise_scale is None else dnoise_scale.data_ptr()
@@ -277,15 +280,17 @@ def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, g
     return grad
 
 
-def downsum2x2(dhi: Act, dlo: Optional[Act] = None, accumulate: bool = False) -> Act:
+def downsum2x2(dhi: Act, dlo: Optional[Act] = None, accumulate: bool = False, out_bf16: bool = False) -> Act:
     lib = _lib.load()
     Hl, Wl = dhi.H // 2, dhi.W // 2
     if dlo is None:
-        dlo = ops.alloc(dhi.N, Hl, Wl, dhi.C, dhi.t.device)
+        dlo = ops.alloc(dhi.N, Hl, Wl, dhi.C, dhi.t.device, bf16=out_bf16 and dhi.C % 8 == 0)
         accumulate = False
+    assert not (dlo.bf16 and accumulate)
     with _Timed("ew", "downsum2x2", 0.0, ops.act_bytes(dhi) * (1.25 + (0.25 if accumulate else 0))):
         _lib.check(lib.hrv_downsum2x2_nhwc_f32(dhi.t.data_ptr(), dhi.N, Hl, Wl, dhi.Cp, dhi.cstride, dhi.coff,
-                                               dlo.t.data_ptr(), dlo.cstride, dlo.coff, 1 if accumulate else 0, _stream()),
+                                               dlo.t.data_ptr(), dlo.cstride, dlo.coff,
+                                               2 if dlo.bf16 else (1 if accumulate else 0), _stream()),
                    "hrv_downsum2x2_nhwc_f32")
     return dlo
 

@@ -241,6 +241,9 @@ typedef struct hrv_norm_bwd {
   float* workspace;
   int32_t dgb_bf16;   /* 1: `dgb` is stored as bf16 (element strides/offsets): a tensor only matrix cores read */
   int32_t out_bf16;   /* 1: `out` is stored as bf16 (only its sign is used here)                              */
+  int32_t dx_bf16;    /* 1: `dx` is stored as bf16 (no accumulate): the gradient of a convolution output that only
+                       *    that convolution's weight / data gradient (matrix cores) read                          */
+  int32_t _pad_nb;
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);
@@ -261,7 +264,8 @@ int hrv_act_bwd_nhwc_f32(float* d, int32_t d_cstride, int32_t d_coff, const floa
 int hrv_tanh_bwd_f32(const float* dy, const float* y, int64_t n, float* out, hrv_stream_t stream);
 int hrv_add_slice_nhwc_f32(const float* a, int32_t a_cstride, int32_t a_coff, float* out, int32_t out_cstride,
                            int32_t out_coff, int32_t C, int64_t npix, int32_t accumulate, hrv_stream_t stream);
-/* nn.Upsample(nearest, x2) backward: dlo (+)= 2x2 block sums of dhi. */
+/* nn.Upsample(nearest, x2) backward: dlo (+)= 2x2 block sums of dhi.  accumulate: 0 write, 1 add, 2 write as bf16
+ * (lo_cstride / lo_coff then count bf16 elements). */
 int hrv_downsum2x2_nhwc_f32(const float* dhi, int32_t N, int32_t Hl, int32_t Wl, int32_t C, int32_t hi_cstride,
                             int32_t hi_coff, float* dlo, int32_t lo_cstride, int32_t lo_coff, int32_t accumulate,
                             hrv_stream_t stream);
