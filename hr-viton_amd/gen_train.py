@@ -154,7 +154,7 @@ class SpadeT:
         co, c, kh, kw = w.shape
         return w.permute(0, 2, 3, 1), self.shared.bparam.data, c
 
-    def forward(self, x: Act, actv: Act, z: Optional[torch.Tensor]):
+    def forward(self, x: Act, actv: Act, z: Optional[torch.Tensor], save: bool = True):
         n = self.norm
         dev = x.t.device
         ns = torch.zeros(self.Cp, device=dev)
@@ -179,7 +179,7 @@ class SpadeT:
         out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=mb and actv.bf16 and self.C % 8 == 0)
         # (1 + gamma) is only read by the backward: the no_grad forward of the discriminator step (train_generator.py:
         # 327-330) does not write it (252 MB per image and norm at up_4)
-        save = torch.is_grad_enabled()
+        # (``save``: passed down by the caller -- torch.is_grad_enabled() is always False inside autograd.Function.forward)
         g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev) if save else None
         e = ops._lib.hrv_spade_epi_t()
         e.x, e.x_cstride, e.x_coff, e.C = x.t.data_ptr(), x.cstride, x.coff, self.Cp
@@ -313,21 +313,22 @@ class BlockT:
             _acc(grads, n_.shared.wparam, g.contiguous())
             _acc(grads, n_.shared.bparam, db[hid * i:hid * (i + 1)].clone())
 
-    def forward(self, x: Act, seg: Act, seg_shift: int, zs, out: Optional[Act], out_up: int, out_act: int):
+    def forward(self, x: Act, seg: Act, seg_shift: int, zs, out: Optional[Act], out_up: int, out_act: int,
+                save: bool = True):
         zi = iter(zs)
         ctx = {"x": x}
         segx, actvs = self.shared_forward(seg, seg_shift)
         ai = iter(actvs)
         ctx["segx"] = segx
         if self.learned:
-            hs, ctx["ns"] = self.ns_.forward(x, next(ai), next(zi))
+            hs, ctx["ns"] = self.ns_.forward(x, next(ai), next(zi), save)
             x_s = self.cs.forward([(hs, 0)])
             ctx["hs"] = hs
         else:
             x_s = x
-        h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi))
+        h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi), save)
         dx = self.c0.forward([(h0, 0)])
-        h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi))
+        h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi), save)
         # the last block's activated output only feeds conv_img (matrix cores + the sign mask of its data gradient)
         o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up,
                             out_bf16=out is None and h1.bf16 and self.c1.conv.out_channels % 8 == 0)
@@ -365,7 +366,8 @@ class GeneratorTrainPlan:
         self.stems = [TConv(getattr(gen, f"conv_{i}"), 1, 1, f"conv_{i}") for i in range(len(names))]
         self.img = TConv(gen.conv_img, 1, 1, "conv_img")
 
-    def forward(self, x: torch.Tensor, seg, noise, power_iteration: bool):
+    def forward(self, x: torch.Tensor, seg, noise, power_iteration: bool, save: bool = True):
+        """``save``: keep what the backward needs (False: the no_grad forward of the discriminator step)."""
         gen = self.gen
         N, _, H, W = x.shape
         nb = len(self.names)
@@ -391,11 +393,11 @@ class GeneratorTrainPlan:
             zs = [z.to(dev).contiguous() for z in noise[name]] if noise is not None else \
                 [torch.randn(N, w, h, 1, device=dev) for _ in range(k)]
             if j == nb - 1:
-                o, c = blk.forward(cur, sg, shift, zs, None, 0, ACT_LRELU)
+                o, c = blk.forward(cur, sg, shift, zs, None, 0, ACT_LRELU, save)
             else:
                 nxt_c = getattr(gen, self.names[j + 1]).input_nc
                 nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)
-                o, c = blk.forward(cur, sg, shift, zs, nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
+                o, c = blk.forward(cur, sg, shift, zs, nxt.slice(0, nxt_c - 16), 1, ACT_NONE, save)
                 o = nxt
             c["shift"] = shift
             ctxs.append(c)
@@ -450,7 +452,7 @@ def generator_train_forward(gen: nn.Module, x: torch.Tensor, seg, noise=None) ->
     if not torch.is_grad_enabled():
         # train-mode forward under no_grad (train_generator.py:327-330): same math, incl. the
         # spectral-norm power iteration, nothing saved
-        out, _ = plan.forward(x, seg, noise, power_iteration=True)
+        out, _ = plan.forward(x, seg, noise, power_iteration=True, save=False)
         return out
     return _GenFn.apply(gen, plan, x, seg, noise, *params)
 
