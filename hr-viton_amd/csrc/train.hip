@@ -193,12 +193,23 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
   }
 }
 
-__global__ void sum_rows_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// out[c] (+)= sum over rows of part[r][c]: 16 channels x 16 row-groups per block (a thread per channel walking all
+// N x slabs rows serially was 111 us per call), fixed combination order
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int accumulate) {
+  __shared__ double red[16][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
   double s = 0.0;
-  for (int r = 0; r < rows; ++r) s += (double)part[(size_t)r * C + c];
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (c < C)
+    for (int r = rg; r < rows; r += 16) s += (double)part[(size_t)r * C + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c < C) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][cl];
+    out[c] = accumulate ? out[c] + (float)t : (float)t;
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -431,16 +442,52 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
 
 __global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
                                                         int K, float* __restrict__ y) {
-  // block handles 64 columns; 4 row-groups of 64 lanes each stride the rows
-  __shared__ float red[4][64];
-  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-  const int rg = threadIdx.x >> 6;
-  float s = 0.f;
-  if (c < K)
-    for (int r = rg; r < R; r += 4) s += Wm[(size_t)r * K + c] * x[r];
-  red[rg][threadIdx.x & 63] = s;
+  // block = 64 columns; 16 row-groups x 16 lanes of 4 columns (16-byte loads when K % 4 == 0), four rows in flight
+  // per thread (a 4-row-group version with one scalar load per iteration was pure latency: 51 us per call, 2.8 ms per
+  // training step); partial sums are combined in row-group order => deterministic
+  __shared__ float red[16][64];
+  const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c0 = blockIdx.x * 64 + cq * 4;
+  float s[4] = {0.f, 0.f, 0.f, 0.f};
+  if ((K & 3) == 0 && c0 + 3 < K) {
+    int r = rg;
+    for (; r + 48 < R; r += 64) {
+      f32x4 v[4];
+      float xr[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        v[u] = *reinterpret_cast<const f32x4*>(Wm + (size_t)(r + 16 * u) * K + c0);
+        xr[u] = x[r + 16 * u];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) s[e] += v[u][e] * xr[u];
+    }
+    for (; r < R; r += 16) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(Wm + (size_t)r * K + c0);
+      const float xr = x[r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += v[e] * xr;
+    }
+  } else {
+    for (int r = rg; r < R; r += 16) {
+      const float xr = x[r];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (c0 + e < K) s[e] += Wm[(size_t)r * K + c0 + e] * xr;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < 4; ++e) red[rg][cq * 4 + e] = s[e];
   __syncthreads();
-  if (rg == 0 && c < K) y[c] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+  if (threadIdx.x < 64) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
+    if (c < K) y[c] = t;
+  }
 }
 
 // x <- x / max(||x||, eps); also returns ||x|| in out_norm (single block)
@@ -541,7 +588,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   rc = check_launch("norm_bwd_stage2_kernel");
   if (rc) return rc;
   if (d->noise_z && d->dnoise_scale) {
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 255) / 256), dim3(256), 0, st, part, d->N * nb, C, d->dnoise_scale,
+    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, d->N * nb, C, d->dnoise_scale,
                        d->dns_accumulate);
     rc = check_launch("sum_rows_kernel");
   }

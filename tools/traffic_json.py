@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""HBM traffic per convolution launch from two rocprofv3 PMC passes (FETCH_SIZE, WRITE_SIZE) of one bench.py command.
+    python tools/traffic_json.py <fetch.summary.txt> <write.summary.txt> <out.json> "<command>"
+Counter values are KiB (rocprofv3 on gfx950); FETCH_SIZE is doubled as MI355X_MICROARCH.md prescribes (it reports half of
+the bytes of wide coalesced reads)."""
+import json
+import re
+import sys
+
+CONV = re.compile(r"hrv::(conv_mfma_kernel|conv_wgrad|conv_patchw)")
+
+
+def per_kernel(path, counter):
+    tot, n = 0.0, 0
+    for l in open(path):
+        m = re.match(rf"{counter}\s+([\d.]+)\s+n=\s*(\d+)\s+(.*)", l)
+        if m and CONV.search(m.group(3)):
+            tot += float(m.group(1))
+            n += int(m.group(2))
+    return tot, n
+
+
+def main(fetch, write, out, cmd):
+    f, nf = per_kernel(fetch, "FETCH_SIZE")
+    w, nw = per_kernel(write, "WRITE_SIZE")
+    n = max(nf, nw, 1)
+    j = {"source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, tools/profile_traffic.sh) of `{cmd}`; "
+                   "all hrv::conv_mfma_kernel / conv_wgrad_* / conv_patchw dispatches of the run",
+         "units": "counter values are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced 16 B/lane reads)",
+         "fetch_KiB_raw_total": f, "write_KiB_total": w, "conv_dispatches": n,
+         "hbm_bytes_total": (2.0 * f + w) * 1024.0, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / n}
+    with open(out, "w") as fo:
+        json.dump(j, fo, indent=1)
+    print(json.dumps(j))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:5])
