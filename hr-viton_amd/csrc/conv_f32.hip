@@ -75,7 +75,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   // vmcnt).  L2 -> LDS bytes per block tile drop from 18 x 48 KB to 81 KB + 18 x 16 KB (2.3x fewer).
   constexpr bool PATCH = (VAR & 64) != 0;
   static_assert(!PATCH || (GLDS && !SPEC && ((BM == 256 && BN == 128 && NT == 512 && ST == 3) ||
-                                            (BM == 128 && (BN == 128 || BN == 64) && NT == 256 && ST == 2))),
+                                            (BM == 128 && (BN == 128 || BN == 64) && NT == 256 && (ST == 2 || BN == 64)))),
                 "patch mode: 16x16 pixels x 128 columns with 8 waves and 3 weight stages (132 KB LDS, one block per "
                 "CU), or 8x16 pixels with 4 waves and 2 weight stages (78 KB: two blocks per CU overlap each "
                 "other's patch load and epilogue; 128 or 64 columns)");
@@ -98,7 +98,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   const int mt = lid / p.n_tiles;
   const int nt = lid - mt * p.n_tiles;
   const int m0 = mt * BM;
-  const int n0 = nt * BN;
+  const int n0 = p.n0_base + nt * BN;
   // patch mode: mt = (image, tile row, tile column) of a 16x16 output tile
   [[maybe_unused]] int pt_n = 0, pt_y0 = 0, pt_x0 = 0;
   if constexpr (PATCH) {
@@ -1191,10 +1191,11 @@ static bool patch_eligible(const ConvParams& p) {
          p.w_bytes != 0 && p.out_step != 2;
 }
 
+// ``n0_base`` / ``n_cols_tiles``: cover only the column tiles [n0_base / BNP, + n_cols_tiles) (0: all of them)
 template <int TMP, int TNP, int WMP, int WNP, int STV>
-static int launch_patch(const ConvParams& p0, hipStream_t st) {
+static int launch_patch(const ConvParams& p0, hipStream_t st, int n0_base = 0, int n_cols_tiles = 0) {
   constexpr int BNP = 32 * TNP * WNP;
-  if (!patch_eligible(p0) || p0.CoutPad % BNP != 0) {
+  if (!patch_eligible(p0) || (n_cols_tiles == 0 && p0.CoutPad % BNP != 0) || n0_base + n_cols_tiles * BNP > p0.CoutPad) {
     set_error("conv2d: tile_cfg 16-18 (patch mode) needs a 3x3 stride-1 'same' convolution over one bf16-stored source with "
               "C %% 128 == 0");
     return HRV_ERR_ARG;
@@ -1203,7 +1204,8 @@ static int launch_patch(const ConvParams& p0, hipStream_t st) {
   p.splitk = 1;
   constexpr int THP = TMP * WMP * 32 / 16;   // tile rows: BM / 16
   p.m_tiles = p.N * ((p.H + THP - 1) / THP) * ((p.W + 15) / 16);
-  p.n_tiles = p.CoutPad / BNP;
+  p.n_tiles = n_cols_tiles > 0 ? n_cols_tiles : p.CoutPad / BNP;
+  p.n0_base = n0_base;
   const int nblk = p.m_tiles * p.n_tiles;
   const int oesz = p.out_f32 ? 4 : 2, resz = p.res_f32 ? 4 : 2;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
@@ -1237,7 +1239,22 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 15: return launch_cfg8w<2, 2, 2, 2, true, true>(p, st);
     case 16: return launch_patch<2, 2, 4, 2, 16>(p, st);
     case 17: return launch_patch<2, 2, 2, 2, 0>(p, st);
-    case 18: return launch_patch<1, 2, 4, 1, 0>(p, st);
+    case 18: {
+      // 64-column patch tile: THREE weight stages still fit two blocks per CU (46 KB patch + 3 x 8 KB): one tile's DMA stays
+      // in flight across the barrier (counted vmcnt) instead of vmcnt(0) per K-tile.  HRV_CONV_PATCH_ST3=0: two stages (A/B)
+      const char* e3 = getenv("HRV_CONV_PATCH_ST3");
+      if (e3 && e3[0] == '0') return launch_patch<1, 2, 4, 1, 0>(p, st);
+      // an odd number (>= 3) of 64-column tiles: the even part runs on the 128-column tile (the halo patch is loaded once
+      // per 128 columns instead of once per 64), the last 64 columns here.  HRV_CONV_PATCH_SPLIT=0: 64-column tiles only
+      const char* es = getenv("HRV_CONV_PATCH_SPLIT");
+      const int c64 = p.CoutPad / 64;
+      if (c64 >= 3 && !(es && es[0] == '0')) {
+        const int rc = launch_patch<2, 2, 2, 2, 0>(p, st, 0, c64 / 2);
+        if (rc) return rc;
+        return launch_patch<1, 2, 4, 1, 16>(p, st, (c64 / 2) * 128, c64 - 2 * (c64 / 2));
+      }
+      return launch_patch<1, 2, 4, 1, 16>(p, st);
+    }
     case 19: return launch_patchw(p, st);
   }
   set_error("conv2d: tile_cfg=%d invalid", tile_cfg);

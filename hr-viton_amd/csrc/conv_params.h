@@ -25,6 +25,7 @@ struct ConvParams {
   int chunks_total;  // sum over sources of ceil(C/16)
   int KT;            // KH*KW*chunks_total
   int m_tiles, n_tiles;
+  int n0_base;       // first output column of this launch (patch tiles: a layer's columns may be covered by launches of different tile widths)
   const float* wp;
   const float* scale;
   const float* shift;

@@ -364,7 +364,8 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   const char* env = getenv("HRV_WGRAD_TR");
   if (env && env[0] == '0') return 0;
   if (KW < 1 || KW > 3 || KH != KW || pad != KH / 2) return 0;
-  if ((Cout | dy_cs | dy_co | x_cs | x_co | x_C) & 7) return 0;                  // 16-byte DMA granules
+  if ((dy_cs | dy_co | x_cs | x_co | x_C) & 7) return 0;                         // 16-byte DMA granules (Cout itself may be
+                                                                                  // anything: rows >= Cout are never written)
   const long long P = (long long)N * H * W;
   if (P < 32768 || W < 32) return 0;                                              // low-resolution levels: weight-bound, old kernel
   const int gpt = (x_C + 31) / 32;

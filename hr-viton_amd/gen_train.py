@@ -103,7 +103,9 @@ class TConv:
                                   out_up=out_up, name=self.name, out_bf16=out_bf16)
 
     def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
-                 act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True, dx_bf16: bool = False) -> Optional[Act]:
+                 act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True, dx_bf16: bool = False,
+                 dy_wgrad: Optional[Act] = None) -> Optional[Act]:
+        """``dy_wgrad``: a bf16 copy of ``dy`` for the weight gradient (so a bf16-stored source takes the LDS-DMA kernel)."""
         w = self.wparam.data
         Cout, cin, KH, KW = w.shape
         if need_w:
@@ -112,8 +114,8 @@ class TConv:
             base = 0
             for a, up in srcs:
                 # the bias gradient rides along with the first source as a ones-column of the same MFMA reduction
-                T.conv_wgrad(dy, a, up, base, cin, KH, KW, self.stride, self.pad, G, name=self.name + ".wgrad",
-                             dbias=db if base == 0 else None)
+                T.conv_wgrad(dy if dy_wgrad is None else dy_wgrad, a, up, base, cin, KH, KW, self.stride, self.pad, G,
+                             name=self.name + ".wgrad", dbias=db if base == 0 else None)
                 base += a.C
             if self.spectral:
                 dwo = grad_buffer(self.wparam)
@@ -414,8 +416,15 @@ class GeneratorTrainPlan:
         # conv_img reads lrelu(x_last): its dgrad carries that LeakyReLU's derivative
         # the gradient of a learned-shortcut block's output is read by conv_1's and conv_s's backward only (matrix
         # cores): stored in bf16 when that block's activations are (BlockT.wants_bf16_dout)
+        dpre8 = None
+        if ctx["last"].bf16:
+            # conv_img's weight gradient (3 output channels over 3.1 M pixels per image: memory-bound): a bf16 copy of
+            # d(pre-tanh), padded to one 16-byte group per pixel, lets it run on the LDS-DMA weight-gradient kernel
+            t8 = torch.zeros(dpre.t.shape[:3] + (8,), dtype=torch.bfloat16, device=dpre.t.device)
+            t8[..., :4].copy_(dpre.t)
+            dpre8 = Act(t8, 3)
         d_cur = self.img.backward(dpre, [(ctx["last"], 0)], grads, act_mask=ctx["last"], slope=0.2,
-                                  dx_bf16=self.blocks[-1].wants_bf16_dout(ctx["blocks"][-1]))
+                                  dx_bf16=self.blocks[-1].wants_bf16_dout(ctx["blocks"][-1]), dy_wgrad=dpre8)
         xin = ctx["xin"]
         for j in range(len(self.names) - 1, -1, -1):
             blk, c = self.blocks[j], ctx["blocks"][j]
