@@ -41,6 +41,16 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32), ("dx_bf16", C.c_int32), ("_pad_nb", C.c_int32)]
 
 
+class hrv_thin_conv_t(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("src_channels", C.c_int32),
+                ("src_cstride", C.c_int32), ("src_coff", C.c_int32),
+                ("w_oihw", C.c_void_p), ("Cout", C.c_int32), ("Cin", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("sigma", C.c_void_p), ("wscale", C.c_float), ("mode", C.c_int32), ("shift", C.c_void_p),
+                ("residual", C.c_void_p), ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("res_bf16", C.c_int32),
+                ("res_mode", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("out_bf16", C.c_int32)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -102,6 +112,8 @@ SYMBOLS = {
     "hrv_colsum_nhwc_f32": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hrv_norm_bwd_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "hrv_spade_norm_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), _vp]),
+    "hrv_thin_conv_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
+    "hrv_thin_conv_bf16": (C.c_int, [C.POINTER(hrv_thin_conv_t), _vp]),
     "hrv_loss_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f, _f, _vp, _vp, _vp, _i32, _vp]),
     "hrv_scale_f32": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
     "hrv_act_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _f, _vp]),

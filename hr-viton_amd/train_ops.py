@@ -102,6 +102,36 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
     return out
 
 
+def _thin_ok(a: Act, KH: int, KW: int, stride: int, pad: int, cols: int, N: int, H: int, W: int) -> bool:
+    """thin_conv.hip serves this layer: mixed precision, ONE bf16-stored source read at its own resolution, 3x3 / 1x1
+    stride-1 'same', <= 96 channels on either side (the 1024x768 level), enough pixels for a persistent grid."""
+    import os
+    return (MMA_BF16[0] and a.bf16 and stride == 1 and KH == KW and pad == KH // 2 and N * H * W >= 65536 and
+            os.environ.get("HRV_THIN_CONV", "1") != "0" and
+            bool(_lib.load().hrv_thin_conv_supported(KH, KW, a.Cp, cols)))
+
+
+def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift, residual: Optional[Act], res_mode: int,
+               act: int, slope: float, out: Act, name: str, flops: float):
+    lib = _lib.load()
+    d = _lib.hrv_thin_conv_t()
+    d.src, d.N, d.H, d.W = src.t.data_ptr(), src.N, src.H, src.W
+    d.src_channels, d.src_cstride, d.src_coff = src.Cp, src.cstride, src.coff
+    d.w_oihw, d.Cout, d.Cin, d.KH, d.KW = w.data_ptr(), w.shape[0], w.shape[1], w.shape[2], w.shape[3]
+    d.sigma = None if sigma is None else sigma.data_ptr()
+    d.wscale, d.mode = wscale, mode
+    d.shift = None if shift is None else shift.data_ptr()
+    if residual is not None:
+        d.residual, d.res_cstride, d.res_coff = residual.t.data_ptr(), residual.cstride, residual.coff
+        d.res_bf16 = 1 if residual.bf16 else 0
+    d.res_mode, d.act, d.act_slope = res_mode, act, slope
+    d.out, d.out_cstride, d.out_coff, d.out_bf16 = out.t.data_ptr(), out.cstride, out.coff, 1 if out.bf16 else 0
+    nbytes = ops.act_bytes(src) + ops.act_bytes(out) + ops.act_bytes(residual, out.C) + 4.0 * w.numel()
+    with _Timed("conv", name, flops, nbytes):
+        _lib.check(lib.hrv_thin_conv_bf16(C.byref(d), _stream()), f"hrv_thin_conv_bf16[{name}]")
+    return out
+
+
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
@@ -115,6 +145,13 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     mb = MMA_BF16[0]
+    if (len(srcs) == 1 and up0 == 0 and out_up == 0 and w.is_contiguous() and
+            _thin_ok(a0, KH, KW, stride, pad, Cout, N, H, W) and (out is None or out.cstride % 4 == 0)):
+        assert a0.C == cin, (name, a0.C, cin)
+        if out is None:
+            out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16 and Cout % 4 == 0)
+        return _thin_conv(a0, w, 0, sigma, wscale, shift, residual, 0, act, slope, out, name,
+                          2.0 * N * Ho * Wo * Cout * cin * KH * KW)
     cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
     if mb:                 # bf16-stored source: the halo patch stays in LDS (ops.patch_tile)
         if KH == 1 and KW == 1 and a0.bf16 and len(srcs) == 1 and a0.Cp <= 128 and Cout % 64 == 0:
@@ -147,6 +184,9 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
     cfg = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * H * W, cin)
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
+    if (stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
+            _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
+        return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
     if stride == 1:
         if mb and (Ho, Wo) == (H, W):   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
             cfg = ops.patch_tile(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) or cfg

@@ -246,6 +246,25 @@ typedef struct hrv_norm_bwd {
   int32_t _pad_nb;
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
+
+/* Thin convolution (thin_conv.hip): 3x3 / 1x1 stride-1 'same' nn.Conv2d with <= 96 channels on either side over a
+ * bf16-STORED NHWC source, forward (mode 0) or data gradient (mode 1: `src` is dY with Cout channels, the result has
+ * Cin columns, taps flipped) -- SPADEResBlock.conv_0 / conv_1 / conv_s at 1024x768 and conv_img
+ * (network_generator.py:141-143,201) in mixed-precision training.  `w_oihw` is the fp32 parameter on the device
+ * (weight_orig for spectral-norm layers; the kernel multiplies it by wscale / sigma[0]).
+ * out = act((conv + shift[c]) (+ residual | * act'(residual) for res_mode 1)), fp32 or bf16.
+ * hrv_thin_conv_supported() says whether a (kernel, source-channel, column) combination is instantiated. */
+typedef struct {
+  const void* src; int32_t N, H, W, src_channels, src_cstride, src_coff;
+  const float* w_oihw; int32_t Cout, Cin, KH, KW; const float* sigma; float wscale;
+  int32_t mode;
+  const float* shift;
+  const void* residual; int32_t res_cstride, res_coff, res_bf16, res_mode;
+  int32_t act; float act_slope;
+  void* out; int32_t out_cstride, out_coff, out_bf16;
+} hrv_thin_conv_t;
+int hrv_thin_conv_supported(int32_t KH, int32_t KW, int32_t src_channels, int32_t out_columns);
+int hrv_thin_conv_bf16(const hrv_thin_conv_t* d, hrv_stream_t stream);
 int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);
 /* Loss value + gradient in one pass.  mode 0: L1 |a-b| (feature matching / VGG,
  * train_generator.py:300-312); 1: hinge-D fake max(1+a,0); 2: hinge-D real max(1-a,0);

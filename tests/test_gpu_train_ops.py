@@ -472,3 +472,62 @@ def test_wgrad_tr_kernel_bf16_stored_operands(case, monkeypatch):
     assert (got[:, 8:] - res["0"][0][:, 8:]).abs().max().item() <= 6e-5 * scale
     dbr = dy.sum((0, 2, 3))
     assert (res["1"][1] - dbr).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item()
+
+
+@pytest.mark.parametrize("case", [("conv_0", 80, 32, 3, True, False, "none"), ("conv_1", 32, 32, 3, True, True, "lrelu"),
+                                  ("conv_s", 80, 32, 1, False, False, "none"), ("conv_img", 32, 3, 3, False, False, "tanh")],
+                         ids=lambda c: c[0])
+def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
+    """thin_conv.hip (weights converted into LDS once per persistent block, LDS-DMA halo patches, 32 pixels x all columns
+    per wave) for the <= 96-channel layers of the 1024x768 level: forward with bias / spectral 1/sigma / residual /
+    activation / bf16 output, and the data gradient (transposed, flipped weights), vs torch on the same bf16-representable
+    operands (fp32 accumulation) and vs the implicit-GEMM engine it replaces (HRV_THIN_CONV=0).  H and W overhang the 8x16
+    tiles, the source is a channel slice of a wider tensor."""
+    ops, T = _mods()
+    name, cin, cout, k, spectral, with_res, actn = case
+    N, H, W, pad = 2, 180, 200, k // 2
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g))
+    w = (torch.randn(cout, cin, k, k, generator=g) * 0.1).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    sigma = torch.tensor([1.7], device="cuda") if spectral else None
+    res = torch.randn(N, cout, H, W, generator=g) if with_res else None
+    dy = rb(torch.randn(N, cout, H, W, generator=g))
+    act = {"none": ops.ACT_NONE, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}[actn]
+
+    def sliced(t):
+        C_ = t.shape[1]
+        full = ops.alloc(t.shape[0], t.shape[2], t.shape[3], C_ + 16, "cuda", bf16=True)
+        full.t.normal_()
+        ops.to_nhwc(t.cuda(), out=full.slice(8, C_))
+        return full.slice(8, C_)
+
+    outs = {}
+    T.MMA_BF16[0] = True
+    try:
+        for thin in ("1", "0"):
+            monkeypatch.setenv("HRV_THIN_CONV", thin)
+            xa = sliced(x)
+            ra = ops.to_nhwc(res.cuda()) if with_res else None
+            y = T.conv_forward_dev(w, [(xa, 0)], 1, pad, sigma=sigma, shift=b, residual=ra, act=act, slope=0.2, name=name,
+                                   out_bf16=with_res)
+            outs[thin] = [ops.to_nchw(y).float().cpu()]
+            if cout % 8 == 0:
+                dx = T.conv_dgrad(sliced(dy), w, H, W, 1, pad, sigma=sigma, name=name + ".dgrad")
+                outs[thin].append(ops.to_nchw(dx).float().cpu())
+            torch.cuda.synchronize()
+    finally:
+        T.MMA_BF16[0] = False
+    ws = rb(w.cpu() / (1.7 if spectral else 1.0))
+    ref = F.conv2d(x, ws, b.cpu(), padding=pad)
+    if with_res:
+        ref = ref + res
+    ref = {"none": lambda t: t, "lrelu": lambda t: F.leaky_relu(t, 0.2), "tanh": torch.tanh}[actn](ref)
+    tol = 1e-2 if with_res else 2e-4            # bf16 output: one bf16 rounding of the result
+    assert (outs["1"][0] - ref).abs().max() <= tol * ref.abs().max(), (outs["1"][0] - ref).abs().max() / ref.abs().max()
+    assert (outs["1"][0] - outs["0"][0]).abs().max() <= tol * ref.abs().max()
+    if cout % 8 == 0:
+        refd = torch.nn.grad.conv2d_input(x.shape, ws, dy, stride=1, padding=pad)
+        assert (outs["1"][1] - refd).abs().max() <= 2e-4 * refd.abs().max(), (outs["1"][1] - refd).abs().max() / refd.abs().max()
+        assert (outs["1"][1] - outs["0"][1]).abs().max() <= 2e-4 * refd.abs().max()
