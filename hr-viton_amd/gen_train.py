@@ -379,6 +379,9 @@ class GeneratorTrainPlan:
             for c in b.convs():
                 c.prepare(power_iteration)
         xin = ops.to_nhwc(x)
+        # mixed precision: the full-resolution stem (conv_7: 9 -> 16 channels over every pixel) reads a bf16 copy of the
+        # input (matrix-core operand only) so that it runs on the thin-convolution kernel
+        xin_top = ops.to_nhwc(x, bf16=True) if (T.MMA_BF16[0] and W % 4 == 0) else xin
         sg = seg if isinstance(seg, Act) else ops.to_nhwc(seg)
         ctxs = []
         cur = None
@@ -387,10 +390,11 @@ class GeneratorTrainPlan:
             h, w = gen.sh << j, gen.sw << j
             shift = top - j
             cin = getattr(gen, name).input_nc
+            xs = xin_top if shift == 0 else xin
             if j == 0:
-                cur = self.stems[0].forward([(xin, -shift)])
+                cur = self.stems[0].forward([(xs, -shift)])
             else:
-                self.stems[j].forward([(xin, -shift)], out=cur.slice(cin - 16, 16))
+                self.stems[j].forward([(xs, -shift)], out=cur.slice(cin - 16, 16))
             k = 3 if blk.learned else 2
             zs = [z.to(dev).contiguous() for z in noise[name]] if noise is not None else \
                 [torch.randn(N, w, h, 1, device=dev) for _ in range(k)]
@@ -405,7 +409,7 @@ class GeneratorTrainPlan:
             ctxs.append(c)
             cur = o
         img = self.img.forward([(cur, 0)], act=ACT_TANH)
-        return ops.to_nchw(img), dict(blocks=ctxs, last=cur, img=img, xin=xin)
+        return ops.to_nchw(img), dict(blocks=ctxs, last=cur, img=img, xin=xin, xin_top=xin_top)
 
     def backward(self, ctx, d_img: torch.Tensor) -> Grads:
         grads: Grads = {}
@@ -423,13 +427,13 @@ class GeneratorTrainPlan:
             t8 = torch.zeros(dpre.t.shape[:3] + (8,), dtype=torch.bfloat16, device=dpre.t.device)
             t8[..., :4].copy_(dpre.t)
             dpre8 = Act(t8, 3)
-        d_cur = self.img.backward(dpre, [(ctx["last"], 0)], grads, act_mask=ctx["last"], slope=0.2,
-                                  dx_bf16=self.blocks[-1].wants_bf16_dout(ctx["blocks"][-1]), dy_wgrad=dpre8)
-        xin = ctx["xin"]
+        d_cur = self.img.backward(dpre if dpre8 is None else dpre8, [(ctx["last"], 0)], grads, act_mask=ctx["last"],
+                                  slope=0.2, dx_bf16=self.blocks[-1].wants_bf16_dout(ctx["blocks"][-1]))
         for j in range(len(self.names) - 1, -1, -1):
             blk, c = self.blocks[j], ctx["blocks"][j]
             d_x = blk.backward(c, d_cur, grads)
             cin = getattr(gen, self.names[j]).input_nc
+            xin = ctx["xin_top"] if c["shift"] == 0 else ctx["xin"]
             if j == 0:
                 self.stems[0].backward(d_x, [(xin, -c["shift"])], grads, need_dx=False)
             else:
