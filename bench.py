@@ -250,8 +250,9 @@ def wl_generator(ctx, mixed, B, train):
             broadcast_module(m)
         og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9))
         od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9))
-        sg = og.make_grad_sync() if world > 1 else None
-        sd = od.make_grad_sync() if world > 1 else None
+        fake = int(os.environ.get("HRV_FAKE_ALLREDUCE", "0") or 0) > 0     # 1-GPU overlap trace (tools/dp_overlap.sh)
+        sg = og.make_grad_sync() if (world > 1 or fake) else None
+        sd = od.make_grad_sync() if (world > 1 or fake) else None
         for s_ in (sg, sd):
             if s_ is not None:
                 attach_grad_sync(s_)

@@ -10,10 +10,36 @@ ring/direct all-reduce is bandwidth- rather than latency-bound; the 402 MB of ge
 go out as ~7 buckets in reverse-forward order (conv_img / up_4 first, head_0 last)."""
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional
 
 import torch
 import torch.distributed as dist
+
+
+class _FakeCollective:
+    """Single-GPU stand-in for a bucket's all-reduce (HRV_FAKE_ALLREDUCE=<repeats>): ``repeats`` device-to-device copies
+    of the bucket on a side stream, started when the bucket's last gradient exists on the compute stream and joined
+    by ``wait()`` -- the stream / event choreography of the RCCL path, so a 1-GPU kernel trace shows how much of the
+    collective's duration the remaining backward kernels hide (tools/dp_overlap.sh, profiles/r02_dp_overlap.txt)."""
+    stream: Optional[torch.cuda.Stream] = None
+
+    def __init__(self, flat: torch.Tensor, repeats: int):
+        if _FakeCollective.stream is None:
+            _FakeCollective.stream = torch.cuda.Stream()
+        ready = torch.cuda.Event()
+        ready.record()                                   # the bucket is final on the compute stream
+        self.done = torch.cuda.Event()
+        with torch.cuda.stream(_FakeCollective.stream):
+            _FakeCollective.stream.wait_event(ready)
+            scratch = torch.empty_like(flat)
+            for _ in range(repeats):
+                scratch.copy_(flat, non_blocking=True)
+            self.done.record()
+        self.scratch = scratch
+
+    def wait(self):
+        torch.cuda.current_stream().wait_event(self.done)
 
 
 class GradSync:
@@ -103,6 +129,8 @@ class GradSync:
     def _fire(self, b):
         if self.world > 1:
             b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
+        elif int(os.environ.get("HRV_FAKE_ALLREDUCE", "0") or 0) > 0 and b["flat"].is_cuda:
+            b["handle"] = _FakeCollective(b["flat"], int(os.environ["HRV_FAKE_ALLREDUCE"]))
         else:
             b["handle"] = True
 
