@@ -41,6 +41,11 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32), ("dx_bf16", C.c_int32), ("_pad_nb", C.c_int32)]
 
 
+class hrv_sn_job_t(C.Structure):
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("sigma", C.c_void_p), ("u_keep", C.c_void_p),
+                ("v_keep", C.c_void_p), ("R", C.c_int32), ("K", C.c_int32)]
+
+
 class hrv_thin_conv_t(C.Structure):
     _fields_ = [("src", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("src_channels", C.c_int32),
                 ("src_cstride", C.c_int32), ("src_coff", C.c_int32),
@@ -93,6 +98,7 @@ SYMBOLS = {
     "hrv_conv2d_pick_tile": (C.c_int, [_i64, _i32]),
     "hrv_conv2d_tile_bn": (C.c_int, [_i32]),
     "hrv_conv2d_tile_bm": (C.c_int, [_i32]),
+    "hrv_conv2d_tile_row_bytes": (C.c_int, [_i32]),
     "hrv_conv2d_packed_elems": (_i64, [_i32, _i32, _i32, _i32, _ip, _i32]),
     "hrv_conv2d_pack_weight_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _vp]),
     "hrv_conv2d_pack_weight_dev_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _i32, _i32, _i32,
@@ -126,6 +132,7 @@ SYMBOLS = {
     "hrv_adam_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _f, _vp]),
     "hrv_spectral_norm_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _f, _vp, _vp, _vp]),
     "hrv_spectral_norm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
+    "hrv_spectral_norm_batched_f32": (C.c_int, [_vp, _i32, _i32, _f, _vp, _vp]),
     "hrv_conv2d_workspace_bytes": (_i64, [C.POINTER(hrv_conv2d_t)]),
     "hrv_conv2d_nhwc_f32": (C.c_int, [C.POINTER(hrv_conv2d_t), _vp]),
     "hrv_conv2d_packed_elems_bf16": (_i64, [_i32, _i32, _i32, _i32, _ip, _i32]),

@@ -697,7 +697,13 @@ extern "C" int hrv_conv2d_pack_weight_dev_bf16(const float* w_oihw_dev, int32_t 
                                                int32_t phase_a, int32_t phase_b, float wscale,
                                                const float* sigma_dev, uint16_t* out_dev, int32_t* out_geom,
                                                hrv_stream_t stream) {
-  const int bke = (tile_cfg >= 8 && tile_cfg <= 11) ? 64 : 32;
+  // k-values per packed row follow the TILE's row size (128-byte rows: the LDS-DMA gather tiles 8-11 and every patch-mode
+  // tile 16-19).  (A range test on 8..11 here packed 32-value rows for the patch tiles: wrong weights whenever a
+  // training-path convolution picked tile 16-18 -- found by tools/diag/patch_train_check.py, pinned by
+  // test_training_convs_on_patch_tiles_match_torch.)
+  const int rb = hrv_conv2d_tile_row_bytes(tile_cfg);
+  HRV_REQUIRE(rb == 64 || rb == 128, "pack_dev: bad tile_cfg %d", tile_cfg);
+  const int bke = rb / 2;
   return pack_weight_dev_impl(w_oihw_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, stride, pad, phase_a,
                               phase_b, wscale, sigma_dev, out_dev, out_geom, stream, bke, 1);
 }

@@ -1267,6 +1267,8 @@ using namespace hrv;
 
 extern "C" int hrv_conv2d_tile_bn(int32_t c) { return (c >= 0 && c < kNumCfgs) ? cfg_bn(c) : -1; }
 extern "C" int hrv_conv2d_tile_bm(int32_t c) { return (c >= 0 && c < kNumCfgs) ? cfg_bm(c) : -1; }
+// bytes per packed K-tile row of the bf16 engine for this tile (64: 32 k-values, 128: 64 k-values)
+extern "C" int hrv_conv2d_tile_row_bytes(int32_t c) { return (c >= 0 && c < kNumCfgs) ? cfg_rb(c) : -1; }
 
 extern "C" int hrv_conv2d_pick_tile(int64_t M, int32_t Cout) {
   // 1) output-channel tile: least padding waste, ties -> wider tile (more A reuse)

@@ -425,10 +425,9 @@ __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, 
 // Spectral-norm power iteration GEMVs on W [R][K] (row-major):  y = W x  and  y = W^T x
 // (one block per row / per 64-column strip; fixed order => deterministic)
 // ---------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
-                                                        int K, float* __restrict__ y) {
+__device__ __forceinline__ void gemv_rows_body(const float* __restrict__ Wm, const float* __restrict__ x, int K,
+                                               float* __restrict__ y, int r) {
   __shared__ float red[256];
-  const int r = blockIdx.x;
   float s = 0.f;
   for (int k = threadIdx.x; k < K; k += 256) s += Wm[(size_t)r * K + k] * x[k];
   red[threadIdx.x] = s;
@@ -440,14 +439,19 @@ __global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict_
   if (threadIdx.x == 0) y[r] = red[0];
 }
 
-__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
+__global__ __launch_bounds__(256) void gemv_rows_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
                                                         int K, float* __restrict__ y) {
+  gemv_rows_body(Wm, x, K, y, blockIdx.x);
+}
+
+__device__ __forceinline__ void gemv_cols_body(const float* __restrict__ Wm, const float* __restrict__ x, int R, int K,
+                                               float* __restrict__ y, int blk) {
   // block = 64 columns; 16 row-groups x 16 lanes of 4 columns (16-byte loads when K % 4 == 0), four rows in flight
   // per thread (a 4-row-group version with one scalar load per iteration was pure latency: 51 us per call, 2.8 ms per
   // training step); partial sums are combined in row-group order => deterministic
   __shared__ float red[16][64];
   const int cq = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c0 = blockIdx.x * 64 + cq * 4;
+  const int c0 = blk * 64 + cq * 4;
   float s[4] = {0.f, 0.f, 0.f, 0.f};
   if ((K & 3) == 0 && c0 + 3 < K) {
     int r = rg;
@@ -482,12 +486,101 @@ __global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict_
   for (int e = 0; e < 4; ++e) red[rg][cq * 4 + e] = s[e];
   __syncthreads();
   if (threadIdx.x < 64) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
+    const int c = blk * 64 + threadIdx.x;
     float t = 0.f;
 #pragma unroll
     for (int g = 0; g < 16; ++g) t += red[g][threadIdx.x];
     if (c < K) y[c] = t;
   }
+}
+
+__global__ __launch_bounds__(256) void gemv_cols_kernel(const float* __restrict__ Wm, const float* __restrict__ x, int R,
+                                                        int K, float* __restrict__ y) {
+  gemv_cols_body(Wm, x, R, K, y, blockIdx.x);
+}
+
+// ---------------------------------------------------------------------------
+// Batched spectral norm: the power iteration of EVERY spectral-normalised convolution of a network in four launches
+// (the per-layer sequence above is eight launches of a few microseconds each; the generator has 27 such layers and runs
+// twice per training step).  The job table travels in the kernel arguments; a block finds its job by a scan of the
+// block-offset prefix (<= SN_MAX entries, wave-uniform).
+// ---------------------------------------------------------------------------
+constexpr int SN_MAX = 40;
+struct SnJob {
+  const float* w;
+  float *u, *v, *wv, *sigma, *u_keep, *v_keep;
+  int R, K;
+};
+struct SnBatch {
+  SnJob job[SN_MAX];
+  int col_blk[SN_MAX + 1], row_blk[SN_MAX + 1];
+  int n;
+  float eps;
+};
+
+__device__ __forceinline__ int sn_find(const int* __restrict__ prefix, int n, int b) {
+  int j = 0;
+  while (j + 1 < n && prefix[j + 1] <= b) ++j;
+  return j;
+}
+
+__global__ __launch_bounds__(256) void sn_gemv_cols_batched_kernel(const SnBatch B) {   // v' = W^T u
+  const int j = sn_find(B.col_blk, B.n, blockIdx.x);
+  const SnJob& J = B.job[j];
+  gemv_cols_body(J.w, J.u, J.R, J.K, J.v, blockIdx.x - B.col_blk[j]);
+}
+
+__global__ __launch_bounds__(256) void sn_gemv_rows_batched_kernel(const SnBatch B) {   // wv = W v
+  const int j = sn_find(B.row_blk, B.n, blockIdx.x);
+  const SnJob& J = B.job[j];
+  gemv_rows_body(J.w, J.v, J.K, J.wv, blockIdx.x - B.row_blk[j]);
+}
+
+__device__ __forceinline__ float block_sum256(float s) {
+  __shared__ float red[256];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  const float t = red[0];
+  __syncthreads();
+  return t;
+}
+
+// one block per job: v <- v / max(||v||, eps), copy kept for the backward
+__global__ __launch_bounds__(256) void sn_normalize_v_batched_kernel(const SnBatch B) {
+  const SnJob& J = B.job[blockIdx.x];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < J.K; i += 256) s += J.v[i] * J.v[i];
+  const float inv = 1.f / fmaxf(sqrtf(block_sum256(s)), B.eps);
+  for (int i = threadIdx.x; i < J.K; i += 256) {
+    const float t = J.v[i] * inv;
+    J.v[i] = t;
+    if (J.v_keep) J.v_keep[i] = t;
+  }
+}
+
+// one block per job: (iterate) u <- wv / max(||wv||, eps); sigma = u . wv; copies kept for the backward
+__global__ __launch_bounds__(256) void sn_finish_batched_kernel(const SnBatch B, int iterate) {
+  const SnJob& J = B.job[blockIdx.x];
+  if (iterate) {
+    float s = 0.f;
+    for (int i = threadIdx.x; i < J.R; i += 256) s += J.wv[i] * J.wv[i];
+    const float inv = 1.f / fmaxf(sqrtf(block_sum256(s)), B.eps);
+    for (int i = threadIdx.x; i < J.R; i += 256) J.u[i] = J.wv[i] * inv;
+  }
+  float d = 0.f;
+  for (int i = threadIdx.x; i < J.R; i += 256) {
+    const float ui = J.u[i];            // each thread re-reads the elements it wrote
+    d += ui * J.wv[i];
+    if (J.u_keep) J.u_keep[i] = ui;
+  }
+  if (!iterate && J.v_keep)
+    for (int i = threadIdx.x; i < J.K; i += 256) J.v_keep[i] = J.v[i];
+  d = block_sum256(d);
+  if (threadIdx.x == 0) J.sigma[0] = d;
 }
 
 // x <- x / max(||x||, eps); also returns ||x|| in out_norm (single block)
@@ -674,6 +767,42 @@ extern "C" int hrv_spectral_norm_f32(const float* w, int32_t R, int32_t K, float
   hipLaunchKernelGGL(gemv_rows_kernel, dim3(R), dim3(256), 0, st, w, v, R, K, wv_scratch);
   hipLaunchKernelGGL(dot_partial_kernel, dim3(1), dim3(256), 0, st, u, wv_scratch, (size_t)R, sigma_out);
   return check_launch("spectral_norm kernels");
+}
+
+extern "C" int hrv_spectral_norm_batched_f32(const hrv_sn_job_t* jobs, int32_t n_jobs, int32_t power_iterations, float eps,
+                                             float* wv_scratch, hrv_stream_t stream) {
+  HRV_REQUIRE(jobs && n_jobs > 0 && wv_scratch && power_iterations >= 0, "spectral_norm_batched: bad args");
+  hipStream_t st = (hipStream_t)stream;
+  float* scratch = wv_scratch;
+  for (int j0 = 0; j0 < n_jobs; j0 += SN_MAX) {
+    SnBatch B;
+    B.n = n_jobs - j0 < SN_MAX ? n_jobs - j0 : SN_MAX;
+    B.eps = eps;
+    B.col_blk[0] = B.row_blk[0] = 0;
+    for (int j = 0; j < B.n; ++j) {
+      const hrv_sn_job_t& s = jobs[j0 + j];
+      HRV_REQUIRE(s.w && s.u && s.v && s.sigma && s.R > 0 && s.K > 0, "spectral_norm_batched: job %d", j0 + j);
+      SnJob& J = B.job[j];
+      J.w = s.w; J.u = s.u; J.v = s.v; J.sigma = s.sigma; J.u_keep = s.u_keep; J.v_keep = s.v_keep; J.R = s.R; J.K = s.K;
+      J.wv = scratch;
+      scratch += s.R;
+      B.col_blk[j + 1] = B.col_blk[j] + (s.K + 63) / 64;
+      B.row_blk[j + 1] = B.row_blk[j] + s.R;
+    }
+    for (int it = 0; it < power_iterations; ++it) {
+      // v <- normalize(W^T u) ; u <- normalize(W v)    (torch SpectralNorm.compute_weight); the last pass also yields sigma
+      hipLaunchKernelGGL(sn_gemv_cols_batched_kernel, dim3(B.col_blk[B.n]), dim3(256), 0, st, B);
+      hipLaunchKernelGGL(sn_normalize_v_batched_kernel, dim3(B.n), dim3(256), 0, st, B);
+      hipLaunchKernelGGL(sn_gemv_rows_batched_kernel, dim3(B.row_blk[B.n]), dim3(256), 0, st, B);
+      // sigma = u . (W v) with the normalised u and the SAME W v (torch recomputes it: identical operands)
+      hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(B.n), dim3(256), 0, st, B, 1);
+    }
+    if (power_iterations == 0) {
+      hipLaunchKernelGGL(sn_gemv_rows_batched_kernel, dim3(B.row_blk[B.n]), dim3(256), 0, st, B);
+      hipLaunchKernelGGL(sn_finish_batched_kernel, dim3(B.n), dim3(256), 0, st, B, 0);
+    }
+  }
+  return check_launch("spectral_norm_batched kernels");
 }
 
 extern "C" int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* u, const float* v,

@@ -375,9 +375,8 @@ class GeneratorTrainPlan:
         nb = len(self.names)
         top = nb - 1
         dev = x.device
-        for b in self.blocks:
-            for c in b.convs():
-                c.prepare(power_iteration)
+        # one batched power iteration for every spectral-normalised convolution of the generator (four launches)
+        T.prepare_convs(self, [c for b in self.blocks for c in b.convs()], power_iteration)
         xin = ops.to_nhwc(x)
         # mixed precision: the full-resolution stem (conv_7: 9 -> 16 channels over every pixel) reads a bf16 copy of the
         # input (matrix-core operand only) so that it runs on the thin-convolution kernel
@@ -528,10 +527,11 @@ class DiscTrainPlan:
                 i += 1
         return self
 
-    def forward(self, a: Act, power_iteration: bool):
+    def forward(self, a: Act, power_iteration: bool, prepared: bool = False):
         feats, ctx = [], []
+        if not prepared:
+            T.prepare_convs(self, [conv for _, conv in self.layers], power_iteration)
         for kind, conv in self.layers:
-            conv.prepare(power_iteration)
             if kind in ("in", "in_drop"):
                 c = conv.forward([(a, 0)])
                 mean, rstd = ops.instnorm_stats(c)
@@ -595,9 +595,10 @@ class MultiscaleDTrainPlan:
     def forward(self, inp: torch.Tensor, power_iteration: bool):
         a = ops.to_nhwc(inp)
         feats_all, ctxs, inputs = [], [], []
+        T.prepare_convs(self, [conv for p in self.plans for _, conv in p.layers], power_iteration)
         for k, p in enumerate(self.plans):
             inputs.append(a)
-            feats, c = p.forward(a, power_iteration)
+            feats, c = p.forward(a, power_iteration, prepared=True)
             feats_all.append(feats)
             ctxs.append(c)
             if k + 1 < len(self.plans):

@@ -40,7 +40,7 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     bn = lib.hrv_conv2d_tile_bn(cfg)
     rows = Cout if mode == 0 else cin
     rows_pad = (rows + bn - 1) // bn * bn
-    bke = (64 if cfg >= 8 else 32) if bf16 else 16
+    bke = lib.hrv_conv2d_tile_row_bytes(cfg) // 2 if bf16 else 16      # k-values per packed row (the tile's row size)
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
     buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
     geom = (C.c_int32 * 8)()
@@ -385,6 +385,59 @@ def spectral_sigma(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, power
     _lib.check(lib.hrv_spectral_norm_f32(w_orig.data_ptr(), R, K, u.data_ptr(), v.data_ptr(), power_iterations, eps,
                                          scratch.data_ptr(), sigma.data_ptr(), _stream()), "hrv_spectral_norm_f32")
     return sigma
+
+
+class SpectralBatch:
+    """Power iteration + sigma of a LIST of spectral-normalised convolutions in four launches
+    (hrv_spectral_norm_batched_f32).  ``items``: (weight_orig, u, v) per layer.  ``run`` returns per-layer views
+    (sigma [1], u_keep, v_keep) of three flat buffers allocated for THIS call -- the (u, v) that produced sigma, which
+    the backward of this forward treats as constants (a later forward advances the module's u, v and gets its own)."""
+
+    def __init__(self, items):
+        self.items = list(items)
+        self.Rs = [w.shape[0] for w, _, _ in self.items]
+        self.Ks = [w.numel() // w.shape[0] for w, _, _ in self.items]
+        self.jobs = (_lib.hrv_sn_job_t * len(self.items))()
+        for j, (R, K) in enumerate(zip(self.Rs, self.Ks)):
+            self.jobs[j].R, self.jobs[j].K = R, K
+
+    def run(self, power_iterations: int, eps: float = 1e-12):
+        lib = _lib.load()
+        dev = self.items[0][0].device
+        n, sR, sK = len(self.items), sum(self.Rs), sum(self.Ks)
+        sig = torch.empty(n, dtype=torch.float32, device=dev)
+        ub = torch.empty(sR, dtype=torch.float32, device=dev)
+        vb = torch.empty(sK, dtype=torch.float32, device=dev)
+        scratch = _workspace(dev, sR)
+        sp, up, vp = sig.data_ptr(), ub.data_ptr(), vb.data_ptr()
+        ro = ko = 0
+        for j, (w, u, v) in enumerate(self.items):
+            J = self.jobs[j]
+            J.w, J.u, J.v = w.data_ptr(), u.data_ptr(), v.data_ptr()
+            J.sigma, J.u_keep, J.v_keep = sp + 4 * j, up + 4 * ro, vp + 4 * ko
+            ro, ko = ro + self.Rs[j], ko + self.Ks[j]
+        _lib.check(lib.hrv_spectral_norm_batched_f32(self.jobs, n, power_iterations, eps, scratch.data_ptr(), _stream()),
+                   "hrv_spectral_norm_batched_f32")
+        return sig.split(1), ub.split(self.Rs), vb.split(self.Ks)
+
+
+def prepare_convs(owner, convs, power_iteration: bool):
+    """TConv.prepare for every spectral-normalised convolution of ``convs`` at once (``owner`` caches the batch)."""
+    sn = [c for c in convs if c.spectral]
+    if not sn:
+        return
+    batch = getattr(owner, "_sn_batch", None)
+    key = tuple(id(c) for c in sn)
+    if batch is None or batch[0] != key:
+        for c in sn:
+            assert c.wparam.data.is_contiguous() and c.conv.weight_u.is_contiguous() and c.conv.weight_v.is_contiguous()
+        batch = (key, SpectralBatch([(c.wparam.data, c.conv.weight_u, c.conv.weight_v) for c in sn]))
+        owner._sn_batch = batch
+    b = batch[1]
+    b.items = [(c.wparam.data, c.conv.weight_u, c.conv.weight_v) for c in sn]     # .data may be re-pointed between steps
+    sig, us, vs = b.run(1 if power_iteration else 0)
+    for c, s_, u_, v_ in zip(sn, sig, us, vs):
+        c.sigma, c.u, c.v = s_, u_, v_
 
 
 def spectral_grad(G: torch.Tensor, w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, sigma: torch.Tensor,

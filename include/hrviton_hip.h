@@ -147,6 +147,8 @@ int hrv_conv2d_pick_tile(int64_t M, int32_t Cout);
 /* BN (output-channel tile) / BM (pixel tile) of a cfg; <0 if cfg is invalid. */
 int hrv_conv2d_tile_bn(int32_t tile_cfg);
 int hrv_conv2d_tile_bm(int32_t tile_cfg);
+/* Bytes per packed K-tile row of the bf16 engine for a cfg (64 = 32 k-values, 128 = 64 k-values); <0 if invalid. */
+int hrv_conv2d_tile_row_bytes(int32_t tile_cfg);
 /* Number of floats of the packed weight for this layer. */
 int64_t hrv_conv2d_packed_elems(int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
                                 const int32_t* srcC, int32_t tile_cfg);
@@ -308,6 +310,18 @@ int hrv_spectral_norm_f32(const float* w, int32_t R, int32_t K, float* u, float*
 int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* u, const float* v, const float* sigma,
                               int32_t R, int32_t K, float* workspace, float* dw_orig, int32_t accumulate,
                               hrv_stream_t stream);
+/* The same power iteration for EVERY spectral-normalised convolution of a network in four launches (27 layers in the
+ * SPADE generator, network_generator.py:121-143 via add_spectral_norm; per layer it is eight launches of microseconds).
+ * u_keep / v_keep (optional): copies of the (u, v) that produced sigma, for the backward.  wv_scratch: sum of R floats. */
+typedef struct {
+  const float* w;         /* weight_orig as [R][K] */
+  float *u, *v;           /* updated in place when power_iterations > 0 */
+  float* sigma;           /* one float per job */
+  float *u_keep, *v_keep; /* or NULL */
+  int32_t R, K;
+} hrv_sn_job_t;
+int hrv_spectral_norm_batched_f32(const hrv_sn_job_t* jobs, int32_t n_jobs, int32_t power_iterations, float eps,
+                                  float* wv_scratch, hrv_stream_t stream);
 
 /* Scratch the engine would like for this launch (0: none).  Layers with fewer than
  * ~192 output tiles split their K range over up to 32 blocks per tile (partials in

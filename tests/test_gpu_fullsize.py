@@ -98,8 +98,8 @@ def test_generator_forward_1024x768_ngf64_fp32_and_bf16_vs_oracle():
 
 def test_generator_step_512x384_ngf64_vs_oracle_autograd():
     """fp32 engine: reassociation only.  Mixed precision (--fp16: bf16 matrix-core operands) against the SAME fp32 oracle
-    pass -- stated bf16 tolerance: image mean-abs 2e-2, loss terms 2e-2 relative, gradient cosine >= 0.93 on every
-    sizeable parameter."""
+    pass -- stated bf16 tolerance: image mean-abs 3e-3 (max 3e-2 of the range), loss terms 2e-3 relative, gradient
+    cosine >= 0.99 on every sizeable parameter."""
     os.makedirs(OUT, exist_ok=True)
     reps = step_check.compare_generator_step(512, 384, 64, 64, 1, seed=0, wmul=8.0, mixed=(False, True), with_vgg=True,
                                              table_path=os.path.join(OUT, "grad_parity_gen_512x384_ngf64.txt"),
@@ -113,6 +113,8 @@ def test_generator_step_512x384_ngf64_vs_oracle_autograd():
     # sign() of the L1 terms (feature matching, VGG) turns round-off into flipped gradient elements deep below the loss
     assert rep["grad_worst_rel_err"] < 2e-2 and rep["grad_median_rel_err"] < 2e-3, rep
     rep = reps[True]
-    assert rep["image_mean_abs_err"] < 2e-2, rep
-    assert all(v < 2e-2 for v in rep["loss_rel_err"].values()), rep
-    assert rep["grad_min_cosine"] > 0.93, rep
+    # measured 1.2e-3 / 1.1e-2 / 1e-4 / 0.9943 -- and 5.4e-3 / 4.7e-2 / 2e-4 / 0.985 while the device packer fed the patch
+    # tiles of up_3 / up_4 wrong gamma|beta weights (gamma, beta are small at initialisation): the bounds sit between
+    assert rep["image_mean_abs_err"] < 3e-3 and rep["image_max_rel_err"] < 3e-2, rep
+    assert all(v < 2e-3 for v in rep["loss_rel_err"].values()), rep
+    assert rep["grad_min_cosine"] > 0.99, rep

@@ -531,3 +531,90 @@ def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
         refd = torch.nn.grad.conv2d_input(x.shape, ws, dy, stride=1, padding=pad)
         assert (outs["1"][1] - refd).abs().max() <= 2e-4 * refd.abs().max(), (outs["1"][1] - refd).abs().max() / refd.abs().max()
         assert (outs["1"][1] - outs["0"][1]).abs().max() <= 2e-4 * refd.abs().max()
+
+
+@pytest.mark.parametrize("case", [("tile17_256cols", 8, 128, 96, 128, 256, 17), ("tile18_192cols_split", 4, 128, 96, 128, 192, 18),
+                                  ("tile17_2chunks", 8, 128, 96, 256, 128, 17), ("tile18_64cols", 8, 128, 96, 128, 64, 18)],
+                         ids=lambda c: c[0])
+def test_training_convs_on_patch_tiles_match_torch(case, monkeypatch):
+    """conv_forward_dev / conv_dgrad (device-packed per-step weights) over a bf16-stored source at sizes where
+    ops.patch_tile SELECTS the LDS-resident patch tiles (>= 512 tiles; the parity fixtures are too small for that):
+    vs torch on the same bf16-representable operands and vs the gather tiles (HRV_CONV_PATCH=0).  Pins the device
+    packer's row size for tiles 16-18 (it packed 32 k-values per row where the kernels read 64: wrong weights in every
+    mixed-precision training convolution that picked a patch tile, which the 2e-2 bf16 image tolerance did not catch
+    because gamma / beta are small at initialisation -- tools/diag/patch_train_check.py, patch_spade_check.py)."""
+    ops, T = _mods()
+    name, N, H, W, cin, cout, want_cfg = case
+    g = torch.Generator().manual_seed(cin + cout)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g))
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    dy = rb(torch.randn(N, cout, H, W, generator=g))
+    assert ops.patch_tile(True, 3, 3, 1, 1, 1, 0, cin, cout, N, H, W) == want_cfg
+    outs = {}
+    T.MMA_BF16[0] = True
+    try:
+        for env in ("1", "0"):
+            monkeypatch.setenv("HRV_CONV_PATCH", env)
+            xa = ops.to_nhwc(x.cuda(), bf16=True)
+            y = T.conv_forward_dev(w, [(xa, 0)], 1, 1, shift=b, act=ops.ACT_LRELU, slope=0.2, name=name)
+            outs[env] = [ops.to_nchw(y).float().cpu()]
+            if cout % 128 == 0:            # the data gradient is a 'same' 3x3 convolution over dY: patch tiles too
+                assert env == "0" or ops.patch_tile(True, 3, 3, 1, 1, 1, 0, cout, cin, N, H, W) in (17, 18)
+                dx = T.conv_dgrad(ops.to_nhwc(dy.cuda(), bf16=True), w, H, W, 1, 1, name=name + ".dgrad")
+                outs[env].append(ops.to_nchw(dx).float().cpu())
+            torch.cuda.synchronize()
+    finally:
+        T.MMA_BF16[0] = False
+    ref = F.leaky_relu(F.conv2d(x, rb(w.cpu()), b.cpu(), padding=1), 0.2)
+    assert (outs["1"][0] - ref).abs().max() <= 2e-5 * ref.abs().max(), (outs["1"][0] - ref).abs().max() / ref.abs().max()
+    assert (outs["1"][0] - outs["0"][0]).abs().max() <= 2e-5 * ref.abs().max()
+    if cout % 128 == 0:
+        dref = F.conv_transpose2d(dy, rb(w.cpu()), padding=1)
+        assert (outs["1"][1] - dref).abs().max() <= 2e-5 * dref.abs().max()
+        assert (outs["1"][1] - outs["0"][1]).abs().max() <= 2e-5 * dref.abs().max()
+
+
+@pytest.mark.parametrize("case", [("C64_tile17", 2, 256, 192, 64, 17), ("C32_tile18", 4, 256, 192, 32, 18),
+                                  ("C96_tile18_split", 2, 256, 192, 96, 18)], ids=lambda c: c[0])
+def test_spade_training_layer_on_patch_tiles(case, monkeypatch):
+    """gen_train.SpadeT (network_generator.py:93-118 in training mode: noise, instance-norm statistics, fused gamma|beta
+    convolution + modulate + LeakyReLU, bf16 output) with the patch tiles selected vs the gather tiles (bit-identical
+    weights, same summation per output) and vs torch on the same bf16-representable operands; actv is a channel slice of
+    the block-wide tensor, as in the plan."""
+    from argparse import Namespace
+    ops, T = _mods()
+    from hr_viton_amd.gen_train import SpadeT
+    from hr_viton_amd.network_generator import SPADENorm
+    name, N, H, W, Cc, want_cfg = case
+    torch.manual_seed(Cc)
+    norm = SPADENorm(Namespace(), "aliasinstance", Cc, 7).cuda()
+    with torch.no_grad():
+        for p in norm.parameters():
+            p.copy_(torch.randn_like(p) * 0.05)
+    rb = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
+    x = torch.randn(N, H, W, Cc, device="cuda")
+    z = torch.randn(N, W, H, 1, device="cuda")
+    actv_all = torch.relu(torch.randn(N, H, W, 384, device="cuda")).to(torch.bfloat16)
+    a_nchw = actv_all[..., 128:256].float().permute(0, 3, 1, 2)
+    gamma = F.conv2d(a_nchw, rb(norm.conv_gamma.weight), norm.conv_gamma.bias, padding=1)
+    beta = F.conv2d(a_nchw, rb(norm.conv_beta.weight), norm.conv_beta.bias, padding=1)
+    xn = F.instance_norm(x.permute(0, 3, 1, 2) + (z * norm.noise_scale).transpose(1, 3), eps=1e-5)
+    ref = F.leaky_relu(xn * (1 + gamma) + beta, 0.2).permute(0, 2, 3, 1)
+    st = SpadeT(norm, ops.ACT_LRELU, name)
+    assert ops.patch_tile(True, 3, 3, 1, 1, 1, 0, 128, st.G * 64, N, H, W, wide=True) == want_cfg
+    outs = {}
+    T.MMA_BF16[0] = True
+    try:
+        for env in ("1", "0"):
+            monkeypatch.setenv("HRV_CONV_PATCH", env)
+            out, ctx = st.forward(ops.Act(x, Cc), ops.Act(actv_all, 128, 128), z, save=True)
+            outs[env] = (out.t[..., :Cc].float(), ctx["g1p"].t[..., :Cc].float())
+            assert out.bf16 == (Cc % 8 == 0)
+    finally:
+        T.MMA_BF16[0] = False
+    tol = 2.0 ** -8 * float(ref.abs().max())             # one bf16 rounding of the stored result
+    assert float((outs["1"][0] - ref).abs().max()) <= tol
+    assert torch.equal(outs["1"][0], outs["0"][0])
+    assert float((outs["1"][1] - (1 + gamma).permute(0, 2, 3, 1)).abs().max()) <= 2e-4 * float((1 + gamma).abs().max())
