@@ -268,7 +268,9 @@ def wl_generator(ctx, mixed, B, train):
             gp = os.path.join(ROOT, "gpurun_out")
             os.makedirs(gp, exist_ok=True)
             engines = (False, True) if mixed else (False,)
-            reps = step_check.compare_generator_step(512, 384, 64, 64, 1, mixed=engines, cpu_threads=ctx["cpu_threads"],
+            # at the bench resolution with two images: the size-gated kernels of the timed path (patch tiles, LDS-DMA weight
+            # gradients, thin convolutions, sub-batch launches) are the ones compared (~30 s of CPU autograd)
+            reps = step_check.compare_generator_step(1024, 768, 64, 64, 2, seed=1, mixed=engines, cpu_threads=ctx["cpu_threads"],
                                                      table_path=os.path.join(gp, "bench_grad_parity_gen.txt"))
             out = {"fp32_engine_vs_oracle": reps[False],
                    "tolerance_fp32": "image / losses 1e-3 rel (north star); per-parameter gradients 2e-2 of max(|g|, 1e-3 module max)"}

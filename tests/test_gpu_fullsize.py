@@ -118,3 +118,24 @@ def test_generator_step_512x384_ngf64_vs_oracle_autograd():
     assert rep["image_mean_abs_err"] < 3e-3 and rep["image_max_rel_err"] < 3e-2, rep
     assert all(v < 2e-3 for v in rep["loss_rel_err"].values()), rep
     assert rep["grad_min_cosine"] > 0.99, rep
+
+
+def test_generator_step_1024x768_batch2_vs_oracle_autograd():
+    """The same comparison at the BENCH resolution with two images: the tile counts of the released configuration, so
+    the size-gated kernels of the mixed-precision path are the ones compared -- patch tiles on up_1..up_4 (gamma|beta
+    forward / data gradient, the 128-channel resblock convolutions), LDS-DMA weight gradients, thin convolutions of the
+    1024x768 level, sub-batch launches.  (~13 GB per image for the CPU autograd pass.)"""
+    os.makedirs(OUT, exist_ok=True)
+    reps = step_check.compare_generator_step(1024, 768, 64, 64, 2, seed=1, wmul=8.0, mixed=(False, True), with_vgg=True,
+                                             table_path=os.path.join(OUT, "grad_parity_gen_1024x768_n2.txt"),
+                                             cpu_threads=min(os.cpu_count() or 1, 32))
+    with open(os.path.join(OUT, "step_parity_gen_1024x768_n2.txt"), "w") as f:
+        f.write(repr(reps) + "\n")
+    rep = reps[False]
+    assert rep["image_max_rel_err"] < 1e-3, rep
+    assert all(v < 1e-3 for v in rep["loss_rel_err"].values()), rep
+    assert rep["grad_worst_rel_err"] < 2e-2 and rep["grad_median_rel_err"] < 2e-3, rep
+    rep = reps[True]
+    assert rep["image_mean_abs_err"] < 3e-3 and rep["image_max_rel_err"] < 3e-2, rep
+    assert all(v < 2e-3 for v in rep["loss_rel_err"].values()), rep
+    assert rep["grad_min_cosine"] > 0.99, rep
