@@ -36,7 +36,30 @@ struct PackParams {
   float* out;            // [KHp*KWp*chunks_total][rows_pad][bke]  (fp32, or bf16 when `bf16`)
   int bke;               // k-values per packed row: 16 (fp32 engine), 32 / 64 (bf16 engine, 64- / 128-byte rows)
   int bf16;
+  // Weight PAIRS (the SPADE gamma / beta convolutions, network_generator.py:93-118, packed as ONE matrix without a
+  // concatenated copy): the Cout axis of the virtual weight is built from w (gamma) and w2 (beta), rows_each couts each.
+  //   pair_mode 1: interleaved 32|32 -- virtual cout 64g + l = gamma[32g + l] (l < 32) / beta[32g + l - 32]
+  //                (the fused modulate epilogue wants gamma_c and beta_c in the same lane)
+  //   pair_mode 2: concatenated  -- virtual cout c = gamma[c] (c < pair_split) / beta[c - pair_split]
+  const float* w2;
+  int pair_mode, rows_each, pair_split;
 };
+
+// virtual cout -> (weight pointer, real cout) of a pair; false: a padding row
+__device__ __forceinline__ bool pack_pair_src(const PackParams& p, int co, const float*& wp, int& cr) {
+  wp = p.w; cr = co;
+  if (p.pair_mode == 1) {
+    const int l = co & 63;
+    cr = (co >> 6) * 32 + (l & 31);
+    if (l >= 32) wp = p.w2;
+    return cr < p.rows_each;
+  }
+  if (p.pair_mode == 2) {
+    if (co >= p.pair_split) { wp = p.w2; cr = co - p.pair_split; }
+    return cr < p.rows_each;
+  }
+  return true;
+}
 
 __global__ void pack_weight_kernel(const PackParams p) {
   const int BKp = p.bke;
@@ -61,7 +84,9 @@ __global__ void pack_weight_kernel(const PackParams p) {
         const int cc = p.src_cbase[s] + c;
         const int co = p.transposed ? cc : row;
         const int ci = p.transposed ? row : cc;
-        v = p.w[(((size_t)co * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
+        const float* wp;
+        int cr;
+        if (pack_pair_src(p, co, wp, cr)) v = wp[(((size_t)cr * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
       }
     }
     if (p.bf16) {  // round to nearest even
@@ -611,7 +636,8 @@ static int pack_weight_dev_impl(const float* w_oihw_dev, int32_t Cout, int32_t K
                                 const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
                                 int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
                                 const float* sigma_dev, void* out_dev, int32_t* out_geom, hrv_stream_t stream,
-                                const int BK, const int as_bf16) {
+                                const int BK, const int as_bf16, const float* w2_dev = nullptr, int pair_mode = 0,
+                                int rows_each = 0) {
   HRV_REQUIRE(w_oihw_dev && out_dev && srcC && srcC_real && nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_dev: bad args");
   const int bn = hrv_conv2d_tile_bn(tile_cfg);
   HRV_REQUIRE(bn > 0, "pack_dev: bad tile_cfg %d", tile_cfg);
@@ -621,6 +647,12 @@ static int pack_weight_dev_impl(const float* w_oihw_dev, int32_t Cout, int32_t K
   memset(&p, 0, sizeof(p));
   p.w = w_oihw_dev; p.Cout = Cout; p.KH = KH; p.KW = KW; p.wscale = wscale; p.sigma = sigma_dev; p.out = (float*)out_dev;
   p.bke = BK; p.bf16 = as_bf16;
+  p.w2 = w2_dev; p.pair_mode = pair_mode; p.rows_each = rows_each;
+  HRV_REQUIRE(pair_mode == 0 || (w2_dev && rows_each > 0 && ((pair_mode == 1 && mode == 0 && Cout == (rows_each + 31) / 32 * 64) ||
+                                                              (pair_mode == 2 && mode == 1 && Cout % 2 == 0 && rows_each <= Cout / 2))),
+              "pack_dev: weight pair (mode 1: forward rows interleaved 32|32, Cout = 64*ceil(rows_each/32); mode 2: data "
+              "gradient over [gamma | beta] halves of Cout)");
+  p.pair_split = Cout / 2;
   int cin = 0;
   for (int i = 0; i < nsrc; ++i) cin += srcC_real[i];
   p.CinTot = cin;
@@ -706,6 +738,23 @@ extern "C" int hrv_conv2d_pack_weight_dev_bf16(const float* w_oihw_dev, int32_t 
   const int bke = rb / 2;
   return pack_weight_dev_impl(w_oihw_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, stride, pad, phase_a,
                               phase_b, wscale, sigma_dev, out_dev, out_geom, stream, bke, 1);
+}
+
+// The same packing for a weight PAIR (SPADE conv_gamma / conv_beta, both [rows_each][Cin][KH][KW]) without materialising
+// the combined matrix: pair_mode 1 = forward, virtual Cout = 64*ceil(rows_each/32) rows interleaved (gamma32 | beta32);
+// pair_mode 2 = stride-1 data gradient (mode 1) over dY = [dgamma | dbeta], each half Cout/2 channels wide.
+extern "C" int hrv_conv2d_pack_weight_pair_dev(const float* w_a_dev, const float* w_b_dev, int32_t rows_each, int32_t pair_mode,
+                                               int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
+                                               const int32_t* srcC_real, int32_t tile_cfg, int32_t mode, int32_t pad,
+                                               int32_t as_bf16, void* out_dev, int32_t* out_geom, hrv_stream_t stream) {
+  int bke = 16;
+  if (as_bf16) {
+    const int rb = hrv_conv2d_tile_row_bytes(tile_cfg);
+    HRV_REQUIRE(rb == 64 || rb == 128, "pack_pair_dev: bad tile_cfg %d", tile_cfg);
+    bke = rb / 2;
+  }
+  return pack_weight_dev_impl(w_a_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, 1, pad, 0, 0, 1.0f, nullptr, out_dev,
+                              out_geom, stream, bke, as_bf16 ? 1 : 0, w_b_dev, pair_mode, rows_each);
 }
 
 extern "C" int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P) {

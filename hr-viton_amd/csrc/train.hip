@@ -3,6 +3,8 @@
 // avg-pool backward, 2x2 max-pool forward/backward (VGG19), fused Adam, and the
 // GEMVs of the spectral-norm power iteration.  All reductions are two-stage with a
 // fixed summation order (deterministic).
+#include <string.h>
+
 #include "hrv_common.h"
 
 namespace hrv {
@@ -630,9 +632,98 @@ __global__ void sn_grad_kernel(const float* __restrict__ G, const float* __restr
   }
 }
 
+// ---------------------------------------------------------------------------
+// Per-step parameter staging of a SPADE norm / a SPADE block in ONE launch each (they were 5-9 torch fill / index_copy /
+// cat launches per norm and forward: ~750 launches of a few microseconds per training step).
+// ---------------------------------------------------------------------------
+// bias of the fused gamma|beta convolution in its interleaved column order (64g + l: gamma[32g + l] | beta[32g + l - 32])
+// and the noise scale padded to the channel stride
+__global__ __launch_bounds__(256) void spade_vec_prep_kernel(const float* __restrict__ gb, const float* __restrict__ bb,
+                                                             const float* __restrict__ ns, int C, int ncols, int Cp,
+                                                             float* __restrict__ bc, float* __restrict__ ns_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < ncols) {
+    const int l = i & 63, c = (i >> 6) * 32 + (l & 31);
+    bc[i] = c < C ? (l < 32 ? gb[c] : bb[c]) : 0.f;
+  }
+  if (i < Cp) ns_out[i] = i < C ? ns[i] : 0.f;
+}
+
+// conv_shared (label_nc -> hid, 3x3) of the n norms of a block as ONE 1x1 weight over the tap-expanded label map
+// (ops.tap_expand: tap-major, cp channels per tap): wt[(i*hid + o)][tap*cp + ch] = w_i[o][ch][tap]; bt = concat of biases
+struct SharedTaps {
+  const float* w[4];
+  const float* b[4];
+  float* gw[4];
+  float* gb[4];
+  int n, hid, c, cp;
+};
+__global__ __launch_bounds__(256) void shared_taps_prep_kernel(const SharedTaps p, float* __restrict__ wt, float* __restrict__ bt) {
+  const int K = 9 * p.cp, total = p.n * p.hid * K;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int k = i % K, row = i / K;
+    const int tap = k / p.cp, ch = k - tap * p.cp;
+    const int j = row / p.hid, o = row - j * p.hid;
+    wt[i] = ch < p.c ? p.w[j][((size_t)o * p.c + ch) * 9 + tap] : 0.f;
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n * p.hid; i += gridDim.x * 256) bt[i] = p.b[i / p.hid][i % p.hid];
+}
+// the inverse map for the gradients: gw_i[o][ch][tap] = dw[(i*hid + o)][tap*cp + ch], gb_i = db[i*hid ..]
+__global__ __launch_bounds__(256) void shared_taps_grad_kernel(const SharedTaps p, const float* __restrict__ dw,
+                                                               const float* __restrict__ db) {
+  const int per = p.hid * p.c * 9, total = p.n * per, K = 9 * p.cp;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int j = i / per, r = i - j * per;
+    const int tap = r % 9, ch = (r / 9) % p.c, o = r / (9 * p.c);
+    p.gw[j][r] = dw[(size_t)(j * p.hid + o) * K + tap * p.cp + ch];
+  }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.n * p.hid; i += gridDim.x * 256) p.gb[i / p.hid][i % p.hid] = db[i];
+}
+
 }  // namespace hrv
 
 using namespace hrv;
+
+extern "C" int hrv_spade_vec_prep_f32(const float* gamma_bias, const float* beta_bias, const float* noise_scale, int32_t C,
+                                      float* bias_interleaved, float* noise_scale_padded, hrv_stream_t stream) {
+  HRV_REQUIRE(gamma_bias && beta_bias && noise_scale && bias_interleaved && noise_scale_padded && C > 0, "spade_vec_prep: bad args");
+  const int ncols = (C + 31) / 32 * 64, Cp = (C + 3) / 4 * 4;
+  hipLaunchKernelGGL(spade_vec_prep_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma_bias, beta_bias,
+                     noise_scale, C, ncols, Cp, bias_interleaved, noise_scale_padded);
+  return check_launch("spade_vec_prep_kernel");
+}
+
+static int shared_taps_fill(SharedTaps& p, const float* const* w, const float* const* b, float* const* gw, float* const* gb,
+                            int32_t n, int32_t hid, int32_t c, int32_t cp) {
+  HRV_REQUIRE(n >= 1 && n <= 4 && hid > 0 && c > 0 && cp >= c, "shared_taps: n in 1..4, cp >= c");
+  memset(&p, 0, sizeof(p));
+  for (int i = 0; i < n; ++i) {
+    if (w) { HRV_REQUIRE(w[i] && b[i], "shared_taps: null weight"); p.w[i] = w[i]; p.b[i] = b[i]; }
+    if (gw) { HRV_REQUIRE(gw[i] && gb[i], "shared_taps: null gradient"); p.gw[i] = gw[i]; p.gb[i] = gb[i]; }
+  }
+  p.n = n; p.hid = hid; p.c = c; p.cp = cp;
+  return HRV_OK;
+}
+
+extern "C" int hrv_shared_taps_prep_f32(const float* const* w, const float* const* b, int32_t n, int32_t hid, int32_t c,
+                                        int32_t cp, float* wt, float* bt, hrv_stream_t stream) {
+  HRV_REQUIRE(w && b && wt && bt, "shared_taps_prep: null pointer");
+  SharedTaps p;
+  const int rc = shared_taps_fill(p, w, b, nullptr, nullptr, n, hid, c, cp);
+  if (rc) return rc;
+  hipLaunchKernelGGL(shared_taps_prep_kernel, dim3(grid_for((size_t)n * hid * 9 * cp)), dim3(256), 0, (hipStream_t)stream, p, wt, bt);
+  return check_launch("shared_taps_prep_kernel");
+}
+
+extern "C" int hrv_shared_taps_grad_f32(const float* dw, const float* db, int32_t n, int32_t hid, int32_t c, int32_t cp,
+                                        float* const* gw, float* const* gb, hrv_stream_t stream) {
+  HRV_REQUIRE(dw && db && gw && gb, "shared_taps_grad: null pointer");
+  SharedTaps p;
+  const int rc = shared_taps_fill(p, nullptr, nullptr, gw, gb, n, hid, c, cp);
+  if (rc) return rc;
+  hipLaunchKernelGGL(shared_taps_grad_kernel, dim3(grid_for((size_t)n * hid * c * 9)), dim3(256), 0, (hipStream_t)stream, p, dw, db);
+  return check_launch("shared_taps_grad_kernel");
+}
 
 extern "C" int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C) {
   if (N <= 0 || H <= 0 || W <= 0 || C <= 0) return -1;

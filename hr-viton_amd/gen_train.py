@@ -159,22 +159,17 @@ class SpadeT:
     def forward(self, x: Act, actv: Act, z: Optional[torch.Tensor], save: bool = True):
         n = self.norm
         dev = x.t.device
-        ns = torch.zeros(self.Cp, device=dev)
-        ns[: self.C] = n.noise_scale.data
+        # bias of the fused conv in its interleaved (gamma32 | beta32) column order + padded noise scale: one launch
+        bc, ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)
         zz = z  # the noise term is always applied in training (noise_scale is a learnable parameter)
         mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
         mb = T.MMA_BF16[0]     # mixed precision: bf16 matrix cores, fp32 epilogue / statistics / x
-        # combined (gamma32 | beta32) weight / bias for the fused modulate epilogue (device gather)
-        wc = torch.zeros((self.G * 64, self.hid, 3, 3), device=dev)
-        wc.index_copy_(0, self.rows_g, n.conv_gamma.weight.data)
-        wc.index_copy_(0, self.rows_b, n.conv_beta.weight.data)
-        bc = torch.zeros(self.G * 64, device=dev)
-        bc.index_copy_(0, self.rows_g, n.conv_gamma.bias.data)
-        bc.index_copy_(0, self.rows_b, n.conv_beta.bias.data)
         cfg = ((8 if self.G % 2 == 0 else 9) if mb else self.cfg)
         if mb:                 # bf16 actv: each tile's halo patch stays in LDS (ops.patch_tile)
             cfg = ops.patch_tile(actv.bf16, 3, 3, 1, 1, 1, 0, self.hid, self.G * 64, x.N, x.H, x.W, wide=True) or cfg
-        packed, _ = T.pack_weight_dev(wc, [self.hid], [self.hid], cfg, 0, 1, 1, bf16=mb)
+        # (conv_gamma, conv_beta) weights packed straight into the combined interleaved matrix (no concatenated copy)
+        packed, _, _ = T.pack_weight_pair_dev(n.conv_gamma.weight.data, n.conv_beta.weight.data, 1, [self.hid], [self.hid],
+                                              cfg, 0, 1, mb)
         # mixed precision: the modulated activation is read by matrix cores only (conv_0 / conv_1 / conv_s, their weight
         # gradients) and as the sign mask of its own LeakyReLU -- stored in bf16 (same operand bits as rounding while
         # staging, half the bytes); widths that are not a multiple of 4 keep the fp32 weight-gradient kernel and fp32
@@ -234,10 +229,13 @@ class SpadeT:
             _acc(grads, n.noise_scale, torch.zeros(C_, device=dev))
         # gamma/beta convs: one conv with Wcat = [Wgamma ; Wbeta] over dgb = [dgamma | dbeta]
         actv = ctx["actv"]
-        wcat = torch.zeros((2 * Cp, self.hid, 3, 3), device=dev)
-        wcat[:C_] = n.conv_gamma.weight.data
-        wcat[Cp:Cp + C_] = n.conv_beta.weight.data
-        dwcat = torch.empty_like(wcat)
+        if Cp == C_:           # dense halves: the data gradient packs (W_gamma, W_beta) as a pair, no concatenated copy
+            wcat = (n.conv_gamma.weight.data, n.conv_beta.weight.data)
+        else:
+            wcat = torch.zeros((2 * Cp, self.hid, 3, 3), device=dev)
+            wcat[:C_] = n.conv_gamma.weight.data
+            wcat[Cp:Cp + C_] = n.conv_beta.weight.data
+        dwcat = torch.empty((2 * Cp, self.hid, 3, 3), device=dev)
         db = torch.empty(2 * Cp, device=dev)
         T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad", dbias=db)
         direct = flat_grad_slot(n.conv_gamma.weight) is not None
@@ -291,15 +289,10 @@ class BlockT:
         mb = mb and sg.bf16
         segx = ops.tap_expand(sg, seg_shift, 3)
         cp = sg.Cp
-        ws, bs = [], []
-        for n_ in norms:
-            w, b, c = n_.shared_as_1x1()
-            wt = torch.zeros((w.shape[0], 9, cp), device=w.device)
-            wt[:, :, :c] = w.reshape(w.shape[0], 9, c)
-            ws.append(wt.reshape(w.shape[0], 9 * cp, 1, 1))
-            bs.append(b)
+        # the norms' conv_shared weights as one tap-major 1x1 weight + concatenated bias: one launch
+        wt_all, b_all = T.shared_taps_prep([n_.shared.wparam.data for n_ in norms], [n_.shared.bparam.data for n_ in norms], cp)
         hid = norms[0].hid
-        actv_all = T.conv_forward_dev(torch.cat(ws, 0), [(segx, 0)], 1, 0, shift=torch.cat(bs, 0), act=ACT_RELU,
+        actv_all = T.conv_forward_dev(wt_all, [(segx, 0)], 1, 0, shift=b_all, act=ACT_RELU,
                                       out_bf16=mb, name=self.name + ".conv_shared[x%d as 1x1 over taps]" % len(norms))
         return segx, [actv_all.slice(hid * i, hid) for i in range(len(norms))]
 
@@ -309,11 +302,13 @@ class BlockT:
         dw = torch.empty((hid * len(norms), segx.C, 1, 1), device=dact_all.t.device)
         db = torch.empty(hid * len(norms), device=dact_all.t.device)
         T.conv_wgrad(dact_all, segx, 0, 0, segx.C, 1, 1, 1, 0, dw, name=self.name + ".conv_shared.wgrad", dbias=db)
-        for i, n_ in enumerate(norms):
-            c = n_.shared.wparam.shape[1]
-            g = dw[hid * i:hid * (i + 1)].reshape(hid, 9, cp)[:, :, :c].permute(0, 2, 1).reshape(hid, c, 3, 3)
-            _acc(grads, n_.shared.wparam, g.contiguous())
-            _acc(grads, n_.shared.bparam, db[hid * i:hid * (i + 1)].clone())
+        # tap-major 1x1 gradient -> the norms' [hid, c, 3, 3] weight / bias gradients (their flat-buffer slots when free)
+        gws = [grad_buffer(n_.shared.wparam) for n_ in norms]
+        gbs = [grad_buffer(n_.shared.bparam) for n_ in norms]
+        T.shared_taps_grad(dw, db, gws, gbs, cp)
+        for n_, gw, gb in zip(norms, gws, gbs):
+            _acc(grads, n_.shared.wparam, gw)
+            _acc(grads, n_.shared.bparam, gb)
 
     def forward(self, x: Act, seg: Act, seg_shift: int, zs, out: Optional[Act], out_up: int, out_act: int,
                 save: bool = True):

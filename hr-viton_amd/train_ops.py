@@ -51,6 +51,71 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     return buf, tuple(geom)
 
 
+def pack_weight_pair_dev(w_a: torch.Tensor, w_b: torch.Tensor, pair_mode: int, src_pad: Sequence[int], src_real: Sequence[int],
+                         cfg: int, mode: int, pad: int, bf16: bool):
+    """hrv_conv2d_pack_weight_pair_dev: (conv_gamma.weight, conv_beta.weight) packed as ONE matrix without a
+    concatenated copy.  pair_mode 1 (forward): rows interleaved (gamma32 | beta32); 2 (data gradient over
+    [dgamma | dbeta]).  Returns (packed, geom, virtual Cout)."""
+    lib = _lib.load()
+    ops.require_cuda(w_a, "pack_weight_pair_dev")
+    assert w_a.is_contiguous() and w_b.is_contiguous() and w_a.shape == w_b.shape
+    rows_each, cin, KH, KW = w_a.shape
+    Cout = (rows_each + 31) // 32 * 64 if pair_mode == 1 else 2 * rows_each
+    assert pair_mode == 1 or rows_each % 4 == 0, "the [dgamma | dbeta] halves must be dense (C % 4 == 0)"
+    n = len(src_pad)
+    srcC = (C.c_int32 * n)(*src_pad)
+    srcR = (C.c_int32 * n)(*src_real)
+    bn = lib.hrv_conv2d_tile_bn(cfg)
+    rows = Cout if mode == 0 else cin
+    rows_pad = (rows + bn - 1) // bn * bn
+    bke = lib.hrv_conv2d_tile_row_bytes(cfg) // 2 if bf16 else 16
+    chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
+    buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w_a.device)
+    geom = (C.c_int32 * 8)()
+    _lib.check(lib.hrv_conv2d_pack_weight_pair_dev(w_a.data_ptr(), w_b.data_ptr(), rows_each, pair_mode, Cout, KH, KW, n, srcC,
+                                                   srcR, cfg, mode, pad, 1 if bf16 else 0, buf.data_ptr(), geom, _stream()),
+               "hrv_conv2d_pack_weight_pair_dev")
+    return buf, tuple(geom), Cout
+
+
+def spade_vec_prep(gamma_bias: torch.Tensor, beta_bias: torch.Tensor, noise_scale: torch.Tensor):
+    """-> (bias of the fused gamma|beta conv in its interleaved column order, noise scale padded to ceil4(C))."""
+    lib = _lib.load()
+    C_ = gamma_bias.numel()
+    bc = torch.empty((C_ + 31) // 32 * 64, dtype=torch.float32, device=gamma_bias.device)
+    ns = torch.empty(_ceil4(C_), dtype=torch.float32, device=gamma_bias.device)
+    _lib.check(lib.hrv_spade_vec_prep_f32(gamma_bias.data_ptr(), beta_bias.data_ptr(), noise_scale.data_ptr(), C_,
+                                          bc.data_ptr(), ns.data_ptr(), _stream()), "hrv_spade_vec_prep_f32")
+    return bc, ns
+
+
+def shared_taps_prep(ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor], cp: int):
+    """conv_shared [hid, c, 3, 3] x n -> one 1x1 weight [n*hid, 9*cp, 1, 1] over the tap-expanded label map, + bias."""
+    lib = _lib.load()
+    n = len(ws)
+    hid, c = ws[0].shape[0], ws[0].shape[1]
+    assert all(w.is_contiguous() and tuple(w.shape) == (hid, c, 3, 3) for w in ws)
+    wt = torch.empty((n * hid, 9 * cp, 1, 1), dtype=torch.float32, device=ws[0].device)
+    bt = torch.empty(n * hid, dtype=torch.float32, device=ws[0].device)
+    wp = (C.c_void_p * n)(*[w.data_ptr() for w in ws])
+    bp = (C.c_void_p * n)(*[b.data_ptr() for b in bs])
+    _lib.check(lib.hrv_shared_taps_prep_f32(wp, bp, n, hid, c, cp, wt.data_ptr(), bt.data_ptr(), _stream()),
+               "hrv_shared_taps_prep_f32")
+    return wt, bt
+
+
+def shared_taps_grad(dw: torch.Tensor, db: torch.Tensor, gws: Sequence[torch.Tensor], gbs: Sequence[torch.Tensor], cp: int):
+    """Inverse of shared_taps_prep for the gradients: writes every gws[i] [hid, c, 3, 3] and gbs[i] [hid]."""
+    lib = _lib.load()
+    n = len(gws)
+    hid, c = gws[0].shape[0], gws[0].shape[1]
+    assert all(g.is_contiguous() for g in gws) and all(g.is_contiguous() for g in gbs)
+    gp = (C.c_void_p * n)(*[g.data_ptr() for g in gws])
+    bp = (C.c_void_p * n)(*[g.data_ptr() for g in gbs])
+    _lib.check(lib.hrv_shared_taps_grad_f32(dw.data_ptr(), db.data_ptr(), n, hid, c, cp, gp, bp, _stream()),
+               "hrv_shared_taps_grad_f32")
+
+
 def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_h, pad_w, out: Act, scale=None,
                 shift=None, residual: Optional[Act] = None, res_mode: int = 0, act: int = ACT_NONE, slope: float = 0.2,
                 free_extent: int = 0, out_step: int = 0, out_off=(0, 0), out_hw=(0, 0), out_up: int = 0,
@@ -169,13 +234,20 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
                        mma_bf16=mb)
 
 
-def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
+def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
                sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
                name: str = "dgrad", out_bf16: bool = False) -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
-    activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x)."""
+    activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x).
+    ``w`` may be a PAIR (w_gamma, w_beta) for dY = [dgamma | dbeta] (stride 1): packed without a concatenated copy."""
     lib = _lib.load()
-    Cout, cin, KH, KW = w.shape
+    pair = w if isinstance(w, (tuple, list)) else None
+    if pair is not None:
+        assert stride == 1 and sigma is None and wscale == 1.0
+        w = pair[0]
+        Cout, cin, KH, KW = 2 * w.shape[0], w.shape[1], w.shape[2], w.shape[3]
+    else:
+        Cout, cin, KH, KW = w.shape
     N, Ho, Wo = dy.N, dy.H, dy.W
     assert dy.C == Cout
     mb = MMA_BF16[0]
@@ -184,13 +256,16 @@ def conv_dgrad(dy: Act, w: torch.Tensor, H: int, W: int, stride: int, pad: int, 
     cfg = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * H * W, cin)
     res_mode = 1 if act_mask is not None else 0
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
-    if (stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
+    if (pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
     if stride == 1:
         if mb and (Ho, Wo) == (H, W):   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
             cfg = ops.patch_tile(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) or cfg
-        packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb)
+        if pair is not None:
+            packed, g, _ = pack_weight_pair_dev(pair[0], pair[1], 2, [_ceil4(cin)], [cin], cfg, 1, pad, mb)
+        else:
+            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
                     residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl, mma_bf16=mb)
         return out
@@ -408,7 +483,7 @@ class SpectralBatch:
         sig = torch.empty(n, dtype=torch.float32, device=dev)
         ub = torch.empty(sR, dtype=torch.float32, device=dev)
         vb = torch.empty(sK, dtype=torch.float32, device=dev)
-        scratch = _workspace(dev, sR)
+        scratch = _workspace(dev, 4 * sR)               # bytes: W v of every job
         sp, up, vp = sig.data_ptr(), ub.data_ptr(), vb.data_ptr()
         ro = ko = 0
         for j, (w, u, v) in enumerate(self.items):

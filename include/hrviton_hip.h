@@ -187,6 +187,14 @@ int hrv_conv2d_pack_weight_dev_bf16(const float* w_oihw_dev, int32_t Cout, int32
                                     const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
                                     int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
                                     const float* sigma_dev, uint16_t* out_dev, int32_t* out_geom, hrv_stream_t stream);
+/* The same packing for a weight PAIR -- SPADE conv_gamma / conv_beta (network_generator.py:93-118), both
+ * [rows_each][Cin][KH][KW] -- without materialising the combined matrix.  pair_mode 1: forward (mode 0), virtual
+ * Cout = 64*ceil(rows_each/32) rows interleaved (gamma32 | beta32), the column order of the fused modulate epilogue;
+ * pair_mode 2: stride-1 data gradient (mode 1) over dY = [dgamma | dbeta], Cout = 2 * (channels per half). */
+int hrv_conv2d_pack_weight_pair_dev(const float* w_a_dev, const float* w_b_dev, int32_t rows_each, int32_t pair_mode,
+                                    int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
+                                    const int32_t* srcC_real, int32_t tile_cfg, int32_t mode, int32_t pad, int32_t as_bf16,
+                                    void* out_dev, int32_t* out_geom, hrv_stream_t stream);
 int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P);
 int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
                               int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,
@@ -310,6 +318,18 @@ int hrv_spectral_norm_f32(const float* w, int32_t R, int32_t K, float* u, float*
 int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* u, const float* v, const float* sigma,
                               int32_t R, int32_t K, float* workspace, float* dw_orig, int32_t accumulate,
                               hrv_stream_t stream);
+/* Per-step parameter staging of a SPADE norm / block, one launch each:
+ *  vec_prep: bias of the fused gamma|beta convolution in its interleaved column order (64*ceil(C/32) floats) and the
+ *            noise scale zero-padded to ceil4(C);
+ *  shared_taps_prep: conv_shared (label_nc=c -> hid, 3x3) of the n <= 4 norms of a block as ONE 1x1 weight
+ *            wt[n*hid][9*cp] over the tap-expanded label map (tap-major, cp channels per tap) + concatenated bias;
+ *  shared_taps_grad: the inverse map of that weight's gradient into the n conv_shared weight / bias gradients. */
+int hrv_spade_vec_prep_f32(const float* gamma_bias, const float* beta_bias, const float* noise_scale, int32_t C,
+                           float* bias_interleaved, float* noise_scale_padded, hrv_stream_t stream);
+int hrv_shared_taps_prep_f32(const float* const* w, const float* const* b, int32_t n, int32_t hid, int32_t c, int32_t cp,
+                             float* wt, float* bt, hrv_stream_t stream);
+int hrv_shared_taps_grad_f32(const float* dw, const float* db, int32_t n, int32_t hid, int32_t c, int32_t cp,
+                             float* const* gw, float* const* gb, hrv_stream_t stream);
 /* The same power iteration for EVERY spectral-normalised convolution of a network in four launches (27 layers in the
  * SPADE generator, network_generator.py:121-143 via add_spectral_norm; per layer it is eight launches of microseconds).
  * u_keep / v_keep (optional): copies of the (u, v) that produced sigma, for the backward.  wv_scratch: sum of R floats. */

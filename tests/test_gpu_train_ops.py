@@ -618,3 +618,31 @@ def test_spade_training_layer_on_patch_tiles(case, monkeypatch):
     assert float((outs["1"][0] - ref).abs().max()) <= tol
     assert torch.equal(outs["1"][0], outs["0"][0])
     assert float((outs["1"][1] - (1 + gamma).permute(0, 2, 3, 1)).abs().max()) <= 2e-4 * float((1 + gamma).abs().max())
+
+
+@pytest.mark.parametrize("iters", [1, 0], ids=["train", "eval"])
+def test_batched_spectral_norm_matches_per_layer_and_torch(iters):
+    """hrv_spectral_norm_batched_f32 (every spectral-normalised convolution of a network in four launches) vs the
+    per-layer entry and vs torch's SpectralNorm.compute_weight formulas, incl. the kept (u, v) copies; the shared
+    scratch starts EMPTY (a too-small scratch faulted in the first call of a fresh process)."""
+    ops, T = _mods()
+    ops._WS.clear()
+    g = torch.Generator().manual_seed(3)
+    shapes = [(16, 9, 3, 3), (1024, 64, 3, 3), (8, 8, 1, 1), (130, 24, 3, 3), (3, 64, 3, 3)]
+    ws = [torch.randn(s, generator=g).cuda() for s in shapes]
+    us = [F.normalize(torch.randn(s[0], generator=g), dim=0).cuda() for s in shapes]
+    vs = [F.normalize(torch.randn(s[1] * s[2] * s[3], generator=g), dim=0).cuda() for s in shapes]
+    u1, v1 = [u.clone() for u in us], [v.clone() for v in vs]
+    sig1 = [T.spectral_sigma(w, u, v, iters) for w, u, v in zip(ws, u1, v1)]
+    u2, v2 = [u.clone() for u in us], [v.clone() for v in vs]
+    sig2, uk, vk = T.SpectralBatch(list(zip(ws, u2, v2))).run(iters)
+    for j, w in enumerate(ws):
+        Wm = w.reshape(w.shape[0], -1)
+        u, v = us[j], vs[j]
+        if iters:
+            v = F.normalize(Wm.t() @ u, dim=0, eps=1e-12)
+            u = F.normalize(Wm @ v, dim=0, eps=1e-12)
+        sg = torch.dot(u, Wm @ v)
+        for got_s, got_u, got_v in ((sig1[j], u1[j], v1[j]), (sig2[j], u2[j], v2[j]), (sig2[j], uk[j], vk[j])):
+            assert abs(float(got_s) - float(sg)) <= 2e-5 * abs(float(sg)), (j, float(got_s), float(sg))
+            assert torch.allclose(got_u, u, atol=2e-6) and torch.allclose(got_v, v, atol=2e-6), j
