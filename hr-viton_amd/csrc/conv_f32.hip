@@ -30,8 +30,10 @@
 
 namespace hrv {
 
+// One output tile of the implicit GEMM.  ``bid``: dispatch-order id of the tile (blockIdx.x for the one-tile-per-block
+// launches; the persistent patch launches walk bid = blockIdx.x, + gridDim.x, ...).
 template <int TM, int TN, int WM, int WN, int VAR, bool BF, int RB = 64>
-__global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma_kernel(const ConvParams p) {
+__device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const int bid) {
   static_assert(WM * WN == 4 || WM * WN == 8, "4 or 8 MMA waves per block");
   constexpr int NT = 64 * WM * WN;   // threads that share the gather / the MMA wave grid
   // VAR bit 5: wave specialisation.  The block carries WM*WN extra LOADER waves: they issue every LDS-DMA
@@ -92,7 +94,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   const int wm = wave / WN;
   const int wn = wave % WN;
 
-  const int lid_all = xcd_remap(blockIdx.x, p.m_tiles * p.n_tiles * p.splitk);
+  const int lid_all = xcd_remap(bid, p.m_tiles * p.n_tiles * p.splitk);
   const int lid = lid_all / p.splitk;       // the splits of one tile are neighbours (same XCD)
   const int ks = lid_all - lid * p.splitk;
   const int mt = lid / p.n_tiles;
@@ -412,6 +414,15 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
   }
 
   f32x4 fa[KQ][TM], fb[KQ][TN];
+  // patch tiles with the vector epilogue: tile constants travel through registers + LDS (see the patch prologue)
+  constexpr bool PCST = PATCH && SWAP;
+  [[maybe_unused]] f32x4 tile_cst = (f32x4)(0.f);
+  // SPADE epilogue on the patch tiles: the wave's x (and noise) values are requested in the PROLOGUE as well -- they are
+  // the oldest requests of the tile, so the counted vmcnt waits of the weight stream never wait longer for them than the
+  // prologue's own vmcnt(0) does, and the epilogue starts with its data in registers (32 + TM registers through the loop)
+  constexpr bool PXV = PCST && TN == 2;
+  [[maybe_unused]] f32x4 xv[PXV ? TM : 1][4];
+  [[maybe_unused]] float zv[PXV ? TM : 1];
 
   if constexpr (PATCH) {
     // ---- patch mode main loop (see the VAR bit 6 note above)
@@ -449,6 +460,48 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
       _Pragma("unroll") for (int j = 0; j < BR; ++j)                                                       \
           dma16(w_rsrc, Bbuf + ((NT * j + 64 * wave) / GPR) * LS, b_voff[j], w_soff);                      \
     }
+    // Tile constants of the epilogue (bias / scale of the BN columns; SPADE: noise scale, mean, rstd of the tile's BN/2
+    // channels): fetched NOW by the first lanes, parked in 4 registers through the main loop and spread through LDS
+    // when the epilogue starts -- the epilogue then has no dependent global load except the pixel data, which it
+    // issues in one batch.  (It was 9 us (dense) / 15 us (SPADE, training) of a 25-33 us tile, longer than the main
+    // loop: up to 11 loads per channel group, each waited for before the next -- tools/patch_timeline.py.)
+    if constexpr (PCST) {
+      const int t4 = tid * 4;
+      const float* src = nullptr;
+      if (p.epi == 1) {
+        const int cb0 = (n0 >> 6) * 32;                   // first channel of this tile's gamma|beta pairs
+        if (tid < BN / 4) src = p.shift + n0 + t4;                                                     // gamma|beta bias
+        else if (tid < 3 * BN / 8) { const int c = cb0 + t4 - BN; if (p.sns && c < p.sC) src = p.sns + c; }
+        else if (tid < BN / 2) { const int c = cb0 + t4 - 3 * BN / 2; if (c < p.sC) src = p.smean + (size_t)pt_n * p.sC + c; }
+        else if (tid < 5 * BN / 8) { const int c = cb0 + t4 - 2 * BN; if (c < p.sC) src = p.srstd + (size_t)pt_n * p.sC + c; }
+      } else {
+        if (tid < BN / 4) { if (p.scale && n0 + t4 < p.Cout) src = p.scale + n0 + t4; }
+        else if (tid < BN / 2) { const int c = n0 + t4 - BN; if (p.shift && c < p.Cout) src = p.shift + c; }
+      }
+      tile_cst = src ? *reinterpret_cast<const f32x4*>(src) : ((p.epi != 1 && tid < BN / 4) ? (f32x4)(1.f) : (f32x4)(0.f));
+    }
+    if constexpr (PXV) {
+      if (p.epi == 1) {
+        const int cb = ((n0 + wn * 64) >> 6) * 32;       // channel base of this wave's gamma|beta pair
+        const int HWo = p.Ho * p.Wo;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int px = row2pix((wm * TM + i) * 32 + l31);
+          const int ps = px < p.M ? px : 0;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int c0 = cb + 8 * g + 4 * lh;
+            xv[i][g] = ld4rt<BF>(p.sx, (size_t)ps * p.sx_cs + p.sx_co + (c0 < p.sC ? c0 : 0), p.sx_f32);
+          }
+          zv[i] = 0.f;
+          if (p.sz) {
+            const int rem = ps - pt_n * HWo;
+            const int h = rem / p.Wo, w = rem - h * p.Wo;
+            zv[i] = p.sz[((size_t)pt_n * p.Wo + w) * p.Ho + h];
+          }
+        }
+      }
+    }
     HRV_PATCH_DMA(0)
     HRV_PATCH_BDMA(0, 0)
     if (ST == 3 && KTOT > 1) {
@@ -459,6 +512,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
     }
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (p.tlog && tid == 0) p.tlog[(size_t)bid * 8 + 1] = wall_clock64();      // patch + first weight tiles have landed
     int rb = 0, wb = ST - 1;
     for (int q = 0; q < KTOT; ++q) {
       const bool more = q + ST - 1 < KTOT;
@@ -500,6 +554,7 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
 #undef HRV_PATCH_DMA
 #undef HRV_PATCH_KT
 #undef HRV_PATCH_BDMA
+    if (p.tlog && tid == 0) p.tlog[(size_t)bid * 8 + 2] = wall_clock64();      // main loop done (phase timeline, diag only)
   } else if constexpr (GLDS && ST == 3) {
     static_assert((BN * GPR) % NT == 0, "LDS-DMA B tile: every wave-instruction must be full");
     // every wave issues exactly AR + BR DMA instructions per K-tile (masked lanes use out-of-range offsets), so
@@ -684,6 +739,90 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
     if (p.epi == 1) {
       // SPADE: tiles come in (gamma | beta) pairs of the same 32 channels, so this lane holds
       // gamma and beta of its pixel for the same 4 channels in acc[i][2q] / acc[i][2q+1].
+      if constexpr (PCST && TN == 2) {
+        // patch tiles: constants from LDS, every pixel load of the wave issued before the first use
+        __syncthreads();                                 // every wave is done with the operand stages
+        float* cbuf = smem;
+        if (tid < 5 * BN / 8) *reinterpret_cast<f32x4*>(cbuf + 4 * tid) = tile_cst;
+        const int col0 = n0 + wn * 64;                   // first gamma column of this wave's pair
+        const int cb = (col0 >> 6) * 32;                 // its channel base
+        const int HWo = p.Ho * p.Wo;
+        int pidx[TM];
+        bool okp[TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          pidx[i] = row2pix((wm * TM + i) * 32 + l31);
+          okp[i] = pidx[i] < p.M;
+        }
+        __syncthreads();                                 // the constants are in LDS
+        // results leave through a per-wave LDS scratch so that the global stores run along the channels: 64-byte (bf16
+        // result) / 128-byte ((1 + gamma), fp32 result) runs per pixel instead of 8- / 16-byte pieces at the pixel stride
+        constexpr int SCS = 36;                          // scratch row stride, floats (32 channels + 4: conflict-free)
+        float* scr = smem + 5 * BN / 2 + wave * (2 * 32 * SCS);   // [v | 1+gamma] x 32 pixels, behind the constants
+        static_assert(sizeof(smem) >= (size_t)(5 * BN / 2 + (NT / 64) * 2 * 32 * SCS) * 4, "SPADE epilogue scratch");
+        const int lc = wn * 32;                          // this wave's first channel within the tile
+        const bool bf_out = BF && !p.out_f32;
+        const bool staged = ((uintptr_t)p.out & 15) == 0 && ((p.out_cs | p.out_co) & 7) == 0 && (p.sC & 3) == 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int cl = lc + 8 * g + 4 * lh, c0 = cb + 8 * g + 4 * lh;
+            const bool c_ok = c0 < p.sC;
+            const f32x4 bg = *reinterpret_cast<const f32x4*>(cbuf + wn * 64 + 8 * g + 4 * lh);
+            const f32x4 bb = *reinterpret_cast<const f32x4*>(cbuf + wn * 64 + 32 + 8 * g + 4 * lh);
+            const f32x4 ns4 = *reinterpret_cast<const f32x4*>(cbuf + BN + cl);
+            const f32x4 mu = *reinterpret_cast<const f32x4*>(cbuf + 3 * BN / 2 + cl);
+            const f32x4 rs = *reinterpret_cast<const f32x4*>(cbuf + 2 * BN + cl);
+            f32x4 v = (f32x4)(0.f), g1 = (f32x4)(0.f);
+            if (c_ok && okp[i]) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float x = xv[i][g][e] + zv[i] * ns4[e];
+                g1[e] = 1.f + acc[i][0][4 * g + e] + bg[e];
+                const float bet = acc[i][1][4 * g + e] + bb[e];
+                v[e] = apply_act((x - mu[e]) * rs[e] * g1[e] + bet, p.act, p.slope);
+              }
+              if (!staged) {
+                if (p.sg1p) *reinterpret_cast<f32x4*>(p.sg1p + (size_t)pidx[i] * p.sC + c0) = g1;
+                st4rt<BF>(p.out, (size_t)pidx[i] * p.out_cs + p.out_co + c0, v, p.out_f32);
+              }
+            }
+            if (staged) {
+              *reinterpret_cast<f32x4*>(scr + l31 * SCS + 8 * g + 4 * lh) = v;
+              *reinterpret_cast<f32x4*>(scr + 32 * SCS + l31 * SCS + 8 * g + 4 * lh) = g1;
+            }
+          }
+          if (staged) {
+            // same wave wrote and reads: LDS operations of a wave complete in order
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {                  // 32 pixels x 8 chunks of 4 channels
+              const int t = lane + 64 * k, px = t >> 3, kk = t & 7;
+              const int po = row2pix((wm * TM + i) * 32 + px);
+              const bool ok = po < p.M && cb + kk * 4 < p.sC;
+              if (p.sg1p && ok)
+                *reinterpret_cast<f32x4*>(p.sg1p + (size_t)po * p.sC + cb + kk * 4) =
+                    *reinterpret_cast<const f32x4*>(scr + 32 * SCS + px * SCS + kk * 4);
+              if (!bf_out && ok)
+                *reinterpret_cast<f32x4*>(p.out + (size_t)po * p.out_cs + p.out_co + cb + kk * 4) =
+                    *reinterpret_cast<const f32x4*>(scr + px * SCS + kk * 4);
+            }
+            if (bf_out) {
+#pragma unroll
+              for (int k = 0; k < 2; ++k) {                // 32 pixels x 4 chunks of 8 channels
+                const int t = lane + 64 * k, px = t >> 2, kk = t & 3;
+                const int po = row2pix((wm * TM + i) * 32 + px);
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + px * SCS + kk * 8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + px * SCS + kk * 8 + 4);
+                if (po < p.M && cb + kk * 8 < p.sC)
+                  *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)po * p.out_cs + p.out_co + cb + kk * 8) =
+                      pack_bf16x8(lo, hi);
+              }
+            }
+          }
+        }
+        return;
+      }
       if constexpr (TN % 2 == 0) {
         const int HWo = p.Ho * p.Wo;
 #pragma unroll
@@ -740,9 +879,32 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
       static_assert(sizeof(smem) >= (size_t)(NT / 64) * 32 * SCR * 4, "epilogue scratch must fit the operand stages");
       __syncthreads();                                       // every wave is done reading the operand stages
       float* scr = smem + wave * (32 * SCR);
+      // patch tiles: scale / shift of the tile's columns come from LDS (parked in registers since the prologue) and
+      // the residual of every accumulator group is requested before the first one is used
+      [[maybe_unused]] float* cbuf = smem + (NT / 64) * 32 * SCR;
+      [[maybe_unused]] f32x4 rv[TM][4];                      // (one 32-column group at a time: two blocks per CU need <= 256 registers)
+      if constexpr (PCST) {
+        static_assert(sizeof(smem) >= (size_t)((NT / 64) * 32 * SCR + 2 * BN) * 4, "epilogue scratch + constants");
+        if (tid < BN / 2) *reinterpret_cast<f32x4*>(cbuf + 4 * tid) = tile_cst;
+        __syncthreads();                                     // the constants are in LDS
+      }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
         const int cj = n0 + (wn * TN + j) * 32;              // first channel of this 32-column tile
+        if constexpr (PCST) {
+          if (p.res) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+              const int px = row2pix((wm * TM + i) * 32 + l31);
+              const int ps = px < p.M ? px : 0;
+#pragma unroll
+              for (int g = 0; g < 4; ++g) {
+                const int c0 = cj + 8 * g + 4 * lh;
+                rv[i][g] = ld4rt<BF>(p.res, (size_t)ps * p.res_cs + p.res_co + (c0 < p.Cout ? c0 : 0), p.res_f32);
+              }
+            }
+          }
+        }
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
           const int pidx = row2pix((wm * TM + i) * 32 + l31);
@@ -751,14 +913,22 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
             const int c0 = cj + 8 * g + 4 * lh;
             const bool c_ok = c0 < p.Cout;
             const int cs = c_ok ? c0 : 0;
-            const f32x4 sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cs) : (f32x4)(1.f);
-            const f32x4 sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cs) : (f32x4)(0.f);
+            f32x4 sc, sh;
+            if constexpr (PCST) {
+              sc = *reinterpret_cast<const f32x4*>(cbuf + (wn * TN + j) * 32 + 8 * g + 4 * lh);
+              sh = *reinterpret_cast<const f32x4*>(cbuf + BN + (wn * TN + j) * 32 + 8 * g + 4 * lh);
+            } else {
+              sc = p.scale ? *reinterpret_cast<const f32x4*>(p.scale + cs) : (f32x4)(1.f);
+              sh = p.shift ? *reinterpret_cast<const f32x4*>(p.shift + cs) : (f32x4)(0.f);
+            }
             f32x4 v = (f32x4)(0.f);
             if (c_ok && pidx < p.M) {
 #pragma unroll
               for (int e = 0; e < 4; ++e) v[e] = acc[i][j][4 * g + e] * sc[e] + sh[e];
               if (p.res) {
-                const f32x4 r4 = ld4rt<BF>(p.res, (size_t)pidx * p.res_cs + p.res_co + c0, p.res_f32);
+                f32x4 r4;
+                if constexpr (PCST) r4 = rv[i][g];
+                else r4 = ld4rt<BF>(p.res, (size_t)pidx * p.res_cs + p.res_co + c0, p.res_f32);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = res_combine(v[e], r4[e], p.res_mode, p.slope);
               }
@@ -832,6 +1002,35 @@ __global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1)) void conv_mfma
         }
       }
     }
+  }
+}
+
+template <int TM, int TN, int WM, int WN, int VAR, bool BF, int RB = 64>
+__global__ __launch_bounds__(64 * WM * WN * ((VAR & 32) ? 2 : 1), ((VAR & 64) && WM * WN == 4) ? 2 : 1) void conv_mfma_kernel(
+    const ConvParams p) {
+  if constexpr ((VAR & 64) != 0) {
+    // patch tiles: PERSISTENT blocks (grid = resident slots).  A one-tile-per-block grid of these 77-KB-LDS blocks spent
+    // ~80 us of a 400 us launch (6144 tiles) on workgroup dispatch alone -- the same launch with every DMA, fragment
+    // read, MFMA and the epilogue switched off (tools/patch_ablation.sh, HRV_PATCH_DBG=31).
+    const int total = p.m_tiles * p.n_tiles;
+    for (int bid = blockIdx.x; bid < total; bid += gridDim.x) {
+      if (p.tlog && threadIdx.x == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        p.tlog[(size_t)bid * 8 + 0] = wall_clock64();
+        p.tlog[(size_t)bid * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
+        p.tlog[(size_t)bid * 8 + 5] = blockIdx.x;
+      }
+      conv_mfma_tile<TM, TN, WM, WN, VAR, BF, RB>(p, bid);
+      if (p.tlog) {
+        __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));   // timeline only: this thread's stores have left
+        if (threadIdx.x == 0) p.tlog[(size_t)bid * 8 + 3] = wall_clock64();
+      }
+      __syncthreads();      // the next tile's DMA overwrites the LDS this tile's epilogue staged through
+    }
+  } else {
+    conv_mfma_tile<TM, TN, WM, WN, VAR, BF, RB>(p, blockIdx.x);
   }
 }
 
@@ -1202,6 +1401,10 @@ static int launch_patch(const ConvParams& p0, hipStream_t st, int n0_base = 0, i
   }
   ConvParams p = p0;
   p.splitk = 1;
+  {
+    const char* e = getenv("HRV_PATCH_TLOG");      // diag only: device buffer (hex address) for per-tile phase timestamps
+    p.tlog = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
+  }
   constexpr int THP = TMP * WMP * 32 / 16;   // tile rows: BM / 16
   p.m_tiles = p.N * ((p.H + THP - 1) / THP) * ((p.W + 15) / 16);
   p.n_tiles = n_cols_tiles > 0 ? n_cols_tiles : p.CoutPad / BNP;
@@ -1212,10 +1415,23 @@ static int launch_patch(const ConvParams& p0, hipStream_t st, int n0_base = 0, i
                       (((uintptr_t)p.scale | (uintptr_t)p.shift) & 15) == 0 && (((uintptr_t)p.out) & (4 * oesz - 1)) == 0 &&
                       (((uintptr_t)p.res) & (4 * resz - 1)) == 0;
   constexpr int V = 4 | STV | 64;
+  // persistent grid: the resident slots (LDS-bound: 160 KB / block) of every CU.  HRV_PATCH_PERSIST=0: one tile per block
+  static int n_cu = 0;
+  if (n_cu == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
+    if (n_cu <= 0) n_cu = 256;
+  }
+  constexpr int PATCH_LDS = ((TMP * WMP * 32 / 16 + 2) * 18 * 64 + ((STV & 16) ? 3 : 2) * BNP * 32) * 4;
+  const int per_cu = PATCH_LDS <= 80 * 1024 ? 2 : 1;
+  const char* ep = getenv("HRV_PATCH_PERSIST");
+  int grid = (ep && ep[0] == '0') ? nblk : n_cu * per_cu;
+  if (grid > nblk) grid = nblk;
   if (vec_ok || p.epi == 1)
-    hipLaunchKernelGGL((conv_mfma_kernel<TMP, TNP, WMP, WNP, V | 1, true, 128>), dim3(nblk), dim3(64 * WMP * WNP), 0, st, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TMP, TNP, WMP, WNP, V | 1, true, 128>), dim3(grid), dim3(64 * WMP * WNP), 0, st, p);
   else
-    hipLaunchKernelGGL((conv_mfma_kernel<TMP, TNP, WMP, WNP, V, true, 128>), dim3(nblk), dim3(64 * WMP * WNP), 0, st, p);
+    hipLaunchKernelGGL((conv_mfma_kernel<TMP, TNP, WMP, WNP, V, true, 128>), dim3(grid), dim3(64 * WMP * WNP), 0, st, p);
   return check_launch("conv_mfma_kernel[patch]");
 }
 

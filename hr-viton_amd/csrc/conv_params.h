@@ -55,6 +55,7 @@ struct ConvParams {
   const float* sz;
   const float* sns;
   float* sg1p;  // optional (1+gamma) output, dense [M][sC]
+  unsigned long long* tlog;   // diag only (HRV_PATCH_TLOG, tools/patch_timeline.py): per-tile phase timestamps of the patch tiles
 };
 
 // VAR bit0: swapped-operand MFMA (D[cout][pixel]) -> each lane owns 4 consecutive
