@@ -220,10 +220,12 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
 // grad[i] = gscale * dl/da ; loss = lscale * sum(l)   (callers pass 1/numel etc.)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
-                                                   int mode, float gscale, float* __restrict__ grad,
+                                                   int mode_flags, float gscale, float* __restrict__ grad,
                                                    float* __restrict__ part) {
   __shared__ float red[256];
   float s = 0.f;
+  const int mode = mode_flags & 15;
+  const bool relu_mask = (mode_flags & 16) != 0;   // a = ReLU(pre): the gradient is handed back w.r.t. pre (x (a > 0))
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     const float x = a[i];
     float l, g;
@@ -233,7 +235,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, 
     else if (mode == 3) { l = -x; g = -1.f; }
     else { const float d = x - b[i]; l = d * d; g = 2.f * d; }
     s += l;
-    if (grad) grad[i] = gscale * g;
+    if (grad) grad[i] = (relu_mask && !(x > 0.f)) ? 0.f : gscale * g;
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -374,7 +376,7 @@ __global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int 
 }
 
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Ho, int Wo,
-                                    int C4, int xcs, int ycs, float* __restrict__ dx) {
+                                    int C4, int xcs, int ycs, float* __restrict__ dx, int relu) {
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int g = (int)(i % C4);
@@ -391,10 +393,11 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const float m = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
-      if (a[e] == m) ga[e] = gy[e];
-      else if (b[e] == m) gb[e] = gy[e];
-      else if (c[e] == m) gc[e] = gy[e];
-      else gd[e] = gy[e];
+      const float gv = (relu && !(m > 0.f)) ? 0.f : gy[e];      // relu: x = ReLU(pre), the gradient goes on to pre
+      if (a[e] == m) ga[e] = gv;
+      else if (b[e] == m) gb[e] = gv;
+      else if (c[e] == m) gc[e] = gv;
+      else gd[e] = gv;
     }
     *reinterpret_cast<f32x4*>(dx + base) = ga;
     *reinterpret_cast<f32x4*>(dx + base + o01) = gb;
@@ -781,8 +784,8 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
 
 extern "C" int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t mode, float lscale, float gscale,
                             float* grad, float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream) {
-  HRV_REQUIRE(a && workspace && loss_out && n > 0 && mode >= 0 && mode <= 4, "loss: bad args");
-  HRV_REQUIRE((mode != 0 && mode != 4) || b, "loss: mode needs a target tensor");
+  HRV_REQUIRE(a && workspace && loss_out && n > 0 && mode >= 0 && (mode & 15) <= 4 && (mode & ~31) == 0, "loss: bad args");
+  HRV_REQUIRE(((mode & 15) != 0 && (mode & 15) != 4) || b, "loss: mode needs a target tensor");
   const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(loss_kernel, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, mode, gscale, grad, workspace);
@@ -829,8 +832,18 @@ extern "C" int hrv_maxpool2x2_bwd_nhwc_f32(const float* x, const float* dy, int3
   HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad args");
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
-                     C / 4, C, C, dx);
+                     C / 4, C, C, dx, 0);
   return check_launch("maxpool2_bwd_kernel");
+}
+
+// the same with the ReLU derivative of the pooled tensor fused (x = ReLU(pre): dx is the gradient w.r.t. pre)
+extern "C" int hrv_maxpool2x2_bwd_relu_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                                float* dx, hrv_stream_t stream) {
+  HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool_bwd_relu: bad args");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
+                     C / 4, C, C, dx, 1);
+  return check_launch("maxpool2_bwd_kernel[relu]");
 }
 
 extern "C" int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -375,6 +375,7 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
 
 
 LOSS_L1, LOSS_HINGE_D_FAKE, LOSS_HINGE_D_REAL, LOSS_NEG_MEAN, LOSS_MSE = 0, 1, 2, 3, 4
+LOSS_RELU_MASK = 16      # or-ed into the mode: a = ReLU(pre), the returned gradient is w.r.t. pre
 
 
 def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, gscale: float, loss_out: torch.Tensor,
@@ -432,12 +433,14 @@ def maxpool2x2(x: Act) -> Act:
     return y
 
 
-def maxpool2x2_bwd(x: Act, dy: Act) -> Act:
+def maxpool2x2_bwd(x: Act, dy: Act, relu: bool = False) -> Act:
+    """``relu``: x = ReLU(pre) -- the result is the gradient w.r.t. pre (the ReLU derivative rides along)."""
     lib = _lib.load()
     dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
+    fn = lib.hrv_maxpool2x2_bwd_relu_nhwc_f32 if relu else lib.hrv_maxpool2x2_bwd_nhwc_f32
     with _Timed("pool", "maxpool2x2_bwd", 0.0, ops.act_bytes(x) * 2.25):
-        _lib.check(lib.hrv_maxpool2x2_bwd_nhwc_f32(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(),
-                                                   _stream()), "hrv_maxpool2x2_bwd_nhwc_f32")
+        _lib.check(fn(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(), _stream()),
+                   "hrv_maxpool2x2_bwd_nhwc_f32")
     return dx
 
 

@@ -135,19 +135,23 @@ class _VGGLossFn(torch.autograd.Function):
         grads: List[Optional[torch.Tensor]] = [None] * 5
         for i in layids:
             n = tx[i].t.numel()          # dense tensors (channels are multiples of 4)
-            grads[i] = T.loss(tx[i].t, ty[i].t, T.LOSS_L1, weights[i] / n, weights[i] / n, loss, accumulate=True,
-                              want_grad=need)
+            # the taps are ReLU outputs: the loss kernel hands the gradient back w.r.t. the pre-activation
+            grads[i] = T.loss(tx[i].t, ty[i].t, T.LOSS_L1 | T.LOSS_RELU_MASK, weights[i] / n, weights[i] / n, loss,
+                              accumulate=True, want_grad=need)
         ctx.vgg, ctx.saved, ctx.grads, ctx.tx = vgg, saved, grads, tx
         return loss
 
     @staticmethod
     def backward(ctx, g_out):
         vgg, saved, grads = ctx.vgg, ctx.saved, ctx.grads
+        # ``d``: gradient w.r.t. the PRE-activation of the conv being processed -- every ReLU derivative rides along with
+        # the kernel that produces the gradient (the tap gradients in the loss kernel, pooled tensors in the max-pool
+        # backward, conv -> conv transitions as the data gradient's activation mask): no separate masking pass
         d: Optional[Act] = None
         for item in reversed(saved):
             if item[0] == "pool":
                 if d is not None:
-                    d = T.maxpool2x2_bwd(item[1], d)
+                    d = T.maxpool2x2_bwd(item[1], d, relu=True)
                 continue
             _, idx, src, out = item
             if idx in _TAPS:
@@ -160,13 +164,10 @@ class _VGGLossFn(torch.autograd.Function):
                         T.add_slice(gact, d, True)
             if d is None:
                 continue
-            T.act_bwd_(d, out, ACT_RELU, 0.0)          # through this conv's ReLU
-            if idx == 0:
-                w = vgg.conv(0).weight.data
-                d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, name="vgg.features.0.dgrad")
-            else:
-                w = vgg.conv(idx).weight.data
-                d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, name=f"vgg.features.{idx}.dgrad")
+            w = vgg.conv(idx).weight.data
+            fused = idx != 0 and (idx - 1) not in _POOLS        # src is the previous conv's ReLU output
+            d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, act_mask=src if fused else None, slope=0.0,
+                             name=f"vgg.features.{idx}.dgrad")
         ctx.saved = ctx.grads = None
         dx = ops.to_nchw(d)
         T.scale_(dx, 1.0, g_out.contiguous())

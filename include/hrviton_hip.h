@@ -305,6 +305,9 @@ int hrv_avgpool3x3s2_bwd_nhwc_f32(const float* dy, int32_t N, int32_t H, int32_t
 int hrv_maxpool2x2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, float* y, hrv_stream_t stream);
 int hrv_maxpool2x2_bwd_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx,
                                 hrv_stream_t stream);
+/* ... with the ReLU derivative of the pooled tensor fused (x = ReLU(pre); dx is the gradient w.r.t. pre). */
+int hrv_maxpool2x2_bwd_relu_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx,
+                                     hrv_stream_t stream);
 /* torch.optim.Adam step over one flat buffer (train_generator.py:154-157,322,360);
  * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
