@@ -80,8 +80,9 @@ class Vgg19(nn.Module):
             self._plan = (key, layers)
         return self._plan[1]
 
-    def features(self, x: Act, save: bool):
-        """Runs the 13 convs + 4 pools; returns (taps [5 Acts], saved list for backward)."""
+    def features(self, x: Act, save: bool, x_bf16: Optional[Act] = None):
+        """Runs the 13 convs + 4 pools; returns (taps [5 Acts], saved list for backward).  ``x_bf16`` (mixed precision):
+        a bf16 copy of the image for features.0 (3 -> 64 channels over every pixel: memory-bound, thin_conv.hip)."""
         layers = self.plan(x.t.device)
         taps, saved = [], []
         cur = x
@@ -94,7 +95,8 @@ class Vgg19(nn.Module):
             if T.MMA_BF16[0]:
                 # mixed-precision training: bf16 matrix cores over the fp32 activations (device-packed weights)
                 m = self.conv(idx)
-                out = T.conv_forward_dev(m.weight.data, [(cur, 0)], 1, 1, shift=m.bias.data, act=ACT_RELU,
+                src = x_bf16 if (idx == 0 and x_bf16 is not None) else cur
+                out = T.conv_forward_dev(m.weight.data, [(src, 0)], 1, 1, shift=m.bias.data, act=ACT_RELU,
                                          name=f"vgg.features.{idx}")
             else:
                 out = layers[idx]([cur])
@@ -113,7 +115,7 @@ class Vgg19(nn.Module):
         key = (y.data_ptr(), y._version, tuple(y.shape), ops.WEIGHTS_EPOCH[0])
         if c is not None and c[0] is y and c[1] == key:
             return c[2]
-        ty, _ = self.features(ops.to_nhwc(y), save=False)
+        ty, _ = self.features(ops.to_nhwc(y), save=False, x_bf16=ops.to_nhwc(y, bf16=True) if T.MMA_BF16[0] else None)
         self._ycache = (y, key, ty)
         return ty
 
@@ -130,7 +132,7 @@ class _VGGLossFn(torch.autograd.Function):
         need = ctx.needs_input_grad[3]
         xa = ops.to_nhwc(x)
         ty = vgg.target_features(y)
-        tx, saved = vgg.features(xa, save=need)
+        tx, saved = vgg.features(xa, save=need, x_bf16=ops.to_nhwc(x, bf16=True) if T.MMA_BF16[0] else None)
         loss = torch.zeros(1, dtype=torch.float32, device=x.device)
         grads: List[Optional[torch.Tensor]] = [None] * 5
         for i in layids:

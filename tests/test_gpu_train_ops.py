@@ -475,7 +475,8 @@ def test_wgrad_tr_kernel_bf16_stored_operands(case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", [("conv_0", 80, 32, 3, True, False, "none"), ("conv_1", 32, 32, 3, True, True, "lrelu"),
-                                  ("conv_s", 80, 32, 1, False, False, "none"), ("conv_img", 32, 3, 3, False, False, "tanh")],
+                                  ("conv_s", 80, 32, 1, False, False, "none"), ("conv_img", 32, 3, 3, False, False, "tanh"),
+                                  ("vgg_features0", 3, 64, 3, False, False, "relu")],
                          ids=lambda c: c[0])
 def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
     """thin_conv.hip (weights converted into LDS once per persistent block, LDS-DMA halo patches, 32 pixels x all columns
@@ -494,7 +495,7 @@ def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
     sigma = torch.tensor([1.7], device="cuda") if spectral else None
     res = torch.randn(N, cout, H, W, generator=g) if with_res else None
     dy = rb(torch.randn(N, cout, H, W, generator=g))
-    act = {"none": ops.ACT_NONE, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH}[actn]
+    act = {"none": ops.ACT_NONE, "lrelu": ops.ACT_LRELU, "tanh": ops.ACT_TANH, "relu": ops.ACT_RELU}[actn]
 
     def sliced(t):
         C_ = t.shape[1]
@@ -523,7 +524,7 @@ def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
     ref = F.conv2d(x, ws, b.cpu(), padding=pad)
     if with_res:
         ref = ref + res
-    ref = {"none": lambda t: t, "lrelu": lambda t: F.leaky_relu(t, 0.2), "tanh": torch.tanh}[actn](ref)
+    ref = {"none": lambda t: t, "lrelu": lambda t: F.leaky_relu(t, 0.2), "tanh": torch.tanh, "relu": torch.relu}[actn](ref)
     tol = 1e-2 if with_res else 2e-4            # bf16 output: one bf16 rounding of the result
     assert (outs["1"][0] - ref).abs().max() <= tol * ref.abs().max(), (outs["1"][0] - ref).abs().max() / ref.abs().max()
     assert (outs["1"][0] - outs["0"][0]).abs().max() <= tol * ref.abs().max()
