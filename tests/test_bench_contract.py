@@ -1,5 +1,5 @@
 """The JSON line bench.py prints (driver contract) -- checked on the committed output of the round's last default run
-on the MI355X box (profiles/r02_final_bench_default.json; the mid-round line if the final one is not there yet)."""
+on the MI355X box (profiles/r02_final_bench_default.json, written by tools/round_end_measure.sh)."""
 import json
 import os
 
@@ -7,7 +7,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _line():
-    for name in ("r02_final_bench_default.json", "r02_mid_bench_default.json"):
+    for name in ("r02_final_bench_default.json",):
         p = os.path.join(ROOT, "profiles", name)
         if os.path.exists(p):
             with open(p) as f:
@@ -57,8 +57,10 @@ def test_cpu_baseline_parity_and_extra_configs():
     f, b = p["fp32_engine_vs_oracle"], p["bf16_engine_vs_oracle"]
     assert f["image_max_rel_err"] < 1e-3 and all(v < 1e-3 for v in f["loss_rel_err"].values())
     assert f["grad_worst_rel_err"] < 2e-2
-    assert b["image_mean_abs_err"] < 2e-2 and all(v < 2e-2 for v in b["loss_rel_err"].values())
-    assert b["grad_min_cosine"] > 0.93
+    # (the mid-round line still shows the 5.4e-3 / 0.985 of the patch-tile packing bug that the final build fixed)
+    assert "1024x768" in f["size"] and "1024x768" in b["size"]
+    assert b["image_mean_abs_err"] < 3e-3 and all(v < 2e-3 for v in b["loss_rel_err"].values())
+    assert b["grad_min_cosine"] > 0.99
     e = j["extra"]
     t, q = e["config5_tryon_infer_bf16_b16"], e["config2_tocg_infer_f32_b4"]
     assert t["batch"] == 16 and abs(t["value"] - 16e3 / t["ms_per_step"]) < 0.01 * t["value"]
