@@ -214,11 +214,19 @@ class CPDataset(_CPBase):
 class CPDataLoader(object):
     """cp_dataset_test.py:240-263: DataLoader wrapper with ``next_batch()`` that restarts at the end."""
 
-    def __init__(self, opt, dataset):
-        sampler = torch.utils.data.sampler.RandomSampler(dataset) if opt.shuffle else None
-        self.data_loader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=(sampler is None),
+    def __init__(self, opt, dataset, rank: int = 0, world: int = 1):
+        """``rank`` / ``world`` (data-parallel training, one process per GPU): the ranks draw DISJOINT shards of one
+        shared per-epoch permutation (DistributedSampler), so no sample is seen twice within an epoch -- the reference's
+        single-process loader feeds every GPU from one stream (train_generator.py:171-178)."""
+        self.epoch = 0
+        if world > 1:
+            self.sampler = torch.utils.data.distributed.DistributedSampler(dataset, num_replicas=world, rank=rank,
+                                                                           shuffle=True, seed=97, drop_last=True)   # (the reference's loader shuffles with and without opt.shuffle)
+        else:
+            self.sampler = torch.utils.data.sampler.RandomSampler(dataset) if opt.shuffle else None
+        self.data_loader = torch.utils.data.DataLoader(dataset, batch_size=opt.batch_size, shuffle=(self.sampler is None),
                                                        num_workers=opt.workers, pin_memory=True, drop_last=True,
-                                                       sampler=sampler)
+                                                       sampler=self.sampler)
         self.dataset = dataset
         self.data_iter = iter(self.data_loader)
 
@@ -226,6 +234,9 @@ class CPDataLoader(object):
         try:
             return next(self.data_iter)
         except StopIteration:
+            self.epoch += 1
+            if hasattr(self.sampler, "set_epoch"):
+                self.sampler.set_epoch(self.epoch)          # a new shared permutation, again cut into disjoint shards
             self.data_iter = iter(self.data_loader)
             return next(self.data_iter)
 

@@ -127,7 +127,16 @@ def condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d
     The networks, warps, softmax, cross entropy, TV, L1, VGG and LSGAN terms run on the HIP kernels
     (cond_train.py, functional.py, losses.py, vgg.py); torch only stitches the scalar sums and the
     elementwise mask compositions.  ``inputs`` as produced by cp_dataset.py: cloth, cloth_mask,
-    parse_agnostic, densepose, parse_onehot (label indices [N,1,H,W]), parse (one-hot), pcm, parse_cloth."""
+    parse_agnostic, densepose, parse_onehot (label indices [N,1,H,W]), parse (one-hot), pcm, parse_cloth.
+
+    Stated deviations from the reference's schedule (same losses, gradients and updates per iteration):
+    * the reference calls D three times before either optimizer step (G pass, fake, real: :262-274); here the fake and
+      real batches of the D loss share ONE forward over [fake; real] and it runs after opt_g.step() -- InstanceNorm is
+      per sample, so the values are the same, but with --spectral D's power iteration advances twice per iteration
+      instead of three times (the (u, v) trajectory differs from a reference run), and with --Ddropout the mask draws
+      are consumed in a different order;
+    * under data-parallel training tocg's BatchNorm uses per-rank batch statistics (the reference's nn.DataParallel
+      does too: its sync_batchnorm package is never instantiated), and checkpoints hold rank 0's running statistics."""
     from . import functional as HF
     from .networks import make_grid
     c_paired = inputs["cloth"]

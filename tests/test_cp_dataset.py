@@ -59,3 +59,21 @@ def test_invariants_and_loader(tmp_path):
     b3 = loader.next_batch()     # wraps around after 2 batches of 2
     assert b1["cloth"]["paired"].shape == (2, 3, 128, 96) and b3["parse"].shape == (2, 13, 128, 96)
     assert len(b1["c_name"]["paired"]) == 2
+
+
+def test_data_parallel_loaders_draw_disjoint_shards(tmp_path):
+    """One process per GPU: the ranks' loaders cut ONE shared per-epoch permutation into disjoint shards
+    (DistributedSampler), reshuffled on wrap-around -- no sample twice within an epoch across the ranks."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import cp_dataset as P
+    P.write_synthetic_dataset(str(tmp_path), n=8, datamode="train", list_name="train_pairs.txt", seed=5)
+    opt = _opt(str(tmp_path), 64, 48, datamode="train", data_list="train_pairs.txt")
+    ds = P.CPDataset(opt)
+    loaders = [P.CPDataLoader(opt, ds, rank=r, world=2) for r in range(2)]
+    epochs = []
+    for _ in range(2):                      # 8 samples / 2 ranks / batch 2 = 2 batches per rank and epoch
+        names = [[n for _ in range(2) for n in ld.next_batch()["im_name"]] for ld in loaders]
+        assert not set(names[0]) & set(names[1])
+        assert len(set(names[0]) | set(names[1])) == 8
+        epochs.append(names)
+    assert epochs[0] != epochs[1]           # set_epoch: a new permutation after the wrap-around

@@ -125,7 +125,7 @@ def _rank_loader(opt, per_rank, rank, world):
     o = copy.copy(opt)
     o.batch_size = per_rank
     torch.manual_seed(hdist.shard_seed(97, rank))     # the sampler's permutation differs per rank
-    return CPDataLoader(o, CPDataset(o))
+    return CPDataLoader(o, CPDataset(o), rank, world)
 
 
 def disk_batch(inputs, device):

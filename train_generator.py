@@ -191,7 +191,7 @@ def main(argv=None):
         o = copy.copy(opt)
         o.batch_size = per_rank
         torch.manual_seed(hdist.shard_seed(97, rank))
-        loader = CPDataLoader(o, CPDataset(o))
+        loader = CPDataLoader(o, CPDataset(o), rank, world)
     last = opt.keep_step + opt.decay_step
     if opt.max_steps:
         last = min(last, opt.load_step + opt.max_steps)
