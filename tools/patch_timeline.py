@@ -61,6 +61,16 @@ def main():
         z = torch.randn(N, W, H, 1, device="cuda")
         run = lambda: st_.forward(xa, av, z, save=True)         # noqa: E731
         name += " [training SPADE epilogue]"
+    elif len(sys.argv) > 3 and sys.argv[3] == "dgrad":      # gamma|beta data gradient: dY = [dgamma|dbeta] bf16, ReLU mask of actv, slices of 384
+        from hr_viton_amd import train_ops as T
+        T.MMA_BF16[0] = True
+        dy = ops.Act(torch.randn(N, H, W, cout, device="cuda").to(torch.bfloat16), cout)
+        wg = (torch.randn(cout // 2, cin, 3, 3, device="cuda") * 0.05, torch.randn(cout // 2, cin, 3, 3, device="cuda") * 0.05)
+        actv_all = torch.relu(torch.randn(N, H, W, 3 * cin, device="cuda")).to(torch.bfloat16)
+        dact_all = torch.empty_like(actv_all)
+        run = lambda: T.conv_dgrad(dy, wg, H, W, 1, 1, act_mask=ops.Act(actv_all, cin, cin), slope=0.0,     # noqa: E731
+                                   out=ops.Act(dact_all, cin, cin), name="gb.dgrad")
+        name += " [gamma|beta data gradient]"
     else:
         x = ops.to_nhwc(torch.randn(N, cin, H, W, generator=g).cuda(), bf16=True)
         layer = ops.ConvLayer(torch.randn(cout, cin, 3, 3, generator=g) * 0.05, [cin], "cuda", shift=torch.randn(cout, generator=g),
@@ -71,7 +81,7 @@ def main():
     for _ in range(3):
         run()
     torch.cuda.synchronize()
-    tiles = N * ((H + 7) // 8) * ((W + 15) // 16) * ((cout + 127) // 128)
+    tiles = N * ((H + 7) // 8) * ((W + 15) // 16) * (((cin if (len(sys.argv) > 3 and sys.argv[3] == 'dgrad') else cout) + 127) // 128)
     tlog = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
     os.environ["HRV_PATCH_TLOG"] = hex(tlog.data_ptr())
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
