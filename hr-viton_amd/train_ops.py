@@ -292,10 +292,17 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     N, Ho, Wo, Cout = dy.N, dy.H, dy.W, dy.C
     H, W = (x.H << x_up, x.W << x_up) if x_up >= 0 else (x.H >> -x_up, x.W >> -x_up)
     assert dw.is_contiguous() and tuple(dw.shape) == (Cout, cin_tot, KH, KW), (dw.shape, Cout, cin_tot, KH, KW)
+    wo_real = Wo
+    if (MMA_BF16[0] and Wo % 4 != 0 and Wo >= 32 and not (x.bf16 or dy.bf16) and dy.coff == 0 and dy.cstride == dy.Cp):
+        # odd-sized maps (the PatchGAN's 513 / 257 / 129 columns): the bf16 matrix-core kernel stages quads of 4 pixels
+        # of one image row, so dY gets zero columns up to the next multiple of 4 -- they add nothing to dW or the bias
+        # gradient (the X taps they would pair with are never weighted) -- instead of taking the fp32 kernel (60-100 TFLOP/s)
+        dy = Act(torch.nn.functional.pad(dy.t, (0, 0, 0, (-Wo) % 4)), dy.C)
+        Wo = dy.W
     need = lib.hrv_conv2d_wgrad_workspace_bytes(Cout, cin_tot, KH, KW, N * Ho * Wo)
     ws = _workspace(dy.t.device, need)
-    fl = 2.0 * N * Ho * Wo * Cout * x.C * KH * KW
-    # mixed precision: bf16 matrix cores (needs Wo % 4 == 0; the odd-sized PatchGAN maps keep the fp32 kernel)
+    fl = 2.0 * N * Ho * wo_real * Cout * x.C * KH * KW
+    # mixed precision: bf16 matrix cores (needs Wo % 4 == 0: narrow odd-sized maps keep the fp32 kernel)
     fn = lib.hrv_conv2d_wgrad_bf16mma_nhwc_f32 if (MMA_BF16[0] and Wo % 4 == 0) else lib.hrv_conv2d_wgrad_nhwc_f32
     args = (dy.t.data_ptr(), dy.cstride, dy.coff, Cout, x.t.data_ptr(), x.Cp, x.cstride, x.coff, x_up, x.C, ci_base,
             cin_tot, N, H, W, Ho, Wo, KH, KW, stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),

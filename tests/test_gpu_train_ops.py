@@ -315,10 +315,13 @@ def test_mixed_precision_conv_forward_and_dgrad(case):
 
 @pytest.mark.parametrize("case", [("w3x3", 24, 40, 3, 1, 1, 12, 12), ("wcat_base", 16, 130, 3, 1, 1, 8, 16),
                                   ("ws2", 12, 96, 4, 2, 1, 16, 24), ("w1x1", 72, 192, 1, 1, 0, 8, 8),
-                                  ("wtiny", 4, 16, 3, 2, 1, 16, 24), ("wup", 8, 32, 3, 1, 1, 8, 8)], ids=lambda c: c[0])
+                                  ("wtiny", 4, 16, 3, 2, 1, 16, 24), ("wup", 8, 32, 3, 1, 1, 8, 8),
+                                  ("patchgan_odd_s2", 12, 64, 4, 2, 2, 40, 96), ("patchgan_odd_s1", 32, 8, 4, 1, 2, 20, 33)],
+                         ids=lambda c: c[0])
 def test_mixed_precision_wgrad(case):
     """hrv_conv2d_wgrad_bf16mma_nhwc_f32 (quad-transposed staging, v_mfma_f32_32x32x16_bf16) vs the fp32 weight
-    gradient of the bf16-rounded operands."""
+    gradient of the bf16-rounded operands.  The odd-width cases (PatchGAN 4x4 convolutions: Wo = W/2 + 1) reach the kernel
+    through a zero-padded dY (conv_wgrad)."""
     ops, T = _mods()
     name, cin, cout, k, stride, pad, H, W = case
     g = torch.Generator().manual_seed(len(name) + cout)
@@ -328,7 +331,7 @@ def test_mixed_precision_wgrad(case):
     x = torch.randn(N, cin, H >> up, W >> up, generator=g)
     xf = x.repeat_interleave(2, 2).repeat_interleave(2, 3) if up else x
     Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
-    assert Wo % 4 == 0
+    assert Wo % 4 == 0 or (name.startswith("patchgan_odd") and Wo >= 32)
     dy = torch.randn(N, cout, Ho, Wo, generator=g)
     ref = torch.nn.grad.conv2d_weight(rb(xf), (cout, cin + 5, k, k)[:1] + (cin,) + (k, k), rb(dy), stride=stride, padding=pad)
     dw = torch.zeros(cout, cin + 8, k, k, device="cuda")       # the source sits at ci_base 4 of a wider Cin axis
