@@ -873,7 +873,8 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const int bi
     // pieces 768 bytes apart.  Pad channels are never written (a slice may sit inside a wider tensor).
     constexpr int SCR = 36;                                  // scratch row stride in floats (32 + 4: conflict-free)
     const bool bf_out = BF && !p.out_f32;
-    const bool lds_store = !SPEC && !p.out_up && p.out_step != 2 && ((uintptr_t)p.out & 15) == 0 &&
+    // (out_up: the fused nearest x2 upsample of the result -- fp32 only -- writes each staged row to its 2x2 block)
+    const bool lds_store = !SPEC && (!p.out_up || !bf_out) && p.out_step != 2 && ((uintptr_t)p.out & 15) == 0 &&
                            (!bf_out || ((p.Cout | p.out_cs | p.out_co) & 7) == 0);
     if (lds_store) {
       static_assert(sizeof(smem) >= (size_t)(NT / 64) * 32 * SCR * 4, "epilogue scratch must fit the operand stages");
@@ -955,8 +956,19 @@ __device__ __forceinline__ void conv_mfma_tile(const ConvParams& p, const int bi
               const int t = lane + 64 * k, px = t >> 3, kk = t & 7;
               const int po = row2pix((wm * TM + i) * 32 + px);
               const f32x4 v = *reinterpret_cast<const f32x4*>(scr + px * SCR + kk * 4);
-              if (po < p.M && cj + kk * 4 < p.Cout)
-                *reinterpret_cast<f32x4*>(p.out + (size_t)po * p.out_cs + p.out_co + cj + kk * 4) = v;
+              if (po < p.M && cj + kk * 4 < p.Cout) {
+                if (!p.out_up) {
+                  *reinterpret_cast<f32x4*>(p.out + (size_t)po * p.out_cs + p.out_co + cj + kk * 4) = v;
+                } else {
+                  const int n = po / (p.Ho * p.Wo), rem = po - n * (p.Ho * p.Wo);
+                  const int h = rem / p.Wo, w = rem - h * p.Wo;
+                  float* o = p.out + (((size_t)n * 2 * p.Ho + 2 * h) * 2 * p.Wo + 2 * w) * p.out_cs + p.out_co + cj + kk * 4;
+                  *reinterpret_cast<f32x4*>(o) = v;
+                  *reinterpret_cast<f32x4*>(o + p.out_cs) = v;
+                  *reinterpret_cast<f32x4*>(o + (size_t)2 * p.Wo * p.out_cs) = v;
+                  *reinterpret_cast<f32x4*>(o + (size_t)2 * p.Wo * p.out_cs + p.out_cs) = v;
+                }
+              }
             }
           }
         }

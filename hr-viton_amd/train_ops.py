@@ -159,7 +159,8 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
                          (0 if src_bf16 else 8))
     else:
         assert not (src_bf16 or out.bf16 or (residual is not None and residual.bf16)), f"{name}: bf16 tensors need MMA_BF16"
-    nbytes = (sum(ops.act_bytes(a, creal) for a, _, creal in srcs) + ops.act_bytes(out, Cout) * (4 if out_up else 1) +
+    nbytes = (sum(ops.act_bytes(a, creal) for a, _, creal in srcs) + ops.act_bytes(out, Cout) +       # (``out`` already has the upsampled extent when out_up is set)
+             
               ops.act_bytes(residual, Cout) + float(Cout) * sum(c for _, _, c in srcs) * KH * KW * (2 if mma_bf16 else 4))
     with _Timed("conv", name, flops, nbytes):
         fn = lib.hrv_conv2d_nhwc_bf16 if mma_bf16 else lib.hrv_conv2d_nhwc_f32
