@@ -64,4 +64,5 @@ def load_training_state(path, modules, optimizers=None, schedulers=None):
         torch.cuda.set_rng_state(blob["rng"]["cuda"])
     from . import ops
     ops.WEIGHTS_EPOCH[0] += 1       # load_state_dict's copy_ bumps every tensor's _version: cached plans rebuild
+    ops.LOAD_EPOCH[0] += 1
     return blob["step"], blob["extra"]

@@ -21,6 +21,7 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, ACT_TANH, HrvError  # noqa: F40
 # bumped by hr_viton_amd.optim.Adam.step(): the fused Adam kernel writes parameters through raw
 # pointers (no torch version-counter bump), so cached inference plans key on this as well
 WEIGHTS_EPOCH = [0]     # global step counter of the fused optimizers (per-iteration caches key on it)
+LOAD_EPOCH = [0]        # bumped by checkpoint loads and replica broadcasts (writes torch's _version may not show)
 
 
 def weights_epoch(tensors) -> int:

@@ -158,3 +158,6 @@ def broadcast_module(module: torch.nn.Module, src: int = 0, process_group=None):
         return
     for t in list(module.parameters()) + list(module.buffers()):
         dist.broadcast(t.data, src=src, group=process_group)
+    from . import ops
+    ops.LOAD_EPOCH[0] += 1          # (the broadcast writes through .data: the parameters' _version does not move)
+    ops.WEIGHTS_EPOCH[0] += 1

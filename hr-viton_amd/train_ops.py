@@ -25,11 +25,31 @@ def _bf16_tile(cout: int) -> int:
     return 8 if p128 <= p64 else 9
 
 
+_FROZEN_PACKS: dict = {}
+
+
+def frozen_stamp(p) -> Optional[tuple]:
+    """Stamp for pack_weight_dev(frozen=...): None for a trainable parameter."""
+    if p.requires_grad:
+        return None
+    return (p._version, getattr(p, "_hrv_epoch", 0))
+
+
 def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
                     stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0,
-                    sigma: Optional[torch.Tensor] = None, bf16: bool = False):
+                    sigma: Optional[torch.Tensor] = None, bf16: bool = False, frozen=None):
     """hrv_conv2d_pack_weight_dev_f32.  ``w``: OIHW fp32 on the device.  Returns (packed, geom)
-    with geom = (KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, elems)."""
+    with geom = (KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, elems).
+    ``frozen`` (a hashable stamp of the owning parameter, or None): the weight belongs to a network that is never
+    trained on this path (VGG19 of the perceptual loss: 39 packs of 20 M parameters per training step otherwise) -- the
+    packed form is kept, keyed on the storage, the stamp (``frozen_stamp``) and ops.LOAD_EPOCH."""
+    key = None
+    if frozen is not None and sigma is None:
+        key = (w.data_ptr(), frozen, ops.LOAD_EPOCH[0], tuple(w.shape), tuple(src_pad), tuple(src_real), cfg, mode,
+               stride, pad, tuple(phase), wscale, bf16)
+        hit = _FROZEN_PACKS.get(key)
+        if hit is not None:
+            return hit
     lib = _lib.load()
     ops.require_cuda(w, "pack_weight_dev")
     w = w.contiguous()
@@ -48,6 +68,10 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     _lib.check(fn(w.data_ptr(), Cout, KH, KW, n, srcC, srcR, cfg, mode, stride, pad, phase[0], phase[1], wscale,
                   None if sigma is None else sigma.data_ptr(), buf.data_ptr(), geom, _stream()),
                "hrv_conv2d_pack_weight_dev_" + ("bf16" if bf16 else "f32"))
+    if key is not None:
+        if len(_FROZEN_PACKS) > 256:
+            _FROZEN_PACKS.clear()
+        _FROZEN_PACKS[key] = (buf, tuple(geom))
     return buf, tuple(geom)
 
 
@@ -201,7 +225,7 @@ def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
-                     out_bf16: bool = False) -> Act:
+                     out_bf16: bool = False, frozen=None) -> Act:
     """Forward convolution with device-resident, per-step packed weights.  ``srcs``: (Act, up_shift).
     ``out_bf16`` (mixed precision only): store the result in bf16 -- for tensors that only matrix cores read."""
     lib = _lib.load()
@@ -226,7 +250,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
     packed, _ = pack_weight_dev(w, [a.Cp for a, _ in srcs], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
-                                bf16=mb)
+                                bf16=mb, frozen=frozen)
     if out is None:
         out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device, bf16=out_bf16 and mb)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
@@ -237,7 +261,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
 
 def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
                sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
-               name: str = "dgrad", out_bf16: bool = False) -> Act:
+               name: str = "dgrad", out_bf16: bool = False, frozen=None) -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
     activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x).
     ``w`` may be a PAIR (w_gamma, w_beta) for dY = [dgamma | dbeta] (stride 1): packed without a concatenated copy."""
@@ -266,7 +290,8 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         if pair is not None:
             packed, g, _ = pack_weight_pair_dev(pair[0], pair[1], 2, [_ceil4(cin)], [cin], cfg, 1, pad, mb)
         else:
-            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb)
+            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb,
+                                        frozen=frozen)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
                     residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl, mma_bf16=mb)
         return out

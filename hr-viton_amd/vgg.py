@@ -97,7 +97,7 @@ class Vgg19(nn.Module):
                 m = self.conv(idx)
                 src = x_bf16 if (idx == 0 and x_bf16 is not None) else cur
                 out = T.conv_forward_dev(m.weight.data, [(src, 0)], 1, 1, shift=m.bias.data, act=ACT_RELU,
-                                         name=f"vgg.features.{idx}")
+                                         name=f"vgg.features.{idx}", frozen=T.frozen_stamp(m.weight))
             else:
                 out = layers[idx]([cur])
             if save:
@@ -169,7 +169,7 @@ class _VGGLossFn(torch.autograd.Function):
             w = vgg.conv(idx).weight.data
             fused = idx != 0 and (idx - 1) not in _POOLS        # src is the previous conv's ReLU output
             d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, act_mask=src if fused else None, slope=0.0,
-                             name=f"vgg.features.{idx}.dgrad")
+                             name=f"vgg.features.{idx}.dgrad", frozen=T.frozen_stamp(vgg.conv(idx).weight))
         ctx.saved = ctx.grads = None
         dx = ops.to_nchw(d)
         T.scale_(dx, 1.0, g_out.contiguous())
