@@ -121,6 +121,7 @@ SYMBOLS = {
     "hrv_thin_conv_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hrv_thin_conv_bf16": (C.c_int, [C.POINTER(hrv_thin_conv_t), _vp]),
     "hrv_loss_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f, _f, _vp, _vp, _vp, _i32, _vp]),
+    "hrv_loss_bf16in_f32": (C.c_int, [_vp, _vp, _i64, _i32, _f, _f, _vp, _vp, _vp, _i32, _vp]),
     "hrv_scale_f32": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
     "hrv_act_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _f, _vp]),
     "hrv_tanh_bwd_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
@@ -128,8 +129,10 @@ SYMBOLS = {
     "hrv_downsum2x2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "hrv_avgpool3x3s2_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "hrv_maxpool2x2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_maxpool2x2_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_maxpool2x2_bwd_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_maxpool2x2_bwd_relu_nhwc_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_maxpool2x2_bwd_relu_nhwc_xbf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_adam_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _f, _vp]),
     "hrv_spectral_norm_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _f, _vp, _vp, _vp]),
     "hrv_spectral_norm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),

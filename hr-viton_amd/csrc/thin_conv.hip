@@ -212,7 +212,8 @@ extern "C" int hrv_thin_conv_supported(int32_t KH, int32_t KW, int32_t src_chann
   const bool k9 = KH == 3;
   // instantiated (TN, KB): up_4 conv_0 forward (1,5) / data gradient (3,2), conv_1 and conv_img (1,2), conv_s forward (1,5) / dgrad (3,2)
   // kb 1: the 9-channel stem, conv_img's data gradient; (tn 2, kb 1): VGG19 features.0 (3 -> 64 over every pixel)
-  if (k9) return (tn == 1 && (kb == 5 || kb == 2 || kb == 1)) || (tn == 3 && kb == 2) || (tn == 2 && kb == 1);
+  // (tn 2, kb 4): VGG19 features.2 (64 -> 64 over every pixel, bf16-stored activations)
+  if (k9) return (tn == 1 && (kb == 5 || kb == 2 || kb == 1)) || (tn == 3 && kb == 2) || (tn == 2 && (kb == 1 || kb == 4));
   return (tn == 1 && kb == 5) || (tn == 3 && kb == 2);
 }
 
@@ -253,6 +254,7 @@ extern "C" int hrv_thin_conv_bf16(const hrv_thin_conv_t* d, hrv_stream_t stream)
     if (tn == 1 && kb == 1) return thin_launch<1, 1, 9>(p, st);
     if (tn == 3 && kb == 2) return thin_launch<3, 2, 9>(p, st);
     if (tn == 2 && kb == 1) return thin_launch<2, 1, 9>(p, st);
+    if (tn == 2 && kb == 4) return thin_launch<2, 4, 9>(p, st);
   } else {
     if (tn == 1 && kb == 5) return thin_launch<1, 5, 1>(p, st);
     if (tn == 3 && kb == 2) return thin_launch<3, 2, 1>(p, st);

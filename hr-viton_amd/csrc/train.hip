@@ -219,6 +219,7 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
 // 2 hinge-D real max(1-a,0) ; 3 -a (generator hinge / wgan) ; 4 (a-b)^2 (LSGAN/MSE)
 // grad[i] = gscale * dl/da ; loss = lscale * sum(l)   (callers pass 1/numel etc.)
 // ---------------------------------------------------------------------------
+template <bool AB>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
                                                    int mode_flags, float gscale, float* __restrict__ grad,
                                                    float* __restrict__ part) {
@@ -227,13 +228,17 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, 
   const int mode = mode_flags & 15;
   const bool relu_mask = (mode_flags & 16) != 0;   // a = ReLU(pre): the gradient is handed back w.r.t. pre (x (a > 0))
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    const float x = a[i];
+    auto ldv = [](const float* p, size_t k) -> float {
+      if constexpr (AB) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[k] << 16);
+      else return p[k];
+    };
+    const float x = ldv(a, i);
     float l, g;
-    if (mode == 0) { const float d = x - b[i]; l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+    if (mode == 0) { const float d = x - ldv(b, i); l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
     else if (mode == 1) { l = fmaxf(1.f + x, 0.f); g = x > -1.f ? 1.f : 0.f; }
     else if (mode == 2) { l = fmaxf(1.f - x, 0.f); g = x < 1.f ? -1.f : 0.f; }
     else if (mode == 3) { l = -x; g = -1.f; }
-    else { const float d = x - b[i]; l = d * d; g = 2.f * d; }
+    else { const float d = x - ldv(b, i); l = d * d; g = 2.f * d; }
     s += l;
     if (grad) grad[i] = (relu_mask && !(x > 0.f)) ? 0.f : gscale * g;
   }
@@ -356,6 +361,24 @@ __global__ void avgpool3s2_bwd_kernel(const float* __restrict__ dy, int N, int H
 // VGG19: 2x2 stride-2 max pool, forward and backward (first maximum in (0,0),(0,1),(1,0),(1,1)
 // scan order takes the gradient, like torch)
 // ---------------------------------------------------------------------------
+// XB: x (and y) are bf16-stored (mixed-precision VGG activations: matrix cores, pools and the L1 taps are the only readers)
+template <bool XB>
+__device__ __forceinline__ f32x4 ldg4(const float* base, size_t idx) {
+  if constexpr (XB) {
+    // loaded as a vector of the STORED element type: reading the bf16 data through uint2 / f32x2 lvalues here came out of the
+    // compiler as one dword load with every lane a copy of element 0 (type-punned access)
+    typedef unsigned short u16x4v __attribute__((ext_vector_type(4)));
+    const u16x4v h = *reinterpret_cast<const u16x4v*>(reinterpret_cast<const unsigned short*>(base) + idx);
+    f32x4 v;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned)h[e] << 16);
+    return v;
+  } else {
+    return ld4(base + idx);
+  }
+}
+
+template <bool XB>
 __global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int Wo, int C4, int xcs, float* __restrict__ y,
                                 int ycs) {
   const size_t total = (size_t)N * Ho * Wo * C4;
@@ -366,15 +389,33 @@ __global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int 
     const size_t t = pix / Wo;
     const int ho = (int)(t % Ho);
     const int n = (int)(t / Ho);
-    const float* s = x + (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
-    const f32x4 a = ld4(s), b = ld4(s + xcs), c = ld4(s + (size_t)2 * Wo * xcs), d = ld4(s + (size_t)2 * Wo * xcs + xcs);
-    f32x4 m;
+    const size_t s = (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
+    if constexpr (XB) {
+      // bf16 storage: the inputs are ReLU outputs (>= +0, never NaN), for which the order of the 16-bit patterns IS the
+      // order of the values -- an integer max on the stored elements, exact, no conversion
+      typedef unsigned short u16x4v __attribute__((ext_vector_type(4)));
+      const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
+      const u16x4v a = *reinterpret_cast<const u16x4v*>(xs + s), b = *reinterpret_cast<const u16x4v*>(xs + s + xcs),
+                   c = *reinterpret_cast<const u16x4v*>(xs + s + (size_t)2 * Wo * xcs),
+                   d = *reinterpret_cast<const u16x4v*>(xs + s + (size_t)2 * Wo * xcs + xcs);
+      u16x4v o;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
-    *reinterpret_cast<f32x4*>(y + pix * ycs + g * 4) = m;
+      for (int e = 0; e < 4; ++e) {
+        const unsigned short p = a[e] > b[e] ? a[e] : b[e], q = c[e] > d[e] ? c[e] : d[e];
+        o[e] = p > q ? p : q;
+      }
+      *reinterpret_cast<u16x4v*>(reinterpret_cast<unsigned short*>(y) + pix * ycs + g * 4) = o;
+    } else {
+      const f32x4 a = ld4(x + s), b = ld4(x + s + xcs), c = ld4(x + s + (size_t)2 * Wo * xcs), d = ld4(x + s + (size_t)2 * Wo * xcs + xcs);
+      f32x4 m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = fmaxf(fmaxf(a[e], b[e]), fmaxf(c[e], d[e]));
+      *reinterpret_cast<f32x4*>(y + pix * ycs + g * 4) = m;
+    }
   }
 }
 
+template <bool XB>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Ho, int Wo,
                                     int C4, int xcs, int ycs, float* __restrict__ dx, int relu) {
   const size_t total = (size_t)N * Ho * Wo * C4;
@@ -387,7 +428,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
     const int n = (int)(t / Ho);
     const size_t base = (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
     const size_t o01 = xcs, o10 = (size_t)2 * Wo * xcs, o11 = o10 + xcs;
-    const f32x4 a = ld4(x + base), b = ld4(x + base + o01), c = ld4(x + base + o10), d = ld4(x + base + o11);
+    const f32x4 a = ldg4<XB>(x, base), b = ldg4<XB>(x, base + o01), c = ldg4<XB>(x, base + o10), d = ldg4<XB>(x, base + o11);
     const f32x4 gy = ld4(dy + pix * ycs + g * 4);
     f32x4 ga = (f32x4)(0.f), gb = ga, gc = ga, gd = ga;
 #pragma unroll
@@ -788,8 +829,23 @@ extern "C" int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t m
   HRV_REQUIRE(((mode & 15) != 0 && (mode & 15) != 4) || b, "loss: mode needs a target tensor");
   const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_kernel, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, mode, gscale, grad, workspace);
+  hipLaunchKernelGGL(loss_kernel<false>, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, mode, gscale, grad, workspace);
   int rc = check_launch("loss_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, workspace, nb, lscale, loss_out, accumulate);
+  return check_launch("loss_final_kernel");
+}
+
+// the same over bf16-stored a and b (mixed-precision VGG taps); loss and gradient stay fp32
+extern "C" int hrv_loss_bf16in_f32(const uint16_t* a, const uint16_t* b, int64_t n, int32_t mode, float lscale, float gscale,
+                                   float* grad, float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(a && workspace && loss_out && n > 0 && mode >= 0 && (mode & 15) <= 4 && (mode & ~31) == 0, "loss_bf16in: bad args");
+  HRV_REQUIRE(((mode & 15) != 0 && (mode & 15) != 4) || b, "loss_bf16in: mode needs a target tensor");
+  const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(loss_kernel<true>, dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, (size_t)n, mode, gscale, grad,
+                     workspace);
+  int rc = check_launch("loss_kernel[bf16 in]");
   if (rc) return rc;
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, workspace, nb, lscale, loss_out, accumulate);
   return check_launch("loss_final_kernel");
@@ -822,16 +878,26 @@ extern "C" int hrv_maxpool2x2_nhwc_f32(const float* x, int32_t N, int32_t H, int
                                        hrv_stream_t stream) {
   HRV_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool: bad args");
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, H / 2, W / 2, C / 4, C,
+  hipLaunchKernelGGL(maxpool2_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, N, H / 2, W / 2, C / 4, C,
                      y, C);
   return check_launch("maxpool2_kernel");
+}
+
+// bf16-stored x and y (mixed-precision VGG activations)
+extern "C" int hrv_maxpool2x2_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y,
+                                        hrv_stream_t stream) {
+  HRV_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0, "maxpool_bf16: bad args");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, N, H / 2,
+                     W / 2, C / 4, C, (float*)y, C);
+  return check_launch("maxpool2_kernel[bf16]");
 }
 
 extern "C" int hrv_maxpool2x2_bwd_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
                                            float* dx, hrv_stream_t stream) {
   HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool_bwd: bad args");
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
                      C / 4, C, C, dx, 0);
   return check_launch("maxpool2_bwd_kernel");
 }
@@ -841,9 +907,19 @@ extern "C" int hrv_maxpool2x2_bwd_relu_nhwc_f32(const float* x, const float* dy,
                                                 float* dx, hrv_stream_t stream) {
   HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 4 == 0, "maxpool_bwd_relu: bad args");
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool2_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<false>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, x, dy, N, H / 2, W / 2,
                      C / 4, C, C, dx, 1);
   return check_launch("maxpool2_bwd_kernel[relu]");
+}
+
+// ... with a bf16-stored x (dy, dx fp32)
+extern "C" int hrv_maxpool2x2_bwd_relu_nhwc_xbf16(const uint16_t* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                                  float* dx, hrv_stream_t stream) {
+  HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0, "maxpool_bwd_xbf16: bad args");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, dy, N,
+                     H / 2, W / 2, C / 4, C, C, dx, 1);
+  return check_launch("maxpool2_bwd_kernel[relu, bf16 x]");
 }
 
 extern "C" int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

@@ -416,16 +416,19 @@ def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, g
     """hrv_loss_f32 over flat contiguous tensors: loss_out[0] (+)= lscale*sum(l); returns grad (same shape as a)."""
     lib = _lib.load()
     cl = torch.channels_last
+    bf = a.dtype == torch.bfloat16          # bf16-stored operands (mixed-precision VGG taps): loss and gradient stay fp32
+    assert b is None or b.dtype == a.dtype, "loss: both operands share one storage type"
     ok = a.is_contiguous() and (b is None or (b.shape == a.shape and b.is_contiguous()))
     ok = ok or (a.dim() == 4 and a.is_contiguous(memory_format=cl) and
                 (b is None or (b.shape == a.shape and b.is_contiguous(memory_format=cl))))
     assert ok, "loss: operands must share one dense layout (strides of size-1 dims do not matter)"
-    grad = torch.empty_like(a) if want_grad else None
+    grad = torch.empty_like(a, dtype=torch.float32) if want_grad else None
     ws = _workspace(a.device, 4096)
-    with _Timed("loss", "loss_f32", 0.0, 4.0 * a.numel() * (1 + (b is not None) + (grad is not None))):
-        _lib.check(lib.hrv_loss_f32(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), mode, lscale, gscale,
-                                    None if grad is None else grad.data_ptr(), ws.data_ptr(), loss_out.data_ptr(),
-                                    1 if accumulate else 0, _stream()), "hrv_loss_f32")
+    fn = lib.hrv_loss_bf16in_f32 if bf else lib.hrv_loss_f32
+    with _Timed("loss", "loss_f32", 0.0, (2.0 if bf else 4.0) * a.numel() * (1 + (b is not None)) + 4.0 * a.numel() * (grad is not None)):
+        _lib.check(fn(a.data_ptr(), None if b is None else b.data_ptr(), a.numel(), mode, lscale, gscale,
+                      None if grad is None else grad.data_ptr(), ws.data_ptr(), loss_out.data_ptr(),
+                      1 if accumulate else 0, _stream()), "hrv_loss_f32")
     return grad
 
 
@@ -457,12 +460,14 @@ def avgpool3x3s2_bwd(dy: Act, H: int, W: int, dx: Optional[Act] = None, accumula
 
 
 def maxpool2x2(x: Act) -> Act:
+    """2x2 / 2 max pool.  A bf16-stored x gives a bf16-stored y, exact; that variant is for ReLU outputs (x >= +0, as in
+    VGG19): it takes the integer max of the stored 16-bit patterns, whose order is the order of non-negative values."""
     lib = _lib.load()
     assert x.coff == 0 and x.cstride == x.Cp
-    y = ops.alloc(x.N, x.H // 2, x.W // 2, x.C, x.t.device)
+    y = ops.alloc(x.N, x.H // 2, x.W // 2, x.C, x.t.device, bf16=x.bf16)
+    fn = lib.hrv_maxpool2x2_nhwc_bf16 if x.bf16 else lib.hrv_maxpool2x2_nhwc_f32
     with _Timed("pool", "maxpool2x2", 0.0, ops.act_bytes(x) * 1.25):
-        _lib.check(lib.hrv_maxpool2x2_nhwc_f32(x.t.data_ptr(), x.N, x.H, x.W, x.Cp, y.t.data_ptr(), _stream()),
-                   "hrv_maxpool2x2_nhwc_f32")
+        _lib.check(fn(x.t.data_ptr(), x.N, x.H, x.W, x.Cp, y.t.data_ptr(), _stream()), "hrv_maxpool2x2_nhwc")
     return y
 
 
@@ -470,8 +475,10 @@ def maxpool2x2_bwd(x: Act, dy: Act, relu: bool = False) -> Act:
     """``relu``: x = ReLU(pre) -- the result is the gradient w.r.t. pre (the ReLU derivative rides along)."""
     lib = _lib.load()
     dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
-    fn = lib.hrv_maxpool2x2_bwd_relu_nhwc_f32 if relu else lib.hrv_maxpool2x2_bwd_nhwc_f32
-    with _Timed("pool", "maxpool2x2_bwd", 0.0, ops.act_bytes(x) * 2.25):
+    assert not dy.bf16 and (relu or not x.bf16), "maxpool2x2_bwd: fp32 gradients; a bf16-stored x needs relu=True"
+    fn = (lib.hrv_maxpool2x2_bwd_relu_nhwc_xbf16 if x.bf16 else lib.hrv_maxpool2x2_bwd_relu_nhwc_f32) if relu \
+        else lib.hrv_maxpool2x2_bwd_nhwc_f32
+    with _Timed("pool", "maxpool2x2_bwd", 0.0, ops.act_bytes(x) + 5.0 * x.N * x.H * x.W * x.C):
         _lib.check(fn(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(), _stream()),
                    "hrv_maxpool2x2_bwd_nhwc_f32")
     return dx

@@ -82,7 +82,9 @@ class Vgg19(nn.Module):
 
     def features(self, x: Act, save: bool, x_bf16: Optional[Act] = None):
         """Runs the 13 convs + 4 pools; returns (taps [5 Acts], saved list for backward).  ``x_bf16`` (mixed precision):
-        a bf16 copy of the image for features.0 (3 -> 64 channels over every pixel: memory-bound, thin_conv.hip)."""
+        a bf16 copy of the image for features.0 (3 -> 64 channels over every pixel: memory-bound, thin_conv.hip); with
+        it the activations are STORED in bf16 as well -- their readers are matrix cores (same operand bits as rounding
+        while staging), max pools (exact), ReLU masks (sign only) and the L1 taps (value and target rounded alike)."""
         layers = self.plan(x.t.device)
         taps, saved = [], []
         cur = x
@@ -97,7 +99,8 @@ class Vgg19(nn.Module):
                 m = self.conv(idx)
                 src = x_bf16 if (idx == 0 and x_bf16 is not None) else cur
                 out = T.conv_forward_dev(m.weight.data, [(src, 0)], 1, 1, shift=m.bias.data, act=ACT_RELU,
-                                         name=f"vgg.features.{idx}", frozen=T.frozen_stamp(m.weight))
+                                         name=f"vgg.features.{idx}", frozen=T.frozen_stamp(m.weight),
+                                         out_bf16=x_bf16 is not None)
             else:
                 out = layers[idx]([cur])
             if save:

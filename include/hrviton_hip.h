@@ -283,6 +283,8 @@ int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);
  * workspace: 1024 floats. */
 int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t mode, float lscale, float gscale, float* grad,
                  float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream);
+int hrv_loss_bf16in_f32(const uint16_t* a, const uint16_t* b, int64_t n, int32_t mode, float lscale, float gscale, float* grad,
+                        float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream);
 /* tanh backward through its output: out = dy*(1-y*y) (network_generator.py:245);
  * add_slice: out[.., out_coff:+C] (+)= a[.., a_coff:+C]  (gradient accumulation / channel split). */
 /* x *= s_host * (s_dev ? s_dev[0] : 1): applies an upstream (device-resident) loss-gradient scalar. */
@@ -308,6 +310,12 @@ int hrv_maxpool2x2_bwd_nhwc_f32(const float* x, const float* dy, int32_t N, int3
 /* ... with the ReLU derivative of the pooled tensor fused (x = ReLU(pre); dx is the gradient w.r.t. pre). */
 int hrv_maxpool2x2_bwd_relu_nhwc_f32(const float* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C, float* dx,
                                      hrv_stream_t stream);
+/* bf16-stored activations (mixed-precision VGG19: matrix cores, pools and the L1 taps are their only readers;
+ * forward bf16 -> bf16 for NON-NEGATIVE inputs (ReLU outputs: integer max of the stored patterns, exact); backward with
+ * bf16 x, fp32 dy / dx; loss over bf16 a, b. */
+int hrv_maxpool2x2_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y, hrv_stream_t stream);
+int hrv_maxpool2x2_bwd_relu_nhwc_xbf16(const uint16_t* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                       float* dx, hrv_stream_t stream);
 /* torch.optim.Adam step over one flat buffer (train_generator.py:154-157,322,360);
  * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,

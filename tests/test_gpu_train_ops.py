@@ -479,7 +479,7 @@ def test_wgrad_tr_kernel_bf16_stored_operands(case, monkeypatch):
 
 @pytest.mark.parametrize("case", [("conv_0", 80, 32, 3, True, False, "none"), ("conv_1", 32, 32, 3, True, True, "lrelu"),
                                   ("conv_s", 80, 32, 1, False, False, "none"), ("conv_img", 32, 3, 3, False, False, "tanh"),
-                                  ("vgg_features0", 3, 64, 3, False, False, "relu")],
+                                  ("vgg_features0", 3, 64, 3, False, False, "relu"), ("vgg_features2", 64, 64, 3, False, True, "relu")],
                          ids=lambda c: c[0])
 def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
     """thin_conv.hip (weights converted into LDS once per persistent block, LDS-DMA halo patches, 32 pixels x all columns
@@ -650,3 +650,21 @@ def test_batched_spectral_norm_matches_per_layer_and_torch(iters):
         for got_s, got_u, got_v in ((sig1[j], u1[j], v1[j]), (sig2[j], u2[j], v2[j]), (sig2[j], uk[j], vk[j])):
             assert abs(float(got_s) - float(sg)) <= 2e-5 * abs(float(sg)), (j, float(got_s), float(sg))
             assert torch.allclose(got_u, u, atol=2e-6) and torch.allclose(got_v, v, atol=2e-6), j
+
+
+def test_bf16_stored_pool_and_loss_kernels_match_fp32_on_the_same_values():
+    """Mixed-precision VGG19 keeps its activations in bf16: the 2x2 max pool (exact), its backward with the fused ReLU
+    derivative, and the L1 tap loss over bf16-stored operands give what the fp32 kernels give on the same values."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(5)
+    x = torch.relu(torch.randn(2, 20, 24, 64, generator=g)).to(torch.bfloat16).cuda()
+    y = torch.relu(torch.randn(2, 20, 24, 64, generator=g)).to(torch.bfloat16).cuda()
+    xa, xf = ops.Act(x, 64), ops.Act(x.float(), 64)
+    p16, p32 = T.maxpool2x2(xa), T.maxpool2x2(xf)
+    assert p16.bf16 and torch.equal(p16.t.float(), p32.t)
+    dy = ops.Act(torch.randn(2, 10, 12, 64, generator=g).cuda(), 64)
+    assert torch.equal(T.maxpool2x2_bwd(xa, dy, relu=True).t, T.maxpool2x2_bwd(xf, dy, relu=True).t)
+    l16, l32 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    g16 = T.loss(x, y, T.LOSS_L1 | T.LOSS_RELU_MASK, 0.5, 0.25, l16, accumulate=False)
+    g32 = T.loss(x.float(), y.float(), T.LOSS_L1 | T.LOSS_RELU_MASK, 0.5, 0.25, l32, accumulate=False)
+    assert g16.dtype == torch.float32 and torch.equal(g16, g32) and torch.equal(l16, l32)
