@@ -222,25 +222,58 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
 template <bool AB>
 __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, const float* __restrict__ b, size_t n,
                                                    int mode_flags, float gscale, float* __restrict__ grad,
-                                                   float* __restrict__ part) {
+                                                   float* __restrict__ part, int vec) {
   __shared__ float red[256];
   float s = 0.f;
   const int mode = mode_flags & 15;
   const bool relu_mask = (mode_flags & 16) != 0;   // a = ReLU(pre): the gradient is handed back w.r.t. pre (x (a > 0))
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-    auto ldv = [](const float* p, size_t k) -> float {
-      if constexpr (AB) return __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p)[k] << 16);
-      else return p[k];
-    };
-    const float x = ldv(a, i);
-    float l, g;
-    if (mode == 0) { const float d = x - ldv(b, i); l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
+  auto term = [&](float x, float y, float& g) -> float {
+    float l;
+    if (mode == 0) { const float d = x - y; l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
     else if (mode == 1) { l = fmaxf(1.f + x, 0.f); g = x > -1.f ? 1.f : 0.f; }
     else if (mode == 2) { l = fmaxf(1.f - x, 0.f); g = x < 1.f ? -1.f : 0.f; }
     else if (mode == 3) { l = -x; g = -1.f; }
-    else { const float d = x - ldv(b, i); l = d * d; g = 2.f * d; }
-    s += l;
-    if (grad) grad[i] = (relu_mask && !(x > 0.f)) ? 0.f : gscale * g;
+    else { const float d = x - y; l = d * d; g = 2.f * d; }
+    g = (relu_mask && !(x > 0.f)) ? 0.f : gscale * g;
+    return l;
+  };
+  typedef unsigned short u16x4v __attribute__((ext_vector_type(4)));
+  auto ld4v = [](const float* p, size_t k) -> f32x4 {      // 4 consecutive elements starting at element k
+    if constexpr (AB) {
+      const u16x4v h = *reinterpret_cast<const u16x4v*>(reinterpret_cast<const unsigned short*>(p) + k);
+      f32x4 v;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = __builtin_bit_cast(float, (unsigned)h[e] << 16);
+      return v;
+    } else {
+      return *reinterpret_cast<const f32x4*>(p + k);
+    }
+  };
+  // 16-byte (fp32) / 8-byte (bf16) accesses: four consecutive elements per thread and iteration
+  const size_t n4 = vec ? n / 4 : 0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+    const f32x4 x4 = ld4v(a, 4 * i);
+    const f32x4 y4 = b ? ld4v(b, 4 * i) : (f32x4)(0.f);
+    f32x4 g4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float g;
+      s += term(x4[e], y4[e], g);
+      g4[e] = g;
+    }
+    if (grad) *reinterpret_cast<f32x4*>(grad + 4 * i) = g4;
+  }
+  for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float x, y = 0.f, g;
+    if constexpr (AB) {
+      x = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(a)[i] << 16);
+      if (b) y = __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(b)[i] << 16);
+    } else {
+      x = a[i];
+      if (b) y = b[i];
+    }
+    s += term(x, y, g);
+    if (grad) grad[i] = g;
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -829,7 +862,8 @@ extern "C" int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t m
   HRV_REQUIRE(((mode & 15) != 0 && (mode & 15) != 4) || b, "loss: mode needs a target tensor");
   const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(loss_kernel<false>, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, mode, gscale, grad, workspace);
+  const int vec = (((uintptr_t)a | (uintptr_t)b | (uintptr_t)grad) & 15) == 0;
+  hipLaunchKernelGGL(loss_kernel<false>, dim3(nb), dim3(256), 0, st, a, b, (size_t)n, mode, gscale, grad, workspace, vec);
   int rc = check_launch("loss_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, workspace, nb, lscale, loss_out, accumulate);
@@ -843,8 +877,9 @@ extern "C" int hrv_loss_bf16in_f32(const uint16_t* a, const uint16_t* b, int64_t
   HRV_REQUIRE(((mode & 15) != 0 && (mode & 15) != 4) || b, "loss_bf16in: mode needs a target tensor");
   const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
   hipStream_t st = (hipStream_t)stream;
+  const int vec = ((((uintptr_t)a | (uintptr_t)b) & 7) | ((uintptr_t)grad & 15)) == 0;
   hipLaunchKernelGGL(loss_kernel<true>, dim3(nb), dim3(256), 0, st, (const float*)a, (const float*)b, (size_t)n, mode, gscale, grad,
-                     workspace);
+                     workspace, vec);
   int rc = check_launch("loss_kernel[bf16 in]");
   if (rc) return rc;
   hipLaunchKernelGGL(loss_final_kernel, dim3(1), dim3(64), 0, st, workspace, nb, lscale, loss_out, accumulate);
