@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 
 #include "../../include/hrviton_hip.h"
 
@@ -51,9 +52,18 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
 // 1040-channel / 64x48-pixel levels of the generator spread over 5 x 24 x N blocks instead of 6 x N (they ran at
 // 50-200 GB/s), and slabs are >= 128 pixels (fixed-order second stage over <= 256 slab partials).
 constexpr int NORM_GCAP = 64;
+inline int norm_slab_cap() {
+  static int cap = 0;
+  if (cap == 0) {
+    const char* e = getenv("HRV_NORM_SLABS_MAX");
+    cap = e ? atoi(e) : 256;
+    if (cap < 1) cap = 256;
+  }
+  return cap;
+}
 inline int norm_slabs(int HW) {
-  int nb = (HW + 127) / 128;
-  return nb < 1 ? 1 : (nb > 256 ? 256 : nb);
+  const int nb = (HW + 127) / 128, cap = norm_slab_cap();
+  return nb < 1 ? 1 : (nb > cap ? cap : nb);
 }
 inline int norm_chunks(int C4) { return (C4 + NORM_GCAP - 1) / NORM_GCAP; }
 
