@@ -551,15 +551,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int tap
   }
 }
 
-// db[co] (+)= sum_s bias_ws[s][co]   (fixed order)
-__global__ void wgrad_bias_reduce_kernel(const float* __restrict__ bws, int S, int Cout, float* __restrict__ db,
-                                         int accumulate) {
-  const int co = blockIdx.x * blockDim.x + threadIdx.x;
-  if (co >= Cout) return;
-  float sum = 0.f;
-  for (int s = 0; s < S; ++s) sum += bws[(size_t)s * Cout + co];
-  db[co] = accumulate ? db[co] + sum : sum;
-}
+// (the bias partials bias_ws[s][co] are summed by sum_rows_kernel, hrv_common.h)
 
 // ------------------------------------------------------------------ column sums (bias gradient)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int P, int C4, int cs, int co,
@@ -846,9 +838,8 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
                      ci_base, x_C_real, dw_oihw, accumulate);
   rc = check_launch("wgrad_reduce_kernel");
   if (rc || !dbias) return rc;
-  hipLaunchKernelGGL(wgrad_bias_reduce_kernel, dim3((Cout + 127) / 128), dim3(128), 0, st, p.bias_ws, S, Cout, dbias,
-                     dbias_accumulate);
-  return check_launch("wgrad_bias_reduce_kernel");
+  hipLaunchKernelGGL(sum_rows_kernel<>, dim3((Cout + 15) / 16), dim3(256), 0, st, p.bias_ws, S, Cout, dbias, dbias_accumulate);
+  return check_launch("sum_rows_kernel[bias]");
 }
 
 extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,

@@ -206,25 +206,6 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
   }
 }
 
-// out[c] (+)= sum over rows of part[r][c]: 16 channels x 16 row-groups per block (a thread per channel walking all
-// N x slabs rows serially was 111 us per call), fixed combination order
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int accumulate) {
-  __shared__ double red[16][16];
-  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
-  double s = 0.0;
-  if (c < C)
-    for (int r = rg; r < rows; r += 16) s += (double)part[(size_t)r * C + c];
-  red[rg][cl] = s;
-  __syncthreads();
-  if (threadIdx.x < 16 && c < C) {
-    double t = 0.0;
-#pragma unroll
-    for (int g = 0; g < 16; ++g) t += red[g][cl];
-    out[c] = accumulate ? out[c] + (float)t : (float)t;
-  }
-}
-
 // ---------------------------------------------------------------------------
 // losses: value + gradient in one pass.  mode: 0 L1 |a-b| ; 1 hinge-D fake max(1+a,0) ;
 // 2 hinge-D real max(1-a,0) ; 3 -a (generator hinge / wgan) ; 4 (a-b)^2 (LSGAN/MSE)
@@ -865,7 +846,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   rc = check_launch("norm_bwd_stage2_kernel");
   if (rc) return rc;
   if (d->noise_z && d->dnoise_scale) {
-    hipLaunchKernelGGL(sum_rows_kernel, dim3((C + 15) / 16), dim3(256), 0, st, part, d->N * nb, C, d->dnoise_scale,
+    hipLaunchKernelGGL(sum_rows_kernel<>, dim3((C + 15) / 16), dim3(256), 0, st, part, d->N * nb, C, d->dnoise_scale,
                        d->dns_accumulate);
     rc = check_launch("sum_rows_kernel");
   }

@@ -347,14 +347,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   }
 }
 
-// bias gradient, second stage: fixed-order sum of the per-slab column sums the kernel above wrote
-__global__ void colsum_bf16_final_kernel(const float* __restrict__ part, int NB, int C, float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float t = 0.f;
-  for (int b = 0; b < NB; ++b) t += part[(size_t)b * C + c];
-  out[c] = accumulate ? out[c] + t : t;
-}
+// (bias gradient, second stage: the per-slab column sums are summed by sum_rows_kernel, hrv_common.h)
 
 // Host side.  Returns 1 when the kernel was launched (partials in `workspace`, *S_out slabs), 0 when the shape is
 // not one it serves (the caller falls back to conv_wgrad_bf16_kernel), < 0 on error.
@@ -435,9 +428,8 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   int rc = check_launch("conv_wgrad_tr_kernel");
   if (rc) return rc;
   if (dbias) {
-    hipLaunchKernelGGL(colsum_bf16_final_kernel, dim3((Cout + 127) / 128), dim3(128), 0, st, p.bias_ws, S, Cout, dbias,
-                       dbias_accumulate);
-    rc = check_launch("colsum_bf16_final_kernel");
+    hipLaunchKernelGGL(sum_rows_kernel<>, dim3((Cout + 15) / 16), dim3(256), 0, st, p.bias_ws, S, Cout, dbias, dbias_accumulate);
+    rc = check_launch("sum_rows_kernel[bias]");
     if (rc) return rc;
   }
   *S_out = S;
