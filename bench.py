@@ -356,6 +356,43 @@ def roofline_obj(wl, res, north_star):
                                  for r in s["top"]]}
 
 
+def self_launch(n):
+    """``python bench.py --gpus N`` started WITHOUT a launcher (the way the driver starts the N=1 run): re-exec this
+    command line as N ranks under torch.distributed.run (one process per GPU, rendezvous on 127.0.0.1, a free port) and
+    hand its exit code back.  Rank 0 of the children prints the JSON line; this parent prints nothing."""
+    import socket
+    import subprocess
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = str(sk.getsockname()[1])
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")     # dmabuf IPC (RCCL across processes)
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    _log(f"--gpus {n} without a launcher: re-exec as {n} ranks: {' '.join(cmd[1:8])} ...")
+    return subprocess.call(cmd, env=env)
+
+
+def wl_stub(ctx, B):
+    """CPU-only stand-in workload (tests/test_bench_selflaunch.py: the launcher / collective / JSON plumbing of
+    ``bench.py --gpus N`` on a box without GPUs, HRV_DIST_BACKEND=gloo).  Never a measurement."""
+    torch = ctx["torch"]
+    import torch.distributed as tdist
+    B = B or 2
+    g = torch.Generator().manual_seed(ctx["hdist"].shard_seed(7, ctx["rank"]))
+    w = torch.randn(64, 64, generator=g)
+
+    def step(_i):
+        y = (w @ w).sum().reshape(1)
+        if tdist.is_initialized():
+            tdist.all_reduce(y)        # the data-path collective of the training workloads (gradient all-reduce)
+    return dict(step=step, B=B, train=True, parity=None, flops_per_img=0.0, metric="stub (plumbing test, not a measurement)",
+                workload="stub: CPU matmul + all-reduce", traffic_tag="stub")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -366,7 +403,7 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads for the CPU legs (0 = min(cores, 32))")
     ap.add_argument("--dump-launches", default=None, help="write the per-launch table of one step to this file")
     ap.add_argument("--workload", default="train_generator",
-                    choices=["train_generator", "tryon_infer", "tocg_infer", "train_condition"],
+                    choices=["train_generator", "tryon_infer", "tocg_infer", "train_condition", "stub"],
                     help="train_generator = BASELINE configs[3], the headline (default); tryon_infer = configs[4]; "
                          "tocg_infer = configs[1]; train_condition = configs[2]")
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0: the config's own)")
@@ -375,6 +412,8 @@ def main():
     ap.add_argument("--graph", action="store_true", help="tryon_infer: replay the step as one captured hipGraph")
     args = ap.parse_args()
     mixed = (args.workload in ("train_generator", "tryon_infer") or args.bf16) and not args.fp32
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args.gpus))
 
     import torch
     import torch.nn as nn
@@ -384,11 +423,29 @@ def main():
 
     rank, local_rank, world = hdist.init_from_env()      # nccl (= RCCL) unless HRV_DIST_BACKEND overrides it
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
+    import torch.distributed as tdist
+    if args.workload == "stub":
+        ctx = dict(torch=torch, nn=nn, hdist=hdist, ops=ops, rank=rank, world=world, dev=torch.device("cpu"), args=args)
+        wl = wl_stub(ctx, args.batch)
+        dt = hdist.timed_steps(wl["step"], args.steps, args.warmup, None)
+        if rank == 0:
+            print(json.dumps({"metric": wl["metric"], "value": round(wl["B"] * world * args.steps / dt, 3), "unit": "images/s",
+                              "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                              "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                              "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "config": {"workload": wl["workload"], "global_batch": wl["B"] * world,
+                                         "parallelism": f"dp{world}-allreduce",
+                                         "dist_backend": tdist.get_backend() if tdist.is_initialized() else "none (single process)",
+                                         "rccl_ranks": tdist.get_world_size() if tdist.is_initialized() else 1},
+                              "roofline": None, "cpu_baseline": None}), flush=True)
+        if tdist.is_initialized():
+            tdist.barrier()
+            tdist.destroy_process_group()
+        return
     ndev = torch.cuda.device_count()
     local_dev = local_rank % ndev        # == local_rank on a real node; lets a 1-GPU box smoke-test the N>1 logic
     torch.cuda.set_device(local_dev)
     dev = torch.device("cuda", local_dev)
-    import torch.distributed as tdist
     ctx = dict(torch=torch, nn=nn, hdist=hdist, ops=ops, rank=rank, world=world, dev=dev, args=args,
                cpu_threads=args.cpu_threads or min(os.cpu_count() or 1, 32))
 
