@@ -56,6 +56,19 @@ class hrv_thin_conv_t(C.Structure):
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("out_bf16", C.c_int32)]
 
 
+class hrv_spade_gb_t(C.Structure):
+    _fields_ = [("mode", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("src", C.c_void_p), ("src_cstride", C.c_int32), ("src_coff", C.c_int32), ("w_packed", C.c_void_p),
+                ("C", C.c_int32), ("Cp", C.c_int32), ("hid", C.c_int32), ("x_f32", C.c_int32),
+                ("x", C.c_void_p), ("x_cstride", C.c_int32), ("x_coff", C.c_int32),
+                ("stat_stride", C.c_int32), ("g1p_bf16", C.c_int32),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("noise_z", C.c_void_p), ("noise_scale", C.c_void_p),
+                ("bias_gamma", C.c_void_p), ("bias_beta", C.c_void_p), ("g1p", C.c_void_p),
+                ("act", C.c_int32), ("act_slope", C.c_float),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("out_f32", C.c_int32),
+                ("_pad", C.c_int32), ("mask", C.c_void_p), ("mask_cstride", C.c_int32), ("mask_coff", C.c_int32)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -188,6 +201,10 @@ SYMBOLS = {
     "hrv_tapsum_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "hrv_tap_expand_nhwc": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_mul_f32": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
+    "hrv_spade_gb_packed_bytes": (_i64, [_i32, _i32, _i32, _i32]),
+    "hrv_spade_gb_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "hrv_spade_gb_pack_dev": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_spade_gb_bf16": (C.c_int, [C.POINTER(hrv_spade_gb_t), _vp]),
     "hrv_tv_loss_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 

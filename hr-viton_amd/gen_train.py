@@ -167,6 +167,20 @@ class SpadeT:
         cfg = ((8 if self.G % 2 == 0 else 9) if mb else self.cfg)
         if mb:                 # bf16 actv: each tile's halo patch stays in LDS (ops.patch_tile)
             cfg = ops.patch_tile(actv.bf16, 3, 3, 1, 1, 1, 0, self.hid, self.G * 64, x.N, x.H, x.W, wide=True) or cfg
+        out_bf16 = mb and actv.bf16 and self.C % 8 == 0
+        if (mb and actv.bf16 and out_bf16 and x.cstride % 4 == 0 and
+                T.spade_gb_ok(0, self.C, self.Cp, self.hid, x.N, x.H, x.W)):
+            # the dedicated kernel: 16x16-pixel tiles x ALL columns per block, no padded columns (csrc/spade_gb.hip)
+            out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=True)
+            g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev) if save else None
+            pk = T.spade_gb_pack(0, n.conv_gamma.weight.data, n.conv_beta.weight.data)
+            fl = 2.0 * x.N * x.H * x.W * 2 * self.C * self.hid * 9
+            nbytes = (ops.act_bytes(actv) + (2 if save else 1) * ops.act_bytes(x) + ops.act_bytes(out) +
+                      2.0 * self.C * self.hid * 9 * 2)
+            T.spade_gb_forward(actv, x, mean, rstd, zz, n.noise_scale.data, pk, n.conv_gamma.bias.data, n.conv_beta.bias.data,
+                               self.act, 0.2, out, g1p, self.name + ".conv_gamma|beta", fl, nbytes)
+            ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)
+            return out, ctx
         # (conv_gamma, conv_beta) weights packed straight into the combined interleaved matrix (no concatenated copy)
         packed, _, _ = T.pack_weight_pair_dev(n.conv_gamma.weight.data, n.conv_beta.weight.data, 1, [self.hid], [self.hid],
                                               cfg, 0, 1, mb)
@@ -245,7 +259,12 @@ class SpadeT:
         _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
         _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
         # d actv, with the ReLU derivative of conv_shared fused (slope 0)
-        T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad")
+        if (Cp == C_ and T.MMA_BF16[0] and dgb.bf16 and actv.bf16 and
+                T.spade_gb_ok(1, C_, Cp, self.hid, actv.N, actv.H, actv.W)):
+            T.spade_gb_dgrad(dgb, T.spade_gb_pack(1, n.conv_gamma.weight.data, n.conv_beta.weight.data), C_, actv, 0.0, dact,
+                             self.name + ".gb.dgrad")
+        else:
+            T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad")
         return dx
 
 

@@ -3,6 +3,8 @@ device-side weight packing, data gradient (stride 1 and the four phases of strid
 weight gradient, bias gradient.  Everything is NHWC fp32 ``Act`` views like ops.py."""
 from __future__ import annotations
 
+import os
+
 import ctypes as C
 from typing import Optional, Sequence, Tuple
 
@@ -715,3 +717,72 @@ def mul_(x: Act, m: torch.Tensor) -> Act:
     assert x.t.is_contiguous() and m.shape == x.t.shape and m.is_contiguous()
     _lib.check(lib.hrv_mul_f32(x.t.data_ptr(), m.data_ptr(), x.t.numel(), x.t.data_ptr(), _stream()), "hrv_mul_f32")
     return x
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SPADE gamma|beta convolution + modulate, and its data gradient, on the dedicated kernel (csrc/spade_gb.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def spade_gb_ok(mode: int, C_: int, Cp: int, hid: int, N: int, H: int, W: int) -> bool:
+    """The dedicated kernel serves this layer (hrv_spade_gb_supported; HRV_SPADE_GB=0 switches it off for A/B runs)."""
+    if os.environ.get("HRV_SPADE_GB", "1") == "0":
+        return False
+    return bool(_lib.load().hrv_spade_gb_supported(mode, C_, Cp, hid, N, H, W))
+
+
+def spade_gb_pack(mode: int, w_gamma: torch.Tensor, w_beta: torch.Tensor) -> torch.Tensor:
+    """(conv_gamma.weight, conv_beta.weight) [C, hid, 3, 3] fp32 -> the bf16 fragment-order stream of ``mode``
+    (0: forward, columns = (gamma | beta) pairs; 1: data gradient over [dgamma | dbeta])."""
+    lib = _lib.load()
+    ops.require_cuda(w_gamma, "spade_gb_pack")
+    assert w_gamma.is_contiguous() and w_beta.is_contiguous() and w_gamma.shape == w_beta.shape
+    C_, hid = w_gamma.shape[0], w_gamma.shape[1]
+    nbytes = lib.hrv_spade_gb_packed_bytes(mode, C_, C_, hid)
+    assert nbytes > 0, (mode, C_, hid)
+    buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_gamma.device)
+    _lib.check(lib.hrv_spade_gb_pack_dev(mode, w_gamma.data_ptr(), w_beta.data_ptr(), C_, C_, hid, buf.data_ptr(), _stream()),
+               "hrv_spade_gb_pack_dev")
+    return buf
+
+
+def spade_gb_forward(actv: Act, x: Act, mean: torch.Tensor, rstd: torch.Tensor, z: Optional[torch.Tensor],
+                     noise_scale: Optional[torch.Tensor], packed: torch.Tensor, bias_gamma: torch.Tensor, bias_beta: torch.Tensor,
+                     act: int, slope: float, out: Act, g1p: Optional[torch.Tensor], name: str, flops: float, nbytes: float):
+    """out = act(IN(x + z*noise_scale) * (1 + conv_gamma(actv)) + conv_beta(actv)); g1p (optional) <- 1 + gamma."""
+    lib = _lib.load()
+    d = _lib.hrv_spade_gb_t()
+    C_ = x.C
+    d.mode, d.N, d.H, d.W = 0, x.N, x.H, x.W
+    d.src, d.src_cstride, d.src_coff = actv.t.data_ptr(), actv.cstride, actv.coff
+    d.w_packed = packed.data_ptr()
+    d.C, d.Cp, d.hid = C_, C_, actv.C
+    d.x, d.x_cstride, d.x_coff, d.x_f32 = x.t.data_ptr(), x.cstride, x.coff, 0 if x.bf16 else 1
+    d.mean, d.rstd, d.stat_stride = mean.data_ptr(), rstd.data_ptr(), C_
+    if z is not None:
+        d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
+    d.bias_gamma, d.bias_beta = bias_gamma.data_ptr(), bias_beta.data_ptr()
+    if g1p is not None:
+        d.g1p, d.g1p_bf16 = g1p.data_ptr(), 1 if g1p.dtype == torch.bfloat16 else 0
+    d.act, d.act_slope = act, slope
+    d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
+    with ops._Timed("conv", name, flops, nbytes):
+        _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[forward]")
+
+
+def spade_gb_dgrad(dgb: Act, packed: torch.Tensor, C_: int, mask: Optional[Act], slope: float, out: Act, name: str):
+    """d(actv) [.., hid] = conv^T([dgamma | dbeta]) * (mask > 0 ? 1 : slope)."""
+    lib = _lib.load()
+    d = _lib.hrv_spade_gb_t()
+    hid = out.C
+    d.mode, d.N, d.H, d.W = 1, dgb.N, dgb.H, dgb.W
+    d.src, d.src_cstride, d.src_coff = dgb.t.data_ptr(), dgb.cstride, dgb.coff
+    d.w_packed = packed.data_ptr()
+    d.C, d.Cp, d.hid = C_, C_, hid
+    if mask is not None:
+        assert mask.bf16
+        d.mask, d.mask_cstride, d.mask_coff = mask.t.data_ptr(), mask.cstride, mask.coff
+    d.act, d.act_slope = ACT_NONE, slope
+    d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
+    fl = 2.0 * dgb.N * dgb.H * dgb.W * 2 * C_ * hid * 9
+    nb = ops.act_bytes(dgb) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0)
+    with ops._Timed("conv", name, fl, nb):
+        _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[dgrad]")

@@ -580,6 +580,41 @@ int hrv_mul_f32(const float* x, const float* m, int64_t n, float* out, hrv_strea
 int hrv_tv_loss_f32(const float* flow, int32_t N, int32_t H, int32_t W, float* grad, float* workspace, float* loss_out,
                     hrv_stream_t stream);
 
+/* SPADENorm's conv_gamma || conv_beta (network_generator.py:117-121: two 3x3 convolutions 128 -> C over
+ * actv = ReLU(conv_shared(seg))) fused with `normalized * (1 + gamma) + beta` (+ LeakyReLU, :170-171), and the data
+ * gradient of that pair, d(actv) = conv^T([dgamma | dbeta]) * relu'(actv), on a dedicated kernel (csrc/spade_gb.hip):
+ * one persistent 8-wave block per CU owns a 16x16-pixel tile and ALL of the layer's columns (no padded columns, the
+ * halo patch loaded once), weights streamed in MFMA-fragment order through a 3-stage LDS ring.
+ *   mode 0 (forward):  src = actv, bf16 NHWC [.,hid]; columns = (gamma | beta) of the C norm channels;
+ *                      out = act((x + z*noise_scale - mean) * rstd * (1 + gamma + bias_gamma) + beta + bias_beta);
+ *                      g1p (optional) receives (1 + gamma), dense [pixels][stat_stride], fp32 or bf16.
+ *   mode 1 (data gradient): src = [dgamma (Cp) | dbeta (Cp)], bf16 NHWC; out[.., hid] = conv^T * (mask > 0 ? 1 :
+ *                      act_slope), mask = actv (bf16) or NULL.
+ * Shapes served: hid == 128, C % 32 in {0, 16} with an even number of 32-channel pairs (80, 144, 272, 528; 64, 128, ...),
+ * at least 256 tiles (hrv_spade_gb_supported); everything else keeps hrv_conv2d_nhwc_bf16's tiles. */
+typedef struct hrv_spade_gb {
+  int32_t mode, N, H, W;
+  const void* src; int32_t src_cstride, src_coff;
+  const void* w_packed;        /* hrv_spade_gb_pack_dev(mode, ...)                                   */
+  int32_t C, Cp, hid;          /* norm channels, their padded count (layout of [dgamma|dbeta]), 128  */
+  int32_t x_f32;               /* forward: x is fp32 (else bf16)                                     */
+  const void* x; int32_t x_cstride, x_coff;
+  int32_t stat_stride;         /* floats per image in mean / rstd, channels per pixel in g1p        */
+  int32_t g1p_bf16;
+  const float* mean; const float* rstd; const float* noise_z; const float* noise_scale;
+  const float* bias_gamma; const float* bias_beta;
+  void* g1p;
+  int32_t act; float act_slope;
+  void* out; int32_t out_cstride, out_coff, out_f32, _pad;
+  const void* mask; int32_t mask_cstride, mask_coff;
+} hrv_spade_gb_t;
+int64_t hrv_spade_gb_packed_bytes(int32_t mode, int32_t C, int32_t Cp, int32_t hid);   /* -1: shape not served */
+int hrv_spade_gb_supported(int32_t mode, int32_t C, int32_t Cp, int32_t hid, int32_t N, int32_t H, int32_t W);
+/* fp32 conv_gamma.weight / conv_beta.weight [C][hid][3][3] (device) -> the bf16 fragment-order stream of `mode` */
+int hrv_spade_gb_pack_dev(int32_t mode, const float* w_gamma, const float* w_beta, int32_t C, int32_t Cp, int32_t hid,
+                          void* out, hrv_stream_t stream);
+int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
