@@ -213,7 +213,7 @@ __device__ __forceinline__ void gb_pass(const GbParams& p, const int pass, unsig
     const int kc = p.C - 128 * chunk;
 #pragma unroll 1
     for (int u = wave; u < 90; u += 8) {
-      const int hy = (u * 13) >> 6, i4 = (u - 5 * hy) << 2;          // u / 5, 4 * (u % 5)   (u < 90)
+      const int hy = (u * 205) >> 10, i4 = (u - 5 * hy) << 2;        // u / 5, 4 * (u % 5)   (u < 90)
       const int y = pt_y0 - 1 + hy, x = pt_x0 - 1 + i4 + dma_dx;
       const int g = dma_s ^ (i4 & 15);
       const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && g * 8 < kc;
