@@ -3,12 +3,17 @@
 // d(actv) = conv^T([dgamma | dbeta]) * relu'(actv) -- the two largest convolution families of one train_generator.py
 // iteration.  One persistent block per CU:
 //
-//   * 512 threads = 8 waves (two per SIMD).  A block owns a 16x16-pixel tile and ALL the layer's columns: the 18x18
+//   * 256 threads = 4 waves, one per SIMD (up to 512 registers each).  A block owns a 16x16-pixel tile and ALL the layer's columns: the 18x18
 //     halo patch of the source (128 bf16 channels per chunk, 90 KB) is DMA'd into LDS once per tile, and the columns
 //     run in passes of 4 or 5 column tiles of 32 (160 = 5 x 32 for the 80-channel norms, 288 = 4 + 5 for the 144-channel
 //     ones: no padded columns -- the generic patch tiles issue 160 columns as 128 + 64 and load the patch twice).
-//   * wave w multiplies tile rows 2w, 2w+1 (32 pixels) by every column of the pass: NTP accumulator tiles of 32x32.
-//     A fragments come from the patch (tap = pixel offset), B fragments from a 3-stage weight ring.
+//   * wave w multiplies tile rows 4w .. 4w+3 (64 pixels) by every column of the pass: 2 x NTP accumulator tiles of 32x32
+//     (per 16-k step 2 A + NTP B fragment reads feed 2 NTP MFMAs: the LDS is ~35 % busy at the full MFMA rate; with
+//     eight waves of 32 pixels it was ~60 % and the measured main loop ran at 41 % of the MFMA rate).
+//     A fragments come from the patch (tap = pixel offset), B fragments from a 3-stage weight ring.  Reads run one k-step
+//     ahead of the MFMAs across K-tile boundaries: the barrier that publishes the next weight tile sits in front of the
+//     last k-step's MFMAs.  The next tile's patch and first weight tiles are requested when the main loop ends and fly
+//     under the epilogue.
 //   * weights are packed (hrv_spade_gb_pack_dev) in FRAGMENT order: [pass][K-tile][column tile][k-step][lane][8 bf16],
 //     so a stage is one linear DMA copy and a B fragment read is lane-linear (conflict-free, immediate offsets).  A stage
 //     holds 64 k-values x (NTP x 32) columns (16 / 20 KB) and feeds 256 pixels: half the L2 -> LDS weight bytes per FLOP
@@ -24,10 +29,33 @@
 #include <string.h>
 
 #include <type_traits>
+#include <utility>
 
 #include "conv_params.h"
 
 namespace hrv {
+
+// compile-time loop (the scheduling hints take literal arguments)
+#if defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void gb_store16(f32x4 v, rsrc_t r, unsigned voff) {
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)voff, 0, 0);
+}
+#else
+__device__ inline void gb_store16(f32x4, rsrc_t, unsigned) {}
+#endif
+
+// registers 4g .. 4g+3 of an accumulator tile (4 consecutive output channels of the lane's pixel)
+__device__ __forceinline__ f32x4 gb_acc4(const f32x16& a, int g) {
+  f32x4 r;
+  r[0] = a[4 * g]; r[1] = a[4 * g + 1]; r[2] = a[4 * g + 2]; r[3] = a[4 * g + 3];
+  return r;
+}
+
+template <typename F, int... Is>
+__device__ __forceinline__ void gb_static_for(std::integer_sequence<int, Is...>, F&& f) {
+  (f(std::integral_constant<int, Is>{}), ...);
+}
 
 constexpr int GB_MAXP = 16;
 constexpr int GB_PW = 20;                      // patch row pitch in pixels (18 + 2: a row is five 4-pixel DMA pieces)
@@ -56,6 +84,7 @@ struct GbParams {
   // data-gradient epilogue
   const void* mask; int mask_cs, mask_co;
   unsigned long long* tlog;
+  int stagger_ticks;        // 100 MHz ticks between the phase groups' starts (0: none)
 };
 
 struct GbPlan {
@@ -174,358 +203,509 @@ __global__ __launch_bounds__(256) void gb_pack_kernel(const GbPackParams p) {
 // s_waitcnt immediates (gfx9 encoding: vmcnt[3:0] bits 3:0, expcnt bits 6:4, lgkmcnt bits 11:8, vmcnt[5:4] bits 15:14)
 constexpr int gb_wait(int vm) { return (vm & 15) | (7 << 4) | (0 << 8) | ((vm >> 4) << 14); }   // vmcnt(vm) lgkmcnt(0)
 
-template <int NTP, int EPI>
-__device__ __forceinline__ void gb_pass(const GbParams& p, const int pass, unsigned char* const smem, const int pt_n,
-                                        const int pt_y0, const int pt_x0, const int bid, const bool load_patch0,
-                                        const bool first, const bool last) {
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int l31 = lane & 31, lh = lane >> 5;
-  constexpr int NP = NTP * 4;               // 1-KB pieces (column tile, k-step) per weight stage
-  constexpr int NB = (NP + 7) / 8;          // DMA instructions per wave per stage
-  constexpr int SB = NP * 1024;
-  constexpr int NPAIR = NTP / 2, TAIL = NTP & 1;
-  static_assert(NPAIR * 32 + TAIL * 16 <= GB_CV, "constant vectors");
-  unsigned char* const patch = smem;
-  unsigned char* const bst = smem + GB_PATCH_B;
-  float* const cbuf = reinterpret_cast<float*>(smem + GB_CB_OFF);
-  const rsrc_t a_rsrc = make_rsrc(p.src, p.src_bytes);
-  const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
-  const unsigned wbase = p.woff[pass];
-  const int KT = p.KT;
-  const int tile0 = p.tile0[pass];
-
-  auto b_dma = [&](int q, int st) {
+// Everything one (tile, pass) needs before its main loop: the halo patch (chunk 0) and weight tiles 0, 1 of the pass.
+// Issued by the PREVIOUS pass's epilogue (after the barrier that frees the patch and ring stages 0 / 1), so the loads fly
+// while that epilogue computes and stores.
+template <int NTP>
+struct GbIssue {
+  static constexpr int NP = NTP * 4;        // 1-KB pieces (column tile, k-step) per weight stage
+  static constexpr int NB = NP / 4;         // DMA instructions per wave per stage (4 waves)
+  static constexpr int SB = NP * 1024;
+  static __device__ __forceinline__ void b_dma(const GbParams& p, unsigned char* smem, unsigned wbase, int q, int st, int wave, int lane) {
+    const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
     const unsigned soff0 = wbase + (unsigned)q * (unsigned)SB;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
-      int idx = wave + 8 * i;                // wave-uniform; a wrapped index re-writes identical bytes (benign)
-      if (idx >= NP) idx -= NP;
-      dma16(w_rsrc, reinterpret_cast<float*>(bst + st * GB_SBMAX + idx * 1024), (unsigned)lane * 16u, soff0 + (unsigned)idx * 1024u);
+      const int idx = wave + 4 * i;          // wave-uniform
+      dma16(w_rsrc, reinterpret_cast<float*>(smem + GB_PATCH_B + st * GB_SBMAX + idx * 1024), (unsigned)lane * 16u,
+            soff0 + (unsigned)idx * 1024u);
     }
-  };
+  }
   // one instruction = 4 consecutive halo pixels of one patch row x 16 groups of 8 channels (90 instructions per patch,
-  // instruction u = 5 * row + piece, dealt round-robin to the 8 waves); the 16-byte groups of a pixel are XOR-swizzled
-  // by (hx & 15) on the SOURCE side: tap-shifted b128 fragment reads of 16 adjacent pixels are bank-disjoint.  Per
+  // instruction u = 5 * row + piece, dealt round-robin to the waves); the 16-byte groups of a pixel are XOR-swizzled by
+  // (hx & 15) on the SOURCE side: tap-shifted b128 fragment reads of 16 adjacent pixels are bank-disjoint.  Per
   // instruction the lane offset is (lane constant) + (scalar): no division, nothing worth hoisting.
-  const int dma_dx = lane >> 4, dma_s = (lane & 15) ^ (lane >> 4);
-  auto patch_dma = [&](int chunk) {
+  static __device__ __forceinline__ void patch_dma(const GbParams& p, unsigned char* smem, int pt_n, int pt_y0, int pt_x0, int chunk,
+                                                   int wave, int lane) {
+    const rsrc_t a_rsrc = make_rsrc(p.src, p.src_bytes);
+    const int dma_dx = lane >> 4, dma_s = (lane & 15) ^ (lane >> 4);
     const int kc = p.C - 128 * chunk;
 #pragma unroll 1
-    for (int u = wave; u < 90; u += 8) {
+    for (int u = wave; u < 90; u += 4) {
       const int hy = (u * 205) >> 10, i4 = (u - 5 * hy) << 2;        // u / 5, 4 * (u % 5)   (u < 90)
       const int y = pt_y0 - 1 + hy, x = pt_x0 - 1 + i4 + dma_dx;
       const int g = dma_s ^ (i4 & 15);
       const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && g * 8 < kc;
       const unsigned off = ((unsigned)((pt_n * p.H + y) * p.W + x) * (unsigned)p.src_cs + (unsigned)(p.src_co + chunk * 128 + g * 8)) * 2u;
-      dma16(a_rsrc, reinterpret_cast<float*>(patch + u * 1024), ok ? off : 0xFFFFFFF0u, 0u);
+      dma16(a_rsrc, reinterpret_cast<float*>(smem + u * 1024), ok ? off : 0xFFFFFFF0u, 0u);
     }
-  };
+  }
+  // piece i (0..NB-1) of this wave's share of weight tile q -> ring stage st
+  static __device__ __forceinline__ void b_dma1(const GbParams& p, unsigned char* smem, unsigned wbase, int q, int st, int wave, int lane,
+                                                int i) {
+    const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
+    const int idx = wave + 4 * i;
+    dma16(w_rsrc, reinterpret_cast<float*>(smem + GB_PATCH_B + st * GB_SBMAX + idx * 1024), (unsigned)lane * 16u,
+          wbase + (unsigned)q * (unsigned)SB + (unsigned)idx * 1024u);
+  }
+  static __device__ __forceinline__ void issue(const GbParams& p, unsigned char* smem, int pass, bool with_patch, int pt_n, int pt_y0,
+                                               int pt_x0, int wave, int lane) {
+    if (with_patch) patch_dma(p, smem, pt_n, pt_y0, pt_x0, 0, wave, lane);
+    const unsigned wbase = p.woff[pass];
+    b_dma(p, smem, wbase, 0, 0, wave, lane);
+    if (p.KT > 1) b_dma(p, smem, wbase, 1, 1, wave, lane);
+  }
+};
 
-  // ---- this lane's pixel and fragment addresses
-  const int ty = 2 * wave + (l31 >> 4), tx = l31 & 15;
-  const int py = pt_y0 + ty, px = pt_x0 + tx;
-  const bool pix_ok = py < p.H && px < p.W;
-  const int pidx = pix_ok ? (pt_n * p.H + py) * p.W + px : 0;
+struct GbTile { int n, y0, x0; };
+__device__ __forceinline__ GbTile gb_tile(const GbParams& p, int bid) {
+  const int tx = (p.W + 15) >> 4, ty = (p.H + 15) >> 4;
+  const int mt = xcd_remap(bid, p.m_tiles);
+  GbTile t;
+  t.n = mt / (tx * ty);
+  const int rr = mt - t.n * (tx * ty);
+  t.y0 = (rr / tx) << 4;
+  t.x0 = (rr % tx) << 4;
+  return t;
+}
+
+// One (tile, pass).  On entry its patch / weight tiles 0, 1 are in flight or landed (GbIssue::issue); ``nxt_*`` describe
+// what to issue for the next (tile, pass) of this block once the main loop is done (nxt_pass < 0: nothing).
+template <int NTP, int EPI, bool HALF>
+__device__ __forceinline__ void gb_pass(const GbParams& p, const int pass, unsigned char* const smem, const GbTile T,
+                                        const int bid, const bool first, const bool last, const int nxt_pass, const bool nxt_patch,
+                                        const GbTile NT_) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lh = lane >> 5;
+  using IS = GbIssue<NTP>;
+  constexpr int NB = IS::NB;
+  constexpr int NPAIR = NTP / 2, TAIL = NTP & 1;
+  static_assert(NPAIR * 32 + TAIL * 16 <= GB_CV, "constant vectors");
+  unsigned char* const patch = smem;
+  unsigned char* const bst = smem + GB_PATCH_B;
+  float* const cbuf = reinterpret_cast<float*>(smem + GB_CB_OFF);
+  const int KT = p.KT;
+  const int tile0 = p.tile0[pass];
+  const unsigned wbase = p.woff[pass];
+  const int pt_n = T.n, pt_y0 = T.y0, pt_x0 = T.x0;
+
+  // ---- this lane's pixels (two: tile rows 4 w + (l31 >> 4) and + 2) and fragment addresses
+  const int ty = 4 * wave + (l31 >> 4), tx = l31 & 15;
+  const int px = pt_x0 + tx;
+  int pidx[2];
+  bool pix_ok[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int py = pt_y0 + ty + 2 * i;
+    pix_ok[i] = py < p.H && px < p.W;
+    pidx[i] = pix_ok[i] ? (pt_n * p.H + py) * p.W + px : 0;
+  }
   const unsigned char* const a_lb = patch + (ty * GB_PW + tx) * 256;
   const unsigned char* const b_lb = bst + lane * 16;
 
-  f32x16 acc[NTP];
+  f32x16 acc[2][NTP];
 #pragma unroll
-  for (int j = 0; j < NTP; ++j)
+  for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+    for (int j = 0; j < NTP; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  // ---- prologue: (patch chunk 0,) weight tiles 0 and 1, the pass's per-channel constants
-  if (load_patch0) patch_dma(0);
-  b_dma(0, 0);
-  if (KT > 1) b_dma(1, 1);
+  // ---- the pass's per-channel constants -> LDS (read by the epilogue only)
   const int cb0 = (tile0 >> 1) * 32;          // first norm channel of this pass (forward)
   if constexpr (EPI == 1) {
-    // bias gamma | bias beta | noise scale | mean | rstd of the pass's channels -> LDS (read by the epilogue only).
-    // Scalar loads: the bias / noise-scale parameters are views into the fused optimizer's flat buffer (4-byte aligned)
-    if (tid < 5 * GB_CV) {
-      const int v = tid / GB_CV, c = cb0 + (tid - v * GB_CV);
-      float val = 0.f;
+    // bias gamma | bias beta | noise scale | mean | rstd.  Scalar loads: the bias / noise-scale parameters are views into
+    // the fused optimizer's flat buffer (4-byte aligned)
+    // per channel: 1 + bias_gamma | bias_beta | rstd | noise_scale * rstd | -mean * rstd, so that
+    //   IN(x + z ns) = x * rstd + (z * (ns rstd) - mean rstd)
+    for (int t = tid; t < GB_CV; t += 256) {
+      const int c = cb0 + t;
+      float b1 = 1.f, b2 = 0.f, rs = 0.f, nr = 0.f, mr = 0.f;
       if (c < p.sC) {
-        if (v == 0) val = p.bg[c];
-        else if (v == 1) val = p.bb[c];
-        else if (v == 2) val = p.sns ? p.sns[c] : 0.f;
-        else if (v == 3) val = p.smean[(size_t)pt_n * p.sC + c];
-        else val = p.srstd[(size_t)pt_n * p.sC + c];
+        b1 = 1.f + p.bg[c];
+        b2 = p.bb[c];
+        rs = p.srstd[(size_t)pt_n * p.sC + c];
+        nr = p.sns ? p.sns[c] * rs : 0.f;
+        mr = -p.smean[(size_t)pt_n * p.sC + c] * rs;
       }
-      cbuf[tid] = val;
+      cbuf[t] = b1; cbuf[GB_CV + t] = b2; cbuf[2 * GB_CV + t] = rs; cbuf[3 * GB_CV + t] = nr; cbuf[4 * GB_CV + t] = mr;
     }
   }
-  if (KT > 1) __builtin_amdgcn_s_waitcnt(gb_wait(NB));
-  else __builtin_amdgcn_s_waitcnt(gb_wait(0));
+  // the patch and weight tiles 0, 1 (issued before this call) have landed
+  __builtin_amdgcn_s_waitcnt(gb_wait(0));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (p.tlog && tid == 0 && first) p.tlog[(size_t)bid * 8 + 1] = wall_clock64();
 
-  // epilogue operands requested inside the main loop
-  [[maybe_unused]] f32x4 xv[NPAIR][4];
-  [[maybe_unused]] f32x4 xt[2];
-  [[maybe_unused]] float zv = 0.f;
-  [[maybe_unused]] u16x4 mv[NTP][4];
-  auto prefetch_epi = [&]() {
-    if constexpr (EPI == 1) {
+  // epilogue operands: requested now (the oldest requests of the pass: the counted vmcnt waits of the weight stream
+  // never wait for them longer than the prologue did), used after the main loop
+  [[maybe_unused]] f32x4 xv[2][NPAIR][4];
+  [[maybe_unused]] f32x4 xt[2][2];
+  [[maybe_unused]] float zv[2] = {0.f, 0.f};
+  [[maybe_unused]] u16x4 mv[2][NTP][4];
+  if constexpr (EPI == 1) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
 #pragma unroll
       for (int pr = 0; pr < NPAIR; ++pr)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          xv[pr][g] = ld4rt<true>(p.sx, (size_t)pidx * p.sx_cs + p.sx_co + cb0 + pr * 32 + 8 * g + 4 * lh, p.sx_f32);
+          xv[i][pr][g] = ld4rt<true>(p.sx, (size_t)pidx[i] * p.sx_cs + p.sx_co + cb0 + pr * 32 + 8 * g + 4 * lh, p.sx_f32);
       if constexpr (TAIL != 0) {
 #pragma unroll
         for (int g = 0; g < 2; ++g)
-          xt[g] = ld4rt<true>(p.sx, (size_t)pidx * p.sx_cs + p.sx_co + cb0 + NPAIR * 32 + 8 * g + 4 * lh, p.sx_f32);
+          xt[i][g] = ld4rt<true>(p.sx, (size_t)pidx[i] * p.sx_cs + p.sx_co + cb0 + NPAIR * 32 + 8 * g + 4 * lh, p.sx_f32);
       }
-      if (p.sz) zv = p.sz[((size_t)pt_n * p.W + (pix_ok ? px : 0)) * p.H + (pix_ok ? py : 0)];
-    } else {
-      if (p.mask) {
+      if (p.sz) {
+        const int py = pt_y0 + ty + 2 * i;
+        zv[i] = p.sz[((size_t)pt_n * p.W + (pix_ok[i] ? px : 0)) * p.H + (pix_ok[i] ? py : 0)];
+      }
+    }
+  } else {
+    if (p.mask) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int j = 0; j < NTP; ++j)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            mv[j][g] = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.mask) +
-                                                       (size_t)pidx * p.mask_cs + p.mask_co + (tile0 + j) * 32 + 8 * g + 4 * lh);
-      }
+            mv[i][j][g] = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.mask) +
+                                                          (size_t)pidx[i] * p.mask_cs + p.mask_co + (tile0 + j) * 32 + 8 * g + 4 * lh);
     }
-  };
+  }
 
-  // ---- main loop over the K-tiles (chunk, tap, 64-k half)
+  // ---- main loop over the K-tiles (chunk, tap, 64-k half).  Fragment reads run one k-step ahead of the MFMAs, ACROSS
+  // K-tiles: the wait + barrier that publishes weight tile q+1 sits in front of the LAST k-step's MFMAs of tile q (all
+  // of this wave's reads of tile q are complete there), so tile q+1's first fragments are read under those MFMAs.
   int it_chunk = 0, it_tap = 0, it_half = 0;
   int kc = p.C < 128 ? p.C : 128;             // channels of the current chunk
   int nhalf = (kc + 63) >> 6;
   int rb = 0, wb = 2;
-  prefetch_epi();
-  // K-tile q with NKS k-steps of 16 (4: a full 64-k half; 2: the 32-channel last chunk of a data-gradient source)
-  auto ktile = [&](const int q, auto nks_c) {
-    constexpr int NKS = decltype(nks_c)::value;
-    const bool more = q + 2 < KT;
-    if (more) b_dma(q + 2, wb);               // that stage was read in K-tile q-1: every wave has passed the barrier
-    {
-      const int kh = (it_tap * 11) >> 5, kw = it_tap - 3 * kh;
-      const unsigned char* const Ap = a_lb + (kh * GB_PW + kw) * 256;
-      const unsigned ax = (unsigned)(((((tx + kw) & 15) ^ lh) << 4) ^ (it_half << 7));
-      const unsigned char* const Bp = b_lb + rb * GB_SBMAX;
-      f32x4 fa[2], fb[2][NTP];
+  f32x4 fa[2][2], fb[2][NTP];
+  // fragment source of the K-tile the iterator points at
+  const unsigned char* Ap;
+  unsigned ax;
+  const unsigned char* Bp;
+  auto point = [&]() {
+    const int kh = (it_tap * 11) >> 5, kw = it_tap - 3 * kh;
+    Ap = a_lb + (kh * GB_PW + kw) * 256;
+    ax = (unsigned)(((((tx + kw) & 15) ^ lh) << 4) ^ (it_half << 7));
+    Bp = b_lb + rb * GB_SBMAX;
+  };
 #define GB_READ(SET, S)                                                                                    \
-      {                                                                                                    \
-        fa[SET] = *reinterpret_cast<const f32x4*>(Ap + (ax ^ (unsigned)((S) << 5)));                       \
-        _Pragma("unroll") for (int j = 0; j < NTP; ++j)                                                    \
-            fb[SET][j] = *reinterpret_cast<const f32x4*>(Bp + (j * 4 + (S)) * 1024);                        \
-      }
+  {                                                                                                        \
+    fa[SET][0] = *reinterpret_cast<const f32x4*>(Ap + (ax ^ (unsigned)((S) << 5)));                        \
+    fa[SET][1] = *reinterpret_cast<const f32x4*>(Ap + 2 * GB_PW * 256 + (ax ^ (unsigned)((S) << 5)));      \
+    _Pragma("unroll") for (int j = 0; j < NTP; ++j)                                                        \
+        fb[SET][j] = *reinterpret_cast<const f32x4*>(Bp + (j * 4 + (S)) * 1024);                            \
+  }
 #define GB_MMA(SET)                                                                                        \
-      {                                                                                                    \
-        _Pragma("unroll") for (int j = 0; j < NTP; ++j)                                                    \
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[SET][j]),      \
-                                                             __builtin_bit_cast(bf16x8, fa[SET]), acc[j], 0, 0, 0); \
+  {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < NTP; ++j) {                                                      \
+      acc[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[SET][j]),         \
+                                                          __builtin_bit_cast(bf16x8, fa[SET][0]), acc[0][j], 0, 0, 0); \
+      acc[1][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fb[SET][j]),         \
+                                                          __builtin_bit_cast(bf16x8, fa[SET][1]), acc[1][j], 0, 0, 0); \
+    }                                                                                                      \
+  }
+  // issue order of one k-step: the NTP + 2 fragment reads of the next step spread between this step's 2 NTP MFMAs
+  // (left alone, the scheduler sinks every read next to its MFMA and waits lgkmcnt(0) per MFMA)
+#define GB_ORDER(NDMA)                                                                                     \
+  {                                                                                                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                                                     \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                     \
+    _Pragma("unroll") for (int j = 0; j < NTP; ++j) {                                                      \
+      __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < (NDMA); ++j) {                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                                                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                                                   \
+    }                                                                                                      \
+    __builtin_amdgcn_sched_group_barrier(0x008, NTP - 1 - (NDMA), 0);                                      \
+  }
+  point();
+  GB_READ(0, 0)
+  // K-tile q with NKS k-steps of 16 (4: a full 64-k half; 2: the 32-channel last chunk of a data-gradient source);
+  // NEXT: a K-tile follows.  (The MFMA sequences appear once per instantiation, in straight-line code: accumulators that
+  // flow through diverging branches made the register allocator shuffle them between the two register files.)
+  auto ktile = [&](const int q, auto nks_c, auto next_c, auto more_c) {
+    constexpr int NKS = decltype(nks_c)::value;
+    constexpr bool NEXT = decltype(next_c)::value;       // K-tile q+1 exists
+    constexpr bool more = decltype(more_c)::value;       // K-tile q+2 exists (compile time: no branch splits the k-step's schedule)
+    // weight tile q+2 -> the stage K-tile q-1 read (every wave has passed that barrier).  Its NB DMA instructions are
+    // dealt over the first k-steps, each behind a few MFMAs: issued back to back at the top of the K-tile they held this
+    // wave's (in-order) instruction stream for ~100 cycles apiece with the matrix pipe drained -- one wave per SIMD has
+    // nobody to cover that.
+    gb_static_for(std::make_integer_sequence<int, NKS - 1>{}, [&](auto s_c) {
+      constexpr int s = decltype(s_c)::value;
+      constexpr int NS = NKS - 1;                       // k-steps that carry DMA pieces
+      constexpr int d0 = (NB * s) / NS, d1 = (NB * (s + 1)) / NS;
+      GB_READ((s + 1) & 1, s + 1)
+      if constexpr (more) {
+#pragma unroll
+        for (int i = d0; i < d1; ++i) IS::b_dma1(p, smem, wbase, q + 2, wb, wave, lane, i);
       }
-      GB_READ(0, 0)
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        if (s + 1 < NKS) GB_READ((s + 1) & 1, s + 1)
-        GB_MMA(s & 1)
-      }
-      // issue order (the scheduler otherwise sinks every fragment read next to its MFMA and waits lgkmcnt(0) per MFMA):
-      // the first k-step's reads, then per k-step the next step's NTP + 1 reads spread between this step's NTP MFMAs
-      __builtin_amdgcn_sched_group_barrier(0x100, NTP + 1, 0);
-#pragma unroll
-      for (int s = 0; s < NKS; ++s) {
-        if (s + 1 < NKS) {
-          __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-#pragma unroll
-          for (int j = 1; j < NTP; ++j) {
-            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-          }
-        } else {
-          __builtin_amdgcn_sched_group_barrier(0x008, NTP, 0);
+      GB_MMA(s & 1)
+      GB_ORDER(more ? d1 - d0 : 0)
+    });
+    if constexpr (NEXT) {
+      // last k-step: advance to K-tile q+1, publish its weights, read its first fragments under this step's MFMAs
+      [[maybe_unused]] bool new_chunk = false;
+      if (++it_half == nhalf) {
+        it_half = 0;
+        if (++it_tap == 9) {
+          it_tap = 0;
+          ++it_chunk;
+          new_chunk = true;
         }
       }
-#undef GB_READ
-#undef GB_MMA
-    }
-    // advance the K-tile iterator
-    bool new_chunk = false;
-    if (++it_half == nhalf) {
-      it_half = 0;
-      if (++it_tap == 9) {
-        it_tap = 0;
-        ++it_chunk;
-        new_chunk = true;
-      }
-    }
-    if (q + 1 < KT) {
+      rb = rb == 2 ? 0 : rb + 1;
+      wb = wb == 2 ? 0 : wb + 1;
       asm volatile("" ::: "memory");
-      if (new_chunk) {
-        // next 128-channel chunk of the source: every wave is done with the patch; the in-flight weight tiles stay
-        __builtin_amdgcn_s_waitcnt(gb_wait(0));
-        __builtin_amdgcn_s_barrier();
-        kc = p.C - 128 * it_chunk;
-        kc = kc < 128 ? kc : 128;
-        nhalf = (kc + 63) >> 6;
-        patch_dma(it_chunk);
-        __builtin_amdgcn_s_waitcnt(gb_wait(0));
-      } else {
-        if (more) __builtin_amdgcn_s_waitcnt(gb_wait(NB));
-        else __builtin_amdgcn_s_waitcnt(gb_wait(0));
-      }
+      if (more) __builtin_amdgcn_s_waitcnt(gb_wait(NB));
+      else __builtin_amdgcn_s_waitcnt(gb_wait(0));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      if constexpr (EPI == 2) {
+        // next 128-channel chunk of the source: every wave's reads of the patch are complete (lgkmcnt(0) above); its DMA
+        // flies under this step's MFMAs
+        if (new_chunk) {
+          kc = p.C - 128 * it_chunk;
+          kc = kc < 128 ? kc : 128;
+          nhalf = (kc + 63) >> 6;
+          IS::patch_dma(p, smem, pt_n, pt_y0, pt_x0, it_chunk, wave, lane);
+        } else {
+          point();
+          GB_READ(0, 0)
+        }
+        GB_MMA((NKS - 1) & 1)
+        if (new_chunk) {
+          asm volatile("" ::: "memory");
+          __builtin_amdgcn_s_waitcnt(gb_wait(0));
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          point();
+          GB_READ(0, 0)
+        }
+      } else {
+        point();
+        GB_READ(0, 0)
+        GB_MMA((NKS - 1) & 1)
+        GB_ORDER(0)
+      }
+    } else {
+      GB_MMA((NKS - 1) & 1)
     }
-    rb = rb == 2 ? 0 : rb + 1;
-    wb = wb == 2 ? 0 : wb + 1;
   };
-  // full 64-k K-tiles first; a 32-channel last chunk (data gradient: 2 Cp = 160, 288, ...) ends with 9 two-step tiles
-  const int KT4 = (p.C & 127) == 32 ? KT - 9 : KT;
+  using C4 = std::integral_constant<int, 4>;
+  using C2 = std::integral_constant<int, 2>;
+  using Y = std::true_type;
+  using N = std::false_type;
+  if constexpr (!HALF) {
 #pragma unroll 1
-  for (int q = 0; q < KT4; ++q) ktile(q, std::integral_constant<int, 4>{});
-  if constexpr (EPI == 2) {
+    for (int q = 0; q < KT - 2; ++q) ktile(q, C4{}, Y{}, Y{});
+    ktile(KT - 2, C4{}, Y{}, N{});
+    ktile(KT - 1, C4{}, N{}, N{});
+  } else {
+    // a 32-channel last chunk (data gradient: 2 Cp = 160, 288, ...): the last 9 K-tiles are two-step tiles
 #pragma unroll 1
-    for (int q = KT4; q < KT; ++q) ktile(q, std::integral_constant<int, 2>{});
+    for (int q = 0; q < KT - 9; ++q) ktile(q, C4{}, Y{}, Y{});
+#pragma unroll 1
+    for (int q = KT - 9; q < KT - 2; ++q) ktile(q, C2{}, Y{}, Y{});
+    ktile(KT - 2, C2{}, Y{}, N{});
+    ktile(KT - 1, C2{}, N{}, N{});
   }
+#undef GB_READ
+#undef GB_MMA
+#undef GB_ORDER
   if (p.tlog && tid == 0 && last) p.tlog[(size_t)bid * 8 + 2] = wall_clock64();
 
   // ---- epilogue.  D layout (swapped operands): lane -> pixel l31; regs 4g..4g+3 -> channels 8g + 4 lh + (0..3) of the tile
   __syncthreads();                             // every wave is done with the patch and the weight ring
+  // the next (tile, pass) of this block: its patch and first two weight tiles fly while this epilogue computes and stores
+  if (nxt_pass >= 0) IS::issue(p, smem, nxt_pass, nxt_patch, NT_.n, NT_.y0, NT_.x0, wave, lane);
   // (the epilogue's index arithmetic depends on the lane id only: hidden from the optimiser behind an empty asm, or it is
   //  hoisted out of the persistent tile loop and lives -- spilled -- through the main loop)
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
-  constexpr int SCS = 36;                       // scratch row stride in floats (32 channels + 4: conflict-free)
+  constexpr int SCS = 36;                      // scratch row stride in floats (32 channels + 4: conflict-free)
   const int l31e = lane_e & 31, lhe = lane_e >> 5;
-  // per-wave scratch, 32 pixels x 32 channels, inside the (now idle) weight ring: the patch survives for the next pass
-  float* const scr = reinterpret_cast<float*>(smem + GB_PATCH_B) + wave * (32 * SCS);
-  static_assert(8 * 32 * SCS * 4 <= 3 * GB_SBMAX, "epilogue scratch fits the weight ring");
-  auto row_pix = [&](int r) -> int {           // pixel index of row r (0..31) of this wave, or -1
-    const int y = pt_y0 + 2 * wave + (r >> 4), x = pt_x0 + (r & 15);
-    return (y < p.H && x < p.W) ? (pt_n * p.H + y) * p.W + x : -1;
+  // per-wave scratch, 32 pixels x 32 channels, in ring stage 2 (stages 0 / 1 are being refilled for the next pass)
+  float* const scr = reinterpret_cast<float*>(smem + GB_PATCH_B + 2 * GB_SBMAX) + wave * (32 * SCS);
+  static_assert(4 * 32 * SCS * 4 <= GB_SBMAX, "epilogue scratch fits one ring stage");
+  // Stores go through buffer resources of this tile's IMAGE (32-bit byte offsets; an out-of-image row gets an offset
+  // beyond num_records and the hardware drops the store: no branches, no 64-bit address arithmetic -- the first version
+  // of this epilogue was ~8000 instructions per wave and took as long as the main loop).
+  const int oes = p.out_f32 ? 4 : 2;
+  const size_t img_px = (size_t)p.H * p.W;
+  const rsrc_t o_rsrc = make_rsrc(reinterpret_cast<const char*>(p.out) + (size_t)pt_n * img_px * p.out_cs * oes,
+                                  (unsigned)(img_px * p.out_cs * oes));
+  // byte offset of channel 0 of row r (0..31) of this wave's half i in a tensor of `cs` channels of `es` bytes
+  auto row_off = [&](int i, int r, int cs, int es) -> unsigned {
+    const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
+    return (y < p.H && x < p.W) ? (unsigned)((y * p.W + x) * cs) * (unsigned)es : 0xFFFFFFF0u;
   };
-  if constexpr (EPI == 1) {
-    // NCH channels of the group starting at local channel lc0 / norm channel cb: modulate, stage, store along the channels
-    auto group = [&](const int lc0, const int NG, auto&& gam, auto&& bet, auto&& xin) {
-      f32x4 g1r[4];
+  // scratch rows (NG 16-byte groups of 8 channels per pixel, NG = 2 or 4) -> global, along the channels
+  auto copy_out = [&](const int i, auto ng_c, const rsrc_t rs, const int dcs, const int dco, const bool f32) {
+    constexpr int NG = decltype(ng_c)::value;
+    constexpr int SH = NG == 4 ? 2 : 1;        // log2(NG)
+    if (!f32) {
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        if (g >= NG) break;
-        const int lc = lc0 + 8 * g + 4 * lhe;
-        const f32x4 bgv = *reinterpret_cast<const f32x4*>(cbuf + lc);
-        const f32x4 bbv = *reinterpret_cast<const f32x4*>(cbuf + GB_CV + lc);
-        const f32x4 ns4 = *reinterpret_cast<const f32x4*>(cbuf + 2 * GB_CV + lc);
-        const f32x4 mu = *reinterpret_cast<const f32x4*>(cbuf + 3 * GB_CV + lc);
-        const f32x4 rs = *reinterpret_cast<const f32x4*>(cbuf + 4 * GB_CV + lc);
-        const f32x4 x4 = xin(g);
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const float x = x4[e] + zv * ns4[e];
-          g1r[g][e] = 1.f + gam(g, e) + bgv[e];
-          v[e] = apply_act((x - mu[e]) * rs[e] * g1r[g][e] + (bet(g, e) + bbv[e]), p.act, p.slope);
-        }
-        *reinterpret_cast<f32x4*>(scr + l31e * SCS + 8 * g + 4 * lhe) = v;
+      for (int k = 0; k < NG / 2; ++k) {       // bf16 rows: 32 pixels x NG pieces of 8 channels
+        const int t = lane_e + 64 * k, r = t >> SH, kk = t & (NG - 1);
+        const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 8);
+        const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 8 + 4);
+        const unsigned ro = row_off(i, r, dcs, 2);
+        gb_store16(pack_bf16x8(lo, hi), rs, ro == 0xFFFFFFF0u ? ro : ro + (unsigned)(dco + kk * 8) * 2u);
       }
-      const int cb = cb0 + lc0;                // first norm channel of the group; NG * 8 channels
-      // same wave wrote and reads: LDS operations of a wave complete in order.  ``which`` 0: the activation, 1: (1 + gamma)
-      auto copy_out = [&](const int which) {
-        void* const dst = which == 0 ? p.out : p.g1p;
-        const int dcs = which == 0 ? p.out_cs : p.sC, dco = which == 0 ? p.out_co : 0;
-        const bool f32 = which == 0 ? p.out_f32 != 0 : p.g1_bf16 == 0;
-        if (!f32) {
+    } else {
 #pragma unroll
-          for (int k = 0; k < 2; ++k) {        // bf16 rows: 32 pixels x NG pieces of 8 channels
-            const int t = lane_e + 64 * k;
-            if (t < 32 * NG) {
-              const int r = t / NG, kk = t - r * NG;
-              const int po = row_pix(r);
-              if (po >= 0) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 8);
-                const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 8 + 4);
-                *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(dst) + (size_t)po * dcs + dco + cb + kk * 8) = pack_bf16x8(lo, hi);
-              }
-            }
-          }
-        } else {
-#pragma unroll
-          for (int k = 0; k < 4; ++k) {        // fp32 rows: 32 pixels x 2 NG pieces of 4 channels
-            const int t = lane_e + 64 * k;
-            if (t < 64 * NG) {
-              const int r = t / (2 * NG), kk = t - r * (2 * NG);
-              const int po = row_pix(r);
-              if (po >= 0)
-                *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(dst) + (size_t)po * dcs + dco + cb + kk * 4) =
-                    *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 4);
-            }
-          }
-        }
-      };
-      copy_out(0);
-      if (p.g1p) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          if (g >= NG) break;
-          *reinterpret_cast<f32x4*>(scr + l31e * SCS + 8 * g + 4 * lhe) = g1r[g];
-        }
-        copy_out(1);
-      }
-    };
-#pragma unroll
-    for (int pr = 0; pr < NPAIR; ++pr)
-      group(pr * 32, 4, [&](int g, int e) { return acc[2 * pr][4 * g + e]; }, [&](int g, int e) { return acc[2 * pr + 1][4 * g + e]; },
-            [&](int g) { return xv[pr][g]; });
-    if constexpr (TAIL != 0)
-      group(NPAIR * 32, 2, [&](int g, int e) { return acc[NTP - 1][4 * g + e]; },
-            [&](int g, int e) { return acc[NTP - 1][4 * (g + 2) + e]; }, [&](int g) { return xt[g]; });
-  } else {
-#pragma unroll
-    for (int j = 0; j < NTP; ++j) {
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float a = acc[j][4 * g + e];
-          if (p.mask) a = bf2f(mv[j][g][e]) > 0.f ? a : a * p.slope;
-          v[e] = a;
-        }
-        *reinterpret_cast<f32x4*>(scr + l31e * SCS + 8 * g + 4 * lhe) = v;
-      }
-      const int cb = (tile0 + j) * 32;
-      if (p.out_f32) {
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int t = lane_e + 64 * k, r = t >> 3, kk = t & 7;
-          const int po = row_pix(r);
-          if (po >= 0)
-            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.out) + (size_t)po * p.out_cs + p.out_co + cb + kk * 4) =
-                *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 4);
-        }
-      } else {
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int t = lane_e + 64 * k, r = t >> 2, kk = t & 3;
-          const int po = row_pix(r);
-          if (po >= 0) {
-            const f32x4 lo = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 8);
-            const f32x4 hi = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 8 + 4);
-            *reinterpret_cast<f32x4*>(reinterpret_cast<unsigned short*>(p.out) + (size_t)po * p.out_cs + p.out_co + cb + kk * 8) =
-                pack_bf16x8(lo, hi);
-          }
-        }
+      for (int k = 0; k < NG; ++k) {           // fp32 rows: 32 pixels x 2 NG pieces of 4 channels
+        const int t = lane_e + 64 * k, r = t >> (SH + 1), kk = t & (2 * NG - 1);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(scr + r * SCS + kk * 4);
+        const unsigned ro = row_off(i, r, dcs, 4);
+        gb_store16(v, rs, ro == 0xFFFFFFF0u ? ro : ro + (unsigned)(dco + kk * 4) * 4u);
       }
     }
+  };
+  if constexpr (EPI == 1) {
+    // Both outputs are bf16 (the activation feeds matrix cores and its own LeakyReLU mask; (1 + gamma) is read once, by
+    // the normalisation backward).  The two 32-pixel halves of the wave go through the scratch TOGETHER (two buffers of
+    // 32 rows x 64 B + pad): a group's LDS write -> read -> store chain is exposed once per group, not once per half,
+    // and the per-channel constants are fetched once for both.
+    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+    unsigned char* const sb0 = smem + GB_PATCH_B + 2 * GB_SBMAX + wave * 5120;
+    static_assert(4 * 5120 <= GB_SBMAX, "epilogue scratch fits one ring stage");
+    constexpr int RS = 80;                     // scratch row stride in bytes (32 bf16 channels + 16)
+    const rsrc_t g_rsrc = make_rsrc(reinterpret_cast<const char*>(p.g1p) + (size_t)pt_n * img_px * p.sC * 2,
+                                    p.g1p ? (unsigned)(img_px * p.sC * 2) : 0u);
+    // act(v) = max(v, v * sl): LeakyReLU (sl = slope), ReLU (0), none (1) -- the SPADE sites use LeakyReLU / none
+    const float sl = p.act == HRV_ACT_LRELU ? p.slope : (p.act == HRV_ACT_RELU ? 0.f : 1.f);
+    // pixel (in-image index, or -1) of the scratch rows this lane stores: 4-group rows (lane >> 2) + 16 k, 2-group rows lane >> 1
+    int pp4[2][2], pp2[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        const int r = (lane_e >> 2) + 16 * k;
+        const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
+        pp4[i][k] = (y < p.H && x < p.W) ? y * p.W + x : -1;
+      }
+      const int r = lane_e >> 1;
+      const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
+      pp2[i] = (y < p.H && x < p.W) ? y * p.W + x : -1;
+    }
+    // scratch rows of both halves -> global: 16 bytes (8 channels) per lane, along the channels
+    auto rows_out = [&](auto ng_c, const rsrc_t rs, const int dcs, const int dco) {
+      constexpr int NG = decltype(ng_c)::value;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const unsigned char* sb = sb0 + i * 2560;
+        if constexpr (NG == 4) {
+#pragma unroll
+          for (int k = 0; k < 2; ++k) {
+            const int r = (lane_e >> 2) + 16 * k, kk = lane_e & 3;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * RS + kk * 16);
+            gb_store16(v, rs, pp4[i][k] < 0 ? 0xFFFFFFF0u : (unsigned)(pp4[i][k] * dcs + dco + kk * 8) * 2u);
+          }
+        } else {
+          const int r = lane_e >> 1, kk = lane_e & 1;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * RS + kk * 16);
+          gb_store16(v, rs, pp2[i] < 0 ? 0xFFFFFFF0u : (unsigned)(pp2[i] * dcs + dco + kk * 8) * 2u);
+        }
+      }
+    };
+    // NG * 8 channels starting at local channel lc0: modulate, stage, store the activation, then (1 + gamma)
+    auto group = [&](const int lc0, auto ng_c, auto&& gam, auto&& bet, auto&& xin) {
+      constexpr int NG = decltype(ng_c)::value;
+      f32x4 g1r[2][NG];
+#pragma unroll
+      for (int g = 0; g < NG; ++g) {
+        const int lc = lc0 + 8 * g + 4 * lhe;
+        const f32x4 b1 = *reinterpret_cast<const f32x4*>(cbuf + lc);
+        const f32x4 b2 = *reinterpret_cast<const f32x4*>(cbuf + GB_CV + lc);
+        const f32x4 rs = *reinterpret_cast<const f32x4*>(cbuf + 2 * GB_CV + lc);
+        const f32x4 nr = *reinterpret_cast<const f32x4*>(cbuf + 3 * GB_CV + lc);
+        const f32x4 mr = *reinterpret_cast<const f32x4*>(cbuf + 4 * GB_CV + lc);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+          // whole-vector arithmetic: pairs of lanes' channels go through the packed fp32 instructions
+          const f32x4 xn = xin(i, g) * rs + (nr * zv[i] + mr);
+          g1r[i][g] = gam(i, g) + b1;
+          const f32x4 t = xn * g1r[i][g] + (bet(i, g) + b2);
+          const f32x4 ts = t * sl;
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(t[e], ts[e]);
+          *reinterpret_cast<bf16x4v*>(sb0 + i * 2560 + l31e * RS + 16 * g + 8 * lhe) = __builtin_convertvector(v, bf16x4v);
+        }
+      }
+      const int cb = cb0 + lc0;                // first norm channel of the group
+      // same wave wrote and reads: LDS operations of a wave complete in order
+      rows_out(ng_c, o_rsrc, p.out_cs, p.out_co + cb);
+      if (p.g1p) {
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+            *reinterpret_cast<bf16x4v*>(sb0 + i * 2560 + l31e * RS + 16 * g + 8 * lhe) = __builtin_convertvector(g1r[i][g], bf16x4v);
+        rows_out(ng_c, g_rsrc, p.sC, cb);
+      }
+    };
+    using G4 = std::integral_constant<int, 4>;
+    using G2 = std::integral_constant<int, 2>;
+#pragma unroll
+    for (int pr = 0; pr < NPAIR; ++pr)
+      group(pr * 32, G4{}, [&](int i, int g) { return gb_acc4(acc[i][2 * pr], g); },
+            [&](int i, int g) { return gb_acc4(acc[i][2 * pr + 1], g); }, [&](int i, int g) { return xv[i][pr][g]; });
+    if constexpr (TAIL != 0)
+      group(NPAIR * 32, G2{}, [&](int i, int g) { return gb_acc4(acc[i][NTP - 1], g); },
+            [&](int i, int g) { return gb_acc4(acc[i][NTP - 1], g + 2); }, [&](int i, int g) { return xt[i][g]; });
+  } else {
+    using G4 = std::integral_constant<int, 4>;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < NTP; ++j) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float a = acc[i][j][4 * g + e];
+            if (p.mask) a = bf2f(mv[i][j][g][e]) > 0.f ? a : a * p.slope;
+            v[e] = a;
+          }
+          *reinterpret_cast<f32x4*>(scr + l31e * SCS + 8 * g + 4 * lhe) = v;
+        }
+        copy_out(i, G4{}, o_rsrc, p.out_cs, p.out_co + (tile0 + j) * 32, p.out_f32 != 0);
+      }
   }
-  __syncthreads();                             // the scratch lives in the weight ring: the next pass / tile refills it
+  if (p.tlog && tid == 0 && last) p.tlog[(size_t)bid * 8 + 6] = wall_clock64();      // every store of the tile is issued
+  // (the caller's next gb_pass waits vmcnt(0) + barrier before touching the ring: this pass's scratch reads are done then)
 }
 
 // One launch covers the passes [pass0, pass1) of the plan, all of NTP column tiles (a single-chunk source's patch stays
 // resident across them: the epilogue's scratch lives in the weight ring).
-template <int NTP, int EPI>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void spade_gb_kernel(const GbParams p, const int pass0, const int pass1) {
+template <int NTP, int EPI, bool HALF>
+__global__ __launch_bounds__(256) void spade_gb_kernel(const GbParams p, const int pass0, const int pass1) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[GB_LDS];
-  const int tx = (p.W + 15) >> 4, ty = (p.H + 15) >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  const bool repatch = p.nchunk > 1;           // a multi-chunk source's patch holds its LAST chunk when a pass ends
+  // Staggered start.  Every tile is a compute phase (main loop, HBM idle) followed by a memory phase (epilogue stores,
+  // the next tile's patch and x: ~280 KB per tile); blocks that start together stay in lock step, so all 256 CUs hit HBM
+  // at once and then leave it idle (measured: a 14 us memory phase = 256 x 283 KB at HBM speed, next to a 19 us main
+  // loop).  Four phase groups, a quarter of a tile apart, spread the memory phases over the compute phases.
+  if (p.stagger_ticks > 0) {
+    const unsigned long long t_go = wall_clock64() + (unsigned long long)((blockIdx.x >> 3) & 3) * (unsigned)p.stagger_ticks;
+    while (wall_clock64() < t_go) __builtin_amdgcn_s_sleep(32);
+  }
+  if ((int)blockIdx.x < p.m_tiles) {
+    const GbTile T0 = gb_tile(p, blockIdx.x);
+    GbIssue<NTP>::issue(p, smem, pass0, true, T0.n, T0.y0, T0.x0, wave, lane);
+  }
 #pragma unroll 1
   for (int bid = blockIdx.x; bid < p.m_tiles; bid += gridDim.x) {
     if (p.tlog && threadIdx.x == 0) {
@@ -536,13 +716,15 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
       p.tlog[(size_t)bid * 8 + 4] = ((unsigned long long)xcc << 32) | hw;
       p.tlog[(size_t)bid * 8 + 5] = blockIdx.x;
     }
-    const int mt = xcd_remap(bid, p.m_tiles);
-    const int pt_n = mt / (tx * ty);
-    const int rr = mt - pt_n * (tx * ty);
-    const int pt_y0 = (rr / tx) << 4, pt_x0 = (rr % tx) << 4;
+    const GbTile T = gb_tile(p, bid);
+    const int nbid = bid + gridDim.x;
+    const GbTile TN = gb_tile(p, nbid < p.m_tiles ? nbid : bid);
 #pragma unroll 1
-    for (int pass = pass0; pass < pass1; ++pass)
-      gb_pass<NTP, EPI>(p, pass, smem, pt_n, pt_y0, pt_x0, bid, pass == pass0 || p.nchunk > 1, pass == pass0, pass == pass1 - 1);
+    for (int pass = pass0; pass < pass1; ++pass) {
+      const bool lastp = pass == pass1 - 1;
+      const int nxt_pass = !lastp ? pass + 1 : (nbid < p.m_tiles ? pass0 : -1);
+      gb_pass<NTP, EPI, HALF>(p, pass, smem, T, bid, pass == pass0, lastp, nxt_pass, lastp || repatch, lastp ? TN : T);
+    }
     if (p.tlog) {
       __builtin_amdgcn_s_waitcnt(gb_wait(0));
       if (threadIdx.x == 0) p.tlog[(size_t)bid * 8 + 3] = wall_clock64();
@@ -622,10 +804,19 @@ extern "C" int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream) {
   }
   int grid = gb_n_cu();
   if (grid > p.m_tiles) grid = p.m_tiles;
+  {
+    // a quarter of a tile's time (~7 us) per phase group when a block runs >= 8 tiles; HRV_GB_STAGGER overrides (ticks of 10 ns)
+    const char* e = getenv("HRV_GB_STAGGER");
+    const int per_block = (p.m_tiles + grid - 1) / grid;
+    (void)per_block;
+    p.stagger_ticks = e ? atoi(e) : 0;      // measured: no gain (the epilogue is issue-bound, not HBM-bound) -- off by default
+  }
   if (d->mode == 0) {
     HRV_REQUIRE(d->x && d->mean && d->rstd && d->bias_gamma && d->bias_beta, "spade_gb: null epilogue pointer");
     HRV_REQUIRE((d->noise_z == nullptr) == (d->noise_scale == nullptr), "spade_gb: noise_z/noise_scale go together");
     HRV_REQUIRE(d->out_cstride >= d->out_coff + d->C, "spade_gb: out slice");
+    HRV_REQUIRE(d->out_f32 == 0 && (d->g1p == nullptr || d->g1p_bf16 == 1), "spade_gb: the forward stores bf16 (out and 1 + gamma)");
+    HRV_REQUIRE((int64_t)d->H * d->W * d->out_cstride * 2 < (int64_t)0xFFFFFFF0, "spade_gb: one image of `out` exceeds 4 GB");
     HRV_REQUIRE(d->x_cstride % 4 == 0 && d->x_coff % 4 == 0 && d->x_coff + d->C <= d->x_cstride,
                 "spade_gb: x slice");
     HRV_REQUIRE((((uintptr_t)d->x | (uintptr_t)d->g1p) & 15) == 0, "spade_gb: x / g1p must be 16-byte aligned");
@@ -635,14 +826,15 @@ extern "C" int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream) {
     p.g1p = d->g1p; p.g1_bf16 = d->g1p_bf16;
     // the passes of 4 column tiles in one launch, the 5-tile tail pass (16-channel tail) in another
     const int n4 = pl.ntp[pl.npass - 1] == 5 ? pl.npass - 1 : pl.npass;
-    if (n4 > 0) hipLaunchKernelGGL((spade_gb_kernel<4, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, 0, n4);
-    if (n4 < pl.npass) hipLaunchKernelGGL((spade_gb_kernel<5, 1>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, n4, pl.npass);
+    if (n4 > 0) hipLaunchKernelGGL((spade_gb_kernel<4, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, 0, n4);
+    if (n4 < pl.npass) hipLaunchKernelGGL((spade_gb_kernel<5, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, n4, pl.npass);
   } else {
     HRV_REQUIRE(d->out_cstride >= d->out_coff + d->hid, "spade_gb: out slice");
     HRV_REQUIRE(d->mask == nullptr || (d->mask_cstride % 4 == 0 && d->mask_coff % 4 == 0 && ((uintptr_t)d->mask & 7) == 0),
                 "spade_gb: mask slice");
     p.mask = d->mask; p.mask_cs = d->mask_cstride; p.mask_co = d->mask_coff;
-    hipLaunchKernelGGL((spade_gb_kernel<4, 2>), dim3(grid), dim3(512), 0, (hipStream_t)stream, p, 0, 1);
+    if ((p.C & 127) == 32) hipLaunchKernelGGL((spade_gb_kernel<4, 2, true>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, 0, 1);
+    else hipLaunchKernelGGL((spade_gb_kernel<4, 2, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, 0, 1);
   }
   return check_launch("spade_gb_kernel");
 }

@@ -44,6 +44,7 @@ struct NormBwdParams {
   int N, H, W, C4, act; float slope;
   int NB; float* part;                       // [N][NB][C][2]
   int dgb_bf16, out_bf16;                    // storage of dgb / out: bf16 when only matrix cores (and this mask) read them
+  int g1p_bf16;                              // (1 + gamma) stored as bf16 (the dedicated gamma|beta kernel writes it so)
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -90,7 +91,10 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
           for (int e = 0; e < 4; ++e) dpre[e] *= dact(o[e], p.act, p.slope);
         }
         f32x4 dnh = dpre;
-        if (p.g1p) dnh *= ld4(p.g1p + pix * p.g_cs + p.g_co + g * 4);
+        if (p.g1p) {
+          const size_t ge1 = pix * p.g_cs + p.g_co + g * 4;
+          dnh *= p.g1p_bf16 ? ld4_bf16(p.g1p, ge1) : ld4(p.g1p + ge1);
+        }
         *reinterpret_cast<f32x4*>(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) = dnh;
         if (p.dgb) {
           const size_t ge = pix * p.dgb_cs + p.dgb_co + g * 4;
@@ -822,7 +826,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   NormBwdParams p;
   p.x = d->x; p.x_cs = d->x_cstride; p.x_co = d->x_coff; p.z = d->noise_z; p.ns = d->noise_scale;
   p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
-  p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff;
+  p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff; p.g1p_bf16 = d->g1p_bf16;
   p.dout = d->dout; p.do_cs = d->dout_cstride; p.do_co = d->dout_coff;
   p.dnh = d->dnh; p.dn_cs = d->dnh_cstride; p.dn_co = d->dnh_coff;
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;

@@ -172,10 +172,11 @@ class SpadeT:
                 T.spade_gb_ok(0, self.C, self.Cp, self.hid, x.N, x.H, x.W)):
             # the dedicated kernel: 16x16-pixel tiles x ALL columns per block, no padded columns (csrc/spade_gb.hip)
             out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=True)
-            g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.float32, device=dev) if save else None
+            # (1 + gamma) in bf16: the normalisation backward is its only reader (half the bytes of the fp32 form)
+            g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.bfloat16, device=dev) if save else None
             pk = T.spade_gb_pack(0, n.conv_gamma.weight.data, n.conv_beta.weight.data)
             fl = 2.0 * x.N * x.H * x.W * 2 * self.C * self.hid * 9
-            nbytes = (ops.act_bytes(actv) + (2 if save else 1) * ops.act_bytes(x) + ops.act_bytes(out) +
+            nbytes = (ops.act_bytes(actv) + (1.5 if save else 1) * ops.act_bytes(x) + ops.act_bytes(out) +
                       2.0 * self.C * self.hid * 9 * 2)
             T.spade_gb_forward(actv, x, mean, rstd, zz, n.noise_scale.data, pk, n.conv_gamma.bias.data, n.conv_beta.bias.data,
                                self.act, 0.2, out, g1p, self.name + ".conv_gamma|beta", fl, nbytes)

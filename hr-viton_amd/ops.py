@@ -468,6 +468,9 @@ class SpadeModulate:
             w[g * 64 + 32: g * 64 + 32 + n] = wb[g * 32: g * 32 + n]
             b[g * 64: g * 64 + n] = b_gamma.detach().cpu().float()[g * 32: g * 32 + n]
             b[g * 64 + 32: g * 64 + 32 + n] = b_beta.detach().cpu().float()[g * 32: g * 32 + n]
+        self._w_raw = (wg, wb)                  # the dedicated kernel packs the pair itself (lazily, on first use)
+        self._b_raw = (b_gamma.detach().cpu().float().contiguous(), b_beta.detach().cpu().float().contiguous())
+        self._gb = None
         self.conv = ConvLayer(w, [hid], device, shift=b, stride=1, pad=k // 2, act=act, name=name, bf16=bf16)
         self.conv.flops_cout = 2 * self.Creal   # algorithmic (unpadded) gamma+beta columns
         # 128x128 tile when the pair count is even (bf16: the 128-byte-row variant), else 128x64
@@ -491,6 +494,20 @@ class SpadeModulate:
         e.noise_scale = self.ns.data_ptr() if use_noise else None
         if out is None:
             out = alloc(x.N, x.H, x.W, self.Creal, x.t.device, self.bf16)
+        if self.bf16 and actv.bf16 and out.bf16 and self.Cp == self.Creal:
+            from . import train_ops as T       # (train_ops imports this module)
+            if T.spade_gb_ok(0, self.Creal, self.Cp, actv.C, x.N, x.H, x.W):
+                # the dedicated gamma|beta kernel (csrc/spade_gb.hip): 16x16-pixel tiles x all columns, no padded columns
+                if self._gb is None:
+                    dev = x.t.device
+                    wg, wb = self._w_raw
+                    self._gb = (T.spade_gb_pack(0, wg.to(dev).contiguous(), wb.to(dev).contiguous()),
+                                self._b_raw[0].to(dev), self._b_raw[1].to(dev))
+                pk, bg, bb = self._gb
+                nb = act_bytes(actv) + act_bytes(x) + act_bytes(out) + 2.0 * self.Creal * actv.C * 9 * 2
+                T.spade_gb_forward(actv, x, mean, rstd, z if use_noise else None, self.ns if use_noise else None, pk, bg, bb,
+                                   self.conv.act, self.conv.slope, out, None, self.conv.name, self.flops(x.N, x.H, x.W), nb)
+                return out
         cfg = self.cfg
         cfg = patch_tile(self.bf16, 3, 3, 1, 1, 1, 0, actv.Cp, self.conv.Cout, x.N, x.H, x.W, wide=True) or cfg
         return self.conv([actv], out=out, spade=e, out_channels=self.Creal, cfg=cfg)

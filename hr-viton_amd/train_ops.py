@@ -3,9 +3,9 @@ device-side weight packing, data gradient (stride 1 and the four phases of strid
 weight gradient, bias gradient.  Everything is NHWC fp32 ``Act`` views like ops.py."""
 from __future__ import annotations
 
-import os
-
 import ctypes as C
+import itertools
+import os
 from typing import Optional, Sequence, Tuple
 
 import torch
@@ -30,11 +30,20 @@ def _bf16_tile(cout: int) -> int:
 _FROZEN_PACKS: dict = {}
 
 
+_PACK_TOKENS = itertools.count(1)
+
+
 def frozen_stamp(p) -> Optional[tuple]:
-    """Stamp for pack_weight_dev(frozen=...): None for a trainable parameter."""
+    """Stamp for pack_weight_dev(frozen=...): None for a trainable parameter.  Carries a token that is unique to the
+    Parameter OBJECT: a storage address alone can be recycled by the caching allocator for another frozen network of
+    the same shapes (two VGG criteria built one after the other, as consecutive tests do) and would then return the dead
+    network's packed weights."""
     if p.requires_grad:
         return None
-    return (p._version, getattr(p, "_hrv_epoch", 0))
+    tok = getattr(p, "_hrv_pack_token", None)
+    if tok is None:
+        tok = p._hrv_pack_token = next(_PACK_TOKENS)
+    return (tok, p._version, getattr(p, "_hrv_epoch", 0))
 
 
 def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
@@ -391,6 +400,7 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
         d.out_bf16 = 1 if out.bf16 else 0
     if g1p is not None:
         d.g1p, d.g1p_cstride, d.g1p_coff = g1p.t.data_ptr(), g1p.cstride, g1p.coff
+        d.g1p_bf16 = 1 if g1p.bf16 else 0
     d.dout, d.dout_cstride, d.dout_coff = dout.t.data_ptr(), dout.cstride, dout.coff
     d.dnh, d.dnh_cstride, d.dnh_coff = dnh.data_ptr(), Cp, 0
     if dgb is not None:

@@ -253,7 +253,7 @@ typedef struct hrv_norm_bwd {
   int32_t out_bf16;   /* 1: `out` is stored as bf16 (only its sign is used here)                              */
   int32_t dx_bf16;    /* 1: `dx` is stored as bf16 (no accumulate): the gradient of a convolution output that only
                        *    that convolution's weight / data gradient (matrix cores) read                          */
-  int32_t _pad_nb;
+  int32_t g1p_bf16;   /* 1: `g1p` is stored as bf16 (written by hrv_spade_gb_bf16; this kernel is its only reader) */
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 

@@ -35,7 +35,7 @@ def test_forward_matches_torch_on_bf16_rounded_operands(C_, N, H, W, cs_mult):
     bg, bb = (torch.randn(C_, generator=g) * 0.1).to(dev), (torch.randn(C_, generator=g) * 0.1).to(dev)
     mean, rstd = torch.randn(N, C_, generator=g).to(dev) * 0.1, (torch.rand(N, C_, generator=g) + 0.5).to(dev)
     out = ops.alloc(N, H, W, C_, dev, bf16=True)
-    g1p = torch.empty(N, H, W, C_, device=dev)
+    g1p = torch.empty(N, H, W, C_, device=dev, dtype=torch.bfloat16)     # (1 + gamma) is stored in bf16
     pk = T.spade_gb_pack(0, wg, wb)
     T.spade_gb_forward(actv, x, mean, rstd, z, ns, pk, bg, bb, ops.ACT_LRELU, 0.2, out, g1p, "t", 1.0, 1.0)
     torch.cuda.synchronize()
@@ -50,24 +50,24 @@ def test_forward_matches_torch_on_bf16_rounded_operands(C_, N, H, W, cs_mult):
     err = (got - want).abs()
     assert float((err / (want.abs() * 2 ** -8 + 2e-3)).max()) < 1.0, float(err.max())
     g1w = (1 + gam).permute(0, 2, 3, 1)
-    assert float((g1p - g1w).abs().max()) < 2e-4 * float(g1w.abs().max())
+    assert float(((g1p.float() - g1w).abs() / (g1w.abs() * 2 ** -8 + 1e-3)).max()) < 1.0
 
 
-@pytest.mark.parametrize("out_f32,g1_bf16,noise", [(True, True, False), (False, False, True)])
-def test_forward_output_types(out_f32, g1_bf16, noise):
+@pytest.mark.parametrize("x_bf16,noise,save", [(True, False, True), (False, True, False)])
+def test_forward_input_types(x_bf16, noise, save):
     C_, N, H, W = 80, 1, 48, 64
     ops, actv, wg, wb, g, dev, hid = _mk(N, H, W, C_, 2)
     from hr_viton_amd import train_ops as T
     xb = torch.randn(N, H, W, C_, generator=g).to(dev)
-    x = ops.Act(xb.to(torch.bfloat16) if not out_f32 else xb, C_)       # x may be bf16-stored (inference) or fp32 (training)
+    x = ops.Act(xb.to(torch.bfloat16) if x_bf16 else xb, C_)       # x may be bf16-stored (inference) or fp32 (training)
     z = torch.randn(N, W, H, 1, generator=g).to(dev) if noise else None
     ns = (torch.randn(C_, generator=g) * 0.1).to(dev)
     bg, bb = torch.zeros(C_, device=dev), torch.zeros(C_, device=dev)
     mean, rstd = torch.zeros(N, C_, device=dev), torch.ones(N, C_, device=dev)
-    out = ops.alloc(N, H, W, C_, dev, bf16=not out_f32)
-    g1p = torch.empty(N, H, W, C_, device=dev, dtype=torch.bfloat16 if g1_bf16 else torch.float32)
-    T.spade_gb_forward(actv, x, mean, rstd, z, ns if noise else None, T.spade_gb_pack(0, wg, wb), bg, bb, ops.ACT_NONE, 0.2, out, g1p,
-                       "t", 1.0, 1.0)
+    out = ops.alloc(N, H, W, C_, dev, bf16=True)
+    g1p = torch.full((N, H, W, C_), 5.0, device=dev, dtype=torch.bfloat16)
+    T.spade_gb_forward(actv, x, mean, rstd, z, ns if noise else None, T.spade_gb_pack(0, wg, wb), bg, bb, ops.ACT_NONE, 0.2, out,
+                       g1p if save else None, "t", 1.0, 1.0)
     torch.cuda.synchronize()
     a = actv.t.float().permute(0, 3, 1, 2)
     gam = F.conv2d(a, wg.to(torch.bfloat16).float(), padding=1)
@@ -76,10 +76,12 @@ def test_forward_output_types(out_f32, g1_bf16, noise):
     if noise:
         xn = xn + z.permute(0, 3, 2, 1) * ns.view(1, -1, 1, 1)
     want = (xn * (1 + gam) + bet).permute(0, 2, 3, 1)
-    tol = 2e-4 if out_f32 else 2 ** -8
-    assert float(((out.t[..., :C_].float() - want).abs() / (want.abs() * tol + 2e-3)).max()) < 1.0
+    assert float(((out.t[..., :C_].float() - want).abs() / (want.abs() * 2 ** -8 + 2e-3)).max()) < 1.0
     g1w = (1 + gam).permute(0, 2, 3, 1)
-    assert float((g1p.float() - g1w).abs().max()) < (2 ** -8 if g1_bf16 else 2e-4) * float(g1w.abs().max())
+    if save:
+        assert float(((g1p.float() - g1w).abs() / (g1w.abs() * 2 ** -8 + 1e-3)).max()) < 1.0
+    else:
+        assert bool((g1p == 5.0).all())
 
 
 @pytest.mark.parametrize("C_,N,H,W,cs_mult", [(80, 1, 250, 270, 3), (144, 1, 96, 112, 1), (64, 1, 64, 80, 2), (32, 1, 40, 48, 1),
@@ -133,6 +135,6 @@ def test_spade_layer_through_the_training_plan_uses_the_kernel_and_matches_the_g
         torch.cuda.synchronize()
         a, b = res["1"], res["0"]
         assert float((a[0] - b[0]).abs().max()) <= 2 ** -7 * float(b[0].abs().max())
-        assert float((a[1] - b[1]).abs().max()) < 1e-4 * float(b[1].abs().max())
+        assert float((a[1].float() - b[1].float()).abs().max()) < 2 ** -7 * float(b[1].abs().max())
     finally:
         T.MMA_BF16[0] = False

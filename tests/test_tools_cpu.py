@@ -31,3 +31,16 @@ def test_committed_traffic_json_is_consistent():
     with open(os.path.join(ROOT, "profiles", "r02_final_bench_default.json")) as f:
         b = json.load(f)
     assert abs(b["roofline"]["traffic"] - t["hbm_bytes_per_launch"]) < 1.0      # the bench line carries this file's figure
+
+
+def test_frozen_pack_stamp_is_unique_per_parameter_object():
+    """The packed-weight cache of frozen networks (VGG19) must not confuse two Parameter objects whose storage address
+    the caching allocator recycled (it made the fp32 gradient parity of a later test depend on an earlier one)."""
+    import torch
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import train_ops as T
+    a = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+    b = torch.nn.Parameter(torch.zeros(4), requires_grad=False)
+    sa, sb = T.frozen_stamp(a), T.frozen_stamp(b)
+    assert sa != sb and sa == T.frozen_stamp(a)
+    assert T.frozen_stamp(torch.nn.Parameter(torch.zeros(4))) is None      # trainable: never cached

@@ -30,7 +30,9 @@ def timeline(run, tiles, label):
     us = lambda v: (v - t0).double() / 100.0          # noqa: E731   wall_clock64: 100 MHz
     st, lp, ep, en = us(t[:, 0]), us(t[:, 1]), us(t[:, 2]), us(t[:, 3])
     print(f"   timeline {label}: {t.shape[0]}/{tiles} tiles, device span {float(en.max()):.0f} us")
-    for nm, d in (("prologue", lp - st), ("main loop(s)", ep - lp), ("epilogue", en - ep), ("tile", en - st)):
+    iss = us(t[:, 6])
+    for nm, d in (("prologue", lp - st), ("main loop(s)", ep - lp), ("epilogue", en - ep), ("  stores issued", iss - ep),
+                  ("  drain (vmcnt 0)", en - iss), ("tile", en - st)):
         print(f"      {nm:14s} mean {float(d.mean()):7.2f} us  median {float(d.median()):7.2f}  p90 {float(d.quantile(0.9)):7.2f}")
 
 
@@ -61,10 +63,14 @@ def main():
         fl = 2.0 * N * H * W * 2 * Cc * 128 * 9
         print(f"{name}: C={Cc} N={N} {H}x{W}  ({fl / 1e12:.3f} TFLOP per launch)")
         for what, fn in (("forward", fwd), ("dgrad", dgrad)):
-            times = {"1": [], "0": []}
+            times = {"1": [], "0": [], "ns": []}
             for rd in range(rounds + 2):
-                for flag in ("1", "0"):
-                    os.environ["HRV_SPADE_GB"] = flag
+                for flag in ("1", "0", "ns"):
+                    os.environ["HRV_SPADE_GB"] = "0" if flag == "0" else "1"
+                    if flag == "ns":
+                        os.environ["HRV_GB_STAGGER"] = "0"
+                    else:
+                        os.environ.pop("HRV_GB_STAGGER", None)
                     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                     s.record()
                     fn()
@@ -72,7 +78,8 @@ def main():
                     torch.cuda.synchronize()
                     if rd >= 2:
                         times[flag].append(s.elapsed_time(e))
-            for flag, lab in (("1", "spade_gb kernel"), ("0", "generic patch tiles")):
+            os.environ.pop("HRV_GB_STAGGER", None)
+            for flag, lab in (("1", "spade_gb kernel"), ("ns", "spade_gb, no stagger"), ("0", "generic patch tiles")):
                 ts = sorted(times[flag])
                 med = ts[len(ts) // 2]
                 print(f"   {what:8s} {lab:20s} median {med:7.3f} ms  min {ts[0]:7.3f}  {fl / (med * 1e-3) / 1e12:7.1f} TFLOP/s "
