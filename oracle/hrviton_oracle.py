@@ -170,18 +170,32 @@ def _bn_eval(x: Tensor, sd: SD, p: str, eps: float = 1e-5) -> Tensor:
                         sd[p + ".weight"], sd[p + ".bias"], False, 0.0, eps)
 
 
+def _tq(x: Tensor, w: Tensor, b, **kw) -> Tensor:
+    """A tocg convolution.  With QUANT["fn"] set (emulation of the --fp16 / bf16-matrix-core engine, networks.py's
+    mixed_precision mode of the HIP port) the input and the weight are rounded and the accumulation stays fp32 -- the
+    engine's rounding points: ResBlock convolutions, the 1x1 laterals, the bottlenecks; the flow heads stay fp32."""
+    q = globals()["QUANT"]["fn"]
+    if q is not None:
+        x, w = q(x), q(w)
+    return F.conv2d(x, w, b, **kw)
+
+
 def resblock(sd: SD, p: str, x: Tensor, scale: str) -> Tensor:
     """ResBlock.forward -- networks.py:171-198 (BatchNorm2d, eval mode)."""
     if scale == "down":
-        r = F.conv2d(x, sd[p + ".scale.weight"], None, stride=2, padding=1)
+        r = _tq(x, sd[p + ".scale.weight"], None, stride=2, padding=1)
     elif scale == "same":
-        r = F.conv2d(x, sd[p + ".scale.weight"], sd[p + ".scale.bias"])
+        r = _tq(x, sd[p + ".scale.weight"], sd[p + ".scale.bias"])
+    elif globals()["QUANT"]["fn"] is not None:
+        # the engine runs the 1x1 before the bilinear upsample (linear operators commute): its rounding point is the
+        # low-resolution input
+        r = resize_bilinear(_tq(x, sd[p + ".scale.1.weight"], None), scale_factor=2) + sd[p + ".scale.1.bias"].view(1, -1, 1, 1)
     else:  # up
         r = resize_bilinear(x, scale_factor=2)
         r = F.conv2d(r, sd[p + ".scale.1.weight"], sd[p + ".scale.1.bias"])
-    t = F.conv2d(r, sd[p + ".block.0.weight"], None, padding=1)
+    t = _tq(r, sd[p + ".block.0.weight"], None, padding=1)
     t = F.relu(_bn_eval(t, sd, p + ".block.1"))
-    t = F.conv2d(t, sd[p + ".block.3.weight"], None, padding=1)
+    t = _tq(t, sd[p + ".block.3.weight"], None, padding=1)
     t = _bn_eval(t, sd, p + ".block.4")
     return F.relu(r + t)
 
@@ -211,15 +225,15 @@ def tocg_forward(sd: SD, input1: Tensor, input2: Tensor,
             x = resblock(sd, "conv", T2, "same")
             x = resblock(sd, "SegDecoder.0", x, "up")
         else:
-            T1 = resize_bilinear(T1, scale_factor=2) + F.conv2d(
+            T1 = resize_bilinear(T1, scale_factor=2) + _tq(
                 E1[4 - i], sd[f"conv1.{4 - i}.weight"], sd[f"conv1.{4 - i}.bias"])
-            T2 = resize_bilinear(T2, scale_factor=2) + F.conv2d(
+            T2 = resize_bilinear(T2, scale_factor=2) + _tq(
                 E2[4 - i], sd[f"conv2.{4 - i}.weight"], sd[f"conv2.{4 - i}.bias"])
             flow = resize_bilinear(flow_list[i - 1].permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1)
             flow_norm = torch.cat([flow[..., 0:1] / ((iW / 2 - 1.0) / 2.0),
                                    flow[..., 1:2] / ((iH / 2 - 1.0) / 2.0)], 3)
             warped_T1 = grid_sample_bilinear_border(T1, flow_norm + grid)
-            b = F.relu(F.conv2d(x, sd[f"bottleneck.{i - 1}.0.weight"], sd[f"bottleneck.{i - 1}.0.bias"], padding=1))
+            b = F.relu(_tq(x, sd[f"bottleneck.{i - 1}.0.weight"], sd[f"bottleneck.{i - 1}.0.bias"], padding=1))
             flow = flow + F.conv2d(torch.cat([warped_T1, b], 1), sd[f"flow_conv.{i}.weight"],
                                    sd[f"flow_conv.{i}.bias"], padding=1).permute(0, 2, 3, 1)
             flow_list.append(flow)

@@ -48,13 +48,13 @@ def condstep_opt(cuda: bool):
     return Namespace(cuda=cuda, warp_feature="T1", out_layer="relu", semantic_nc=13, output_nc=13)
 
 
-def condstep_build(tocg_cls, define_D, cuda: bool = False):
+def condstep_build(tocg_cls, define_D, cuda: bool = False, ngf: int = 8, N: int = 2, H: int = 128, W: int = 96):
     """ConditionGenerator(ngf=8) + define_D(33 ch, Ddownx2, num_D=2) + one synthetic train_condition.py
-    batch (N=2, 128x96).  tocg keeps torch's default conv init with randomised BatchNorm affine terms
+    batch (default N=2, 128x96, ngf=8 -- the golden recipe; the full-size parity tests pass the timed sizes).  tocg keeps torch's default conv init with randomised BatchNorm affine terms
     and non-trivial running statistics; D uses the reference's weights_init (N(0, 0.02)) scaled x2."""
     opt = condstep_opt(cuda)
     torch.manual_seed(31)
-    tocg = tocg_cls(opt, input1_nc=4, input2_nc=16, output_nc=13, ngf=8, norm_layer=torch.nn.BatchNorm2d)
+    tocg = tocg_cls(opt, input1_nc=4, input2_nc=16, output_nc=13, ngf=ngf, norm_layer=torch.nn.BatchNorm2d)
     D = define_D(input_nc=4 + 16 + 13, Ddownx2=True, Ddropout=False, n_layers_D=3, spectral=False, num_D=2)
     g = torch.Generator().manual_seed(91)
     with torch.no_grad():
@@ -69,7 +69,6 @@ def condstep_build(tocg_cls, define_D, cuda: bool = False):
                 p.mul_(0.3)   # keep the synthetic flows inside the image so the warps have gradients
         for p in D.parameters():
             p.copy_(0.02 * 2.0 * torch.randn(p.shape, generator=g))
-    N, H, W = 2, 128, 96
     lab = torch.randint(0, 13, (N, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)
     parse = torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0)
     agn = torch.randint(0, 13, (N, 1, H // 8, W // 8), generator=g).repeat_interleave(8, 2).repeat_interleave(8, 3)

@@ -2,11 +2,12 @@
 MI355X against torch autograd over the CPU restatement (hrviton_oracle.py), at any size the CPU can afford.
 
 TEST INFRASTRUCTURE ONLY -- imported by tests/ and by bench.py's parity / cpu_baseline legs, never by the
-product package.  Three entry points:
+product package.  Entry points:
 
 * ``build``            one deterministic (generator, PatchGAN, VGG criterion, batch, SPADE noise) recipe;
 * ``compare_generator_step``  G-step losses, the generated image and EVERY parameter gradient, HIP vs oracle
                        (fp32: reassociation only; ``mixed=True``: bf16 matrix-core operands, stated tolerance);
+* ``compare_discriminator_step``  the D half (no_grad G forward, D losses, every D gradient, post-step D weights);
 * ``cpu_train_generator_step``  the whole iteration (G step + D step + Adam) on the oracle, for the CPU baseline.
 """
 from __future__ import annotations
@@ -179,6 +180,102 @@ def _hip_pass(opt, gen, D, vgg, x, seg, real, noise, mixed, with_vgg, losses, fa
             for r in rows_g:
                 f.write("%.3e %.3e %.3e %.6f %s\n" % r)
     return rep
+
+
+def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: int = 1, seed: int = 0, wmul: float = 8.0,
+                               mixed=(False,), cpu_threads: int = 0, table_path: Optional[str] = None) -> dict:
+    """The DISCRIMINATOR half of the iteration (train_generator.py:327-360) on cuda:0 against the oracle, from identical
+    weights: no_grad generator forward (its own noise draw), PatchGAN on [fake; real] (spectral norm in training mode),
+    hinge D losses, backward, Adam(lr 4e-4, betas 0 / 0.9).  Compared: the two loss terms, EVERY discriminator parameter
+    gradient (the odd-extent 4x4 stride-2 layers at 513x385 / 257x193 go through the zero-padded-dY weight gradients in
+    mixed precision), and the post-step weights."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import train_ops as T
+    from hr_viton_amd.losses import GANLoss
+    from hr_viton_amd.optim import Adam
+    if cpu_threads:
+        torch.set_num_threads(cpu_threads)
+    engines = tuple(mixed) if isinstance(mixed, (tuple, list)) else (mixed,)
+    opt, gen, D, _vgg, x, seg, real, noise = build(H, W, ngf, ndf, N, seed, wmul)
+    sd_g, sd_d = oracle_sd(gen), oracle_sd(D)
+    t0 = time.perf_counter()
+    O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+    try:
+        with torch.no_grad():
+            fake = O.spade_generator_forward(sd_g, x, seg, H, W, opt.num_upsampling_layers, noise=noise)
+        pred = O.gen_discriminator_forward(sd_d, torch.cat([torch.cat([seg, fake], 1), torch.cat([seg, real], 1)], 0))
+    finally:
+        O.SN_TRAIN["on"] = False
+    pf, pr = O.split_fake_real(pred)
+    want_l = {"D_Fake": O.hinge_loss(pf, False, True), "D_Real": O.hinge_loss(pr, True, True)}
+    pd = [(k, v) for k, v in sd_d.items() if v.requires_grad]
+    od = torch.optim.Adam([v for _, v in pd], lr=4e-4, betas=(0.0, 0.9))
+    od.zero_grad()
+    sum(want_l.values()).backward()
+    want_g = {k: v.grad.detach().clone() for k, v in pd if v.grad is not None}
+    od.step()
+    want_w = {k: v.detach().clone() for k, v in pd}
+    t_oracle = time.perf_counter() - t0
+    gen.cuda().train()
+    D.cuda().train()
+    sd0_g = {k: v.detach().clone() for k, v in gen.state_dict().items()}
+    sd0_d = {k: v.detach().clone() for k, v in D.state_dict().items()}
+    reports = {}
+    for mx in engines:
+        gen.load_state_dict(sd0_g)
+        D.load_state_dict(sd0_d)
+        for p_ in D.parameters():
+            p_.grad = None
+        T.MMA_BF16[0] = bool(mx)
+        try:
+            xc, sc, rc = x.cuda(), seg.cuda(), real.cuda()
+            with torch.no_grad():
+                out = gen(xc, sc, noise={k: [z.cuda() for z in v] for k, v in noise.items()})
+            pfh, prh = D(torch.cat([torch.cat([sc, out], 1), torch.cat([sc, rc], 1)], 0), split=True)
+            crit = GANLoss("hinge")
+            got_l = {"D_Fake": crit(pfh, False, for_discriminator=True), "D_Real": crit(prh, True, for_discriminator=True)}
+            opt_d = Adam(D.parameters(), lr=4e-4, betas=(0.0, 0.9))
+            opt_d.zero_grad()
+            sum(got_l.values()).mean().backward()
+            got_g = {n: p.grad.detach().float().cpu().clone() for n, p in D.named_parameters() if p.grad is not None}
+            opt_d.step()
+            torch.cuda.synchronize()
+        finally:
+            T.MMA_BF16[0] = False
+        gmax = max(float(w.abs().max()) for w in want_g.values())
+        rows = []
+        for n, w in want_g.items():
+            a = got_g[n]
+            cos = float(torch.nn.functional.cosine_similarity(a.flatten(), w.flatten(), dim=0)) if w.numel() > 1 else 1.0
+            rows.append((float((a - w).abs().max()) / max(float(w.abs().max()), 1e-3 * gmax), float((a - w).abs().max()),
+                         float(w.abs().max()), cos, n))
+        rows.sort(reverse=True)
+        # post-step weights: Adam's first step is -lr * g / (|g| + eps): compared where the reference gradient is not ~0
+        worst_w, bad_frac = 0.0, 0.0
+        params = dict(D.named_parameters())
+        for n, w in want_w.items():
+            if n not in want_g:
+                continue
+            g = want_g[n]
+            big = g.abs() > 1e-2 * g.abs().max()
+            dw = (params[n].detach().float().cpu() - w)[big].abs()
+            if dw.numel():
+                worst_w = max(worst_w, float(dw.max()))
+                bad_frac = max(bad_frac, float((dw > 4e-5).float().mean()))
+        rep = {"size": f"{N}x{H}x{W} ndf={ndf}", "mixed": bool(mx), "oracle_s": round(t_oracle, 2),
+               "loss_rel_err": {k: abs(float(got_l[k]) - float(want_l[k])) / max(1.0, abs(float(want_l[k]))) for k in want_l},
+               "losses_oracle": {k: float(v) for k, v in want_l.items()},
+               "grad_worst_rel_err": rows[0][0], "grad_worst_name": rows[0][4], "grad_median_rel_err": rows[len(rows) // 2][0],
+               "grad_min_cosine": min(r_[3] for r_ in rows if r_[2] > 1e-2 * gmax),
+               "post_step_weight_max_abs_diff": worst_w, "post_step_weight_frac_off_by_more_than_lr_tenth": bad_frac,
+               "n_params_compared": len(rows)}
+        reports[bool(mx)] = rep
+        if table_path:
+            with open(table_path.replace(".txt", "_bf16.txt" if mx else "_f32.txt"), "w") as f:
+                f.write(f"# discriminator step {rep['size']} mixed={bool(mx)}: rel_err abs_err |want|max cosine name\n")
+                for r_ in rows:
+                    f.write("%.3e %.3e %.3e %.6f %s\n" % r_)
+    return reports
 
 
 def cpu_train_generator_step(H: int = 256, W: int = 192, ngf: int = 64, ndf: int = 64, N: int = 1, layers: str = "more",

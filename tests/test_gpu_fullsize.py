@@ -139,3 +139,23 @@ def test_generator_step_1024x768_batch2_vs_oracle_autograd():
     assert rep["image_mean_abs_err"] < 3e-3 and rep["image_max_rel_err"] < 3e-2, rep
     assert all(v < 2e-3 for v in rep["loss_rel_err"].values()), rep
     assert rep["grad_min_cosine"] > 0.99, rep
+
+
+def test_discriminator_step_1024x768_batch2_vs_oracle_autograd():
+    """The D half of the headline iteration (train_generator.py:327-360) at the bench resolution, two images: hinge D losses,
+    every PatchGAN gradient (odd extents 513x385 / 257x193: zero-padded-dY bf16 weight gradients, stride-2 phase data
+    gradients), D's Adam step -- fp32 engine and --fp16 engine against torch autograd over the oracle."""
+    os.makedirs(OUT, exist_ok=True)
+    reps = step_check.compare_discriminator_step(1024, 768, 64, 64, 2, seed=1, mixed=(False, True),
+                                                 cpu_threads=min(os.cpu_count() or 1, 32),
+                                                 table_path=os.path.join(OUT, "grad_parity_dis_1024x768_n2.txt"))
+    with open(os.path.join(OUT, "step_parity_dis_1024x768_n2.txt"), "w") as f:
+        f.write(repr(reps) + "\n")
+    rep = reps[False]
+    assert all(v < 1e-4 for v in rep["loss_rel_err"].values()), rep
+    assert rep["grad_worst_rel_err"] < 1e-2 and rep["grad_min_cosine"] > 0.9999, rep
+    assert rep["post_step_weight_frac_off_by_more_than_lr_tenth"] < 1e-3, rep
+    rep = reps[True]
+    # bf16 operands (8 mantissa bits): loss terms 5e-3 relative, gradient cosine >= 0.99 on every sizeable parameter
+    assert all(v < 5e-3 for v in rep["loss_rel_err"].values()), rep
+    assert rep["grad_min_cosine"] > 0.99, rep

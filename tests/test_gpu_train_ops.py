@@ -610,6 +610,7 @@ def test_spade_training_layer_on_patch_tiles(case, monkeypatch):
     assert ops.patch_tile(True, 3, 3, 1, 1, 1, 0, 128, st.G * 64, N, H, W, wide=True) == want_cfg
     outs = {}
     T.MMA_BF16[0] = True
+    monkeypatch.setenv("HRV_SPADE_GB", "0")      # this test pins the GENERIC patch tiles (tests/test_gpu_spade_gb.py: the dedicated kernel)
     try:
         for env in ("1", "0"):
             monkeypatch.setenv("HRV_CONV_PATCH", env)
