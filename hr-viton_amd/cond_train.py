@@ -213,7 +213,15 @@ class FlowConv:
         lib = _lib.load()
         acts = [(v.a, 0) for v in srcs]
         wt = self.w_taps()
-        y = T.conv_forward_dev(wt, acts, 1, 0, name=self.name + "[taps 1x1]")
+        # the flow heads stay on the fp32 matrix cores in --fp16 mode too (as in inference, networks.py of this port): a
+        # bf16-rounded 768-channel operand moves the flow by ~1e-2 px, which flips floor() cells of every warp downstream
+        # (measured at 512x384 ngf=96: tocg gradient cosine vs the oracle 0.88 with bf16 heads)
+        mb = T.MMA_BF16[0]
+        T.MMA_BF16[0] = False
+        try:
+            y = T.conv_forward_dev(wt, acts, 1, 0, name=self.name + "[taps 1x1]")
+        finally:
+            T.MMA_BF16[0] = mb
         a0 = srcs[0].a
         out_t = torch.empty((a0.N, a0.H, a0.W, self.Cout), dtype=torch.float32, device=a0.t.device)
         _lib.check(lib.hrv_tapsum_nhwc_f32(y.t.data_ptr(), y.N, y.H, y.W, self.KH, self.KW, self.pad, self.Cout, y.cstride,
@@ -237,12 +245,17 @@ class FlowConv:
             _acc(tape.grads, self.m.bias, (s4[:2] + s4[2:]) if self.Cout == 2 else s4.view(-1, self.Cout).sum(0))
             Gt = torch.empty_like(wt)
             base = 0
-            for a, _ in acts:
-                T.conv_wgrad(dy, a, 0, base, self.cin, 1, 1, 1, 0, Gt, name=self.name + ".wgrad")
-                base += a.C
+            mb_ = T.MMA_BF16[0]
+            T.MMA_BF16[0] = False              # fp32 heads (see forward)
+            try:
+                for a, _ in acts:
+                    T.conv_wgrad(dy, a, 0, base, self.cin, 1, 1, 1, 0, Gt, name=self.name + ".wgrad")
+                    base += a.C
+                dx = T.conv_dgrad(dy, wt, H, W, 1, 0, name=self.name + ".dgrad")
+            finally:
+                T.MMA_BF16[0] = mb_
             G = Gt.view(self.KH, self.KW, self.Cout, self.cin).permute(2, 3, 0, 1).contiguous()
             _acc(tape.grads, self.m.weight, G)
-            dx = T.conv_dgrad(dy, wt, H, W, 1, 0, name=self.name + ".dgrad")
             c0 = 0
             for v in srcs:
                 v.add_grad(dx.slice(c0, v.a.C), owned=False)

@@ -302,7 +302,14 @@ def _qconv_sn(sd: SD, p: str, x: Tensor, b, **kw) -> Tensor:
     if q is None or p + ".weight_orig" not in sd:
         return _qconv(x, _sn_weight(sd, p), b, **kw)
     w = sd[p + ".weight_orig"]
-    sigma = spectral_sigma(w, sd[p + ".weight_u"], sd[p + ".weight_v"])
+    u, v = sd[p + ".weight_u"], sd[p + ".weight_v"]
+    if SN_TRAIN["on"]:                      # training mode: one power iteration first (as _sn_weight does)
+        with torch.no_grad():
+            wm = w.reshape(w.shape[0], -1)
+            v = F.normalize(torch.mv(wm.t(), u), dim=0, eps=1e-12)
+            u = F.normalize(torch.mv(wm, v), dim=0, eps=1e-12)
+        SN_TRAIN["uv"][p] = (u.clone(), v.clone())
+    sigma = spectral_sigma(w, u, v)
     y = F.conv2d(q(x), q(w), None, **kw) / sigma
     return y if b is None else y + b.view(1, -1, 1, 1)
 
@@ -382,13 +389,14 @@ def gen_discriminator_forward(sd: SD, inp: Tensor, num_D: int = 2, n_layers_D: i
     for d in range(num_D):
         p = f"discriminator_{d}"
         feats = []
-        h = F.leaky_relu(F.conv2d(inp, sd[p + ".model0.0.weight"], sd[p + ".model0.0.bias"], stride=2, padding=2), 0.2)
+        # (_qconv / _qconv_sn: plain F.conv2d unless QUANT["fn"] emulates the bf16 engine's operand rounding)
+        h = F.leaky_relu(_qconv(inp, sd[p + ".model0.0.weight"], sd[p + ".model0.0.bias"], stride=2, padding=2), 0.2)
         feats.append(h)
         for n in range(1, n_layers_D):
-            h = F.conv2d(h, _sn_weight(sd, f"{p}.model{n}.0.0"), None, stride=2, padding=2)
+            h = _qconv_sn(sd, f"{p}.model{n}.0.0", h, None, stride=2, padding=2)
             h = F.leaky_relu(instance_norm(h), 0.2)
             feats.append(h)
-        h = F.conv2d(h, sd[f"{p}.model{n_layers_D}.0.weight"], sd[f"{p}.model{n_layers_D}.0.bias"], stride=1, padding=2)
+        h = _qconv(h, sd[f"{p}.model{n_layers_D}.0.weight"], sd[f"{p}.model{n_layers_D}.0.bias"], stride=1, padding=2)
         feats.append(h)
         out.append(feats)
         inp = F.avg_pool2d(inp, kernel_size=3, stride=2, padding=[1, 1], count_include_pad=False)

