@@ -66,15 +66,17 @@ def make_generator_inputs(opt, tocg, inputs: Dict[str, torch.Tensor]):
 
 
 def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, crit_vgg, opt_g, opt_d, x, parse7, im,
-                         sync_g=None, sync_d=None):
-    """One G step + one D step of train_generator.py:279-360.  ``parse7``: Act [N,H,W,8] (7 real)."""
+                         sync_g=None, sync_d=None, noise=None, noise_d=None):
+    """One G step + one D step of train_generator.py:279-360.  ``parse7``: Act [N,H,W,8] (7 real).
+    ``noise`` / ``noise_d``: the SPADE noise draws of the two generator forwards (default: drawn like the reference,
+    network_generator.py:104-107); the data-parallel equivalence test injects them."""
     parse_nchw = ops.to_nchw(parse7)
     # ---------------- generator ----------------
     if sync_g is not None:
         sync_g.begin()
     if sync_d is not None:
         sync_d.enabled = False          # D's gradients of the G step are discarded (:354)
-    output_paired = generator(x, parse7)
+    output_paired = generator(x, parse7, noise=noise)
     fake_concat = torch.cat((parse_nchw, output_paired), dim=1)
     real_concat = torch.cat((parse_nchw, im), dim=1)
     discriminator._hrv_discard_param_grads = True      # :354 zeroes D's gradients of loss_gen before they are ever used
@@ -101,7 +103,7 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
         sync_d.enabled = True
         sync_d.begin()
     with torch.no_grad():
-        output = generator(x, parse7)       # new noise, post-update weights (:327-330)
+        output = generator(x, parse7, noise=noise_d)       # new noise, post-update weights (:327-330)
     fake_concat = torch.cat((parse_nchw, output), dim=1)
     pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)
     d_losses = {"D_Fake": crit_gan(pred_fake, False, for_discriminator=True),

@@ -66,6 +66,6 @@ def test_cpu_baseline_parity_and_extra_configs():
     assert t["batch"] == 16 and abs(t["value"] - 16e3 / t["ms_per_step"]) < 0.01 * t["value"]
     assert q["roofline"]["peak"] == 157.3
     qp = q["parity"]
-    assert qp["seg_max_rel_err"] < 1e-3 and qp["argmax_mismatch_pixels"] <= 1e-4 * qp["pixels"]
+    assert qp["seg_max_rel_err"] < 1e-3 and qp["argmax_mismatch_pixels"] <= 2e-5 * qp["pixels"]      # measured: 6 of 786 432
     # every mismatching pixel is a near-tie: the oracle's top-2 logits are within a few hundred fp32 ulps
-    assert all(m <= 4096 for m in qp["mismatch_top2_margin_ulps_of_logit"])
+    assert all(m <= 1024 for m in qp["mismatch_top2_margin_ulps_of_logit"])      # measured <= 286

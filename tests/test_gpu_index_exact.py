@@ -97,8 +97,8 @@ def _ulps(margin, top):
 def test_trained_like_regime_1024x768_margins_in_ulps():
     """tocg (ngf=96, out_layer='relu': non-negative logits with exact zeros) at 256x192 -> parse glue at 1024x768, the
     deployed configuration of test_generator.py.  (a) glue alone on IDENTICAL logits: only the blur's summation order
-    differs -> every mismatch within 64 ulps; (b) end to end vs the oracle: within 4096 ulps (fp32 reassociation
-    through the whole tocg, measured max-rel-err of the logits ~5e-5 = 400 ulps)."""
+    differs -> measured 1 pixel of 1 572 864 at a 4-ulp top-2 margin, bound 8 ulps / 4 pixels; (b) end to end vs the oracle
+    (fp32 reassociation through the whole tocg): measured 2 pixels at <= 8 ulps, bound 32 ulps / 8 pixels."""
     from hr_viton_amd import glue
     opt, m = _tocg()
     g = torch.Generator().manual_seed(11)
@@ -115,16 +115,16 @@ def test_trained_like_regime_1024x768_margins_in_ulps():
     _, lab_h, parse_h = glue.make_parse(seg_h, cm_h, H, W, "warp_grad")
     lab_h = lab_h.cpu()[:, 0]
     lines, checks = [], []
-    for tag, seg_ref, cm_ref, bound in (("glue only, identical logits", seg_h.cpu(), cm_h.cpu(), 64.0),
-                                        ("end to end vs oracle tocg", seg_o, cm_o, 4096.0)):
+    for tag, seg_ref, cm_ref, bound, max_px in (("glue only, identical logits", seg_h.cpu(), cm_h.cpu(), 8.0, 4),
+                                                ("end to end vs oracle tocg", seg_o, cm_o, 32.0, 8)):
         g_ref, lab_ref, _ = O.parse_glue(seg_ref, cm_ref, H, W, "warp_grad")
         bad = lab_h != lab_ref
         top2 = g_ref.topk(2, dim=1).values
         u = _ulps((top2[:, 0] - top2[:, 1])[bad], top2[:, 0][bad])
         lines.append(f"{tag}: {int(bad.sum())} of {bad.numel()} pixels differ; top-2 margin of the differing pixels in "
                      f"ulps of the winning logit: max {float(u.max()) if u.numel() else 0.0:.1f}, "
-                     f"all {[round(float(x), 1) for x in u[:32]]}; bound {bound}")
-        checks.append((bad.sum().item() <= 1e-4 * bad.numel() and (u.numel() == 0 or float(u.max()) <= bound), lines[-1]))
+                     f"all {[round(float(x), 1) for x in u[:32]]}; bound {bound} ulps, {max_px} pixels")
+        checks.append((bad.sum().item() <= max_px and (u.numel() == 0 or float(u.max()) <= bound), lines[-1]))
         lines.append(f"   exact top-2 ties after the blur (first-max rule decides there): "
                      f"{float((top2[:, 0] == top2[:, 1]).float().mean()):.2e} of the pixels")
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
