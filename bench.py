@@ -68,6 +68,7 @@ def summarize(recs, peak_tflops):
         a[3] += by
     mm = [r for r in recs if r[0] in ("conv", "wgrad")]
     sp = [r for r in mm if is_spade_gen_3x3(r[0], r[1])]
+    gb = [r for r in mm if r[1].endswith("[spade_gb]")]      # launches served by hrv::spade_gb_kernel (train_ops.spade_gb_*)
 
     def agg(rows):
         ms = sum(r[4] for r in rows)
@@ -82,7 +83,9 @@ def summarize(recs, peak_tflops):
         gbps = by / (ms * 1e-3) / 1e9
         hbm[k] = {"launches": n, "ms": round(ms, 3), "GBps": round(gbps, 1), "frac_of_6.3TBps": round(gbps / HBM_ACHIEVABLE_GBPS, 3)}
     conv_bytes = sum(r[3] for r in mm)
-    return {"kinds": kinds, "spade": agg(sp), "all": agg(mm), "hbm": hbm,
+    gba = agg(gb)
+    gba["algorithmic_bytes_per_launch"] = sum(r[3] for r in gb) / max(1, len(gb))
+    return {"kinds": kinds, "spade": agg(sp), "all": agg(mm), "hbm": hbm, "gb": gba,
             "conv_alg_bytes_per_launch": conv_bytes / max(1, len(mm)), "conv_launches": len(mm),
             "top": sorted(mm, key=lambda r: -r[4])[:6]}
 
@@ -94,14 +97,19 @@ def dump_launches(path, recs):
                     f"{by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s\n")
 
 
-def load_traffic(tag):
-    """HBM bytes per conv launch from the committed PMC passes of this command (cannot be read in-process)."""
-    for rnd in ("r02", "r01"):
+def load_traffic(tag, family=None):
+    """HBM bytes per launch from the committed PMC passes of this command (cannot be read in-process): of one kernel
+    family (``family``, e.g. "spade_gb_kernel") or averaged over every convolution launch."""
+    for rnd in ("r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{tag}.json")
         if os.path.exists(tp):
             with open(tp) as f:
                 tj = json.load(f)
-            return tj.get("hbm_bytes_per_launch"), f"profiles/{os.path.basename(tp)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            src = f"profiles/{os.path.basename(tp)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+            if family is not None:
+                fam = (tj.get("per_kernel_family") or {}).get(family)
+                return (fam["hbm_bytes_per_launch"], src + f", dispatches of hrv::{family}") if fam else (None, None)
+            return tj.get("hbm_bytes_per_launch"), src
     return None, None
 
 
@@ -212,8 +220,20 @@ def wl_train_condition(ctx, mixed, B):
     batch = tc.synthetic_batch(opt, B, ctx["hdist"].shard_seed(4321, rank), dev)
 
     def step(_i):
+        _T.MMA_BF16[0] = bool(mixed)     # (another workload of this process may have switched it)
         condition_train_step(opt, tocg, D, l1, crit_vgg, gan, og, od, batch, sg, sd)
-    return dict(step=step, B=B, train=True, parity=None, flops_per_img=13.2e12,
+
+    def parity():
+        """one iteration at 1x512x384 ngf=96 (the timed network at a size the CPU autograd pass affords): fp32 and --fp16
+        engines against torch autograd over the oracle; the bf16 gradient is judged against the oracle's own bf16-operand
+        evaluation (tests/test_gpu_fullsize_tocg.py holds the same comparison with its bounds)"""
+        from oracle import step_check
+        try:
+            return step_check.compare_condition_step(512, 384, 96, 1, engines=(False, True) if mixed else (False,),
+                                                     cpu_threads=ctx["cpu_threads"])
+        finally:
+            _T.MMA_BF16[0] = bool(mixed)
+    return dict(step=step, B=B, train=True, parity=parity, flops_per_img=13.2e12,
                 metric="1024x768 images/sec (train_condition.py step: tocg fwd/bwd with batch-stat BN, 5 VGG pairs, LSGAN D, Adam)",
                 workload="BASELINE configs[2]: train_condition.py 1024x768 --Ddownx2 --lasttvonly --interflowloss, ngf=96, "
                          "random-init weights", traffic_tag="train_condition")
@@ -278,19 +298,30 @@ def wl_generator(ctx, mixed, B, train):
                 out["bf16_engine_vs_oracle"] = reps[True]
                 out["tolerance_bf16"] = ("operands carry 8 mantissa bits: image mean-abs 3e-3 (max 3e-2 of the range), loss terms "
                                          "2e-3 rel, gradient cosine >= 0.99 on every sizeable parameter")
+            # the discriminator half of the same iteration (train_generator.py:327-360): D losses, every D gradient, D's Adam step
+            dreps = step_check.compare_discriminator_step(1024, 768, 64, 64, 2, seed=1, mixed=engines, cpu_threads=ctx["cpu_threads"],
+                                                          table_path=os.path.join(gp, "bench_grad_parity_dis.txt"))
+            out["discriminator_half_fp32_engine_vs_oracle"] = dreps[False]
+            if mixed:
+                out["discriminator_half_bf16_engine_vs_oracle"] = dreps[True]
+                out["tolerance_bf16_discriminator"] = ("loss terms 5e-3 rel; gradient no further from the fp32 oracle than the oracle's own "
+                                                       "bf16-operand evaluation (bf16_rounded_oracle_vs_fp32_oracle): cosine within 0.01")
             return out
 
         def cpu_baseline():
             from oracle import step_check
             r = step_check.cpu_train_generator_step(256, 192, 64, 64, 1, "more", repeats=3, warmup=1, threads=ctx["cpu_threads"])
-            return {"value": round(r["images_per_s"], 4), "unit": "images/s", "cores": ctx["cpu_threads"], "kind": "port",
+            # ... and ONE iteration at the metric's own resolution: 1 image 1024x768 'most', no warm-up
+            rf = step_check.cpu_train_generator_step(1024, 768, 64, 64, 1, "most", repeats=1, warmup=0, threads=ctx["cpu_threads"])
+            return {"value": round(rf["images_per_s"], 5), "unit": "images/s", "cores": ctx["cpu_threads"], "kind": "port",
                     "sample": "oracle/step_check.cpu_train_generator_step: the whole train_generator.py iteration (G fwd/bwd, "
-                              "PatchGAN x2, VGG + feat + hinge, Adam x2) on torch-CPU fp32, 1 image 256x192 'more' ngf=64 "
-                              "(BASELINE.md section 4), 1 warm-up + 3 timed, median",
-                    "seconds_per_step": round(r["seconds_per_step_median"], 3),
-                    "scaled_to_1024x768_images_per_s": round(r["images_per_s"] / 16.0, 5),
-                    "scaling_note": "x1/16 by pixel count (conv work is linear in pixels; 'most' adds up_4 on top, so this "
-                                    "over-states the CPU)"}
+                              "PatchGAN x2, VGG + feat + hinge, Adam x2) on torch-CPU fp32, ONE image 1024x768 'most' ngf=64, one "
+                              "timed iteration (the metric's resolution and generator depth)",
+                    "seconds_per_step": round(rf["seconds_per_step_median"], 2),
+                    "at_256x192_more": {"images_per_s": round(r["images_per_s"], 4),
+                                        "seconds_per_step_median": round(r["seconds_per_step_median"], 3),
+                                        "sample": "1 image 256x192 'more' (BASELINE.md section 4), 1 warm-up + 3 timed, median",
+                                        "scaled_to_1024x768_images_per_s": round(r["images_per_s"] / 16.0, 5)}}
         return dict(step=step, B=B, train=True, parity=parity, cpu_baseline=cpu_baseline, flops_per_img=8.8e12,
                     metric="1024x768 try-on images/sec (train_generator.py step: tocg+glue, G fwd/bwd, D fwd/bwd x2, VGG, Adam)",
                     workload="BASELINE configs[3] (SURVEY 8d config #4, headline): train_generator.py 1024x768, "
@@ -338,22 +369,49 @@ def measure(ctx, wl, steps, warmup, mixed, dump=None):
 
 
 def roofline_obj(wl, res, north_star):
+    """north_star workloads (the SPADE generator runs): the object describes ONE launch set end to end -- the dominant
+    kernel, hrv::spade_gb_kernel (gamma|beta 3x3 convolution + modulate, forward and data gradient): achieved / frac from the
+    HIP-event durations of exactly those launches, algorithmic bytes of exactly those launches, HBM traffic of exactly
+    that kernel name from the PMC passes.  `spade_3x3_set` keeps the north-star aggregate of rounds 1-2 (every 3x3
+    convolution launch of the SPADE generator: forward, data and weight gradients)."""
     s = res["summary"]
+    common = {"whole_step_conv_family": s["all"],
+              "end_to_end_TFLOPs_vs_survey_work": round(wl["B"] * wl["flops_per_img"] / (res["dt"] / res["steps"]) / 1e12, 2),
+              "hbm_kinds": s["hbm"],
+              "slowest_launches": [{"name": r[1], "ms": round(r[4], 3), "TFLOPs": round(r[2] / (r[4] * 1e-3) / 1e12, 1)}
+                                   for r in s["top"]]}
+    gb = s["gb"]
+    if north_star and gb["launches"] > 0:
+        traffic, src = load_traffic(wl["traffic_tag"], "spade_gb_kernel")
+        alg = gb["algorithmic_bytes_per_launch"]
+        out = {"bound": "mfma",
+               "kernel": "hrv::spade_gb_kernel -- the SPADE gamma|beta 3x3 convolutions with the modulate epilogue and their data "
+                         "gradients (network_generator.py:117-121), the dominant kernel of the step",
+               "achieved": gb["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": gb["frac"],
+               "launches_per_step": gb["launches"], "ms_per_step": gb["ms_per_step"],
+               "algorithmic_flops_per_launch": gb["flops_per_step"] / max(1, gb["launches"]),
+               "algorithmic_bytes_per_launch": round(alg, 1),
+               "traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (same launch set as achieved / frac)",
+               "traffic_source": src,
+               "wasted_traffic_ratio": round(traffic / alg, 3) if (traffic and alg) else None,
+               "spade_3x3_set": dict(s["spade"], note="every 3x3 convolution launch of the SPADE generator (forward, data and weight "
+                                                      "gradients): the north-star aggregate of rounds 1-2")}
+        out.update(common)
+        return out
     head = s["spade"] if north_star else s["all"]
     traffic, src = load_traffic(wl["traffic_tag"])
-    return {"bound": "mfma",
-            "kernel": ("hrv::conv_mfma_kernel / conv_wgrad_* over the SPADE-generator 3x3 convolutions (fwd+dgrad+wgrad)"
-                       if north_star else "hrv::conv_mfma_kernel / conv_wgrad_* (every convolution launch of the step)"),
-            "achieved": head["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": head["frac"],
-            "launches_per_step": head["launches"], "ms_per_step": head["ms_per_step"],
-            "algorithmic_flops_per_launch": head["flops_per_step"] / max(1, head["launches"]),
-            "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (average over the step's conv launches)",
-            "traffic_source": src, "algorithmic_bytes_per_launch": round(s["conv_alg_bytes_per_launch"], 1),
-            "whole_step_conv_family": s["all"],
-            "end_to_end_TFLOPs_vs_survey_work": round(wl["B"] * wl["flops_per_img"] / (res["dt"] / res["steps"]) / 1e12, 2),
-            "hbm_kinds": s["hbm"],
-            "slowest_launches": [{"name": r[1], "ms": round(r[4], 3), "TFLOPs": round(r[2] / (r[4] * 1e-3) / 1e12, 1)}
-                                 for r in s["top"]]}
+    alg = s["conv_alg_bytes_per_launch"]
+    out = {"bound": "mfma",
+           "kernel": ("hrv::conv_mfma_kernel / conv_wgrad_* over the SPADE-generator 3x3 convolutions (fwd+dgrad+wgrad)"
+                      if north_star else "hrv::conv_mfma_kernel / conv_wgrad_* (every convolution launch of the step)"),
+           "achieved": head["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": head["frac"],
+           "launches_per_step": head["launches"], "ms_per_step": head["ms_per_step"],
+           "algorithmic_flops_per_launch": head["flops_per_step"] / max(1, head["launches"]),
+           "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (average over the step's conv launches)",
+           "traffic_source": src, "algorithmic_bytes_per_launch": round(alg, 1),
+           "wasted_traffic_ratio": round(traffic / alg, 3) if (traffic and alg and not north_star) else None}
+    out.update(common)
+    return out
 
 
 def self_launch(n):
@@ -485,7 +543,9 @@ def main():
         del wl
         torch.cuda.empty_cache()
         for key, name, mx, st in (("config5_tryon_infer_bf16_b16", "tryon_infer", True, 5),
-                                  ("config2_tocg_infer_f32_b4", "tocg_infer", False, 10)):
+                                  ("config2_tocg_infer_f32_b4", "tocg_infer", False, 10),
+                                  ("config3_train_condition_f32_b8", "train_condition", False, 2),
+                                  ("config3_train_condition_fp16_b8", "train_condition", True, 3)):
             from hr_viton_amd import train_ops as _T
             _T.MMA_BF16[0] = False
             _log(f"extra: {key}")

@@ -774,7 +774,7 @@ def spade_gb_forward(actv: Act, x: Act, mean: torch.Tensor, rstd: torch.Tensor, 
         d.g1p, d.g1p_bf16 = g1p.data_ptr(), 1 if g1p.dtype == torch.bfloat16 else 0
     d.act, d.act_slope = act, slope
     d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
-    with ops._Timed("conv", name, flops, nbytes):
+    with ops._Timed("conv", name + " [spade_gb]", flops, nbytes):      # (the tag: bench.py prices this kernel's launches)
         _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[forward]")
 
 
@@ -794,5 +794,5 @@ def spade_gb_dgrad(dgb: Act, packed: torch.Tensor, C_: int, mask: Optional[Act],
     d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
     fl = 2.0 * dgb.N * dgb.H * dgb.W * 2 * C_ * hid * 9
     nb = ops.act_bytes(dgb) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0)
-    with ops._Timed("conv", name, fl, nb):
+    with ops._Timed("conv", name + " [spade_gb]", fl, nb):
         _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[dgrad]")

@@ -60,103 +60,10 @@ def test_tocg_bf16_engine_1024x768_ngf96_vs_quant_oracle():
     assert dis < 2.0 * dis_self + 1e-3, rep["argmax_disagreement"]
 
 
-def _cond_step(mixed, opt, tocg, D, batch):
-    """one condition_train_step on the HIP path; returns (losses, tocg grads, D grads) captured before the optimizer steps"""
-    from hr_viton_amd import networks, pipeline, train_ops as T
-    from hr_viton_amd.losses import L1Loss
-    from hr_viton_amd.optim import Adam
-    opt.fp16 = mixed
-    T.MMA_BF16[0] = bool(mixed)
-    try:
-        og = Adam(tocg.parameters(), lr=0.0002, betas=(0.5, 0.999))
-        od = Adam(D.parameters(), lr=0.0002, betas=(0.5, 0.999))
-        gg, gd = {}, {}
-        sg, sd_ = og.step, od.step
-
-        def step_g():
-            gg.update({n: p.grad.detach().float().cpu().clone() for n, p in tocg.named_parameters() if p.grad is not None})
-            return sg()
-
-        def step_d():
-            gd.update({n: p.grad.detach().float().cpu().clone() for n, p in D.named_parameters() if p.grad is not None})
-            return sd_()
-        og.step, od.step = step_g, step_d
-        losses = pipeline.condition_train_step(opt, tocg, D, L1Loss(), None, networks.GANLoss(use_lsgan=True), og, od,
-                                               {k: v.cuda() for k, v in batch.items()})
-        torch.cuda.synchronize()
-        return {k: float(v.detach()) for k, v in losses.items() if torch.is_tensor(v) and v.numel() == 1}, gg, gd
-    finally:
-        T.MMA_BF16[0] = False
-
-
 def test_train_condition_iteration_512x384_ngf96_fp32_and_fp16_vs_oracle_autograd():
-    import hr_viton_amd  # noqa: F401
-    from hr_viton_amd import networks
-    from oracle.recipes import condstep_build
-    torch.set_num_threads(min(os.cpu_count() or 1, 32))
-    opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D, ngf=96, N=1, H=512, W=384)
-    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, True, False, "warp_grad"
-    opt.edgeawaretv, opt.add_lasttv = "no_edge", False
-    opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
-    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in tocg.state_dict().items()}
-    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
-    r = O.condition_train_losses(sd_g, sd_d, None, batch, occlusion=False, composition="warp_grad", edgeawaretv="no_edge",
-                                 add_lasttv=False)
-    r["loss_G"].backward(retain_graph=True)
-    want_g = {k: v.grad.clone() for k, v in sd_g.items() if v.grad is not None}
-    for v in sd_d.values():
-        v.grad = None
-    r["loss_D"].backward()
-    want_d = {k: v.grad.clone() for k, v in sd_d.items() if v.grad is not None}
-    # the same iteration on the oracle WITH THE ENGINE'S ROUNDING POINTS (bf16 conv operands in the forward, straight-through
-    # in the backward): what a bf16-operand evaluation of this loss does to its (discontinuous) gradient, engine or not
-    for v in list(sd_g.values()) + list(sd_d.values()):
-        v.grad = None
-    O.QUANT["fn"] = lambda t: t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
-    try:
-        rq = O.condition_train_losses(sd_g, sd_d, None, batch, occlusion=False, composition="warp_grad", edgeawaretv="no_edge",
-                                      add_lasttv=False)
-        rq["loss_G"].backward()
-    finally:
-        O.QUANT["fn"] = None
-    wantq_g = {k: v.grad.clone() for k, v in sd_g.items() if v.grad is not None}
-    sd0_g = {k: v.detach().clone() for k, v in tocg.state_dict().items()}
-    sd0_d = {k: v.detach().clone() for k, v in D.state_dict().items()}
-    tocg.cuda().train()
-    D.cuda().train()
-    rep = {}
-    for mixed in (False, True):
-        tocg.load_state_dict(sd0_g)
-        D.load_state_dict(sd0_d)
-        for p_ in list(tocg.parameters()) + list(D.parameters()):
-            p_.grad = None
-        losses, gg, gd = _cond_step(mixed, opt, tocg, D, batch)
-        lerr = {k: abs(losses[k] - float(r[k].detach())) / max(1.0, abs(float(r[k].detach())))
-                for k in ("l1", "tv", "ce", "g_gan", "loss_G", "d_fake", "d_real", "loss_D")}
-
-        def table(got, want):
-            gmax = max(float(w.abs().max()) for w in want.values())
-            rows = []
-            for n, w in want.items():
-                a = got[n]
-                cos = float(torch.nn.functional.cosine_similarity(a.flatten(), w.flatten(), dim=0)) if w.numel() > 1 else 1.0
-                rows.append((float((a - w).abs().max()) / max(float(w.abs().max()), 1e-3 * gmax), cos, float(w.abs().max()), n))
-            rows.sort(reverse=True)
-            sizeable = [x for x in rows if x[2] > 1e-2 * gmax]
-            return rows, dict(worst_rel=rows[0][0], worst=rows[0][3], median_rel=rows[len(rows) // 2][0],
-                              min_cosine=min(x[1] for x in sizeable), n=len(rows))
-        rows_g, sum_g = table(gg, want_g)
-        rows_d, sum_d = table(gd, want_d)
-        rep[mixed] = dict(loss_rel_err=lerr, tocg=sum_g, D=sum_d)
-        if mixed:
-            rep["fp16_engine_vs_bf16_rounded_oracle"] = table(gg, wantq_g)[1]
-            rep["bf16_rounded_oracle_vs_fp32_oracle"] = table(wantq_g, want_g)[1]
-        with open(os.path.join(OUT, "grad_parity_cond_512x384_ngf96_%s.txt" % ("fp16" if mixed else "f32")), "w") as f:
-            f.write(f"# train_condition iteration 1x512x384 ngf=96 engine={'bf16 MFMA' if mixed else 'fp32'}: {rep[mixed]}\n")
-            for x in rows_g:
-                f.write("tocg %.3e %.6f %.3e %s\n" % x)
-            for x in rows_d:
-                f.write("D    %.3e %.6f %.3e %s\n" % x)
+    from oracle import step_check
+    os.makedirs(OUT, exist_ok=True)
+    rep = step_check.compare_condition_step(512, 384, 96, 1, cpu_threads=min(os.cpu_count() or 1, 32), out_dir=OUT)
     with open(os.path.join(OUT, "step_parity_cond_512x384_ngf96.txt"), "w") as f:
         f.write(repr(rep) + "\n")
     f32, f16 = rep[False], rep[True]

@@ -7,7 +7,8 @@ import json
 import re
 import sys
 
-CONV = re.compile(r"hrv::(conv_mfma_kernel|conv_wgrad|conv_patchw)")
+CONV = re.compile(r"hrv::(conv_mfma_kernel|conv_wgrad|conv_patchw|spade_gb_kernel|thin_conv)")
+FAMILIES = ("spade_gb_kernel", "conv_mfma_kernel", "conv_wgrad_tr", "conv_wgrad", "thin_conv", "norm_bwd", "instnorm")
 
 
 def per_kernel(path, counter):
@@ -20,6 +21,22 @@ def per_kernel(path, counter):
     return tot, n
 
 
+def per_family(path, counter):
+    """{family: (counter sum, dispatches)} -- a dispatch is booked to the FIRST family whose name its kernel contains"""
+    out = {}
+    for l in open(path):
+        m = re.match(rf"{counter}\s+([\d.]+)\s+n=\s*(\d+)\s+(.*)", l)
+        if not m:
+            continue
+        for fam in FAMILIES:
+            if fam in m.group(3):
+                a = out.setdefault(fam, [0.0, 0])
+                a[0] += float(m.group(1))
+                a[1] += int(m.group(2))
+                break
+    return out
+
+
 def main(fetch, write, out, cmd):
     f, nf = per_kernel(fetch, "FETCH_SIZE")
     w, nw = per_kernel(write, "WRITE_SIZE")
@@ -29,6 +46,12 @@ def main(fetch, write, out, cmd):
          "units": "counter values are KiB; FETCH_SIZE doubled per MI355X_MICROARCH.md (gfx950 reports 1/2 of wide coalesced 16 B/lane reads)",
          "fetch_KiB_raw_total": f, "write_KiB_total": w, "conv_dispatches": n,
          "hbm_bytes_total": (2.0 * f + w) * 1024.0, "hbm_bytes_per_launch": (2.0 * f + w) * 1024.0 / n}
+    ff, wf = per_family(fetch, "FETCH_SIZE"), per_family(write, "WRITE_SIZE")
+    j["per_kernel_family"] = {fam: {"dispatches": max(ff.get(fam, [0, 0])[1], wf.get(fam, [0, 0])[1]),
+                                    "fetch_KiB_raw": ff.get(fam, [0.0, 0])[0], "write_KiB": wf.get(fam, [0.0, 0])[0],
+                                    "hbm_bytes_per_launch": (2.0 * ff.get(fam, [0.0, 0])[0] + wf.get(fam, [0.0, 0])[0]) * 1024.0 /
+                                    max(1, max(ff.get(fam, [0, 0])[1], wf.get(fam, [0, 0])[1]))}
+                             for fam in FAMILIES if fam in ff or fam in wf}
     with open(out, "w") as fo:
         json.dump(j, fo, indent=1)
     print(json.dumps(j))
