@@ -66,7 +66,7 @@ constexpr int GB_LDS = GB_CB_OFF + 2048;
 constexpr int GB_CV = 80;                      // channels per pass the constant vectors hold
 
 struct GbParams {
-  const void* src; int src_cs, src_co, C; unsigned src_bytes;   // bf16 NHWC source, C % 16 == 0
+  const void* src; int src_cs, src_co, C; unsigned src_bytes;   // bf16 NHWC source, C % 16 == 0; src_bytes: ONE image
   int N, H, W, M;
   const void* wp; unsigned w_bytes;
   int npass;
@@ -107,11 +107,14 @@ static bool gb_plan(int mode, int C, int Cp, int hid, GbPlan& pl) {
     NT = hid / 32;
     Cs = 2 * Cp;
   }
-  int n5 = NT & 1;
-  if ((NT - 5 * n5) < 0 || (NT - 5 * n5) % 4 != 0) return false;
-  const int n4 = (NT - 5 * n5) / 4;
-  if (n4 + n5 > GB_MAXP || n4 + n5 < 1) return false;
-  pl.npass = n4 + n5;
+  // column passes: 4 tiles each, then (NT % 4 == 2) one pass of 2, then (16-channel tail) one pass of 5 = two pairs + the tail
+  const int n5 = NT & 1;
+  const int rest = NT - 5 * n5;
+  if (rest < 0) return false;
+  const int n2 = (rest % 4 == 2) ? 1 : 0;
+  const int n4 = (rest - 2 * n2) / 4;
+  if (n4 + n2 + n5 > GB_MAXP || n4 + n2 + n5 < 1) return false;
+  pl.npass = n4 + n2 + n5;
   pl.nchunk = (Cs + 127) / 128;
   {
     const int last = Cs - 128 * (pl.nchunk - 1);     // the kernel's K-tiles are 64-k halves; a last chunk of 32 runs two-step tiles
@@ -125,9 +128,11 @@ static bool gb_plan(int mode, int C, int Cp, int hid, GbPlan& pl) {
   }
   pl.KT = KT;
   long long off = 0;
+  int t0 = 0;
   for (int i = 0; i < pl.npass; ++i) {
-    pl.ntp[i] = (i == pl.npass - 1 && n5) ? 5 : 4;
-    pl.tile0[i] = 4 * i;
+    pl.ntp[i] = i < n4 ? 4 : (i < n4 + n2 ? 2 : 5);
+    pl.tile0[i] = t0;
+    t0 += pl.ntp[i];
     pl.woff[i] = (unsigned)off;
     off += (long long)KT * pl.ntp[i] * 4096;
   }
@@ -227,7 +232,8 @@ struct GbIssue {
   // instruction the lane offset is (lane constant) + (scalar): no division, nothing worth hoisting.
   static __device__ __forceinline__ void patch_dma(const GbParams& p, unsigned char* smem, int pt_n, int pt_y0, int pt_x0, int chunk,
                                                    int wave, int lane) {
-    const rsrc_t a_rsrc = make_rsrc(p.src, p.src_bytes);
+    // buffer resource of the tile's IMAGE (serving batches of 16 x 1024x768 x 384 channels exceed one 32-bit range)
+    const rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const char*>(p.src) + (size_t)pt_n * p.src_bytes, p.src_bytes);
     const int dma_dx = lane >> 4, dma_s = (lane & 15) ^ (lane >> 4);
     const int kc = p.C - 128 * chunk;
 #pragma unroll 1
@@ -236,7 +242,7 @@ struct GbIssue {
       const int y = pt_y0 - 1 + hy, x = pt_x0 - 1 + i4 + dma_dx;
       const int g = dma_s ^ (i4 & 15);
       const bool ok = (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && g * 8 < kc;
-      const unsigned off = ((unsigned)((pt_n * p.H + y) * p.W + x) * (unsigned)p.src_cs + (unsigned)(p.src_co + chunk * 128 + g * 8)) * 2u;
+      const unsigned off = ((unsigned)(y * p.W + x) * (unsigned)p.src_cs + (unsigned)(p.src_co + chunk * 128 + g * 8)) * 2u;
       dma16(a_rsrc, reinterpret_cast<float*>(smem + u * 1024), ok ? off : 0xFFFFFFF0u, 0u);
     }
   }
@@ -783,8 +789,8 @@ extern "C" int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream) {
   HRV_REQUIRE(d->src && d->w_packed && d->out, "spade_gb: null pointer");
   const int Cs = d->mode == 0 ? d->hid : 2 * d->Cp;
   HRV_REQUIRE(d->src_cstride % 8 == 0 && d->src_coff % 8 == 0 && d->src_coff + Cs <= d->src_cstride, "spade_gb: source slice");
-  const int64_t sbytes = (int64_t)d->N * d->H * d->W * d->src_cstride * 2;
-  HRV_REQUIRE(sbytes < (int64_t)0xFFFFFFF0, "spade_gb: source exceeds the 32-bit buffer range (%lld bytes)", (long long)sbytes);
+  const int64_t sbytes = (int64_t)d->H * d->W * d->src_cstride * 2;      // one image: the kernel addresses the source per image
+  HRV_REQUIRE(sbytes < (int64_t)0xFFFFFFF0, "spade_gb: one image of the source exceeds the 32-bit buffer range (%lld bytes)", (long long)sbytes);
   HRV_REQUIRE((((uintptr_t)d->src | (uintptr_t)d->w_packed | (uintptr_t)d->out) & 15) == 0, "spade_gb: 16-byte alignment");
   GbParams p;
   memset(&p, 0, sizeof(p));
@@ -824,10 +830,15 @@ extern "C" int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream) {
     p.sx = (const float*)d->x; p.sx_cs = d->x_cstride; p.sx_co = d->x_coff; p.sx_f32 = d->x_f32; p.sC = d->stat_stride;
     p.smean = d->mean; p.srstd = d->rstd; p.sz = d->noise_z; p.sns = d->noise_scale; p.bg = d->bias_gamma; p.bb = d->bias_beta;
     p.g1p = d->g1p; p.g1_bf16 = d->g1p_bf16;
-    // the passes of 4 column tiles in one launch, the 5-tile tail pass (16-channel tail) in another
-    const int n4 = pl.ntp[pl.npass - 1] == 5 ? pl.npass - 1 : pl.npass;
-    if (n4 > 0) hipLaunchKernelGGL((spade_gb_kernel<4, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, 0, n4);
-    if (n4 < pl.npass) hipLaunchKernelGGL((spade_gb_kernel<5, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, n4, pl.npass);
+    // the passes of equal width share a launch (the patch stays resident across them): 4-tile passes, a 2-tile pass, the 5-tile tail pass
+    for (int a = 0; a < pl.npass;) {
+      int b = a;
+      while (b < pl.npass && pl.ntp[b] == pl.ntp[a]) ++b;
+      if (pl.ntp[a] == 4) hipLaunchKernelGGL((spade_gb_kernel<4, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+      else if (pl.ntp[a] == 2) hipLaunchKernelGGL((spade_gb_kernel<2, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+      else hipLaunchKernelGGL((spade_gb_kernel<5, 1, false>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+      a = b;
+    }
   } else {
     HRV_REQUIRE(d->out_cstride >= d->out_coff + d->hid, "spade_gb: out slice");
     HRV_REQUIRE(d->mask == nullptr || (d->mask_cstride % 4 == 0 && d->mask_coff % 4 == 0 && ((uintptr_t)d->mask & 7) == 0),

@@ -357,7 +357,10 @@ class BlockT:
         x = ctx["x"]
         norms = self.norms()
         hid = norms[0].hid
-        dact_all = ops.alloc(x.N, x.H, x.W, hid * len(norms), x.t.device)
+        # d(actv) of the block's norms, side by side: read by conv_shared's weight gradient only (matrix cores) -- bf16 in
+        # mixed precision when the tap-expanded label map is (the LDS-DMA weight-gradient kernel then takes both operands)
+        dact_all = ops.alloc(x.N, x.H, x.W, hid * len(norms), x.t.device,
+                             bf16=bool(T.MMA_BF16[0] and ctx["segx"].bf16 and x.W % 4 == 0))
         k0 = 1 if self.learned else 0          # slice order = norms(): [norm_s,] norm_0, norm_1
         d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads)
         # d(conv_0 output) is read by conv_0's weight / data gradient only: bf16 when the mixed-precision plan stores

@@ -590,7 +590,7 @@ int hrv_tv_loss_f32(const float* flow, int32_t N, int32_t H, int32_t W, float* g
  *                      g1p (optional) receives (1 + gamma), dense [pixels][stat_stride], fp32 or bf16.
  *   mode 1 (data gradient): src = [dgamma (Cp) | dbeta (Cp)], bf16 NHWC; out[.., hid] = conv^T * (mask > 0 ? 1 :
  *                      act_slope), mask = actv (bf16) or NULL.
- * Shapes served: hid == 128, C % 32 in {0, 16} with an even number of 32-channel pairs (80, 144, 272, 528; 64, 128, ...),
+ * Shapes served: hid == 128, C % 32 in {0, 16} (32, 64, 80, 128, 144, 272, 528, ...; not 48: one pair + tail),
  * at least 256 tiles (hrv_spade_gb_supported); everything else keeps hrv_conv2d_nhwc_bf16's tiles. */
 typedef struct hrv_spade_gb {
   int32_t mode, N, H, W;

@@ -1,7 +1,8 @@
 """The dedicated SPADE gamma|beta kernel (csrc/spade_gb.hip; network_generator.py:117-121 + the modulate of :120-121 and
 the LeakyReLU of :170-171) against plain torch on the same bf16-rounded operands: forward (SPADE epilogue, (1 + gamma)
 side output) and data gradient (ReLU mask of actv), at the channel counts of the generator's blocks -- 80 (5 column tiles:
-two pairs + the 16-channel tail), 144 (two launches: 4-tile passes + the 5-tile tail pass), 64 / 128 (pairs only) -- on
+two pairs + the 16-channel tail), 144 (two launches: 4-tile passes + the 5-tile tail pass), 64 / 128 (pairs only), 32 / 96
+(a 2-tile pass) -- on
 extents that are not multiples of the 16x16 tile and with more tiles than CUs (persistent loop)."""
 import pytest
 import torch
@@ -25,7 +26,7 @@ def _mk(N, H, W, C_, seed, cs_mult=1):
 
 
 @pytest.mark.parametrize("C_,N,H,W,cs_mult", [(80, 1, 250, 270, 3), (144, 2, 96, 112, 1), (64, 1, 128, 144, 2), (128, 1, 70, 50, 1),
-                                                (272, 1, 40, 48, 1)])
+                                                (272, 1, 40, 48, 1), (32, 1, 64, 80, 1), (96, 1, 48, 64, 2)])
 def test_forward_matches_torch_on_bf16_rounded_operands(C_, N, H, W, cs_mult):
     ops, actv, wg, wb, g, dev, hid = _mk(N, H, W, C_, 1, cs_mult)
     from hr_viton_amd import train_ops as T

@@ -14,7 +14,7 @@ from hr_viton_amd import ops, train_ops as T  # noqa: E402
 from hr_viton_amd.gen_train import SpadeT  # noqa: E402
 from hr_viton_amd.network_generator import SPADENorm  # noqa: E402
 
-SHAPES = [("up_4.norm_0", 80, 4, 1024, 768), ("up_3.norm_0", 144, 4, 512, 384), ("up_3.norm_1", 64, 4, 512, 384),
+SHAPES = [("up_4.norm_0", 80, 4, 1024, 768), ("up_4.norm_1", 32, 4, 1024, 768), ("up_3.norm_0", 144, 4, 512, 384), ("up_3.norm_1", 64, 4, 512, 384),
           ("up_2.norm_0", 272, 4, 256, 192)]
 
 
