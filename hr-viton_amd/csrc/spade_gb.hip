@@ -576,53 +576,55 @@ __device__ __forceinline__ void gb_pass(const GbParams& p, const int pass, unsig
       }
     }
   };
+  // ---- bf16 staging shared by both epilogues: the two 32-pixel halves of the wave go through the scratch TOGETHER (two
+  // buffers of 32 rows x 64 B + pad), rows leave 16 bytes (8 channels) per lane along the channels
+  typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
+  unsigned char* const sb0 = smem + GB_PATCH_B + 2 * GB_SBMAX + wave * 5120;
+  static_assert(4 * 5120 <= GB_SBMAX, "epilogue scratch fits one ring stage");
+  constexpr int RS = 80;                     // scratch row stride in bytes (32 bf16 channels + 16)
+  // pixel (in-image index, or -1) of the scratch rows this lane stores: 4-group rows (lane >> 2) + 16 k, 2-group rows lane >> 1
+  int pp4[2][2], pp2[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      const int r = (lane_e >> 2) + 16 * k;
+      const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
+      pp4[i][k] = (y < p.H && x < p.W) ? y * p.W + x : -1;
+    }
+    const int r = lane_e >> 1;
+    const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
+    pp2[i] = (y < p.H && x < p.W) ? y * p.W + x : -1;
+  }
+  // scratch rows of both halves -> global: 16 bytes (8 channels) per lane, along the channels
+  auto rows_out = [&](auto ng_c, const rsrc_t rs, const int dcs, const int dco) {
+    constexpr int NG = decltype(ng_c)::value;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const unsigned char* sb = sb0 + i * 2560;
+      if constexpr (NG == 4) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+          const int r = (lane_e >> 2) + 16 * k, kk = lane_e & 3;
+          const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * RS + kk * 16);
+          gb_store16(v, rs, pp4[i][k] < 0 ? 0xFFFFFFF0u : (unsigned)(pp4[i][k] * dcs + dco + kk * 8) * 2u);
+        }
+      } else {
+        const int r = lane_e >> 1, kk = lane_e & 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * RS + kk * 16);
+        gb_store16(v, rs, pp2[i] < 0 ? 0xFFFFFFF0u : (unsigned)(pp2[i] * dcs + dco + kk * 8) * 2u);
+      }
+    }
+  };
   if constexpr (EPI == 1) {
     // Both outputs are bf16 (the activation feeds matrix cores and its own LeakyReLU mask; (1 + gamma) is read once, by
     // the normalisation backward).  The two 32-pixel halves of the wave go through the scratch TOGETHER (two buffers of
     // 32 rows x 64 B + pad): a group's LDS write -> read -> store chain is exposed once per group, not once per half,
     // and the per-channel constants are fetched once for both.
-    typedef __bf16 bf16x4v __attribute__((ext_vector_type(4)));
-    unsigned char* const sb0 = smem + GB_PATCH_B + 2 * GB_SBMAX + wave * 5120;
-    static_assert(4 * 5120 <= GB_SBMAX, "epilogue scratch fits one ring stage");
-    constexpr int RS = 80;                     // scratch row stride in bytes (32 bf16 channels + 16)
     const rsrc_t g_rsrc = make_rsrc(reinterpret_cast<const char*>(p.g1p) + (size_t)pt_n * img_px * p.sC * 2,
                                     p.g1p ? (unsigned)(img_px * p.sC * 2) : 0u);
     // act(v) = max(v, v * sl): LeakyReLU (sl = slope), ReLU (0), none (1) -- the SPADE sites use LeakyReLU / none
     const float sl = p.act == HRV_ACT_LRELU ? p.slope : (p.act == HRV_ACT_RELU ? 0.f : 1.f);
-    // pixel (in-image index, or -1) of the scratch rows this lane stores: 4-group rows (lane >> 2) + 16 k, 2-group rows lane >> 1
-    int pp4[2][2], pp2[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        const int r = (lane_e >> 2) + 16 * k;
-        const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
-        pp4[i][k] = (y < p.H && x < p.W) ? y * p.W + x : -1;
-      }
-      const int r = lane_e >> 1;
-      const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
-      pp2[i] = (y < p.H && x < p.W) ? y * p.W + x : -1;
-    }
-    // scratch rows of both halves -> global: 16 bytes (8 channels) per lane, along the channels
-    auto rows_out = [&](auto ng_c, const rsrc_t rs, const int dcs, const int dco) {
-      constexpr int NG = decltype(ng_c)::value;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const unsigned char* sb = sb0 + i * 2560;
-        if constexpr (NG == 4) {
-#pragma unroll
-          for (int k = 0; k < 2; ++k) {
-            const int r = (lane_e >> 2) + 16 * k, kk = lane_e & 3;
-            const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * RS + kk * 16);
-            gb_store16(v, rs, pp4[i][k] < 0 ? 0xFFFFFFF0u : (unsigned)(pp4[i][k] * dcs + dco + kk * 8) * 2u);
-          }
-        } else {
-          const int r = lane_e >> 1, kk = lane_e & 1;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(sb + r * RS + kk * 16);
-          gb_store16(v, rs, pp2[i] < 0 ? 0xFFFFFFF0u : (unsigned)(pp2[i] * dcs + dco + kk * 8) * 2u);
-        }
-      }
-    };
     // NG * 8 channels starting at local channel lc0: modulate, stage, store the activation, then (1 + gamma)
     auto group = [&](const int lc0, auto ng_c, auto&& gam, auto&& bet, auto&& xin) {
       constexpr int NG = decltype(ng_c)::value;
@@ -671,23 +673,42 @@ __device__ __forceinline__ void gb_pass(const GbParams& p, const int pass, unsig
             [&](int i, int g) { return gb_acc4(acc[i][NTP - 1], g + 2); }, [&](int i, int g) { return xt[i][g]; });
   } else {
     using G4 = std::integral_constant<int, 4>;
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
+    if (!p.out_f32) {
+      // bf16 d(actv) (its only reader is conv_shared's weight gradient): both halves staged together
 #pragma unroll
       for (int j = 0; j < NTP; ++j) {
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          f32x4 v;
+        for (int g = 0; g < 4; ++g)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float a = acc[i][j][4 * g + e];
-            if (p.mask) a = bf2f(mv[i][j][g][e]) > 0.f ? a : a * p.slope;
-            v[e] = a;
+          for (int i = 0; i < 2; ++i) {
+            f32x4 v = gb_acc4(acc[i][j], g);
+            if (p.mask) {
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[e] = bf2f(mv[i][j][g][e]) > 0.f ? v[e] : v[e] * p.slope;
+            }
+            *reinterpret_cast<bf16x4v*>(sb0 + i * 2560 + l31e * RS + 16 * g + 8 * lhe) = __builtin_convertvector(v, bf16x4v);
           }
-          *reinterpret_cast<f32x4*>(scr + l31e * SCS + 8 * g + 4 * lhe) = v;
-        }
-        copy_out(i, G4{}, o_rsrc, p.out_cs, p.out_co + (tile0 + j) * 32, p.out_f32 != 0);
+        rows_out(G4{}, o_rsrc, p.out_cs, p.out_co + (tile0 + j) * 32);
       }
+    } else {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < NTP; ++j) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4 v;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float a = acc[i][j][4 * g + e];
+              if (p.mask) a = bf2f(mv[i][j][g][e]) > 0.f ? a : a * p.slope;
+              v[e] = a;
+            }
+            *reinterpret_cast<f32x4*>(scr + l31e * SCS + 8 * g + 4 * lhe) = v;
+          }
+          copy_out(i, G4{}, o_rsrc, p.out_cs, p.out_co + (tile0 + j) * 32, true);
+        }
+    }
   }
   if (p.tlog && tid == 0 && last) p.tlog[(size_t)bid * 8 + 6] = wall_clock64();      // every store of the tile is issued
   // (the caller's next gb_pass waits vmcnt(0) + barrier before touching the ring: this pass's scratch reads are done then)

@@ -48,7 +48,7 @@ def main():
         actv = ops.Act(actv_all, 128, 128)
         z = torch.randn(N, W, H, 1, device="cuda")
         dgb = ops.Act(torch.randn(N, H, W, 2 * Cc, device="cuda").to(torch.bfloat16), 2 * Cc)
-        dact_all = torch.empty(N, H, W, 384, device="cuda")
+        dact_all = torch.empty(N, H, W, 384, device="cuda", dtype=torch.bfloat16)      # bf16 d(actv), as in the mixed-precision plan
         dact = ops.Act(dact_all, 128, 128)
         wpair = (norm.conv_gamma.weight.data, norm.conv_beta.weight.data)
 
