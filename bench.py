@@ -108,7 +108,10 @@ def load_traffic(tag, family=None):
             src = f"profiles/{os.path.basename(tp)} (rocprofv3 FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
             if family is not None:
                 fam = (tj.get("per_kernel_family") or {}).get(family)
-                return (fam["hbm_bytes_per_launch"], src + f", dispatches of hrv::{family}") if fam else (None, None)
+                if not fam or not fam.get("hbm_bytes_per_step"):
+                    return None, None
+                # bytes of the family per STEP: the caller divides by its own launch count (a layer may take two dispatches)
+                return fam["hbm_bytes_per_step"], src + f", dispatches of hrv::{family}, per step"
             return tj.get("hbm_bytes_per_launch"), src
     return None, None
 
@@ -382,7 +385,8 @@ def roofline_obj(wl, res, north_star):
                                    for r in s["top"]]}
     gb = s["gb"]
     if north_star and gb["launches"] > 0:
-        traffic, src = load_traffic(wl["traffic_tag"], "spade_gb_kernel")
+        per_step, src = load_traffic(wl["traffic_tag"], "spade_gb_kernel")
+        traffic = per_step / gb["launches"] if per_step else None
         alg = gb["algorithmic_bytes_per_launch"]
         out = {"bound": "mfma",
                "kernel": "hrv::spade_gb_kernel -- the SPADE gamma|beta 3x3 convolutions with the modulate epilogue and their data "

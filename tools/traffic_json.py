@@ -52,6 +52,13 @@ def main(fetch, write, out, cmd):
                                     "hbm_bytes_per_launch": (2.0 * ff.get(fam, [0.0, 0])[0] + wf.get(fam, [0.0, 0])[0]) * 1024.0 /
                                     max(1, max(ff.get(fam, [0, 0])[1], wf.get(fam, [0, 0])[1]))}
                              for fam in FAMILIES if fam in ff or fam in wf}
+    # the profiled command runs warm-up + timed + ONE per-launch-profiled step (bench.py measure()): --steps 1 --warmup 1 -> 3
+    m = re.search(r"--steps (\d+) --warmup (\d+)", cmd)
+    steps = (int(m.group(1)) + int(m.group(2)) + 1) if m else None
+    j["steps_in_the_profiled_run"] = steps
+    if steps:
+        for fam, v in j["per_kernel_family"].items():
+            v["hbm_bytes_per_step"] = v["hbm_bytes_per_launch"] * v["dispatches"] / steps
     with open(out, "w") as fo:
         json.dump(j, fo, indent=1)
     print(json.dumps(j))
