@@ -30,8 +30,10 @@ static inline int grid_for(size_t work, int block = 256) {
 // contiguous run of the tile's pixels (coalesced); the [64][65] LDS tile absorbs the stride change.
 constexpr int LT_P = 64, LT_C = 64;
 
+// ``zpad`` > 0: the destination is a whole channel-padded tensor (co == 0, cs == C + zpad): the pad channels are
+// written as zeros here (the conv engine requires them to read as zero) instead of by a fill of the entire tensor.
 __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, int N, int C, int HW,
-                                                           float* __restrict__ out, int cs, int co) {
+                                                           float* __restrict__ out, int cs, int co, int zpad) {
   __shared__ float tile[LT_P][LT_C + 1];
   const int tiles_per_img = (HW + LT_P - 1) / LT_P;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -47,6 +49,8 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         const int p = i / nc, c = i - p * nc;
         out[((size_t)n * HW + p0 + p) * cs + co + c0 + c] = tile[p][c];
       }
+      if (zpad > 0 && c0 + nc == C)
+        for (int i = threadIdx.x; i < np * zpad; i += 256) out[((size_t)n * HW + p0 + i / zpad) * cs + C + i % zpad] = 0.f;
       __syncthreads();
     }
   }
@@ -75,7 +79,7 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float* __restri
 }
 
 __global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ in, int N, int C, int HW,
-                                            unsigned short* __restrict__ out, int cs, int co) {
+                                            unsigned short* __restrict__ out, int cs, int co, int zpad) {
   const size_t total = (size_t)N * HW;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t n = i / HW, hw = i - n * HW;
@@ -86,6 +90,7 @@ __global__ void nchw_f32_to_nhwc_bf16_kernel(const float* __restrict__ in, int N
       u += 0x7fffu + ((u >> 16) & 1u);
       dst[c] = (unsigned short)(u >> 16);
     }
+    for (int c = 0; c < zpad; ++c) dst[C + c] = 0;
   }
 }
 
@@ -293,7 +298,8 @@ extern "C" int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32
   (void)total;
   const size_t tiles = (size_t)N * (((size_t)H * W + LT_P - 1) / LT_P);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)(tiles > 16384 ? 16384 : tiles)), dim3(256), 0,
-                     (hipStream_t)stream, in, N, C, H * W, out, out_cstride, out_coff);
+                     (hipStream_t)stream, in, N, C, H * W, out, out_cstride, out_coff,
+                     (out_coff == 0 && out_cstride - C < 4) ? out_cstride - C : 0);
   return check_launch("nchw_to_nhwc_kernel");
 }
 
@@ -315,7 +321,7 @@ extern "C" int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, 
   HRV_REQUIRE(out_coff >= 0 && out_coff + C <= out_cstride, "nchw_f32_to_nhwc_bf16: slice out of range");
   const size_t total = (size_t)N * H * W;
   hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, C,
-                     H * W, out, out_cstride, out_coff);
+                     H * W, out, out_cstride, out_coff, (out_coff == 0 && out_cstride - C < 8) ? out_cstride - C : 0);
   return check_launch("nchw_f32_to_nhwc_bf16_kernel");
 }
 

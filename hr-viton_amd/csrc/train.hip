@@ -45,6 +45,7 @@ struct NormBwdParams {
   int NB; float* part;                       // [N][NB][C][2]
   int dgb_bf16, out_bf16;                    // storage of dgb / out: bf16 when only matrix cores (and this mask) read them
   int g1p_bf16;                              // (1 + gamma) stored as bf16 (the dedicated gamma|beta kernel writes it so)
+  int dnh_bf16;                              // dnh (stage 1 -> stage 2) stored as bf16
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
           const size_t ge1 = pix * p.g_cs + p.g_co + g * 4;
           dnh *= p.g1p_bf16 ? ld4_bf16(p.g1p, ge1) : ld4(p.g1p + ge1);
         }
-        *reinterpret_cast<f32x4*>(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) = dnh;
+        if (p.dnh_bf16) st4_bf16(p.dnh, pix * p.dn_cs + p.dn_co + g * 4, dnh);
+        else *reinterpret_cast<f32x4*>(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) = dnh;
         if (p.dgb) {
           const size_t ge = pix * p.dgb_cs + p.dgb_co + g * 4;
           if (p.dgb_bf16) {
@@ -155,7 +157,7 @@ struct NormBwd2Params {
   const float* x; int x_cs, x_co;
   const float* z; const float* ns;
   const float* mean; const float* rstd; const float* m1; const float* m2;
-  const float* dnh; int dn_cs, dn_co;
+  const float* dnh; int dn_cs, dn_co; int dnh_bf16;
   float* dx; int dx_cs, dx_co; int accumulate;
   int dx_bf16;
   int N, H, W, C4;
@@ -188,7 +190,8 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
           v += zz * ns4;
         }
         const f32x4 nh = (v - mu) * rs;
-        f32x4 d = rs * (ld4(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) - a1 - nh * a2);
+        const size_t de = pix * p.dn_cs + p.dn_co + g * 4;
+        f32x4 d = rs * ((p.dnh_bf16 ? ld4_bf16(p.dnh, de) : ld4(p.dnh + de)) - a1 - nh * a2);
         sz += d * zz;
         if (p.dx_bf16) {
           st4_bf16(p.dx, pix * p.dx_cs + p.dx_co + g * 4, d);
@@ -828,7 +831,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
   p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff; p.g1p_bf16 = d->g1p_bf16;
   p.dout = d->dout; p.do_cs = d->dout_cstride; p.do_co = d->dout_coff;
-  p.dnh = d->dnh; p.dn_cs = d->dnh_cstride; p.dn_co = d->dnh_coff;
+  p.dnh = d->dnh; p.dn_cs = d->dnh_cstride; p.dn_co = d->dnh_coff; p.dnh_bf16 = d->dnh_bf16;
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;
   p.dgb_bf16 = d->dgb_bf16; p.out_bf16 = d->out_bf16;
@@ -841,7 +844,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   NormBwd2Params q;
   q.x = d->x; q.x_cs = d->x_cstride; q.x_co = d->x_coff; q.z = d->noise_z; q.ns = d->noise_scale;
   q.mean = d->mean; q.rstd = d->rstd; q.m1 = m1; q.m2 = m2;
-  q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff;
+  q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff; q.dnh_bf16 = d->dnh_bf16;
   q.dx = d->dx; q.dx_cs = d->dx_cstride; q.dx_co = d->dx_coff; q.accumulate = d->dx_accumulate;
   q.dx_bf16 = d->dx_bf16;
   HRV_REQUIRE(!(d->dx_bf16 && d->dx_accumulate), "norm_bwd: a bf16 dx cannot be accumulated into");

@@ -104,7 +104,7 @@ class TConv:
 
     def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
                  act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True, dx_bf16: bool = False,
-                 dy_wgrad: Optional[Act] = None) -> Optional[Act]:
+                 dy_wgrad: Optional[Act] = None, add: Optional[Act] = None) -> Optional[Act]:
         """``dy_wgrad``: a bf16 copy of ``dy`` for the weight gradient (so a bf16-stored source takes the LDS-DMA kernel)."""
         w = self.wparam.data
         Cout, cin, KH, KW = w.shape
@@ -130,7 +130,7 @@ class TConv:
         a0, up0 = srcs[0]
         H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
         return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope,
-                            name=self.name + ".dgrad", out_bf16=dx_bf16)
+                            name=self.name + ".dgrad", out_bf16=dx_bf16, add=add)
 
 
 class SpadeT:
@@ -588,13 +588,14 @@ class DiscTrainPlan:
                 return a
             return Act(a.t[:rows], a.C, a.coff) if isinstance(a, Act) else a[:rows]
         d_next: Optional[Act] = None   # gradient flowing back into feats[i] from layer i+1
+        tap_in_dnext = False           # dfeats[i] already summed into d_next by layer i+1's data-gradient epilogue
         for i in range(len(self.layers) - 1, -1, -1):
             kind, conv = self.layers[i]
             c = {k: cut(v) for k, v in ctx[i].items()}
             d = dfeats[i]
             if d is None and d_next is None:
                 continue
-            if d is None:
+            if d is None or tap_in_dnext:
                 d = d_next
             elif d_next is not None:
                 T.add_slice(d_next, d, True)
@@ -607,7 +608,11 @@ class DiscTrainPlan:
                 d_c = d
             else:
                 d_c = d
-            d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx), need_w=need_w)
+            # the feature-matching gradient of this layer's INPUT feature rides along with the data gradient
+            tap = dfeats[i - 1] if i > 0 else None
+            tap_in_dnext = tap is not None and tap.t.dtype == torch.float32 and tap.t.shape[:3] == c["src"].t.shape[:3]
+            d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx), need_w=need_w,
+                                   add=tap if tap_in_dnext else None)
         return d_next
 
 
@@ -726,8 +731,9 @@ class _DiscFn(torch.autograd.Function):
         if need_dx and d_in is not None:
             d_inp = ops.to_nchw(d_in)
             if rows is not None:      # the real half of the input gets a zero gradient
-                full = torch.zeros(ctx.in_shape, dtype=d_inp.dtype, device=d_inp.device)
+                full = torch.empty(ctx.in_shape, dtype=d_inp.dtype, device=d_inp.device)
                 full[:rows] = d_inp
+                full[rows:].zero_()       # (only the half that needs it is filled)
                 d_inp = full
         return (None, None, d_inp, None) + tuple(grads.get(p) for p in ctx.params)
 

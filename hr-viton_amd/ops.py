@@ -137,7 +137,8 @@ def to_nhwc(x: torch.Tensor, out: Optional[Act] = None, bf16: bool = False) -> A
     x = x.contiguous()
     N, Cc, H, W = x.shape
     if out is None:
-        out = alloc(N, H, W, Cc, x.device, bf16)
+        # (the converter writes the pad channels as zeros itself: no fill of the whole tensor)
+        out = Act(torch.empty((N, H, W, _cpad(Cc, bf16)), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device), Cc, 0)
     lib = _lib.load()
     with _Timed("layout", "nchw_to_nhwc", 0.0, 4.0 * x.numel() + act_bytes(out, Cc)):
         if out.bf16:

@@ -272,11 +272,14 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
 
 def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
                sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
-               name: str = "dgrad", out_bf16: bool = False, frozen=None) -> Act:
+               name: str = "dgrad", out_bf16: bool = False, frozen=None, add: Optional[Act] = None) -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
     activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x).
-    ``w`` may be a PAIR (w_gamma, w_beta) for dY = [dgamma | dbeta] (stride 1): packed without a concatenated copy."""
+    ``w`` may be a PAIR (w_gamma, w_beta) for dY = [dgamma | dbeta] (stride 1): packed without a concatenated copy.
+    ``add`` (instead of ``act_mask``): a second gradient of the same tensor, summed in the epilogue (the feature-matching
+    tap gradient of a PatchGAN feature joins the gradient flowing down through it: no separate accumulation pass)."""
     lib = _lib.load()
+    assert add is None or act_mask is None, "conv_dgrad: one residual slot (mask or addend)"
     pair = w if isinstance(w, (tuple, list)) else None
     if pair is not None:
         assert stride == 1 and sigma is None and wscale == 1.0
@@ -291,8 +294,10 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         out = ops.alloc(N, H, W, cin, dy.t.device, bf16=out_bf16 and mb and cin % 8 == 0 and stride == 1)
     cfg = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * H * W, cin)
     res_mode = 1 if act_mask is not None else 0
+    if add is not None:
+        act_mask = add           # (the engine's residual slot: res_mode 0 adds it)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
-    if (pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
+    if (add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
     if stride == 1:
@@ -385,7 +390,8 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
         # ``dx_bf16``: the gradient of a convolution OUTPUT that only that convolution's backward reads (matrix cores)
         dx = ops.alloc(N, H, W, x.C, dev, bf16=dx_bf16 and x.C % 8 == 0)
         dx_accumulate = False
-    dnh = torch.empty((N, H, W, Cp), dtype=torch.float32, device=dev)
+    # stage 1 -> stage 2 intermediate: bf16 in mixed precision (written once, read once: 4 of the ~34 bytes per element)
+    dnh = torch.empty((N, H, W, Cp), dtype=torch.bfloat16 if MMA_BF16[0] else torch.float32, device=dev)
     dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.bfloat16 if dgb_bf16 else torch.float32, device=dev),
               2 * Cp) if want_dgb else None
     ws = torch.empty(lib.hrv_norm_bwd_workspace_elems(N, H, W, Cp), dtype=torch.float32, device=dev)
@@ -403,6 +409,7 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
         d.g1p_bf16 = 1 if g1p.bf16 else 0
     d.dout, d.dout_cstride, d.dout_coff = dout.t.data_ptr(), dout.cstride, dout.coff
     d.dnh, d.dnh_cstride, d.dnh_coff = dnh.data_ptr(), Cp, 0
+    d.dnh_bf16 = 1 if dnh.dtype == torch.bfloat16 else 0
     if dgb is not None:
         d.dgb, d.dgb_cstride, d.dgb_coff = dgb.t.data_ptr(), 2 * Cp, 0
         d.dgb_bf16 = 1 if dgb.bf16 else 0

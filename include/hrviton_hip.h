@@ -254,6 +254,8 @@ typedef struct hrv_norm_bwd {
   int32_t dx_bf16;    /* 1: `dx` is stored as bf16 (no accumulate): the gradient of a convolution output that only
                        *    that convolution's weight / data gradient (matrix cores) read                          */
   int32_t g1p_bf16;   /* 1: `g1p` is stored as bf16 (written by hrv_spade_gb_bf16; this kernel is its only reader) */
+  int32_t dnh_bf16;   /* 1: the stage-1 -> stage-2 intermediate `dnh` is stored as bf16 (mixed precision: half its bytes) */
+  int32_t _pad_nb2;
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 
@@ -433,6 +435,8 @@ int hrv_occlusion_nhwc_f32(const float* g, int32_t g_cstride, int32_t nclass, fl
 
 /* ------------------------------------------------------------------------
  * Layout converters at the module boundary (the reference's tensors are NCHW).
+ * NCHW -> NHWC into a WHOLE channel-padded tensor (out_coff == 0, out_cstride - C < one 16-byte group): the pad
+ * channels are written as zeros by the converter (the conv engine requires zero pads; no separate fill).
  * ---------------------------------------------------------------------- */
 int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, float* out,
                          int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
