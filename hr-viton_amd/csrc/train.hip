@@ -226,6 +226,7 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, 
   float s = 0.f;
   const int mode = mode_flags & 15;
   const bool relu_mask = (mode_flags & 16) != 0;   // a = ReLU(pre): the gradient is handed back w.r.t. pre (x (a > 0))
+  const bool grad_bf16 = (mode_flags & 32) != 0;   // the gradient is stored as bf16 (its readers: matrix cores, pool backward)
   auto term = [&](float x, float y, float& g) -> float {
     float l;
     if (mode == 0) { const float d = x - y; l = fabsf(d); g = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f); }
@@ -260,7 +261,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, 
       s += term(x4[e], y4[e], g);
       g4[e] = g;
     }
-    if (grad) *reinterpret_cast<f32x4*>(grad + 4 * i) = g4;
+    if (grad) {
+      if (grad_bf16) st4_bf16(grad, 4 * i, g4);
+      else *reinterpret_cast<f32x4*>(grad + 4 * i) = g4;
+    }
   }
   for (size_t i = 4 * n4 + (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
     float x, y = 0.f, g;
@@ -272,7 +276,10 @@ __global__ __launch_bounds__(256) void loss_kernel(const float* __restrict__ a, 
       if (b) y = b[i];
     }
     s += term(x, y, g);
-    if (grad) grad[i] = g;
+    if (grad) {
+      if (grad_bf16) reinterpret_cast<unsigned short*>(grad)[i] = (unsigned short)(__builtin_bit_cast(unsigned, __builtin_bit_cast(unsigned, g) + 0x7fffu + ((__builtin_bit_cast(unsigned, g) >> 16) & 1u)) >> 16);
+      else grad[i] = g;
+    }
   }
   red[threadIdx.x] = s;
   __syncthreads();
@@ -452,7 +459,9 @@ __global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int 
   }
 }
 
-template <bool XB>
+// XB: x is bf16-stored; GB: dy and dx are bf16-stored too (mixed-precision VGG backward: gradients that only matrix cores
+// and this routing read)
+template <bool XB, bool GB = false>
 __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy, int N, int Ho, int Wo,
                                     int C4, int xcs, int ycs, float* __restrict__ dx, int relu) {
   const size_t total = (size_t)N * Ho * Wo * C4;
@@ -466,7 +475,7 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
     const size_t base = (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
     const size_t o01 = xcs, o10 = (size_t)2 * Wo * xcs, o11 = o10 + xcs;
     const f32x4 a = ldg4<XB>(x, base), b = ldg4<XB>(x, base + o01), c = ldg4<XB>(x, base + o10), d = ldg4<XB>(x, base + o11);
-    const f32x4 gy = ld4(dy + pix * ycs + g * 4);
+    const f32x4 gy = GB ? ld4_bf16(dy, pix * ycs + g * 4) : ld4(dy + pix * ycs + g * 4);
     f32x4 ga = (f32x4)(0.f), gb = ga, gc = ga, gd = ga;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
@@ -477,10 +486,28 @@ __global__ void maxpool2_bwd_kernel(const float* __restrict__ x, const float* __
       else if (c[e] == m) gc[e] = gv;
       else gd[e] = gv;
     }
-    *reinterpret_cast<f32x4*>(dx + base) = ga;
-    *reinterpret_cast<f32x4*>(dx + base + o01) = gb;
-    *reinterpret_cast<f32x4*>(dx + base + o10) = gc;
-    *reinterpret_cast<f32x4*>(dx + base + o11) = gd;
+    if constexpr (GB) {
+      st4_bf16(dx, base, ga); st4_bf16(dx, base + o01, gb); st4_bf16(dx, base + o10, gc); st4_bf16(dx, base + o11, gd);
+    } else {
+      *reinterpret_cast<f32x4*>(dx + base) = ga;
+      *reinterpret_cast<f32x4*>(dx + base + o01) = gb;
+      *reinterpret_cast<f32x4*>(dx + base + o10) = gc;
+      *reinterpret_cast<f32x4*>(dx + base + o11) = gd;
+    }
+  }
+}
+
+// out (+)= a over bf16-stored tensors (fp32 sum, one rounding)
+__global__ void add_slice_bf16_kernel(const unsigned short* __restrict__ a, int acs, int aco, unsigned short* __restrict__ out,
+                                      int ocs, int oco, int C4, size_t npix, int accumulate) {
+  const size_t total = npix * C4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    f32x4 v = ld4_bf16(a, pix * acs + aco + g * 4);
+    const size_t oe = pix * ocs + oco + g * 4;
+    if (accumulate) v += ld4_bf16(out, oe);
+    st4_bf16(out, oe, v);
   }
 }
 
@@ -877,7 +904,7 @@ extern "C" int hrv_loss_f32(const float* a, const float* b, int64_t n, int32_t m
 // the same over bf16-stored a and b (mixed-precision VGG taps); loss and gradient stay fp32
 extern "C" int hrv_loss_bf16in_f32(const uint16_t* a, const uint16_t* b, int64_t n, int32_t mode, float lscale, float gscale,
                                    float* grad, float* workspace, float* loss_out, int32_t accumulate, hrv_stream_t stream) {
-  HRV_REQUIRE(a && workspace && loss_out && n > 0 && mode >= 0 && (mode & 15) <= 4 && (mode & ~31) == 0, "loss_bf16in: bad args");
+  HRV_REQUIRE(a && workspace && loss_out && n > 0 && mode >= 0 && (mode & 15) <= 4 && (mode & ~63) == 0, "loss_bf16in: bad args");
   HRV_REQUIRE(((mode & 15) != 0 && (mode & 15) != 4) || b, "loss_bf16in: mode needs a target tensor");
   const int nb = grid_for((size_t)n) > 1024 ? 1024 : grid_for((size_t)n);
   hipStream_t st = (hipStream_t)stream;
@@ -959,6 +986,25 @@ extern "C" int hrv_maxpool2x2_bwd_relu_nhwc_xbf16(const uint16_t* x, const float
   hipLaunchKernelGGL(maxpool2_bwd_kernel<true>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x, dy, N,
                      H / 2, W / 2, C / 4, C, C, dx, 1);
   return check_launch("maxpool2_bwd_kernel[relu, bf16 x]");
+}
+
+// ... with bf16-stored x, dy AND dx
+extern "C" int hrv_maxpool2x2_bwd_relu_nhwc_bf16(const uint16_t* x, const uint16_t* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                                 uint16_t* dx, hrv_stream_t stream) {
+  HRV_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && H % 2 == 0 && W % 2 == 0 && C > 0 && C % 8 == 0, "maxpool_bwd_bf16: bad args");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL((maxpool2_bwd_kernel<true, true>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                     (const float*)dy, N, H / 2, W / 2, C / 4, C, C, (float*)dx, 1);
+  return check_launch("maxpool2_bwd_kernel[relu, bf16]");
+}
+
+extern "C" int hrv_add_slice_nhwc_bf16(const uint16_t* a, int32_t a_cstride, int32_t a_coff, uint16_t* out, int32_t out_cstride,
+                                       int32_t out_coff, int32_t C, int64_t npix, int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(a && out && npix > 0 && C > 0 && C % 4 == 0 && ((a_cstride | a_coff | out_cstride | out_coff) & 3) == 0,
+              "add_slice_bf16: bad args");
+  hipLaunchKernelGGL(add_slice_bf16_kernel, dim3(grid_for((size_t)npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, a, a_cstride,
+                     a_coff, out, out_cstride, out_coff, C / 4, (size_t)npix, accumulate);
+  return check_launch("add_slice_bf16_kernel");
 }
 
 extern "C" int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2,

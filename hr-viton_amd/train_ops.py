@@ -431,8 +431,9 @@ LOSS_RELU_MASK = 16      # or-ed into the mode: a = ReLU(pre), the returned grad
 
 
 def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, gscale: float, loss_out: torch.Tensor,
-         accumulate: bool = True, want_grad: bool = True) -> Optional[torch.Tensor]:
-    """hrv_loss_f32 over flat contiguous tensors: loss_out[0] (+)= lscale*sum(l); returns grad (same shape as a)."""
+         accumulate: bool = True, want_grad: bool = True, grad_bf16: bool = False) -> Optional[torch.Tensor]:
+    """hrv_loss_f32 over flat contiguous tensors: loss_out[0] (+)= lscale*sum(l); returns grad (same shape as a).
+    ``grad_bf16`` (bf16-stored operands only): the gradient is stored in bf16 too (mixed-precision VGG backward)."""
     lib = _lib.load()
     cl = torch.channels_last
     bf = a.dtype == torch.bfloat16          # bf16-stored operands (mixed-precision VGG taps): loss and gradient stay fp32
@@ -441,7 +442,10 @@ def loss(a: torch.Tensor, b: Optional[torch.Tensor], mode: int, lscale: float, g
     ok = ok or (a.dim() == 4 and a.is_contiguous(memory_format=cl) and
                 (b is None or (b.shape == a.shape and b.is_contiguous(memory_format=cl))))
     assert ok, "loss: operands must share one dense layout (strides of size-1 dims do not matter)"
-    grad = torch.empty_like(a, dtype=torch.float32) if want_grad else None
+    grad_bf16 = bool(grad_bf16 and bf and a.numel() % 4 == 0)
+    grad = torch.empty_like(a, dtype=torch.bfloat16 if grad_bf16 else torch.float32) if want_grad else None
+    if grad_bf16:
+        mode |= 32
     ws = _workspace(a.device, 4096)
     fn = lib.hrv_loss_bf16in_f32 if bf else lib.hrv_loss_f32
     with _Timed("loss", "loss_f32", 0.0, (2.0 if bf else 4.0) * a.numel() * (1 + (b is not None)) + 4.0 * a.numel() * (grad is not None)):
@@ -493,10 +497,14 @@ def maxpool2x2(x: Act) -> Act:
 def maxpool2x2_bwd(x: Act, dy: Act, relu: bool = False) -> Act:
     """``relu``: x = ReLU(pre) -- the result is the gradient w.r.t. pre (the ReLU derivative rides along)."""
     lib = _lib.load()
-    dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device)
-    assert not dy.bf16 and (relu or not x.bf16), "maxpool2x2_bwd: fp32 gradients; a bf16-stored x needs relu=True"
-    fn = (lib.hrv_maxpool2x2_bwd_relu_nhwc_xbf16 if x.bf16 else lib.hrv_maxpool2x2_bwd_relu_nhwc_f32) if relu \
-        else lib.hrv_maxpool2x2_bwd_nhwc_f32
+    dx = ops.alloc(x.N, x.H, x.W, x.C, x.t.device, bf16=dy.bf16)
+    assert (relu or not x.bf16) and (not dy.bf16 or (x.bf16 and relu)), \
+        "maxpool2x2_bwd: a bf16-stored x needs relu=True; bf16 gradients need a bf16 x"
+    if dy.bf16:
+        fn = lib.hrv_maxpool2x2_bwd_relu_nhwc_bf16
+    else:
+        fn = (lib.hrv_maxpool2x2_bwd_relu_nhwc_xbf16 if x.bf16 else lib.hrv_maxpool2x2_bwd_relu_nhwc_f32) if relu \
+            else lib.hrv_maxpool2x2_bwd_nhwc_f32
     with _Timed("pool", "maxpool2x2_bwd", 0.0, ops.act_bytes(x) + 5.0 * x.N * x.H * x.W * x.C):
         _lib.check(fn(x.t.data_ptr(), dy.t.data_ptr(), x.N, x.H, x.W, x.Cp, dx.t.data_ptr(), _stream()),
                    "hrv_maxpool2x2_bwd_nhwc_f32")
@@ -597,12 +605,14 @@ def tanh_bwd(dy: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
 
 
 def add_slice(a: Act, out: Act, accumulate: bool):
-    """out (+)= a over a's channels (both views may be channel slices)."""
+    """out (+)= a over a's channels (both views may be channel slices; both fp32 or both bf16-stored)."""
     lib = _lib.load()
     assert (a.N, a.H, a.W) == (out.N, out.H, out.W) and a.Cp <= out.cstride - out.coff
+    assert a.bf16 == out.bf16, "add_slice: operands share one storage type"
+    fn = lib.hrv_add_slice_nhwc_bf16 if a.bf16 else lib.hrv_add_slice_nhwc_f32
     with _Timed("ew", "add_slice", 0.0, ops.act_bytes(a) * (3 if accumulate else 2)):
-        _lib.check(lib.hrv_add_slice_nhwc_f32(a.t.data_ptr(), a.cstride, a.coff, out.t.data_ptr(), out.cstride, out.coff, a.Cp,
-                                              a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc_f32")
+        _lib.check(fn(a.t.data_ptr(), a.cstride, a.coff, out.t.data_ptr(), out.cstride, out.coff, a.Cp,
+                      a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc")
 
 
 def act_bwd_(d: Act, y: Act, act: int, slope: float = 0.2):

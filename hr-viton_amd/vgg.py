@@ -142,8 +142,10 @@ class _VGGLossFn(torch.autograd.Function):
         for i in layids:
             n = tx[i].t.numel()          # dense tensors (channels are multiples of 4)
             # the taps are ReLU outputs: the loss kernel hands the gradient back w.r.t. the pre-activation
+            # (mixed precision: bf16-stored taps get bf16-stored gradients -- the backward's tensors are read by the
+            #  data-gradient matrix cores, the pool routing and the tap sums only, like the forward's)
             grads[i] = T.loss(tx[i].t, ty[i].t, T.LOSS_L1 | T.LOSS_RELU_MASK, weights[i] / n, weights[i] / n, loss,
-                              accumulate=True, want_grad=need)
+                              accumulate=True, want_grad=need, grad_bf16=bool(T.MMA_BF16[0] and tx[i].bf16))
         ctx.vgg, ctx.saved, ctx.grads, ctx.tx = vgg, saved, grads, tx
         return loss
 
@@ -173,7 +175,8 @@ class _VGGLossFn(torch.autograd.Function):
             w = vgg.conv(idx).weight.data
             fused = idx != 0 and (idx - 1) not in _POOLS        # src is the previous conv's ReLU output
             d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, act_mask=src if fused else None, slope=0.0,
-                             name=f"vgg.features.{idx}.dgrad", frozen=T.frozen_stamp(vgg.conv(idx).weight))
+                             name=f"vgg.features.{idx}.dgrad", frozen=T.frozen_stamp(vgg.conv(idx).weight),
+                             out_bf16=d.bf16)
         ctx.saved = ctx.grads = None
         dx = ops.to_nchw(d)
         T.scale_(dx, 1.0, g_out.contiguous())

@@ -316,6 +316,13 @@ int hrv_maxpool2x2_bwd_relu_nhwc_f32(const float* x, const float* dy, int32_t N,
  * forward bf16 -> bf16 for NON-NEGATIVE inputs (ReLU outputs: integer max of the stored patterns, exact); backward with
  * bf16 x, fp32 dy / dx; loss over bf16 a, b. */
 int hrv_maxpool2x2_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, uint16_t* y, hrv_stream_t stream);
+/* mixed-precision VGG19 BACKWARD keeps its gradient tensors in bf16 too (their readers are the data-gradient matrix cores,
+ * the pool routing and these sums): pool backward over bf16 x / dy / dx; out (+)= a over bf16 tensors (fp32 sum, one
+ * rounding); hrv_loss_bf16in_f32 with mode | 32 stores its gradient as bf16 (`grad` then points at bf16 elements). */
+int hrv_maxpool2x2_bwd_relu_nhwc_bf16(const uint16_t* x, const uint16_t* dy, int32_t N, int32_t H, int32_t W, int32_t C,
+                                      uint16_t* dx, hrv_stream_t stream);
+int hrv_add_slice_nhwc_bf16(const uint16_t* a, int32_t a_cstride, int32_t a_coff, uint16_t* out, int32_t out_cstride,
+                            int32_t out_coff, int32_t C, int64_t npix, int32_t accumulate, hrv_stream_t stream);
 int hrv_maxpool2x2_bwd_relu_nhwc_xbf16(const uint16_t* x, const float* dy, int32_t N, int32_t H, int32_t W, int32_t C,
                                        float* dx, hrv_stream_t stream);
 /* torch.optim.Adam step over one flat buffer (train_generator.py:154-157,322,360);

@@ -669,3 +669,26 @@ def test_bf16_stored_pool_and_loss_kernels_match_fp32_on_the_same_values():
     g16 = T.loss(x, y, T.LOSS_L1 | T.LOSS_RELU_MASK, 0.5, 0.25, l16, accumulate=False)
     g32 = T.loss(x.float(), y.float(), T.LOSS_L1 | T.LOSS_RELU_MASK, 0.5, 0.25, l32, accumulate=False)
     assert g16.dtype == torch.float32 and torch.equal(g16, g32) and torch.equal(l16, l32)
+
+
+def test_bf16_stored_gradients_of_the_vgg_backward_match_fp32_on_the_same_values():
+    """Mixed-precision VGG19 backward keeps its GRADIENT tensors in bf16 as well: the tap-loss gradient (mode | 32), the
+    2x2 max-pool backward over bf16 x / dy / dx and the bf16 accumulation give the fp32 kernels' results on the same
+    (bf16-representable) values, rounded once."""
+    ops, T = _mods()
+    g = torch.Generator().manual_seed(6)
+    rb = lambda t: t.to(torch.bfloat16)     # noqa: E731
+    x = torch.relu(torch.randn(2, 20, 24, 64, generator=g)).to(torch.bfloat16).cuda()
+    y = torch.relu(torch.randn(2, 20, 24, 64, generator=g)).to(torch.bfloat16).cuda()
+    l16, l32 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
+    g16 = T.loss(x, y, T.LOSS_L1 | T.LOSS_RELU_MASK, 0.5, 0.25, l16, accumulate=False, grad_bf16=True)
+    g32 = T.loss(x, y, T.LOSS_L1 | T.LOSS_RELU_MASK, 0.5, 0.25, l32, accumulate=False)
+    assert g16.dtype == torch.bfloat16 and torch.equal(g16, rb(g32)) and torch.equal(l16, l32)
+    dy = torch.randn(2, 10, 12, 64, generator=g).to(torch.bfloat16).cuda()
+    d16 = T.maxpool2x2_bwd(ops.Act(x, 64), ops.Act(dy, 64), relu=True)
+    d32 = T.maxpool2x2_bwd(ops.Act(x, 64), ops.Act(dy.float(), 64), relu=True)
+    assert d16.bf16 and torch.equal(d16.t.float(), d32.t)          # routing only: exact
+    a = torch.randn(2, 20, 24, 64, generator=g).to(torch.bfloat16).cuda()
+    acc = d16.t.clone()
+    T.add_slice(ops.Act(a, 64), ops.Act(acc, 64), True)
+    assert torch.equal(acc, rb(a.float() + d16.t.float()))
