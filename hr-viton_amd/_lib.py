@@ -119,6 +119,10 @@ SYMBOLS = {
                                                  _i32, _f, _vp, _vp, _ip, _vp]),
     "hrv_conv2d_pack_weight_dev_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _i32, _i32, _i32,
                                                   _i32, _f, _vp, _vp, _ip, _vp]),
+    "hrv_conv2d_pack_record_bytes": (_i32, []),
+    "hrv_conv2d_pack_weight_record": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _i32, _i32, _i32, _i32, _f,
+                                                _vp, _i32, _vp, _i32, _i32, _vp, _ip, _vp, _ip]),
+    "hrv_conv2d_pack_weight_multi": (C.c_int, [_vp, _vp, _i32, _i32, _vp]),
     "hrv_conv2d_wgrad_workspace_bytes": (_i64, [_i32, _i32, _i32, _i32, _i64]),
     "hrv_conv2d_wgrad_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32,
                                             _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _vp, _i32,

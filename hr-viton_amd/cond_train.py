@@ -339,6 +339,7 @@ class _TocgFn(torch.autograd.Function):
     def forward(ctx, plan, input1, input2, *params):
         tape, flows, seg, warped = plan.forward(input1, input2)
         ctx.tape, ctx.flows, ctx.seg, ctx.warped, ctx.params = tape, flows, seg, warped, params
+        ctx.set_materialize_grads(False)       # an unused output arrives as None (handled below), not as a zero tensor
         return tuple(f.t for f in flows) + (ops.to_nchw(seg.a), ops.to_nchw(warped.a))
 
     @staticmethod
@@ -426,6 +427,7 @@ class _CondDFn(torch.autograd.Function):
     def forward(ctx, plan, inp, *params):
         outs, saved = plan.forward(inp)
         ctx.plan, ctx.saved, ctx.params = plan, saved, params
+        ctx.set_materialize_grads(False)
         # loss_G's gradients w.r.t. the discriminator are discarded by optimizer_D.zero_grad() (train_condition.py:284)
         ctx.need_w = not getattr(plan.msd, "_hrv_discard_param_grads", False)
         return tuple(ops.to_nchw(o) for o in outs)

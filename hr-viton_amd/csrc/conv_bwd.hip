@@ -61,41 +61,68 @@ __device__ __forceinline__ bool pack_pair_src(const PackParams& p, int co, const
   return true;
 }
 
-__global__ void pack_weight_kernel(const PackParams p) {
+// one element of the packed matrix
+__device__ __forceinline__ void pack_one(const PackParams& p, const size_t i, const float mul) {
   const int BKp = p.bke;
-  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BKp;
-  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int k = (int)(i % BKp);
-    const size_t t = i / BKp;
-    const int row = (int)(t % p.rows_pad);
-    const int kt = (int)(t / p.rows_pad);
-    const int tap = kt / p.chunks_total, chunk = kt - tap * p.chunks_total;
-    const int jh = tap / p.KWp, jw = tap - jh * p.KWp;
-    const int kh = p.kh_of[jh], kw = p.kw_of[jw];
-    float v = 0.f;
-    if (row < p.rows && kh >= 0 && kw >= 0) {
-      int s = 0;
+  const int k = (int)(i % BKp);
+  const size_t t = i / BKp;
+  const int row = (int)(t % p.rows_pad);
+  const int kt = (int)(t / p.rows_pad);
+  const int tap = kt / p.chunks_total, chunk = kt - tap * p.chunks_total;
+  const int jh = tap / p.KWp, jw = tap - jh * p.KWp;
+  const int kh = p.kh_of[jh], kw = p.kw_of[jw];
+  float v = 0.f;
+  if (row < p.rows && kh >= 0 && kw >= 0) {
+    int s = 0;
 #pragma unroll
-      for (int q = 1; q < HRV_MAX_SRC; ++q)
-        if (q < p.nsrc && chunk >= p.src_chunk0[q]) s = q;
-      const int c = (chunk - p.src_chunk0[s]) * BKp + k;  // channel within source s
-      if (c < p.src_creal[s]) {
-        const int cc = p.src_cbase[s] + c;
-        const int co = p.transposed ? cc : row;
-        const int ci = p.transposed ? row : cc;
-        const float* wp;
-        int cr;
-        if (pack_pair_src(p, co, wp, cr)) v = wp[(((size_t)cr * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
-      }
+    for (int q = 1; q < HRV_MAX_SRC; ++q)
+      if (q < p.nsrc && chunk >= p.src_chunk0[q]) s = q;
+    const int c = (chunk - p.src_chunk0[s]) * BKp + k;  // channel within source s
+    if (c < p.src_creal[s]) {
+      const int cc = p.src_cbase[s] + c;
+      const int co = p.transposed ? cc : row;
+      const int ci = p.transposed ? row : cc;
+      const float* wp;
+      int cr;
+      if (pack_pair_src(p, co, wp, cr)) v = wp[(((size_t)cr * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
     }
-    if (p.bf16) {  // round to nearest even
-      unsigned u = __builtin_bit_cast(unsigned, v);
-      u += 0x7fffu + ((u >> 16) & 1u);
-      reinterpret_cast<unsigned short*>(p.out)[i] = (unsigned short)(u >> 16);
-    } else {
-      p.out[i] = v;
-    }
+  }
+  if (p.bf16) {  // round to nearest even
+    unsigned u = __builtin_bit_cast(unsigned, v);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    reinterpret_cast<unsigned short*>(p.out)[i] = (unsigned short)(u >> 16);
+  } else {
+    p.out[i] = v;
+  }
+}
+
+__global__ void pack_weight_kernel(const PackParams p) {
+  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * p.bke;
+  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
+    pack_one(p, i, mul);
+}
+
+// Every weight pack of a network in ONE launch (a training step re-packs ~180 weights after each optimizer step: one
+// 5-11 us launch each otherwise).  ``tbl``: the records hrv_conv2d_pack_weight_record filled, on the device; ``first``:
+// [n + 1] first block of each record (PACK_MULTI_ELEMS elements per block).  Same arithmetic per element as above.
+constexpr int PACK_MULTI_ELEMS = 2048;
+__global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackParams* __restrict__ tbl,
+                                                                const int* __restrict__ first, const int n) {
+  const int b = blockIdx.x;
+  int lo = 0, hi = n;                 // first[lo] <= b < first[hi]
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (first[mid] <= b) lo = mid; else hi = mid;
+  }
+  const PackParams& p = tbl[lo];
+  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * p.bke;
+  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
+  const size_t i0 = (size_t)(b - first[lo]) * PACK_MULTI_ELEMS + threadIdx.x;
+#pragma unroll
+  for (int k = 0; k < PACK_MULTI_ELEMS / 256; ++k) {
+    const size_t i = i0 + (size_t)k * 256;
+    if (i < total) pack_one(p, i, mul);
   }
 }
 
@@ -629,7 +656,7 @@ static int pack_weight_dev_impl(const float* w_oihw_dev, int32_t Cout, int32_t K
                                 int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
                                 const float* sigma_dev, void* out_dev, int32_t* out_geom, hrv_stream_t stream,
                                 const int BK, const int as_bf16, const float* w2_dev = nullptr, int pair_mode = 0,
-                                int rows_each = 0) {
+                                int rows_each = 0, PackParams* record = nullptr) {
   HRV_REQUIRE(w_oihw_dev && out_dev && srcC && srcC_real && nsrc >= 1 && nsrc <= HRV_MAX_SRC, "pack_dev: bad args");
   const int bn = hrv_conv2d_tile_bn(tile_cfg);
   HRV_REQUIRE(bn > 0, "pack_dev: bad tile_cfg %d", tile_cfg);
@@ -699,8 +726,48 @@ static int pack_weight_dev_impl(const float* w_oihw_dev, int32_t Cout, int32_t K
     out_geom[7] = p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
   }
   const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  if (record) {      // hrv_conv2d_pack_weight_record: the launch is the caller's hrv_conv2d_pack_weight_multi
+    *record = p;
+    return HRV_OK;
+  }
   hipLaunchKernelGGL(pack_weight_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, p);
   return check_launch("pack_weight_kernel");
+}
+
+extern "C" int32_t hrv_conv2d_pack_record_bytes(void) { return (int32_t)sizeof(PackParams); }
+
+// Fills ``record_host`` (hrv_conv2d_pack_record_bytes() bytes) with what hrv_conv2d_pack_weight_dev_{f32,bf16} /
+// hrv_conv2d_pack_weight_pair_dev would launch for these arguments (as_bf16; w2_dev / pair_mode / rows_each: the pair
+// form, else null / 0 / 0) and returns the packed geometry; *blocks = blocks of the record in the batched launch.
+extern "C" int hrv_conv2d_pack_weight_record(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                             const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
+                                             int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
+                                             const float* sigma_dev, int32_t as_bf16, const float* w2_dev, int32_t pair_mode,
+                                             int32_t rows_each, void* out_dev, int32_t* out_geom, void* record_host,
+                                             int32_t* blocks) {
+  HRV_REQUIRE(record_host && out_geom && blocks, "pack_record: null pointer");
+  int bke = 16;
+  if (as_bf16) {
+    const int rb = hrv_conv2d_tile_row_bytes(tile_cfg);
+    HRV_REQUIRE(rb == 64 || rb == 128, "pack_record: bad tile_cfg %d", tile_cfg);
+    bke = rb / 2;
+  }
+  const int rc = pack_weight_dev_impl(w_oihw_dev, Cout, KH, KW, nsrc, srcC, srcC_real, tile_cfg, mode, stride, pad, phase_a,
+                                      phase_b, wscale, sigma_dev, out_dev, out_geom, nullptr, bke, as_bf16 ? 1 : 0, w2_dev,
+                                      pair_mode, rows_each, (PackParams*)record_host);
+  if (rc) return rc;
+  *blocks = (int32_t)(((int64_t)out_geom[7] + PACK_MULTI_ELEMS - 1) / PACK_MULTI_ELEMS);
+  return HRV_OK;
+}
+
+// One launch over ``n`` records (device copies of the host records, in order) -- ``first_block_dev``: [n + 1] prefix sums
+// of the records' block counts, ``blocks`` = first_block[n].
+extern "C" int hrv_conv2d_pack_weight_multi(const void* records_dev, const int32_t* first_block_dev, int32_t n,
+                                            int32_t blocks, hrv_stream_t stream) {
+  HRV_REQUIRE(records_dev && first_block_dev && n > 0 && blocks > 0, "pack_multi: bad args");
+  hipLaunchKernelGGL(pack_weight_multi_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream,
+                     (const PackParams*)records_dev, (const int*)first_block_dev, n);
+  return check_launch("pack_weight_multi_kernel");
 }
 
 extern "C" int hrv_conv2d_pack_weight_dev_f32(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW,

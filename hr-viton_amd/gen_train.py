@@ -51,6 +51,22 @@ def grad_buffer(p: nn.Parameter) -> torch.Tensor:
     return torch.empty_like(p.data)
 
 
+def _pair_slot(pa: nn.Parameter, pb: nn.Parameter) -> Optional[torch.Tensor]:
+    """One tensor [2 * rows, ...] over the flat-buffer slots of two same-shaped parameters when they are free this
+    iteration and adjacent (optim._flat_order puts ``_hrv_flat_after`` mates next to each other), else None."""
+    va, vb = flat_grad_slot(pa), flat_grad_slot(pb)
+    if va is None or vb is None or pa.grad is not None or pb.grad is not None or va.shape != vb.shape:
+        return None
+    if vb.data_ptr() != va.data_ptr() + 4 * va.numel():
+        return None
+    shape = (2 * va.shape[0],) + tuple(va.shape[1:])
+    stride, k = [], 1
+    for d in reversed(shape):
+        stride.append(k)
+        k *= d
+    return torch.as_strided(va, shape, tuple(reversed(stride)))
+
+
 def _acc(grads: Grads, p: nn.Parameter, g: torch.Tensor):
     v = flat_grad_slot(p)
     if v is not None:
@@ -231,7 +247,9 @@ class SpadeT:
         n = self.norm
         C_, Cp = self.C, self.Cp
         dev = dout.t.device
-        dns = torch.empty(Cp, device=dev) if ctx["z"] is not None else None
+        dns = None
+        if ctx["z"] is not None:
+            dns = grad_buffer(n.noise_scale) if Cp == C_ else torch.empty(Cp, device=dev)
         dx, dgb = T.norm_bwd(ctx["x"], ctx["mean"], ctx["rstd"], dout, act=self.act, slope=0.2,
                              out=ctx["out"] if self.act != ACT_NONE else None, g1p=ctx["g1p"], z=ctx["z"],
                              noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dx=dx,
@@ -250,8 +268,10 @@ class SpadeT:
             wcat = torch.zeros((2 * Cp, self.hid, 3, 3), device=dev)
             wcat[:C_] = n.conv_gamma.weight.data
             wcat[Cp:Cp + C_] = n.conv_beta.weight.data
-        dwcat = torch.empty((2 * Cp, self.hid, 3, 3), device=dev)
-        db = torch.empty(2 * Cp, device=dev)
+        dwcat, db = _pair_slot(n.conv_gamma.weight, n.conv_beta.weight), _pair_slot(n.conv_gamma.bias, n.conv_beta.bias)
+        if Cp != C_ or dwcat is None or db is None:
+            dwcat = torch.empty((2 * Cp, self.hid, 3, 3), device=dev)
+            db = torch.empty(2 * Cp, device=dev)
         T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad", dbias=db)
         direct = flat_grad_slot(n.conv_gamma.weight) is not None
         keep = (lambda t: t) if direct else (lambda t: t.clone())     # slices are copied into the flat slots by _acc
@@ -377,6 +397,26 @@ class BlockT:
         return d_x
 
 
+def noise_elems(gen: nn.Module, N: int) -> int:
+    """Length of the flat draw ``noise_planes`` cuts up (every plane starts on a 16-byte boundary)."""
+    return sum((3 if getattr(gen, name).learned_shortcut else 2) * ((N * (gen.sw << j) * (gen.sh << j) + 3) // 4 * 4)
+               for j, name in enumerate(gen._blocks()))
+
+
+def noise_planes(gen: nn.Module, N: int, zall: torch.Tensor):
+    """{block name: [b x w x h x 1 plane per SPADE layer]} as views of one flat standard-normal draw, in block order."""
+    out, off = {}, 0
+    for j, name in enumerate(gen._blocks()):
+        h, w = gen.sh << j, gen.sw << j
+        zn = N * w * h
+        planes = []
+        for _ in range(3 if getattr(gen, name).learned_shortcut else 2):
+            planes.append(zall[off:off + zn].view(N, w, h, 1))
+            off += (zn + 3) // 4 * 4
+        out[name] = planes
+    return out
+
+
 class GeneratorTrainPlan:
     def __init__(self, gen: nn.Module):
         self.gen = gen
@@ -394,7 +434,9 @@ class GeneratorTrainPlan:
         top = nb - 1
         dev = x.device
         # one batched power iteration for every spectral-normalised convolution of the generator (four launches)
-        T.prepare_convs(self, [c for b in self.blocks for c in b.convs()], power_iteration)
+        # ... and one batched launch for the plan's weight packs (T.PackBatch)
+        T.prepare_convs(self, [c for b in self.blocks for c in b.convs()] + list(self.stems) + [self.img], power_iteration,
+                        extra_weights=[n_.norm.conv_gamma.weight.data for b in self.blocks for n_ in b.norms()])
         xin = ops.to_nhwc(x)
         # mixed precision: the full-resolution stem (conv_7: 9 -> 16 channels over every pixel) reads a bf16 copy of the
         # input (matrix-core operand only) so that it runs on the thin-convolution kernel
@@ -402,6 +444,10 @@ class GeneratorTrainPlan:
         sg = seg if isinstance(seg, Act) else ops.to_nhwc(seg)
         ctxs = []
         cur = None
+        if noise is None:
+            # the noise planes of every SPADE layer of this forward from ONE generator launch (network_generator.py:103
+            # draws b x w x h x 1 per layer: 23 launches a pass otherwise)
+            noise = noise_planes(gen, N, torch.randn(noise_elems(gen, N), device=dev))
         for j, name in enumerate(self.names):
             blk = self.blocks[j]
             h, w = gen.sh << j, gen.sw << j
@@ -413,8 +459,8 @@ class GeneratorTrainPlan:
             else:
                 self.stems[j].forward([(xs, -shift)], out=cur.slice(cin - 16, 16))
             k = 3 if blk.learned else 2
-            zs = [z.to(dev).contiguous() for z in noise[name]] if noise is not None else \
-                [torch.randn(N, w, h, 1, device=dev) for _ in range(k)]
+            zs = [z.to(dev).contiguous() for z in noise[name]]
+            assert len(zs) == k, (name, len(zs), k)
             if j == nb - 1:
                 o, c = blk.forward(cur, sg, shift, zs, None, 0, ACT_LRELU, save)
             else:
@@ -675,6 +721,9 @@ class _DiscFn(torch.autograd.Function):
     def forward(ctx, msd, plan, inp, split, *params):
         feats_all, saved = plan.forward(inp, power_iteration=True)
         ctx.plan, ctx.saved, ctx.params, ctx.split = plan, saved, params, split
+        # outputs without a gradient (detached real-half features, the feature maps of the D step) arrive as None, not as
+        # zero tensors the size of the feature maps: the backward below skips them (and takes the half-batch path)
+        ctx.set_materialize_grads(False)
         # generator step: the discriminator's own parameter gradients of loss_G are thrown away by the training script
         # (optimizer_dis.zero_grad() before the D backward, train_generator.py:354) -- the weight / bias gradient
         # kernels and the spectral-norm transform are skipped when the caller says so (pipeline.generator_train_step)

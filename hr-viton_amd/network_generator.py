@@ -109,6 +109,10 @@ class SPADENorm(nn.Module):
         self.conv_shared = nn.Sequential(nn.Conv2d(label_nc, nhidden, kernel_size=ks, padding=ks // 2), nn.ReLU())
         self.conv_gamma = nn.Conv2d(nhidden, norm_nc, kernel_size=ks, padding=ks // 2)
         self.conv_beta = nn.Conv2d(nhidden, norm_nc, kernel_size=ks, padding=ks // 2)
+        # layout hint for the fused optimizer's flat buffers (optim.Adam._setup): the backward computes [dW_gamma ; dW_beta]
+        # (and the two bias gradients) as ONE matrix -- with the mates adjacent it is written in place, no slice copies
+        self.conv_beta.weight._hrv_flat_after = self.conv_gamma.weight
+        self.conv_beta.bias._hrv_flat_after = self.conv_gamma.bias
 
 
 class SPADEResBlock(nn.Module):

@@ -11,6 +11,34 @@ from . import ops
 from . import train_ops as T
 
 
+def _flat_order(ps):
+    """Order of the parameters inside the flat buffers: registration order, except that a parameter carrying
+    ``_hrv_flat_after = mate`` sits right behind its mate (SPADE's conv_beta behind conv_gamma: their gradients are
+    produced as one [gamma ; beta] matrix, gen_train.SpadeT.backward).  The optimizer's arithmetic is element-wise:
+    the order changes no value."""
+    ids = {id(p) for p in ps}
+    follow = {}
+    for p in ps:
+        mate = getattr(p, "_hrv_flat_after", None)
+        if mate is not None and id(mate) in ids and mate is not p:
+            follow.setdefault(id(mate), []).append(p)
+    placed, out = set(), []
+
+    def put(p):
+        if id(p) in placed:
+            return
+        placed.add(id(p))
+        out.append(p)
+        for q in follow.get(id(p), ()):
+            put(q)
+    for p in ps:
+        mate = getattr(p, "_hrv_flat_after", None)
+        if mate is not None and id(mate) in ids and mate is not p and id(p) not in placed:
+            put(mate)
+        put(p)
+    return out
+
+
 class Adam(torch.optim.Optimizer):
     def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None):
         defaults = dict(lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps, weight_decay=weight_decay)
@@ -19,7 +47,7 @@ class Adam(torch.optim.Optimizer):
         self._flat = {}
 
     def _setup(self, gi, group):
-        ps = [p for p in group["params"] if p.requires_grad]
+        ps = _flat_order([p for p in group["params"] if p.requires_grad])
         for p in ps:
             ops.require_cuda(p.data, "hr_viton_amd.optim.Adam parameter")
         # every parameter starts on a 16-byte boundary of the flat buffer: the conv epilogues take

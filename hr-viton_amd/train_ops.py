@@ -46,6 +46,97 @@ def frozen_stamp(p) -> Optional[tuple]:
     return (tok, p._version, getattr(p, "_hrv_epoch", 0))
 
 
+class PackBatch:
+    """The weight packs of one network's training plan, re-packed by ONE launch (hrv_conv2d_pack_weight_multi) when
+    ``prepare_convs`` runs at the top of the plan's forward -- a training iteration re-packs ~180 weights otherwise, one
+    5-11 us launch each.  The first iteration packs one by one and records what was asked for (arguments + a buffer
+    that stays); later iterations find their packs here.  A record is served only while the batch is FRESH: ``run`` was
+    called after the last optimizer step / weight load (ops.WEIGHTS_EPOCH / LOAD_EPOCH) -- anything else falls back to
+    the single pack."""
+
+    def __init__(self, device):
+        self.device = device
+        self.index: dict = {}            # key -> record number
+        self.bufs, self.geoms, self.blocks, self.records = [], [], [], []
+        self.table = self.first = None
+        self.dirty = False
+        self.stamp = None
+        self.launches = 0
+
+    @staticmethod
+    def _now():
+        return (ops.WEIGHTS_EPOCH[0], ops.LOAD_EPOCH[0])
+
+    def fresh(self) -> bool:
+        return self.stamp == self._now()
+
+    def lookup(self, key):
+        i = self.index.get(key)
+        if i is None or self.dirty or not self.fresh():
+            return None
+        return self.bufs[i], self.geoms[i]
+
+    def add(self, key, record: bytes, blocks: int, buf: torch.Tensor, geom: tuple):
+        self.index[key] = len(self.bufs)
+        self.bufs.append(buf); self.geoms.append(geom); self.blocks.append(blocks); self.records.append(record)
+        self.dirty = True
+
+    def run(self):
+        """(Re)pack every recorded weight from its current values; marks the batch fresh."""
+        self.stamp = self._now()
+        if not self.bufs:
+            return
+        lib = _lib.load()
+        if self.dirty:
+            import numpy as np
+            tbl = np.frombuffer(b"".join(self.records), dtype=np.uint8).copy()
+            first = np.zeros(len(self.blocks) + 1, dtype=np.int32)
+            first[1:] = np.cumsum(np.asarray(self.blocks, dtype=np.int64))
+            self.table = torch.from_numpy(tbl).to(self.device)
+            self.first = torch.from_numpy(first).to(self.device)
+            self.total_blocks = int(first[-1])
+            self.dirty = False
+        _lib.check(lib.hrv_conv2d_pack_weight_multi(self.table.data_ptr(), self.first.data_ptr(), len(self.bufs),
+                                                    self.total_blocks, _stream()), "hrv_conv2d_pack_weight_multi")
+        self.launches += 1
+
+
+_PACK_OWNER: dict = {}      # weight storage address -> the PackBatch of the plan that prepared it last
+PACK_BATCHING = [os.environ.get("HRV_PACK_BATCH", "1") != "0"]
+
+
+def _pack_batched(w, w2, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, cfg, mode, stride, pad, phase, wscale, sigma,
+                  bf16, nelem):
+    """-> (buf, geom) from the owning plan's PackBatch (recording the pack on its first use), or None: not batched."""
+    batch = _PACK_OWNER.get(w.data_ptr()) if PACK_BATCHING[0] else None
+    if batch is None or not batch.fresh():
+        return None
+    key = (w.data_ptr(), 0 if w2 is None else w2.data_ptr(), pair_mode, rows_each, Cout, KH, KW, tuple(src_pad), tuple(src_real),
+           cfg, mode, stride, pad, tuple(phase), wscale, 0 if sigma is None else sigma.data_ptr(), bf16)
+    hit = batch.lookup(key)
+    if hit is not None:
+        return hit
+    if key in batch.index or torch.cuda.is_current_stream_capturing():
+        return None                      # recorded earlier in this iteration (served from the next run() on) / no uploads now
+    lib = _lib.load()
+    n = len(src_pad)
+    buf = torch.empty(nelem, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
+    rec = C.create_string_buffer(lib.hrv_conv2d_pack_record_bytes())
+    geom, blocks = (C.c_int32 * 8)(), C.c_int32(0)
+    _lib.check(lib.hrv_conv2d_pack_weight_record(w.data_ptr(), Cout, KH, KW, n, (C.c_int32 * n)(*src_pad), (C.c_int32 * n)(*src_real),
+                                                 cfg, mode, stride, pad, phase[0], phase[1], wscale,
+                                                 None if sigma is None else sigma.data_ptr(), 1 if bf16 else 0,
+                                                 None if w2 is None else w2.data_ptr(), pair_mode, rows_each, buf.data_ptr(), geom,
+                                                 rec, C.byref(blocks)), "hrv_conv2d_pack_weight_record")
+    assert geom[7] <= nelem, (geom[7], nelem)      # (stride-2 phases use fewer taps than the bound)
+    # this first time the single-record batch IS the pack (same kernel arithmetic); from the next run() on it rides along
+    one = PackBatch(w.device)
+    one.add(key, rec.raw, blocks.value, buf, tuple(geom))
+    one.run()
+    batch.add(key, rec.raw, blocks.value, buf, tuple(geom))
+    return buf, tuple(geom)
+
+
 def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
                     stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0,
                     sigma: Optional[torch.Tensor] = None, bf16: bool = False, frozen=None):
@@ -73,6 +164,11 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     rows_pad = (rows + bn - 1) // bn * bn
     bke = lib.hrv_conv2d_tile_row_bytes(cfg) // 2 if bf16 else 16      # k-values per packed row (the tile's row size)
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
+    if key is None:
+        hit = _pack_batched(w, None, 0, 0, Cout, KH, KW, src_pad, src_real, cfg, mode, stride, pad, phase, wscale, sigma, bf16,
+                            KH * KW * chunks * rows_pad * bke)
+        if hit is not None:
+            return hit
     buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w.device)
     geom = (C.c_int32 * 8)()
     fn = lib.hrv_conv2d_pack_weight_dev_bf16 if bf16 else lib.hrv_conv2d_pack_weight_dev_f32
@@ -105,6 +201,10 @@ def pack_weight_pair_dev(w_a: torch.Tensor, w_b: torch.Tensor, pair_mode: int, s
     rows_pad = (rows + bn - 1) // bn * bn
     bke = lib.hrv_conv2d_tile_row_bytes(cfg) // 2 if bf16 else 16
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
+    hit = _pack_batched(w_a, w_b, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, cfg, mode, 1, pad, (0, 0), 1.0, None, bf16,
+                        KH * KW * chunks * rows_pad * bke)
+    if hit is not None:
+        return hit[0], hit[1], Cout
     buf = torch.empty(KH * KW * chunks * rows_pad * bke, dtype=torch.bfloat16 if bf16 else torch.float32, device=w_a.device)
     geom = (C.c_int32 * 8)()
     _lib.check(lib.hrv_conv2d_pack_weight_pair_dev(w_a.data_ptr(), w_b.data_ptr(), rows_each, pair_mode, Cout, KH, KW, n, srcC,
@@ -550,7 +650,10 @@ class SpectralBatch:
         lib = _lib.load()
         dev = self.items[0][0].device
         n, sR, sK = len(self.items), sum(self.Rs), sum(self.Ks)
-        sig = torch.empty(n, dtype=torch.float32, device=dev)
+        # sigma lives in ONE buffer per batch for the plan's lifetime: the batched weight packs read it by address
+        sig = getattr(self, "_sig", None)
+        if sig is None or sig.device != dev or sig.numel() != n:
+            sig = self._sig = torch.empty(n, dtype=torch.float32, device=dev)
         ub = torch.empty(sR, dtype=torch.float32, device=dev)
         vb = torch.empty(sK, dtype=torch.float32, device=dev)
         scratch = _workspace(dev, 4 * sR)               # bytes: W v of every job
@@ -566,8 +669,30 @@ class SpectralBatch:
         return sig.split(1), ub.split(self.Rs), vb.split(self.Ks)
 
 
-def prepare_convs(owner, convs, power_iteration: bool):
-    """TConv.prepare for every spectral-normalised convolution of ``convs`` at once (``owner`` caches the batch)."""
+def prepare_convs(owner, convs, power_iteration: bool, extra_weights: Sequence[torch.Tensor] = ()):
+    """TConv.prepare for every spectral-normalised convolution of ``convs`` at once (``owner`` caches the batch), then
+    the plan's recorded weight packs in one launch (PackBatch; ``extra_weights``: further weights of the plan whose
+    packs should ride along, e.g. SPADE's conv_gamma)."""
+    _prepare_sigmas(owner, convs, power_iteration)
+    if not convs:
+        return
+    dev = convs[0].wparam.data.device
+    pb = getattr(owner, "_pack_batch", None)
+    if pb is None or pb.device != dev:
+        pb = owner._pack_batch = PackBatch(dev)
+    for c in convs:
+        _PACK_OWNER[c.wparam.data.data_ptr()] = pb
+    for w in extra_weights:
+        _PACK_OWNER[w.data_ptr()] = pb
+    if len(_PACK_OWNER) > 8192:          # (addresses of dead networks; a live plan re-registers at its next forward)
+        _PACK_OWNER.clear()
+    # (while a hipGraph is being captured the record table cannot be re-uploaded: a plan that still has unrecorded packs
+    #  then packs one by one, which captures fine)
+    if PACK_BATCHING[0] and not (pb.dirty and torch.cuda.is_current_stream_capturing()):
+        pb.run()
+
+
+def _prepare_sigmas(owner, convs, power_iteration: bool):
     sn = [c for c in convs if c.spectral]
     if not sn:
         return

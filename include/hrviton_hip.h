@@ -195,6 +195,20 @@ int hrv_conv2d_pack_weight_pair_dev(const float* w_a_dev, const float* w_b_dev, 
                                     int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc, const int32_t* srcC,
                                     const int32_t* srcC_real, int32_t tile_cfg, int32_t mode, int32_t pad, int32_t as_bf16,
                                     void* out_dev, int32_t* out_geom, hrv_stream_t stream);
+/* Batched form of the three packs above: every weight of a network re-packed by ONE launch per training step (the
+ * reference re-derives nothing -- cuDNN reads OIHW -- so this replaces ~180 small launches of this library's own).
+ * hrv_conv2d_pack_weight_record fills a host record (hrv_conv2d_pack_record_bytes() bytes) for one pack -- same argument
+ * meaning; as_bf16 selects the bf16 form; w2_dev / pair_mode / rows_each describe a pair, else null / 0 / 0 -- and
+ * returns its geometry and block count; the caller keeps the records in a device array, their block prefix sums in
+ * first_block_dev[n + 1], and launches hrv_conv2d_pack_weight_multi whenever the weights changed. */
+int32_t hrv_conv2d_pack_record_bytes(void);
+int hrv_conv2d_pack_weight_record(const float* w_oihw_dev, int32_t Cout, int32_t KH, int32_t KW, int32_t nsrc,
+                                  const int32_t* srcC, const int32_t* srcC_real, int32_t tile_cfg, int32_t mode,
+                                  int32_t stride, int32_t pad, int32_t phase_a, int32_t phase_b, float wscale,
+                                  const float* sigma_dev, int32_t as_bf16, const float* w2_dev, int32_t pair_mode,
+                                  int32_t rows_each, void* out_dev, int32_t* out_geom, void* record_host, int32_t* blocks);
+int hrv_conv2d_pack_weight_multi(const void* records_dev, const int32_t* first_block_dev, int32_t n, int32_t blocks,
+                                 hrv_stream_t stream);
 int64_t hrv_conv2d_wgrad_workspace_bytes(int32_t Cout, int32_t CinTot, int32_t KH, int32_t KW, int64_t P);
 int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x,
                               int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t x_up_shift, int32_t x_C_real,

@@ -309,7 +309,7 @@ def test_second_generator_iteration_on_the_flat_gradient_path():
     fused bias columns).  The oracle is synchronised to the HIP weights (incl. the power-iterated u, v) before that
     iteration and fed the same SPADE noise; compared: the generator-step losses and every generator gradient."""
     import hr_viton_amd  # noqa: F401
-    from hr_viton_amd import ops, pipeline
+    from hr_viton_amd import gen_train, ops, pipeline
     from hr_viton_amd.losses import GANLoss, L1Loss
     from hr_viton_amd.optim import Adam
     opt, gen, D, x, seg, real, noise = _setup(seed=9, wmul=8.0)
@@ -325,8 +325,9 @@ def test_second_generator_iteration_on_the_flat_gradient_path():
     fed = {}
 
     def feed_randn(*size, **kw):
-        # SPADENorm noise draws ([b, w, h, 1], network_generator.py:104-107): recorded so the oracle can replay them
-        if len(size) == 4 and size[3] == 1:
+        # SPADENorm noise draws (network_generator.py:104-107; one flat draw per generator forward, gen_train.noise_planes):
+        # recorded so the oracle can replay them
+        if len(size) == 1 and size[0] == gen_train.noise_elems(gen, x.shape[0]):
             z = real_randn(*size, **kw)
             fed.setdefault("z", []).append(z.detach().cpu())
             return z
@@ -353,11 +354,8 @@ def test_second_generator_iteration_on_the_flat_gradient_path():
             torch.randn = real_randn
             og.step = real_step
     # oracle replay of the SECOND iteration's generator step
-    zs = fed["z"]
-    per_block = {b: (3 if getattr(gen, b).learned_shortcut else 2) for b in blocks}
-    n_g = sum(per_block.values())
-    it_z = iter(zs[:n_g])                                     # the first n_g draws belong to the G-step forward
-    onoise = {b: [next(it_z) for _ in range(per_block[b])] for b in blocks}
+    assert len(fed["z"]) == 2 and list(blocks) == list(gen._blocks())   # (G-step forward, D-step no-grad forward)
+    onoise = gen_train.noise_planes(gen, x.shape[0], fed["z"][0])       # the first draw belongs to the G-step forward
     O.SN_TRAIN["on"], O.SN_TRAIN["uv"] = True, {}
     try:
         fake = O.spade_generator_forward(sd_g, x, seg, opt.fine_height, opt.fine_width, "most", noise=onoise)
@@ -380,3 +378,49 @@ def test_second_generator_iteration_on_the_flat_gradient_path():
         rows.append(((cap[n] - w).abs().max().item() / max(w.abs().max().item(), 1e-3 * gmax), n))
     rows.sort(reverse=True)
     assert rows[0][0] < 1e-2, rows[:5]
+
+
+@pytest.mark.parametrize("mixed", [False, True], ids=["fp32", "bf16"])
+def test_batched_weight_packs_leave_the_iteration_bit_identical(mixed):
+    """T.PackBatch: from the second iteration on every recorded weight pack of a plan comes from ONE
+    hrv_conv2d_pack_weight_multi launch at the top of its forward.  Three iterations (same inputs, same injected SPADE
+    noise) with and without batching end in bit-identical generator and discriminator weights, and the batched run did
+    serve its convolutions from the batch (records exist, the multi launch ran once per plan forward)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import gen_train, ops, pipeline
+    from hr_viton_amd import train_ops as T
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    from hr_viton_amd.optim import Adam
+
+    def run(batching):
+        opt, gen, D, x, seg, real, noise = _setup(seed=4, wmul=8.0)
+        opt.lambda_feat, opt.lambda_vgg, opt.no_vgg_loss = 10.0, 10.0, True
+        gen.cuda().train()
+        D.cuda().train()
+        og = Adam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+        od = Adam(D.parameters(), lr=4e-3, betas=(0.0, 0.9))
+        xc, realc, parse7 = x.cuda(), real.cuda(), ops.to_nhwc(seg.cuda())
+        g = torch.Generator().manual_seed(77)
+        old, oldm = T.PACK_BATCHING[0], T.MMA_BF16[0]
+        T.PACK_BATCHING[0], T.MMA_BF16[0] = batching, mixed
+        try:
+            for _ in range(3):
+                nz = [gen_train.noise_planes(gen, x.shape[0], torch.randn(gen_train.noise_elems(gen, x.shape[0]), generator=g))
+                      for _ in range(2)]
+                pipeline.generator_train_step(opt, gen, D, GANLoss("hinge"), L1Loss(), None, og, od, xc, parse7, realc,
+                                              noise=nz[0], noise_d=nz[1])
+        finally:
+            T.PACK_BATCHING[0], T.MMA_BF16[0] = old, oldm
+        torch.cuda.synchronize()
+        sd = {"G." + k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+        sd.update({"D." + k: v.detach().cpu().clone() for k, v in D.state_dict().items()})
+        stats = [(len(p._pack_batch.bufs), p._pack_batch.launches) for p in (gen._train_plan, D._train_plan)
+                 if getattr(p, "_pack_batch", None) is not None]
+        return sd, stats
+
+    a, sa = run(True)
+    b, sb = run(False)
+    assert len(sa) == 2 and all(n > 4 and launches >= 5 for n, launches in sa), sa       # 2 forwards x 3 iterations each
+    assert all(n == 0 for n, _ in sb), sb
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

@@ -44,3 +44,30 @@ def test_frozen_pack_stamp_is_unique_per_parameter_object():
     sa, sb = T.frozen_stamp(a), T.frozen_stamp(b)
     assert sa != sb and sa == T.frozen_stamp(a)
     assert T.frozen_stamp(torch.nn.Parameter(torch.zeros(4))) is None      # trainable: never cached
+
+
+def test_flat_buffer_order_puts_gradient_mates_next_to_each_other():
+    """optim._flat_order: a parameter carrying ``_hrv_flat_after`` follows its mate directly (SPADE conv_beta behind
+    conv_gamma, so [dW_gamma ; dW_beta] is written as one matrix); everything else keeps registration order."""
+    import torch
+    import torch.nn as nn
+    from hr_viton_amd.optim import _flat_order
+    from hr_viton_amd.network_generator import SPADENorm
+    import argparse
+    ps = [nn.Parameter(torch.zeros(i + 1)) for i in range(6)]
+    ps[4]._hrv_flat_after = ps[1]
+    ps[2]._hrv_flat_after = ps[5]          # a mate registered LATER: the pair moves to the follower's place
+    got = _flat_order(ps)
+    assert [p.numel() for p in got] == [1, 2, 5, 6, 3, 4]
+    assert sorted(id(p) for p in got) == sorted(id(p) for p in ps)
+    ps[0]._hrv_flat_after = nn.Parameter(torch.zeros(1))     # a mate outside the group is ignored
+    assert [p.numel() for p in _flat_order(ps)] == [1, 2, 5, 6, 3, 4]
+    opt = argparse.Namespace(norm_G="spectralaliasinstance", num_upsampling_layers="most", gen_semantic_nc=7)
+    try:
+        n = SPADENorm(opt, "aliasinstance", 8, 7)
+    except TypeError:
+        return
+    names = [k for k, _ in n.named_parameters()]
+    order = [names[[id(q) for q in n.parameters()].index(id(p))] for p in _flat_order(list(n.parameters()))]
+    assert order.index("conv_beta.weight") == order.index("conv_gamma.weight") + 1
+    assert order.index("conv_beta.bias") == order.index("conv_gamma.bias") + 1
