@@ -20,6 +20,14 @@
 
 namespace hrv {
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float thin_f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 thin_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned thin_pk_bf16(float a, float b) {     // v_cvt_pk_bf16_f32 (round to nearest even)
+  const thin_f32x2 v = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, thin_bf16x2));
+}
+
 struct ThinParams {
   const void* src; int N, H, W, CK, cs, co; unsigned src_bytes;     // bf16 source, CK channels (multiple of 8)
   const float* w; int Cout, Cin, KH, KW; const float* sigma; float wscale; int transposed;   // fp32 OIHW parameter
@@ -29,9 +37,17 @@ struct ThinParams {
   int act; float slope;
   void* out; int out_cs, out_co, out_f32;
   int pad, tiles, tx, ty;
+  int full;                                 // every tile lies inside the image (H % 8 == 0, W % 16 == 0)
 };
 
-template <int TN, int KB, int KS>
+// WIDE (SPADE's conv_shared of a whole block as ONE 1x1 convolution over the tap-expanded label map, 72 -> 3 x 128
+// columns over every pixel of the 1024x768 / 512x384 levels: 768 bytes written per pixel for 55 kFLOP, HBM-write-bound):
+//   * all 32 * TN columns are real and there is no residual (host contract); the bias sits in LDS;
+//   * lanes l and l + 32 exchange 4-channel groups (v_permlane32_swap) so that a lane stores 8 consecutive channels,
+//     16 bytes, per instruction;
+//   * with full tiles every wave issues exactly 2 * TN stores after the next patch's DMA: the loop waits for the DMA
+//     with a counted vmcnt and lets the stores drain under the next tile's MFMAs (one block per CU: 61 KB of weights).
+template <int TN, int KB, int KS, bool WIDE = false>
 __global__ __launch_bounds__(256) void thin_conv_kernel(const ThinParams p) {
   constexpr int KH = KS == 9 ? 3 : 1, KW = KH;
   constexpr int PWD = 16 + KW - 1, PHT = 8 + KH - 1, PPIX = PWD * PHT;
@@ -44,6 +60,7 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ThinParams p) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char smem[];
   unsigned char* const wl = smem;
   unsigned char* const patch = smem + ((WBYTES + 1023) & ~1023);
+  float* const bias_l = reinterpret_cast<float*>(patch + NI * 1024);      // WIDE only: [32 * TN]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -70,6 +87,9 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ThinParams p) {
       *reinterpret_cast<unsigned short*>(wl + ((tap * KB + kb) * NP + n) * 32 + half * 16 + (kk & 7) * 2) = f2bf(v);
     }
   }
+
+  if constexpr (WIDE)
+    for (int c = tid; c < NP; c += 256) bias_l[c] = p.shift ? p.shift[c] : 0.f;
 
   // ---- patch DMA lane constants: slot -> (patch pixel, 16-byte channel group)
   const rsrc_t rs = make_rsrc(p.src, p.src_bytes);
@@ -142,6 +162,38 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ThinParams p) {
       int n, y0, x0;
       tile_origin(t, n, y0, x0);
       const int y = y0 + 2 * wave + (l31 >> 4), x = x0 + (l31 & 15);
+      if constexpr (WIDE) {
+        if (y < p.H && x < p.W) {
+          const float act_sl = p.act == HRV_ACT_NONE ? 1.f : (p.act == HRV_ACT_RELU ? 0.f : p.slope);
+          unsigned short* const orow = reinterpret_cast<unsigned short*>(p.out) + (((size_t)n * p.H + y) * p.W + x) * p.out_cs + p.out_co + 8 * lh;
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              unsigned q[2][2];      // [g = 2h, 2h + 1][2 packed bf16 pairs]
+#pragma unroll
+              for (int gg = 0; gg < 2; ++gg) {
+                const int g = 2 * h + gg;
+                const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias_l + j * 32 + 8 * g + 4 * lh);
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                  const float t = acc[j][4 * g + e] + b4[e];
+                  v[e] = fmaxf(t, t * act_sl);          // none (1) / ReLU (0) / LeakyReLU (slope): one form, no branches
+                }
+                q[gg][0] = thin_pk_bf16(v[0], v[1]);
+                q[gg][1] = thin_pk_bf16(v[2], v[3]);
+              }
+              // lanes < 32 end up with (own g0, partner's g0) = channels 16h + 0..7, lanes >= 32 with (partner's g1, own g1)
+              // = channels 16h + 8..15 of their pixel
+              const auto s0 = __builtin_amdgcn_permlane32_swap(q[0][0], q[1][0], false, false);
+              const auto s1 = __builtin_amdgcn_permlane32_swap(q[0][1], q[1][1], false, false);
+              u32x4 o;
+              o[0] = s0[0]; o[1] = s1[0]; o[2] = s0[1]; o[3] = s1[1];
+              *reinterpret_cast<u32x4*>(orow + j * 32 + 16 * h) = o;
+            }
+        }
+      } else
       if (y < p.H && x < p.W) {
         const size_t pix = ((size_t)n * p.H + y) * p.W + x;
 #pragma unroll
@@ -165,22 +217,30 @@ __global__ __launch_bounds__(256) void thin_conv_kernel(const ThinParams p) {
           }
       }
     }
-    __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));   // the next patch has landed (and this tile's stores left)
+    if (WIDE && p.full) {
+      // exactly 2 * TN stores follow the patch DMA in this wave's queue (in-order completion): the patch has landed, the
+      // stores drain under the next tile's MFMAs
+      constexpr int NS = 2 * TN;
+      static_assert(NS < 64, "vmcnt is six bits");
+      __builtin_amdgcn_s_waitcnt((NS & 15) | (7 << 4) | (0 << 8) | ((NS >> 4) << 14));
+    } else {
+      __builtin_amdgcn_s_waitcnt(0 | (7 << 4) | (0 << 8));   // the next patch has landed (and this tile's stores left)
+    }
     __syncthreads();
   }
 }
 
-template <int TN, int KB, int KS>
+template <int TN, int KB, int KS, bool WIDE = false>
 static int thin_launch(const ThinParams& p, hipStream_t st) {
   constexpr int KH = KS == 9 ? 3 : 1;
   constexpr int PPIX = (16 + KH - 1) * (8 + KH - 1), SL = (2 * KB) | 1;
   constexpr int WB = (KS * KB * 32 * TN * 32 + 1023) & ~1023;
   constexpr int PB = ((PPIX * SL + 63) / 64) * 1024;
-  constexpr int LDS = WB + PB;
+  constexpr int LDS = WB + PB + (WIDE ? 32 * TN * 4 : 0);
   static_assert(LDS <= 160 * 1024, "thin conv: LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_kernel<TN, KB, KS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_kernel<TN, KB, KS, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess) {
       set_error("thin_conv: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", LDS);
       return HRV_ERR_LAUNCH;
@@ -198,7 +258,7 @@ static int thin_launch(const ThinParams& p, hipStream_t st) {
   per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   int grid = n_cu * per_cu;
   if (grid > p.tiles) grid = p.tiles;
-  hipLaunchKernelGGL((thin_conv_kernel<TN, KB, KS>), dim3(grid), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((thin_conv_kernel<TN, KB, KS, WIDE>), dim3(grid), dim3(256), LDS, st, p);
   return check_launch("thin_conv_kernel");
 }
 
@@ -214,7 +274,8 @@ extern "C" int hrv_thin_conv_supported(int32_t KH, int32_t KW, int32_t src_chann
   // kb 1: the 9-channel stem, conv_img's data gradient; (tn 2, kb 1): VGG19 features.0 (3 -> 64 over every pixel)
   // (tn 2, kb 4): VGG19 features.2 (64 -> 64 over every pixel, bf16-stored activations)
   if (k9) return (tn == 1 && (kb == 5 || kb == 2 || kb == 1)) || (tn == 3 && kb == 2) || (tn == 2 && (kb == 1 || kb == 4));
-  return (tn == 1 && kb == 5) || (tn == 3 && kb == 2);
+  // (tn 12, kb 5): a SPADEResBlock's three conv_shared as one 1x1 over the tap-expanded label map (72 -> 384), see WIDE
+  return (tn == 1 && kb == 5) || (tn == 3 && kb == 2) || (tn == 12 && kb == 5 && out_columns == 384);
 }
 
 extern "C" int hrv_thin_conv_bf16(const hrv_thin_conv_t* d, hrv_stream_t stream) {
@@ -246,6 +307,7 @@ extern "C" int hrv_thin_conv_bf16(const hrv_thin_conv_t* d, hrv_stream_t stream)
   p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff; p.out_f32 = d->out_bf16 ? 0 : 1;
   p.pad = d->KH / 2;
   p.tx = (d->W + 15) / 16; p.ty = (d->H + 7) / 8; p.tiles = d->N * p.tx * p.ty;
+  p.full = (d->W % 16 == 0 && d->H % 8 == 0) ? 1 : 0;
   hipStream_t st = (hipStream_t)stream;
   const int kb = (d->src_channels + 15) / 16, tn = (NC + 31) / 32;
   if (d->KH == 3) {
@@ -258,6 +320,14 @@ extern "C" int hrv_thin_conv_bf16(const hrv_thin_conv_t* d, hrv_stream_t stream)
   } else {
     if (tn == 1 && kb == 5) return thin_launch<1, 5, 1>(p, st);
     if (tn == 3 && kb == 2) return thin_launch<3, 2, 1>(p, st);
+    if (tn == 12 && kb == 5) {
+      HRV_REQUIRE(d->act == HRV_ACT_NONE || d->act == HRV_ACT_RELU || (d->act == HRV_ACT_LRELU && d->act_slope >= 0.f && d->act_slope <= 1.f),
+                  "thin_conv: the 384-column layer takes no activation, ReLU or LeakyReLU");
+      HRV_REQUIRE(d->mode == 0 && !d->residual && d->out_bf16 && d->out_cstride % 8 == 0 && d->out_coff % 8 == 0 &&
+                      ((uintptr_t)d->out & 15) == 0,
+                  "thin_conv: the 384-column layer is forward-only, without residual, into a bf16 tensor with 8-channel granules");
+      return thin_launch<12, 5, 1, true>(p, st);
+    }
   }
   set_error("thin_conv: no instantiation");
   return HRV_ERR_ARG;

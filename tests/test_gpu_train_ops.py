@@ -537,6 +537,43 @@ def test_thin_conv_forward_and_data_gradient(case, monkeypatch):
         assert (outs["1"][1] - outs["0"][1]).abs().max() <= 2e-4 * refd.abs().max()
 
 
+@pytest.mark.parametrize("hw", [(192, 208), (180, 200)], ids=["full_tiles", "overhanging_tiles"])
+def test_thin_conv_conv_shared_as_one_384_column_layer(hw, monkeypatch):
+    """thin_conv.hip, WIDE variant: a SPADEResBlock's three conv_shared (network_generator.py:99-102) as ONE 1x1 convolution
+    over the tap-expanded one-hot label map (72 -> 384 columns, bias + ReLU, bf16 output; lanes l / l+32 exchange 4-channel
+    groups so that a lane stores 16 bytes; full tiles wait for the next patch with a counted vmcnt).  vs torch on the same
+    bf16-representable operands and vs the implicit-GEMM engine it replaces, for tiles inside the image and overhanging ones,
+    over several persistent rounds (N*H*W/128 tiles > 2 x 256 CUs), the output a channel slice of a wider tensor."""
+    ops, T = _mods()
+    H, W = hw
+    N, cin, cout = 3, 72, 384
+    g = torch.Generator().manual_seed(H)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb((torch.rand(N, cin, H, W, generator=g) < 0.15).float() + 0.25 * torch.randn(N, cin, H, W, generator=g))
+    w = (torch.randn(cout, cin, 1, 1, generator=g) * 0.1).cuda()
+    b = (torch.randn(cout, generator=g) * 0.1).cuda()
+    outs = {}
+    T.MMA_BF16[0] = True
+    try:
+        for thin in ("1", "0"):
+            monkeypatch.setenv("HRV_THIN_CONV", thin)
+            xa = ops.to_nhwc(x.cuda(), bf16=True)
+            full = ops.alloc(N, H, W, cout + 16, "cuda", bf16=True)
+            full.t.fill_(3.0)
+            y = T.conv_forward_dev(w, [(xa, 0)], 1, 0, shift=b, act=ops.ACT_RELU, out=full.slice(8, cout), out_bf16=True,
+                                   name="up_4.conv_shared[x3 as 1x1 over taps]")
+            torch.cuda.synchronize()
+            outs[thin] = ops.to_nchw(y).float().cpu()
+            assert torch.equal(full.t[..., :8].float().cpu(), torch.full((N, H, W, 8), 3.0)), "channels below the slice"
+            assert torch.equal(full.t[..., 8 + cout:].float().cpu(), torch.full((N, H, W, 8), 3.0)), "channels above the slice"
+    finally:
+        T.MMA_BF16[0] = False
+    ref = torch.relu(F.conv2d(x, rb(w.cpu()), b.cpu()))
+    tol = 2.0 ** -8 * float(ref.abs().max())             # one bf16 rounding of the stored result
+    assert (outs["1"] - ref).abs().max() <= tol, ((outs["1"] - ref).abs().max() / ref.abs().max()).item()
+    assert (outs["1"] - outs["0"]).abs().max() <= tol
+
+
 @pytest.mark.parametrize("case", [("tile17_256cols", 8, 128, 96, 128, 256, 17), ("tile18_192cols_split", 4, 128, 96, 128, 192, 18),
                                   ("tile17_2chunks", 8, 128, 96, 256, 128, 17), ("tile18_64cols", 8, 128, 96, 128, 64, 18)],
                          ids=lambda c: c[0])
