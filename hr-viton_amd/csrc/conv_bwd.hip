@@ -61,18 +61,19 @@ __device__ __forceinline__ bool pack_pair_src(const PackParams& p, int co, const
   return true;
 }
 
-// one element of the packed matrix
-__device__ __forceinline__ void pack_one(const PackParams& p, const size_t i, const float mul) {
-  const int BKp = p.bke;
-  const int k = (int)(i % BKp);
-  const size_t t = i / BKp;
-  const int row = (int)(t % p.rows_pad);
-  const int kt = (int)(t / p.rows_pad);
-  const int tap = kt / p.chunks_total, chunk = kt - tap * p.chunks_total;
-  const int jh = tap / p.KWp, jw = tap - jh * p.KWp;
-  const int kh = p.kh_of[jh], kw = p.kw_of[jw];
-  float v = 0.f;
-  if (row < p.rows && kh >= 0 && kw >= 0) {
+// one COLUMN of the packed matrix: the (row, k) position ``i`` (over [chunk][row][k]) for every tap.  A thread reads the
+// KH*KW taps of its (cout, cin) pair -- contiguous in the OIHW parameter -- once, and writes one element per tap plane
+// (consecutive lanes = consecutive k: coalesced).  (One element per thread re-fetched the same 32-byte sectors once per
+// tap: the batched pack of the generator, 140 M elements, took 0.3 ms per launch = gather-bound.)
+template <typename IDX>
+__device__ __forceinline__ void pack_col(const PackParams& p, const IDX i, const float mul) {
+  const int BKp = p.bke;                 // 16 / 32 / 64
+  const int k = (int)(i & (IDX)(BKp - 1));
+  const IDX t = i >> (31 - __clz(BKp));
+  const int row = (int)(t % (IDX)p.rows_pad);
+  const int chunk = (int)(t / (IDX)p.rows_pad);
+  const float* src = nullptr;            // &w[co][ci][0][0], or null: a padding position
+  if (row < p.rows) {
     int s = 0;
 #pragma unroll
     for (int q = 1; q < HRV_MAX_SRC; ++q)
@@ -84,29 +85,38 @@ __device__ __forceinline__ void pack_one(const PackParams& p, const size_t i, co
       const int ci = p.transposed ? row : cc;
       const float* wp;
       int cr;
-      if (pack_pair_src(p, co, wp, cr)) v = wp[(((size_t)cr * p.CinTot + ci) * p.KH + kh) * p.KW + kw] * mul;
+      if (pack_pair_src(p, co, wp, cr)) src = wp + ((size_t)cr * p.CinTot + ci) * p.KH * p.KW;
     }
   }
-  if (p.bf16) {  // round to nearest even
-    unsigned u = __builtin_bit_cast(unsigned, v);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    reinterpret_cast<unsigned short*>(p.out)[i] = (unsigned short)(u >> 16);
-  } else {
-    p.out[i] = v;
+  const size_t plane = (size_t)p.chunks_total * p.rows_pad * BKp;      // elements per tap
+  size_t o = (size_t)i;
+  for (int jh = 0; jh < p.KHp; ++jh) {
+    const int kh = p.kh_of[jh];
+    for (int jw = 0; jw < p.KWp; ++jw, o += plane) {
+      const int kw = p.kw_of[jw];
+      const float v = (src && kh >= 0 && kw >= 0) ? src[kh * p.KW + kw] * mul : 0.f;
+      if (p.bf16) {  // round to nearest even
+        unsigned u = __builtin_bit_cast(unsigned, v);
+        u += 0x7fffu + ((u >> 16) & 1u);
+        reinterpret_cast<unsigned short*>(p.out)[o] = (unsigned short)(u >> 16);
+      } else {
+        p.out[o] = v;
+      }
+    }
   }
 }
 
 __global__ void pack_weight_kernel(const PackParams p) {
-  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * p.bke;
+  const size_t cols = (size_t)p.chunks_total * p.rows_pad * p.bke;
   const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x)
-    pack_one(p, i, mul);
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < cols; i += (size_t)gridDim.x * blockDim.x)
+    pack_col(p, i, mul);
 }
 
 // Every weight pack of a network in ONE launch (a training step re-packs ~180 weights after each optimizer step: one
 // 5-11 us launch each otherwise).  ``tbl``: the records hrv_conv2d_pack_weight_record filled, on the device; ``first``:
-// [n + 1] first block of each record (PACK_MULTI_ELEMS elements per block).  Same arithmetic per element as above.
-constexpr int PACK_MULTI_ELEMS = 2048;
+// [n + 1] first block of each record (PACK_MULTI_ELEMS columns per block).  Same arithmetic per element as above.
+constexpr int PACK_MULTI_ELEMS = 1024;
 __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackParams* __restrict__ tbl,
                                                                 const int* __restrict__ first, const int n) {
   const int b = blockIdx.x;
@@ -115,14 +125,20 @@ __global__ __launch_bounds__(256) void pack_weight_multi_kernel(const PackParams
     const int mid = (lo + hi) >> 1;
     if (first[mid] <= b) lo = mid; else hi = mid;
   }
-  const PackParams& p = tbl[lo];
-  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * p.bke;
-  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
-  const size_t i0 = (size_t)(b - first[lo]) * PACK_MULTI_ELEMS + threadIdx.x;
-#pragma unroll
+  // the record moves to LDS: read through the table pointer, every field would be re-loaded from global memory after each
+  // store (the compiler cannot rule out that the packed output aliases the table) -- first build: 0.94 ms per launch
+  __shared__ PackParams sp;
+  static_assert(sizeof(PackParams) % 4 == 0, "record is copied in dwords");
+  for (int k = threadIdx.x; k < (int)(sizeof(PackParams) / 4); k += 256)
+    reinterpret_cast<unsigned*>(&sp)[k] = reinterpret_cast<const unsigned*>(tbl + lo)[k];
+  __syncthreads();
+  const unsigned cols = (unsigned)((size_t)sp.chunks_total * sp.rows_pad * sp.bke);   // < 2^30 (host check)
+  const float mul = sp.sigma ? sp.wscale / sp.sigma[0] : sp.wscale;
+  const unsigned i0 = (unsigned)(b - first[lo]) * PACK_MULTI_ELEMS + threadIdx.x;
+#pragma unroll 2
   for (int k = 0; k < PACK_MULTI_ELEMS / 256; ++k) {
-    const size_t i = i0 + (size_t)k * 256;
-    if (i < total) pack_one(p, i, mul);
+    const unsigned i = i0 + (unsigned)k * 256;
+    if (i < cols) pack_col(sp, i, mul);
   }
 }
 
@@ -725,7 +741,7 @@ static int pack_weight_dev_impl(const float* w_oihw_dev, int32_t Cout, int32_t K
     out_geom[4] = p.rows; out_geom[5] = p.rows_pad; out_geom[6] = p.chunks_total;
     out_geom[7] = p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
   }
-  const size_t total = (size_t)p.KHp * p.KWp * p.chunks_total * p.rows_pad * BK;
+  const size_t total = (size_t)p.chunks_total * p.rows_pad * BK;       // columns: one thread packs every tap of a column
   if (record) {      // hrv_conv2d_pack_weight_record: the launch is the caller's hrv_conv2d_pack_weight_multi
     *record = p;
     return HRV_OK;
@@ -756,7 +772,9 @@ extern "C" int hrv_conv2d_pack_weight_record(const float* w_oihw_dev, int32_t Co
                                       phase_b, wscale, sigma_dev, out_dev, out_geom, nullptr, bke, as_bf16 ? 1 : 0, w2_dev,
                                       pair_mode, rows_each, (PackParams*)record_host);
   if (rc) return rc;
-  *blocks = (int32_t)(((int64_t)out_geom[7] + PACK_MULTI_ELEMS - 1) / PACK_MULTI_ELEMS);
+  HRV_REQUIRE(out_geom[7] > 0 && (int64_t)out_geom[7] < (int64_t)1 << 30, "pack_record: packed size");
+  const int64_t cols = (int64_t)out_geom[7] / ((int64_t)out_geom[0] * out_geom[1]);      // elements per tap plane
+  *blocks = (int32_t)((cols + PACK_MULTI_ELEMS - 1) / PACK_MULTI_ELEMS);
   return HRV_OK;
 }
 

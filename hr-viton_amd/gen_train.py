@@ -116,7 +116,7 @@ class TConv:
         b = self.bparam
         return T.conv_forward_dev(self.wparam.data, srcs, self.stride, self.pad, sigma=self.sigma,
                                   shift=None if b is None else b.data, residual=residual, act=act, slope=slope, out=out,
-                                  out_up=out_up, name=self.name, out_bf16=out_bf16)
+                                  out_up=out_up, name=self.name, out_bf16=out_bf16, batch=getattr(self, "pack_batch", None))
 
     def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
                  act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True, dx_bf16: bool = False,
@@ -146,7 +146,7 @@ class TConv:
         a0, up0 = srcs[0]
         H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
         return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope,
-                            name=self.name + ".dgrad", out_bf16=dx_bf16, add=add)
+                            name=self.name + ".dgrad", out_bf16=dx_bf16, add=add, batch=getattr(self, "pack_batch", None))
 
 
 class SpadeT:
@@ -200,7 +200,7 @@ class SpadeT:
             return out, ctx
         # (conv_gamma, conv_beta) weights packed straight into the combined interleaved matrix (no concatenated copy)
         packed, _, _ = T.pack_weight_pair_dev(n.conv_gamma.weight.data, n.conv_beta.weight.data, 1, [self.hid], [self.hid],
-                                              cfg, 0, 1, mb)
+                                              cfg, 0, 1, mb, batch=getattr(self.shared, "pack_batch", None))
         # mixed precision: the modulated activation is read by matrix cores only (conv_0 / conv_1 / conv_s, their weight
         # gradients) and as the sign mask of its own LeakyReLU -- stored in bf16 (same operand bits as rounding while
         # staging, half the bytes); widths that are not a multiple of 4 keep the fp32 weight-gradient kernel and fp32
@@ -285,7 +285,8 @@ class SpadeT:
             T.spade_gb_dgrad(dgb, T.spade_gb_pack(1, n.conv_gamma.weight.data, n.conv_beta.weight.data), C_, actv, 0.0, dact,
                              self.name + ".gb.dgrad")
         else:
-            T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad")
+            T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad",
+                         batch=getattr(self.shared, "pack_batch", None))
         return dx
 
 
@@ -435,8 +436,8 @@ class GeneratorTrainPlan:
         dev = x.device
         # one batched power iteration for every spectral-normalised convolution of the generator (four launches)
         # ... and one batched launch for the plan's weight packs (T.PackBatch)
-        T.prepare_convs(self, [c for b in self.blocks for c in b.convs()] + list(self.stems) + [self.img], power_iteration,
-                        extra_weights=[n_.norm.conv_gamma.weight.data for b in self.blocks for n_ in b.norms()])
+        T.prepare_convs(self, [c for b in self.blocks for c in b.convs()] + list(self.stems) + [self.img] +
+                        [n_.shared for b in self.blocks for n_ in b.norms()], power_iteration, backward=save)
         xin = ops.to_nhwc(x)
         # mixed precision: the full-resolution stem (conv_7: 9 -> 16 channels over every pixel) reads a bf16 copy of the
         # input (matrix-core operand only) so that it runs on the thin-convolution kernel

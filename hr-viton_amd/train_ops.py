@@ -57,10 +57,11 @@ class PackBatch:
     def __init__(self, device):
         self.device = device
         self.index: dict = {}            # key -> record number
-        self.bufs, self.geoms, self.blocks, self.records = [], [], [], []
-        self.table = self.first = None
+        self.bufs, self.geoms, self.blocks, self.records, self.group = [], [], [], [], []
+        self.tables = [None, None]       # per group (0: forward packs, 1: data-gradient packs): (records, first block, n, blocks)
         self.dirty = False
-        self.stamp = None
+        self.stamp = None                # epoch of the last run()
+        self.bwd_fresh = False           # ... which also packed group 1
         self.launches = 0
 
     @staticmethod
@@ -72,44 +73,54 @@ class PackBatch:
 
     def lookup(self, key):
         i = self.index.get(key)
-        if i is None or self.dirty or not self.fresh():
+        if i is None or self.dirty or not self.fresh() or (self.group[i] == 1 and not self.bwd_fresh):
             return None
         return self.bufs[i], self.geoms[i]
 
-    def add(self, key, record: bytes, blocks: int, buf: torch.Tensor, geom: tuple):
+    def add(self, key, record: bytes, blocks: int, buf: torch.Tensor, geom: tuple, group: int = 0):
         self.index[key] = len(self.bufs)
         self.bufs.append(buf); self.geoms.append(geom); self.blocks.append(blocks); self.records.append(record)
+        self.group.append(group)
         self.dirty = True
 
-    def run(self):
-        """(Re)pack every recorded weight from its current values; marks the batch fresh."""
+    def run(self, backward: bool = True):
+        """(Re)pack the recorded weights from their current values -- ``backward`` False: the forward packs only (a no_grad
+        forward never asks for the data-gradient forms); marks the batch fresh."""
         self.stamp = self._now()
+        self.bwd_fresh = backward
         if not self.bufs:
             return
         lib = _lib.load()
         if self.dirty:
             import numpy as np
-            tbl = np.frombuffer(b"".join(self.records), dtype=np.uint8).copy()
-            first = np.zeros(len(self.blocks) + 1, dtype=np.int32)
-            first[1:] = np.cumsum(np.asarray(self.blocks, dtype=np.int64))
-            self.table = torch.from_numpy(tbl).to(self.device)
-            self.first = torch.from_numpy(first).to(self.device)
-            self.total_blocks = int(first[-1])
+            for g in (0, 1):
+                idx = [i for i in range(len(self.bufs)) if self.group[i] == g]
+                if not idx:
+                    self.tables[g] = None
+                    continue
+                tbl = np.frombuffer(b"".join(self.records[i] for i in idx), dtype=np.uint8).copy()
+                first = np.zeros(len(idx) + 1, dtype=np.int32)
+                first[1:] = np.cumsum(np.asarray([self.blocks[i] for i in idx], dtype=np.int64))
+                self.tables[g] = (torch.from_numpy(tbl).to(self.device), torch.from_numpy(first).to(self.device), len(idx),
+                                  int(first[-1]))
             self.dirty = False
-        _lib.check(lib.hrv_conv2d_pack_weight_multi(self.table.data_ptr(), self.first.data_ptr(), len(self.bufs),
-                                                    self.total_blocks, _stream()), "hrv_conv2d_pack_weight_multi")
-        self.launches += 1
+        for g in ((0, 1) if backward else (0,)):
+            t = self.tables[g]
+            if t is not None:
+                _lib.check(lib.hrv_conv2d_pack_weight_multi(t[0].data_ptr(), t[1].data_ptr(), t[2], t[3], _stream()),
+                           "hrv_conv2d_pack_weight_multi")
+                self.launches += 1
 
 
-_PACK_OWNER: dict = {}      # weight storage address -> the PackBatch of the plan that prepared it last
 PACK_BATCHING = [os.environ.get("HRV_PACK_BATCH", "1") != "0"]
 
 
-def _pack_batched(w, w2, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, cfg, mode, stride, pad, phase, wscale, sigma,
+def _pack_batched(batch, w, w2, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, cfg, mode, stride, pad, phase, wscale, sigma,
                   bf16, nelem):
-    """-> (buf, geom) from the owning plan's PackBatch (recording the pack on its first use), or None: not batched."""
-    batch = _PACK_OWNER.get(w.data_ptr()) if PACK_BATCHING[0] else None
-    if batch is None or not batch.fresh():
+    """-> (buf, geom) from ``batch``, the PackBatch of the plan that owns the weight (handed down by its TConv / SpadeT;
+    recording the pack on its first use), or None: not batched.  (The owner is named by the caller, never looked up by
+    storage address: a temporary at a recycled address must not be served another network's pack.)"""
+    if batch is None or not PACK_BATCHING[0] or not batch.fresh():
         return None
     key = (w.data_ptr(), 0 if w2 is None else w2.data_ptr(), pair_mode, rows_each, Cout, KH, KW, tuple(src_pad), tuple(src_real),
            cfg, mode, stride, pad, tuple(phase), wscale, 0 if sigma is None else sigma.data_ptr(), bf16)
@@ -133,13 +144,13 @@ def _pack_batched(w, w2, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, 
     one = PackBatch(w.device)
     one.add(key, rec.raw, blocks.value, buf, tuple(geom))
     one.run()
-    batch.add(key, rec.raw, blocks.value, buf, tuple(geom))
+    batch.add(key, rec.raw, blocks.value, buf, tuple(geom), group=0 if mode == 0 else 1)
     return buf, tuple(geom)
 
 
 def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[int], cfg: int, mode: int = 0,
                     stride: int = 1, pad: int = 0, phase: Tuple[int, int] = (0, 0), wscale: float = 1.0,
-                    sigma: Optional[torch.Tensor] = None, bf16: bool = False, frozen=None):
+                    sigma: Optional[torch.Tensor] = None, bf16: bool = False, frozen=None, batch=None):
     """hrv_conv2d_pack_weight_dev_f32.  ``w``: OIHW fp32 on the device.  Returns (packed, geom)
     with geom = (KHp, KWp, pad_h, pad_w, rows, rows_pad, chunks_total, elems).
     ``frozen`` (a hashable stamp of the owning parameter, or None): the weight belongs to a network that is never
@@ -165,7 +176,7 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
     bke = lib.hrv_conv2d_tile_row_bytes(cfg) // 2 if bf16 else 16      # k-values per packed row (the tile's row size)
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
     if key is None:
-        hit = _pack_batched(w, None, 0, 0, Cout, KH, KW, src_pad, src_real, cfg, mode, stride, pad, phase, wscale, sigma, bf16,
+        hit = _pack_batched(batch, w, None, 0, 0, Cout, KH, KW, src_pad, src_real, cfg, mode, stride, pad, phase, wscale, sigma, bf16,
                             KH * KW * chunks * rows_pad * bke)
         if hit is not None:
             return hit
@@ -183,7 +194,7 @@ def pack_weight_dev(w: torch.Tensor, src_pad: Sequence[int], src_real: Sequence[
 
 
 def pack_weight_pair_dev(w_a: torch.Tensor, w_b: torch.Tensor, pair_mode: int, src_pad: Sequence[int], src_real: Sequence[int],
-                         cfg: int, mode: int, pad: int, bf16: bool):
+                         cfg: int, mode: int, pad: int, bf16: bool, batch=None):
     """hrv_conv2d_pack_weight_pair_dev: (conv_gamma.weight, conv_beta.weight) packed as ONE matrix without a
     concatenated copy.  pair_mode 1 (forward): rows interleaved (gamma32 | beta32); 2 (data gradient over
     [dgamma | dbeta]).  Returns (packed, geom, virtual Cout)."""
@@ -201,7 +212,7 @@ def pack_weight_pair_dev(w_a: torch.Tensor, w_b: torch.Tensor, pair_mode: int, s
     rows_pad = (rows + bn - 1) // bn * bn
     bke = lib.hrv_conv2d_tile_row_bytes(cfg) // 2 if bf16 else 16
     chunks = sum((c + bke - 1) // bke for c in src_pad) if mode == 0 else (_ceil4(Cout) + bke - 1) // bke
-    hit = _pack_batched(w_a, w_b, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, cfg, mode, 1, pad, (0, 0), 1.0, None, bf16,
+    hit = _pack_batched(batch, w_a, w_b, pair_mode, rows_each, Cout, KH, KW, src_pad, src_real, cfg, mode, 1, pad, (0, 0), 1.0, None, bf16,
                         KH * KW * chunks * rows_pad * bke)
     if hit is not None:
         return hit[0], hit[1], Cout
@@ -336,7 +347,7 @@ def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
-                     out_bf16: bool = False, frozen=None) -> Act:
+                     out_bf16: bool = False, frozen=None, batch=None) -> Act:
     """Forward convolution with device-resident, per-step packed weights.  ``srcs``: (Act, up_shift).
     ``out_bf16`` (mixed precision only): store the result in bf16 -- for tensors that only matrix cores read."""
     lib = _lib.load()
@@ -361,7 +372,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     real = [a.C for a, _ in srcs]
     assert sum(real) == cin, (name, real, cin)
     packed, _ = pack_weight_dev(w, [a.Cp for a, _ in srcs], real, cfg, 0, stride, pad, wscale=wscale, sigma=sigma,
-                                bf16=mb, frozen=frozen)
+                                bf16=mb, frozen=frozen, batch=batch)
     if out is None:
         out = ops.alloc(N, Ho << out_up, Wo << out_up, Cout, a0.t.device, bf16=out_bf16 and mb)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
@@ -372,7 +383,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
 
 def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
                sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
-               name: str = "dgrad", out_bf16: bool = False, frozen=None, add: Optional[Act] = None) -> Act:
+               name: str = "dgrad", out_bf16: bool = False, frozen=None, add: Optional[Act] = None, batch=None) -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
     activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x).
     ``w`` may be a PAIR (w_gamma, w_beta) for dY = [dgamma | dbeta] (stride 1): packed without a concatenated copy.
@@ -404,10 +415,10 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         if mb and (Ho, Wo) == (H, W):   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
             cfg = ops.patch_tile(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) or cfg
         if pair is not None:
-            packed, g, _ = pack_weight_pair_dev(pair[0], pair[1], 2, [_ceil4(cin)], [cin], cfg, 1, pad, mb)
+            packed, g, _ = pack_weight_pair_dev(pair[0], pair[1], 2, [_ceil4(cin)], [cin], cfg, 1, pad, mb, batch=batch)
         else:
             packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg, 1, 1, pad, wscale=wscale, sigma=sigma, bf16=mb,
-                                        frozen=frozen)
+                                        frozen=frozen, batch=batch)
         _run_engine([(dy, 0, Cout)], packed, cin, cfg, N, Ho, Wo, H, W, g[0], g[1], 1, g[2], g[3], out,
                     residual=act_mask, res_mode=res_mode, slope=slope, name=name, flops=fl, mma_bf16=mb)
         return out
@@ -418,7 +429,7 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
             if Hp <= 0 or Wp <= 0:
                 continue
             cfg_p = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * Hp * Wp, cin)
-            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale, sigma, bf16=mb)
+            packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale, sigma, bf16=mb, batch=batch)
             _run_engine([(dy, 0, Cout)], packed, cin, cfg_p, N, Ho, Wo, Hp, Wp, g[0], g[1], 1, g[2], g[3], out,
                         residual=act_mask, res_mode=res_mode, slope=slope, free_extent=1, out_step=2, out_off=(a, b),
                         out_hw=(H, W), name=f"{name}[phase {a}{b}]", flops=fl / 4, mma_bf16=mb)
@@ -669,10 +680,10 @@ class SpectralBatch:
         return sig.split(1), ub.split(self.Rs), vb.split(self.Ks)
 
 
-def prepare_convs(owner, convs, power_iteration: bool, extra_weights: Sequence[torch.Tensor] = ()):
+def prepare_convs(owner, convs, power_iteration: bool, backward: bool = True):
     """TConv.prepare for every spectral-normalised convolution of ``convs`` at once (``owner`` caches the batch), then
-    the plan's recorded weight packs in one launch (PackBatch; ``extra_weights``: further weights of the plan whose
-    packs should ride along, e.g. SPADE's conv_gamma)."""
+    the plan's recorded weight packs in one launch (PackBatch, handed to every conv as ``pack_batch``; ``backward`` False:
+    a no_grad forward, the data-gradient packs are left alone)."""
     _prepare_sigmas(owner, convs, power_iteration)
     if not convs:
         return
@@ -681,15 +692,11 @@ def prepare_convs(owner, convs, power_iteration: bool, extra_weights: Sequence[t
     if pb is None or pb.device != dev:
         pb = owner._pack_batch = PackBatch(dev)
     for c in convs:
-        _PACK_OWNER[c.wparam.data.data_ptr()] = pb
-    for w in extra_weights:
-        _PACK_OWNER[w.data_ptr()] = pb
-    if len(_PACK_OWNER) > 8192:          # (addresses of dead networks; a live plan re-registers at its next forward)
-        _PACK_OWNER.clear()
+        c.pack_batch = pb
     # (while a hipGraph is being captured the record table cannot be re-uploaded: a plan that still has unrecorded packs
     #  then packs one by one, which captures fine)
     if PACK_BATCHING[0] and not (pb.dirty and torch.cuda.is_current_stream_capturing()):
-        pb.run()
+        pb.run(backward)
 
 
 def _prepare_sigmas(owner, convs, power_iteration: bool):
