@@ -263,6 +263,27 @@ __global__ void tapsum_kernel(const float* __restrict__ y, int N, int H, int W, 
   }
 }
 
+// ------------------------------------------------------------------ space <-> depth (factor 2)
+// out[n][y/2][x/2][((y&1)*2 + (x&1))*C + c] = in[n][y][x][c]: a 4x4 stride-2 pad-2 convolution over C channels becomes a
+// 2x2 stride-1 pad-1 convolution over 4C (PatchGAN model0, 10 channels: one 64-k row per tap wastes 5/6 of the matrix
+// cores and of the gather otherwise -- gen_train.S2DConv).  dir 0: in -> out, dir 1: the inverse.
+__global__ void space_depth2_kernel(const float* __restrict__ a, int N, int H, int W, int C4, int cs, int co,
+                                    float* __restrict__ b, int dir) {
+  const size_t total = (size_t)N * H * W * C4;
+  const int Hc = H >> 1, Wc = W >> 1, C = C4 * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const size_t full = (((size_t)n * H + y) * W + x) * cs + co + 4 * c4;
+    const size_t cell = ((((size_t)n * Hc + (y >> 1)) * Wc + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1)) * C + 4 * c4;
+    if (dir == 0) *reinterpret_cast<float4*>(b + cell) = *reinterpret_cast<const float4*>(a + full);
+    else *reinterpret_cast<float4*>(b + full) = *reinterpret_cast<const float4*>(a + cell);
+  }
+}
+
 }  // namespace hrv
 
 using namespace hrv;
@@ -389,4 +410,29 @@ extern "C" int hrv_tapsum_nhwc_f32(const float* y, int32_t N, int32_t H, int32_t
   hipLaunchKernelGGL(tapsum_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, y, N, H, W, KH, KW,
                      pad, Cout, y_cstride, bias, residual, res_cstride, out, out_cstride);
   return check_launch("tapsum_kernel");
+}
+
+// [N,H,W,C] (a channel slice of a wider fp32 tensor) -> dense [N,H/2,W/2,4C], channel = ((y&1)*2 + (x&1))*C + c.
+extern "C" int hrv_space_to_depth2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
+                                            int32_t in_coff, float* out, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0, "space_to_depth2: bad args");
+  HRV_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && in_cstride % 4 == 0 && in_coff % 4 == 0 && in_coff + C <= in_cstride &&
+                  (((uintptr_t)in | (uintptr_t)out) & 15) == 0,
+              "space_to_depth2: even extents, 4-channel granules");
+  const size_t total = (size_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(space_depth2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C / 4, in_cstride,
+                     in_coff, out, 0);
+  return check_launch("space_depth2_kernel");
+}
+
+// the inverse: dense [N,H/2,W/2,4C] -> dense [N,H,W,C]  (H, W: the FULL extents)
+extern "C" int hrv_depth_to_space2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out,
+                                            hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0, "depth_to_space2: bad args");
+  HRV_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && (((uintptr_t)in | (uintptr_t)out) & 15) == 0,
+              "depth_to_space2: even extents, 4-channel granules");
+  const size_t total = (size_t)N * H * W * (C / 4);
+  hipLaunchKernelGGL(space_depth2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C / 4, C, 0,
+                     out, 1);
+  return check_launch("space_depth2_kernel");
 }

@@ -11,6 +11,7 @@ down-sum of the fused nearest-upsample store, spectral-norm gradient transform.
 """
 from __future__ import annotations
 
+import os
 from typing import Dict, List, Optional, Sequence, Tuple
 
 import torch
@@ -147,6 +148,83 @@ class TConv:
         H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
         return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope,
                             name=self.name + ".dgrad", out_bf16=dx_bf16, add=add, batch=getattr(self, "pack_batch", None))
+
+
+class S2DConv(TConv):
+    """A 4x4, stride-2, pad-2 convolution over a handful of channels -- PatchGAN's model0 (network_generator.py
+    NLayerDiscriminator: input_nc = 7 + 3 -> ndf) -- computed as a 2x2 stride-1 pad-1 convolution over the space-to-depth
+    tensor [N, H/2, W/2, 4*Cp]:  kh = 2*ty + dy, kw = 2*tx + dx, in[2(o-1+ty)+dy] = cell (o-1+ty), sub-pixel dy.
+    The implicit-GEMM engine gives every TAP its own 64-k row group: 16 taps x 10 of 64 channels is 5/6 padding (model0
+    forward 0.64 ms, its weight gradient 0.64 ms, its four-phase data gradient 0.67 ms at 1024x768, all at ~1 TB/s);
+    4 taps x 48 channels fill it.  Same products, same fp32 accumulation -- only the summation order inside a K-tile
+    changes.  The weight lives in a buffer that stays (the plan's PackBatch reads it by address); ``refresh`` re-derives
+    it from the parameter before the plan's ``prepare_convs``."""
+
+    @staticmethod
+    def fits(m: nn.Module) -> bool:
+        return (tuple(m.kernel_size) == (4, 4) and tuple(m.stride) == (2, 2) and tuple(m.padding) == (2, 2) and
+                m.in_channels <= 16 and m.groups == 1 and tuple(m.dilation) == (1, 1) and
+                os.environ.get("HRV_S2D_CONV", "1") != "0")
+
+    def __init__(self, conv: nn.Module, name: str):
+        super().__init__(conv, 2, 2, name)
+        self.Cq = _ceil4(conv.in_channels)
+        self._w2: Optional[torch.Tensor] = None
+        self._cache = None
+
+    def refresh(self):
+        w = self.wparam.data
+        Cout, cin = w.shape[0], w.shape[1]
+        if self._w2 is None or self._w2.device != w.device:
+            self._w2 = torch.zeros((Cout, 2, 2, self.Cq, 2, 2), dtype=torch.float32, device=w.device)
+        # (co, c, ty, dy, tx, dx) -> (co, dy, dx, c, ty, tx); the pad channels stay zero
+        self._w2[:, :, :, :cin].copy_(w.view(Cout, cin, 2, 2, 2, 2).permute(0, 3, 5, 1, 2, 4))
+
+    @property
+    def w2(self) -> torch.Tensor:
+        return self._w2.view(self._w2.shape[0], 4 * self.Cq, 2, 2)
+
+    def forward(self, srcs, act: int = ACT_NONE, residual=None, out=None, out_up: int = 0, slope: float = 0.2,
+                out_bf16: bool = False) -> Act:
+        a, up = srcs[0]
+        if (len(srcs) != 1 or up != 0 or a.bf16 or a.H % 2 or a.W % 2 or a.Cp != self.Cq or residual is not None or
+                out is not None or out_up != 0 or self._w2 is None):
+            self._cache = None
+            return super().forward(srcs, act, residual, out, out_up, slope, out_bf16)
+        a2 = T.space_to_depth2(a)
+        self._cache = (a.t.data_ptr(), a.coff, a2)
+        b = self.bparam
+        return T.conv_forward_dev(self.w2, [(a2, 0)], 1, 1, sigma=self.sigma, shift=None if b is None else b.data, act=act,
+                                  slope=slope, name=self.name, out_bf16=out_bf16, batch=getattr(self, "pack_batch", None))
+
+    def backward(self, dy: Act, srcs, grads: Grads, need_dx: bool = True, act_mask=None, slope: float = 0.2,
+                 need_w: bool = True, dx_bf16: bool = False, dy_wgrad=None, add=None):
+        a, _ = srcs[0]
+        c = self._cache
+        if c is None or c[0] != a.t.data_ptr() or c[1] != a.coff or act_mask is not None or add is not None:
+            return super().backward(dy, srcs, grads, need_dx, act_mask, slope, need_w, dx_bf16, dy_wgrad, add)
+        a2 = Act(c[2].t[:a.N], c[2].C)             # (the generator step back-propagates the fake half of the batch only)
+        w = self.wparam.data
+        Cout, cin = w.shape[0], w.shape[1]
+        if need_w:
+            dw2 = torch.empty_like(self._w2)
+            db = grad_buffer(self.bparam) if self.bparam is not None else None
+            T.conv_wgrad(dy, a2, 0, 0, 4 * self.Cq, 2, 2, 1, 1, dw2.view(Cout, 4 * self.Cq, 2, 2), name=self.name + ".wgrad",
+                         dbias=db)
+            G = dw2[:, :, :, :cin].permute(0, 3, 4, 1, 5, 2).reshape(Cout, cin, 4, 4)      # back to (co, c, kh, kw)
+            if self.spectral:
+                dwo = grad_buffer(self.wparam)
+                T.spectral_grad(G, w, self.u, self.v, self.sigma, dwo)
+                _acc(grads, self.wparam, dwo)
+            else:
+                _acc(grads, self.wparam, G)
+            if db is not None:
+                _acc(grads, self.bparam, db)
+        if not need_dx:
+            return None
+        d2 = T.conv_dgrad(dy, self.w2, a2.H, a2.W, 1, 1, sigma=self.sigma, name=self.name + ".dgrad",
+                          batch=getattr(self, "pack_batch", None))
+        return T.depth_to_space2(d2, a.C)
 
 
 class SpadeT:
@@ -560,8 +638,9 @@ class DiscTrainPlan:
                 conv = first[0]
                 self.layers.append(("in", TConv(conv, conv.stride[0], conv.padding[0], f"{name}.model{n}")))
             else:
-                self.layers.append(("lrelu" if len(m) > 1 else "plain",
-                                    TConv(first, first.stride[0], first.padding[0], f"{name}.model{n}")))
+                tc = (S2DConv(first, f"{name}.model{n}") if (n == 0 and S2DConv.fits(first)) else
+                      TConv(first, first.stride[0], first.padding[0], f"{name}.model{n}"))
+                self.layers.append(("lrelu" if len(m) > 1 else "plain", tc))
 
     @classmethod
     def from_sequential(cls, seq: nn.Sequential, name: str) -> "DiscTrainPlan":
@@ -576,7 +655,7 @@ class DiscTrainPlan:
             if not isinstance(m, nn.Conv2d):
                 raise NotImplementedError(f"hr-viton_amd tocg discriminator: unsupported layer {type(m).__name__} "
                                           "(Ddropout / use_sigmoid / BatchNorm variants are not on the HIP path)")
-            tc = TConv(m, m.stride[0], m.padding[0], f"{name}.{i}")
+            tc = S2DConv(m, f"{name}.{i}") if (not self.layers and S2DConv.fits(m)) else TConv(m, m.stride[0], m.padding[0], f"{name}.{i}")
             nxt = mods[i + 1] if i + 1 < len(mods) else None
             if isinstance(nxt, nn.InstanceNorm2d):
                 if nxt.affine or not isinstance(mods[i + 2], nn.LeakyReLU):
@@ -598,9 +677,15 @@ class DiscTrainPlan:
                 i += 1
         return self
 
+    def refresh_s2d(self):
+        for _, conv in self.layers:
+            if isinstance(conv, S2DConv):
+                conv.refresh()
+
     def forward(self, a: Act, power_iteration: bool, prepared: bool = False):
         feats, ctx = [], []
         if not prepared:
+            self.refresh_s2d()
             T.prepare_convs(self, [conv for _, conv in self.layers], power_iteration)
         for kind, conv in self.layers:
             if kind in ("in", "in_drop"):
@@ -671,6 +756,8 @@ class MultiscaleDTrainPlan:
     def forward(self, inp: torch.Tensor, power_iteration: bool):
         a = ops.to_nhwc(inp)
         feats_all, ctxs, inputs = [], [], []
+        for p in self.plans:
+            p.refresh_s2d()
         T.prepare_convs(self, [conv for p in self.plans for _, conv in p.layers], power_iteration)
         for k, p in enumerate(self.plans):
             inputs.append(a)

@@ -747,6 +747,29 @@ def add_slice(a: Act, out: Act, accumulate: bool):
                       a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc")
 
 
+def space_to_depth2(a: Act) -> Act:
+    """[N,H,W,C] fp32 -> dense [N,H/2,W/2,4*Cp], channel ((y&1)*2 + (x&1))*Cp + c (hrv_space_to_depth2_nhwc_f32)."""
+    lib = _lib.load()
+    assert not a.bf16 and a.H % 2 == 0 and a.W % 2 == 0
+    out = torch.empty((a.N, a.H // 2, a.W // 2, 4 * a.Cp), dtype=torch.float32, device=a.t.device)
+    with _Timed("layout", "space_to_depth2", 0.0, 2.0 * ops.act_bytes(a)):
+        _lib.check(lib.hrv_space_to_depth2_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, out.data_ptr(),
+                                                    _stream()), "hrv_space_to_depth2_nhwc_f32")
+    return Act(out, 4 * a.Cp)
+
+
+def depth_to_space2(a2: Act, C_: int) -> Act:
+    """The inverse: dense [N,Hc,Wc,4*Cp] -> [N,2*Hc,2*Wc,Cp] carrying ``C_`` real channels."""
+    lib = _lib.load()
+    Cp = a2.C // 4
+    assert not a2.bf16 and a2.coff == 0 and a2.cstride == a2.C == 4 * Cp and Cp == _ceil4(C_)
+    out = torch.empty((a2.N, 2 * a2.H, 2 * a2.W, Cp), dtype=torch.float32, device=a2.t.device)
+    with _Timed("layout", "depth_to_space2", 0.0, 2.0 * ops.act_bytes(a2)):
+        _lib.check(lib.hrv_depth_to_space2_nhwc_f32(a2.t.data_ptr(), a2.N, 2 * a2.H, 2 * a2.W, Cp, out.data_ptr(), _stream()),
+                   "hrv_depth_to_space2_nhwc_f32")
+    return Act(out, C_)
+
+
 def act_bwd_(d: Act, y: Act, act: int, slope: float = 0.2):
     """d *= act'(y) in place."""
     lib = _lib.load()

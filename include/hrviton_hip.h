@@ -463,6 +463,12 @@ int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32
                          int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
 int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
                          int32_t H, int32_t W, float* out, hrv_stream_t stream);
+/* Space-to-depth by 2 and its inverse over NHWC fp32: out[n][y/2][x/2][((y&1)*2 + (x&1))*C + c] = in[n][y][x][c].  Host side
+ * (gen_train.S2DConv): PatchGAN's first convolution -- 4x4, stride 2, pad 2 over 10 channels (network_generator.py
+ * NLayerDiscriminator model0) -- runs as a 2x2 stride-1 pad-1 convolution over the 4C-channel tensor. */
+int hrv_space_to_depth2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
+                                 int32_t in_coff, float* out, hrv_stream_t stream);
+int hrv_depth_to_space2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, hrv_stream_t stream);
 /* fp32 NCHW (module boundary) <-> bf16 NHWC (inside the bf16 generator path) */
 int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, uint16_t* out,
                               int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);

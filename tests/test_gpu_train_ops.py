@@ -729,3 +729,68 @@ def test_bf16_stored_gradients_of_the_vgg_backward_match_fp32_on_the_same_values
     acc = d16.t.clone()
     T.add_slice(ops.Act(a, 64), ops.Act(acc, 64), True)
     assert torch.equal(acc, rb(a.float() + d16.t.float()))
+
+
+def test_space_to_depth_pair_and_patchgan_model0_as_a_2x2_convolution(monkeypatch):
+    """hrv_space_to_depth2 / depth_to_space2 against torch indexing (source a channel slice), then gen_train.S2DConv --
+    PatchGAN's 4x4 stride-2 pad-2 first convolution (network_generator.py NLayerDiscriminator model0, spectral-normalised,
+    10 input channels) run as a 2x2 stride-1 pad-1 convolution over the space-to-depth tensor -- against torch autograd on
+    the same weights: output, dW_orig through the spectral-norm backward, bias gradient, input gradient (fp32 engine:
+    reassociation only), and the half-batch backward of the generator step."""
+    import torch.nn as nn
+    ops, T = _mods()
+    from hr_viton_amd import gen_train
+    g = torch.Generator().manual_seed(12)
+    N, C_, H, W = 4, 10, 96, 80
+    x = torch.randn(N, C_, H, W, generator=g)
+    wide = ops.alloc(N, H, W, 24, "cuda")
+    wide.t.normal_()
+    a = wide.slice(8, 12)
+    ops.to_nhwc(x.cuda(), out=wide.slice(8, C_))
+    wide.t[..., 8 + C_:20] = 0
+    a2 = T.space_to_depth2(Act_(ops, a.t, C_, 8))
+    ref2 = torch.zeros(N, H // 2, W // 2, 4, 12)
+    for dy in range(2):
+        for dx in range(2):
+            ref2[:, :, :, dy * 2 + dx, :C_] = x[:, :, dy::2, dx::2].permute(0, 2, 3, 1)
+    assert a2.C == 48 and torch.equal(a2.t.cpu(), ref2.view(N, H // 2, W // 2, 48))
+    back = T.depth_to_space2(a2, C_)
+    assert torch.equal(ops.to_nchw(back).cpu(), x)
+
+    conv = nn.utils.spectral_norm(nn.Conv2d(C_, 64, 4, stride=2, padding=2)).cuda().train()
+    with torch.no_grad():
+        conv.weight_orig.mul_(3.0)
+    assert gen_train.S2DConv.fits(conv)
+    tc = gen_train.S2DConv(conv, "model0")
+    tc.refresh()
+    tc.prepare(power_iteration=True)
+    xa = ops.to_nhwc(x.cuda())
+    y = tc.forward([(xa, 0)], act=ops.ACT_LRELU)
+    w_sn = (conv.weight_orig / tc.sigma).detach().cpu().requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    yr = F.leaky_relu(F.conv2d(xr, w_sn, conv.bias.detach().cpu(), stride=2, padding=2), 0.2)
+    assert tuple(y.t.shape) == (N, H // 2 + 1, W // 2 + 1, 64)
+    assert (ops.to_nchw(y).cpu() - yr).abs().max() <= 2e-5 * yr.abs().max()
+    dyt = torch.randn(yr.shape, generator=g)
+    yr.backward(dyt)
+    d = ops.to_nhwc(dyt.cuda())
+    T.act_bwd_(d, y, ops.ACT_LRELU, 0.2)
+    grads = {}
+    dx = tc.backward(d, [(xa, 0)], grads, need_dx=True)
+    assert (ops.to_nchw(dx).cpu() - xr.grad).abs().max() <= 2e-5 * xr.grad.abs().max()
+    gw = grads[conv.weight_orig] if conv.weight_orig in grads else conv.weight_orig.grad
+    # d/dW_orig of W_orig / sigma(W_orig) with (u, v) held constant, as torch's spectral_norm backward does
+    u, v, sig = tc.u.cpu(), tc.v.cpu(), tc.sigma.cpu()
+    Gm = w_sn.grad.reshape(64, -1)
+    ref_gw = ((Gm - (Gm * w_sn.detach().reshape(64, -1)).sum() * torch.outer(u, v)) / sig).reshape(64, C_, 4, 4)
+    assert (gw.cpu() - ref_gw).abs().max() <= 5e-5 * ref_gw.abs().max()
+    gb = grads[conv.bias] if conv.bias in grads else conv.bias.grad
+    assert (gb.cpu() - dyt.mul((yr > 0).float() + 0.2 * (yr <= 0).float()).sum((0, 2, 3))).abs().max() <= 1e-4 * dyt.abs().sum((0, 2, 3)).max()
+    # half-batch backward (generator step: the fake half only)
+    half = N // 2
+    dxh = tc.backward(Act_(ops, d.t[:half], 64, 0), [(Act_(ops, xa.t[:half], C_, 0), 0)], {}, need_dx=True, need_w=False)
+    assert (ops.to_nchw(dxh).cpu() - xr.grad[:half]).abs().max() <= 2e-5 * xr.grad.abs().max()
+
+
+def Act_(ops, t, C_, coff):
+    return ops.Act(t, C_, coff)
