@@ -567,10 +567,17 @@ __global__ __launch_bounds__(256) void conv_wgrad_bf16_kernel(const WgradParams 
 }
 
 // dW[co][ci][tap] (torch OIHW) (+)= sum_s ws[s][tap][co][ci], for ci in [ci_base, ci_base+ci_real)
-__global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int taps, int Cout, int CinTot, int ci_base,
-                                    int ci_real, float* __restrict__ dw, int accumulate) {
+// Blocks [nb_main, gridDim.x) (when bias_ws is given) sum the bias partials bias_ws[s][co] instead -- one launch for both
+// reductions of a weight gradient (71 + 83 launches per training iteration as two).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int taps, int Cout, int CinTot, int ci_base,
+                                    int ci_real, float* __restrict__ dw, int accumulate, int nb_main,
+                                    const float* __restrict__ bias_ws, float* __restrict__ dbias, int dbias_accumulate) {
+  if ((int)blockIdx.x >= nb_main) {
+    sum_rows_block(blockIdx.x - nb_main, bias_ws, S, Cout, dbias, dbias_accumulate);
+    return;
+  }
   const size_t total = (size_t)Cout * ci_real * taps;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)nb_main * blockDim.x) {
     const int ci = (int)(i % ci_real);
     const size_t t = i / ci_real;
     const int tap = (int)(t % taps);
@@ -594,7 +601,7 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ ws, int S, int tap
   }
 }
 
-// (the bias partials bias_ws[s][co] are summed by sum_rows_kernel, hrv_common.h)
+// (the bias partials bias_ws[s][co] are summed by the tail blocks of wgrad_reduce_kernel: sum_rows_block, hrv_common.h)
 
 // ------------------------------------------------------------------ column sums (bias gradient)
 __global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ x, int P, int C4, int cs, int co,
@@ -875,10 +882,12 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
     const int r = wgrad_tr_try(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_C_real, ci_base, CinTot, N, H, W,
                                KH, KW, pad, workspace, workspace_bytes, dbias, dbias_accumulate, (hipStream_t)stream, &S2);
     if (r < 0) return r;
-    if (r == 1) {
+    if (r == 1) {      // (the kernel left its bias partials right behind the S2 weight slabs, as the kernels below do)
       const size_t total = (size_t)Cout * x_C_real * KH * KW;
-      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, workspace, S2,
-                         KH * KW, Cout, CinTot, ci_base, x_C_real, dw_oihw, accumulate);
+      const int nb = grid_for(total);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb + (dbias ? (Cout + 15) / 16 : 0)), dim3(256), 0, (hipStream_t)stream, workspace,
+                         S2, KH * KW, Cout, CinTot, ci_base, x_C_real, dw_oihw, accumulate, nb,
+                         workspace + (size_t)S2 * KH * KW * Cout * CinTot, dbias, dbias_accumulate);
       return check_launch("wgrad_reduce_kernel");
     }
   }
@@ -919,12 +928,10 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
   int rc = check_launch("conv_wgrad_mfma_kernel");
   if (rc) return rc;
   const size_t total = (size_t)Cout * x_C_real * p.taps;
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(total)), dim3(256), 0, st, workspace, S, p.taps, Cout, CinTot,
-                     ci_base, x_C_real, dw_oihw, accumulate);
-  rc = check_launch("wgrad_reduce_kernel");
-  if (rc || !dbias) return rc;
-  hipLaunchKernelGGL(sum_rows_kernel<>, dim3((Cout + 15) / 16), dim3(256), 0, st, p.bias_ws, S, Cout, dbias, dbias_accumulate);
-  return check_launch("sum_rows_kernel[bias]");
+  const int nb = grid_for(total);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb + (dbias ? (Cout + 15) / 16 : 0)), dim3(256), 0, st, workspace, S, p.taps, Cout,
+                     CinTot, ci_base, x_C_real, dw_oihw, accumulate, nb, p.bias_ws, dbias, dbias_accumulate);
+  return check_launch("wgrad_reduce_kernel");
 }
 
 extern "C" int hrv_conv2d_wgrad_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout,

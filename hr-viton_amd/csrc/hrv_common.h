@@ -70,11 +70,11 @@ inline int norm_chunks(int C4) { return (C4 + NORM_GCAP - 1) / NORM_GCAP; }
 // out[c] (+)= sum over rows of part[r][c]: 16 channels x 16 row-groups per block, double accumulation, fixed combination
 // order (a thread per channel walking all rows serially was 15-111 us per call).  A template so that every translation
 // unit that launches it carries its own instance (separate compilation, no relocatable device code).
-template <int = 0>
-__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int accumulate) {
+__device__ __forceinline__ void sum_rows_block(const int block, const float* __restrict__ part, int rows, int C,
+                                               float* __restrict__ out, int accumulate) {
   __shared__ double red[16][16];
   const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
-  const int c = blockIdx.x * 16 + cl;
+  const int c = block * 16 + cl;
   double s = 0.0;
   if (c < C)
     for (int r = rg; r < rows; r += 16) s += (double)part[(size_t)r * C + c];
@@ -86,6 +86,11 @@ __global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__
     for (int g = 0; g < 16; ++g) t += red[g][cl];
     out[c] = accumulate ? out[c] + (float)t : (float)t;
   }
+}
+
+template <int = 0>
+__global__ __launch_bounds__(256) void sum_rows_kernel(const float* __restrict__ part, int rows, int C, float* __restrict__ out, int accumulate) {
+  sum_rows_block(blockIdx.x, part, rows, C, out, accumulate);
 }
 
 }  // namespace hrv

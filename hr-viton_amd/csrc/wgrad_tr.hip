@@ -347,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   }
 }
 
-// (bias gradient, second stage: the per-slab column sums are summed by sum_rows_kernel, hrv_common.h)
+// (bias gradient, second stage: the per-slab column sums are summed by the caller's wgrad_reduce_kernel launch)
 
 // Host side.  Returns 1 when the kernel was launched (partials in `workspace`, *S_out slabs), 0 when the shape is
 // not one it serves (the caller falls back to conv_wgrad_bf16_kernel), < 0 on error.
@@ -427,11 +427,7 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   }
   int rc = check_launch("conv_wgrad_tr_kernel");
   if (rc) return rc;
-  if (dbias) {
-    hipLaunchKernelGGL(sum_rows_kernel<>, dim3((Cout + 15) / 16), dim3(256), 0, st, p.bias_ws, S, Cout, dbias, dbias_accumulate);
-    rc = check_launch("sum_rows_kernel[bias]");
-    if (rc) return rc;
-  }
+  (void)dbias_accumulate;     // the caller's reduce launch sums bias_ws ([S][Cout], right behind the S weight slabs) as well
   *S_out = S;
   return 1;
 }
