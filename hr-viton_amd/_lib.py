@@ -189,6 +189,7 @@ SYMBOLS = {
     "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_space_to_depth2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_depth_to_space2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_concat_nhwc_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,
                                                _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
     "hrv_flow_warp_nhwc_f32": (C.c_int, [C.POINTER(hrv_flow_warp_t), _vp]),

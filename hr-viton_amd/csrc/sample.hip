@@ -284,6 +284,44 @@ __global__ void space_depth2_kernel(const float* __restrict__ a, int N, int H, i
   }
 }
 
+// ------------------------------------------------------------------ channel concat of an NHWC and an NCHW tensor into NHWC
+// out[n][p][0:Ca] = a[n][p][co : co+Ca],  out[n][p][Ca : Ca+Cb] = b[n][:, p],  pad channels up to ocs = 0  (one thread a pixel:
+// the plane reads of b are coalesced across the wave, a pixel's output row is contiguous)
+__global__ void concat_nhwc_nchw_kernel(const float* __restrict__ a, int Ca, int acs, int aco, const float* __restrict__ b,
+                                        int Cb, int N, int HW, float* __restrict__ out, int ocs) {
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / HW), p = (int)(i - (size_t)n * HW);
+    float* o = out + i * ocs;
+    const float* ap = a + i * acs + aco;
+    for (int c = 0; c < Ca; ++c) o[c] = ap[c];
+    const float* bp = b + (size_t)n * Cb * HW + p;
+    for (int c = 0; c < Cb; ++c) o[Ca + c] = bp[(size_t)c * HW];
+    for (int c = Ca + Cb; c < ocs; ++c) o[c] = 0.f;
+  }
+}
+
+// the PatchGAN shape (8-channel label rows, at most 12 output channels): 16-byte loads of the label row, 16-byte stores
+template <int CA, int CB>
+__global__ void concat_nhwc_nchw_v4_kernel(const float* __restrict__ a, const float* __restrict__ b, int N, int HW,
+                                           float* __restrict__ out) {
+  static_assert(CA <= 8 && CA + CB <= 12, "one 8-float label row, three float4 of output");
+  const size_t total = (size_t)N * HW;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i / HW), p = (int)(i - (size_t)n * HW);
+    const float4 a0 = *reinterpret_cast<const float4*>(a + i * 8), a1 = *reinterpret_cast<const float4*>(a + i * 8 + 4);
+    const float av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+    const float* bp = b + (size_t)n * CB * HW + p;
+    float o[12];
+#pragma unroll
+    for (int c = 0; c < 12; ++c) o[c] = c < CA ? av[c] : (c < CA + CB ? bp[(size_t)(c - CA) * HW] : 0.f);
+    float4* op = reinterpret_cast<float4*>(out + i * 12);
+    op[0] = make_float4(o[0], o[1], o[2], o[3]);
+    op[1] = make_float4(o[4], o[5], o[6], o[7]);
+    op[2] = make_float4(o[8], o[9], o[10], o[11]);
+  }
+}
+
 }  // namespace hrv
 
 using namespace hrv;
@@ -435,4 +473,20 @@ extern "C" int hrv_depth_to_space2_nhwc_f32(const float* in, int32_t N, int32_t 
   hipLaunchKernelGGL(space_depth2_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C / 4, C, 0,
                      out, 1);
   return check_launch("space_depth2_kernel");
+}
+
+// cat((a, b), dim=channel) with a NHWC (a channel slice) and b NCHW, written NHWC with zeroed pad channels -- the PatchGAN
+// input cat((parse, image), 1) of train_generator.py:283-284 without materialising NCHW copies.
+extern "C" int hrv_concat_nhwc_nchw_f32(const float* a, int32_t Ca, int32_t a_cstride, int32_t a_coff, const float* b, int32_t Cb,
+                                        int32_t N, int32_t H, int32_t W, float* out, int32_t out_cstride, hrv_stream_t stream) {
+  HRV_REQUIRE(a && b && out && Ca > 0 && Cb > 0 && N > 0 && H > 0 && W > 0, "concat_nhwc_nchw: bad args");
+  HRV_REQUIRE(a_coff >= 0 && a_coff + Ca <= a_cstride && Ca + Cb <= out_cstride, "concat_nhwc_nchw: channel ranges");
+  const size_t total = (size_t)N * H * W;
+  if (Ca == 7 && Cb == 3 && a_cstride == 8 && a_coff == 0 && out_cstride == 12 && (((uintptr_t)a | (uintptr_t)out) & 15) == 0) {
+    hipLaunchKernelGGL((concat_nhwc_nchw_v4_kernel<7, 3>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, b, N, H * W, out);
+    return check_launch("concat_nhwc_nchw_v4_kernel");
+  }
+  hipLaunchKernelGGL(concat_nhwc_nchw_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, a, Ca, a_cstride, a_coff, b,
+                     Cb, N, H * W, out, out_cstride);
+  return check_launch("concat_nhwc_nchw_kernel");
 }

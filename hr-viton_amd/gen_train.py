@@ -753,8 +753,10 @@ class MultiscaleDTrainPlan:
         self.msd = msd
         self.plans = [DiscTrainPlan(D, f"discriminator_{k}") for k, D in enumerate(msd.children())]
 
-    def forward(self, inp: torch.Tensor, power_iteration: bool):
-        a = ops.to_nhwc(inp)
+    def forward(self, inp: Optional[torch.Tensor], power_iteration: bool, a: Optional[Act] = None):
+        """``a``: the input already as an NHWC activation (the [fake ; real] pair assembled by _DiscPairFn)."""
+        if a is None:
+            a = ops.to_nhwc(inp)
         feats_all, ctxs, inputs = [], [], []
         for p in self.plans:
             p.refresh_s2d()
@@ -818,54 +820,13 @@ class _DiscFn(torch.autograd.Function):
         ctx.need_w = not getattr(msd, "_hrv_discard_param_grads", False)
         ctx.shapes = [[(f.N, f.H, f.W, f.C) for f in fs] for fs in feats_all]
         ctx.in_shape = tuple(inp.shape)
-        outs = []
-        for fs in feats_all:
-            for f in fs:
-                v = _nchw_view(f)
-                if split:
-                    h = v.shape[0] // 2
-                    outs += [v[:h], v[h:]]
-                else:
-                    outs.append(v)
-        return tuple(outs)
+        return _disc_outputs(feats_all, split)
 
     @staticmethod
     def backward(ctx, *d_outs):
-        it = iter(d_outs)
-        dfeats_all, rows = [], None
-        if ctx.split:
-            pairs = [[(next(it), next(it)) for _ in fs] for fs in ctx.shapes]
-            only_fake = all(dr is None for fs in pairs for _, dr in fs)
-            half = ctx.shapes[0][0][0] // 2
-            rows = half if only_fake else None
-            for fs, shp in zip(pairs, ctx.shapes):
-                row = []
-                for (df, dr), (n, h, w, c) in zip(fs, shp):
-                    if df is None and dr is None:
-                        row.append(None)
-                    elif only_fake:
-                        row.append(_nhwc_act(df, c))
-                    else:   # both halves (discriminator step: hinge terms on the last, tiny, maps)
-                        full = ops.alloc(n, h, w, c, (df if df is not None else dr).device)
-                        full.t.zero_()
-                        if df is not None:
-                            T.add_slice(_nhwc_act(df, c), Act(full.t[:half], c), False)
-                        if dr is not None:
-                            T.add_slice(_nhwc_act(dr, c), Act(full.t[half:], c), False)
-                        row.append(full)
-                dfeats_all.append(row)
-        else:
-            for fs in ctx.shapes:
-                row = []
-                for (n, h, w, c) in fs:
-                    d = next(it)
-                    row.append(None if d is None else _nhwc_act(d, c))
-                dfeats_all.append(row)
-        need_dx = ctx.needs_input_grad[2]
-        grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx, rows, ctx.need_w)
-        ctx.saved = None
+        grads, d_in, rows = _disc_backward(ctx, d_outs, ctx.needs_input_grad[2])
         d_inp = None
-        if need_dx and d_in is not None:
+        if d_in is not None:
             d_inp = ops.to_nchw(d_in)
             if rows is not None:      # the real half of the input gets a zero gradient
                 full = torch.empty(ctx.in_shape, dtype=d_inp.dtype, device=d_inp.device)
@@ -873,6 +834,111 @@ class _DiscFn(torch.autograd.Function):
                 full[rows:].zero_()       # (only the half that needs it is filled)
                 d_inp = full
         return (None, None, d_inp, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+def _disc_backward(ctx, d_outs, need_dx: bool):
+    """Shared by _DiscFn / _DiscPairFn: output gradients -> plan backward.  Returns (parameter gradients, d(input) as an NHWC
+    Act or None, rows: the leading samples d(input) covers when only the fake half carried a gradient, else None)."""
+    it = iter(d_outs)
+    dfeats_all, rows = [], None
+    if ctx.split:
+        pairs = [[(next(it), next(it)) for _ in fs] for fs in ctx.shapes]
+        only_fake = all(dr is None for fs in pairs for _, dr in fs)
+        half = ctx.shapes[0][0][0] // 2
+        rows = half if only_fake else None
+        for fs, shp in zip(pairs, ctx.shapes):
+            row = []
+            for (df, dr), (n, h, w, c) in zip(fs, shp):
+                if df is None and dr is None:
+                    row.append(None)
+                elif only_fake:
+                    row.append(_nhwc_act(df, c))
+                else:   # both halves (discriminator step: hinge terms on the last, tiny, maps)
+                    full = ops.alloc(n, h, w, c, (df if df is not None else dr).device)
+                    full.t.zero_()
+                    if df is not None:
+                        T.add_slice(_nhwc_act(df, c), Act(full.t[:half], c), False)
+                    if dr is not None:
+                        T.add_slice(_nhwc_act(dr, c), Act(full.t[half:], c), False)
+                    row.append(full)
+            dfeats_all.append(row)
+    else:
+        for fs in ctx.shapes:
+            row = []
+            for (n, h, w, c) in fs:
+                d = next(it)
+                row.append(None if d is None else _nhwc_act(d, c))
+            dfeats_all.append(row)
+    grads, d_in = ctx.plan.backward(ctx.saved, dfeats_all, need_dx, rows, ctx.need_w)
+    ctx.saved = None
+    return grads, (d_in if need_dx else None), rows
+
+
+def _disc_outputs(feats_all, split: bool):
+    outs = []
+    for fs in feats_all:
+        for f in fs:
+            v = _nchw_view(f)
+            if split:
+                h = v.shape[0] // 2
+                outs += [v[:h], v[h:]]
+            else:
+                outs.append(v)
+    return tuple(outs)
+
+
+class _DiscPairFn(torch.autograd.Function):
+    """The [fake ; real] discriminator pass of train_generator.py:283-295 / :327-345 without the three torch.cat's and the
+    layout round trip: the PatchGAN input cat((parse, image), 1) of both halves is assembled NHWC by one kernel per half
+    (hrv_concat_nhwc_nchw_f32) straight from the label-map activation and the two NCHW images, and the backward returns
+    d(fake image) only -- the label map and the real image have no gradient.  Same outputs as _DiscFn with ``split``."""
+
+    @staticmethod
+    def forward(ctx, msd, plan, parse7, fake, real, *params):
+        N, Cb, H, W = fake.shape
+        assert tuple(real.shape) == tuple(fake.shape) and (parse7.N, parse7.H, parse7.W) == (N, H, W) and not parse7.bf16
+        Ca = parse7.C
+        a = Act(torch.empty((2 * N, H, W, _ceil4(Ca + Cb)), dtype=torch.float32, device=fake.device), Ca + Cb)
+        T.concat_nhwc_nchw(parse7, fake.detach(), Act(a.t[:N], Ca + Cb))
+        T.concat_nhwc_nchw(parse7, real.detach(), Act(a.t[N:], Ca + Cb))
+        feats_all, saved = plan.forward(None, power_iteration=True, a=a)
+        ctx.plan, ctx.saved, ctx.params, ctx.split = plan, saved, params, True
+        ctx.set_materialize_grads(False)
+        ctx.need_w = not getattr(msd, "_hrv_discard_param_grads", False)
+        ctx.shapes = [[(f.N, f.H, f.W, f.C) for f in fs] for fs in feats_all]
+        ctx.cut = (N, Ca, Cb)
+        return _disc_outputs(feats_all, True)
+
+    @staticmethod
+    def backward(ctx, *d_outs):
+        grads, d_in, rows = _disc_backward(ctx, d_outs, ctx.needs_input_grad[3])
+        N, Ca, Cb = ctx.cut
+        d_fake = None
+        if d_in is not None:
+            d_fake = ops.to_nchw(Act(d_in.t[:N], Ca + Cb), Ca, Cb)      # channels [Ca, Ca+Cb) of the fake half
+        return (None, None, None, d_fake, None) + tuple(grads.get(p) for p in ctx.params)
+
+
+def discriminator_train_forward_pair(msd: nn.Module, parse7: Act, fake: torch.Tensor, real: torch.Tensor):
+    """discriminator(cat((cat((parse, fake), 1), cat((parse, real), 1)), 0)) of train_generator.py:283-295, returning
+    (pred_fake, pred_real) like ``discriminator_train_forward(..., split=True)`` -- see _DiscPairFn."""
+    ops.require_cuda(fake, "MultiscaleDiscriminator.forward_pair")
+    plan = getattr(msd, "_train_plan", None)
+    if plan is None:
+        plan = msd._train_plan = MultiscaleDTrainPlan(msd)
+    params = [p for p in msd.parameters()]
+    nD = len(plan.plans)
+    if not torch.is_grad_enabled():
+        with torch.no_grad():
+            flat = list(_DiscPairFn.apply(msd, plan, parse7, fake, real, *params))
+    else:
+        flat = list(_DiscPairFn.apply(msd, plan, parse7, fake, real, *params))
+
+    def group(seq):
+        per = len(seq) // nD
+        res = [seq[k * per:(k + 1) * per] for k in range(nD)]
+        return [[r[-1]] for r in res] if msd.no_ganFeat_loss else res
+    return group(flat[0::2]), group(flat[1::2])
 
 
 def discriminator_train_forward(msd: nn.Module, inp: torch.Tensor, split: bool = False):

@@ -473,6 +473,14 @@ class MultiscaleDiscriminator(BaseNetwork):
     def downsample(self, input):
         raise RuntimeError("executed inside forward() by hrv_avgpool3x3s2_nhwc_f32")
 
+    def forward_pair(self, parse7, fake, real):
+        """Training mode: (pred_fake, pred_real) of discriminator(cat((cat((parse, fake), 1), cat((parse, real), 1)), 0)) --
+        train_generator.py:283-295 -- with the input assembled NHWC by one kernel per half instead of three torch.cat's
+        and a layout pass; ``parse7``: the label-map activation (ops.Act), ``fake`` / ``real``: NCHW images."""
+        assert self.training, "forward_pair is the training-step form"
+        from .gen_train import discriminator_train_forward_pair
+        return discriminator_train_forward_pair(self, parse7, fake.contiguous(), real.contiguous())
+
     def forward(self, input, split: bool = False):
         """List (scales) of lists (layers) of NCHW tensors -- network_generator.py:306-316.  ``split=True`` (an
         extension for the [fake ; real] batches of train_generator.py:283-295) returns (pred_fake, pred_real)."""

@@ -70,18 +70,23 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
     """One G step + one D step of train_generator.py:279-360.  ``parse7``: Act [N,H,W,8] (7 real).
     ``noise`` / ``noise_d``: the SPADE noise draws of the two generator forwards (default: drawn like the reference,
     network_generator.py:104-107); the data-parallel equivalence test injects them."""
-    parse_nchw = ops.to_nchw(parse7)
+    pair = hasattr(discriminator, "forward_pair") and not getattr(opt, "_hrv_no_pair", False)
+    parse_nchw = None if pair else ops.to_nchw(parse7)
     # ---------------- generator ----------------
     if sync_g is not None:
         sync_g.begin()
     if sync_d is not None:
         sync_d.enabled = False          # D's gradients of the G step are discarded (:354)
     output_paired = generator(x, parse7, noise=noise)
-    fake_concat = torch.cat((parse_nchw, output_paired), dim=1)
-    real_concat = torch.cat((parse_nchw, im), dim=1)
+    if not pair:
+        fake_concat = torch.cat((parse_nchw, output_paired), dim=1)
+        real_concat = torch.cat((parse_nchw, im), dim=1)
     discriminator._hrv_discard_param_grads = True      # :354 zeroes D's gradients of loss_gen before they are ever used
     try:
-        pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)   # :283-295
+        if pair:      # the same [fake ; real] batch, assembled NHWC inside (no cat / layout round trip)
+            pred_fake, pred_real = discriminator.forward_pair(parse7, output_paired, im)
+        else:
+            pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)   # :283-295
     finally:
         discriminator._hrv_discard_param_grads = False
     losses = {"GAN": crit_gan(pred_fake, True, for_discriminator=False)}
@@ -104,8 +109,11 @@ def generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, cri
         sync_d.begin()
     with torch.no_grad():
         output = generator(x, parse7, noise=noise_d)       # new noise, post-update weights (:327-330)
-    fake_concat = torch.cat((parse_nchw, output), dim=1)
-    pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)
+    if pair:
+        pred_fake, pred_real = discriminator.forward_pair(parse7, output, im)
+    else:
+        fake_concat = torch.cat((parse_nchw, output), dim=1)
+        pred_fake, pred_real = discriminator(torch.cat((fake_concat, real_concat), dim=0), split=True)
     d_losses = {"D_Fake": crit_gan(pred_fake, False, for_discriminator=True),
                 "D_Real": crit_gan(pred_real, True, for_discriminator=True)}
     loss_dis = sum(d_losses.values()).mean()

@@ -747,6 +747,18 @@ def add_slice(a: Act, out: Act, accumulate: bool):
                       a.N * a.H * a.W, 1 if accumulate else 0, _stream()), "hrv_add_slice_nhwc")
 
 
+def concat_nhwc_nchw(a: Act, b: torch.Tensor, out: Act):
+    """out = cat((a, b), channels): ``a`` an fp32 NHWC activation, ``b`` fp32 NCHW, ``out`` a dense NHWC activation of
+    a.C + b.shape[1] channels (pad channels zeroed) -- hrv_concat_nhwc_nchw_f32."""
+    lib = _lib.load()
+    N, Cb, H, W = b.shape
+    assert (a.N, a.H, a.W) == (N, H, W) == (out.N, out.H, out.W) and not a.bf16 and not out.bf16 and out.coff == 0
+    assert b.is_contiguous() and b.dtype == torch.float32 and out.C == a.C + Cb and out.t.is_contiguous()
+    with _Timed("layout", "concat_nhwc_nchw", 0.0, 4.0 * N * H * W * (a.C + Cb + out.cstride)):
+        _lib.check(lib.hrv_concat_nhwc_nchw_f32(a.t.data_ptr(), a.C, a.cstride, a.coff, b.data_ptr(), Cb, N, H, W, out.t.data_ptr(),
+                                                out.cstride, _stream()), "hrv_concat_nhwc_nchw_f32")
+
+
 def space_to_depth2(a: Act) -> Act:
     """[N,H,W,C] fp32 -> dense [N,H/2,W/2,4*Cp], channel ((y&1)*2 + (x&1))*Cp + c (hrv_space_to_depth2_nhwc_f32)."""
     lib = _lib.load()

@@ -468,6 +468,10 @@ int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, i
  * NLayerDiscriminator model0) -- runs as a 2x2 stride-1 pad-1 convolution over the 4C-channel tensor. */
 int hrv_space_to_depth2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
                                  int32_t in_coff, float* out, hrv_stream_t stream);
+/* cat((a, b), 1) for a NHWC (channels [a_coff, a_coff+Ca) of a_cstride) and b NCHW [N,Cb,H,W], written NHWC
+ * [N,H,W,out_cstride] with zeroed pad channels: the PatchGAN input of train_generator.py:283-284. */
+int hrv_concat_nhwc_nchw_f32(const float* a, int32_t Ca, int32_t a_cstride, int32_t a_coff, const float* b, int32_t Cb, int32_t N,
+                             int32_t H, int32_t W, float* out, int32_t out_cstride, hrv_stream_t stream);
 int hrv_depth_to_space2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, hrv_stream_t stream);
 /* fp32 NCHW (module boundary) <-> bf16 NHWC (inside the bf16 generator path) */
 int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, uint16_t* out,

@@ -794,3 +794,21 @@ def test_space_to_depth_pair_and_patchgan_model0_as_a_2x2_convolution(monkeypatc
 
 def Act_(ops, t, C_, coff):
     return ops.Act(t, C_, coff)
+
+
+@pytest.mark.parametrize("shape", [(7, 3, 8), (5, 6, 8), (13, 3, 20)], ids=["patchgan_7_3", "generic_5_6", "sliced_13_3"])
+def test_concat_of_an_nhwc_and_an_nchw_tensor(shape):
+    """hrv_concat_nhwc_nchw_f32 (the PatchGAN input cat((parse, image), 1), train_generator.py:283-284) == torch.cat, pad
+    channels zero: the vectorised 7 + 3 form and the generic form (a channel slice as the NHWC operand)."""
+    ops, T = _mods()
+    Ca, Cb, acs = shape
+    N, H, W = 3, 37, 45
+    g = torch.Generator().manual_seed(Ca)
+    a = torch.randn(N, H, W, acs, generator=g).cuda()
+    b = torch.randn(N, Cb, H, W, generator=g).cuda()
+    coff = 0 if acs == 8 else 4
+    cs = (Ca + Cb + 3) // 4 * 4
+    out = ops.Act(torch.full((N, H, W, cs), 9.0, device="cuda"), Ca + Cb)
+    T.concat_nhwc_nchw(ops.Act(a, Ca, coff), b, out)
+    ref = torch.cat((a[..., coff:coff + Ca], b.permute(0, 2, 3, 1)), 3)
+    assert torch.equal(out.t[..., :Ca + Cb], ref) and bool((out.t[..., Ca + Cb:] == 0).all())

@@ -424,3 +424,51 @@ def test_batched_weight_packs_leave_the_iteration_bit_identical(mixed):
     assert all(n == 0 for n, _ in sb), sb
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+@pytest.mark.parametrize("which", ["generator_step", "discriminator_step"])
+def test_discriminator_pair_form_equals_the_concatenated_batch_form(which):
+    """MultiscaleDiscriminator.forward_pair(parse, fake, real) -- the PatchGAN input of train_generator.py:283-295 assembled
+    NHWC by hrv_concat_nhwc_nchw_f32 -- against discriminator(cat((cat((parse, fake), 1), cat((parse, real), 1)), 0),
+    split=True) on the same weights and spectral-norm state: every output bit-identical, d(fake) and (discriminator
+    step) every parameter gradient equal."""
+    import copy
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    opt, gen, D, x, seg, real, noise = _setup(seed=21, H=128, W=96, wmul=6.0)
+    D.cuda().train()
+    D2 = copy.deepcopy(D)
+    g = torch.Generator().manual_seed(5)
+    fake = (torch.rand(2, 3, 128, 96, generator=g) * 2 - 1).cuda()
+    realc, parse7 = real.cuda(), ops.to_nhwc(seg.cuda())
+    cg, cf = GANLoss("hinge"), L1Loss()
+
+    def losses(pf, pr):
+        if which == "generator_step":
+            tot = cg(pf, True, for_discriminator=False)
+            for i in range(len(pf)):
+                for j in range(len(pf[i]) - 1):
+                    tot = tot + cf(pf[i][j], pr[i][j].detach()) * 10.0 / len(pf)
+            return tot
+        return cg(pf, False, for_discriminator=True) + cg(pr, True, for_discriminator=True)
+
+    fa = fake.clone().requires_grad_(which == "generator_step")
+    pf_a, pr_a = D.forward_pair(parse7, fa, realc)
+    la = losses(pf_a, pr_a)
+    la.sum().backward()
+    fb = fake.clone().requires_grad_(which == "generator_step")
+    pn = ops.to_nchw(parse7)
+    pf_b, pr_b = D2(torch.cat((torch.cat((pn, fb), 1), torch.cat((pn, realc), 1)), 0), split=True)
+    lb = losses(pf_b, pr_b)
+    lb.sum().backward()
+    for u, v in zip([t for s_ in pf_a + pr_a for t in s_], [t for s_ in pf_b + pr_b for t in s_]):
+        assert torch.equal(u, v)
+    assert torch.equal(la, lb)
+    if which == "generator_step":
+        assert torch.equal(fa.grad, fb.grad)
+    else:
+        for (n, p), (_, q) in zip(D.named_parameters(), D2.named_parameters()):
+            assert (p.grad is None) == (q.grad is None), n
+            if p.grad is not None:
+                assert torch.equal(p.grad, q.grad), n

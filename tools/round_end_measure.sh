@@ -1,14 +1,20 @@
 #!/bin/bash
 # Round-end measurement sweep -- run on the GPU box via gpurun from the repo root.
-# Writes gpurun_out/final/: the default bench line (headline config, with cpu_baseline / parity / extras), one line per
-# secondary workload, per-launch HIP-event tables, the HBM-traffic PMC passes and the rocprofv3 kernel-trace summary of the
-# headline step, the 1-GPU collective-overlap numbers.
+# Writes gpurun_out/final/: the HBM-traffic PMC passes and the rocprofv3 kernel-trace summary of the headline iteration (first:
+# bench.py's roofline.traffic reads the per-kernel bytes of THIS build), the default bench line (headline config, with
+# cpu_baseline / parity / extras), one line per secondary workload, per-launch HIP-event tables, the per-iteration launch
+# table (two differenced traces), the 1-GPU collective-overlap numbers.  Copy what should be judged into profiles/.
 set -u
 REPO=$(pwd)
 OUT=$REPO/gpurun_out/final
 mkdir -p $OUT
 cd $REPO
-timeout 900 python bench.py --dump-launches $OUT/launches_default.txt 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
+bash tools/profile_traffic.sh train_generator > $OUT/profile_traffic.log 2>&1
+cp gpurun_out/traffic_train_generator/*.summary.txt gpurun_out/traffic_train_generator/*.json $OUT/ 2>/dev/null
+# (on the box only: the default run below prices its traffic from the passes just taken; the copy under profiles/ that is
+#  committed afterwards is this same file)
+cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r03_pmc_traffic_train_generator.json 2>/dev/null
+timeout 1200 python bench.py --dump-launches $OUT/launches_default.txt 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 cut -c1-300 $OUT/bench_default.json
 b() { name=$1; shift; timeout 400 python bench.py "$@" --no-cpu-baseline --no-extras --dump-launches $OUT/launches_$name.txt 2>$OUT/$name.err | tail -1 > $OUT/$name.json; cut -c1-200 $OUT/$name.json; }
 b train_generator_f32 --workload train_generator --fp32 --steps 3 --warmup 2
@@ -17,8 +23,8 @@ b train_condition_bf16 --workload train_condition --bf16 --steps 3 --warmup 2
 b tryon_infer_bf16 --workload tryon_infer --bf16 --steps 10 --warmup 3
 b tocg_infer_bf16 --workload tocg_infer --bf16 --steps 10 --warmup 3
 python tools/launch_summary.py $OUT/launches_default.txt > $OUT/launch_summary_default.txt 2>&1
-bash tools/profile_traffic.sh train_generator > $OUT/profile_traffic.log 2>&1
-cp gpurun_out/traffic_train_generator/*.summary.txt gpurun_out/traffic_train_generator/*.json $OUT/ 2>/dev/null
+bash tools/launch_count.sh > $OUT/launch_count.log 2>&1
+cp gpurun_out/launch_count/per_step.txt $OUT/launches_per_iteration.txt 2>/dev/null
 timeout 500 bash tools/dp_overlap.sh > $OUT/dp_overlap.log 2>&1
 cp gpurun_out/dp_overlap/overlap.txt $OUT/dp_overlap.txt 2>/dev/null
 ls -la $OUT | head -40
