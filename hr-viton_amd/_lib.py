@@ -57,6 +57,16 @@ class hrv_thin_conv_t(C.Structure):
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("out_bf16", C.c_int32)]
 
 
+class hrv_conv_cout1_t(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("x_cstride", C.c_int32), ("x_coff", C.c_int32), ("w_oihw", C.c_void_p), ("sigma", C.c_void_p),
+                ("wscale", C.c_float), ("bias", C.c_void_p), ("K", C.c_int32), ("pad", C.c_int32),
+                ("y", C.c_void_p), ("y_cstride", C.c_int32), ("y_coff", C.c_int32),
+                ("dx", C.c_void_p), ("dx_cstride", C.c_int32), ("dx_coff", C.c_int32),
+                ("add", C.c_void_p), ("add_cstride", C.c_int32), ("add_coff", C.c_int32),
+                ("workspace", C.c_void_p), ("round_bf16", C.c_int32)]
+
+
 class hrv_spade_gb_t(C.Structure):
     _fields_ = [("mode", C.c_int32), ("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("src", C.c_void_p), ("src_cstride", C.c_int32), ("src_coff", C.c_int32), ("w_packed", C.c_void_p),
@@ -189,6 +199,10 @@ SYMBOLS = {
     "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_space_to_depth2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_depth_to_space2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_conv_cout1_fwd_f32": (C.c_int, [C.POINTER(hrv_conv_cout1_t), _vp]),
+    "hrv_conv_cout1_dgrad_f32": (C.c_int, [C.POINTER(hrv_conv_cout1_t), _vp]),
+    "hrv_conv_cout1_wgrad_slabs": (_i32, [_i32, _i32, _i32]),
+    "hrv_conv_cout1_wgrad_f32": (C.c_int, [C.POINTER(hrv_conv_cout1_t), _vp, _i32, _vp, _i32, _vp]),
     "hrv_concat_nhwc_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "hrv_resize_bilinear_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _f, _f,
                                                _vp, _i32, _i32, _vp, _i32, _i32, _vp]),

@@ -1,0 +1,278 @@
+// Convolutions with ONE output channel -- the last layer of every PatchGAN scale (network_generator.py NLayerDiscriminator:
+// Conv2d(nf, 1, kernel_size=4, stride=1, padding=2); networks.py:389-393 for the condition generator's discriminator):
+// forward, data gradient and weight gradient.  The implicit-GEMM engine pads the single column to a 64-column tile: at
+// 2 x 4 x 131 x 99 pixels x 256 channels the forward took 0.23 ms (3.6 TFLOP/s, 0.44 TB/s), the data gradient 0.09-0.13 ms,
+// the weight gradient 0.19 ms.  None of them is a matrix product worth the matrix cores: the forward is a 4096-long dot
+// product per pixel (HBM floor: one read of x), the data gradient an outer product (one write of dx), the weight gradient
+// a reduction over pixels.  fp32 FMAs, fp32 accumulation; ``round_bf16`` rounds both operands to bf16 first -- the
+// arithmetic of the bf16 matrix-core engine these kernels replace in mixed-precision training.
+#include "conv_params.h"
+
+namespace hrv {
+
+__device__ __forceinline__ float c1_rb(float v, int round_bf16) {
+  if (!round_bf16) return v;
+  unsigned u = __builtin_bit_cast(unsigned, v);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  u &= 0xffff0000u;
+  return __builtin_bit_cast(float, u);
+}
+
+struct Cout1Params {
+  const float* x; int N, H, W, C, xcs, xco;       // fp32 NHWC source (C % 4 == 0, 16-byte aligned rows)
+  const float* w;                                   // [1][C][K][K] fp32 (OIHW)
+  const float* sigma; float wscale;                 // weights are multiplied by wscale / sigma[0]
+  const float* bias;                                // [1] or null
+  int K, pad, Ho, Wo;
+  float* y; int ycs, yco;                           // forward output / data-gradient input: [N][Ho][Wo][ycs], channel yco
+  float* dx; int dcs, dco;                          // data gradient output [N][H][W][dcs]
+  const float* add; int acs, aco;                   // optional tensor added to dx (feature-matching gradient)
+  float* part; int S;                               // weight gradient: partials [S][C*K*K + 1] (last: bias)
+  int round_bf16;
+};
+
+constexpr int C1_STRIP = 8;
+
+// forward: one wave per strip of 8 output pixels of a row; lane = 4 channels (x channel groups of 256); weights in LDS
+__global__ __launch_bounds__(256) void cout1_fwd_kernel(const Cout1Params p) {
+  extern __shared__ float wl[];                     // [K*K][C]
+  const int KK = p.K * p.K;
+  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
+  for (int i = threadIdx.x; i < KK * p.C; i += 256) {
+    const int tap = i / p.C, c = i - tap * p.C;
+    wl[i] = c1_rb(p.w[(size_t)c * KK + tap] * mul, p.round_bf16);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int strips_per_row = (p.Wo + C1_STRIP - 1) / C1_STRIP;
+  const int total = p.N * p.Ho * strips_per_row;
+  const float b = p.bias ? p.bias[0] : 0.f;
+  for (int s = blockIdx.x * 4 + wave; s < total; s += gridDim.x * 4) {
+    const int sx = s % strips_per_row;
+    const int t = s / strips_per_row;
+    const int ho = t % p.Ho, n = t / p.Ho;
+    const int wo0 = sx * C1_STRIP;
+    float acc[C1_STRIP];
+#pragma unroll
+    for (int o = 0; o < C1_STRIP; ++o) acc[o] = 0.f;
+    for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
+      for (int r = 0; r < p.K; ++r) {
+        const int h = ho + r - p.pad;
+        if (h < 0 || h >= p.H) continue;
+        const float* xrow = p.x + ((size_t)n * p.H + h) * p.W * p.xcs + p.xco + c0;
+        const float* wr = wl + (size_t)r * p.K * p.C + c0;
+        // input columns wo0 - pad .. wo0 + STRIP - 1 - pad + K - 1; column q feeds output o = q - kw (kw = 0..K-1)
+        for (int q = 0; q < C1_STRIP + p.K - 1; ++q) {
+          const int wi = wo0 + q - p.pad;
+          if (wi < 0 || wi >= p.W) continue;
+          float4 xv = *reinterpret_cast<const float4*>(xrow + (size_t)wi * p.xcs);
+          xv.x = c1_rb(xv.x, p.round_bf16); xv.y = c1_rb(xv.y, p.round_bf16);
+          xv.z = c1_rb(xv.z, p.round_bf16); xv.w = c1_rb(xv.w, p.round_bf16);
+#pragma unroll
+          for (int o = 0; o < C1_STRIP; ++o) {
+            const int kw = q - o;
+            if (kw >= 0 && kw < p.K) {
+              const float4 wv = *reinterpret_cast<const float4*>(wr + (size_t)kw * p.C);
+              acc[o] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 0; o < C1_STRIP; ++o) {
+      float v = acc[o];
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+      if (lane == 0 && wo0 + o < p.Wo) p.y[(((size_t)n * p.Ho + ho) * p.Wo + wo0 + o) * p.ycs + p.yco] = v + b;
+    }
+  }
+}
+
+// data gradient: dx[n][h][w][c] = sum_{kh,kw} dy[n][h - kh + pad][w - kw + pad] * w[c][kh][kw]  (+ add): one wave per pixel
+__global__ __launch_bounds__(256) void cout1_dgrad_kernel(const Cout1Params p) {
+  extern __shared__ float wl[];                     // [K*K][C]
+  const int KK = p.K * p.K;
+  const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
+  for (int i = threadIdx.x; i < KK * p.C; i += 256) {
+    const int tap = i / p.C, c = i - tap * p.C;
+    wl[i] = c1_rb(p.w[(size_t)c * KK + tap] * mul, p.round_bf16);
+  }
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const size_t total = (size_t)p.N * p.H * p.W;
+  for (size_t px = (size_t)blockIdx.x * 4 + wave; px < total; px += (size_t)gridDim.x * 4) {
+    const int w_ = (int)(px % p.W);
+    const size_t t = px / p.W;
+    const int h = (int)(t % p.H), n = (int)(t / p.H);
+    float g[16];                                    // the K*K (<= 16) output-gradient values this pixel sees
+#pragma unroll
+    for (int tap = 0; tap < 16; ++tap) {
+      const int kh = tap / p.K, kw = tap - kh * p.K;
+      const int ho = h - kh + p.pad, wo = w_ - kw + p.pad;
+      float v = 0.f;
+      if (tap < KK && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo)
+        v = c1_rb(p.y[(((size_t)n * p.Ho + ho) * p.Wo + wo) * p.ycs + p.yco], p.round_bf16);
+      g[tap] = v;
+    }
+    for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
+      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap)
+        if (tap < KK) {
+          const float4 wv = *reinterpret_cast<const float4*>(wl + (size_t)tap * p.C + c0);
+          acc.x += g[tap] * wv.x; acc.y += g[tap] * wv.y; acc.z += g[tap] * wv.z; acc.w += g[tap] * wv.w;
+        }
+      if (p.add) {
+        const float4 a = *reinterpret_cast<const float4*>(p.add + px * p.acs + p.aco + c0);
+        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+      }
+      *reinterpret_cast<float4*>(p.dx + px * p.dcs + p.dco + c0) = acc;
+    }
+  }
+}
+
+// weight gradient partials: block s walks a slab of the EXTENDED pixel grid (n, h < Ho, w < Wo); thread = channel.
+//   dw[c][kh][kw] += x[n][h][w][c] * dy[n][h - kh + pad][w - kw + pad]   (h < H, w < W),   dbias += dy[n][h][w]
+__global__ __launch_bounds__(256) void cout1_wgrad_kernel(const Cout1Params p) {
+  const int KK = p.K * p.K;
+  const int c = blockIdx.y * 256 + threadIdx.x;
+  const size_t total = (size_t)p.N * p.Ho * p.Wo;
+  const size_t per = (total + p.S - 1) / p.S;
+  const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < total ? p0 + per : total;
+  float acc[16];
+#pragma unroll
+  for (int tap = 0; tap < 16; ++tap) acc[tap] = 0.f;
+  float bsum = 0.f;
+  for (size_t e = p0; e < p1; ++e) {
+    const int w_ = (int)(e % p.Wo);
+    const size_t t = e / p.Wo;
+    const int h = (int)(t % p.Ho), n = (int)(t / p.Ho);
+    const float* dyn = p.y + (size_t)n * p.Ho * p.Wo * p.ycs + p.yco;
+    bsum += dyn[((size_t)h * p.Wo + w_) * p.ycs];
+    if (h < p.H && w_ < p.W && c < p.C) {
+      const float xv = c1_rb(p.x[(((size_t)n * p.H + h) * p.W + w_) * p.xcs + p.xco + c], p.round_bf16);
+#pragma unroll
+      for (int tap = 0; tap < 16; ++tap) {
+        const int kh = tap / p.K, kw = tap - kh * p.K;
+        const int ho = h - kh + p.pad, wo = w_ - kw + p.pad;
+        if (tap < KK && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo)
+          acc[tap] += xv * c1_rb(dyn[((size_t)ho * p.Wo + wo) * p.ycs], p.round_bf16);
+      }
+    }
+  }
+  float* dst = p.part + (size_t)blockIdx.x * (p.C * KK + 1);
+  if (c < p.C)
+    for (int tap = 0; tap < KK; ++tap) dst[c * KK + tap] = acc[tap];
+  if (c == 0) dst[p.C * KK] = bsum;
+}
+
+// dw[col] (+)= sum_s part[s][col] (col < cols), dbias[0] (+)= sum_s part[s][cols]: 16 columns x 16 row groups per block,
+// double accumulation, fixed combination order (the shape of hrv_common.h's sum_rows_block, rows cols + 1 apart)
+__global__ __launch_bounds__(256) void cout1_reduce_kernel(const float* __restrict__ part, int S, int cols, float* __restrict__ dw,
+                                                           int accumulate, float* __restrict__ dbias, int dbias_accumulate) {
+  __shared__ double red[16][16];
+  const int cl = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 16 + cl;
+  double s = 0.0;
+  if (c <= cols)
+    for (int r = rg; r < S; r += 16) s += (double)part[(size_t)r * (cols + 1) + c];
+  red[rg][cl] = s;
+  __syncthreads();
+  if (threadIdx.x < 16 && c <= cols) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < 16; ++g) t += red[g][cl];
+    if (c < cols) dw[c] = accumulate ? dw[c] + (float)t : (float)t;
+    else if (dbias) dbias[0] = dbias_accumulate ? dbias[0] + (float)t : (float)t;
+  }
+}
+
+}  // namespace hrv
+
+using namespace hrv;
+
+static int c1_fill(const hrv_conv_cout1_t* d, Cout1Params& p, const char* who) {
+  HRV_REQUIRE(d && d->x && d->w_oihw && d->y, "%s: null pointer", who);
+  HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 4 == 0 && d->C <= 2048, "%s: extents (C %% 4 == 0, C <= 2048)", who);
+  HRV_REQUIRE(d->K >= 1 && d->K <= 4 && d->pad >= 0 && d->pad < d->K, "%s: kernel size 1..4, stride 1", who);
+  HRV_REQUIRE(d->x_cstride % 4 == 0 && d->x_coff % 4 == 0 && d->x_coff + d->C <= d->x_cstride && ((uintptr_t)d->x & 15) == 0,
+              "%s: source slice (4-channel granules)", who);
+  HRV_REQUIRE(d->y_coff >= 0 && d->y_coff < d->y_cstride, "%s: y channel", who);
+  p.x = d->x; p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.xcs = d->x_cstride; p.xco = d->x_coff;
+  p.w = d->w_oihw; p.sigma = d->sigma; p.wscale = d->wscale; p.bias = d->bias;
+  p.K = d->K; p.pad = d->pad; p.Ho = d->H + 2 * d->pad - d->K + 1; p.Wo = d->W + 2 * d->pad - d->K + 1;
+  p.y = d->y; p.ycs = d->y_cstride; p.yco = d->y_coff;
+  p.dx = d->dx; p.dcs = d->dx_cstride; p.dco = d->dx_coff;
+  p.add = d->add; p.acs = d->add_cstride; p.aco = d->add_coff;
+  p.part = d->workspace; p.S = 0;
+  p.round_bf16 = d->round_bf16 ? 1 : 0;
+  HRV_REQUIRE(p.Ho > 0 && p.Wo > 0, "%s: empty output", who);
+  return HRV_OK;
+}
+
+static int c1_lds(const void* fn, int bytes, const char* who) {
+  if (bytes > 48 * 1024 &&
+      hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) {
+    set_error("%s: hipFuncSetAttribute(MaxDynamicSharedMemorySize=%d) failed", who, bytes);
+    return HRV_ERR_LAUNCH;
+  }
+  return HRV_OK;
+}
+
+extern "C" int hrv_conv_cout1_fwd_f32(const hrv_conv_cout1_t* d, hrv_stream_t stream) {
+  Cout1Params p;
+  int rc = c1_fill(d, p, "conv_cout1_fwd");
+  if (rc) return rc;
+  const int lds = p.K * p.K * p.C * 4;
+  rc = c1_lds(reinterpret_cast<const void*>(&cout1_fwd_kernel), lds, "conv_cout1_fwd");
+  if (rc) return rc;
+  const int strips = p.N * p.Ho * ((p.Wo + C1_STRIP - 1) / C1_STRIP);
+  int grid = (strips + 3) / 4;
+  if (grid > 2048) grid = 2048;
+  hipLaunchKernelGGL(cout1_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
+  return check_launch("cout1_fwd_kernel");
+}
+
+extern "C" int hrv_conv_cout1_dgrad_f32(const hrv_conv_cout1_t* d, hrv_stream_t stream) {
+  Cout1Params p;
+  int rc = c1_fill(d, p, "conv_cout1_dgrad");
+  if (rc) return rc;
+  HRV_REQUIRE(d->dx && d->dx_cstride % 4 == 0 && d->dx_coff % 4 == 0 && d->dx_coff + d->C <= d->dx_cstride &&
+                  ((uintptr_t)d->dx & 15) == 0, "conv_cout1_dgrad: dx slice");
+  HRV_REQUIRE(!d->add || (d->add_cstride % 4 == 0 && d->add_coff % 4 == 0 && ((uintptr_t)d->add & 15) == 0), "conv_cout1_dgrad: add slice");
+  const int lds = p.K * p.K * p.C * 4;
+  rc = c1_lds(reinterpret_cast<const void*>(&cout1_dgrad_kernel), lds, "conv_cout1_dgrad");
+  if (rc) return rc;
+  const size_t px = (size_t)p.N * p.H * p.W;
+  size_t grid = (px + 3) / 4;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(cout1_dgrad_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
+  return check_launch("cout1_dgrad_kernel");
+}
+
+extern "C" int32_t hrv_conv_cout1_wgrad_slabs(int32_t N, int32_t Ho, int32_t Wo) {
+  const int64_t total = (int64_t)N * Ho * Wo;
+  int64_t S = total / 128;
+  if (S > 1024) S = 1024;
+  if (S < 1) S = 1;
+  return (int32_t)S;
+}
+
+// workspace: hrv_conv_cout1_wgrad_slabs() x (C*K*K + 1) floats; dw [1][C][K][K] and dbias [1] (+)= the slab sums
+extern "C" int hrv_conv_cout1_wgrad_f32(const hrv_conv_cout1_t* d, float* dw, int32_t accumulate, float* dbias,
+                                        int32_t dbias_accumulate, hrv_stream_t stream) {
+  Cout1Params p;
+  int rc = c1_fill(d, p, "conv_cout1_wgrad");
+  if (rc) return rc;
+  HRV_REQUIRE(d->workspace && dw, "conv_cout1_wgrad: null pointer");
+  p.S = hrv_conv_cout1_wgrad_slabs(p.N, p.Ho, p.Wo);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(p.S, (p.C + 255) / 256), dim3(256), 0, st, p);
+  rc = check_launch("cout1_wgrad_kernel");
+  if (rc) return rc;
+  const int cols = p.C * p.K * p.K;
+  hipLaunchKernelGGL(cout1_reduce_kernel, dim3((cols + 1 + 15) / 16), dim3(256), 0, st, p.part, p.S, cols, dw, accumulate, dbias,
+                     dbias_accumulate);
+  return check_launch("cout1_reduce_kernel");
+}

@@ -344,6 +344,25 @@ def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift
     return out
 
 
+def _cout1_ok(w: torch.Tensor, x: Act, stride: int, pad: int) -> bool:
+    """conv_cout1.hip serves this layer: ONE output channel, K <= 4, stride 1, an fp32 source with 4-channel granules
+    (PatchGAN's last convolution)."""
+    Cout, cin, KH, KW = w.shape
+    return (Cout == 1 and KH == KW and KH <= 4 and stride == 1 and 0 <= pad < KH and not x.bf16 and x.C == cin and
+            cin % 4 == 0 and cin <= 2048 and x.cstride % 4 == 0 and x.coff % 4 == 0 and w.is_contiguous() and
+            os.environ.get("HRV_CONV_COUT1", "1") != "0")
+
+
+def _cout1_desc(w, x: Act, pad: int, wscale: float, sigma, y: Act):
+    d = _lib.hrv_conv_cout1_t()
+    d.x, d.N, d.H, d.W, d.C, d.x_cstride, d.x_coff = x.t.data_ptr(), x.N, x.H, x.W, x.C, x.cstride, x.coff
+    d.w_oihw, d.wscale, d.K, d.pad = w.data_ptr(), wscale, w.shape[2], pad
+    d.sigma = None if sigma is None else sigma.data_ptr()
+    d.y, d.y_cstride, d.y_coff = y.t.data_ptr(), y.cstride, y.coff
+    d.round_bf16 = 1 if MMA_BF16[0] else 0
+    return d
+
+
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
@@ -357,6 +376,14 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
     H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
     Ho, Wo = (H + 2 * pad - KH) // stride + 1, (W + 2 * pad - KW) // stride + 1
     mb = MMA_BF16[0]
+    if (len(srcs) == 1 and up0 == 0 and out_up == 0 and residual is None and act == ACT_NONE and out is None and
+            _cout1_ok(w, a0, stride, pad)):
+        out = ops.alloc(N, Ho, Wo, 1, a0.t.device)          # (pad channels 1..3 are zero)
+        d = _cout1_desc(w, a0, pad, wscale, sigma, out)
+        d.bias = None if shift is None else shift.data_ptr()
+        with _Timed("conv", name, 2.0 * N * Ho * Wo * cin * KH * KW, ops.act_bytes(a0) + 4.0 * N * Ho * Wo):
+            _lib.check(lib.hrv_conv_cout1_fwd_f32(C.byref(d), _stream()), f"hrv_conv_cout1_fwd_f32[{name}]")
+        return out
     if (len(srcs) == 1 and up0 == 0 and out_up == 0 and w.is_contiguous() and
             _thin_ok(a0, KH, KW, stride, pad, Cout, N, H, W) and (out is None or out.cstride % 4 == 0)):
         assert a0.C == cin, (name, a0.C, cin)
@@ -408,6 +435,15 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
     if add is not None:
         act_mask = add           # (the engine's residual slot: res_mode 0 adds it)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
+    if (pair is None and res_mode == 0 and not dy.bf16 and not out.bf16 and (add is None or not add.bf16) and
+            (Ho, Wo) == (H + 2 * pad - KH + 1, W + 2 * pad - KW + 1) and _cout1_ok(w, Act(out.t, cin, out.coff), stride, pad)):
+        d = _cout1_desc(w, Act(out.t, cin, out.coff), pad, wscale, sigma, dy)      # (x slot: geometry only)
+        d.dx, d.dx_cstride, d.dx_coff = out.t.data_ptr(), out.cstride, out.coff
+        if add is not None:
+            d.add, d.add_cstride, d.add_coff = add.t.data_ptr(), add.cstride, add.coff
+        with _Timed("conv", name, fl, ops.act_bytes(out) * (2 if add is not None else 1) + 4.0 * N * Ho * Wo):
+            _lib.check(lib.hrv_conv_cout1_dgrad_f32(C.byref(d), _stream()), f"hrv_conv_cout1_dgrad_f32[{name}]")
+        return out
     if (add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
@@ -445,6 +481,17 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     N, Ho, Wo, Cout = dy.N, dy.H, dy.W, dy.C
     H, W = (x.H << x_up, x.W << x_up) if x_up >= 0 else (x.H >> -x_up, x.W >> -x_up)
     assert dw.is_contiguous() and tuple(dw.shape) == (Cout, cin_tot, KH, KW), (dw.shape, Cout, cin_tot, KH, KW)
+    if (Cout == 1 and x_up == 0 and ci_base == 0 and cin_tot == x.C and not dy.bf16 and
+            (Ho, Wo) == (H + 2 * pad - KH + 1, W + 2 * pad - KW + 1) and _cout1_ok(dw, x, stride, pad)):
+        S = lib.hrv_conv_cout1_wgrad_slabs(N, Ho, Wo)
+        ws = _workspace(dy.t.device, 4 * S * (x.C * KH * KW + 1))
+        d = _cout1_desc(dw, x, pad, 1.0, None, dy)
+        d.workspace = ws.data_ptr()
+        with _Timed("wgrad", name, 2.0 * N * Ho * Wo * x.C * KH * KW, ops.act_bytes(x) + 4.0 * N * Ho * Wo):
+            _lib.check(lib.hrv_conv_cout1_wgrad_f32(C.byref(d), dw.data_ptr(), 1 if accumulate else 0,
+                                                    None if dbias is None else dbias.data_ptr(), 1 if dbias_accumulate else 0,
+                                                    _stream()), f"hrv_conv_cout1_wgrad_f32[{name}]")
+        return
     wo_real = Wo
     if (MMA_BF16[0] and Wo % 4 != 0 and Wo >= 32 and not (x.bf16 or dy.bf16) and dy.coff == 0 and dy.cstride == dy.Cp):
         # odd-sized maps (the PatchGAN's 513 / 257 / 129 columns): the bf16 matrix-core kernel stages quads of 4 pixels

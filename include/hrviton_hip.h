@@ -468,6 +468,29 @@ int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, i
  * NLayerDiscriminator model0) -- runs as a 2x2 stride-1 pad-1 convolution over the 4C-channel tensor. */
 int hrv_space_to_depth2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
                                  int32_t in_coff, float* out, hrv_stream_t stream);
+/* Stride-1 convolutions with ONE output channel (K <= 4): PatchGAN's last layer -- Conv2d(nf, 1, kernel_size=4, stride=1,
+ * padding=2) of network_generator.py NLayerDiscriminator and networks.py:389-393 -- forward, data gradient (+ an optional
+ * tensor added to dx) and weight / bias gradient as dot-product / outer-product / reduction kernels (the implicit-GEMM engine
+ * pads the single column to a 64-column tile).  fp32 FMAs; round_bf16: both operands rounded to bf16 first (the arithmetic
+ * of the bf16 matrix-core engine in mixed-precision training).  y is the forward OUTPUT and the backward's dY:
+ * [N][H+2*pad-K+1][W+2*pad-K+1][y_cstride], channel y_coff. */
+typedef struct {
+  const float* x; int32_t N, H, W, C, x_cstride, x_coff;
+  const float* w_oihw;             /* [1][C][K][K] */
+  const float* sigma; float wscale; /* weights are multiplied by wscale / sigma[0] (sigma may be null) */
+  const float* bias;               /* [1] or null (forward) */
+  int32_t K, pad;
+  float* y; int32_t y_cstride, y_coff;
+  float* dx; int32_t dx_cstride, dx_coff;            /* data gradient output [N][H][W][dx_cstride] */
+  const float* add; int32_t add_cstride, add_coff;   /* optional: dx = dgrad + add */
+  float* workspace;                /* weight gradient: hrv_conv_cout1_wgrad_slabs() * (C*K*K + 1) floats */
+  int32_t round_bf16;
+} hrv_conv_cout1_t;
+int hrv_conv_cout1_fwd_f32(const hrv_conv_cout1_t* d, hrv_stream_t stream);
+int hrv_conv_cout1_dgrad_f32(const hrv_conv_cout1_t* d, hrv_stream_t stream);
+int32_t hrv_conv_cout1_wgrad_slabs(int32_t N, int32_t Ho, int32_t Wo);
+int hrv_conv_cout1_wgrad_f32(const hrv_conv_cout1_t* d, float* dw, int32_t accumulate, float* dbias, int32_t dbias_accumulate,
+                             hrv_stream_t stream);
 /* cat((a, b), 1) for a NHWC (channels [a_coff, a_coff+Ca) of a_cstride) and b NCHW [N,Cb,H,W], written NHWC
  * [N,H,W,out_cstride] with zeroed pad channels: the PatchGAN input of train_generator.py:283-284. */
 int hrv_concat_nhwc_nchw_f32(const float* a, int32_t Ca, int32_t a_cstride, int32_t a_coff, const float* b, int32_t Cb, int32_t N,

@@ -812,3 +812,55 @@ def test_concat_of_an_nhwc_and_an_nchw_tensor(shape):
     T.concat_nhwc_nchw(ops.Act(a, Ca, coff), b, out)
     ref = torch.cat((a[..., coff:coff + Ca], b.permute(0, 2, 3, 1)), 3)
     assert torch.equal(out.t[..., :Ca + Cb], ref) and bool((out.t[..., Ca + Cb:] == 0).all())
+
+
+@pytest.mark.parametrize("case", [("patchgan_last_4x4", 256, 4, 2, 3, 35, 27, False), ("wide_512ch_bf16_operands", 512, 4, 2, 2, 18, 19, True),
+                                  ("k3_same_64ch", 64, 3, 1, 2, 20, 16, False)], ids=lambda c: c[0])
+def test_one_output_channel_convolution_kernels(case, monkeypatch):
+    """conv_cout1.hip -- PatchGAN's last layer Conv2d(nf, 1, 4, stride=1, padding=2) (network_generator.py
+    NLayerDiscriminator) -- through conv_forward_dev / conv_dgrad (with the feature-matching addend) / conv_wgrad: against
+    torch (fp32; mixed precision: on bf16-rounded operands, the engine's arithmetic) and against the implicit-GEMM engine
+    it replaces (HRV_CONV_COUT1=0); the source is a channel slice of a wider tensor."""
+    ops, T = _mods()
+    name, Cin, K, pad, N, H, W, mixed = case
+    g = torch.Generator().manual_seed(Cin + K)
+    rb = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mixed else (lambda t: t)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(1, Cin, K, K, generator=g) * 0.05).cuda()
+    b = torch.randn(1, generator=g).cuda()
+    Ho, Wo = H + 2 * pad - K + 1, W + 2 * pad - K + 1
+    dy = torch.randn(N, 1, Ho, Wo, generator=g)
+    addt = torch.randn(N, Cin, H, W, generator=g)
+    res = {}
+    T.MMA_BF16[0] = mixed
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("HRV_CONV_COUT1", mode)
+            wide = ops.alloc(N, H, W, Cin + 8, "cuda")
+            wide.t.normal_()
+            xa = wide.slice(4, Cin)
+            ops.to_nhwc(x.cuda(), out=xa)
+            y = T.conv_forward_dev(w, [(xa, 0)], 1, pad, shift=b, name=name)
+            dya = ops.to_nhwc(dy.cuda())
+            dx = T.conv_dgrad(dya, w, H, W, 1, pad, add=ops.to_nhwc(addt.cuda()), name=name + ".dgrad")
+            dw = torch.full((1, Cin, K, K), 5.0, device="cuda")
+            db = torch.full((1,), 5.0, device="cuda")
+            T.conv_wgrad(dya, xa, 0, 0, Cin, K, K, 1, pad, dw, name=name + ".wgrad", dbias=db)
+            torch.cuda.synchronize()
+            assert bool((y.t[..., 1:] == 0).all()), "pad channels of the one-channel output stay zero"
+            res[mode] = (ops.to_nchw(y).cpu(), ops.to_nchw(dx).cpu(), dw.cpu(), db.cpu())
+    finally:
+        T.MMA_BF16[0] = False
+    xr, wr, dyr = rb(x), rb(w.cpu()), rb(dy)
+    ref_y = F.conv2d(xr, wr, b.cpu(), padding=pad)
+    ref_dx = torch.nn.grad.conv2d_input(x.shape, wr, dyr, padding=pad) + addt
+    ref_dw = torch.nn.grad.conv2d_weight(xr, w.shape, dyr, padding=pad)
+    tol = 2e-5
+    got = res["1"]
+    assert (got[0] - ref_y).abs().max() <= tol * ref_y.abs().max()
+    assert (got[1] - ref_dx).abs().max() <= tol * ref_dx.abs().max()
+    assert (got[2] - ref_dw).abs().max() <= 5 * tol * ref_dw.abs().max()
+    assert abs(got[3].item() - dy.sum().item()) <= 1e-4 * dy.abs().sum().item()
+    # ... and the engine it replaces computes the same thing (same operand rounding in mixed precision)
+    for a, e, s in zip(got[:3], res["0"][:3], (ref_y, ref_dx, ref_dw)):
+        assert (a - e).abs().max() <= 1e-4 * s.abs().max()

@@ -52,6 +52,17 @@ def main(fetch, write, out, cmd):
                                     "hbm_bytes_per_launch": (2.0 * ff.get(fam, [0.0, 0])[0] + wf.get(fam, [0.0, 0])[0]) * 1024.0 /
                                     max(1, max(ff.get(fam, [0, 0])[1], wf.get(fam, [0, 0])[1]))}
                              for fam in FAMILIES if fam in ff or fam in wf}
+    # every kernel of the run (the "over N samples" totals of the two summaries): the whole iteration's HBM traffic
+    def total(path, counter):
+        for l in open(path):
+            m = re.match(rf"{counter}\s+([\d.]+)\s+over\s+(\d+)\s+samples", l)
+            if m:
+                return float(m.group(1)), int(m.group(2))
+        return None, None
+    fa, na = total(fetch, "FETCH_SIZE")
+    wa, _ = total(write, "WRITE_SIZE")
+    if fa is not None and wa is not None:
+        j["all_kernels"] = {"dispatches": na, "fetch_KiB_raw": fa, "write_KiB": wa, "hbm_bytes_whole_run": (2.0 * fa + wa) * 1024.0}
     # the profiled command runs warm-up + timed + ONE per-launch-profiled step (bench.py measure()): --steps 1 --warmup 1 -> 3
     m = re.search(r"--steps (\d+) --warmup (\d+)", cmd)
     steps = (int(m.group(1)) + int(m.group(2)) + 1) if m else None
@@ -59,6 +70,8 @@ def main(fetch, write, out, cmd):
     if steps:
         for fam, v in j["per_kernel_family"].items():
             v["hbm_bytes_per_step"] = v["hbm_bytes_per_launch"] * v["dispatches"] / steps
+        if "all_kernels" in j:      # (set-up kernels -- parameter upload, optimizer set-up -- are in the total: an upper bound)
+            j["all_kernels"]["hbm_bytes_per_step"] = j["all_kernels"]["hbm_bytes_whole_run"] / steps
     with open(out, "w") as fo:
         json.dump(j, fo, indent=1)
     print(json.dumps(j))
