@@ -344,13 +344,17 @@ def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift
     return out
 
 
-def _cout1_ok(w: torch.Tensor, x: Act, stride: int, pad: int) -> bool:
+def _cout1_ok(w: torch.Tensor, x: Act, stride: int, pad: int, part: str = "fwd") -> bool:
     """conv_cout1.hip serves this layer: ONE output channel, K <= 4, stride 1, an fp32 source with 4-channel granules
-    (PatchGAN's last convolution)."""
+    (PatchGAN's last convolution).  HRV_CONV_COUT1: "0" off, "1" (default) the forward kernel, "all" also the data- and
+    weight-gradient kernels -- measured at 2 x 4 x 131 x 99 x 256: forward 0.233 -> 0.109 ms, data gradient 0.094 -> 0.099 ms
+    (no gain), weight gradient 0.19 -> 0.72 ms (a thread-per-channel walk with 16 bounds-checked dY loads per pixel: slower
+    than the padded matrix-core kernel) -- so only the forward is selected."""
     Cout, cin, KH, KW = w.shape
+    mode = os.environ.get("HRV_CONV_COUT1", "1")
     return (Cout == 1 and KH == KW and KH <= 4 and stride == 1 and 0 <= pad < KH and not x.bf16 and x.C == cin and
             cin % 4 == 0 and cin <= 2048 and x.cstride % 4 == 0 and x.coff % 4 == 0 and w.is_contiguous() and
-            os.environ.get("HRV_CONV_COUT1", "1") != "0")
+            (mode == "all" or (mode != "0" and part == "fwd")))
 
 
 def _cout1_desc(w, x: Act, pad: int, wscale: float, sigma, y: Act):
@@ -436,7 +440,7 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         act_mask = add           # (the engine's residual slot: res_mode 0 adds it)
     fl = 2.0 * N * Ho * Wo * Cout * cin * KH * KW
     if (pair is None and res_mode == 0 and not dy.bf16 and not out.bf16 and (add is None or not add.bf16) and
-            (Ho, Wo) == (H + 2 * pad - KH + 1, W + 2 * pad - KW + 1) and _cout1_ok(w, Act(out.t, cin, out.coff), stride, pad)):
+            (Ho, Wo) == (H + 2 * pad - KH + 1, W + 2 * pad - KW + 1) and _cout1_ok(w, Act(out.t, cin, out.coff), stride, pad, "dgrad")):
         d = _cout1_desc(w, Act(out.t, cin, out.coff), pad, wscale, sigma, dy)      # (x slot: geometry only)
         d.dx, d.dx_cstride, d.dx_coff = out.t.data_ptr(), out.cstride, out.coff
         if add is not None:
@@ -482,7 +486,7 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     H, W = (x.H << x_up, x.W << x_up) if x_up >= 0 else (x.H >> -x_up, x.W >> -x_up)
     assert dw.is_contiguous() and tuple(dw.shape) == (Cout, cin_tot, KH, KW), (dw.shape, Cout, cin_tot, KH, KW)
     if (Cout == 1 and x_up == 0 and ci_base == 0 and cin_tot == x.C and not dy.bf16 and
-            (Ho, Wo) == (H + 2 * pad - KH + 1, W + 2 * pad - KW + 1) and _cout1_ok(dw, x, stride, pad)):
+            (Ho, Wo) == (H + 2 * pad - KH + 1, W + 2 * pad - KW + 1) and _cout1_ok(dw, x, stride, pad, "wgrad")):
         S = lib.hrv_conv_cout1_wgrad_slabs(N, Ho, Wo)
         ws = _workspace(dy.t.device, 4 * S * (x.C * KH * KW + 1))
         d = _cout1_desc(dw, x, pad, 1.0, None, dy)
