@@ -132,26 +132,39 @@ def test_tocg_full_size_properties():
     assert (a[1] >= 0).all()                                  # out_layer='relu' ends in ReLU
 
 
-def test_mixed_precision_inference_tracks_fp32():
-    """opt.fp16 (test_generator.py --fp16): bf16 matrix-core operands over fp32 tensors (flow heads stay fp32).
-    Against the fp32 HIP path on the same weights: flows / logits within the stated bf16 tolerance, labels agree."""
+def test_mixed_precision_inference_matches_the_oracle_with_the_same_rounding_points():
+    """opt.fp16 (test_generator.py --fp16): bf16 matrix-core operands over fp32 tensors (flow heads stay fp32) against the
+    ORACLE evaluated with the same rounding points (oracle.QUANT: every ResBlock / lateral / bottleneck convolution rounds
+    its input and weight to bf16, fp32 accumulate) -- not against this package's own fp32 engine.  Stated bf16 tolerance:
+    in the mean the engine is at most twice as far from the rounded oracle as that oracle is from its own re-evaluation with
+    the input nudged by 1e-6 (+ 2^-9 of the tensor's scale); the label maps disagree on at most twice (+0.5 %) the pixels
+    two evaluations of the rounded oracle disagree on; and the rounding is really there (differs from the fp32 oracle)."""
     from argparse import Namespace
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd.networks import ConditionGenerator
+    from oracle import hrviton_oracle as O
     g = load_golden("tocg_ngf8_96x64.pt")
-
-    def run(fp16):
-        opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu", fp16=fp16)
-        m = ConditionGenerator(opt, 4, 16, 13, ngf=8, norm_layer=torch.nn.BatchNorm2d)
-        m.load_state_dict(g["state_dict"])
-        m.cuda().eval()
-        return m(opt, g["input1"].cuda(), g["input2"].cuda())
-
-    f32, f16 = run(False), run(True)
-    for a, b in zip(f16[0], f32[0]):
-        assert (a - b).abs().max() <= 3e-2 * b.abs().max() + 1e-3
-    seg16, seg32 = f16[1], f32[1]
-    assert (seg16 - seg32).abs().max() <= 3e-2 * seg32.abs().max()
-    assert (seg16 - seg32).abs().mean() > 1e-6          # it is a different rounding
-    agree = (seg16.argmax(1) == seg32.argmax(1)).float().mean().item()
-    assert agree > 0.98, agree
+    opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu", fp16=True)
+    m = ConditionGenerator(opt, 4, 16, 13, ngf=8, norm_layer=torch.nn.BatchNorm2d)
+    m.load_state_dict(g["state_dict"])
+    m.cuda().eval()
+    got = m(opt, g["input1"].cuda(), g["input2"].cuda())
+    sd = {k: v.detach().clone() for k, v in g["state_dict"].items()}
+    i1, i2 = g["input1"], g["input2"]
+    with torch.no_grad():
+        fp32 = O.tocg_forward(sd, i1, i2)
+        O.QUANT["fn"] = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        try:
+            want = O.tocg_forward(sd, i1, i2)
+            gen = torch.Generator().manual_seed(3)
+            want2 = O.tocg_forward(sd, i1 * (1 + 1e-6 * torch.randn(i1.shape, generator=gen)), i2)
+        finally:
+            O.QUANT["fn"] = None
+    for name, a, b, c in (("flow_last", got[0][-1].cpu(), want[0][-1], want2[0][-1]), ("seg", got[1].cpu(), want[1], want2[1]),
+                          ("warped_cloth", got[2].cpu(), want[2], want2[2])):
+        err, self_err, scale = (a - b).abs().mean().item(), (c - b).abs().mean().item(), b.abs().max().item()
+        assert err < 2.0 * self_err + scale * 2.0 ** -9, (name, err, self_err, scale)
+    dis = (got[1].cpu().argmax(1) != want[1].argmax(1)).float().mean().item()
+    dis_self = (want2[1].argmax(1) != want[1].argmax(1)).float().mean().item()
+    assert dis < 2.0 * dis_self + 5e-3, (dis, dis_self)
+    assert (got[1].cpu() - fp32[1]).abs().mean() > 1e-6          # it is a different rounding than the fp32 path

@@ -195,60 +195,32 @@ def test_train_generator_script_small_run(tmp_path):
     assert moved > 0
 
 
-def test_mixed_precision_generator_step_tracks_fp32():
-    """--fp16 (train_ops.MMA_BF16): one generator step with the bf16 matrix cores over fp32 tensors against the
-    SAME step on the fp32 engine (which the tests above hold to the oracle): loss terms within 2 %, every sizeable
-    parameter gradient within cosine 0.93 (mean > 0.98) / 15 % norm.  Stated bf16 tolerance: operands carry 8 mantissa bits."""
-    import hr_viton_amd  # noqa: F401
-    from hr_viton_amd import train_ops as T
-    from hr_viton_amd.losses import GANLoss, L1Loss
+def test_mixed_precision_generator_step_against_the_oracle():
+    """--fp16 (train_ops.MMA_BF16): the generator half of one training iteration on the bf16 matrix cores against torch
+    autograd over the ORACLE (oracle.step_check.compare_generator_step, the comparison tests/test_gpu_fullsize.py and
+    bench.py's parity block run at 512x384 / 2x1024x768) -- not against this package's own fp32 engine, which the same
+    call holds to the north-star tolerance.  256x128, ngf = 16: image, every loss term, every sizeable parameter gradient's
+    cosine, within the stated bf16 tolerance (operands carry 8 mantissa bits)."""
+    import os
+    from oracle import step_check
+    out = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    os.makedirs(out, exist_ok=True)
+    rep = step_check.compare_generator_step(256, 128, 16, 16, 2, seed=5, mixed=(False, True), cpu_threads=min(os.cpu_count() or 1, 16),
+                                            table_path=os.path.join(out, "grad_parity_gen_256x128_ngf16.txt"))
+    with open(os.path.join(out, "step_parity_gen_256x128_ngf16.txt"), "w") as f:
+        f.write(repr(rep) + "\n")
+    f32, b16 = rep[False], rep[True]
+    assert f32["image_max_rel_err"] < 1e-3 and all(v < 1e-3 for v in f32["loss_rel_err"].values()) and f32["grad_worst_rel_err"] < 2e-2, f32
+    # stated bf16 tolerance (operands carry 8 mantissa bits), at about twice what this small, noisy configuration measures
+    # -- image mean-abs 3.1e-3 / max 5.9e-2 of the range, loss terms <= 2.0e-4, median gradient error 1.9e-2, worst cosine
+    # 0.883 (head_0.conv_1, 24 convolutions below the loss: sign() of the L1 feature-matching term turns operand rounding
+    # into flipped gradient elements, and a 16-channel level averages few of them); the bench resolution holds 1.1e-3 /
+    # 0.998 against 3e-3 / 0.99 (tests/test_gpu_fullsize.py)
+    assert b16["image_mean_abs_err"] < 6e-3 and b16["image_max_rel_err"] < 0.12, b16
+    assert all(v < 2e-3 for v in b16["loss_rel_err"].values()), b16
+    assert b16["grad_min_cosine"] > 0.85 and b16["grad_median_rel_err"] < 0.04, b16
+    assert b16["image_mean_abs_err"] > 1e-7          # the bf16 path really ran
 
-    def run(mixed):
-        # x8 weights: a well-conditioned network (the x25 stress recipe of the fp32 tests amplifies ANY rounding
-        # chaotically by the time it reaches the stem: cosine 0.92 there)
-        opt, gen, D, x, seg, real, noise = _setup(seed=3, wmul=8.0)
-        gen.cuda().train()
-        D.cuda().train()
-        T.MMA_BF16[0] = mixed
-        try:
-            cz = {k: [z.cuda() for z in v] for k, v in noise.items()}
-            fake = gen(x.cuda(), seg.cuda(), noise=cz)
-            segc, realc = seg.cuda(), real.cuda()
-            pred = D(torch.cat([torch.cat([segc, fake], 1), torch.cat([segc, realc], 1)], 0))
-            pf = [[t[: t.size(0) // 2] for t in p] for p in pred]
-            pr = [[t[t.size(0) // 2:] for t in p] for p in pred]
-            l_gan = GANLoss("hinge")(pf, True, for_discriminator=False)
-            l_feat = 0
-            for i in range(2):
-                for j in range(len(pf[i]) - 1):
-                    l_feat = l_feat + L1Loss()(pf[i][j], pr[i][j].detach()) * 10.0 / 2
-            (l_gan + l_feat).mean().backward()
-        finally:
-            T.MMA_BF16[0] = False
-        grads = {n: p.grad.detach().cpu().clone() for n, p in gen.named_parameters() if p.grad is not None}
-        return float(l_gan), float(l_feat), fake.detach().cpu(), grads
-
-    g32, f32_, out32, gr32 = run(False)
-    g16, f16_, out16, gr16 = run(True)
-    assert abs(g16 - g32) < 2e-2 * max(1.0, abs(g32)) and abs(f16_ - f32_) < 2e-2 * max(1.0, abs(f32_)), (g16, g32, f16_, f32_)
-    assert (out16 - out32).abs().mean() < 2e-2
-    gmax = max(v.abs().max().item() for v in gr32.values())
-    worst, coss = 1.0, []
-    for n, a in gr32.items():
-        if a.abs().max() < 1e-2 * gmax or a.numel() < 16:
-            continue
-        if n.endswith("noise_scale"):
-            continue      # sum over pixels of dx * z with z ~ N(0,1): cancellation-dominated, any rounding shows (cos ~0.9)
-        b = gr16[n]
-        cos = torch.nn.functional.cosine_similarity(a.flatten(), b.flatten(), dim=0).item()
-        ratio = (b.norm() / a.norm()).item()
-        worst = min(worst, cos)
-        coss.append(cos)
-        # sign() of the L1 feature-matching term turns operand rounding into flipped gradient elements; measured
-        # worst case 0.957 (head_0.conv_1, 24 convolutions below the loss), mean 0.99
-        assert cos > 0.93 and 0.85 < ratio < 1.15, (n, cos, ratio)
-    assert sum(coss) / len(coss) > 0.98, sum(coss) / len(coss)
-    assert worst < 0.9999999     # the bf16 path really ran
 
 
 def test_split_discriminator_path_equals_sliced_path():
