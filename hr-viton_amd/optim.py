@@ -63,7 +63,10 @@ class Adam(torch.optim.Optimizer):
             p.data = w[off:off + k].view_as(p.data)      # the parameter now lives in the flat buffer
             spans.append((p, off, k))
             off += (k + 3) // 4 * 4
-        st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w), g=torch.zeros_like(w), spans=spans, step=0)
+        # ``steps``: one counter per parameter, like torch.optim.Adam's state[p]["step"] -- a parameter without a gradient
+        # in some iteration (skipped below) falls behind the others, and its bias correction must use ITS count
+        st = dict(w=w, m=torch.zeros_like(w), v=torch.zeros_like(w), g=torch.zeros_like(w), spans=spans, step=0,
+                  steps=[0] * len(spans))
         self._flat[gi] = st
         # the backward plans write gradients straight into these slots (gen_train.grad_buffer / _acc)
         for p, off, k in spans:
@@ -95,20 +98,43 @@ class Adam(torch.optim.Optimizer):
             g = st["g"]
             base = g.data_ptr()
             skipped = []
-            for p, off, k in st["spans"]:
+            steps = st["steps"]
+            for i, (p, off, k) in enumerate(st["spans"]):
                 src = self.grad_sync.grad_of(p) if self.grad_sync is not None else p.grad
                 if src is None:
-                    # torch's Adam SKIPS a parameter without a gradient (weight, moments and weight decay untouched): the
-                    # fused launch covers the whole flat buffer, so the span is snapshotted here and restored below
+                    # torch's Adam SKIPS a parameter without a gradient (weight, moments, weight decay and its step count
+                    # untouched): the fused launch covers whole runs of the flat buffer, so the span is snapshotted here
+                    # and restored below
                     g[off:off + k].zero_()
                     skipped.append((off, k, st["w"][off:off + k].clone(), st["m"][off:off + k].clone(),
                                     st["v"][off:off + k].clone()))
-                elif src.data_ptr() != base + 4 * off:   # already produced in place by the backward plan otherwise
-                    g[off:off + k].copy_(src.reshape(-1))
+                else:
+                    steps[i] += 1
+                    if src.data_ptr() != base + 4 * off:   # already produced in place by the backward plan otherwise
+                        g[off:off + k].copy_(src.reshape(-1))
             st["step"] += 1
             b1, b2 = group["betas"]
-            T.adam_step(st["w"], g, st["m"], st["v"], float(group["lr"]), b1, b2, group["eps"], group["weight_decay"],
-                        st["step"], world_scale)
+            # one launch per run of consecutive spans that share a step count (a skipped span rides along with either
+            # neighbour: it is restored afterwards) -- ONE launch over the whole buffer unless some parameter fell behind
+            runs, n_sp = [], len(st["spans"])
+            skipped_offs = {off for off, _, _, _, _ in skipped}
+            i = 0
+            while i < n_sp:
+                if st["spans"][i][1] in skipped_offs:
+                    i += 1
+                    continue
+                j, cnt = i, steps[i]
+                while j + 1 < n_sp and (st["spans"][j + 1][1] in skipped_offs or steps[j + 1] == cnt):
+                    j += 1
+                a = st["spans"][i][1]
+                b = st["spans"][j][1] + (st["spans"][j][2] + 3) // 4 * 4
+                runs.append((a, min(b, g.numel()), cnt))
+                i = j + 1
+            if len(runs) == 1 and len(skipped) == 0:
+                runs = [(0, g.numel(), runs[0][2])]
+            for a, b, cnt in runs:
+                T.adam_step(st["w"][a:b], g[a:b], st["m"][a:b], st["v"][a:b], float(group["lr"]), b1, b2, group["eps"],
+                            group["weight_decay"], cnt, world_scale)
             for off, k, w0, m0, v0 in skipped:
                 st["w"][off:off + k].copy_(w0)
                 st["m"][off:off + k].copy_(m0)
@@ -127,11 +153,12 @@ class Adam(torch.optim.Optimizer):
         for gi, group in enumerate(self.param_groups):
             st = self._flat.get(gi)
             spans = {id(p): (off, k) for p, off, k in st["spans"]} if st else {}
+            pos = {id(p): i for i, (p, _, _) in enumerate(st["spans"])} if st else {}
             ids = []
             for p in group["params"]:
                 if st and id(p) in spans:
                     off, k = spans[id(p)]
-                    state[idx] = {"step": torch.tensor(float(st["step"])),
+                    state[idx] = {"step": torch.tensor(float(st["steps"][pos[id(p)]])),
                                   "exp_avg": st["m"][off:off + k].view_as(p).clone(),
                                   "exp_avg_sq": st["v"][off:off + k].view_as(p).clone()}
                 ids.append(idx)
@@ -149,11 +176,13 @@ class Adam(torch.optim.Optimizer):
                     group[k] = tuple(v) if k == "betas" else v
             st = self._flat.get(gi) or self._setup(gi, group)
             spans = {id(p): (off, k) for p, off, k in st["spans"]}
+            pos = {id(p): i for i, (p, _, _) in enumerate(st["spans"])}
             for p in group["params"]:
                 ent = sd["state"].get(idx)
                 if ent is not None and id(p) in spans:
                     off, k = spans[id(p)]
                     st["m"][off:off + k].copy_(ent["exp_avg"].reshape(-1).to(st["m"].device))
                     st["v"][off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(st["v"].device))
-                    st["step"] = int(ent["step"])
+                    st["steps"][pos[id(p)]] = int(ent["step"])
+                    st["step"] = max(st["step"], int(ent["step"]))
                 idx += 1

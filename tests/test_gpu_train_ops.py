@@ -864,3 +864,29 @@ def test_one_output_channel_convolution_kernels(case, monkeypatch):
     # ... and the engine it replaces computes the same thing (same operand rounding in mixed precision)
     for a, e, s in zip(got[:3], res["0"][:3], (ref_y, ref_dx, ref_dw)):
         assert (a - e).abs().max() <= 1e-4 * s.abs().max()
+
+
+def test_fused_adam_keeps_a_step_count_per_parameter_like_torch():
+    """hr_viton_amd.optim.Adam against torch.optim.Adam when a parameter has NO gradient in some iterations (torch skips it:
+    weight, moments and its step count stay) -- the bias correction of a parameter that fell behind uses its own count
+    (one fused launch per run of equal counts), and state_dict() reports the per-parameter steps."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.optim import Adam
+    g = torch.Generator().manual_seed(8)
+    shapes = [(7, 5), (33,), (4, 3, 3, 3), (10,)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, generator=g)) for s in shapes]
+    hip_p = [torch.nn.Parameter(p.detach().clone().cuda()) for p in ref_p]
+    ro = torch.optim.Adam(ref_p, lr=1e-2, betas=(0.5, 0.9), weight_decay=1e-3)
+    ho = Adam(hip_p, lr=1e-2, betas=(0.5, 0.9), weight_decay=1e-3)
+    present = [(1, 1, 1, 1), (1, 0, 1, 0), (1, 1, 0, 0), (0, 1, 1, 1), (1, 1, 1, 1)]
+    for it, mask in enumerate(present):
+        for p, q, on in zip(ref_p, hip_p, mask):
+            gr = torch.randn(p.shape, generator=g)
+            p.grad = gr.clone() if on else None
+            q.grad = gr.cuda() if on else None
+        ro.step()
+        ho.step()
+        for i, (p, q) in enumerate(zip(ref_p, hip_p)):
+            assert _rel(q.detach(), p.detach()) < 2e-6, (it, i)
+    sd = ho.state_dict()["state"]
+    assert [int(sd[i]["step"]) for i in range(4)] == [sum(m[i] for m in present) for i in range(4)] == [4, 4, 4, 3]
