@@ -76,26 +76,44 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
     if (r < R && g < p.C4) {
       const f32x4 mu = ld4(p.mean + (size_t)n * C + g * 4), rs = ld4(p.rstd + (size_t)n * C + g * 4);
       const f32x4 ns4 = p.z ? ld4(p.ns + g * 4) : (f32x4)(0.f);
-      for (int px = p0 + r; px < p1; px += R) {
+      // two pixels per iteration: all eight loads of both are requested before the first result is stored (the stores may
+      // alias the loads as far as the compiler knows, so a plain loop keeps one pixel's four loads in flight per thread);
+      // every value and the order of the two sums are those of the plain loop
+      struct In { f32x4 v, d, o, g1; float zz; };
+      auto load = [&](int px) {
+        In L;
         const size_t pix = (size_t)n * HW + px;
-        f32x4 v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        L.v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        L.zz = 0.f;
         if (p.z) {
           const int h = px / p.W, w = px - h * p.W;
-          v += p.z[((size_t)n * p.W + w) * p.H + h] * ns4;
+          L.zz = p.z[((size_t)n * p.W + w) * p.H + h];
         }
-        const f32x4 nh = (v - mu) * rs;
-        f32x4 dpre = ld4(p.dout + pix * p.do_cs + p.do_co + g * 4);
+        L.d = ld4(p.dout + pix * p.do_cs + p.do_co + g * 4);
+        L.o = (f32x4)(0.f);
         if (p.act != HRV_ACT_NONE) {
           const size_t oe = pix * p.out_cs + p.out_co + g * 4;
-          const f32x4 o = p.out_bf16 ? ld4_bf16(p.out, oe) : ld4(p.out + oe);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) dpre[e] *= dact(o[e], p.act, p.slope);
+          L.o = p.out_bf16 ? ld4_bf16(p.out, oe) : ld4(p.out + oe);
         }
-        f32x4 dnh = dpre;
+        L.g1 = (f32x4)(1.f);
         if (p.g1p) {
           const size_t ge1 = pix * p.g_cs + p.g_co + g * 4;
-          dnh *= p.g1p_bf16 ? ld4_bf16(p.g1p, ge1) : ld4(p.g1p + ge1);
+          L.g1 = p.g1p_bf16 ? ld4_bf16(p.g1p, ge1) : ld4(p.g1p + ge1);
         }
+        return L;
+      };
+      auto finish = [&](int px, const In& L) {
+        const size_t pix = (size_t)n * HW + px;
+        f32x4 v = L.v;
+        if (p.z) v += L.zz * ns4;
+        const f32x4 nh = (v - mu) * rs;
+        f32x4 dpre = L.d;
+        if (p.act != HRV_ACT_NONE) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) dpre[e] *= dact(L.o[e], p.act, p.slope);
+        }
+        f32x4 dnh = dpre;
+        if (p.g1p) dnh *= L.g1;
         if (p.dnh_bf16) st4_bf16(p.dnh, pix * p.dn_cs + p.dn_co + g * 4, dnh);
         else *reinterpret_cast<f32x4*>(p.dnh + pix * p.dn_cs + p.dn_co + g * 4) = dnh;
         if (p.dgb) {
@@ -110,7 +128,14 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
         }
         s1 += dnh;
         s2 += dnh * nh;
+      };
+      int px = p0 + r;
+      for (; px + R < p1; px += 2 * R) {
+        const In A = load(px), B = load(px + R);
+        finish(px, A);
+        finish(px + R, B);
       }
+      if (px < p1) finish(px, load(px));
     }
     red[0][t] = s1;
     red[1][t] = s2;
@@ -180,27 +205,45 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
       const size_t sc = (size_t)n * C + g * 4;
       const f32x4 mu = ld4(p.mean + sc), rs = ld4(p.rstd + sc), a1 = ld4(p.m1 + sc), a2 = ld4(p.m2 + sc);
       const f32x4 ns4 = p.z ? ld4(p.ns + g * 4) : (f32x4)(0.f);
-      for (int px = p0 + r; px < p1; px += R) {
+      // two pixels per iteration, loads of both first (see stage 1); values and the order of the sum are unchanged
+      struct In { f32x4 v, dn, acc; float zz; };
+      auto load = [&](int px) {
+        In L;
         const size_t pix = (size_t)n * HW + px;
-        f32x4 v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
-        float zz = 0.f;
+        L.v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        L.zz = 0.f;
         if (p.z) {
           const int h = px / p.W, w = px - h * p.W;
-          zz = p.z[((size_t)n * p.W + w) * p.H + h];
-          v += zz * ns4;
+          L.zz = p.z[((size_t)n * p.W + w) * p.H + h];
         }
-        const f32x4 nh = (v - mu) * rs;
         const size_t de = pix * p.dn_cs + p.dn_co + g * 4;
-        f32x4 d = rs * ((p.dnh_bf16 ? ld4_bf16(p.dnh, de) : ld4(p.dnh + de)) - a1 - nh * a2);
-        sz += d * zz;
+        L.dn = p.dnh_bf16 ? ld4_bf16(p.dnh, de) : ld4(p.dnh + de);
+        L.acc = (f32x4)(0.f);
+        if (!p.dx_bf16 && p.accumulate) L.acc = ld4(p.dx + pix * p.dx_cs + p.dx_co + g * 4);
+        return L;
+      };
+      auto finish = [&](int px, const In& L) {
+        const size_t pix = (size_t)n * HW + px;
+        f32x4 v = L.v;
+        if (p.z) v += L.zz * ns4;
+        const f32x4 nh = (v - mu) * rs;
+        f32x4 d = rs * (L.dn - a1 - nh * a2);
+        sz += d * L.zz;
         if (p.dx_bf16) {
           st4_bf16(p.dx, pix * p.dx_cs + p.dx_co + g * 4, d);
         } else {
           float* o = p.dx + pix * p.dx_cs + p.dx_co + g * 4;
-          if (p.accumulate) d += ld4(o);
+          if (p.accumulate) d += L.acc;
           *reinterpret_cast<f32x4*>(o) = d;
         }
+      };
+      int px = p0 + r;
+      for (; px + R < p1; px += 2 * R) {
+        const In A = load(px), B = load(px + R);
+        finish(px, A);
+        finish(px + R, B);
       }
+      if (px < p1) finish(px, load(px));
     }
     if (p.z) {
       red[t] = sz;
