@@ -39,7 +39,7 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dx_accumulate", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
                 ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p),
                 ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32), ("dx_bf16", C.c_int32), ("g1p_bf16", C.c_int32),
-                ("dnh_bf16", C.c_int32), ("_pad_nb2", C.c_int32)]
+                ("dnh_bf16", C.c_int32), ("dout_bf16", C.c_int32)]
 
 
 class hrv_sn_job_t(C.Structure):

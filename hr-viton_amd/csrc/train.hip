@@ -46,6 +46,7 @@ struct NormBwdParams {
   int dgb_bf16, out_bf16;                    // storage of dgb / out: bf16 when only matrix cores (and this mask) read them
   int g1p_bf16;                              // (1 + gamma) stored as bf16 (the dedicated gamma|beta kernel writes it so)
   int dnh_bf16;                              // dnh (stage 1 -> stage 2) stored as bf16
+  int dout_bf16;                             // dout stored as bf16 (the data gradient of a bf16-stored SPADE output)
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -89,7 +90,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
           const int h = px / p.W, w = px - h * p.W;
           L.zz = p.z[((size_t)n * p.W + w) * p.H + h];
         }
-        L.d = ld4(p.dout + pix * p.do_cs + p.do_co + g * 4);
+        L.d = p.dout_bf16 ? ld4_bf16(p.dout, pix * p.do_cs + p.do_co + g * 4) : ld4(p.dout + pix * p.do_cs + p.do_co + g * 4);
         L.o = (f32x4)(0.f);
         if (p.act != HRV_ACT_NONE) {
           const size_t oe = pix * p.out_cs + p.out_co + g * 4;
@@ -900,7 +901,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   p.x = d->x; p.x_cs = d->x_cstride; p.x_co = d->x_coff; p.z = d->noise_z; p.ns = d->noise_scale;
   p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
   p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff; p.g1p_bf16 = d->g1p_bf16;
-  p.dout = d->dout; p.do_cs = d->dout_cstride; p.do_co = d->dout_coff;
+  p.dout = d->dout; p.do_cs = d->dout_cstride; p.do_co = d->dout_coff; p.dout_bf16 = d->dout_bf16;
   p.dnh = d->dnh; p.dn_cs = d->dnh_cstride; p.dn_co = d->dnh_coff; p.dnh_bf16 = d->dnh_bf16;
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;

@@ -461,14 +461,17 @@ class BlockT:
         dact_all = ops.alloc(x.N, x.H, x.W, hid * len(norms), x.t.device,
                              bf16=bool(T.MMA_BF16[0] and ctx["segx"].bf16 and x.W % 4 == 0))
         k0 = 1 if self.learned else 0          # slice order = norms(): [norm_s,] norm_0, norm_1
-        d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads)
+        # d(h): the gradient of a bf16-STORED SPADE output, read once by that norm's backward -- stored in bf16 as well
+        # (autocast hands the gradient of a half-precision convolution input back in half precision; HRV_DH_BF16=0: fp32)
+        dh16 = bool(T.MMA_BF16[0] and os.environ.get("HRV_DH_BF16", "1") != "0")
+        d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads, dx_bf16=dh16 and ctx["h1"].bf16)
         # d(conv_0 output) is read by conv_0's weight / data gradient only: bf16 when the mixed-precision plan stores
         # that level's matrix-core tensors in bf16
         d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid), dx_bf16=True)
-        d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads)
+        d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads, dx_bf16=dh16 and ctx["h0"].bf16)
         d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False, dact_all.slice(hid * k0, hid))
         if self.learned:
-            d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads)
+            d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads, dx_bf16=dh16 and ctx["hs"].bf16)
             self.ns_.backward(ctx["ns"], d_hs, grads, d_x, True, dact_all.slice(0, hid))
         else:
             T.add_slice(d_out, d_x, True)

@@ -570,6 +570,7 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
         d.g1p, d.g1p_cstride, d.g1p_coff = g1p.t.data_ptr(), g1p.cstride, g1p.coff
         d.g1p_bf16 = 1 if g1p.bf16 else 0
     d.dout, d.dout_cstride, d.dout_coff = dout.t.data_ptr(), dout.cstride, dout.coff
+    d.dout_bf16 = 1 if dout.bf16 else 0
     d.dnh, d.dnh_cstride, d.dnh_coff = dnh.data_ptr(), Cp, 0
     d.dnh_bf16 = 1 if dnh.dtype == torch.bfloat16 else 0
     if dgb is not None:

@@ -269,7 +269,8 @@ typedef struct hrv_norm_bwd {
                        *    that convolution's weight / data gradient (matrix cores) read                          */
   int32_t g1p_bf16;   /* 1: `g1p` is stored as bf16 (written by hrv_spade_gb_bf16; this kernel is its only reader) */
   int32_t dnh_bf16;   /* 1: the stage-1 -> stage-2 intermediate `dnh` is stored as bf16 (mixed precision: half its bytes) */
-  int32_t _pad_nb2;
+  int32_t dout_bf16;  /* 1: `dout` is stored as bf16 (mixed precision: the data gradient of a bf16-stored SPADE output, as
+                       * autocast hands the gradient of a half-precision convolution input back in half precision) */
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 
