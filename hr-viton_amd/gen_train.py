@@ -931,11 +931,7 @@ def discriminator_train_forward_pair(msd: nn.Module, parse7: Act, fake: torch.Te
         plan = msd._train_plan = MultiscaleDTrainPlan(msd)
     params = [p for p in msd.parameters()]
     nD = len(plan.plans)
-    if not torch.is_grad_enabled():
-        with torch.no_grad():
-            flat = list(_DiscPairFn.apply(msd, plan, parse7, fake, real, *params))
-    else:
-        flat = list(_DiscPairFn.apply(msd, plan, parse7, fake, real, *params))
+    flat = list(_DiscPairFn.apply(msd, plan, parse7, fake, real, *params))     # (under no_grad: no graph is recorded)
 
     def group(seq):
         per = len(seq) // nD
