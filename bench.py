@@ -271,8 +271,9 @@ def wl_generator(ctx, mixed, B, train):
         crit_vgg = VGGLoss(opt).to(dev)
         for m in (gen, dis, crit_vgg):
             broadcast_module(m)
-        og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9))
-        od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9))
+        graph = bool(ctx["args"].graph and world == 1)      # --graph: the whole iteration replayed as one hipGraph
+        og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9), device_step=graph)
+        od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9), device_step=graph)
         fake = int(os.environ.get("HRV_FAKE_ALLREDUCE", "0") or 0) > 0     # 1-GPU overlap trace (tools/dp_overlap.sh)
         sg = og.make_grad_sync() if (world > 1 or fake) else None
         sd = od.make_grad_sync() if (world > 1 or fake) else None
@@ -325,11 +326,16 @@ def wl_generator(ctx, mixed, B, train):
                                         "seconds_per_step_median": round(r["seconds_per_step_median"], 3),
                                         "sample": "1 image 256x192 'more' (BASELINE.md section 4), 1 warm-up + 3 timed, median",
                                         "scaled_to_1024x768_images_per_s": round(r["images_per_s"] / 16.0, 5)}}
-        return dict(step=step, B=B, train=True, parity=parity, cpu_baseline=cpu_baseline, flops_per_img=8.8e12,
+        timed = None
+        if graph:
+            from hr_viton_amd.graph import GraphedIteration
+            timed = (lambda gi: (lambda _i: gi()))(GraphedIteration(lambda: step(0), (og, od), warmup=3))
+        return dict(step=step, timed=timed, B=B, train=True, parity=parity, cpu_baseline=cpu_baseline, flops_per_img=8.8e12,
                     metric="1024x768 try-on images/sec (train_generator.py step: tocg+glue, G fwd/bwd, D fwd/bwd x2, VGG, Adam)",
                     workload="BASELINE configs[3] (SURVEY 8d config #4, headline): train_generator.py 1024x768, "
                              f"{B} img/GPU, " + ("--fp16 (bf16 MFMA operands, fp32 accumulate)" if mixed else "fp32") +
-                             ", SPADE ngf=64 'most' + multiscale-D + VGG/feat-match, random-init weights",
+                             ", SPADE ngf=64 'most' + multiscale-D + VGG/feat-match, random-init weights" +
+                             (" [whole iteration replayed as one hipGraph]" if graph else ""),
                     traffic_tag="train_generator")
     gen.eval()
 
@@ -471,7 +477,7 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0: the config's own)")
     ap.add_argument("--bf16", action="store_true", help="bf16 matrix cores (default for train_generator / tryon_infer)")
     ap.add_argument("--fp32", action="store_true", help="fp32 engine (default for tocg_infer / train_condition)")
-    ap.add_argument("--graph", action="store_true", help="tryon_infer: replay the step as one captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="tryon_infer / train_generator (1 GPU): replay the step as one captured hipGraph")
     args = ap.parse_args()
     mixed = (args.workload in ("train_generator", "tryon_infer") or args.bf16) and not args.fp32
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -164,6 +164,8 @@ SYMBOLS = {
     "hrv_maxpool2x2_bwd_relu_nhwc_bf16": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_add_slice_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _i32, _i32, _i64, _i32, _vp]),
     "hrv_adam_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i32, _f, _vp]),
+    "hrv_adam_hyper_f32": (C.c_int, [_vp, _vp, _f, _f, _vp, _vp]),
+    "hrv_adam_dev_f32": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _f, _vp]),
     "hrv_spectral_norm_f32": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _f, _vp, _vp, _vp]),
     "hrv_spectral_norm_bwd_f32": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp]),
     "hrv_spectral_norm_batched_f32": (C.c_int, [_vp, _i32, _i32, _f, _vp, _vp]),

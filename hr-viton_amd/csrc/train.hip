@@ -575,6 +575,37 @@ __global__ void adam_kernel(float* __restrict__ w, const float* __restrict__ g, 
   }
 }
 
+// The same update with its step-dependent scalars on the DEVICE (hipGraph-capturable training iteration: a replay must not
+// freeze the step count or the learning rate into the launch arguments).  adam_hyper_kernel: ++step; hyper = {lr, 1 - b1^t,
+// sqrt(1 - b2^t)} (the same expressions the host evaluates for hrv_adam_f32, here with the device's powf / sqrtf).
+__global__ void adam_hyper_kernel(int* __restrict__ step, const float* __restrict__ lr, float b1, float b2,
+                                  float* __restrict__ hyper) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    const int t = step[0] + 1;
+    step[0] = t;
+    hyper[0] = lr[0];
+    hyper[1] = 1.f - powf(b1, (float)t);
+    hyper[2] = sqrtf(1.f - powf(b2, (float)t));
+  }
+}
+
+__global__ void adam_dev_kernel(float* __restrict__ w, const float* __restrict__ g, float* __restrict__ m,
+                                float* __restrict__ v, size_t n, const float* __restrict__ hyper, float b1, float b2, float eps,
+                                float wd, float gscale) {
+  const float lr = hyper[0], bc1 = hyper[1], bc2_sqrt = hyper[2];
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float gi = g[i] * gscale;
+    const float wi = w[i];
+    if (wd != 0.f) gi += wd * wi;
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    w[i] = wi - (lr / bc1) * (mi / denom);
+  }
+}
+
 // ---------------------------------------------------------------------------
 // Spectral-norm power iteration GEMVs on W [R][K] (row-major):  y = W x  and  y = W^T x
 // (one block per row / per 64-column strip; fixed order => deterministic)
@@ -1059,6 +1090,21 @@ extern "C" int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (size_t)n, lr,
                      beta1, beta2, eps, weight_decay, bc1, bc2s, grad_scale);
   return check_launch("adam_kernel");
+}
+
+extern "C" int hrv_adam_hyper_f32(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev,
+                                  hrv_stream_t stream) {
+  HRV_REQUIRE(step_dev && lr_dev && hyper_dev, "adam_hyper: null pointer");
+  hipLaunchKernelGGL(adam_hyper_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, step_dev, lr_dev, beta1, beta2, hyper_dev);
+  return check_launch("adam_hyper_kernel");
+}
+
+extern "C" int hrv_adam_dev_f32(float* w, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1,
+                                float beta2, float eps, float weight_decay, float grad_scale, hrv_stream_t stream) {
+  HRV_REQUIRE(w && g && m && v && hyper_dev && n > 0, "adam_dev: bad args");
+  hipLaunchKernelGGL(adam_dev_kernel, dim3(grid_for((size_t)n)), dim3(256), 0, (hipStream_t)stream, w, g, m, v, (size_t)n, hyper_dev,
+                     beta1, beta2, eps, weight_decay, grad_scale);
+  return check_launch("adam_dev_kernel");
 }
 
 extern "C" int hrv_spectral_norm_f32(const float* w, int32_t R, int32_t K, float* u, float* v, int32_t power_iterations,

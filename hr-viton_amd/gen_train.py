@@ -518,7 +518,9 @@ class GeneratorTrainPlan:
         # one batched power iteration for every spectral-normalised convolution of the generator (four launches)
         # ... and one batched launch for the plan's weight packs (T.PackBatch)
         T.prepare_convs(self, [c for b in self.blocks for c in b.convs()] + list(self.stems) + [self.img] +
-                        [n_.shared for b in self.blocks for n_ in b.norms()], power_iteration, backward=save)
+                        [n_.shared for b in self.blocks for n_ in b.norms()], power_iteration, backward=save,
+                        extra_weights=[w_ for b in self.blocks for n_ in b.norms()
+                                       for w_ in (n_.norm.conv_gamma.weight.data, n_.norm.conv_beta.weight.data)])
         xin = ops.to_nhwc(x)
         # mixed precision: the full-resolution stem (conv_7: 9 -> 16 channels over every pixel) reads a bf16 copy of the
         # input (matrix-core operand only) so that it runs on the thin-convolution kernel

@@ -7,8 +7,9 @@ synchronises -- is recorded once into a hipGraph (``torch.cuda.CUDAGraph`` IS hi
 with one host call per step.  Inputs live in static device buffers that ``__call__`` refreshes; outputs are the
 static tensors the captured step produced (valid until the next replay).
 
-Only inference steps are captured: the training steps are GPU-bound (kernel time == wall time) and
-their optimizer/grad-sync control flow is host-driven."""
+``GraphedTrainStep`` captures a whole train_generator.py iteration the same way (single process: the data-parallel
+bucket all-reduces stay host-driven).  The iteration is GPU-bound (kernel time == wall time), so the replay is
+no faster than eager -- it exists so that the launch path is not on the critical path when a future kernel set is faster."""
 from __future__ import annotations
 
 from typing import Callable, Dict
@@ -65,3 +66,83 @@ def graphed_tryon(opt, tocg, generator, example_inputs: Dict[str, torch.Tensor],
 def graphed_condition(opt, tocg, input1: torch.Tensor, input2: torch.Tensor, warmup: int = 2) -> GraphedStep:
     """ConditionGenerator.forward (networks.py:98-159) as one hipGraph; call with {'input1':…, 'input2':…}."""
     return GraphedStep(lambda b: tocg(opt, b["input1"], b["input2"]), {"input1": input1, "input2": input2}, warmup)
+
+
+class GraphedIteration:
+    """``fn()`` -- a whole training iteration over STATIC device buffers, optimizer steps included -- as one hipGraph.
+    ``optimizers``: hr_viton_amd.optim.Adam instances built with ``device_step=True`` (their learning rates are pushed to
+    the device before every replay)."""
+
+    def __init__(self, fn: Callable[[], object], optimizers, warmup: int = 3):
+        _lib.load()
+        for o in optimizers:
+            if not getattr(o, "device_step", False):
+                raise HrvError("GraphedIteration: build the optimizers with hr_viton_amd.optim.Adam(..., device_step=True)")
+            if getattr(o, "grad_sync", None) is not None:
+                raise HrvError("GraphedIteration: data-parallel gradient synchronisation is host-driven; single process only")
+        self.optimizers = list(optimizers)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(1, warmup)):          # eager iterations: plans, pack records, flat buffers, device scalars
+                fn()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.warmup_iterations = max(1, warmup)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.static_out = fn()
+        self.replays = 0
+
+    def __call__(self):
+        for o in self.optimizers:
+            o.push_lr()
+        self.graph.replay()
+        self.replays += 1
+        return self.static_out
+
+
+class GraphedTrainStep:
+    """One train_generator.py iteration (pipeline.generator_train_step: G step + D step, both Adam updates) as one hipGraph.
+
+    Requirements, checked here: both optimizers were built with ``device_step=True`` (step count and learning rate on the
+    device -- a replay must not freeze them); no GradSync (single process).  ``inputs``: {'x': [N,9,H,W], 'parse7': the
+    label-map activation tensor [N,H,W,8], 'im': [N,3,H,W]} -- static buffers refreshed by ``__call__``.  SPADE noise is
+    drawn inside the captured region (torch's graph-safe Philox) unless ``noise`` / ``noise_d`` plane dicts are given
+    (then they are static inputs too).  Losses come back as the static tensors of the capture."""
+
+    def __init__(self, opt, generator, discriminator, crit_gan, crit_feat, crit_vgg, opt_g, opt_d, inputs: Dict[str, torch.Tensor],
+                 noise=None, noise_d=None, warmup: int = 3):
+        from .ops import Act
+        from .pipeline import generator_train_step
+        _lib.load()
+        for o in (opt_g, opt_d):
+            if not getattr(o, "device_step", False):
+                raise HrvError("GraphedTrainStep: build the optimizers with hr_viton_amd.optim.Adam(..., device_step=True)")
+            if getattr(o, "grad_sync", None) is not None:
+                raise HrvError("GraphedTrainStep: data-parallel gradient synchronisation is host-driven; single process only")
+        self.opt_g, self.opt_d = opt_g, opt_d
+        self.static_in = {k: v.clone() for k, v in inputs.items()}
+        self.noise = None if noise is None else {k: [z.clone() for z in v] for k, v in noise.items()}
+        self.noise_d = None if noise_d is None else {k: [z.clone() for z in v] for k, v in noise_d.items()}
+
+        def body():
+            b = self.static_in
+            return generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, crit_vgg, opt_g, opt_d, b["x"],
+                                        Act(b["parse7"], 7), b["im"], noise=self.noise, noise_d=self.noise_d)
+        self._it = GraphedIteration(body, (opt_g, opt_d), warmup)
+        self.graph, self.static_out = self._it.graph, self._it.static_out
+        self.replays = 0
+
+    def __call__(self, inputs: Dict[str, torch.Tensor] = None):
+        if inputs is not None:
+            for k, dst in self.static_in.items():
+                src = inputs[k]
+                if src.shape != dst.shape or src.dtype != dst.dtype:
+                    raise HrvError(f"GraphedTrainStep: input '{k}' is {tuple(src.shape)}/{src.dtype}, captured with "
+                                   f"{tuple(dst.shape)}/{dst.dtype}")
+                if src.data_ptr() != dst.data_ptr():
+                    dst.copy_(src, non_blocking=True)
+        out = self._it()
+        self.replays += 1
+        return out

@@ -40,11 +40,23 @@ def _flat_order(ps):
 
 
 class Adam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None):
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, grad_sync=None, device_step=False):
+        """``device_step``: the step count and the learning rate live on the device (hrv_adam_hyper_f32 / _dev_f32), so a
+        hipGraph-captured iteration (graph.GraphedTrainStep) keeps counting and follows the scheduler; every parameter must
+        then receive a gradient in every iteration."""
         defaults = dict(lr=lr, betas=(float(betas[0]), float(betas[1])), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         self.grad_sync = grad_sync
         self._flat = {}
+        self.device_step = bool(device_step)
+
+    def push_lr(self):
+        """device_step: copy each group's current learning rate to its device scalar (call BEFORE replaying a captured
+        iteration; an eager step() does it itself)."""
+        for gi, group in enumerate(self.param_groups):
+            st = self._flat.get(gi)
+            if st is not None and "lr_dev" in st:
+                st["lr_dev"].fill_(float(group["lr"]))
 
     def _setup(self, gi, group):
         ps = _flat_order([p for p in group["params"] if p.requires_grad])
@@ -114,6 +126,18 @@ class Adam(torch.optim.Optimizer):
                         g[off:off + k].copy_(src.reshape(-1))
             st["step"] += 1
             b1, b2 = group["betas"]
+            if self.device_step:
+                assert not skipped, "device_step Adam: every parameter needs a gradient in every iteration"
+                if "step_dev" not in st:
+                    dev = g.device
+                    st["step_dev"] = torch.full((1,), st["step"] - 1, dtype=torch.int32, device=dev)
+                    st["lr_dev"] = torch.full((1,), float(group["lr"]), dtype=torch.float32, device=dev)
+                    st["hyper"] = torch.zeros(3, dtype=torch.float32, device=dev)
+                if not torch.cuda.is_current_stream_capturing():
+                    st["lr_dev"].fill_(float(group["lr"]))       # (a captured iteration reads what push_lr() wrote)
+                T.adam_step_dev(st["w"], g, st["m"], st["v"], st["step_dev"], st["lr_dev"], st["hyper"], b1, b2, group["eps"],
+                                group["weight_decay"], world_scale)
+                continue
             # one launch per run of consecutive spans that share a step count (a skipped span rides along with either
             # neighbour: it is restored afterwards) -- ONE launch over the whole buffer unless some parameter fell behind
             runs, n_sp = [], len(st["spans"])
@@ -158,7 +182,8 @@ class Adam(torch.optim.Optimizer):
             for p in group["params"]:
                 if st and id(p) in spans:
                     off, k = spans[id(p)]
-                    state[idx] = {"step": torch.tensor(float(st["steps"][pos[id(p)]])),
+                    stp = int(st["step_dev"].item()) if "step_dev" in st else st["steps"][pos[id(p)]]
+                    state[idx] = {"step": torch.tensor(float(stp)),
                                   "exp_avg": st["m"][off:off + k].view_as(p).clone(),
                                   "exp_avg_sq": st["v"][off:off + k].view_as(p).clone()}
                 ids.append(idx)

@@ -64,6 +64,14 @@ class PackBatch:
         self.bwd_fresh = False           # ... which also packed group 1
         self.launches = 0
 
+    def reset(self):
+        """Forget every record (the weights moved: e.g. the fused optimizer re-pointed the parameters into its flat buffer
+        at its first step -- records made before that hold addresses of freed storages)."""
+        self.index.clear()
+        self.bufs, self.geoms, self.blocks, self.records, self.group = [], [], [], [], []
+        self.tables = [None, None]
+        self.dirty, self.stamp, self.bwd_fresh = False, None, False
+
     @staticmethod
     def _now():
         return (ops.WEIGHTS_EPOCH[0], ops.LOAD_EPOCH[0])
@@ -682,6 +690,17 @@ def adam_step(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor
                                     weight_decay, step, grad_scale, _stream()), "hrv_adam_f32")
 
 
+def adam_step_dev(w: torch.Tensor, g: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step_dev: torch.Tensor, lr_dev: torch.Tensor,
+                  hyper: torch.Tensor, beta1: float, beta2: float, eps: float, weight_decay: float, grad_scale: float = 1.0):
+    """adam_step with the step count (int32 [1]) and the learning rate (float [1]) on the device: capturable in a hipGraph."""
+    lib = _lib.load()
+    _lib.check(lib.hrv_adam_hyper_f32(step_dev.data_ptr(), lr_dev.data_ptr(), beta1, beta2, hyper.data_ptr(), _stream()),
+               "hrv_adam_hyper_f32")
+    with _Timed("adam", "adam_f32", 0.0, 28.0 * w.numel()):
+        _lib.check(lib.hrv_adam_dev_f32(w.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), w.numel(), hyper.data_ptr(), beta1,
+                                        beta2, eps, weight_decay, grad_scale, _stream()), "hrv_adam_dev_f32")
+
+
 def spectral_sigma(w_orig: torch.Tensor, u: torch.Tensor, v: torch.Tensor, power_iterations: int,
                    eps: float = 1e-12) -> torch.Tensor:
     """In-place power iteration on (u, v) + sigma (device scalar tensor [1])."""
@@ -732,7 +751,7 @@ class SpectralBatch:
         return sig.split(1), ub.split(self.Rs), vb.split(self.Ks)
 
 
-def prepare_convs(owner, convs, power_iteration: bool, backward: bool = True):
+def prepare_convs(owner, convs, power_iteration: bool, backward: bool = True, extra_weights: Sequence[torch.Tensor] = ()):
     """TConv.prepare for every spectral-normalised convolution of ``convs`` at once (``owner`` caches the batch), then
     the plan's recorded weight packs in one launch (PackBatch, handed to every conv as ``pack_batch``; ``backward`` False:
     a no_grad forward, the data-gradient packs are left alone)."""
@@ -745,6 +764,16 @@ def prepare_convs(owner, convs, power_iteration: bool, backward: bool = True):
         pb = owner._pack_batch = PackBatch(dev)
     for c in convs:
         c.pack_batch = pb
+    # the records hold raw addresses of the weights: when any weight of the plan lives somewhere else than at the last
+    # forward (the fused optimizer moves every parameter into its flat buffer at its FIRST step; load_state_dict on a
+    # re-created module; .to(device)), the old records would keep packing from freed storages -- garbage into buffers nobody
+    # reads in eager mode, an illegal access once the allocator has returned those storages to the driver (found by replaying
+    # a captured iteration: torch.cuda.graph empties the cache before it captures)
+    where = tuple(c.wparam.data.data_ptr() for c in convs) + tuple(w.data_ptr() for w in extra_weights)
+    if getattr(pb, "where", None) != where:
+        if pb.bufs:
+            pb.reset()
+        pb.where = where
     # (while a hipGraph is being captured the record table cannot be re-uploaded: a plan that still has unrecorded packs
     #  then packs one by one, which captures fine)
     if PACK_BATCHING[0] and not (pb.dirty and torch.cuda.is_current_stream_capturing()):

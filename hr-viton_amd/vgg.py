@@ -114,6 +114,11 @@ class Vgg19(nn.Module):
         """Taps of the (detached, networks.py:250) target.  train_condition.py calls the criterion five times
         per iteration with the SAME target tensor (:185,248): its features are computed once and reused while
         the identical tensor object (same storage, same version counter) keeps being passed."""
+        if torch.cuda.is_current_stream_capturing():
+            # a captured iteration is replayed on NEW targets in the same static buffer: the cache (keyed on the tensor
+            # object and its version counter, which a replay never touches) must not elide the forward from the graph
+            ty, _ = self.features(ops.to_nhwc(y), save=False, x_bf16=ops.to_nhwc(y, bf16=True) if T.MMA_BF16[0] else None)
+            return ty
         c = getattr(self, "_ycache", None)
         # (engine mode: the taps are stored in bf16 in mixed precision; LOAD_EPOCH: writes torch's _version does not show)
         key = (y.data_ptr(), y._version, tuple(y.shape), ops.WEIGHTS_EPOCH[0], bool(T.MMA_BF16[0]), ops.LOAD_EPOCH[0])

@@ -344,6 +344,12 @@ int hrv_maxpool2x2_bwd_relu_nhwc_xbf16(const uint16_t* x, const float* dy, int32
  * g is multiplied by grad_scale first (1/world_size after a sum all-reduce). */
 int hrv_adam_f32(float* w, const float* g, float* m, float* v, int64_t n, float lr, float beta1, float beta2, float eps,
                  float weight_decay, int32_t step, float grad_scale, hrv_stream_t stream);
+/* The same update with its step-dependent scalars on the device, for a hipGraph-captured training iteration (a replay must
+ * not freeze the step count or the learning rate into launch arguments): hrv_adam_hyper_f32 increments step_dev[0] and
+ * writes hyper_dev[3] = {lr_dev[0], 1 - beta1^t, sqrt(1 - beta2^t)}; hrv_adam_dev_f32 reads them. */
+int hrv_adam_hyper_f32(int32_t* step_dev, const float* lr_dev, float beta1, float beta2, float* hyper_dev, hrv_stream_t stream);
+int hrv_adam_dev_f32(float* w, const float* g, float* m, float* v, int64_t n, const float* hyper_dev, float beta1, float beta2,
+                     float eps, float weight_decay, float grad_scale, hrv_stream_t stream);
 /* torch spectral_norm (SpectralNorm.compute_weight): `power_iterations` rounds of
  * v<-normalize(W^T u), u<-normalize(W v) in place (eps 1e-12), then sigma = u.(W v).
  * W is [R][K] = weight_orig.reshape(Cout,-1); wv_scratch holds R floats.

@@ -354,10 +354,11 @@ def test_second_generator_iteration_on_the_flat_gradient_path():
 
 @pytest.mark.parametrize("mixed", [False, True], ids=["fp32", "bf16"])
 def test_batched_weight_packs_leave_the_iteration_bit_identical(mixed):
-    """T.PackBatch: from the second iteration on every recorded weight pack of a plan comes from ONE
-    hrv_conv2d_pack_weight_multi launch at the top of its forward.  Three iterations (same inputs, same injected SPADE
+    """T.PackBatch: from the third iteration on every recorded weight pack of a plan comes from ONE
+    hrv_conv2d_pack_weight_multi launch at the top of its forward.  Four iterations (same inputs, same injected SPADE
     noise) with and without batching end in bit-identical generator and discriminator weights, and the batched run did
-    serve its convolutions from the batch (records exist, the multi launch ran once per plan forward)."""
+    serve its convolutions from the batch (records exist, the multi launch ran once per plan forward).  Four iterations:
+    the first records packs of parameters that the fused optimizer then MOVES (flat buffers) -- those records are dropped."""
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd import gen_train, ops, pipeline
     from hr_viton_amd import train_ops as T
@@ -376,11 +377,17 @@ def test_batched_weight_packs_leave_the_iteration_bit_identical(mixed):
         old, oldm = T.PACK_BATCHING[0], T.MMA_BF16[0]
         T.PACK_BATCHING[0], T.MMA_BF16[0] = batching, mixed
         try:
-            for _ in range(3):
+            counts = []
+            for _ in range(4):
                 nz = [gen_train.noise_planes(gen, x.shape[0], torch.randn(gen_train.noise_elems(gen, x.shape[0]), generator=g))
                       for _ in range(2)]
                 pipeline.generator_train_step(opt, gen, D, GANLoss("hinge"), L1Loss(), None, og, od, xc, parse7, realc,
                                               noise=nz[0], noise_d=nz[1])
+                counts.append(tuple(len(p._pack_batch.bufs) for p in (gen._train_plan, D._train_plan)
+                                    if getattr(p, "_pack_batch", None) is not None))
+            # the fused optimizers move every parameter into their flat buffers at their first step: the records made
+            # before that are dropped (they hold addresses of freed storages), and the set is stable afterwards
+            assert counts[2] == counts[3], counts
         finally:
             T.PACK_BATCHING[0], T.MMA_BF16[0] = old, oldm
         torch.cuda.synchronize()
@@ -392,7 +399,7 @@ def test_batched_weight_packs_leave_the_iteration_bit_identical(mixed):
 
     a, sa = run(True)
     b, sb = run(False)
-    assert len(sa) == 2 and all(n > 4 and launches >= 5 for n, launches in sa), sa       # 2 forwards x 3 iterations each
+    assert len(sa) == 2 and all(n > 4 and launches >= 5 for n, launches in sa), sa       # from the third iteration on
     assert all(n == 0 for n, _ in sb), sb
     for k in a:
         assert torch.equal(a[k], b[k]), k
@@ -444,3 +451,71 @@ def test_discriminator_pair_form_equals_the_concatenated_batch_form(which):
             assert (p.grad is None) == (q.grad is None), n
             if p.grad is not None:
                 assert torch.equal(p.grad, q.grad), n
+
+
+def test_graphed_training_iteration_is_bit_identical_to_eager():
+    """graph.GraphedTrainStep: one train_generator.py iteration (G step, D step, VGG + feature-matching + hinge losses, both
+    fused Adam updates with step count and learning rate on the device) captured as ONE hipGraph.  Three eager warm-up
+    iterations + two replays end in bit-identical generator / discriminator weights, optimizer moments and step counts as
+    five eager iterations from the same start -- including a learning-rate change between the replays (the scheduler's
+    value reaches the captured iteration through push_lr) and the VGG target features (recomputed inside the graph)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import gen_train, ops, pipeline
+    from hr_viton_amd.graph import GraphedTrainStep
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    from hr_viton_amd.optim import Adam
+    from hr_viton_amd.vgg import VGGLoss
+
+    def build():
+        opt, gen, D, x, seg, real, noise = _setup(seed=31, wmul=6.0)          # 2 x 256 x 128
+        opt.lambda_feat, opt.lambda_vgg, opt.no_vgg_loss = 10.0, 10.0, False
+        gen.cuda().train()
+        D.cuda().train()
+        torch.manual_seed(77)
+        vgg = VGGLoss(opt).cuda()
+        og = Adam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9), device_step=True)
+        od = Adam(D.parameters(), lr=2e-3, betas=(0.0, 0.9), device_step=True)
+        g = torch.Generator().manual_seed(5)
+        n_el = gen_train.noise_elems(gen, x.shape[0])
+        nz = [gen_train.noise_planes(gen, x.shape[0], torch.randn(n_el, generator=g).cuda()) for _ in range(2)]
+        inputs = {"x": x.cuda(), "parse7": ops.to_nhwc(seg.cuda()).t, "im": real.cuda()}
+        return opt, gen, D, vgg, og, od, inputs, nz
+
+    def lr_at(it, o, base):
+        for grp in o.param_groups:
+            grp["lr"] = base * (0.5 if it >= 4 else 1.0)
+
+    def snapshot(gen, D, og, od):
+        torch.cuda.synchronize()
+        sd = {"G." + k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+        sd.update({"D." + k: v.detach().cpu().clone() for k, v in D.state_dict().items()})
+        for tag, o in (("og", og), ("od", od)):
+            st = o._flat[0]
+            sd[tag + ".m"], sd[tag + ".v"] = st["m"].detach().cpu().clone(), st["v"].detach().cpu().clone()
+            sd[tag + ".step"] = st["step_dev"].detach().cpu().clone()
+        return sd
+
+    # ---- eager: five iterations
+    opt, gen, D, vgg, og, od, inputs, nz = build()
+    cg, cf = GANLoss("hinge"), L1Loss()
+    for it in range(5):
+        lr_at(it, og, 1e-3)
+        lr_at(it, od, 2e-3)
+        losses_e, _ = pipeline.generator_train_step(opt, gen, D, cg, cf, vgg, og, od, inputs["x"], ops.Act(inputs["parse7"], 7),
+                                                    inputs["im"], noise=nz[0], noise_d=nz[1])
+    want = snapshot(gen, D, og, od)
+    want_losses = {k: float(v) for k, v in losses_e.items()}
+    # ---- graph: three eager warm-up iterations inside the constructor, then two replays
+    opt, gen, D, vgg, og, od, inputs, nz = build()
+    gs = GraphedTrainStep(opt, gen, D, GANLoss("hinge"), L1Loss(), vgg, og, od, inputs, noise=nz[0], noise_d=nz[1], warmup=3)
+    for it in (3, 4):
+        lr_at(it, og, 1e-3)
+        lr_at(it, od, 2e-3)
+        losses_g, _ = gs(inputs)
+    got = snapshot(gen, D, og, od)
+    assert gs.replays == 2 and int(got["og.step"]) == 5 and int(got["od.step"]) == 5
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    for k, v in want_losses.items():
+        assert float(losses_g[k]) == v, (k, float(losses_g[k]), v)
+    assert int(og.state_dict()["state"][0]["step"]) == 5
