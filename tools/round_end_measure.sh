@@ -17,6 +17,7 @@ cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/
 timeout 1200 python bench.py --dump-launches $OUT/launches_default.txt 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 cut -c1-300 $OUT/bench_default.json
 b() { name=$1; shift; timeout 400 python bench.py "$@" --no-cpu-baseline --no-extras --dump-launches $OUT/launches_$name.txt 2>$OUT/$name.err | tail -1 > $OUT/$name.json; cut -c1-200 $OUT/$name.json; }
+b train_generator_bf16_graph --workload train_generator --graph --steps 8 --warmup 3
 b train_generator_f32 --workload train_generator --fp32 --steps 3 --warmup 2
 b train_condition_f32 --workload train_condition --steps 3 --warmup 1
 b train_condition_bf16 --workload train_condition --bf16 --steps 3 --warmup 2
