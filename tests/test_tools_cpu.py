@@ -71,3 +71,45 @@ def test_flat_buffer_order_puts_gradient_mates_next_to_each_other():
     order = [names[[id(q) for q in n.parameters()].index(id(p))] for p in _flat_order(list(n.parameters()))]
     assert order.index("conv_beta.weight") == order.index("conv_gamma.weight") + 1
     assert order.index("conv_beta.bias") == order.index("conv_gamma.bias") + 1
+
+
+def test_per_iteration_launch_table_is_the_difference_of_two_traces(tmp_path):
+    """tools/rocprof_per_step.py: calls and time per iteration = (trace B - trace A) / (steps B - steps A); set-up kernels
+    (same count in both traces) cancel, kernels that only appear in the longer trace are counted from zero."""
+    import subprocess
+    import sys
+    a = tmp_path / "a.txt"
+    b = tmp_path / "b.txt"
+    a.write_text("# rocprofv3 summary\n  calls   total_ms     avg_us    pct  kernel\n"
+                 "     20     10.000     500.00  50.00  void hrv::conv(hrv::P)\n"
+                 "    100      1.000      10.00   5.00  setup_copy\n")
+    b.write_text("# rocprofv3 summary\n  calls   total_ms     avg_us    pct  kernel\n"
+                 "     60     30.000     500.00  50.00  void hrv::conv(hrv::P)\n"
+                 "    100      1.000      10.00   5.00  setup_copy\n"
+                 "      8      0.400      50.00   1.00  late_kernel\n")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rocprof_per_step.py"), str(a), "2", str(b), "6"],
+                         capture_output=True, text=True, check=True).stdout
+    lines = [l for l in out.splitlines() if l and not l.startswith("#")]
+    assert out.splitlines()[0].startswith("# per training iteration: 12.0 kernel launches, 5.100 ms")
+    assert lines[0].split()[:2] == ["10.0", "5.000"] and "hrv::conv" in lines[0]
+    assert lines[1].split()[:2] == ["2.0", "0.100"] and "late_kernel" in lines[1]
+    assert not any("setup_copy" in l for l in lines)
+
+
+def test_committed_traffic_file_carries_the_whole_iteration_total():
+    """profiles/r03_pmc_traffic_train_generator.json (tools/traffic_json.py): per-kernel-family bytes and the all-kernels total
+    of the two PMC passes; the dominant kernel's bytes per iteration are what bench.py's roofline.traffic divides by its
+    launch count; the families sum to less than the whole."""
+    import json
+    with open(os.path.join(ROOT, "profiles", "r03_pmc_traffic_train_generator.json")) as f:
+        j = json.load(f)
+    allk, fam = j["all_kernels"], j["per_kernel_family"]
+    assert abs(allk["hbm_bytes_whole_run"] - (2.0 * allk["fetch_KiB_raw"] + allk["write_KiB"]) * 1024.0) < 1.0
+    assert abs(allk["hbm_bytes_per_step"] - allk["hbm_bytes_whole_run"] / j["steps_in_the_profiled_run"]) < 1.0
+    assert 150e9 < allk["hbm_bytes_per_step"] < 300e9                      # measured 244 GB (round 2: 315)
+    assert sum(v["hbm_bytes_per_step"] for v in fam.values()) < allk["hbm_bytes_per_step"]
+    gb = fam["spade_gb_kernel"]
+    assert gb["dispatches"] % j["steps_in_the_profiled_run"] == 0
+    with open(os.path.join(ROOT, "profiles", "r03_final_bench_default.json")) as f:
+        r = json.load(f)["roofline"]
+    assert abs(r["traffic"] - gb["hbm_bytes_per_step"] / r["launches_per_step"]) < 1e-6 * r["traffic"]
