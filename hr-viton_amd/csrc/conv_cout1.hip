@@ -89,82 +89,117 @@ __global__ __launch_bounds__(256) void cout1_fwd_kernel(const Cout1Params p) {
   }
 }
 
-// data gradient: dx[n][h][w][c] = sum_{kh,kw} dy[n][h - kh + pad][w - kw + pad] * w[c][kh][kw]  (+ add): one wave per pixel
+// The K rows of dY one INPUT row (n, h) sees, zero-padded, in LDS:  dyl[kh][K + wo] = dY[n][h - kh + pad][wo]  (0 outside).
+// A tap (kh, kw) of input pixel w then reads dyl[kh][K + w - kw + pad] -- no bounds checks in the inner loops.
+__device__ __forceinline__ void c1_stage_dy(const Cout1Params& p, int n, int h, float* dyl, int LW) {
+  for (int idx = threadIdx.x; idx < p.K * LW; idx += 256) {
+    const int kh = idx / LW, wo = idx - kh * LW - p.K;
+    const int ho = h - kh + p.pad;
+    float v = 0.f;
+    if (wo >= 0 && wo < p.Wo && ho >= 0 && ho < p.Ho)
+      v = c1_rb(p.y[(((size_t)n * p.Ho + ho) * p.Wo + wo) * p.ycs + p.yco], p.round_bf16);
+    dyl[idx] = v;
+  }
+}
+
+// data gradient: dx[n][h][w][c] = sum_{kh,kw} dy[n][h - kh + pad][w - kw + pad] * w[c][kh][kw]  (+ add).  One block per
+// input row; weights [K*K][C] and the dY rows in LDS; a wave per pixel, a lane per 4 channels (x channel groups of 256).
+// (First build: one wave per pixel with its 16 dY values fetched from global memory one after the other -- 0.099 ms at
+// 2 x 4 x 130 x 98 x 256, no faster than the padded matrix-core path.)
 __global__ __launch_bounds__(256) void cout1_dgrad_kernel(const Cout1Params p) {
-  extern __shared__ float wl[];                     // [K*K][C]
-  const int KK = p.K * p.K;
+  extern __shared__ float smem[];
+  const int KK = p.K * p.K, LW = p.Wo + 2 * p.K;
+  float* const wl = smem;                           // [K*K][C]
+  float* const dyl = smem + KK * p.C;               // [K][LW]
   const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
   for (int i = threadIdx.x; i < KK * p.C; i += 256) {
     const int tap = i / p.C, c = i - tap * p.C;
     wl[i] = c1_rb(p.w[(size_t)c * KK + tap] * mul, p.round_bf16);
   }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const size_t total = (size_t)p.N * p.H * p.W;
-  for (size_t px = (size_t)blockIdx.x * 4 + wave; px < total; px += (size_t)gridDim.x * 4) {
-    const int w_ = (int)(px % p.W);
-    const size_t t = px / p.W;
-    const int h = (int)(t % p.H), n = (int)(t / p.H);
-    float g[16];                                    // the K*K (<= 16) output-gradient values this pixel sees
+  for (int row = blockIdx.x; row < p.N * p.H; row += gridDim.x) {
+    const int n = row / p.H, h = row - n * p.H;
+    __syncthreads();                                // (weights staged / previous row's dyl fully read)
+    c1_stage_dy(p, n, h, dyl, LW);
+    __syncthreads();
+    for (int w_ = wave; w_ < p.W; w_ += 4) {
+      const size_t px = (size_t)row * p.W + w_;
+      float g[4][4];
 #pragma unroll
-    for (int tap = 0; tap < 16; ++tap) {
-      const int kh = tap / p.K, kw = tap - kh * p.K;
-      const int ho = h - kh + p.pad, wo = w_ - kw + p.pad;
-      float v = 0.f;
-      if (tap < KK && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo)
-        v = c1_rb(p.y[(((size_t)n * p.Ho + ho) * p.Wo + wo) * p.ycs + p.yco], p.round_bf16);
-      g[tap] = v;
-    }
-    for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
-      float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+      for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-      for (int tap = 0; tap < 16; ++tap)
-        if (tap < KK) {
-          const float4 wv = *reinterpret_cast<const float4*>(wl + (size_t)tap * p.C + c0);
-          acc.x += g[tap] * wv.x; acc.y += g[tap] * wv.y; acc.z += g[tap] * wv.z; acc.w += g[tap] * wv.w;
+        for (int kw = 0; kw < 4; ++kw)
+          g[kh][kw] = (kh < p.K && kw < p.K) ? dyl[kh * LW + p.K + w_ - kw + p.pad] : 0.f;
+      for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+          for (int kw = 0; kw < 4; ++kw)
+            if (kh < p.K && kw < p.K) {
+              const float4 wv = *reinterpret_cast<const float4*>(wl + (size_t)(kh * p.K + kw) * p.C + c0);
+              acc.x += g[kh][kw] * wv.x; acc.y += g[kh][kw] * wv.y; acc.z += g[kh][kw] * wv.z; acc.w += g[kh][kw] * wv.w;
+            }
+        if (p.add) {
+          const float4 a = *reinterpret_cast<const float4*>(p.add + px * p.acs + p.aco + c0);
+          acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
         }
-      if (p.add) {
-        const float4 a = *reinterpret_cast<const float4*>(p.add + px * p.acs + p.aco + c0);
-        acc.x += a.x; acc.y += a.y; acc.z += a.z; acc.w += a.w;
+        *reinterpret_cast<float4*>(p.dx + px * p.dcs + p.dco + c0) = acc;
       }
-      *reinterpret_cast<float4*>(p.dx + px * p.dcs + p.dco + c0) = acc;
     }
   }
 }
 
-// weight gradient partials: block s walks a slab of the EXTENDED pixel grid (n, h < Ho, w < Wo); thread = channel.
-//   dw[c][kh][kw] += x[n][h][w][c] * dy[n][h - kh + pad][w - kw + pad]   (h < H, w < W),   dbias += dy[n][h][w]
+// weight gradient partials: one block per input row (n, h), thread = channel; the dY rows in LDS (broadcast reads).
+//   part[row][c][kh][kw] = sum_w x[n][h][w][c] * dY[n][h - kh + pad][w - kw + pad],   part[row][C*K*K] = sum of dY row h
+//   (+ the rows below the image, h = H-1 only): the bias gradient.
+// (First build: a slab walk with 16 bounds-checked global dY loads per pixel and thread: 0.72 ms against the engine's 0.19.)
 __global__ __launch_bounds__(256) void cout1_wgrad_kernel(const Cout1Params p) {
-  const int KK = p.K * p.K;
+  extern __shared__ float smem[];
+  __shared__ float red[4];
+  const int KK = p.K * p.K, LW = p.Wo + 2 * p.K;
+  float* const dyl = smem;                          // [K][LW]
+  const int row = blockIdx.x, n = row / p.H, h = row - n * p.H;
   const int c = blockIdx.y * 256 + threadIdx.x;
-  const size_t total = (size_t)p.N * p.Ho * p.Wo;
-  const size_t per = (total + p.S - 1) / p.S;
-  const size_t p0 = (size_t)blockIdx.x * per, p1 = p0 + per < total ? p0 + per : total;
-  float acc[16];
+  c1_stage_dy(p, n, h, dyl, LW);
+  __syncthreads();
+  float acc[4][4];
 #pragma unroll
-  for (int tap = 0; tap < 16; ++tap) acc[tap] = 0.f;
-  float bsum = 0.f;
-  for (size_t e = p0; e < p1; ++e) {
-    const int w_ = (int)(e % p.Wo);
-    const size_t t = e / p.Wo;
-    const int h = (int)(t % p.Ho), n = (int)(t / p.Ho);
-    const float* dyn = p.y + (size_t)n * p.Ho * p.Wo * p.ycs + p.yco;
-    bsum += dyn[((size_t)h * p.Wo + w_) * p.ycs];
-    if (h < p.H && w_ < p.W && c < p.C) {
-      const float xv = c1_rb(p.x[(((size_t)n * p.H + h) * p.W + w_) * p.xcs + p.xco + c], p.round_bf16);
+  for (int kh = 0; kh < 4; ++kh)
 #pragma unroll
-      for (int tap = 0; tap < 16; ++tap) {
-        const int kh = tap / p.K, kw = tap - kh * p.K;
-        const int ho = h - kh + p.pad, wo = w_ - kw + p.pad;
-        if (tap < KK && ho >= 0 && ho < p.Ho && wo >= 0 && wo < p.Wo)
-          acc[tap] += xv * c1_rb(dyn[((size_t)ho * p.Wo + wo) * p.ycs], p.round_bf16);
-      }
+    for (int kw = 0; kw < 4; ++kw) acc[kh][kw] = 0.f;
+  if (c < p.C) {
+    const float* xrow = p.x + ((size_t)row * p.W) * p.xcs + p.xco + c;
+#pragma unroll 4
+    for (int w_ = 0; w_ < p.W; ++w_) {
+      const float xv = c1_rb(xrow[(size_t)w_ * p.xcs], p.round_bf16);
+      const float* dq = dyl + p.K + w_ + p.pad;
+#pragma unroll
+      for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw)
+          if (kh < p.K && kw < p.K) acc[kh][kw] += xv * dq[kh * LW - kw];
     }
   }
-  float* dst = p.part + (size_t)blockIdx.x * (p.C * KK + 1);
-  if (c < p.C)
-    for (int tap = 0; tap < KK; ++tap) dst[c * KK + tap] = acc[tap];
-  if (c == 0) dst[p.C * KK] = bsum;
+  float* dst = p.part + (size_t)row * (p.C * KK + 1);
+  if (c < p.C) {
+#pragma unroll
+    for (int kh = 0; kh < 4; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 4; ++kw)
+        if (kh < p.K && kw < p.K) dst[c * KK + kh * p.K + kw] = acc[kh][kw];
+  }
+  if (blockIdx.y == 0) {                            // bias partial: the UNROUNDED dY of output row h (and of the rows >= H)
+    float bs = 0.f;
+    const int ho_end = h == p.H - 1 ? p.Ho : h + 1;
+    for (int ho = h; ho < ho_end; ++ho)
+      for (int wo = threadIdx.x; wo < p.Wo; wo += 256) bs += p.y[(((size_t)n * p.Ho + ho) * p.Wo + wo) * p.ycs + p.yco];
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) bs += __shfl_xor(bs, d, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = bs;
+    __syncthreads();
+    if (threadIdx.x == 0) dst[p.C * KK] = (red[0] + red[1]) + (red[2] + red[3]);
+  }
 }
 
 // dw[col] (+)= sum_s part[s][col] (col < cols), dbias[0] (+)= sum_s part[s][cols]: 16 columns x 16 row groups per block,
@@ -241,22 +276,19 @@ extern "C" int hrv_conv_cout1_dgrad_f32(const hrv_conv_cout1_t* d, hrv_stream_t 
   HRV_REQUIRE(d->dx && d->dx_cstride % 4 == 0 && d->dx_coff % 4 == 0 && d->dx_coff + d->C <= d->dx_cstride &&
                   ((uintptr_t)d->dx & 15) == 0, "conv_cout1_dgrad: dx slice");
   HRV_REQUIRE(!d->add || (d->add_cstride % 4 == 0 && d->add_coff % 4 == 0 && ((uintptr_t)d->add & 15) == 0), "conv_cout1_dgrad: add slice");
-  const int lds = p.K * p.K * p.C * 4;
+  const int lds = (p.K * p.K * p.C + p.K * (p.Wo + 2 * p.K)) * 4;
+  HRV_REQUIRE(lds <= 160 * 1024, "conv_cout1_dgrad: weights + dY rows exceed the LDS (%d bytes)", lds);
   rc = c1_lds(reinterpret_cast<const void*>(&cout1_dgrad_kernel), lds, "conv_cout1_dgrad");
   if (rc) return rc;
-  const size_t px = (size_t)p.N * p.H * p.W;
-  size_t grid = (px + 3) / 4;
-  if (grid > 4096) grid = 4096;
+  int grid = p.N * p.H;
+  if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(cout1_dgrad_kernel, dim3((unsigned)grid), dim3(256), lds, (hipStream_t)stream, p);
   return check_launch("cout1_dgrad_kernel");
 }
 
 extern "C" int32_t hrv_conv_cout1_wgrad_slabs(int32_t N, int32_t Ho, int32_t Wo) {
-  const int64_t total = (int64_t)N * Ho * Wo;
-  int64_t S = total / 128;
-  if (S > 1024) S = 1024;
-  if (S < 1) S = 1;
-  return (int32_t)S;
+  (void)Wo;
+  return N * Ho;            // one partial row per INPUT row (N * H <= N * Ho of them are used)
 }
 
 // workspace: hrv_conv_cout1_wgrad_slabs() x (C*K*K + 1) floats; dw [1][C][K][K] and dbias [1] (+)= the slab sums
@@ -266,9 +298,14 @@ extern "C" int hrv_conv_cout1_wgrad_f32(const hrv_conv_cout1_t* d, float* dw, in
   int rc = c1_fill(d, p, "conv_cout1_wgrad");
   if (rc) return rc;
   HRV_REQUIRE(d->workspace && dw, "conv_cout1_wgrad: null pointer");
-  p.S = hrv_conv_cout1_wgrad_slabs(p.N, p.Ho, p.Wo);
+  HRV_REQUIRE(p.H <= p.Ho, "conv_cout1_wgrad: pad < (K - 1) / 2 is not built (the bias rows are walked from row h on)");
+  p.S = p.N * p.H;
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(p.S, (p.C + 255) / 256), dim3(256), 0, st, p);
+  const int lds = p.K * (p.Wo + 2 * p.K) * 4;
+  HRV_REQUIRE(lds <= 64 * 1024, "conv_cout1_wgrad: dY rows exceed 64 KB of LDS");
+  rc = c1_lds(reinterpret_cast<const void*>(&cout1_wgrad_kernel), lds, "conv_cout1_wgrad");
+  if (rc) return rc;
+  hipLaunchKernelGGL(cout1_wgrad_kernel, dim3(p.S, (p.C + 255) / 256), dim3(256), lds, st, p);
   rc = check_launch("cout1_wgrad_kernel");
   if (rc) return rc;
   const int cols = p.C * p.K * p.K;

@@ -353,16 +353,16 @@ def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift
 
 
 def _cout1_ok(w: torch.Tensor, x: Act, stride: int, pad: int, part: str = "fwd") -> bool:
-    """conv_cout1.hip serves this layer: ONE output channel, K <= 4, stride 1, an fp32 source with 4-channel granules
-    (PatchGAN's last convolution).  HRV_CONV_COUT1: "0" off, "1" (default) the forward kernel, "all" also the data- and
-    weight-gradient kernels -- measured at 2 x 4 x 131 x 99 x 256: forward 0.233 -> 0.109 ms, data gradient 0.094 -> 0.099 ms
-    (no gain), weight gradient 0.19 -> 0.72 ms (a thread-per-channel walk with 16 bounds-checked dY loads per pixel: slower
-    than the padded matrix-core kernel) -- so only the forward is selected."""
+    """conv_cout1.hip serves this layer: ONE output channel, K <= 4, stride 1, pad >= (K-1)/2, an fp32 source with 4-channel
+    granules (PatchGAN's last convolution).  HRV_CONV_COUT1: "0" off, "fwd" the forward kernel only, default all three.
+    Measured at 2 x 4 x 131 x 99 x 256: forward 0.233 -> 0.109 ms; the first data- / weight-gradient kernels (16 global dY
+    loads per pixel) were no faster than the padded matrix-core path (0.099 / 0.72 ms against 0.094 / 0.19) and were
+    rewritten with the dY rows of an input row staged in LDS."""
     Cout, cin, KH, KW = w.shape
     mode = os.environ.get("HRV_CONV_COUT1", "1")
-    return (Cout == 1 and KH == KW and KH <= 4 and stride == 1 and 0 <= pad < KH and not x.bf16 and x.C == cin and
-            cin % 4 == 0 and cin <= 2048 and x.cstride % 4 == 0 and x.coff % 4 == 0 and w.is_contiguous() and
-            (mode == "all" or (mode != "0" and part == "fwd")))
+    return (Cout == 1 and KH == KW and KH <= 4 and stride == 1 and 0 <= pad < KH and 2 * pad >= KH - 1 and not x.bf16 and
+            x.C == cin and cin % 4 == 0 and cin <= 2048 and x.cstride % 4 == 0 and x.coff % 4 == 0 and w.is_contiguous() and
+            mode != "0" and (mode != "fwd" or part == "fwd"))
 
 
 def _cout1_desc(w, x: Act, pad: int, wscale: float, sigma, y: Act):

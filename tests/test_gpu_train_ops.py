@@ -835,7 +835,7 @@ def test_one_output_channel_convolution_kernels(case, monkeypatch):
     T.MMA_BF16[0] = mixed
     try:
         for mode in ("1", "0"):
-            monkeypatch.setenv("HRV_CONV_COUT1", "all" if mode == "1" else "0")     # ("1", the default, selects the forward only)
+            monkeypatch.setenv("HRV_CONV_COUT1", mode)
             wide = ops.alloc(N, H, W, Cin + 8, "cuda")
             wide.t.normal_()
             xa = wide.slice(4, Cin)
