@@ -119,6 +119,9 @@ SYMBOLS = {
     "hrv_version": (C.c_char_p, []),
     "hrv_last_error": (C.c_char_p, []),
     "hrv_device_check": (C.c_int, []),
+    "hrv_set_reserved_cus": (C.c_int, [_i32]),
+    "hrv_persistent_cus": (C.c_int, []),
+    "hrv_diag_set_tlog": (C.c_int, [_vp, _i64]),
     "hrv_conv2d_pick_tile": (C.c_int, [_i64, _i32]),
     "hrv_conv2d_tile_bn": (C.c_int, [_i32]),
     "hrv_conv2d_tile_bm": (C.c_int, [_i32]),
@@ -195,8 +198,8 @@ SYMBOLS = {
     "hrv_parse_argmax_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp, _i32, _vp]),
     "hrv_resize_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_occlusion_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i64, _vp]),
-    "hrv_nchw_to_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
-    "hrv_nchw_f32_to_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_nchw_to_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
+    "hrv_nchw_f32_to_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp]),
     "hrv_nhwc_bf16_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_nhwc_to_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_space_to_depth2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),

@@ -1413,10 +1413,6 @@ static int launch_patch(const ConvParams& p0, hipStream_t st, int n0_base = 0, i
   }
   ConvParams p = p0;
   p.splitk = 1;
-  {
-    const char* e = getenv("HRV_PATCH_TLOG");      // diag only: device buffer (hex address) for per-tile phase timestamps
-    p.tlog = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
-  }
   constexpr int THP = TMP * WMP * 32 / 16;   // tile rows: BM / 16
   p.m_tiles = p.N * ((p.H + THP - 1) / THP) * ((p.W + 15) / 16);
   p.n_tiles = n_cols_tiles > 0 ? n_cols_tiles : p.CoutPad / BNP;
@@ -1428,13 +1424,8 @@ static int launch_patch(const ConvParams& p0, hipStream_t st, int n0_base = 0, i
                       (((uintptr_t)p.res) & (4 * resz - 1)) == 0;
   constexpr int V = 4 | STV | 64;
   // persistent grid: the resident slots (LDS-bound: 160 KB / block) of every CU.  HRV_PATCH_PERSIST=0: one tile per block
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = persistent_cus();
+  p.tlog = diag_tlog(p.m_tiles);       // diag only (hrv_diag_set_tlog): per-tile phase timestamps
   constexpr int PATCH_LDS = ((TMP * WMP * 32 / 16 + 2) * 18 * 64 + ((STV & 16) ? 3 : 2) * BNP * 32) * 4;
   const int per_cu = PATCH_LDS <= 80 * 1024 ? 2 : 1;
   const char* ep = getenv("HRV_PATCH_PERSIST");

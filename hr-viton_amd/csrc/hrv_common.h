@@ -20,6 +20,19 @@ inline int check_launch(const char* what) {
   return HRV_OK;
 }
 
+// ---- per-DEVICE facts (one process per GPU is the deployment, but the library must not assume it: nothing here is keyed
+// on "the process")
+constexpr int HRV_MAX_DEVICES = 64;
+int current_device();      // hipGetDevice, clamped into [0, HRV_MAX_DEVICES)
+int device_cus();          // multiProcessorCount of the current device (cached per device)
+// The CU count persistent kernels (grid = one block per CU, each owning most of the LDS) size themselves to: device_cus()
+// minus the CUs reserved for kernels that must run CONCURRENTLY with them -- RCCL's collective kernels during a
+// data-parallel backward would otherwise queue behind 40 us .. 1 ms persistent blocks (hrv_set_reserved_cus /
+// HRV_RESERVE_CUS, default 0).
+int persistent_cus();
+// diagnostic per-tile timeline buffer (hrv_diag_set_tlog; nullptr in production): 8 u64 per tile, owned by the measuring tool
+unsigned long long* diag_tlog(long long tiles);
+
 #define HRV_REQUIRE(cond, ...)     \
   do {                             \
     if (!(cond)) {                 \

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restri
         out[((size_t)n * HW + p0 + p) * cs + co + c0 + c] = tile[p][c];
       }
       if (zpad > 0 && c0 + nc == C)
-        for (int i = threadIdx.x; i < np * zpad; i += 256) out[((size_t)n * HW + p0 + i / zpad) * cs + C + i % zpad] = 0.f;
+        for (int i = threadIdx.x; i < np * zpad; i += 256) out[((size_t)n * HW + p0 + i / zpad) * cs + co + C + i % zpad] = 0.f;
       __syncthreads();
     }
   }
@@ -329,6 +329,54 @@ using namespace hrv;
 extern "C" const char* hrv_version(void) { return "hrviton-hip 0.1 (gfx950)"; }
 extern "C" const char* hrv_last_error(void) { return g_err; }
 
+namespace hrv {
+int current_device() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  return dev < HRV_MAX_DEVICES ? dev : HRV_MAX_DEVICES - 1;
+}
+int device_cus() {
+  static int cus[HRV_MAX_DEVICES] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0) dev = 0;
+  if (dev < HRV_MAX_DEVICES && cus[dev] > 0) return cus[dev];
+  hipDeviceProp_t prop;
+  int n = 0;
+  if (hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+  if (n <= 0) n = 256;
+  if (dev < HRV_MAX_DEVICES) cus[dev] = n;
+  return n;
+}
+static int g_reserved_cus = -1;      // -1: not set yet (HRV_RESERVE_CUS is read once)
+int persistent_cus() {
+  if (g_reserved_cus < 0) {
+    const char* e = getenv("HRV_RESERVE_CUS");
+    int k = e ? atoi(e) : 0;
+    g_reserved_cus = k < 0 ? 0 : k;
+  }
+  const int n = device_cus() - g_reserved_cus;
+  return n < 8 ? 8 : n;
+}
+static unsigned long long* g_tlog = nullptr;
+static long long g_tlog_tiles = 0;
+unsigned long long* diag_tlog(long long tiles) { return (g_tlog != nullptr && tiles <= g_tlog_tiles) ? g_tlog : nullptr; }
+}  // namespace hrv
+
+extern "C" int hrv_set_reserved_cus(int32_t k) {
+  HRV_REQUIRE(k >= 0 && k < 4096, "set_reserved_cus: %d", k);
+  hrv::g_reserved_cus = k;
+  return HRV_OK;
+}
+
+extern "C" int hrv_persistent_cus(void) { return hrv::persistent_cus(); }
+
+extern "C" int hrv_diag_set_tlog(void* buf, int64_t tiles) {
+  HRV_REQUIRE((buf == nullptr) == (tiles == 0) && tiles >= 0, "diag_set_tlog: buf and tiles go together");
+  hrv::g_tlog = (unsigned long long*)buf;
+  hrv::g_tlog_tiles = tiles;
+  return HRV_OK;
+}
+
 extern "C" int hrv_device_check(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n < 1) {
@@ -350,15 +398,16 @@ extern "C" int hrv_device_check(void) {
 }
 
 extern "C" int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, float* out,
-                                    int32_t out_cstride, int32_t out_coff, hrv_stream_t stream) {
+                                    int32_t out_cstride, int32_t out_coff, int32_t zero_tail, hrv_stream_t stream) {
   HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nchw_to_nhwc: bad args");
   HRV_REQUIRE(out_coff >= 0 && out_coff + C <= out_cstride, "nchw_to_nhwc: slice out of range");
+  HRV_REQUIRE(zero_tail >= 0 && out_coff + C + zero_tail <= out_cstride, "nchw_to_nhwc: zero_tail %d leaves the pixel (coff %d, C %d, cstride %d)",
+              zero_tail, out_coff, C, out_cstride);
   const size_t total = (size_t)N * H * W;
   (void)total;
   const size_t tiles = (size_t)N * (((size_t)H * W + LT_P - 1) / LT_P);
   hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3((unsigned)(tiles > 16384 ? 16384 : tiles)), dim3(256), 0,
-                     (hipStream_t)stream, in, N, C, H * W, out, out_cstride, out_coff,
-                     (out_coff == 0 && out_cstride - C < 4) ? out_cstride - C : 0);
+                     (hipStream_t)stream, in, N, C, H * W, out, out_cstride, out_coff, zero_tail);
   return check_launch("nchw_to_nhwc_kernel");
 }
 
@@ -375,12 +424,13 @@ extern "C" int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t
 }
 
 extern "C" int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, uint16_t* out,
-                                         int32_t out_cstride, int32_t out_coff, hrv_stream_t stream) {
+                                         int32_t out_cstride, int32_t out_coff, int32_t zero_tail, hrv_stream_t stream) {
   HRV_REQUIRE(in && out && N > 0 && C > 0 && H > 0 && W > 0, "nchw_f32_to_nhwc_bf16: bad args");
   HRV_REQUIRE(out_coff >= 0 && out_coff + C <= out_cstride, "nchw_f32_to_nhwc_bf16: slice out of range");
+  HRV_REQUIRE(zero_tail >= 0 && out_coff + C + zero_tail <= out_cstride, "nchw_f32_to_nhwc_bf16: zero_tail %d leaves the pixel", zero_tail);
   const size_t total = (size_t)N * H * W;
   hipLaunchKernelGGL(nchw_f32_to_nhwc_bf16_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, C,
-                     H * W, out, out_cstride, out_coff, (out_coff == 0 && out_cstride - C < 8) ? out_cstride - C : 0);
+                     H * W, out, out_cstride, out_coff, zero_tail);
   return check_launch("nchw_f32_to_nhwc_bf16_kernel");
 }
 

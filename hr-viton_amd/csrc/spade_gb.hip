@@ -759,17 +759,6 @@ __global__ __launch_bounds__(256) void spade_gb_kernel(const GbParams p, const i
   }
 }
 
-static int gb_n_cu() {
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
-  return n_cu;
-}
-
 }  // namespace hrv
 
 using namespace hrv;
@@ -825,19 +814,13 @@ extern "C" int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream) {
   p.act = d->act; p.slope = d->act_slope;
   const int oal = d->out_f32 ? 4 : 8;
   HRV_REQUIRE(d->out_cstride % oal == 0 && d->out_coff % oal == 0, "spade_gb: out slice must be 16-byte aligned");
-  {
-    const char* e = getenv("HRV_PATCH_TLOG");      // diag only: device buffer (hex address) for per-tile phase timestamps
-    p.tlog = e ? (unsigned long long*)strtoull(e, nullptr, 16) : nullptr;
-  }
-  int grid = gb_n_cu();
+  // diag only (tools/gb_bench.py): per-tile phase timestamps into a device buffer the TOOL owns -- 8 u64 per tile, handed
+  // over through hrv_diag_set_tlog (never read from the environment: a stray variable must not turn the hottest
+  // kernel of the iteration into a scribbler on arbitrary device memory)
+  p.tlog = diag_tlog(p.m_tiles);
+  int grid = persistent_cus();
   if (grid > p.m_tiles) grid = p.m_tiles;
-  {
-    // a quarter of a tile's time (~7 us) per phase group when a block runs >= 8 tiles; HRV_GB_STAGGER overrides (ticks of 10 ns)
-    const char* e = getenv("HRV_GB_STAGGER");
-    const int per_block = (p.m_tiles + grid - 1) / grid;
-    (void)per_block;
-    p.stagger_ticks = e ? atoi(e) : 0;      // measured: no gain (the epilogue is issue-bound, not HBM-bound) -- off by default
-  }
+  p.stagger_ticks = 0;      // (staggered block starts measured no gain: the epilogue is issue-bound, not HBM-bound)
   if (d->mode == 0) {
     HRV_REQUIRE(d->x && d->mean && d->rstd && d->bias_gamma && d->bias_beta, "spade_gb: null epilogue pointer");
     HRV_REQUIRE((d->noise_z == nullptr) == (d->noise_scale == nullptr), "spade_gb: noise_z/noise_scale go together");

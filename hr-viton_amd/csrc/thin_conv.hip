@@ -238,7 +238,8 @@ static int thin_launch(const ThinParams& p, hipStream_t st) {
   constexpr int PB = ((PPIX * SL + 63) / 64) * 1024;
   constexpr int LDS = WB + PB + (WIDE ? 32 * TN * 4 : 0);
   static_assert(LDS <= 160 * 1024, "thin conv: LDS");
-  static bool attr_done = false;
+  static bool attr_done_dev[HRV_MAX_DEVICES] = {false};      // the attribute is per device (and per instantiation: this is a template)
+  bool& attr_done = attr_done_dev[current_device()];
   if (!attr_done) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(&thin_conv_kernel<TN, KB, KS, WIDE>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS) !=
         hipSuccess) {
@@ -247,13 +248,7 @@ static int thin_launch(const ThinParams& p, hipStream_t st) {
     }
     attr_done = true;
   }
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = persistent_cus();
   int per_cu = (160 * 1024) / LDS;
   per_cu = per_cu < 1 ? 1 : (per_cu > 4 ? 4 : per_cu);
   int grid = n_cu * per_cu;

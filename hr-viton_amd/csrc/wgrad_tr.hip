@@ -387,13 +387,7 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   const int jobs = p.co_tiles * p.col_tiles;
   // one block per CU (a block owns 126-152 KB of LDS): the grid must NOT exceed the CU count, or the surplus blocks
   // run as a second round on an otherwise idle chip (first build: 258 blocks, kernel time 2x the wave lifetime)
-  static int n_cu = 0;
-  if (n_cu == 0) {
-    int dev = 0;
-    hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n_cu = prop.multiProcessorCount;
-    if (n_cu <= 0) n_cu = 256;
-  }
+  const int n_cu = persistent_cus();
   int S = n_cu / jobs;
   if (S > p.n_tiles / 8) S = p.n_tiles / 8;
   if (S > 256) S = 256;

@@ -363,8 +363,10 @@ class SpadeT:
             T.spade_gb_dgrad(dgb, T.spade_gb_pack(1, n.conv_gamma.weight.data, n.conv_beta.weight.data), C_, actv, 0.0, dact,
                              self.name + ".gb.dgrad")
         else:
+            # (a padded ``wcat`` is a temporary: a PackBatch record holds the weight's raw address, so only the persistent
+            #  parameter pair may be recorded -- train_ops._pack_batched)
             T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad",
-                         batch=getattr(self.shared, "pack_batch", None))
+                         batch=getattr(self.shared, "pack_batch", None) if Cp == C_ else None)
         return dx
 
 

@@ -20,6 +20,42 @@ from . import _lib
 from .ops import HrvError
 
 
+class CaptureGuard:
+    """What a captured region baked into its hipGraph besides the tensors torch's graph pool owns: raw addresses of
+    Python-owned buffers -- the per-device split-K / weight-gradient workspace (ops._WS), the pack buffers and record tables
+    of the plans' PackBatches, persistent per-plan buffers (S2DConv._w2, the spectral-norm sigma buffer; those are never
+    re-allocated while their module lives).  ``before()`` is taken ahead of the capture, ``after()`` behind it:
+
+    * every such tensor alive at the end of the capture is KEPT alive by the guard, so a later eager call that grows the
+      workspace (ops._workspace replaces the tensor) or a PackBatch.reset() cannot hand the graph's memory to someone else --
+      replays keep reading and writing buffers only they reference;
+    * a PackBatch the region used that was reset() afterwards (a weight moved: optimizer re-creation, .to(), load into a new
+      module) makes the graph STALE -- its pack launches would read the weights' old addresses: ``check()`` raises HrvError
+      instead of replaying."""
+
+    def __init__(self):
+        from . import ops
+        self._runs = {id(o): o.runs for o in list(ops.GRAPH_WATCH)}
+        self.keep, self.watch = [], []
+
+    def after(self):
+        import weakref
+        from . import ops
+        self.keep = list(ops._WS.values())
+        for o in list(ops.GRAPH_WATCH):
+            if o.runs != self._runs.get(id(o), 0):           # launched inside the captured region
+                self.keep.extend(o.graph_keep())
+                self.watch.append((weakref.ref(o), o.generation))
+        return self
+
+    def check(self, who: str):
+        for ref, gen in self.watch:
+            o = ref()
+            if o is not None and o.generation != gen:
+                raise HrvError(f"{who}: a weight-pack batch of the captured plan was reset after the capture (a weight moved to a new "
+                               "address); the graph holds the old addresses -- capture again")
+
+
 class GraphedStep:
     def __init__(self, fn: Callable[[Dict[str, torch.Tensor]], object], example_inputs: Dict[str, torch.Tensor],
                  warmup: int = 2):
@@ -39,8 +75,10 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
+        guard = CaptureGuard()
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = fn(self.static_in)
+        self.guard = guard.after()
         self.replays = 0
 
     def __call__(self, inputs: Dict[str, torch.Tensor]):
@@ -51,6 +89,7 @@ class GraphedStep:
                                f"{tuple(dst.shape)}/{dst.dtype} (re-capture for a new shape)")
             if src.data_ptr() != dst.data_ptr():
                 dst.copy_(src, non_blocking=True)
+        self.guard.check("GraphedStep")
         self.graph.replay()
         self.replays += 1
         return self.static_out
@@ -90,11 +129,14 @@ class GraphedIteration:
         torch.cuda.synchronize()
         self.warmup_iterations = max(1, warmup)
         self.graph = torch.cuda.CUDAGraph()
+        guard = CaptureGuard()
         with torch.cuda.graph(self.graph):
             self.static_out = fn()
+        self.guard = guard.after()
         self.replays = 0
 
     def __call__(self):
+        self.guard.check("GraphedIteration")
         for o in self.optimizers:
             o.push_lr()
         self.graph.replay()

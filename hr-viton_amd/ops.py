@@ -12,6 +12,8 @@ import os
 from dataclasses import dataclass
 from typing import Optional, Sequence, Tuple, Union
 
+import weakref
+
 import torch
 
 from . import _lib
@@ -136,17 +138,19 @@ def to_nhwc(x: torch.Tensor, out: Optional[Act] = None, bf16: bool = False) -> A
     require_cuda(x, "to_nhwc")
     x = x.contiguous()
     N, Cc, H, W = x.shape
+    zero_tail = 0      # a caller's ``out`` may be one slice of a concatenation buffer: nothing outside it is touched
     if out is None:
-        # (the converter writes the pad channels as zeros itself: no fill of the whole tensor)
+        # (the converter writes the pad channels of a tensor allocated HERE as zeros itself: no fill of the whole tensor)
         out = Act(torch.empty((N, H, W, _cpad(Cc, bf16)), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device), Cc, 0)
+        zero_tail = out.cstride - Cc
     lib = _lib.load()
     with _Timed("layout", "nchw_to_nhwc", 0.0, 4.0 * x.numel() + act_bytes(out, Cc)):
         if out.bf16:
             _lib.check(lib.hrv_nchw_f32_to_nhwc_bf16(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
-                                                     _stream()), "hrv_nchw_f32_to_nhwc_bf16")
+                                                     zero_tail, _stream()), "hrv_nchw_f32_to_nhwc_bf16")
         else:
             _lib.check(lib.hrv_nchw_to_nhwc_f32(x.data_ptr(), N, Cc, H, W, out.t.data_ptr(), out.cstride, out.coff,
-                                                _stream()), "hrv_nchw_to_nhwc_f32")
+                                                zero_tail, _stream()), "hrv_nchw_to_nhwc_f32")
     return out
 
 
@@ -206,11 +210,17 @@ class _Timed:
 
 
 _WS = {}
+# objects that own device buffers whose RAW ADDRESSES end up inside captured hipGraphs (train_ops.PackBatch: pack buffers and
+# record tables).  Each has ``generation`` (bumped when it drops its buffers), ``runs`` (bumped when it launches) and
+# ``graph_keep()`` (the tensors a graph that used it must keep alive) -- see graph.CaptureGuard.
+GRAPH_WATCH = weakref.WeakSet()
 
 
 def _workspace(device, nbytes: int) -> torch.Tensor:
     """Per-device split-K scratch (stream-ordered reuse: every conv launch on the stream finishes
-    reading it before the next one writes)."""
+    reading it before the next one writes).  A request beyond the current size REPLACES the tensor; a captured hipGraph
+    that recorded the old address keeps the old tensor alive itself (graph.CaptureGuard), so its replays stay on memory
+    nobody else owns."""
     key = str(device)
     t = _WS.get(key)
     if t is None or t.numel() * 4 < nbytes:

@@ -127,7 +127,9 @@ class Adam(torch.optim.Optimizer):
             st["step"] += 1
             b1, b2 = group["betas"]
             if self.device_step:
-                assert not skipped, "device_step Adam: every parameter needs a gradient in every iteration"
+                if skipped:
+                    raise ops.HrvError("device_step Adam: every parameter needs a gradient in every iteration (one device-side "
+                                       f"step count serves the whole buffer); {len(skipped)} parameter(s) had none")
                 if "step_dev" not in st:
                     dev = g.device
                     st["step_dev"] = torch.full((1,), st["step"] - 1, dtype=torch.int32, device=dev)
@@ -179,10 +181,11 @@ class Adam(torch.optim.Optimizer):
             spans = {id(p): (off, k) for p, off, k in st["spans"]} if st else {}
             pos = {id(p): i for i, (p, _, _) in enumerate(st["spans"])} if st else {}
             ids = []
+            dev_step = int(st["step_dev"].item()) if st and "step_dev" in st else None      # ONE host sync per group
             for p in group["params"]:
                 if st and id(p) in spans:
                     off, k = spans[id(p)]
-                    stp = int(st["step_dev"].item()) if "step_dev" in st else st["steps"][pos[id(p)]]
+                    stp = dev_step if dev_step is not None else st["steps"][pos[id(p)]]
                     state[idx] = {"step": torch.tensor(float(stp)),
                                   "exp_avg": st["m"][off:off + k].view_as(p).clone(),
                                   "exp_avg_sq": st["v"][off:off + k].view_as(p).clone()}
@@ -202,6 +205,7 @@ class Adam(torch.optim.Optimizer):
             st = self._flat.get(gi) or self._setup(gi, group)
             spans = {id(p): (off, k) for p, off, k in st["spans"]}
             pos = {id(p): i for i, (p, _, _) in enumerate(st["spans"])}
+            loaded = None
             for p in group["params"]:
                 ent = sd["state"].get(idx)
                 if ent is not None and id(p) in spans:
@@ -209,5 +213,12 @@ class Adam(torch.optim.Optimizer):
                     st["m"][off:off + k].copy_(ent["exp_avg"].reshape(-1).to(st["m"].device))
                     st["v"][off:off + k].copy_(ent["exp_avg_sq"].reshape(-1).to(st["v"].device))
                     st["steps"][pos[id(p)]] = int(ent["step"])
-                    st["step"] = max(st["step"], int(ent["step"]))
+                    loaded = int(ent["step"]) if loaded is None else max(loaded, int(ent["step"]))
                 idx += 1
+            if loaded is not None:
+                st["step"] = loaded
+            if "step_dev" in st:
+                # device-side step count / learning rate (device_step=True after the first step): a resume must continue the
+                # bias correction from the LOADED count, not from the one this optimizer had reached before the load
+                st["step_dev"].fill_(int(st["step"]))
+                st["lr_dev"].fill_(float(group["lr"]))

@@ -63,6 +63,13 @@ class PackBatch:
         self.stamp = None                # epoch of the last run()
         self.bwd_fresh = False           # ... which also packed group 1
         self.launches = 0
+        self.generation = 0              # bumped by reset(): a captured hipGraph that used this batch is then stale
+        self.runs = 0                    # run() calls (graph.CaptureGuard: which batches did the captured region use)
+        ops.GRAPH_WATCH.add(self)
+
+    def graph_keep(self):
+        """every device tensor whose address a captured run() / conv launch of this batch holds"""
+        return list(self.bufs) + [x for t in self.tables if t is not None for x in t[:2]]
 
     def reset(self):
         """Forget every record (the weights moved: e.g. the fused optimizer re-pointed the parameters into its flat buffer
@@ -71,6 +78,7 @@ class PackBatch:
         self.bufs, self.geoms, self.blocks, self.records, self.group = [], [], [], [], []
         self.tables = [None, None]
         self.dirty, self.stamp, self.bwd_fresh = False, None, False
+        self.generation += 1
 
     @staticmethod
     def _now():
@@ -96,6 +104,7 @@ class PackBatch:
         forward never asks for the data-gradient forms); marks the batch fresh."""
         self.stamp = self._now()
         self.bwd_fresh = backward
+        self.runs += 1
         if not self.bufs:
             return
         lib = _lib.load()
@@ -375,6 +384,19 @@ def _cout1_desc(w, x: Act, pad: int, wscale: float, sigma, y: Act):
     return d
 
 
+_ALT_F32_TILE = {0: 7, 6: 4, 1: 2, 5: 3}      # 128-row fp32 tiles -> the 256-row tile of the same width
+
+
+def _f32_tile(M: int, cout: int) -> int:
+    """fp32-engine tile of a training convolution: hrv_conv2d_pick_tile, or -- HRV_CONV_TILE_TRAIN=bm256, a TEST knob -- the
+    256-row tile of the same width (another block shape, wave layout and split-K geometry for the same convolution: the
+    at-size self-consistency check of tests/test_gpu_fullsize_tocg.py)."""
+    cfg = _lib.load().hrv_conv2d_pick_tile(M, cout)
+    if os.environ.get("HRV_CONV_TILE_TRAIN") == "bm256":
+        cfg = _ALT_F32_TILE.get(cfg, cfg)
+    return cfg
+
+
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
@@ -403,7 +425,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
             out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16 and Cout % 4 == 0)
         return _thin_conv(a0, w, 0, sigma, wscale, shift, residual, 0, act, slope, out, name,
                           2.0 * N * Ho * Wo * Cout * cin * KH * KW)
-    cfg = _bf16_tile(Cout) if mb else lib.hrv_conv2d_pick_tile(N * Ho * Wo, Cout)
+    cfg = _bf16_tile(Cout) if mb else _f32_tile(N * Ho * Wo, Cout)
     if mb:                 # bf16-stored source: the halo patch stays in LDS (ops.patch_tile)
         if KH == 1 and KW == 1 and a0.bf16 and len(srcs) == 1 and a0.Cp <= 128 and Cout % 64 == 0:
             cfg = 6        # one or two K-tiles: the small tile with 64-byte rows keeps more blocks resident
@@ -442,7 +464,7 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
     mb = MMA_BF16[0]
     if out is None:
         out = ops.alloc(N, H, W, cin, dy.t.device, bf16=out_bf16 and mb and cin % 8 == 0 and stride == 1)
-    cfg = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * H * W, cin)
+    cfg = _bf16_tile(cin) if mb else _f32_tile(N * H * W, cin)
     res_mode = 1 if act_mask is not None else 0
     if add is not None:
         act_mask = add           # (the engine's residual slot: res_mode 0 adds it)
@@ -476,7 +498,7 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
             Hp, Wp = (H - a + 1) // 2, (W - b + 1) // 2
             if Hp <= 0 or Wp <= 0:
                 continue
-            cfg_p = _bf16_tile(cin) if mb else lib.hrv_conv2d_pick_tile(N * Hp * Wp, cin)
+            cfg_p = _bf16_tile(cin) if mb else _f32_tile(N * Hp * Wp, cin)
             packed, g = pack_weight_dev(w, [_ceil4(cin)], [cin], cfg_p, 2, 2, pad, (a, b), wscale, sigma, bf16=mb, batch=batch)
             _run_engine([(dy, 0, Cout)], packed, cin, cfg_p, N, Ho, Wo, Hp, Wp, g[0], g[1], 1, g[2], g[3], out,
                         residual=act_mask, res_mode=res_mode, slope=slope, free_extent=1, out_step=2, out_off=(a, b),

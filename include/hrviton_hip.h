@@ -45,6 +45,18 @@ const char* hrv_version(void);
 const char* hrv_last_error(void);
 /* 0 if a gfx950 device is visible to the process. */
 int hrv_device_check(void);
+/* Persistent kernels (one block per CU holding most of its LDS: the SPADE gamma|beta kernel, the patch tiles, the thin and
+ * weight-gradient kernels) size their grids to the CURRENT device's CU count (cached per device) minus ``k`` reserved CUs,
+ * so that kernels which must run concurrently with them -- RCCL's collectives during a data-parallel backward (the
+ * reference's DataParallelWithCallback reduction, train_generator.py:171-178) -- find free CUs instead of queueing behind
+ * 40 us .. 1 ms blocks.  Default 0; the environment variable HRV_RESERVE_CUS sets the initial value.
+ * hrv_persistent_cus(): the resulting grid size. */
+int hrv_set_reserved_cus(int32_t k);
+int hrv_persistent_cus(void);
+/* Diagnostics only (tools/gb_bench.py, tools/patch_timeline.py): a device buffer of 8 x uint64 per tile, OWNED BY THE TOOL,
+ * into which the persistent tile kernels write per-tile phase timestamps while it is set; (NULL, 0) switches it off.  A
+ * launch with more tiles than the buffer holds does not log. */
+int hrv_diag_set_tlog(void* buf, int64_t tiles);
 
 /* ------------------------------------------------------------------------
  * Convolution engine (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).
@@ -463,11 +475,13 @@ int hrv_occlusion_nhwc_f32(const float* g, int32_t g_cstride, int32_t nclass, fl
 
 /* ------------------------------------------------------------------------
  * Layout converters at the module boundary (the reference's tensors are NCHW).
- * NCHW -> NHWC into a WHOLE channel-padded tensor (out_coff == 0, out_cstride - C < one 16-byte group): the pad
- * channels are written as zeros by the converter (the conv engine requires zero pads; no separate fill).
+ * NCHW -> NHWC writes channels [out_coff, out_coff + C) of every pixel and, when the caller asks for it, ``zero_tail``
+ * further channels [out_coff + C, out_coff + C + zero_tail) as zeros (the pad channels of a tensor the caller owns
+ * whole: the conv engine requires zero pads, and this saves a fill of the whole tensor).  zero_tail == 0 touches nothing
+ * outside the slice -- the form to use when ``out`` is one slice of a wider concatenation buffer.
  * ---------------------------------------------------------------------- */
 int hrv_nchw_to_nhwc_f32(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, float* out,
-                         int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+                         int32_t out_cstride, int32_t out_coff, int32_t zero_tail, hrv_stream_t stream);
 int hrv_nhwc_to_nchw_f32(const float* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
                          int32_t H, int32_t W, float* out, hrv_stream_t stream);
 /* Space-to-depth by 2 and its inverse over NHWC fp32: out[n][y/2][x/2][((y&1)*2 + (x&1))*C + c] = in[n][y][x][c].  Host side
@@ -505,7 +519,7 @@ int hrv_concat_nhwc_nchw_f32(const float* a, int32_t Ca, int32_t a_cstride, int3
 int hrv_depth_to_space2_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, float* out, hrv_stream_t stream);
 /* fp32 NCHW (module boundary) <-> bf16 NHWC (inside the bf16 generator path) */
 int hrv_nchw_f32_to_nhwc_bf16(const float* in, int32_t N, int32_t C, int32_t H, int32_t W, uint16_t* out,
-                              int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+                              int32_t out_cstride, int32_t out_coff, int32_t zero_tail, hrv_stream_t stream);
 int hrv_nhwc_bf16_to_nchw_f32(const uint16_t* in, int32_t in_cstride, int32_t in_coff, int32_t N, int32_t C,
                               int32_t H, int32_t W, float* out, hrv_stream_t stream);
 

@@ -352,6 +352,7 @@ def compare_condition_step(H: int = 512, W: int = 384, ngf: int = 96, N: int = 1
     opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
     sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in tocg.state_dict().items()}
     sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    t0 = time.perf_counter()
     r = O.condition_train_losses(sd_g, sd_d, None, batch, occlusion=False, composition="warp_grad", edgeawaretv="no_edge",
                                  add_lasttv=False)
     r["loss_G"].backward(retain_graph=True)
@@ -360,18 +361,23 @@ def compare_condition_step(H: int = 512, W: int = 384, ngf: int = 96, N: int = 1
         v.grad = None
     r["loss_D"].backward()
     want_d = {k: v.grad.clone() for k, v in sd_d.items() if v.grad is not None}
+    t_oracle = time.perf_counter() - t0
+    r = {k: (v.detach() if torch.is_tensor(v) else v) for k, v in r.items()}      # (drop the autograd graph: GBs at 1024x768)
     # the same iteration on the oracle WITH THE ENGINE'S ROUNDING POINTS (bf16 conv operands in the forward, straight-through
     # in the backward): what a bf16-operand evaluation of this loss does to its (discontinuous) gradient, engine or not
-    for v in list(sd_g.values()) + list(sd_d.values()):
-        v.grad = None
-    O.QUANT["fn"] = lambda t: t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
-    try:
-        rq = O.condition_train_losses(sd_g, sd_d, None, batch, occlusion=False, composition="warp_grad", edgeawaretv="no_edge",
-                                      add_lasttv=False)
-        rq["loss_G"].backward()
-    finally:
-        O.QUANT["fn"] = None
-    wantq_g = {k: v.grad.clone() for k, v in sd_g.items() if v.grad is not None}
+    wantq_g = None
+    if any(engines):
+        for v in list(sd_g.values()) + list(sd_d.values()):
+            v.grad = None
+        O.QUANT["fn"] = lambda t: t + (t.to(torch.bfloat16).to(torch.float32) - t).detach()
+        try:
+            rq = O.condition_train_losses(sd_g, sd_d, None, batch, occlusion=False, composition="warp_grad", edgeawaretv="no_edge",
+                                          add_lasttv=False)
+            rq["loss_G"].backward()
+        finally:
+            O.QUANT["fn"] = None
+        wantq_g = {k: v.grad.clone() for k, v in sd_g.items() if v.grad is not None}
+        del rq
     sd0_g = {k: v.detach().clone() for k, v in tocg.state_dict().items()}
     sd0_d = {k: v.detach().clone() for k, v in D.state_dict().items()}
     tocg.cuda().train()
@@ -411,7 +417,68 @@ def compare_condition_step(H: int = 512, W: int = 384, ngf: int = 96, N: int = 1
                 for x in rows_d:
                     f.write("D    %.3e %.6f %.3e %s\n" % x)
     rep["size"] = f"{N}x{H}x{W} ngf={ngf}"
+    rep["oracle_fwd_bwd_s"] = round(t_oracle, 2)
     return rep
+
+
+def compare_tryon_step(opt, tocg, gen, inputs: Dict[str, torch.Tensor], mixed: bool, cpu_threads: int = 0) -> dict:
+    """One image of the end-to-end test_generator.py step (test_generator.py:118-219: tocg at 256x192 -> parse glue -> high-
+    resolution warp -> occlusion -> SPADE generator) on the HIP path against the oracle's composition of the same step.
+    ``mixed``: the bf16 engines are compared with the oracle evaluated WITH THE SAME ROUNDING POINTS (oracle.QUANT), and the
+    bound is that oracle's own re-evaluation with the inputs nudged by 1e-6 (two bf16 evaluations of this pipeline differ
+    by flipped label pixels and by rounding-boundary flips amplified through eight SPADE blocks)."""
+    import torch.nn.functional as F
+    from hr_viton_amd.pipeline import tryon_step
+    if cpu_threads:
+        torch.set_num_threads(cpu_threads)
+    H, W = opt.fine_height, opt.fine_width
+    inp = {k: v[:1].detach().float().cpu() for k, v in inputs.items()}
+    sd_t = {k: v.detach().cpu().clone() for k, v in tocg.state_dict().items()}
+    sd_g = {k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+    layers = opt.num_upsampling_layers
+    comp = getattr(opt, "clothmask_composition", "warp_grad")
+
+    def oracle(nudge: float):
+        g = torch.Generator().manual_seed(17)
+        j = (lambda t: t * (1 + nudge * torch.randn(t.shape, generator=g))) if nudge else (lambda t: t)
+        lo = (256, 192)
+        cm = (inp["cloth_mask"] > 0.5).float()
+        cloth, pose, agn = j(inp["cloth"]), j(inp["densepose"]), j(inp["agnostic"])
+        i1 = torch.cat([O.resize_bilinear(cloth, size=lo), O.resize_nearest(cm, lo)], 1)
+        i2 = torch.cat([O.resize_nearest(inp["parse_agnostic"], lo), O.resize_bilinear(pose, size=lo)], 1)
+        flow_list, seg, _, wcm_p = O.tocg_forward(sd_t, i1, i2)
+        gauss, lab_w, parse_w = O.parse_glue(seg, wcm_p, H, W, comp)
+        wc, wm = O.hires_warp(flow_list[-1], cloth, cm)
+        if getattr(opt, "occlusion", False):
+            wm = O.remove_overlap(F.softmax(gauss, dim=1), wm)
+            wc = wc * wm + torch.ones_like(wc) * (1 - wm)
+        out = O.spade_generator_forward(sd_g, torch.cat((agn, pose, wc), 1), parse_w, H, W, layers)
+        return out, lab_w, wc
+
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.QUANT["fn"] = (lambda t: t.to(torch.bfloat16).to(torch.float32)) if mixed else None
+        try:
+            want, lab_w, wc_w = oracle(0.0)
+            want2, lab_w2, _ = oracle(1e-6) if mixed else (want, lab_w, None)
+        finally:
+            O.QUANT["fn"] = None
+    t_oracle = time.perf_counter() - t0
+    dev = next(gen.parameters()).device
+    with torch.no_grad():
+        res = tryon_step(opt, tocg, gen, {k: v.to(dev) for k, v in inp.items()})
+    got, lab_g = res["output"].float().cpu(), res["fake_parse"].cpu()[:, 0]
+    err, self_err = (got - want).abs(), (want2 - want).abs()
+    return {"size": f"1x{H}x{W}", "mixed": bool(mixed), "oracle_s": round(t_oracle, 2),
+            "oracle": "oracle composition of test_generator.py:118-219" + (" with bf16 operand rounding at the engine's rounding points "
+                                                                            "(oracle.QUANT)" if mixed else ""),
+            "label_map_mismatch_frac": float((lab_g != lab_w).float().mean()),
+            "label_map_mismatch_frac_oracle_vs_nudged_oracle": float((lab_w2 != lab_w).float().mean()),
+            "warped_cloth_max_abs_err": float((res["warped_cloth"].float().cpu() - wc_w).abs().max()),
+            "image_mean_abs_err": float(err.mean()), "image_max_abs_err": float(err.max()),
+            "image_frac_off_by_2e-2": float((err > 2e-2).float().mean()),
+            "oracle_vs_nudged_oracle_mean_abs": float(self_err.mean()), "oracle_vs_nudged_oracle_max_abs": float(self_err.max()),
+            "oracle_vs_nudged_oracle_frac_off_by_2e-2": float((self_err > 2e-2).float().mean())}
 
 
 def cpu_train_generator_step(H: int = 256, W: int = 192, ngf: int = 64, ndf: int = 64, N: int = 1, layers: str = "more",

@@ -24,7 +24,7 @@ def test_gpus2_without_a_launcher_self_launches_two_ranks_and_prints_one_json_li
     assert len(lines) == 1, r.stdout            # rank 0 only
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["steps"] == 4 and j["warmup"] == 1 and j["scaling"] == "weak"
-    assert j["config"]["rccl_ranks"] == 2 and j["config"]["dist_backend"] == "gloo" and j["config"]["global_batch"] == 4
+    assert j["config"]["rccl_ranks"] == 0 and j["config"]["world_size"] == 2 and j["config"]["dist_backend"] == "gloo" and j["config"]["global_batch"] == 4
     assert j["config"]["parallelism"] == "dp2-allreduce"
     # whole-job throughput: images of both ranks / max-over-ranks time
     assert abs(j["value"] - j["config"]["global_batch"] * 1e3 / j["ms_per_step"]) < 0.02 * j["value"]
@@ -34,7 +34,7 @@ def test_gpus1_runs_in_process_without_a_process_group():
     r = _run(["--gpus", "1", "--workload", "stub", "--steps", "2", "--warmup", "0"])
     assert r.returncode == 0, r.stderr[-2000:]
     j = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][0])
-    assert j["n_gpus"] == 1 and j["config"]["rccl_ranks"] == 1 and j["config"]["dist_backend"].startswith("none")
+    assert j["n_gpus"] == 1 and j["config"]["rccl_ranks"] == 0 and j["config"]["world_size"] == 1 and j["config"]["dist_backend"].startswith("none")
 
 
 def test_launched_by_torch_distributed_run_it_does_not_relaunch():

@@ -75,6 +75,18 @@ def test_layout_roundtrip():
         assert torch.equal(a.t[..., :C].cpu(), x.permute(0, 2, 3, 1))
         assert (a.t[..., C:] == 0).all()
         assert torch.equal(ops.to_nchw(a).cpu(), x)
+    # a slice of a wider concatenation buffer (also at channel offset 0): the neighbours' channels are left alone, fp32 and bf16
+    for bf16 in (False, True):
+        x = torch.randn(2, 13, 9, 7, generator=g)
+        full = torch.full((2, 9, 7, 24), 7.0, device="cuda", dtype=torch.bfloat16 if bf16 else torch.float32)
+        for off in (0, 8):
+            full.fill_(7.0)
+            ops.to_nhwc(x.cuda(), out=ops.Act(full, 13, off))
+            want = x.permute(0, 2, 3, 1)
+            want = want.to(torch.bfloat16).float() if bf16 else want
+            assert torch.equal(full[..., off:off + 13].float().cpu(), want)
+            rest = torch.cat([full[..., :off], full[..., off + 13:]], -1)
+            assert (rest == 7.0).all()
 
 
 @pytest.mark.parametrize("shape,out", [((2, 8, 5, 4), (10, 8)), ((1, 12, 6, 9), (12, 18)), ((2, 4, 7, 3), (19, 11))])

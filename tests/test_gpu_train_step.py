@@ -512,6 +512,18 @@ def test_graphed_training_iteration_is_bit_identical_to_eager():
         lr_at(it, og, 1e-3)
         lr_at(it, od, 2e-3)
         losses_g, _ = gs(inputs)
+        if it == 3:
+            # an eager call that outgrows the shared split-K / weight-gradient workspace replaces the tensor; the graph
+            # recorded the old address and must keep that memory to itself (graph.CaptureGuard) -- poison what a freed
+            # workspace would have been recycled into
+            dev = str(inputs["x"].device)
+            old = ops._WS[dev]
+            new = ops._workspace(inputs["x"].device, 2 * old.numel() * 4 + 4096)
+            assert new.data_ptr() != old.data_ptr() and any(t.data_ptr() == old.data_ptr() for t in gs._it.guard.keep)
+            n_old = old.numel()
+            del old
+            new.fill_(float("nan"))
+            junk = [torch.full((n_old,), float("nan"), device="cuda") for _ in range(3)]      # noqa: F841
     got = snapshot(gen, D, og, od)
     assert gs.replays == 2 and int(got["og.step"]) == 5 and int(got["od.step"]) == 5
     for k in want:
@@ -519,3 +531,9 @@ def test_graphed_training_iteration_is_bit_identical_to_eager():
     for k, v in want_losses.items():
         assert float(losses_g[k]) == v, (k, float(losses_g[k]), v)
     assert int(og.state_dict()["state"][0]["step"]) == 5
+    # a weight-pack batch of the captured plan dropping its buffers (a weight moved) makes the graph stale: loud, not silent
+    from hr_viton_amd.ops import HrvError
+    assert gs._it.guard.watch, "the captured iteration ran batched weight packs"
+    gs._it.guard.watch[0][0]().reset()
+    with pytest.raises(HrvError):
+        gs(inputs)

@@ -2,7 +2,7 @@
 """A/B of the dedicated SPADE gamma|beta kernel (csrc/spade_gb.hip, HRV_SPADE_GB=1) against the generic patch tiles
 (HRV_SPADE_GB=0) on the generator's norm shapes: training forward (SPADE epilogue, (1 + gamma) saved) and data gradient
 (ReLU mask), interleaved rounds in ONE process, median; plus the per-tile phase timeline of the new kernel
-(HRV_PATCH_TLOG).      python tools/gb_bench.py [rounds]      (via gpurun)"""
+(hrv_diag_set_tlog).      python tools/gb_bench.py [rounds]      (via gpurun)"""
 import os
 import sys
 from argparse import Namespace
@@ -20,10 +20,11 @@ SHAPES = [("up_4.norm_0", 80, 4, 1024, 768), ("up_4.norm_1", 32, 4, 1024, 768), 
 
 def timeline(run, tiles, label):
     tlog = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
-    os.environ["HRV_PATCH_TLOG"] = hex(tlog.data_ptr())
+    from hr_viton_amd import _lib
+    _lib.check(_lib.load().hrv_diag_set_tlog(tlog.data_ptr(), tiles), "hrv_diag_set_tlog")
     run()
     torch.cuda.synchronize()
-    del os.environ["HRV_PATCH_TLOG"]
+    _lib.check(_lib.load().hrv_diag_set_tlog(None, 0), "hrv_diag_set_tlog")
     t = tlog.cpu().view(tiles, 8)
     t = t[t[:, 3] > 0]
     t0 = int(t[:, 0].min())

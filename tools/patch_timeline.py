@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Phase timeline of the persistent patch-tile convolution (diag): every tile logs wall-clock stamps at tile start, main
 loop start (patch + first weight tiles landed), main loop end and epilogue end, plus the CU it ran on
-(HRV_PATCH_TLOG).  Reports the phase durations and, per CU, how much of the co-resident blocks' epilogue / prologue time
+(hrv_diag_set_tlog).  Reports the phase durations and, per CU, how much of the co-resident blocks' epilogue / prologue time
 is covered by another block's main loop.      python tools/patch_timeline.py [layer_idx] [cfg]      (via gpurun)"""
 import os
 import sys
@@ -83,13 +83,14 @@ def main():
     torch.cuda.synchronize()
     tiles = N * ((H + 7) // 8) * ((W + 15) // 16) * (((cin if (len(sys.argv) > 3 and sys.argv[3] == 'dgrad') else cout) + 127) // 128)
     tlog = torch.zeros(tiles * 8, dtype=torch.int64, device="cuda")
-    os.environ["HRV_PATCH_TLOG"] = hex(tlog.data_ptr())
+    from hr_viton_amd import _lib
+    _lib.check(_lib.load().hrv_diag_set_tlog(tlog.data_ptr(), tiles), "hrv_diag_set_tlog")
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     s.record()
     run()
     e.record()
     torch.cuda.synchronize()
-    del os.environ["HRV_PATCH_TLOG"]
+    _lib.check(_lib.load().hrv_diag_set_tlog(None, 0), "hrv_diag_set_tlog")
     t = tlog.cpu().view(tiles, 8)
     ok = t[:, 3] > 0
     t = t[ok]
