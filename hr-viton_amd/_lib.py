@@ -80,6 +80,18 @@ class hrv_spade_gb_t(C.Structure):
                 ("_pad", C.c_int32), ("mask", C.c_void_p), ("mask_cstride", C.c_int32), ("mask_coff", C.c_int32)]
 
 
+class hrv_spade_fused_t(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32),
+                ("seg", C.c_void_p), ("seg_H", C.c_int32), ("seg_W", C.c_int32), ("seg_shift", C.c_int32), ("x_f32", C.c_int32),
+                ("w_packed", C.c_void_p),
+                ("x", C.c_void_p), ("x_cstride", C.c_int32), ("x_coff", C.c_int32),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("noise_z", C.c_void_p), ("noise_scale", C.c_void_p),
+                ("bias_gamma", C.c_void_p), ("bias_beta", C.c_void_p), ("g1p", C.c_void_p),
+                ("act", C.c_int32), ("act_slope", C.c_float),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
+                ("actv", C.c_void_p), ("actv_cstride", C.c_int32), ("actv_coff", C.c_int32)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -234,6 +246,10 @@ SYMBOLS = {
     "hrv_spade_gb_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "hrv_spade_gb_pack_dev": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "hrv_spade_gb_bf16": (C.c_int, [C.POINTER(hrv_spade_gb_t), _vp]),
+    "hrv_spade_fused_packed_bytes": (C.c_int64, [_i32]),
+    "hrv_spade_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "hrv_spade_fused_pack_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),
+    "hrv_spade_fused_bf16": (C.c_int, [C.POINTER(hrv_spade_fused_t), _vp]),
     "hrv_tv_loss_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
 }
 

@@ -250,9 +250,24 @@ class SpadeT:
         co, c, kh, kw = w.shape
         return w.permute(0, 2, 3, 1), self.shared.bparam.data, c
 
-    def forward(self, x: Act, actv: Act, z: Optional[torch.Tensor], save: bool = True):
+    def forward(self, x: Act, actv: Optional[Act], z: Optional[torch.Tensor], save: bool = True, fused=None):
+        """``fused`` = (bf16 label map Act [N, H << shift, W << shift, 8], shift): conv_shared + ReLU are computed inside the
+        gamma|beta kernel (csrc/spade_fused.hip); ``actv`` is then the slice the kernel WRITES for the backward (None: no_grad
+        forward, actv never reaches HBM)."""
         n = self.norm
         dev = x.t.device
+        if fused is not None:
+            sg, shift = fused
+            zz = z
+            ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)[1] if zz is not None else None
+            mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
+            out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=True)
+            g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.bfloat16, device=dev) if save else None
+            pk = T.spade_fused_pack(self.shared.wparam.data, self.shared.bparam.data, n.conv_gamma.weight.data, n.conv_beta.weight.data)
+            T.spade_fused_forward(sg, shift, x, mean, rstd, zz, n.noise_scale.data, pk, n.conv_gamma.bias.data, n.conv_beta.bias.data,
+                                  self.act, 0.2, out, g1p, actv if save else None, self.name + ".conv_shared+gamma|beta")
+            ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)
+            return out, ctx
         # bias of the fused conv in its interleaved (gamma32 | beta32) column order + padded noise scale: one launch
         bc, ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)
         zz = z  # the noise term is always applied in training (noise_scale is a learnable parameter)
@@ -393,6 +408,20 @@ class BlockT:
     def norms(self):
         return ([self.ns_] if self.learned else []) + [self.n0, self.n1]
 
+    def fused_label_map(self, x: Act, seg: Act, seg_shift: int) -> Optional[Act]:
+        """The bf16 label map when EVERY norm of this block can run conv_shared inside its gamma|beta kernel (mixed precision,
+        csrc/spade_fused.hip: two blocks per CU, actv never read from HBM), else None."""
+        if not (T.MMA_BF16[0] and seg.coff == 0 and seg.cstride == 8 and (seg.W >> seg_shift) % 4 == 0 and x.cstride % 4 == 0):
+            return None
+        norms = self.norms()
+        if not all(n_.C % 8 == 0 and n_.Cp == n_.C and n_.norm.conv_shared[0].weight.shape[1] <= 8 and
+                   T.spade_fused_ok(n_.C, n_.hid, n_.norm.conv_shared[0].weight.shape[1], x.N, x.H, x.W) for n_ in norms):
+            return None
+        sg = seg if seg.bf16 else getattr(seg, "_as_bf16", None)          # one cast per step, shared by the blocks
+        if sg is None:
+            sg = seg._as_bf16 = Act(seg.t.to(torch.bfloat16), seg.C)
+        return sg
+
     def shared_forward(self, seg: Act, seg_shift: int):
         """The conv_shared 3x3s (label_nc -> 128, + ReLU) of the block's norms as ONE 1x1 convolution over the
         tap-expanded label map (ops.tap_expand: 9 taps x 8 padded channels = 72 dense inputs): the label map is
@@ -435,18 +464,33 @@ class BlockT:
                 save: bool = True):
         zi = iter(zs)
         ctx = {"x": x}
-        segx, actvs = self.shared_forward(seg, seg_shift)
+        sgf = self.fused_label_map(x, seg, seg_shift)
+        fused = None
+        if sgf is not None:
+            # conv_shared runs inside each norm's gamma|beta kernel.  The training forward keeps what the backward reads: the
+            # norms' actv side by side (written by those kernels, bf16) and the tap-expanded label map (conv_shared's weight
+            # gradient); the no_grad forward keeps neither
+            fused = (sgf, seg_shift)
+            norms = self.norms()
+            hid = norms[0].hid
+            segx, actvs = None, [None] * len(norms)
+            if save:
+                segx = ops.tap_expand(sgf, seg_shift, 3)
+                actv_all = Act(torch.empty((x.N, x.H, x.W, hid * len(norms)), dtype=torch.bfloat16, device=x.t.device), hid * len(norms))
+                actvs = [actv_all.slice(hid * i, hid) for i in range(len(norms))]
+        else:
+            segx, actvs = self.shared_forward(seg, seg_shift)
         ai = iter(actvs)
         ctx["segx"] = segx
         if self.learned:
-            hs, ctx["ns"] = self.ns_.forward(x, next(ai), next(zi), save)
+            hs, ctx["ns"] = self.ns_.forward(x, next(ai), next(zi), save, fused)
             x_s = self.cs.forward([(hs, 0)])
             ctx["hs"] = hs
         else:
             x_s = x
-        h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi), save)
+        h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi), save, fused)
         dx = self.c0.forward([(h0, 0)])
-        h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi), save)
+        h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi), save, fused)
         # the last block's activated output only feeds conv_img (matrix cores + the sign mask of its data gradient)
         o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up,
                             out_bf16=out is None and h1.bf16 and self.c1.conv.out_channels % 8 == 0)

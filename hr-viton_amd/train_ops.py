@@ -1083,3 +1083,63 @@ def spade_gb_dgrad(dgb: Act, packed: torch.Tensor, C_: int, mask: Optional[Act],
     nb = ops.act_bytes(dgb) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0)
     with ops._Timed("conv", name + " [spade_gb]", fl, nb):
         _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[dgrad]")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# SPADENorm forward fused end to end: conv_shared + ReLU computed inside the gamma|beta kernel (csrc/spade_fused.hip)
+# ---------------------------------------------------------------------------------------------------------------
+def spade_fused_ok(C_: int, hid: int, label_nc: int, N: int, H: int, W: int) -> bool:
+    """The fused kernel serves this norm (hrv_spade_fused_supported; HRV_SPADE_FUSED=0 switches it off for A/B runs)."""
+    if os.environ.get("HRV_SPADE_FUSED", "1") == "0":
+        return False
+    return bool(_lib.load().hrv_spade_fused_supported(C_, hid, label_nc, N, H, W))
+
+
+def spade_fused_pack(w_shared: torch.Tensor, b_shared: torch.Tensor, w_gamma: torch.Tensor, w_beta: torch.Tensor) -> torch.Tensor:
+    """conv_shared.weight [128, label_nc, 3, 3] / .bias, conv_gamma.weight / conv_beta.weight [C, 128, 3, 3] (fp32, device) -> the
+    bf16 fragment-order stream of hrv_spade_fused_bf16."""
+    lib = _lib.load()
+    ops.require_cuda(w_gamma, "spade_fused_pack")
+    assert w_shared.is_contiguous() and b_shared.is_contiguous() and w_gamma.is_contiguous() and w_beta.is_contiguous()
+    assert w_gamma.shape == w_beta.shape and w_shared.shape[0] == w_gamma.shape[1] == 128
+    C_, label_nc = w_gamma.shape[0], w_shared.shape[1]
+    nbytes = lib.hrv_spade_fused_packed_bytes(C_)
+    assert nbytes > 0, C_
+    buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w_gamma.device)
+    _lib.check(lib.hrv_spade_fused_pack_dev(w_shared.data_ptr(), b_shared.data_ptr(), label_nc, w_gamma.data_ptr(), w_beta.data_ptr(),
+                                            C_, buf.data_ptr(), _stream()), "hrv_spade_fused_pack_dev")
+    return buf
+
+
+def spade_fused_forward(seg: Act, seg_shift: int, x: Act, mean: torch.Tensor, rstd: torch.Tensor, z: Optional[torch.Tensor],
+                        noise_scale: Optional[torch.Tensor], packed: torch.Tensor, bias_gamma: torch.Tensor, bias_beta: torch.Tensor,
+                        act: int, slope: float, out: Act, g1p: Optional[torch.Tensor], actv: Optional[Act], name: str):
+    """out = act(IN(x + z*noise_scale) * (1 + conv_gamma(a)) + conv_beta(a)), a = ReLU(conv_shared(nearest(seg))) computed in the
+    kernel; g1p (optional) <- 1 + gamma; actv (optional, bf16 slice of 128 channels) <- a.  ``seg``: the bf16 label map
+    [N, H << seg_shift, W << seg_shift, 8]."""
+    lib = _lib.load()
+    assert seg.bf16 and seg.cstride == 8 and seg.coff == 0 and out.bf16
+    d = _lib.hrv_spade_fused_t()
+    C_ = x.C
+    d.N, d.H, d.W, d.C = x.N, x.H, x.W, C_
+    d.seg, d.seg_H, d.seg_W, d.seg_shift = seg.t.data_ptr(), seg.H, seg.W, seg_shift
+    d.w_packed = packed.data_ptr()
+    d.x, d.x_cstride, d.x_coff, d.x_f32 = x.t.data_ptr(), x.cstride, x.coff, 0 if x.bf16 else 1
+    d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
+    if z is not None:
+        d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
+    d.bias_gamma, d.bias_beta = bias_gamma.data_ptr(), bias_beta.data_ptr()
+    if g1p is not None:
+        assert g1p.dtype == torch.bfloat16
+        d.g1p = g1p.data_ptr()
+    d.act, d.act_slope = act, slope
+    d.out, d.out_cstride, d.out_coff = out.t.data_ptr(), out.cstride, out.coff
+    if actv is not None:
+        assert actv.bf16 and actv.C == 128
+        d.actv, d.actv_cstride, d.actv_coff = actv.t.data_ptr(), actv.cstride, actv.coff
+    px = float(x.N * x.H * x.W)
+    fl = 2.0 * px * 2 * C_ * 128 * 9          # the gamma|beta convolution (SURVEY 8d work; conv_shared's 2 * 72 * 128 per pixel rides along)
+    nbytes = (px * 16 + (1.5 if g1p is not None else 1.0) * ops.act_bytes(x) + ops.act_bytes(out) + (px * 256 if actv is not None else 0.0) +
+              2.0 * C_ * 128 * 9 * 2)
+    with ops._Timed("conv", name + " [spade_gb]", fl, nbytes):      # (the tag: bench.py prices this kernel family's launches)
+        _lib.check(lib.hrv_spade_fused_bf16(C.byref(d), _stream()), "hrv_spade_fused_bf16")

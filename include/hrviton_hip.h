@@ -694,6 +694,39 @@ int hrv_spade_gb_pack_dev(int32_t mode, const float* w_gamma, const float* w_bet
                           void* out, hrv_stream_t stream);
 int hrv_spade_gb_bf16(const hrv_spade_gb_t* d, hrv_stream_t stream);
 
+/* SPADENorm forward fused end to end (spade_fused.hip; network_generator.py:93-121): replaces, for one norm,
+ *     actv  = F.relu(conv_shared(F.interpolate(segmap, size, 'nearest')))            (:115-116)
+ *     out   = act(param_free_norm(x + noise) * (1 + conv_gamma(actv)) + conv_beta(actv))   (:104-110, :117-121)
+ * `actv` is computed inside the kernel from the label patch (two blocks per CU; it never travels through HBM unless the
+ * caller asks for it).
+ *   seg      bf16 NHWC [N, H << seg_shift, W << seg_shift, 8] (label_nc <= 8 real channels, the rest zero): the level's
+ *            nearest-downsampled label map is read in place (pixel (y << seg_shift, x << seg_shift));
+ *   w_packed hrv_spade_fused_pack_dev(conv_shared.weight / .bias, conv_gamma.weight, conv_beta.weight);
+ *   x        fp32 (x_f32 = 1) or bf16 NHWC slice; mean / rstd [N][C]; noise_z [N][W][H] + noise_scale [C] or both NULL;
+ *   out      bf16 NHWC slice; g1p (optional) <- 1 + gamma, bf16 dense [N,H,W,C];
+ *   actv     (optional) <- ReLU(conv_shared(seg)), bf16 NHWC slice of 128 channels (the training forward keeps it for
+ *            the backward: ReLU mask of the data gradient, operand of the gamma|beta weight gradient).
+ * Shapes served: hid == 128, C % 32 in {0, 16}, C >= 32, at least two tiles per CU (hrv_spade_fused_supported). */
+typedef struct hrv_spade_fused {
+  int32_t N, H, W, C;
+  const void* seg; int32_t seg_H, seg_W, seg_shift, x_f32;
+  const void* w_packed;
+  const void* x; int32_t x_cstride, x_coff;
+  const float* mean; const float* rstd; const float* noise_z; const float* noise_scale;
+  const float* bias_gamma; const float* bias_beta;
+  void* g1p;
+  int32_t act; float act_slope;
+  void* out; int32_t out_cstride, out_coff;
+  void* actv; int32_t actv_cstride, actv_coff;
+} hrv_spade_fused_t;
+int64_t hrv_spade_fused_packed_bytes(int32_t C);   /* -1: norm width not served */
+int hrv_spade_fused_supported(int32_t C, int32_t hid, int32_t label_nc, int32_t N, int32_t H, int32_t W);
+/* conv_shared.weight [128][label_nc][3][3] + bias [128], conv_gamma.weight / conv_beta.weight [C][128][3][3] (fp32, device)
+ * -> the bf16 fragment-order stream the kernel's LDS ring consumes */
+int hrv_spade_fused_pack_dev(const float* w_shared, const float* b_shared, int32_t label_nc, const float* w_gamma,
+                             const float* w_beta, int32_t C, void* out, hrv_stream_t stream);
+int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
