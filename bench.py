@@ -44,8 +44,11 @@ H, W = 1024, 768
 _GEN = re.compile(r"^(head_0|G_middle_\d|up_\d|conv_\d+|conv_img)(\.|\[|$)")
 
 
+_CONV_S = re.compile(r"\.conv_s(\.|\[| |$)")      # the learned shortcut (1x1); NOT "conv_shared..."
+
+
 def is_spade_gen_3x3(kind, name):
-    return kind in ("conv", "wgrad") and _GEN.match(name) is not None and ".conv_s" not in name
+    return kind in ("conv", "wgrad") and _GEN.match(name) is not None and _CONV_S.search(name) is None
 
 
 _T0 = time.perf_counter()

@@ -213,10 +213,56 @@ __device__ __forceinline__ GfTile gf_tile(const GfParams& p, int bid) {
 
 typedef __bf16 gf_bf16x4 __attribute__((ext_vector_type(4)));
 
-// One (tile, pass).  ``load_seg``: the label patch of the tile is not in LDS yet (first pass of the tile in this launch).
+// The head of a (tile, pass): what its first barrier waits for -- the label patch (first pass of a tile), the conv_shared
+// weights of half 0 (item 0 -> stage 0) and k-tile 0 (item 1 -> stage 1).  Issued by the PREVIOUS pass right after its main
+// loop (ring and label patch are free then), so the loads fly under that pass's epilogue and are OLDER than its stores:
+// the counted wait at the top of this pass does not wait for the stores to drain.
+template <int NTP>
+__device__ __forceinline__ void gf_head(const GfParams& p, const int pass, unsigned char* const smem, const GfTile T, const bool load_seg,
+                                        const int wave, const int lane) {
+  constexpr int NPW = NTP * 2, NBW = (NPW + 3) / 4;
+  unsigned char* const ring = smem;
+  unsigned char* const segp = smem + GF_SEG_OFF;
+  const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
+  if (load_seg) {
+    // label patch: halo pixel (j, i) of the 20 x 20 patch = level pixel (y0 - 2 + j, x0 - 2 + i) = label-map pixel
+    // (that << seg_shift) -- F.interpolate(segmap, size=x.size()[2:], mode='nearest') of network_generator.py:115 for the
+    // power-of-two ratios of the generator; out of the image: zeros (conv_shared's zero padding)
+    const rsrc_t s_rsrc = make_rsrc(reinterpret_cast<const char*>(p.seg) + (size_t)T.n * p.seg_bytes, p.seg_bytes);
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu) {
+      // 7 pieces of 64 pixels: waves 0..2 issue two; wave 3's second instruction re-loads its first piece (same bytes to the
+      // same place: every wave issues the same number of instructions -- the vmcnt arithmetic is the same in every wave)
+      const int u = wave + 4 * uu < 7 ? wave + 4 * uu : wave;
+      const int q = u * 64 + lane;
+      const int j = (q * 3277) >> 16, i = q - 20 * j;                    // q / 20, q % 20 (q < 448)
+      const int y = T.y0 - 2 + j, x = T.x0 - 2 + i;
+      const bool ok = q < 400 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
+      const unsigned off = (unsigned)((y << p.seg_shift) * p.seg_W + (x << p.seg_shift)) * 16u;
+      dma16(s_rsrc, reinterpret_cast<float*>(segp + u * 1024), ok ? off : 0xFFFFFFF0u, 0u);
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {                                          // item 0: conv_shared half 0 -> stage 0
+    int idx = wave + 4 * k;
+    idx = idx < 10 ? idx : idx - 2;
+    dma16(w_rsrc, reinterpret_cast<float*>(ring + idx * 1024), (unsigned)lane * 16u, (unsigned)idx * 1024u);
+  }
+#pragma unroll
+  for (int k = 0; k < NBW; ++k) {                                        // item 1: k-tile 0 -> stage 1
+    int idx = wave + 4 * k;
+    idx = idx < NPW ? idx : idx - (NPW == 10 ? 2 : 4);
+    dma16(w_rsrc, reinterpret_cast<float*>(ring + GF_SB + idx * 1024), (unsigned)lane * 16u, p.woff[pass] + (unsigned)idx * 1024u);
+  }
+}
+
+// One (tile, pass).  Its head is in flight or landed (gf_head).  ``load_consts``: the per-channel constants in LDS belong to
+// another (image, pass).  ``wait_all``: nothing of a previous pass is in flight behind the head (first pass of the block).
+// ``nxt_*``: the (tile, pass) whose head this pass issues after its main loop (nxt_pass < 0: none).
 template <int NTP>
 __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsigned char* const smem, const GfTile T, const int bid,
-                                        const bool load_seg, const bool save_actv, const bool first, const bool last) {
+                                        const bool load_consts, const bool wait_all, const bool save_actv, const bool first, const bool last,
+                                        const int nxt_pass, const GfTile NT_, const bool nxt_seg) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
@@ -224,6 +270,8 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   constexpr int NBW = (NPW + 3) / 4;                         // DMA instructions per wave per k-tile (NTP 5: 3, two of the 12 re-load a piece)
   constexpr int NBS = 3;                                     // ... per conv_shared half (10 pieces)
   constexpr int NPAIR = NTP / 2, TAIL = NTP & 1;
+  constexpr int NST1 = 4 * NPAIR + 2 * TAIL, NST2 = 2 * NST1;   // global stores of one epilogue per wave (out; out + (1 + gamma))
+  constexpr int NSA = 8;                                     // global stores of one saved actv half per wave
   static_assert(NPAIR * 32 + TAIL * 16 <= GF_CV, "constant vectors");
   static_assert(NPW * 1024 <= GF_SB, "ring stage");
   unsigned char* const ring = smem;
@@ -253,28 +301,11 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
           (unsigned)half * (unsigned)GF_SB + (unsigned)idx * 1024u);
   };
 
-  // every wave is done with the previous (tile, pass): its epilogue's staging scratch lives in the ring, its constants in cbuf
-  __syncthreads();
+  // every wave is done with the previous (tile, pass): its epilogue's staging scratch lives in the patch, its constants in cbuf
+  __builtin_amdgcn_s_waitcnt(gf_wait(63));
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
   if (p.tlog && tid == 0 && first) p.tlog[(size_t)bid * 8 + 0] = wall_clock64();
-  if (load_seg) {
-    // label patch: halo pixel (j, i) of the 20 x 20 patch = level pixel (y0 - 2 + j, x0 - 2 + i) = label-map pixel
-    // (that << seg_shift) -- F.interpolate(segmap, size=x.size()[2:], mode='nearest') of network_generator.py:115 for the
-    // power-of-two ratios of the generator; out of the image: zeros (conv_shared's zero padding)
-    const rsrc_t s_rsrc = make_rsrc(reinterpret_cast<const char*>(p.seg) + (size_t)pt_n * p.seg_bytes, p.seg_bytes);
-#pragma unroll 1
-    for (int u = wave; u < 7; u += 4) {
-      const int q = u * 64 + lane;
-      const int j = (q * 3277) >> 16, i = q - 20 * j;                    // q / 20, q % 20 (q < 448)
-      const int y = pt_y0 - 2 + j, x = pt_x0 - 2 + i;
-      const bool ok = q < 400 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
-      const unsigned off = (unsigned)((y << p.seg_shift) * p.seg_W + (x << p.seg_shift)) * 16u;
-      dma16(s_rsrc, reinterpret_cast<float*>(segp + u * 1024), ok ? off : 0xFFFFFFF0u, 0u);
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NBS; ++k) dma_s(0, 0, k);              // item 0: conv_shared half 0 -> stage 0
-#pragma unroll
-  for (int k = 0; k < NBW; ++k) dma_w(0, 1, k);              // item 1: k-tile 0 -> stage 1
 
   // ---- this lane's pixels (two: tile rows 4 w + (l31 >> 4) and + 2) and fragment addresses
   const int ty = 4 * wave + (l31 >> 4), tx = l31 & 15;
@@ -292,19 +323,20 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   // ---- the pass's per-channel constants -> LDS: 1 + bias_gamma | bias_beta | rstd | noise_scale * rstd | -mean * rstd,
   // so that IN(x + z ns) = x * rstd + (z * (ns rstd) - mean rstd); and conv_shared's bias
   const int cb0 = (tile0 >> 1) * 32;          // first norm channel of this pass
-  for (int t = tid; t < GF_CV; t += 256) {
-    const int c = cb0 + t;
-    float b1 = 1.f, b2 = 0.f, rs = 0.f, nr = 0.f, mr = 0.f;
-    if (c < p.sC) {
-      b1 = 1.f + p.bg[c];
-      b2 = p.bb[c];
-      rs = p.srstd[(size_t)pt_n * p.sC + c];
-      nr = p.sns ? p.sns[c] * rs : 0.f;
-      mr = -p.smean[(size_t)pt_n * p.sC + c] * rs;
+  if (load_consts) {
+    for (int t = tid; t < GF_CV; t += 256) {
+      const int c = cb0 + t;
+      float b1 = 1.f, b2 = 0.f, rs = 0.f, nr = 0.f, mr = 0.f;
+      if (c < p.sC) {
+        b1 = 1.f + p.bg[c];
+        b2 = p.bb[c];
+        rs = p.srstd[(size_t)pt_n * p.sC + c];
+        nr = p.sns ? p.sns[c] * rs : 0.f;
+        mr = -p.smean[(size_t)pt_n * p.sC + c] * rs;
+      }
+      cbuf[t] = b1; cbuf[GF_CV + t] = b2; cbuf[2 * GF_CV + t] = rs; cbuf[3 * GF_CV + t] = nr; cbuf[4 * GF_CV + t] = mr;
     }
-    cbuf[t] = b1; cbuf[GF_CV + t] = b2; cbuf[2 * GF_CV + t] = rs; cbuf[3 * GF_CV + t] = nr; cbuf[4 * GF_CV + t] = mr;
   }
-  if (tid < 128) bsh[tid] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wp) + GF_WSH_B)[tid];
 
   // ---- one half of the actv patch: ReLU(conv_shared(label patch)), zero outside the image, bf16 -> LDS.
   // GEMM per 32 patch pixels: D[channel][pixel] += Wsh[channel][k] * S[k][pixel], k = (tap, label channel), 5 k-steps of
@@ -393,15 +425,20 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
     }
   };
 
-  // items 0 and 1 (and the label patch) have landed
-  __builtin_amdgcn_s_waitcnt(gf_wait(0));
+  // The head (label patch, items 0 and 1) has landed.  Behind it in this wave's queue sit only the previous pass's epilogue
+  // stores (NST of them: they need not drain) -- unless this pass loaded constants or is the block's first
+  if (wait_all || load_consts) __builtin_amdgcn_s_waitcnt(gf_wait(0));
+  else if (p.g1p) __builtin_amdgcn_s_waitcnt(gf_wait(NST2));
+  else __builtin_amdgcn_s_waitcnt(gf_wait(NST1));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 #pragma unroll
   for (int k = 0; k < NBW; ++k) dma_w(1, 2, k);              // item 2: k-tile 1 -> stage 2
   conv_shared(0, 0);
-  __syncthreads();                                           // half 0 of the patch is published; stage 0 is free
-  if (save_actv) store_actv(0);
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(gf_wait(63));                   // (LDS writes only: the k-tile in flight stays in flight)
+  __builtin_amdgcn_s_barrier();                              // half 0 of the patch is published; stage 0 is free
+  asm volatile("" ::: "memory");
   if (p.tlog && tid == 0 && first) p.tlog[(size_t)bid * 8 + 1] = wall_clock64();
 
   // ---- main loop over the k-tiles (half, tap, 32-k sub-tile).  Fragment reads run one k-step ahead of the MFMAs, ACROSS
@@ -461,7 +498,7 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   // nothing, 1 k-tile kt + 2, 2 the conv_shared weights of half 1.  NEXT: a k-tile follows directly (its k-step 0 is read
   // under this one's last MFMAs, behind the counted wait + barrier that publishes it: vmcnt(WAITN)); otherwise the caller
   // publishes what comes next.
-  auto ktile = [&](auto issue_c, auto next_c, auto waitn_c, const bool wait_all = false) {
+  auto ktile = [&](auto issue_c, auto next_c, auto waitn_c) {
     constexpr int ISSUE = decltype(issue_c)::value;
     constexpr bool NEXT = decltype(next_c)::value;
     constexpr int WAITN = decltype(waitn_c)::value;
@@ -478,10 +515,7 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
     wb = wb == 2 ? 0 : wb + 1;
     if constexpr (NEXT) {
       asm volatile("" ::: "memory");
-      // (a branch around the wait alone: MFMA sequences in diverging branches make the register allocator shuffle -- and
-      //  spill -- the accumulators)
-      if (wait_all) __builtin_amdgcn_s_waitcnt(gf_wait(0));
-      else __builtin_amdgcn_s_waitcnt(gf_wait(WAITN));
+      __builtin_amdgcn_s_waitcnt(gf_wait(WAITN));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       point();
@@ -508,10 +542,11 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   using N = std::false_type;
   // half 0: k-tiles 0..17 = items 1..18; the item requested under k-tile kt is item kt + 3: k-tile kt + 2 -- or, under
   // k-tile 16, the conv_shared weights of half 1 (item 19), and under k-tile 17 k-tile 18 (item 20).
-  // (The stores of a saved half are older than every DMA that follows, but a counted wait must not mistake them for
-  //  landed weights: the first publish after them waits for everything.)
+  // Training forward: a half of actv leaves for HBM at the END of its main loop (the patch still holds it), so its NSA
+  // stores per wave are the YOUNGEST entries of the queue at the next two publishes (vmcnt counts them, nobody waits for
+  // them) and are long done when the third comes.
   first_frags();
-  ktile(I1{}, Y{}, WN{}, save_actv);                        // k-tile 0 (requests k-tile 2)
+  ktile(I1{}, Y{}, WN{});                                   // k-tile 0 (requests k-tile 2)
 #pragma unroll 1
   for (int q = 1; q < 16; ++q) ktile(I1{}, Y{}, WN{});      // k-tiles 1..15 (request 3..17)
   ktile(I2{}, Y{}, WS{});                                   // k-tile 16: requests conv_shared half 1
@@ -525,9 +560,11 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
     wb = wb == 2 ? 0 : wb + 1;
     GF_STEP(1, false, 0, ;, 0)
   }
+  if (save_actv) store_actv(0);
   // every wave is done with half 0 of the patch; the conv_shared weights of half 1 (requested one item ago) have landed
   asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(gf_wait(NBW));
+  if (save_actv) __builtin_amdgcn_s_waitcnt(gf_wait(NBW + NSA));
+  else __builtin_amdgcn_s_waitcnt(gf_wait(NBW));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   {
@@ -540,17 +577,18 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   }
   // publish: half 1 of the patch (LDS writes of every wave) and k-tile 18 (requested two items ago)
   asm volatile("" ::: "memory");
-  __builtin_amdgcn_s_waitcnt(gf_wait(NBW));
+  if (save_actv) __builtin_amdgcn_s_waitcnt(gf_wait(NBW + NSA));
+  else __builtin_amdgcn_s_waitcnt(gf_wait(NBW));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
-  if (save_actv) store_actv(1);
   // half 1: k-tiles 18..35; under k-tile kt request k-tile kt + 2 (<= 35)
   first_frags();
-  ktile(I1{}, Y{}, WN{}, save_actv);                        // k-tile 18 (requests 20)
+  ktile(I1{}, Y{}, WN{});                                   // k-tile 18 (requests 20)
 #pragma unroll 1
   for (int q = 19; q < 34; ++q) ktile(I1{}, Y{}, WN{});     // k-tiles 19..33 (request 21..35)
   ktile(I0{}, Y{}, I0{});                                   // k-tile 34
   ktile(I0{}, N{}, I0{});                                   // k-tile 35
+  if (save_actv) store_actv(1);
 #undef GF_READ_A
 #undef GF_READ_B
 #undef GF_STEP
@@ -558,7 +596,12 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   if (p.tlog && tid == 0 && last) p.tlog[(size_t)bid * 8 + 2] = wall_clock64();
 
   // ---- epilogue.  D layout (swapped operands): lane -> pixel l31; regs 4g..4g+3 -> channels 8g + 4 lh + (0..3) of the tile
-  __syncthreads();                             // every wave is done with the patch and the weight ring
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(gf_wait(63));
+  __builtin_amdgcn_s_barrier();                // every wave is done with the patch and the weight ring
+  asm volatile("" ::: "memory");
+  // the next (tile, pass) of this block: its head flies while this epilogue computes and stores
+  if (nxt_pass >= 0) gf_head<NTP>(p, nxt_pass, smem, NT_, nxt_seg, wave, lane);
   // (the epilogue's index arithmetic depends on the lane id only: hidden from the optimiser behind an empty asm, or it is
   //  hoisted out of the persistent tile loop and lives -- spilled -- through the main loop)
   int lane_e = lane;
@@ -582,8 +625,8 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
                                   p.g1p ? (unsigned)(img_px * p.sC * 2) : 0u);
   // bf16 staging: the two 32-pixel halves of the wave go through the scratch TOGETHER (two buffers of 32 rows x 64 B + pad),
   // rows leave 16 bytes (8 channels) per lane along the channels
-  unsigned char* const sb0 = ring + wave * 5120;
-  static_assert(4 * 5120 <= 3 * GF_SB, "epilogue scratch fits the ring");
+  unsigned char* const sb0 = patch + wave * 5120;      // (the ring and the label patch are being refilled for the next pass)
+  static_assert(4 * 5120 <= GF_PATCH_B, "epilogue scratch fits the patch");
   constexpr int RS = 80;                     // scratch row stride in bytes (32 bf16 channels + 16)
   // pixel (in-image index, or -1) of the scratch rows this lane stores: 4-group rows (lane >> 2) + 16 k, 2-group rows lane >> 1
   int pp4[2][2], pp2[2];
@@ -705,6 +748,13 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
 template <int NTP>
 __global__ __launch_bounds__(256, 2) void spade_fused_kernel(const GfParams p, const int pass0, const int pass1) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[GF_LDS];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // conv_shared's bias: the same for every tile and pass
+  if (threadIdx.x < 128)
+    reinterpret_cast<float*>(smem + GF_CB_OFF)[5 * GF_CV + threadIdx.x] =
+        reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wp) + GF_WSH_B)[threadIdx.x];
+  if ((int)blockIdx.x < p.m_tiles) gf_head<NTP>(p, pass0, smem, gf_tile(p, blockIdx.x), true, wave, lane);
+  int c_n = -1, c_pass = -1;                   // (image, pass) of the constants in LDS
 #pragma unroll 1
   for (int bid = blockIdx.x; bid < p.m_tiles; bid += gridDim.x) {
     if (p.tlog && threadIdx.x == 0) {
@@ -715,9 +765,17 @@ __global__ __launch_bounds__(256, 2) void spade_fused_kernel(const GfParams p, c
       p.tlog[(size_t)bid * 8 + 5] = blockIdx.x;
     }
     const GfTile T = gf_tile(p, bid);
+    const int nbid = bid + gridDim.x;
+    const GfTile TN = gf_tile(p, nbid < p.m_tiles ? nbid : bid);
 #pragma unroll 1
-    for (int pass = pass0; pass < pass1; ++pass)
-      gf_pass<NTP>(p, pass, smem, T, bid, pass == pass0, p.actv != nullptr && pass == 0, pass == pass0, pass == pass1 - 1);
+    for (int pass = pass0; pass < pass1; ++pass) {
+      const bool lastp = pass == pass1 - 1;
+      const int nxt_pass = !lastp ? pass + 1 : (nbid < p.m_tiles ? pass0 : -1);
+      const bool lc = c_n != T.n || c_pass != pass;
+      c_n = T.n; c_pass = pass;
+      gf_pass<NTP>(p, pass, smem, T, bid, lc, bid == (int)blockIdx.x && pass == pass0, p.actv != nullptr && pass == 0, pass == pass0, lastp,
+                   nxt_pass, lastp ? TN : T, lastp);
+    }
     if (p.tlog) {
       __builtin_amdgcn_s_waitcnt(gf_wait(0));
       if (threadIdx.x == 0) p.tlog[(size_t)bid * 8 + 3] = wall_clock64();
