@@ -92,6 +92,15 @@ class hrv_spade_fused_t(C.Structure):
                 ("actv", C.c_void_p), ("actv_cstride", C.c_int32), ("actv_coff", C.c_int32)]
 
 
+class hrv_conv_p2_t(C.Structure):
+    _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("src", C.c_void_p), ("src_cstride", C.c_int32), ("src_coff", C.c_int32), ("Cout", C.c_int32),
+                ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+                ("act", C.c_int32), ("act_slope", C.c_float),
+                ("mask", C.c_void_p), ("mask_cstride", C.c_int32), ("mask_coff", C.c_int32), ("mask_slope", C.c_float), ("out_f32", C.c_int32),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -246,6 +255,10 @@ SYMBOLS = {
     "hrv_spade_gb_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "hrv_spade_gb_pack_dev": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _i32, _vp, _vp]),
     "hrv_spade_gb_bf16": (C.c_int, [C.POINTER(hrv_spade_gb_t), _vp]),
+    "hrv_conv_p2_packed_bytes": (C.c_int64, [_i32, _i32]),
+    "hrv_conv_p2_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
+    "hrv_conv_p2_pack_dev": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _f, _vp, _vp]),
+    "hrv_conv_p2_bf16": (C.c_int, [C.POINTER(hrv_conv_p2_t), _vp]),
     "hrv_spade_fused_packed_bytes": (C.c_int64, [_i32]),
     "hrv_spade_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "hrv_spade_fused_pack_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),

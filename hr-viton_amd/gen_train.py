@@ -373,7 +373,13 @@ class SpadeT:
         _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
         _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
         # d actv, with the ReLU derivative of conv_shared fused (slope 0)
-        if (Cp == C_ and T.MMA_BF16[0] and dgb.bf16 and actv.bf16 and
+        if (Cp == C_ and T.MMA_BF16[0] and dgb.bf16 and actv.bf16 and dact.cstride % 8 == 0 and (2 * C_) % 32 == 0 and
+                T.conv_p2_ok(2 * C_, self.hid, actv.N, actv.H, actv.W)):
+            # two blocks per CU, 32-channel source chunks double-buffered (csrc/conv_p2.hip)
+            pk = T.conv_p2_pack(2, n.conv_gamma.weight.data, n.conv_beta.weight.data, 2 * C_, self.hid)
+            T.conv_p2(dgb, pk, self.hid, dact, mask=actv, mask_slope=0.0, name=self.name + ".gb.dgrad",
+                      flops=2.0 * actv.N * actv.H * actv.W * 2 * C_ * self.hid * 9, tag=" [spade_gb]")
+        elif (Cp == C_ and T.MMA_BF16[0] and dgb.bf16 and actv.bf16 and
                 T.spade_gb_ok(1, C_, Cp, self.hid, actv.N, actv.H, actv.W)):
             T.spade_gb_dgrad(dgb, T.spade_gb_pack(1, n.conv_gamma.weight.data, n.conv_beta.weight.data), C_, actv, 0.0, dact,
                              self.name + ".gb.dgrad")

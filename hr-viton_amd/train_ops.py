@@ -425,6 +425,13 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
             out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16 and Cout % 4 == 0)
         return _thin_conv(a0, w, 0, sigma, wscale, shift, residual, 0, act, slope, out, name,
                           2.0 * N * Ho * Wo * Cout * cin * KH * KW)
+    if (mb and len(srcs) == 1 and up0 == 0 and out_up == 0 and residual is None and (KH, KW, stride, pad) == (3, 3, 1, 1) and a0.bf16 and
+            a0.C == cin and cin % 32 == 0 and Cout % 64 == 0 and w.is_contiguous() and conv_p2_ok(cin, Cout, N, H, W)):
+        # plain 3x3 over one bf16 source: the two-blocks-per-CU kernel (VGG19's 128..512-channel layers)
+        if out is None:
+            out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16)
+        pk = conv_p2_pack(0, w, None, cin, Cout, sigma, wscale, frozen)
+        return conv_p2(a0, pk, Cout, out, bias=shift, act=act, slope=slope, name=name, flops=2.0 * N * Ho * Wo * Cout * cin * 9)
     cfg = _bf16_tile(Cout) if mb else _f32_tile(N * Ho * Wo, Cout)
     if mb:                 # bf16-stored source: the halo patch stays in LDS (ops.patch_tile)
         if KH == 1 and KW == 1 and a0.bf16 and len(srcs) == 1 and a0.Cp <= 128 and Cout % 64 == 0:
@@ -481,6 +488,13 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
     if (add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
+    if (mb and stride == 1 and (KH, KW, pad) == (3, 3, 1) and (Ho, Wo) == (H, W) and dy.bf16 and add is None and dy.C == Cout and
+            Cout % 32 == 0 and cin % 64 == 0 and (act_mask is None or (act_mask.bf16 and act_mask.C == cin)) and w.is_contiguous() and
+            conv_p2_ok(Cout, cin, N, H, W)):
+        # a stride-1 data gradient is a 'same' 3x3 convolution over dY: the two-blocks-per-CU kernel
+        pk = (conv_p2_pack(2, pair[0], pair[1], Cout, cin) if pair is not None else
+              conv_p2_pack(1, w, None, Cout, cin, sigma, wscale, frozen))
+        return conv_p2(dy, pk, cin, out, mask=act_mask if res_mode == 1 else None, mask_slope=slope, name=name, flops=fl)
     if stride == 1:
         if mb and (Ho, Wo) == (H, W):   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
             cfg = ops.patch_tile(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) or cfg
@@ -1143,3 +1157,61 @@ def spade_fused_forward(seg: Act, seg_shift: int, x: Act, mean: torch.Tensor, rs
               2.0 * C_ * 128 * 9 * 2)
     with ops._Timed("conv", name + " [spade_gb]", fl, nbytes):      # (the tag: bench.py prices this kernel family's launches)
         _lib.check(lib.hrv_spade_fused_bf16(C.byref(d), _stream()), "hrv_spade_fused_bf16")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# 3x3 'same' convolution over one bf16 source, two blocks per CU (csrc/conv_p2.hip): VGG19 forward / data gradient, the
+# data gradient of the SPADE (conv_gamma, conv_beta) pair
+# ---------------------------------------------------------------------------------------------------------------
+def conv_p2_ok(K: int, cols: int, N: int, H: int, W: int) -> bool:
+    """hrv_conv_p2_supported (HRV_CONV_P2=0 switches the kernel off for A/B runs)."""
+    if os.environ.get("HRV_CONV_P2", "1") == "0":
+        return False
+    return bool(_lib.load().hrv_conv_p2_supported(K, cols, N, H, W))
+
+
+def conv_p2_pack(mode: int, w: torch.Tensor, w2: Optional[torch.Tensor], K: int, cols: int, sigma: Optional[torch.Tensor] = None,
+                 wscale: float = 1.0, frozen=None) -> torch.Tensor:
+    """The bf16 fragment-order weight stream of hrv_conv_p2_bf16 (mode 0 forward / 1 data gradient / 2 data gradient of a pair);
+    ``frozen``: kept across calls like pack_weight_dev's."""
+    lib = _lib.load()
+    key = None
+    if frozen is not None and sigma is None:
+        key = ("p2", w.data_ptr(), frozen, ops.LOAD_EPOCH[0], tuple(w.shape), mode, K, cols, wscale)
+        hit = _FROZEN_PACKS.get(key)
+        if hit is not None:
+            return hit[0]
+    assert w.is_contiguous() and (w2 is None or w2.is_contiguous())
+    nbytes = lib.hrv_conv_p2_packed_bytes(K, cols)
+    assert nbytes > 0, (K, cols)
+    buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.hrv_conv_p2_pack_dev(mode, w.data_ptr(), None if w2 is None else w2.data_ptr(), K, cols,
+                                        None if sigma is None else sigma.data_ptr(), wscale, buf.data_ptr(), _stream()),
+               "hrv_conv_p2_pack_dev")
+    if key is not None:
+        if len(_FROZEN_PACKS) > 256:
+            _FROZEN_PACKS.clear()
+        _FROZEN_PACKS[key] = (buf, ())
+    return buf
+
+
+def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.2,
+            mask: Optional[Act] = None, mask_slope: float = 0.0, name: str = "conv", flops: float = 0.0, tag: str = ""):
+    """out = act(conv3x3(src) + bias) [* (mask > 0 ? 1 : mask_slope)] on csrc/conv_p2.hip."""
+    lib = _lib.load()
+    assert src.bf16 and out.C == cols
+    d = _lib.hrv_conv_p2_t()
+    d.N, d.H, d.W, d.Cin = src.N, src.H, src.W, src.C
+    d.src, d.src_cstride, d.src_coff, d.Cout = src.t.data_ptr(), src.cstride, src.coff, cols
+    d.w_packed = packed.data_ptr()
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    d.act, d.act_slope = act, slope
+    if mask is not None:
+        assert mask.bf16 and mask.C == cols
+        d.mask, d.mask_cstride, d.mask_coff, d.mask_slope = mask.t.data_ptr(), mask.cstride, mask.coff, mask_slope
+    d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
+    nb = ops.act_bytes(src) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0) + 2.0 * src.C * cols * 9
+    with ops._Timed("conv", name + tag, flops, nb):
+        _lib.check(lib.hrv_conv_p2_bf16(C.byref(d), _stream()), f"hrv_conv_p2_bf16[{name}]")
+    return out

@@ -727,6 +727,31 @@ int hrv_spade_fused_pack_dev(const float* w_shared, const float* b_shared, int32
                              const float* w_beta, int32_t C, void* out, hrv_stream_t stream);
 int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t stream);
 
+/* 3x3 stride-1 'same' convolution over ONE bf16-stored NHWC source with Cin % 32 == 0 and Cout % 64 == 0, two blocks per CU
+ * (conv_p2.hip): nn.Conv2d forward (VGG19 of the perceptual loss, networks.py:201-233) and data gradients -- of such a
+ * convolution (mode 1) or of the SPADE (conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118).
+ *   out = act(conv + bias[c]) [* (mask > 0 ? 1 : mask_slope)], bf16 or fp32 NHWC slice.
+ * `Cin` = K (channels of `src`), `Cout` = columns, whatever the mode; w_packed from hrv_conv_p2_pack_dev of the same mode:
+ *   mode 0: w = the layer's OIHW weight [Cout][Cin][3][3];
+ *   mode 1: w = the FORWARD layer's OIHW weight [Cin][Cout][3][3] (its output channels are this call's K), taps flipped;
+ *   mode 2: (w, w2) = [Cin / 2][Cout][3][3] each, K = [w rows | w2 rows], taps flipped.
+ * `sigma` (optional device scalar) and `wscale`: packed weight = w * wscale / sigma[0].
+ * hrv_conv_p2_supported: shape served and at least two tiles per CU. */
+typedef struct hrv_conv_p2 {
+  int32_t N, H, W, Cin;
+  const void* src; int32_t src_cstride, src_coff, Cout;
+  const void* w_packed;
+  const float* bias;
+  int32_t act; float act_slope;
+  const void* mask; int32_t mask_cstride, mask_coff; float mask_slope; int32_t out_f32;
+  void* out; int32_t out_cstride, out_coff;
+} hrv_conv_p2_t;
+int64_t hrv_conv_p2_packed_bytes(int32_t Cin, int32_t Cout);   /* -1: shape not served */
+int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32_t H, int32_t W);
+int hrv_conv_p2_pack_dev(int32_t mode, const float* w, const float* w2, int32_t Cin, int32_t Cout, const float* sigma, float wscale,
+                         void* out, hrv_stream_t stream);
+int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,111 @@
+"""csrc/conv_p2.hip -- the two-blocks-per-CU 3x3 convolution over one bf16 source (32-channel chunks double-buffered in LDS) --
+against plain torch on the same bf16-rounded operands: nn.Conv2d forward with bias + ReLU (VGG19, networks.py:201-233), the data
+gradient of such a convolution with the ReLU mask of its input (mode 1), and the data gradient of the SPADE
+(conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118); K of 64 .. 544 (2 .. 17 chunks),
+128 / 256 / 64 / 192 columns (4-tile passes, a 2-tile pass, both), extents that are not multiples of the 16x16 tile, more tiles
+than resident blocks, bf16 and fp32 outputs, channel slices of wider tensors."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf(t):
+    return t.to(torch.bfloat16).float()
+
+
+@pytest.mark.parametrize("Cin,Cout,N,H,W,out_bf16", [(64, 128, 1, 250, 270, True), (128, 256, 2, 40, 56, True), (256, 64, 1, 33, 47, False),
+                                                      (96, 192, 1, 64, 48, True), (512, 128, 1, 24, 32, False)])
+def test_forward_bias_relu_matches_torch(Cin, Cout, N, H, W, out_bf16):
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(Cin + Cout)
+    xall = torch.randn(N, H, W, Cin + 32, generator=g).to(torch.bfloat16).cuda()          # a channel slice of a wider tensor
+    x = ops.Act(xall, Cin, 32)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    oall = torch.full((N, H, W, Cout + 16), 7.0, device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    out = ops.Act(oall, Cout, 8)
+    T.conv_p2(x, T.conv_p2_pack(0, w, None, Cin, Cout), Cout, out, bias=b, act=ops.ACT_RELU, name="t")
+    torch.cuda.synchronize()
+    want = F.relu(F.conv2d(xall[..., 32:].float().permute(0, 3, 1, 2), _bf(w), b, padding=1)).permute(0, 2, 3, 1)
+    got = oall[..., 8:8 + Cout].float()
+    tol = (want.abs() * 2 ** -8 if out_bf16 else 0.0) + 2e-4 * float(want.abs().max())
+    assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+    assert bool((oall[..., :8] == 7.0).all()) and bool((oall[..., 8 + Cout:] == 7.0).all())      # neighbours untouched
+
+
+@pytest.mark.parametrize("Ck,Ccol,N,H,W,out_bf16,masked", [(128, 64, 1, 70, 50, True, True), (256, 128, 1, 48, 40, True, True),
+                                                            (64, 128, 2, 32, 48, False, False), (128, 256, 1, 40, 24, True, True)])
+def test_data_gradient_with_relu_mask_matches_torch(Ck, Ccol, N, H, W, out_bf16, masked):
+    """dX = conv^T(dY) * relu'(x): the forward layer maps Ccol -> Ck channels (VGG19's backward, vgg.py)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(Ck * 3 + Ccol)
+    dy_t = torch.randn(N, H, W, Ck, generator=g).to(torch.bfloat16).cuda()
+    w = (torch.randn(Ck, Ccol, 3, 3, generator=g) * 0.05).cuda()
+    xin = torch.relu(torch.randn(N, H, W, Ccol, generator=g)).to(torch.bfloat16).cuda()
+    out = ops.alloc(N, H, W, Ccol, "cuda", bf16=out_bf16)
+    T.conv_p2(ops.Act(dy_t, Ck), T.conv_p2_pack(1, w, None, Ck, Ccol), Ccol, out, mask=ops.Act(xin, Ccol) if masked else None, mask_slope=0.0,
+              name="t")
+    torch.cuda.synchronize()
+    want = F.conv_transpose2d(dy_t.float().permute(0, 3, 1, 2), _bf(w), padding=1).permute(0, 2, 3, 1)
+    if masked:
+        want = want * (xin.float() > 0)
+    got = out.t[..., :Ccol].float()
+    tol = (want.abs() * 2 ** -8 if out_bf16 else 0.0) + 3e-4 * float(want.abs().max())
+    assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("C_,N,H,W,cs_mult,out_bf16", [(80, 1, 250, 270, 3, True), (144, 1, 96, 112, 1, True), (32, 1, 40, 48, 1, False),
+                                                         (272, 1, 24, 32, 2, True), (64, 2, 64, 80, 1, True)])
+def test_pair_data_gradient_matches_torch(C_, N, H, W, cs_mult, out_bf16):
+    """d(actv) = conv^T([dgamma | dbeta]) * relu'(actv) (the shapes of tests/test_gpu_spade_gb.py's data-gradient cases)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(C_)
+    hid = 128
+    actv_all = torch.relu(torch.randn(N, H, W, hid * cs_mult, generator=g)).to(torch.bfloat16).cuda()
+    actv = ops.Act(actv_all, hid, hid * (cs_mult - 1))
+    wg = (torch.randn(C_, hid, 3, 3, generator=g) * 0.03).cuda()
+    wb = (torch.randn(C_, hid, 3, 3, generator=g) * 0.03).cuda()
+    dgb_t = torch.randn(N, H, W, 2 * C_, generator=g).to(torch.bfloat16).cuda()
+    dact_all = torch.full((N, H, W, hid * cs_mult), 7.0, device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    dact = ops.Act(dact_all, hid, hid * (cs_mult - 1))
+    T.conv_p2(ops.Act(dgb_t, 2 * C_), T.conv_p2_pack(2, wg, wb, 2 * C_, hid), hid, dact, mask=actv, mask_slope=0.0, name="t")
+    torch.cuda.synchronize()
+    dy = dgb_t.float().permute(0, 3, 1, 2)
+    want = (F.conv_transpose2d(dy[:, :C_], _bf(wg), padding=1) + F.conv_transpose2d(dy[:, C_:], _bf(wb), padding=1))
+    want = (want * (actv.t[..., actv.coff:actv.coff + hid].float() > 0).permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
+    got = dact_all[..., dact.coff:dact.coff + hid].float()
+    tol = (want.abs() * 2 ** -8 if out_bf16 else 0.0) + 3e-4 * float(want.abs().max())
+    assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+    if cs_mult > 1:
+        assert bool((dact_all[..., :dact.coff] == 7.0).all())
+
+
+def test_training_convs_route_through_the_kernel_and_match_the_generic_tiles(monkeypatch):
+    """train_ops.conv_forward_dev / conv_dgrad pick the kernel for plain 3x3 bf16 layers with >= 2 tiles per CU (HRV_CONV_P2=0:
+    the generic patch tiles); both agree to accumulation-order noise on a VGG-like layer."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    T.MMA_BF16[0] = True
+    try:
+        g = torch.Generator().manual_seed(5)
+        N, H, W, Cin, Cout = 2, 256, 272, 128, 128                     # 2 x 16 x 17 = 544 tiles
+        x = ops.Act(torch.relu(torch.randn(N, H, W, Cin, generator=g)).to(torch.bfloat16).cuda(), Cin)
+        w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.03).cuda()
+        b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+        dy = ops.Act(torch.randn(N, H, W, Cout, generator=g).to(torch.bfloat16).cuda(), Cout)
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HRV_CONV_P2", flag)
+            y = T.conv_forward_dev(w, [(x, 0)], 1, 1, shift=b, act=ops.ACT_RELU, out_bf16=True, name="l")
+            dx = T.conv_dgrad(dy, w, H, W, 1, 1, act_mask=x, slope=0.0, out_bf16=True, name="l.dgrad")
+            torch.cuda.synchronize()
+            res[flag] = (y.t.float().clone(), dx.t.float().clone())
+        for a, b_ in zip(res["1"], res["0"]):
+            assert float((a - b_).abs().max()) <= 2 ** -7 * float(b_.abs().max())
+    finally:
+        T.MMA_BF16[0] = False
