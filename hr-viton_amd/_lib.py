@@ -209,6 +209,7 @@ SYMBOLS = {
     "hrv_instnorm_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
     "hrv_instnorm_stats_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
                                               _vp]),
+    "hrv_instnorm_stats2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hrv_instnorm_stats_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
                                                _vp]),
     "hrv_instnorm_apply_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32,

@@ -125,6 +125,75 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const StatsParam
   rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
 }
 
+// Two normalisations over the SAME x with different noise terms (a learned-shortcut SPADEResBlock: norm_0 and norm_s both
+// normalise the block input, network_generator.py:158-166): x is read ONCE, both shifted partial sums keep the single
+// kernel's summation order (same loop, one chain per statistic) -- bit-identical to two separate passes.
+struct Stats2Params {
+  StatsParams a;          // x, geometry, z / ns / part of the first norm
+  const float* z2;
+  const float* ns2;
+  float* part2;
+};
+
+__global__ __launch_bounds__(256) void instnorm_partial2_kernel(const Stats2Params q) {
+  __shared__ f32x4 red[4][256];
+  const StatsParams& p = q.a;
+  const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+  const int HW = p.H * p.W;
+  const int PB = (HW + p.NB - 1) / p.NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, HW);
+  const int GB = p.C4 < NORM_GCAP ? p.C4 : NORM_GCAP;
+  const int R = 256 / GB;
+  const int r = t / GB, gl = t - r * GB;
+  const int g = blockIdx.z * GB + gl;
+  const bool active = r < R && g < p.C4;
+  f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f), u1 = (f32x4)(0.f), u2 = (f32x4)(0.f);
+  if (active) {
+    const f32x4 na = *reinterpret_cast<const f32x4*>(p.ns + g * 4), nb = *reinterpret_cast<const f32x4*>(q.ns2 + g * 4);
+    auto val = [&](int pix, f32x4& va, f32x4& vb) {
+      const f32x4 x = *reinterpret_cast<const f32x4*>(p.x + ((size_t)n * HW + pix) * p.cs + p.co + g * 4);
+      const int h = pix / p.W, w = pix - h * p.W;
+      const size_t zi = ((size_t)n * p.W + w) * p.H + h;
+      va = x + p.z[zi] * na;
+      vb = x + q.z2[zi] * nb;
+    };
+    f32x4 Ka, Kb;
+    val(0, Ka, Kb);
+    int px = p0 + r;
+    for (; px + 3 * R < p1; px += 4 * R) {
+      f32x4 da[4], db[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        val(px + u * R, da[u], db[u]);
+        da[u] -= Ka;
+        db[u] -= Kb;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { s1 += da[u]; s2 += da[u] * da[u]; u1 += db[u]; u2 += db[u] * db[u]; }
+    }
+    for (; px < p1; px += R) {
+      f32x4 da, db;
+      val(px, da, db);
+      da -= Ka; db -= Kb;
+      s1 += da; s2 += da * da; u1 += db; u2 += db * db;
+    }
+  }
+  red[0][t] = s1; red[1][t] = s2; red[2][t] = u1; red[3][t] = u2;
+  __syncthreads();
+  if (r == 0 && g < p.C4) {
+    for (int rr = 1; rr < R; ++rr) {
+      s1 += red[0][rr * GB + gl]; s2 += red[1][rr * GB + gl];
+      u1 += red[2][rr * GB + gl]; u2 += red[3][rr * GB + gl];
+    }
+    const size_t o = (((size_t)n * p.NB + b) * p.C4 * 4 + g * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      p.part[o + 2 * e] = s1[e]; p.part[o + 2 * e + 1] = s2[e];
+      q.part2[o + 2 * e] = u1[e]; q.part2[o + 2 * e + 1] = u2[e];
+    }
+  }
+}
+
 // out = lrelu((x - mean) * rstd)   (InstanceNorm2d(affine=False) + LeakyReLU(0.2), in place allowed)
 __global__ void instnorm_apply_kernel(const float* __restrict__ x, int N, int HW, int C4, int cs, int co,
                                       const float* __restrict__ mean, const float* __restrict__ rstd, int act,
@@ -205,6 +274,34 @@ static int instnorm_stats_impl(const void* x, int32_t N, int32_t H, int32_t W, i
   int rc = check_launch("instnorm_partial_kernel");
   if (rc) return rc;
   hipLaunchKernelGGL(instnorm_finalize_kernel<BF>, dim3((N * C + 3) / 4), dim3(256), 0, st, p, eps, mean, rstd);
+  return check_launch("instnorm_finalize_kernel");
+}
+
+extern "C" int hrv_instnorm_stats2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
+                                            const float* z_a, const float* ns_a, const float* z_b, const float* ns_b, float eps,
+                                            float* workspace, float* mean_a, float* rstd_a, float* mean_b, float* rstd_b,
+                                            hrv_stream_t stream) {
+  HRV_REQUIRE(x && workspace && mean_a && rstd_a && mean_b && rstd_b && z_a && ns_a && z_b && ns_b && N > 0 && H > 0 && W > 0,
+              "instnorm_stats2: bad args");
+  HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && coff + C <= cstride,
+              "instnorm_stats2: channels must be multiples of 4 and in range");
+  HRV_REQUIRE(((((uintptr_t)x) | (uintptr_t)ns_a | (uintptr_t)ns_b) & 15) == 0, "instnorm_stats2: alignment");
+  Stats2Params q;
+  StatsParams& p = q.a;
+  p.x = x; p.N = N; p.H = H; p.W = W; p.C4 = C / 4; p.cs = cstride; p.co = coff;
+  p.z = z_a; p.ns = ns_a;
+  p.NB = norm_slabs(H * W);
+  p.part = workspace;
+  q.z2 = z_b; q.ns2 = ns_b;
+  q.part2 = workspace + (size_t)N * p.NB * C * 2;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(instnorm_partial2_kernel, dim3(p.NB, N, norm_chunks(p.C4)), dim3(256), 0, st, q);
+  int rc = check_launch("instnorm_partial2_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(instnorm_finalize_kernel<false>, dim3((N * C + 3) / 4), dim3(256), 0, st, p, eps, mean_a, rstd_a);
+  StatsParams pb = p;
+  pb.z = z_b; pb.ns = ns_b; pb.part = q.part2;
+  hipLaunchKernelGGL(instnorm_finalize_kernel<false>, dim3((N * C + 3) / 4), dim3(256), 0, st, pb, eps, mean_b, rstd_b);
   return check_launch("instnorm_finalize_kernel");
 }
 

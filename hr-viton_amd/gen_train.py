@@ -250,17 +250,21 @@ class SpadeT:
         co, c, kh, kw = w.shape
         return w.permute(0, 2, 3, 1), self.shared.bparam.data, c
 
-    def forward(self, x: Act, actv: Optional[Act], z: Optional[torch.Tensor], save: bool = True, fused=None):
+    def forward(self, x: Act, actv: Optional[Act], z: Optional[torch.Tensor], save: bool = True, fused=None, stats=None):
         """``fused`` = (bf16 label map Act [N, H << shift, W << shift, 8], shift): conv_shared + ReLU are computed inside the
         gamma|beta kernel (csrc/spade_fused.hip); ``actv`` is then the slice the kernel WRITES for the backward (None: no_grad
-        forward, actv never reaches HBM)."""
+        forward, actv never reaches HBM).  ``stats`` = (padded noise scale, (mean, rstd)): the statistics were computed together
+        with another norm's over the same x (BlockT.forward, ops.instnorm_stats2)."""
         n = self.norm
         dev = x.t.device
         if fused is not None:
             sg, shift = fused
             zz = z
-            ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)[1] if zz is not None else None
-            mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
+            if stats is not None:
+                ns, (mean, rstd) = stats
+            else:
+                ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)[1] if zz is not None else None
+                mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
             out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=True)
             g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.bfloat16, device=dev) if save else None
             pk = T.spade_fused_pack(self.shared.wparam.data, self.shared.bparam.data, n.conv_gamma.weight.data, n.conv_beta.weight.data)
@@ -271,7 +275,10 @@ class SpadeT:
         # bias of the fused conv in its interleaved (gamma32 | beta32) column order + padded noise scale: one launch
         bc, ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)
         zz = z  # the noise term is always applied in training (noise_scale is a learnable parameter)
-        mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
+        if stats is not None:
+            mean, rstd = stats[1]
+        else:
+            mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
         mb = T.MMA_BF16[0]     # mixed precision: bf16 matrix cores, fp32 epilogue / statistics / x
         cfg = ((8 if self.G % 2 == 0 else 9) if mb else self.cfg)
         if mb:                 # bf16 actv: each tile's halo patch stays in LDS (ops.patch_tile)
@@ -488,13 +495,22 @@ class BlockT:
             segx, actvs = self.shared_forward(seg, seg_shift)
         ai = iter(actvs)
         ctx["segx"] = segx
+        st_s = st_0 = None
         if self.learned:
-            hs, ctx["ns"] = self.ns_.forward(x, next(ai), next(zi), save, fused)
+            z_s, z_0 = next(zi), next(zi)
+            if z_s is not None and z_0 is not None and not x.bf16 and os.environ.get("HRV_STATS2", "1") != "0":
+                # norm_s and norm_0 normalise the same x (network_generator.py:158-166) with their own noise draws: one pass over it
+                ns_s = T.spade_vec_prep(self.ns_.norm.conv_gamma.bias.data, self.ns_.norm.conv_beta.bias.data, self.ns_.norm.noise_scale.data)[1]
+                ns_0 = T.spade_vec_prep(self.n0.norm.conv_gamma.bias.data, self.n0.norm.conv_beta.bias.data, self.n0.norm.noise_scale.data)[1]
+                ms, m0 = ops.instnorm_stats2(x, z_s, ns_s, z_0, ns_0)
+                st_s, st_0 = (ns_s, ms), (ns_0, m0)
+            hs, ctx["ns"] = self.ns_.forward(x, next(ai), z_s, save, fused, st_s)
             x_s = self.cs.forward([(hs, 0)])
             ctx["hs"] = hs
         else:
             x_s = x
-        h0, ctx["n0"] = self.n0.forward(x, next(ai), next(zi), save, fused)
+            z_0 = next(zi)
+        h0, ctx["n0"] = self.n0.forward(x, next(ai), z_0, save, fused, st_0)
         dx = self.c0.forward([(h0, 0)])
         h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi), save, fused)
         # the last block's activated output only feeds conv_img (matrix cores + the sign mask of its data gradient)

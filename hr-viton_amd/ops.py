@@ -436,6 +436,22 @@ def instnorm_stats(a: Act, z: Optional[torch.Tensor] = None, noise_scale: Option
     return mean, rstd
 
 
+def instnorm_stats2(a: Act, z_a: torch.Tensor, ns_a: torch.Tensor, z_b: torch.Tensor, ns_b: torch.Tensor, eps: float = 1e-5):
+    """hrv_instnorm_stats2_nhwc_f32 -> ((mean, rstd), (mean, rstd)) for v = a + z*noise_scale of two norms over the same fp32
+    ``a``: one pass over it (bit-identical to two instnorm_stats calls)."""
+    lib = _lib.load()
+    Cp = a.Cp
+    dev = a.t.device
+    assert not a.bf16 and z_a.is_contiguous() and z_b.is_contiguous() and ns_a.numel() == Cp and ns_b.numel() == Cp
+    ws = torch.empty(2 * lib.hrv_instnorm_workspace_elems(a.N, a.H, a.W, Cp), dtype=torch.float32, device=dev)
+    st = torch.empty((4, a.N, Cp), dtype=torch.float32, device=dev)
+    with _Timed("stats", "instnorm_stats x2", 0.0, 4.0 * a.N * a.H * a.W * Cp):
+        _lib.check(lib.hrv_instnorm_stats2_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, Cp, a.cstride, a.coff, z_a.data_ptr(), ns_a.data_ptr(),
+                                                    z_b.data_ptr(), ns_b.data_ptr(), eps, ws.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),
+                                                    st[2].data_ptr(), st[3].data_ptr(), _stream()), "hrv_instnorm_stats2_nhwc_f32")
+    return (st[0], st[1]), (st[2], st[3])
+
+
 def instnorm_apply(a: Act, mean: torch.Tensor, rstd: torch.Tensor, act: int = ACT_NONE, slope: float = 0.2,
                    out: Optional[Act] = None) -> Act:
     lib = _lib.load()

@@ -436,6 +436,12 @@ int64_t hrv_instnorm_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C)
 int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
                                 int32_t coff, const float* noise_z, const float* noise_scale, float eps,
                                 float* workspace, float* mean, float* rstd, hrv_stream_t stream);
+/* Two normalisations of the SAME x with different noise terms (norm_0 and norm_s of a learned-shortcut SPADEResBlock,
+ * network_generator.py:158-166) in one pass over x; workspace: 2 x hrv_instnorm_workspace_elems floats.  Results are
+ * bit-identical to two hrv_instnorm_stats_nhwc_f32 calls. */
+int hrv_instnorm_stats2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
+                                 const float* z_a, const float* ns_a, const float* z_b, const float* ns_b, float eps, float* workspace,
+                                 float* mean_a, float* rstd_a, float* mean_b, float* rstd_b, hrv_stream_t stream);
 int hrv_instnorm_stats_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
                                  int32_t coff, const float* noise_z, const float* noise_scale, float eps,
                                  float* workspace, float* mean, float* rstd, hrv_stream_t stream);

@@ -414,3 +414,20 @@ def test_conv_bf16_patch_mode(case):
     bad = ops.ConvLayer(rb(torch.randn(64, 96, 3, 3, generator=g)), [96], "cuda", pad=1, name="bad", bf16=True)
     with pytest.raises(Exception):
         bad([(ops.to_nhwc(torch.zeros(1, 96, 16, 16).cuda(), bf16=True), 0, ops.ACT_NONE)], cfg=16)
+
+
+@pytest.mark.parametrize("N,H,W,C", [(2, 37, 29, 80), (1, 130, 70, 144), (1, 9, 7, 1040)])
+def test_dual_noise_instnorm_stats_are_bit_identical_to_two_passes(N, H, W, C):
+    """ops.instnorm_stats2: the statistics of x + z_a*ns_a and x + z_b*ns_b (norm_s / norm_0 of a learned-shortcut SPADEResBlock,
+    network_generator.py:158-166) from ONE pass over x -- same summation order as the single kernel, bit for bit."""
+    ops = _ops()
+    g = torch.Generator().manual_seed(C)
+    x = ops.Act((torch.randn(N, H, W, C, generator=g) * 2 + 0.5).cuda(), C)
+    za, zb = torch.randn(N, W, H, 1, generator=g).cuda(), torch.randn(N, W, H, 1, generator=g).cuda()
+    na, nb = (torch.randn(C, generator=g) * 0.3).cuda(), (torch.randn(C, generator=g) * 0.3).cuda()
+    (ma, ra), (mb, rb) = ops.instnorm_stats2(x, za, na, zb, nb)
+    wa, wb = ops.instnorm_stats(x, za, na), ops.instnorm_stats(x, zb, nb)
+    torch.cuda.synchronize()
+    assert torch.equal(ma, wa[0]) and torch.equal(ra, wa[1]) and torch.equal(mb, wb[0]) and torch.equal(rb, wb[1])
+    v = x.t.permute(0, 3, 1, 2) + za.permute(0, 3, 2, 1) * na.view(1, -1, 1, 1)
+    assert float((ma - v.mean((2, 3))).abs().max()) < 1e-5 and float((ra - (v.var((2, 3), unbiased=False) + 1e-5).rsqrt()).abs().max()) < 1e-4

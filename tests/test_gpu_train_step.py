@@ -171,6 +171,41 @@ def test_vgg_loss_value_and_input_gradient():
         assert _rel(a, b) < 1e-4
 
 
+def test_mixed_precision_vgg_loss_batches_x_and_y_bit_identically(monkeypatch):
+    """Mixed precision with a fresh target: x and y run through VGG19 as ONE batch of 2 N (13 launches instead of 26), the
+    backward over the x half.  Per-image convolutions, pools and taps are independent of the batch they sit in, so loss and
+    input gradient are bit-identical to the two separate passes (HRV_VGG_BATCH=0) -- and within the bf16 tolerance of the oracle."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import train_ops as T
+    from hr_viton_amd.vgg import VGGLoss
+    torch.manual_seed(2)
+    crit = VGGLoss(Namespace(cuda=False))
+    sd = {k: v.detach().clone() for k, v in crit.vgg.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    x = (torch.rand(2, 3, 128, 96, generator=g) * 2 - 1).requires_grad_()
+    y = torch.rand(2, 3, 128, 96, generator=g) * 2 - 1
+    want = O.vgg_loss(sd, x, y)
+    want.backward()
+    crit.cuda()
+    T.MMA_BF16[0] = True
+    try:
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HRV_VGG_BATCH", flag)
+            crit.vgg._ycache = None
+            xc = x.detach().cuda().requires_grad_()
+            got = crit(xc, y.cuda().clone())
+            got.backward()
+            torch.cuda.synchronize()
+            res[flag] = (got.detach().clone(), xc.grad.clone())
+        assert torch.equal(res["1"][0], res["0"][0]) and torch.equal(res["1"][1], res["0"][1])
+        assert abs(res["1"][0].item() - want.item()) < 2e-3 * max(1.0, abs(want.item()))
+        cos = F.cosine_similarity(res["1"][1].cpu().flatten(), x.grad.flatten(), dim=0).item()
+        assert cos > 0.99, cos
+    finally:
+        T.MMA_BF16[0] = False
+
+
 def test_train_generator_script_small_run(tmp_path):
     """The drop-in train_generator.py loop (frozen tocg -> glue -> G step -> D step -> fused Adam) for a few
     steps on a small configuration: finite losses, parameters move, checkpoints are written and reload."""
