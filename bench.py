@@ -513,6 +513,9 @@ def main():
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (0: the config's own)")
     ap.add_argument("--bf16", action="store_true", help="bf16 matrix cores (default for train_generator / tryon_infer)")
     ap.add_argument("--fp32", action="store_true", help="fp32 engine (default for tocg_infer / train_condition)")
+    ap.add_argument("--reserve-cus", type=int, default=-1,
+                    help="CUs the persistent kernels leave free (hrv_set_reserved_cus) for kernels that run concurrently with them: "
+                         "RCCL's collectives under data parallelism.  Default: HRV_RESERVE_CUS or 0")
     ap.add_argument("--graph", action="store_true", help="tryon_infer / train_generator (1 GPU): replay the step as one captured hipGraph")
     args = ap.parse_args()
     mixed = (args.workload in ("train_generator", "tryon_infer") or args.bf16) and not args.fp32
@@ -525,6 +528,9 @@ def main():
     from hr_viton_amd import dist as hdist
     from hr_viton_amd import ops
 
+    if args.reserve_cus >= 0 and args.workload != "stub":
+        from hr_viton_amd import _lib as _hl
+        _hl.check(_hl.load().hrv_set_reserved_cus(args.reserve_cus), "hrv_set_reserved_cus")
     rank, local_rank, world = hdist.init_from_env()      # nccl (= RCCL) unless HRV_DIST_BACKEND overrides it
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch with torch.distributed.run)"
     import torch.distributed as tdist
@@ -568,6 +574,7 @@ def main():
                 "data": "synthetic",
                 "config": {"workload": wl["workload"], "global_batch": wl["B"] * world, "height": H, "width": W,
                            "parallelism": f"dp{world}" + ("-allreduce" if wl["train"] else "-replicas"),
+                           "persistent_grid_cus": int(ops._lib.load().hrv_persistent_cus()),
                            **dist_fields(tdist)},
                 "roofline": roofline_obj(wl, res, north_star=(args.workload in ("train_generator", "tryon_infer"))),
                 "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in sorted(s["kinds"].items())},

@@ -36,6 +36,8 @@ struct WgradTrParams {
   int CinTot, ci_base, ci_real;
   int co_tiles, col_tiles, S;               // col tile = (kernel row kh, group range)
   int gpt;                                  // 32-channel groups per tap = ceil(x_C / 32)
+  int row_mode;                             // 1: a block's column groups are the KW * gpt groups of ONE kernel row (the rest of its
+                                            //    WN * TN group slots idle) -- sources whose width is not 128
   int tiles_per_row, n_tiles;               // 64-pixel row segments
   float* ws;
   float* bias_ws;                           // [S][Cout] column sums of dY (bias gradient), or null
@@ -105,7 +107,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
   const int s = b / p.co_tiles;
   const int co0 = cot * (32 * TM * WM);
   constexpr int NGB = WN * TN;                    // column groups of this block
-  const int gidx0 = ct * NGB;                     // first global group (tap-major: tap * gpt + chunk)
+  const int gidx0 = p.row_mode ? ct * p.KW * p.gpt : ct * NGB;   // first global group (tap-major: tap * gpt + chunk)
   const int tap0 = gidx0 / p.gpt;
   const int kh = PR == 1 ? tap0 / p.KW : 0;       // first kernel row of the patch
   const int chunk_lo = (NGB >= p.gpt) ? 0 : gidx0 % p.gpt;   // first 32-channel chunk staged (whole taps: all of them)
@@ -154,8 +156,12 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     const int gi = gidx0 + wn * TN + j;
-    const int tap = gi / p.gpt, chunk = gi - tap * p.gpt;
-    const int tc = tap < p.KH * p.KW ? tap : 0;                     // groups past the last tap are computed on tap 0 and dropped
+    int tap = gi / p.gpt, chunk = gi - tap * p.gpt;
+    if (p.row_mode && wn * TN + j >= p.KW * p.gpt) tap = p.KH * p.KW;   // an idle slot of a row-aligned block
+    // groups past the last tap (and idle slots) are computed on the first staged tap / chunk and dropped
+    const bool live = tap < p.KH * p.KW;
+    const int tc = live ? tap : kh * p.KW;
+    if (!live) chunk = chunk_lo;
     const int khj = tc / p.KW, kw = tc - khj * p.KW;
     b_tap[j] = tap; b_chunk[j] = chunk;
     b_base[j] = DYB + ((khj - kh) * PXMAX + 8 * (g >> 1) + (i16 >> 2) + kw) * (RX * 16) +
@@ -373,12 +379,24 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   p.n_tiles = N * H * p.tiles_per_row;
   // shape classes:  0 = 128-channel source, a block = the KW taps of one kernel row x all 128 channels x <= 160 couts
   //                 1..3 = thin layers (<= 32 couts, <= 96 source channels): a block = every tap x every channel
+  //                 4..7 = other source widths (round 4): 4: 144 / 160 channels (5 groups), 6: 272 / 288 (9), 7: 256 (8) -- a block =
+  //                        the KW taps of one kernel row x all groups x 64 couts (row mode); 5: 64 channels x 64 couts, every tap
   int cls = -1, tm = 0;
+  p.row_mode = 0;
   if (gpt == 4 && KW == 3) {
     cls = 0;
     p.co_tiles = (Cout + 159) / 160;
     tm = (((Cout + p.co_tiles - 1) / p.co_tiles) + 31) / 32;                     // 1..5
     p.col_tiles = KH * KW * gpt / 12;                                              // WN 4 x TN 3 groups per block
+  } else if (KW == 3 && Cout % 64 == 0 && (gpt == 5 || gpt == 9 || gpt == 8)) {
+    cls = gpt == 5 ? 4 : (gpt == 9 ? 6 : 7);
+    p.row_mode = 1;
+    p.co_tiles = Cout / 64; tm = 2;
+    p.col_tiles = KH;
+  } else if (KW == 3 && Cout % 64 == 0 && gpt == 2) {
+    cls = 5;
+    p.co_tiles = Cout / 64; tm = 2;
+    p.col_tiles = 1;
   } else if (Cout <= 32 && taps * gpt <= 28 && gpt <= 3) {
     cls = gpt == 3 ? (taps == 1 ? 3 : 1) : (gpt == 1 && taps == 9 ? 2 : -1);
     p.co_tiles = 1; p.col_tiles = 1; tm = 1;
@@ -412,6 +430,14 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
       case 5: hipLaunchKernelGGL((conv_wgrad_tr_kernel<5, 3, 1, 4, 4, 1>), dim3(nblk), dim3(256), 0, st, p); break;
       default: return 0;
     }
+  } else if (cls == 4) {      // 3x3 over 144 / 160 channels: 15 groups per kernel row -> 4 waves x 4
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 4, 1, 4, 5, 1>), dim3(nblk), dim3(256), 0, st, p);
+  } else if (cls == 5) {      // 3x3 over 64 channels: 18 groups -> 4 waves x 5, every tap in one block
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 5, 1, 4, 2, 3>), dim3(nblk), dim3(256), 0, st, p);
+  } else if (cls == 6) {      // 3x3 over 272 / 288 channels: 27 groups per kernel row -> 4 waves x 7
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 7, 1, 4, 9, 1>), dim3(nblk), dim3(256), 0, st, p);
+  } else if (cls == 7) {      // 3x3 over 256 channels: 24 groups per kernel row -> 4 waves x 6
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 6, 1, 4, 8, 1>), dim3(nblk), dim3(256), 0, st, p);
   } else if (cls == 1) {      // 3x3 over <= 96 channels: 27 groups -> 4 waves x 7
     hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 7, 1, 4, 3, 3>), dim3(nblk), dim3(256), 0, st, p);
   } else if (cls == 2) {      // 3x3 over 32 channels: 9 groups -> 4 waves x 3

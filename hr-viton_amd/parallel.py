@@ -7,7 +7,12 @@ Replaces the reference's single-process nn.DataParallel wrapper
 
 xGMI is point-to-point (7 links x ~153 GB/s per GPU): buckets are large (default 64 MiB) so each
 ring/direct all-reduce is bandwidth- rather than latency-bound; the 402 MB of generator gradients
-go out as ~7 buckets in reverse-forward order (conv_img / up_4 first, head_0 last)."""
+go out in reverse-forward order (conv_img / up_4 first, head_0 last).  Two refinements for the END of
+the backward, where a collective can no longer hide under compute: a parameter of >= ``big_mb`` (the
+37.7 MB 3x3 weights of head_0 / G_middle / up_0) is a bucket of its own, fired the moment its weight
+gradient exists instead of waiting for its neighbours; and the parameters whose gradients are produced
+LAST (the front of the flat buffer) are cut into a small tail bucket (``tail_mb``), so that what is
+exposed after the last backward kernel is a few MB, not a 64 MiB bucket."""
 from __future__ import annotations
 
 import os
@@ -44,7 +49,7 @@ class _FakeCollective:
 
 class GradSync:
     def __init__(self, params, bucket_mb: float = 64.0, process_group=None, flat: Optional[torch.Tensor] = None,
-                 spans=None):
+                 spans=None, big_mb: float = 16.0, tail_mb: float = 8.0):
         """``flat`` / ``spans`` ([(param, offset, numel)] in buffer order): reduce IN PLACE on the fused optimizer's
         flat gradient buffer (optim.Adam.make_grad_sync) -- the backward plans already produce every gradient in
         its slot there, so a bucket is a contiguous slice of that buffer and nothing is copied on either side of
@@ -59,13 +64,7 @@ class GradSync:
             self.params = [p for p, _, _ in spans]
             # contiguous ranges of the flat buffer, cut back to front: backward finishes the LAST parameters first,
             # so the highest range completes (and is all-reduced) first
-            ranges, hi, n = [], len(spans), 0
-            for i in range(len(spans) - 1, -1, -1):
-                n += spans[i][2]
-                if n > cap and hi - i > 1:
-                    ranges.append((i + 1, hi))
-                    hi, n = i + 1, spans[i][2]
-            ranges.append((0, hi))
+            ranges = self.cut_ranges([sp[2] for sp in spans], cap, int(big_mb * (1 << 20) / 4), int(tail_mb * (1 << 20) / 4))
             for lo, hi in ranges:
                 a = spans[lo][1]
                 bnd = spans[hi - 1][1] + spans[hi - 1][2]
@@ -97,6 +96,39 @@ class GradSync:
             b["pending"] = set(b["params"])
             b["handle"] = None
         self.begin()
+
+    @staticmethod
+    def cut_ranges(sizes: List[int], cap: int, big: int, tail: int) -> List[tuple]:
+        """[lo, hi) index ranges over the parameters in flat-buffer order, listed back to front (= firing order): <= ``cap``
+        elements each; a parameter of >= ``big`` elements alone; the front of the buffer (gradients produced last) closed off
+        as a bucket of <= ``tail`` elements."""
+        ranges, hi, n = [], len(sizes), 0
+        for i in range(len(sizes) - 1, -1, -1):
+            k = sizes[i]
+            if k >= big:                          # its own bucket, fired as soon as its gradient exists
+                if hi > i + 1:
+                    ranges.append((i + 1, hi))
+                ranges.append((i, i + 1))
+                hi, n = i, 0
+                continue
+            n += k
+            if n > cap and hi - i > 1:
+                ranges.append((i + 1, hi))
+                hi, n = i + 1, k
+        if hi > 0:
+            # the last range [0, hi): split off the parameters produced last into a small tail bucket
+            acc, cut = 0, 0
+            for i in range(hi):
+                if acc + sizes[i] > tail:
+                    break
+                acc += sizes[i]
+                cut = i + 1
+            if 0 < cut < hi:
+                ranges.append((cut, hi))
+                ranges.append((0, cut))
+            else:
+                ranges.append((0, hi))
+        return ranges
 
     def begin(self):
         """Start of a backward pass: all buckets empty."""

@@ -523,6 +523,57 @@ def test_wgrad_tr_kernel_bf16_stored_operands(case, monkeypatch):
     assert (res["1"][1] - dbr).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item()
 
 
+@pytest.mark.parametrize("case", [("up3_conv0", 144, 64, 1, 136, 260, False), ("up3_conv1", 64, 64, 2, 128, 160, False),
+                                  ("up2_conv0", 272, 128, 1, 132, 256, False), ("up1_conv1", 256, 256, 1, 130, 264, False),
+                                  ("sliced_160", 160, 64, 1, 128, 288, True), ("up3_conv0_two_cout_blocks", 144, 128, 1, 128, 256, False)],
+                         ids=lambda c: c[0])
+def test_wgrad_tr_kernel_other_source_widths(case, monkeypatch):
+    """conv_wgrad_tr_kernel's row-aligned classes (round 4): 3x3 weight gradients over 144 / 160 / 272 / 256-channel sources (a block =
+    the three taps of one kernel row x every 32-channel group x 64 couts; the last group of 144 / 272 is half empty) and over 64
+    channels (every tap in one block) -- SPADEResBlock.conv_0 / conv_1 of up_1..up_3 (network_generator.py:141-143) -- vs torch's
+    conv2d_weight on the same bf16-representable operands and vs the register-transposing kernel (HRV_WGRAD_TR=0); the bias
+    gradient rides along."""
+    ops, T = _mods()
+    name, cin, cout, N, H, W, wide = case
+    k, pad = 3, 1
+    g = torch.Generator().manual_seed(cout + cin + H)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g))
+    dy = rb(torch.randn(N, cout, H, W, generator=g) * (torch.rand(N, cout, H, W, generator=g) > 0.3))
+
+    def as_act(t):
+        if not wide:
+            return ops.to_nhwc(t.cuda(), bf16=True)
+        C_ = t.shape[1]
+        full = ops.alloc(t.shape[0], t.shape[2], t.shape[3], C_ + 24, "cuda", bf16=True)
+        full.t.normal_()
+        ops.to_nhwc(t.cuda(), out=full.slice(16, C_))
+        return full.slice(16, C_)
+
+    res = {}
+    T.MMA_BF16[0] = True
+    try:
+        for mode in ("1", "0"):
+            monkeypatch.setenv("HRV_WGRAD_TR", mode)
+            dw = torch.full((cout, cin + 8, k, k), 7.0, device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            ops.profile_begin()
+            T.conv_wgrad(as_act(dy), as_act(x), 0, 8, cin + 8, k, k, 1, pad, dw, name=name, dbias=db)
+            ops.profile_end()
+            torch.cuda.synchronize()
+            res[mode] = (dw.cpu(), db.cpu())
+    finally:
+        T.MMA_BF16[0] = False
+    ref = torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dy, stride=1, padding=pad)
+    scale = ref.abs().max().item()
+    got = res["1"][0]
+    assert torch.equal(got[:, :8], torch.full((cout, 8, k, k), 7.0)), "columns outside [ci_base, ci_base+C) must stay untouched"
+    assert (got[:, 8:] - ref).abs().max().item() <= 3e-5 * scale + 1e-5, (got[:, 8:] - ref).abs().max().item() / scale
+    assert (got[:, 8:] - res["0"][0][:, 8:]).abs().max().item() <= 6e-5 * scale
+    dbr = dy.sum((0, 2, 3))
+    assert (res["1"][1] - dbr).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item()
+
+
 @pytest.mark.parametrize("case", [("conv_0", 80, 32, 3, True, False, "none"), ("conv_1", 32, 32, 3, True, True, "lrelu"),
                                   ("conv_s", 80, 32, 1, False, False, "none"), ("conv_img", 32, 3, 3, False, False, "tanh"),
                                   ("vgg_features0", 3, 64, 3, False, False, "relu"), ("vgg_features2", 64, 64, 3, False, True, "relu")],

@@ -108,3 +108,32 @@ def test_gradsync_world2_gloo(inplace):
     assert early0 and early1, "buckets fire during the backward, not only at the end"
     assert w0 == w1, "broadcast_module makes the replicas identical"
     assert world0 == world1 == 2
+
+
+def test_bucket_cut_policy_big_parameters_alone_and_a_small_tail():
+    """GradSync.cut_ranges: ranges cover every parameter exactly once, are listed in firing order (back to front), none but a
+    single oversized parameter exceeds the cap, a parameter of >= big elements is a bucket of its own, and the bucket that
+    completes LAST (the front of the flat buffer) holds at most ``tail`` elements -- the generator's shapes: 37.7 MB
+    head_0 / G_middle weights, 64 MiB cap."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd.parallel import GradSync
+    MB = (1 << 20) // 4
+    big3x3 = 1024 * 1024 * 9                              # 37.7 MB
+    gb = 1024 * 128 * 9                                   # 4.7 MB (conv_gamma / conv_beta of a 1024-channel norm)
+    sizes = ([128 * 7 * 9, 128, gb, 1024, gb, 1024, 1024] * 2 + [big3x3, 1024, big3x3, 1024]) * 3 + [64 * 64 * 9, 64, 3 * 64 * 9, 3]
+    ranges = GradSync.cut_ranges(sizes, 64 * MB, 16 * MB, 8 * MB)
+    covered = sorted(i for lo, hi in ranges for i in range(lo, hi))
+    assert covered == list(range(len(sizes)))
+    assert all(ranges[k][0] == ranges[k + 1][1] for k in range(len(ranges) - 1)) and ranges[0][1] == len(sizes) and ranges[-1][0] == 0
+    for lo, hi in ranges:
+        n = sum(sizes[lo:hi])
+        assert n <= 64 * MB or hi - lo == 1
+        if any(sizes[i] >= 16 * MB for i in range(lo, hi)):
+            assert hi - lo == 1
+    lo, hi = ranges[-1]
+    assert sum(sizes[lo:hi]) <= 8 * MB and hi - lo >= 1
+    # degenerate inputs
+    assert GradSync.cut_ranges([5], 10, 100, 3) == [(0, 1)]
+    assert GradSync.cut_ranges([200, 1, 1], 10, 100, 3) == [(1, 3), (0, 1)]
