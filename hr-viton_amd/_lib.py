@@ -39,7 +39,8 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dx_accumulate", C.c_int32), ("act", C.c_int32), ("act_slope", C.c_float),
                 ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p),
                 ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32), ("dx_bf16", C.c_int32), ("g1p_bf16", C.c_int32),
-                ("dnh_bf16", C.c_int32), ("dout_bf16", C.c_int32)]
+                ("dnh_bf16", C.c_int32), ("dout_bf16", C.c_int32),
+                ("x_up_channels", C.c_int32), ("x2", C.c_void_p), ("x2_cstride", C.c_int32), ("x2_coff", C.c_int32)]
 
 
 class hrv_sn_job_t(C.Structure):
@@ -89,7 +90,8 @@ class hrv_spade_fused_t(C.Structure):
                 ("bias_gamma", C.c_void_p), ("bias_beta", C.c_void_p), ("g1p", C.c_void_p),
                 ("act", C.c_int32), ("act_slope", C.c_float),
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
-                ("actv", C.c_void_p), ("actv_cstride", C.c_int32), ("actv_coff", C.c_int32)]
+                ("actv", C.c_void_p), ("actv_cstride", C.c_int32), ("actv_coff", C.c_int32),
+                ("x_up_channels", C.c_int32), ("x2", C.c_void_p), ("x2_cstride", C.c_int32), ("x2_coff", C.c_int32)]
 
 
 class hrv_conv_p2_t(C.Structure):
@@ -210,6 +212,8 @@ SYMBOLS = {
     "hrv_instnorm_stats_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
                                               _vp]),
     "hrv_instnorm_stats2_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "hrv_instnorm_stats2_up_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _f, _vp,
+                                                  _vp, _vp, _vp, _vp, _vp]),
     "hrv_instnorm_stats_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _f, _vp, _vp, _vp,
                                                _vp]),
     "hrv_instnorm_apply_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32,

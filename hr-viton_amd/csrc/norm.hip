@@ -19,7 +19,23 @@ struct StatsParams {
   const float* ns;  // [C] or null
   int NB;           // pixel slabs per sample
   float* part;      // [N][NB][C4*4][2]
+  // x = cat(nearest_up2(lo), hi) along channels, never materialised (up_g > 0): channel groups [0, up_g) come from `x` =
+  // lo [N][H/2][W/2][cs] at (h >> 1, w >> 1), the others from `x2` = hi [N][H][W][cs2]
+  const float* x2;
+  int cs2, co2, up_g;
 };
+
+// element index of channel group g of pixel (n, pix = h * W + w) in its source tensor; *base receives that tensor
+__device__ __forceinline__ const float* stats_src(const StatsParams& p, int n, int pix, int g) {
+  if (p.up_g > 0) {
+    if (g < p.up_g) {
+      const int h = pix / p.W, w = pix - h * p.W;
+      return p.x + (((size_t)n * (p.H >> 1) + (h >> 1)) * (p.W >> 1) + (w >> 1)) * p.cs + p.co + g * 4;
+    }
+    return p.x2 + ((size_t)n * p.H * p.W + pix) * p.cs2 + p.co2 + (g - p.up_g) * 4;
+  }
+  return p.x + ((size_t)n * p.H * p.W + pix) * p.cs + p.co + g * 4;
+}
 
 typedef unsigned short u16x4 __attribute__((ext_vector_type(4)));
 
@@ -115,7 +131,8 @@ __global__ __launch_bounds__(256) void instnorm_finalize_kernel(const StatsParam
   }
   if (lane != 0) return;
   const size_t k0 = (size_t)n * p.H * p.W * p.cs + p.co + c;
-  float K = BF ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p.x)[k0] << 16) : p.x[k0];
+  float K = BF ? __builtin_bit_cast(float, (unsigned)reinterpret_cast<const unsigned short*>(p.x)[k0] << 16)
+               : (p.up_g > 0 ? stats_src(p, n, 0, c >> 2)[c & 3] : p.x[k0]);
   if (p.z) K += p.z[(size_t)n * p.W * p.H] * p.ns[c];
   const double cnt = (double)p.H * p.W;
   const double m = s1 / cnt;
@@ -150,9 +167,15 @@ __global__ __launch_bounds__(256) void instnorm_partial2_kernel(const Stats2Para
   f32x4 s1 = (f32x4)(0.f), s2 = (f32x4)(0.f), u1 = (f32x4)(0.f), u2 = (f32x4)(0.f);
   if (active) {
     const f32x4 na = *reinterpret_cast<const f32x4*>(p.ns + g * 4), nb = *reinterpret_cast<const f32x4*>(q.ns2 + g * 4);
+    // (the thread's channel group is fixed: its source tensor / stride are resolved once)
+    const bool lo = p.up_g > 0 && g < p.up_g;
+    const bool hi2 = p.up_g > 0 && !lo;
+    const int xcs = hi2 ? p.cs2 : p.cs, Wl = p.W >> 1;
+    const float* const xb = hi2 ? p.x2 + (size_t)n * HW * p.cs2 + p.co2 + (g - p.up_g) * 4
+                                : p.x + (size_t)n * (lo ? (p.H >> 1) * Wl : HW) * p.cs + p.co + g * 4;
     auto val = [&](int pix, f32x4& va, f32x4& vb) {
-      const f32x4 x = *reinterpret_cast<const f32x4*>(p.x + ((size_t)n * HW + pix) * p.cs + p.co + g * 4);
       const int h = pix / p.W, w = pix - h * p.W;
+      const f32x4 x = *reinterpret_cast<const f32x4*>(xb + (size_t)(lo ? (h >> 1) * Wl + (w >> 1) : pix) * xcs);
       const size_t zi = ((size_t)n * p.W + w) * p.H + h;
       va = x + p.z[zi] * na;
       vb = x + q.z2[zi] * nb;
@@ -269,6 +292,7 @@ static int instnorm_stats_impl(const void* x, int32_t N, int32_t H, int32_t W, i
   p.z = noise_z; p.ns = noise_scale;
   p.NB = norm_slabs(H * W);
   p.part = workspace;
+  p.x2 = nullptr; p.cs2 = p.co2 = p.up_g = 0;
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(instnorm_partial_kernel<BF>, dim3(p.NB, N, norm_chunks(p.C4)), dim3(256), 0, st, p);
   int rc = check_launch("instnorm_partial_kernel");
@@ -277,18 +301,25 @@ static int instnorm_stats_impl(const void* x, int32_t N, int32_t H, int32_t W, i
   return check_launch("instnorm_finalize_kernel");
 }
 
-extern "C" int hrv_instnorm_stats2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
-                                            const float* z_a, const float* ns_a, const float* z_b, const float* ns_b, float eps,
-                                            float* workspace, float* mean_a, float* rstd_a, float* mean_b, float* rstd_b,
-                                            hrv_stream_t stream) {
+static int instnorm_stats2_impl(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff, const float* x2,
+                                int32_t cs2, int32_t co2, int32_t up_c, const float* z_a, const float* ns_a, const float* z_b,
+                                const float* ns_b, float eps, float* workspace, float* mean_a, float* rstd_a, float* mean_b, float* rstd_b,
+                                hrv_stream_t stream) {
   HRV_REQUIRE(x && workspace && mean_a && rstd_a && mean_b && rstd_b && z_a && ns_a && z_b && ns_b && N > 0 && H > 0 && W > 0,
               "instnorm_stats2: bad args");
-  HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && coff + C <= cstride,
-              "instnorm_stats2: channels must be multiples of 4 and in range");
+  HRV_REQUIRE(C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0, "instnorm_stats2: channels must be multiples of 4");
+  if (up_c > 0) {
+    HRV_REQUIRE(x2 && up_c % 4 == 0 && up_c < C && H % 2 == 0 && W % 2 == 0 && coff + up_c <= cstride && cs2 % 4 == 0 && co2 % 4 == 0 &&
+                    co2 + (C - up_c) <= cs2 && ((uintptr_t)x2 & 15) == 0,
+                "instnorm_stats2: upsampled source (up_c %d of C %d, %d x %d)", up_c, C, H, W);
+  } else {
+    HRV_REQUIRE(coff + C <= cstride, "instnorm_stats2: slice out of range");
+  }
   HRV_REQUIRE(((((uintptr_t)x) | (uintptr_t)ns_a | (uintptr_t)ns_b) & 15) == 0, "instnorm_stats2: alignment");
   Stats2Params q;
   StatsParams& p = q.a;
   p.x = x; p.N = N; p.H = H; p.W = W; p.C4 = C / 4; p.cs = cstride; p.co = coff;
+  p.x2 = x2; p.cs2 = cs2; p.co2 = co2; p.up_g = up_c / 4;
   p.z = z_a; p.ns = ns_a;
   p.NB = norm_slabs(H * W);
   p.part = workspace;
@@ -303,6 +334,23 @@ extern "C" int hrv_instnorm_stats2_nhwc_f32(const float* x, int32_t N, int32_t H
   pb.z = z_b; pb.ns = ns_b; pb.part = q.part2;
   hipLaunchKernelGGL(instnorm_finalize_kernel<false>, dim3((N * C + 3) / 4), dim3(256), 0, st, pb, eps, mean_b, rstd_b);
   return check_launch("instnorm_finalize_kernel");
+}
+
+extern "C" int hrv_instnorm_stats2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
+                                            const float* z_a, const float* ns_a, const float* z_b, const float* ns_b, float eps,
+                                            float* workspace, float* mean_a, float* rstd_a, float* mean_b, float* rstd_b,
+                                            hrv_stream_t stream) {
+  return instnorm_stats2_impl(x, N, H, W, C, cstride, coff, nullptr, 0, 0, 0, z_a, ns_a, z_b, ns_b, eps, workspace, mean_a, rstd_a, mean_b,
+                              rstd_b, stream);
+}
+
+extern "C" int hrv_instnorm_stats2_up_nhwc_f32(const float* lo, int32_t lo_cstride, int32_t lo_coff, int32_t up_channels, const float* hi,
+                                               int32_t hi_cstride, int32_t hi_coff, int32_t N, int32_t H, int32_t W, int32_t C, const float* z_a,
+                                               const float* ns_a, const float* z_b, const float* ns_b, float eps, float* workspace,
+                                               float* mean_a, float* rstd_a, float* mean_b, float* rstd_b, hrv_stream_t stream) {
+  HRV_REQUIRE(up_channels > 0, "instnorm_stats2_up: up_channels");
+  return instnorm_stats2_impl(lo, N, H, W, C, lo_cstride, lo_coff, hi, hi_cstride, hi_coff, up_channels, z_a, ns_a, z_b, ns_b, eps, workspace,
+                              mean_a, rstd_a, mean_b, rstd_b, stream);
 }
 
 extern "C" int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C,

@@ -79,6 +79,9 @@ struct GfParams {
   unsigned woff[GF_MAXP];   // byte offset of the pass's k-tile stream in the packed weights
   int m_tiles;
   const float* sx; int sx_cs, sx_co, sx_f32, sC;
+  // x = cat(nearest_up2(lo), hi), never materialised (sx_up_c > 0, fp32): channels [0, sx_up_c) from sx = lo [N][H/2][W/2][sx_cs]
+  // at (y >> 1, x >> 1), the others from sx2 = hi [N][H][W][sx2_cs]
+  const float* sx2; int sx2_cs, sx2_co, sx_up_c;
   const float *smean, *srstd, *sz, *sns, *bg, *bb;
   void* g1p;
   int act; float slope;
@@ -610,13 +613,14 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   const size_t img_px = (size_t)p.H * p.W;
   // this lane's two pixels (tile rows 4 w + (l31 >> 4) and + 2)
   const int tye = 4 * wave + (l31e >> 4), pxe = pt_x0 + (l31e & 15);
-  int pidx[2];
+  int pidx[2], pidx_lo[2];
   bool pix_ok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int py = pt_y0 + tye + 2 * i;
     pix_ok[i] = py < p.H && pxe < p.W;
     pidx[i] = pix_ok[i] ? (pt_n * p.H + py) * p.W + pxe : 0;
+    pidx_lo[i] = pix_ok[i] ? (pt_n * (p.H >> 1) + (py >> 1)) * (p.W >> 1) + (pxe >> 1) : 0;
   }
   // Stores go through buffer resources of this tile's IMAGE (32-bit byte offsets; an out-of-image row gets an offset
   // beyond num_records and the hardware drops the store: no branches, no 64-bit address arithmetic)
@@ -674,7 +678,16 @@ __device__ __forceinline__ void gf_pass(const GfParams& p, const int pass, unsig
   // x of NG groups of 8 channels starting at local channel lc0, both pixels of the lane
   auto load_x = [&](const int lc0, auto ng_c, f32x4 (&xr)[2][4]) {
     constexpr int NG = decltype(ng_c)::value;
-    if (p.sx_f32) {       // (one branch per group of loads, not one per load)
+    if (p.sx_up_c > 0) {  // the group's channels lie on one side of the split (both are multiples of 16)
+      const bool lo = cb0 + lc0 < p.sx_up_c;
+      const float* const base = lo ? p.sx : p.sx2;
+      const int cs = lo ? p.sx_cs : p.sx2_cs, c0 = lo ? p.sx_co + cb0 + lc0 : p.sx2_co + cb0 + lc0 - p.sx_up_c;
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < NG; ++g)
+          xr[i][g] = ld4e<false>(base, (size_t)(lo ? pidx_lo[i] : pidx[i]) * cs + c0 + 8 * g + 4 * lhe);
+    } else if (p.sx_f32) {       // (one branch per group of loads, not one per load)
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -830,7 +843,14 @@ extern "C" int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t str
   HRV_REQUIRE((d->noise_z == nullptr) == (d->noise_scale == nullptr), "spade_fused: noise_z/noise_scale go together");
   HRV_REQUIRE(d->out_cstride % 8 == 0 && d->out_coff % 8 == 0 && d->out_cstride >= d->out_coff + d->C, "spade_fused: out slice");
   HRV_REQUIRE((int64_t)d->H * d->W * d->out_cstride * 2 < (int64_t)0xFFFFFFF0, "spade_fused: one image of `out` exceeds 4 GB");
-  HRV_REQUIRE(d->x_cstride % 4 == 0 && d->x_coff % 4 == 0 && d->x_coff + d->C <= d->x_cstride, "spade_fused: x slice");
+  if (d->x_up_channels > 0) {
+    HRV_REQUIRE(d->x_f32 && d->x2 && d->x_up_channels % 16 == 0 && d->x_up_channels < d->C && d->H % 2 == 0 && d->W % 2 == 0 &&
+                    d->x_cstride % 4 == 0 && d->x_coff % 4 == 0 && d->x_coff + d->x_up_channels <= d->x_cstride && d->x2_cstride % 4 == 0 &&
+                    d->x2_coff % 4 == 0 && d->x2_coff + (d->C - d->x_up_channels) <= d->x2_cstride && ((uintptr_t)d->x2 & 15) == 0,
+                "spade_fused: upsampled x (%d of %d channels, %d x %d)", d->x_up_channels, d->C, d->H, d->W);
+  } else {
+    HRV_REQUIRE(d->x_cstride % 4 == 0 && d->x_coff % 4 == 0 && d->x_coff + d->C <= d->x_cstride, "spade_fused: x slice");
+  }
   HRV_REQUIRE(d->actv == nullptr || (d->actv_cstride % 8 == 0 && d->actv_coff % 8 == 0 && d->actv_coff + 128 <= d->actv_cstride &&
                                      (int64_t)d->H * d->W * d->actv_cstride * 2 < (int64_t)0xFFFFFFF0),
               "spade_fused: actv slice");
@@ -843,6 +863,7 @@ extern "C" int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t str
   for (int i = 0; i < pl.npass; ++i) { p.ntp[i] = pl.ntp[i]; p.tile0[i] = pl.tile0[i]; p.woff[i] = pl.woff[i]; }
   p.m_tiles = d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16);
   p.sx = (const float*)d->x; p.sx_cs = d->x_cstride; p.sx_co = d->x_coff; p.sx_f32 = d->x_f32; p.sC = d->C;
+  p.sx2 = (const float*)d->x2; p.sx2_cs = d->x2_cstride; p.sx2_co = d->x2_coff; p.sx_up_c = d->x_up_channels;
   p.smean = d->mean; p.srstd = d->rstd; p.sz = d->noise_z; p.sns = d->noise_scale; p.bg = d->bias_gamma; p.bb = d->bias_beta;
   p.g1p = d->g1p;
   p.act = d->act; p.slope = d->act_slope;

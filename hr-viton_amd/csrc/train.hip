@@ -32,8 +32,43 @@ __device__ __forceinline__ float dact(float y, int act, float slope) {
 // Writes dnh (needed again by stage 2), optionally dgb = [dgamma | dbeta] (2C channels) and
 // the partial sums S1 = sum dnh, S2 = sum dnh*nh per (n, slab, c).
 // ---------------------------------------------------------------------------
-struct NormBwdParams {
+// x = cat(nearest_up2(lo), hi) along channels, never materialised (up_g > 0): channel groups [0, up_g) come from `x` = lo
+// [N][H/2][W/2][x_cs] at (h >> 1, w >> 1), the others from `x2` = hi [N][H][W][x2_cs]
+struct XSrc {
   const float* x; int x_cs, x_co;
+  const float* x2; int x2_cs, x2_co, up_g;
+  int H, W;
+};
+// a thread's channel group g is fixed: its source (tensor, stride, low-resolution or not) is resolved once, per pixel only the
+// pixel index differs
+struct XThread {
+  const float* base;      // channel group g of pixel 0 of sample n
+  int cs, lo, W, Wl;
+};
+__device__ __forceinline__ XThread xsrc_thread(const XSrc& s, int n, int g) {
+  XThread t;
+  t.W = s.W; t.Wl = s.W >> 1;
+  t.lo = (s.up_g > 0 && g < s.up_g) ? 1 : 0;
+  if (s.up_g > 0 && !t.lo) {
+    t.cs = s.x2_cs;
+    t.base = s.x2 + (size_t)n * s.H * s.W * s.x2_cs + s.x2_co + (g - s.up_g) * 4;
+  } else {
+    t.cs = s.x_cs;
+    t.base = s.x + (size_t)n * (t.lo ? (s.H >> 1) * (s.W >> 1) : s.H * s.W) * s.x_cs + s.x_co + g * 4;
+  }
+  return t;
+}
+__device__ __forceinline__ const float* xsrc_ptr(const XThread& t, int px) {
+  int q = px;
+  if (t.lo) {
+    const int h = px / t.W, w = px - h * t.W;
+    q = (h >> 1) * t.Wl + (w >> 1);
+  }
+  return t.base + (size_t)q * t.cs;
+}
+
+struct NormBwdParams {
+  XSrc xs;
   const float* z; const float* ns;           // noise (nullable)
   const float* mean; const float* rstd;      // [N][C]
   const float* out; int out_cs, out_co;      // activation output (mask), nullable when act == NONE
@@ -77,6 +112,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
     if (r < R && g < p.C4) {
       const f32x4 mu = ld4(p.mean + (size_t)n * C + g * 4), rs = ld4(p.rstd + (size_t)n * C + g * 4);
       const f32x4 ns4 = p.z ? ld4(p.ns + g * 4) : (f32x4)(0.f);
+      const XThread xt = xsrc_thread(p.xs, n, g);
       // two pixels per iteration: all eight loads of both are requested before the first result is stored (the stores may
       // alias the loads as far as the compiler knows, so a plain loop keeps one pixel's four loads in flight per thread);
       // every value and the order of the two sums are those of the plain loop
@@ -84,7 +120,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
       auto load = [&](int px) {
         In L;
         const size_t pix = (size_t)n * HW + px;
-        L.v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        L.v = ld4(xsrc_ptr(xt, px));
         L.zz = 0.f;
         if (p.z) {
           const int h = px / p.W, w = px - h * p.W;
@@ -180,7 +216,7 @@ __global__ void norm_bwd_finalize_kernel(const float* __restrict__ part, int N, 
 // stage 2: dx = rstd * (dnh - m1 - nh*m2)  (+ optional accumulate into dx), and partial sums of
 // dx*z per (n, slab, c) for the noise_scale gradient.
 struct NormBwd2Params {
-  const float* x; int x_cs, x_co;
+  XSrc xs;
   const float* z; const float* ns;
   const float* mean; const float* rstd; const float* m1; const float* m2;
   const float* dnh; int dn_cs, dn_co; int dnh_bf16;
@@ -206,12 +242,13 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
       const size_t sc = (size_t)n * C + g * 4;
       const f32x4 mu = ld4(p.mean + sc), rs = ld4(p.rstd + sc), a1 = ld4(p.m1 + sc), a2 = ld4(p.m2 + sc);
       const f32x4 ns4 = p.z ? ld4(p.ns + g * 4) : (f32x4)(0.f);
+      const XThread xt = xsrc_thread(p.xs, n, g);
       // two pixels per iteration, loads of both first (see stage 1); values and the order of the sum are unchanged
       struct In { f32x4 v, dn, acc; float zz; };
       auto load = [&](int px) {
         In L;
         const size_t pix = (size_t)n * HW + px;
-        L.v = ld4(p.x + pix * p.x_cs + p.x_co + g * 4);
+        L.v = ld4(xsrc_ptr(xt, px));
         L.zz = 0.f;
         if (p.z) {
           const int h = px / p.W, w = px - h * p.W;
@@ -928,8 +965,17 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   float* m1 = part + (size_t)d->N * nb * C * 2;
   float* m2 = m1 + (size_t)d->N * C;
   hipStream_t st = (hipStream_t)stream;
+  XSrc xs;
+  xs.x = d->x; xs.x_cs = d->x_cstride; xs.x_co = d->x_coff; xs.H = d->H; xs.W = d->W;
+  xs.x2 = d->x2; xs.x2_cs = d->x2_cstride; xs.x2_co = d->x2_coff; xs.up_g = d->x_up_channels / 4;
+  if (d->x_up_channels > 0) {
+    HRV_REQUIRE(d->x2 && d->x_up_channels % 4 == 0 && d->x_up_channels < C && d->H % 2 == 0 && d->W % 2 == 0 &&
+                    d->x_coff + d->x_up_channels <= d->x_cstride && d->x2_cstride % 4 == 0 && d->x2_coff % 4 == 0 &&
+                    d->x2_coff + (C - d->x_up_channels) <= d->x2_cstride && ((uintptr_t)d->x2 & 15) == 0,
+                "norm_bwd: upsampled source (%d of %d channels, %d x %d)", d->x_up_channels, C, d->H, d->W);
+  }
   NormBwdParams p;
-  p.x = d->x; p.x_cs = d->x_cstride; p.x_co = d->x_coff; p.z = d->noise_z; p.ns = d->noise_scale;
+  p.xs = xs; p.z = d->noise_z; p.ns = d->noise_scale;
   p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
   p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff; p.g1p_bf16 = d->g1p_bf16;
   p.dout = d->dout; p.do_cs = d->dout_cstride; p.do_co = d->dout_coff; p.dout_bf16 = d->dout_bf16;
@@ -944,7 +990,7 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   rc = check_launch("norm_bwd_finalize_kernel");
   if (rc) return rc;
   NormBwd2Params q;
-  q.x = d->x; q.x_cs = d->x_cstride; q.x_co = d->x_coff; q.z = d->noise_z; q.ns = d->noise_scale;
+  q.xs = xs; q.z = d->noise_z; q.ns = d->noise_scale;
   q.mean = d->mean; q.rstd = d->rstd; q.m1 = m1; q.m2 = m2;
   q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff; q.dnh_bf16 = d->dnh_bf16;
   q.dx = d->dx; q.dx_cs = d->dx_cstride; q.dx_co = d->dx_coff; q.accumulate = d->dx_accumulate;

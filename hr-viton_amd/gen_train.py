@@ -421,19 +421,31 @@ class BlockT:
     def norms(self):
         return ([self.ns_] if self.learned else []) + [self.n0, self.n1]
 
+    def _fused_ok(self, N: int, H: int, W: int, x_cstride: int, seg: Act, seg_shift: int) -> bool:
+        if not (T.MMA_BF16[0] and seg.coff == 0 and seg.cstride == 8 and (seg.W >> seg_shift) % 4 == 0 and x_cstride % 4 == 0):
+            return False
+        return all(n_.C % 8 == 0 and n_.Cp == n_.C and n_.norm.conv_shared[0].weight.shape[1] <= 8 and
+                   T.spade_fused_ok(n_.C, n_.hid, n_.norm.conv_shared[0].weight.shape[1], N, H, W) for n_ in self.norms())
+
     def fused_label_map(self, x: Act, seg: Act, seg_shift: int) -> Optional[Act]:
         """The bf16 label map when EVERY norm of this block can run conv_shared inside its gamma|beta kernel (mixed precision,
         csrc/spade_fused.hip: two blocks per CU, actv never read from HBM), else None."""
-        if not (T.MMA_BF16[0] and seg.coff == 0 and seg.cstride == 8 and (seg.W >> seg_shift) % 4 == 0 and x.cstride % 4 == 0):
-            return None
-        norms = self.norms()
-        if not all(n_.C % 8 == 0 and n_.Cp == n_.C and n_.norm.conv_shared[0].weight.shape[1] <= 8 and
-                   T.spade_fused_ok(n_.C, n_.hid, n_.norm.conv_shared[0].weight.shape[1], x.N, x.H, x.W) for n_ in norms):
+        if not self._fused_ok(x.N, x.H, x.W, x.cstride, seg, seg_shift):
             return None
         sg = seg if seg.bf16 else getattr(seg, "_as_bf16", None)          # one cast per step, shared by the blocks
         if sg is None:
             sg = seg._as_bf16 = Act(seg.t.to(torch.bfloat16), seg.C)
         return sg
+
+    def reads_upsampled_input(self, N: int, H: int, W: int, C_in: int, seg: Act, seg_shift: int) -> bool:
+        """This block can read its input as ops.ActUp (never materialised): every reader of x must understand it -- the one-pass
+        statistics of norm_s / norm_0, the fused SPADE forward, the normalisation backward -- i.e. a learned-shortcut block whose
+        norms all run on csrc/spade_fused.hip (mixed precision).  HRV_XUP=0 switches it off (A/B runs)."""
+        if os.environ.get("HRV_XUP", "1") == "0" or os.environ.get("HRV_STATS2", "1") == "0" or not self.learned:
+            return False
+        if H % 2 or W % 2 or (C_in - 16) % 32 != 0 or self.n0.C != C_in or self.ns_.C != C_in:
+            return False
+        return self._fused_ok(N, H, W, 4, seg, seg_shift)
 
     def shared_forward(self, seg: Act, seg_shift: int):
         """The conv_shared 3x3s (label_nc -> 128, + ReLU) of the block's norms as ONE 1x1 convolution over the
@@ -608,6 +620,8 @@ class GeneratorTrainPlan:
             xs = xin_top if shift == 0 else xin
             if j == 0:
                 cur = self.stems[0].forward([(xs, -shift)])
+            elif isinstance(cur, ops.ActUp):
+                self.stems[j].forward([(xs, -shift)], out=cur.hi)
             else:
                 self.stems[j].forward([(xs, -shift)], out=cur.slice(cin - 16, 16))
             k = 3 if blk.learned else 2
@@ -617,9 +631,16 @@ class GeneratorTrainPlan:
                 o, c = blk.forward(cur, sg, shift, zs, None, 0, ACT_LRELU, save)
             else:
                 nxt_c = getattr(gen, self.names[j + 1]).input_nc
-                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)
-                o, c = blk.forward(cur, sg, shift, zs, nxt.slice(0, nxt_c - 16), 1, ACT_NONE, save)
-                o = nxt
+                if self.blocks[j + 1].reads_upsampled_input(N, h * 2, w * 2, nxt_c, sg, shift - 1):
+                    # the next block reads cat(up2(this output), its stem) in place (ops.ActUp): the 4-fold fp32 copy of this
+                    # block's output is never written and its readers fetch a quarter of the bytes
+                    lo = ops.alloc(N, h, w, nxt_c - 16, dev)
+                    _, c = blk.forward(cur, sg, shift, zs, lo, 0, ACT_NONE, save)
+                    o = ops.ActUp(lo, ops.alloc(N, h * 2, w * 2, 16, dev))
+                else:
+                    nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)
+                    o, c = blk.forward(cur, sg, shift, zs, nxt.slice(0, nxt_c - 16), 1, ACT_NONE, save)
+                    o = nxt
             c["shift"] = shift
             ctxs.append(c)
             cur = o

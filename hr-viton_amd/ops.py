@@ -123,6 +123,28 @@ class Act:
         return Act(self.t, c, self.coff + c0)
 
 
+class ActUp:
+    """x = cat(nearest_up2(lo), hi) along channels, NEVER MATERIALISED (SPADEGenerator.up + the concatenation of the resized input,
+    network_generator.py:203,226-242): ``lo`` is the previous block's output [N, H/2, W/2, Clo] (fp32), ``hi`` the stem's 16
+    channels [N, H, W, Chi] (fp32).  Its readers -- the statistics pass, the fused SPADE forward, the normalisation backward
+    (csrc: x_up_channels) -- address channel c < Clo at (y >> 1, x >> 1) of ``lo``: 4 x fewer HBM bytes for those channels
+    than the 4-fold fp32 copy, which is never written."""
+
+    def __init__(self, lo: Act, hi: Act):
+        assert not lo.bf16 and not hi.bf16 and hi.H == 2 * lo.H and hi.W == 2 * lo.W and lo.N == hi.N and lo.C % 16 == 0
+        self.lo, self.hi = lo, hi
+        self.t = hi.t                      # (device / shape holder)
+
+    N = property(lambda self: self.hi.N)
+    H = property(lambda self: self.hi.H)
+    W = property(lambda self: self.hi.W)
+    C = property(lambda self: self.lo.C + self.hi.C)
+    Cp = property(lambda self: self.lo.C + self.hi.C)
+    cstride = property(lambda self: self.lo.C + self.hi.C)
+    coff = 0
+    bf16 = False
+
+
 def alloc(N: int, H: int, W: int, C: int, device, bf16: bool = False) -> Act:
     cs = _cpad(C, bf16)
     dt = torch.bfloat16 if bf16 else torch.float32
@@ -445,6 +467,14 @@ def instnorm_stats2(a: Act, z_a: torch.Tensor, ns_a: torch.Tensor, z_b: torch.Te
     assert not a.bf16 and z_a.is_contiguous() and z_b.is_contiguous() and ns_a.numel() == Cp and ns_b.numel() == Cp
     ws = torch.empty(2 * lib.hrv_instnorm_workspace_elems(a.N, a.H, a.W, Cp), dtype=torch.float32, device=dev)
     st = torch.empty((4, a.N, Cp), dtype=torch.float32, device=dev)
+    if isinstance(a, ActUp):
+        lo, hi = a.lo, a.hi
+        with _Timed("stats", "instnorm_stats x2 [up]", 0.0, 4.0 * a.N * a.H * a.W * (lo.C / 4 + hi.C)):
+            _lib.check(lib.hrv_instnorm_stats2_up_nhwc_f32(lo.t.data_ptr(), lo.cstride, lo.coff, lo.C, hi.t.data_ptr(), hi.cstride, hi.coff,
+                                                           a.N, a.H, a.W, Cp, z_a.data_ptr(), ns_a.data_ptr(), z_b.data_ptr(), ns_b.data_ptr(),
+                                                           eps, ws.data_ptr(), st[0].data_ptr(), st[1].data_ptr(), st[2].data_ptr(),
+                                                           st[3].data_ptr(), _stream()), "hrv_instnorm_stats2_up_nhwc_f32")
+        return (st[0], st[1]), (st[2], st[3])
     with _Timed("stats", "instnorm_stats x2", 0.0, 4.0 * a.N * a.H * a.W * Cp):
         _lib.check(lib.hrv_instnorm_stats2_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, Cp, a.cstride, a.coff, z_a.data_ptr(), ns_a.data_ptr(),
                                                     z_b.data_ptr(), ns_b.data_ptr(), eps, ws.data_ptr(), st[0].data_ptr(), st[1].data_ptr(),

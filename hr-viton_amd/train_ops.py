@@ -603,7 +603,11 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
     ws = torch.empty(lib.hrv_norm_bwd_workspace_elems(N, H, W, Cp), dtype=torch.float32, device=dev)
     d = _lib.hrv_norm_bwd_t()
     d.N, d.H, d.W, d.C = N, H, W, Cp
-    d.x, d.x_cstride, d.x_coff = x.t.data_ptr(), x.cstride, x.coff
+    if isinstance(x, ops.ActUp):
+        d.x, d.x_cstride, d.x_coff = x.lo.t.data_ptr(), x.lo.cstride, x.lo.coff
+        d.x_up_channels, d.x2, d.x2_cstride, d.x2_coff = x.lo.C, x.hi.t.data_ptr(), x.hi.cstride, x.hi.coff
+    else:
+        d.x, d.x_cstride, d.x_coff = x.t.data_ptr(), x.cstride, x.coff
     if z is not None:
         d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
     d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
@@ -1138,7 +1142,13 @@ def spade_fused_forward(seg: Act, seg_shift: int, x: Act, mean: torch.Tensor, rs
     d.N, d.H, d.W, d.C = x.N, x.H, x.W, C_
     d.seg, d.seg_H, d.seg_W, d.seg_shift = seg.t.data_ptr(), seg.H, seg.W, seg_shift
     d.w_packed = packed.data_ptr()
-    d.x, d.x_cstride, d.x_coff, d.x_f32 = x.t.data_ptr(), x.cstride, x.coff, 0 if x.bf16 else 1
+    if isinstance(x, ops.ActUp):
+        d.x, d.x_cstride, d.x_coff, d.x_f32 = x.lo.t.data_ptr(), x.lo.cstride, x.lo.coff, 1
+        d.x_up_channels, d.x2, d.x2_cstride, d.x2_coff = x.lo.C, x.hi.t.data_ptr(), x.hi.cstride, x.hi.coff
+        xbytes = 4.0 * x.N * x.H * x.W * (x.lo.C / 4 + x.hi.C)
+    else:
+        d.x, d.x_cstride, d.x_coff, d.x_f32 = x.t.data_ptr(), x.cstride, x.coff, 0 if x.bf16 else 1
+        xbytes = ops.act_bytes(x)
     d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
     if z is not None:
         d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
@@ -1153,7 +1163,7 @@ def spade_fused_forward(seg: Act, seg_shift: int, x: Act, mean: torch.Tensor, rs
         d.actv, d.actv_cstride, d.actv_coff = actv.t.data_ptr(), actv.cstride, actv.coff
     px = float(x.N * x.H * x.W)
     fl = 2.0 * px * 2 * C_ * 128 * 9          # the gamma|beta convolution (SURVEY 8d work; conv_shared's 2 * 72 * 128 per pixel rides along)
-    nbytes = (px * 16 + (1.5 if g1p is not None else 1.0) * ops.act_bytes(x) + ops.act_bytes(out) + (px * 256 if actv is not None else 0.0) +
+    nbytes = (px * 16 + xbytes + (px * 2.0 * C_ if g1p is not None else 0.0) + ops.act_bytes(out) + (px * 256 if actv is not None else 0.0) +
               2.0 * C_ * 128 * 9 * 2)
     with ops._Timed("conv", name + " [spade_gb]", fl, nbytes):      # (the tag: bench.py prices this kernel family's launches)
         _lib.check(lib.hrv_spade_fused_bf16(C.byref(d), _stream()), "hrv_spade_fused_bf16")

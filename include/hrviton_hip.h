@@ -283,6 +283,11 @@ typedef struct hrv_norm_bwd {
   int32_t dnh_bf16;   /* 1: the stage-1 -> stage-2 intermediate `dnh` is stored as bf16 (mixed precision: half its bytes) */
   int32_t dout_bf16;  /* 1: `dout` is stored as bf16 (mixed precision: the data gradient of a bf16-stored SPADE output, as
                        * autocast hands the gradient of a half-precision convolution input back in half precision) */
+  /* x = cat(nearest_up2(lo), hi) along channels, never materialised (x_up_channels > 0; SPADEGenerator.up + the resized-input
+   * concatenation, network_generator.py:203,226-242): channels [0, x_up_channels) are read from `x` = lo [N][H/2][W/2][x_cstride]
+   * at (h >> 1, w >> 1), the remaining C - x_up_channels from `x2` = hi [N][H][W][x2_cstride] */
+  int32_t x_up_channels;
+  const float* x2;    int32_t x2_cstride, x2_coff;
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 
@@ -442,6 +447,11 @@ int hrv_instnorm_stats_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W,
 int hrv_instnorm_stats2_nhwc_f32(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
                                  const float* z_a, const float* ns_a, const float* z_b, const float* ns_b, float eps, float* workspace,
                                  float* mean_a, float* rstd_a, float* mean_b, float* rstd_b, hrv_stream_t stream);
+/* ... the same over x = cat(nearest_up2(lo), hi) (see hrv_norm_bwd_t: x_up_channels), C = up_channels + channels of hi */
+int hrv_instnorm_stats2_up_nhwc_f32(const float* lo, int32_t lo_cstride, int32_t lo_coff, int32_t up_channels, const float* hi,
+                                    int32_t hi_cstride, int32_t hi_coff, int32_t N, int32_t H, int32_t W, int32_t C, const float* z_a,
+                                    const float* ns_a, const float* z_b, const float* ns_b, float eps, float* workspace, float* mean_a,
+                                    float* rstd_a, float* mean_b, float* rstd_b, hrv_stream_t stream);
 int hrv_instnorm_stats_nhwc_bf16(const uint16_t* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride,
                                  int32_t coff, const float* noise_z, const float* noise_scale, float eps,
                                  float* workspace, float* mean, float* rstd, hrv_stream_t stream);
@@ -724,6 +734,10 @@ typedef struct hrv_spade_fused {
   int32_t act; float act_slope;
   void* out; int32_t out_cstride, out_coff;
   void* actv; int32_t actv_cstride, actv_coff;
+  /* x = cat(nearest_up2(lo), hi), never materialised (x_up_channels > 0, a multiple of 16; x fp32): channels [0, x_up_channels) are read
+   * from `x` = lo [N][H/2][W/2][x_cstride] at (y >> 1, x >> 1), the rest from `x2` = hi [N][H][W][x2_cstride] (see hrv_norm_bwd_t) */
+  int32_t x_up_channels;
+  const void* x2; int32_t x2_cstride, x2_coff;
 } hrv_spade_fused_t;
 int64_t hrv_spade_fused_packed_bytes(int32_t C);   /* -1: norm width not served */
 int hrv_spade_fused_supported(int32_t C, int32_t hid, int32_t label_nc, int32_t N, int32_t H, int32_t W);

@@ -176,3 +176,55 @@ def test_block_through_the_training_plan_fused_vs_unfused(monkeypatch):
         assert float((o2.t.float() - of).abs().max()) == 0.0
     finally:
         T.MMA_BF16[0] = False
+
+
+def test_block_reads_the_upsampled_input_in_place_bit_identically():
+    """ops.ActUp: x = cat(nearest_up2(previous block's output), stem) is never materialised -- the one-pass statistics of norm_s /
+    norm_0, the fused SPADE forward and the normalisation backward address the low-resolution tensor at (y >> 1, x >> 1)
+    (network_generator.py:203,226-242).  Same values in the same order: the block's output, the gradient of its input and every
+    parameter gradient are BIT-IDENTICAL to the run on the materialised 4-fold copy."""
+    from argparse import Namespace
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import gen_train, ops, train_ops as T
+    from hr_viton_amd.network_generator import SPADEResBlock
+    T.MMA_BF16[0] = True
+    try:
+        torch.manual_seed(1)
+        N, H, W = 1, 384, 352
+        opt = Namespace(norm_G="spectralaliasinstance", gen_semantic_nc=7)
+        blk = SPADEResBlock(opt, 144, 64, use_mask_norm=False).cuda()
+        with torch.no_grad():
+            for n_, p_ in blk.named_parameters():
+                if n_.endswith("noise_scale"):
+                    p_.normal_(0, 0.1)
+                elif "conv_gamma.weight" in n_ or "conv_beta.weight" in n_:
+                    p_.mul_(4.0)
+        bt = gen_train.BlockT(blk, "up_3")
+        lab = torch.randint(0, 7, (N, 2 * H, 2 * W, 1), device="cuda")
+        seg = ops.Act(torch.zeros(N, 2 * H, 2 * W, 8, device="cuda").scatter_(3, lab, 1.0), 7)
+        lo = ops.Act(torch.randn(N, H // 2, W // 2, 128, device="cuda"), 128)
+        hi = ops.Act(torch.randn(N, H, W, 16, device="cuda"), 16)
+        full = ops.Act(torch.cat([lo.t.repeat_interleave(2, 1).repeat_interleave(2, 2), hi.t], 3).contiguous(), 144)
+        zs = [torch.randn(N, W, H, 1, device="cuda") for _ in range(3)]
+        dout = ops.Act(torch.randn(N, H, W, 64, device="cuda") * 0.1, 64)
+        assert bt.reads_upsampled_input(N, H, W, 144, seg, 1)
+        res = []
+        for x in (ops.ActUp(lo, hi), full):
+            for p_ in blk.parameters():
+                p_.grad = None
+            T.prepare_convs(bt, bt.convs() + [n_.shared for n_ in bt.norms()], False)
+            o, ctx = bt.forward(x, seg, 1, zs, None, 0, ops.ACT_NONE, save=True)
+            grads = {}
+            d_x = bt.backward(ctx, dout, grads)
+            torch.cuda.synchronize()
+            res.append((o.t.clone(), d_x.t.clone(), {n_: grads[p_].detach().clone() for n_, p_ in blk.named_parameters() if p_ in grads},
+                        ctx["n0"]["mean"].clone(), ctx["ns"]["rstd"].clone()))
+        a, b = res
+        assert torch.equal(a[3], b[3]) and torch.equal(a[4], b[4]), "statistics"
+        assert torch.equal(a[0], b[0]), "block output"
+        assert torch.equal(a[1], b[1]), "gradient of the block input"
+        assert a[2].keys() == b[2].keys()
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), k
+    finally:
+        T.MMA_BF16[0] = False
