@@ -171,6 +171,7 @@ SYMBOLS = {
                                                        _vp, _i64, _vp, _i32, _vp, _i32, _i32, _vp]),
     "hrv_colsum_nhwc_f32": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _i64, _vp, _i32, _vp]),
     "hrv_norm_bwd_workspace_elems": (_i64, [_i32, _i32, _i32, _i32]),
+    "hrv_spade_norm_bwd2_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), C.POINTER(hrv_norm_bwd_t), _vp]),
     "hrv_spade_norm_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_norm_bwd_t), _vp]),
     "hrv_thin_conv_supported": (C.c_int, [_i32, _i32, _i32, _i32]),
     "hrv_thin_conv_bf16": (C.c_int, [C.POINTER(hrv_thin_conv_t), _vp]),

@@ -261,6 +261,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
         return L;
       };
       auto finish = [&](int px, const In& L) {
+#pragma clang fp contract(off)      // (norm_bwd2_stage2_kernel computes the same values in one pass: keep the roundings identical)
         const size_t pix = (size_t)n * HW + px;
         f32x4 v = L.v;
         if (p.z) v += L.zz * ns4;
@@ -291,6 +292,168 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
         *reinterpret_cast<f32x4*>(p.part + ((size_t)n * p.NB + b) * C + g * 4) = sz;
       }
     }
+  }
+}
+
+// ---- two normalisations over the SAME x (norm_0 and norm_s of a learned-shortcut SPADEResBlock both normalise the block
+// input, network_generator.py:158-166): x is read once per stage, dx = dx_a + dx_b is written once (no read-modify-write of
+// the first norm's result).  Every value is computed as in the single kernels (dx: one fp32 add, commutative), so the results
+// are bit-identical to two sequential calls with dx_accumulate on the second.
+__global__ __launch_bounds__(256) void norm_bwd2_stage1_kernel(const NormBwdParams pa, const NormBwdParams pb) {
+  __shared__ f32x4 red[4][256];
+  const NormBwdParams& p = pa;                       // geometry and x are shared
+  const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+  const int HW = p.H * p.W, C = p.C4 * 4;
+  const int PB = (HW + p.NB - 1) / p.NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, HW);
+  const int GB = p.C4 < NORM_GCAP ? p.C4 : NORM_GCAP;
+  const int R = 256 / GB;
+  const int r = t / GB, gl = t - r * GB;
+  const int g = blockIdx.z * GB + gl;
+  f32x4 s1a = (f32x4)(0.f), s2a = (f32x4)(0.f), s1b = (f32x4)(0.f), s2b = (f32x4)(0.f);
+  if (r < R && g < p.C4) {
+    const f32x4 mua = ld4(pa.mean + (size_t)n * C + g * 4), rsa = ld4(pa.rstd + (size_t)n * C + g * 4);
+    const f32x4 mub = ld4(pb.mean + (size_t)n * C + g * 4), rsb = ld4(pb.rstd + (size_t)n * C + g * 4);
+    const f32x4 nsa = pa.z ? ld4(pa.ns + g * 4) : (f32x4)(0.f), nsb = pb.z ? ld4(pb.ns + g * 4) : (f32x4)(0.f);
+    const XThread xt = xsrc_thread(p.xs, n, g);
+    struct In1 { f32x4 d, o, g1; float zz; };
+    struct In { f32x4 v; In1 a, b; };
+    // (the per-norm pieces take their parameter block by reference to the kernel argument itself: no pointer tables, which
+    //  would force the arguments into scratch memory)
+    auto load1 = [&](const NormBwdParams& q, size_t pix, int h, int w) {
+      In1 L;
+      L.zz = q.z ? q.z[((size_t)n * p.W + w) * p.H + h] : 0.f;
+      L.d = q.dout_bf16 ? ld4_bf16(q.dout, pix * q.do_cs + q.do_co + g * 4) : ld4(q.dout + pix * q.do_cs + q.do_co + g * 4);
+      L.o = (f32x4)(0.f);
+      if (q.act != HRV_ACT_NONE) {
+        const size_t oe = pix * q.out_cs + q.out_co + g * 4;
+        L.o = q.out_bf16 ? ld4_bf16(q.out, oe) : ld4(q.out + oe);
+      }
+      L.g1 = (f32x4)(1.f);
+      if (q.g1p) {
+        const size_t ge1 = pix * q.g_cs + q.g_co + g * 4;
+        L.g1 = q.g1p_bf16 ? ld4_bf16(q.g1p, ge1) : ld4(q.g1p + ge1);
+      }
+      return L;
+    };
+    auto load = [&](int px) {
+      In L;
+      const size_t pix = (size_t)n * HW + px;
+      L.v = ld4(xsrc_ptr(xt, px));
+      const int h = px / p.W, w = px - h * p.W;
+      L.a = load1(pa, pix, h, w);
+      L.b = load1(pb, pix, h, w);
+      return L;
+    };
+    auto finish1 = [&](const NormBwdParams& q, size_t pix, f32x4 v, const In1& L, f32x4 mu, f32x4 rs, f32x4 ns4, f32x4& s1, f32x4& s2) {
+      if (q.z) v += L.zz * ns4;
+      const f32x4 nh = (v - mu) * rs;
+      f32x4 dpre = L.d;
+      if (q.act != HRV_ACT_NONE) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) dpre[e] *= dact(L.o[e], q.act, q.slope);
+      }
+      f32x4 dnh = dpre;
+      if (q.g1p) dnh *= L.g1;
+      if (q.dnh_bf16) st4_bf16(q.dnh, pix * q.dn_cs + q.dn_co + g * 4, dnh);
+      else *reinterpret_cast<f32x4*>(q.dnh + pix * q.dn_cs + q.dn_co + g * 4) = dnh;
+      if (q.dgb) {
+        const size_t ge = pix * q.dgb_cs + q.dgb_co + g * 4;
+        if (q.dgb_bf16) {
+          st4_bf16(q.dgb, ge, dpre * nh);
+          st4_bf16(q.dgb, ge + C, dpre);
+        } else {
+          *reinterpret_cast<f32x4*>(q.dgb + ge) = dpre * nh;
+          *reinterpret_cast<f32x4*>(q.dgb + ge + C) = dpre;
+        }
+      }
+      s1 += dnh;
+      s2 += dnh * nh;
+    };
+    auto finish = [&](int px, const In& L) {
+      const size_t pix = (size_t)n * HW + px;
+      finish1(pa, pix, L.v, L.a, mua, rsa, nsa, s1a, s2a);
+      finish1(pb, pix, L.v, L.b, mub, rsb, nsb, s1b, s2b);
+    };
+    // one pixel per iteration: its seven 16-byte loads (x + three per norm) are as many as the single kernel keeps in flight
+    // with two pixels, at half the registers of a two-pixel body (231 -> two waves per SIMD)
+    for (int px = p0 + r; px < p1; px += R) finish(px, load(px));
+  }
+  red[0][t] = s1a; red[1][t] = s2a; red[2][t] = s1b; red[3][t] = s2b;
+  __syncthreads();
+  if (r == 0 && g < p.C4) {
+    for (int rr = 1; rr < R; ++rr) {
+      s1a += red[0][rr * GB + gl]; s2a += red[1][rr * GB + gl];
+      s1b += red[2][rr * GB + gl]; s2b += red[3][rr * GB + gl];
+    }
+    const size_t o = (((size_t)n * p.NB + b) * C + g * 4) * 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      pa.part[o + 2 * e] = s1a[e]; pa.part[o + 2 * e + 1] = s2a[e];
+      pb.part[o + 2 * e] = s1b[e]; pb.part[o + 2 * e + 1] = s2b[e];
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void norm_bwd2_stage2_kernel(const NormBwd2Params pa, const NormBwd2Params pb) {
+  __shared__ f32x4 red[2][256];
+  const NormBwd2Params& p = pa;
+  const int n = blockIdx.y, b = blockIdx.x, t = threadIdx.x;
+  const int HW = p.H * p.W, C = p.C4 * 4;
+  const int PB = (HW + p.NB - 1) / p.NB;
+  const int p0 = b * PB, p1 = min(p0 + PB, HW);
+  const int GB = p.C4 < NORM_GCAP ? p.C4 : NORM_GCAP;
+  const int R = 256 / GB;
+  const int r = t / GB, gl = t - r * GB;
+  const int g = blockIdx.z * GB + gl;
+  f32x4 sza = (f32x4)(0.f), szb = (f32x4)(0.f);
+  if (r < R && g < p.C4) {
+    const size_t sc = (size_t)n * C + g * 4;
+    const f32x4 mua = ld4(pa.mean + sc), rsa = ld4(pa.rstd + sc), a1a = ld4(pa.m1 + sc), a2a = ld4(pa.m2 + sc);
+    const f32x4 mub = ld4(pb.mean + sc), rsb = ld4(pb.rstd + sc), a1b = ld4(pb.m1 + sc), a2b = ld4(pb.m2 + sc);
+    const f32x4 nsa = pa.z ? ld4(pa.ns + g * 4) : (f32x4)(0.f), nsb = pb.z ? ld4(pb.ns + g * 4) : (f32x4)(0.f);
+    const XThread xt = xsrc_thread(p.xs, n, g);
+    struct In { f32x4 v, dna, dnb; float za, zb; };
+    auto load = [&](int px) {
+      In L;
+      const size_t pix = (size_t)n * HW + px;
+      L.v = ld4(xsrc_ptr(xt, px));
+      const int h = px / p.W, w = px - h * p.W;
+      const size_t zi = ((size_t)n * p.W + w) * p.H + h;
+      L.za = pa.z ? pa.z[zi] : 0.f;
+      L.zb = pb.z ? pb.z[zi] : 0.f;
+      const size_t dea = pix * pa.dn_cs + pa.dn_co + g * 4, deb = pix * pb.dn_cs + pb.dn_co + g * 4;
+      L.dna = pa.dnh_bf16 ? ld4_bf16(pa.dnh, dea) : ld4(pa.dnh + dea);
+      L.dnb = pb.dnh_bf16 ? ld4_bf16(pb.dnh, deb) : ld4(pb.dnh + deb);
+      return L;
+    };
+    auto finish = [&](int px, const In& L) {
+#pragma clang fp contract(off)      // (d_a and d_b are rounded products, their sum one add: as the two sequential calls compute them)
+      const size_t pix = (size_t)n * HW + px;
+      f32x4 va = L.v, vb = L.v;
+      if (pa.z) va += L.za * nsa;
+      if (pb.z) vb += L.zb * nsb;
+      const f32x4 nha = (va - mua) * rsa, nhb = (vb - mub) * rsb;
+      const f32x4 da = rsa * (L.dna - a1a - nha * a2a);
+      const f32x4 db = rsb * (L.dnb - a1b - nhb * a2b);
+      sza += da * L.za;
+      szb += db * L.zb;
+      *reinterpret_cast<f32x4*>(p.dx + pix * p.dx_cs + p.dx_co + g * 4) = db + da;
+    };
+    int px = p0 + r;
+    for (; px + R < p1; px += 2 * R) {
+      const In A = load(px), B = load(px + R);
+      finish(px, A);
+      finish(px + R, B);
+    }
+    if (px < p1) finish(px, load(px));
+  }
+  red[0][t] = sza; red[1][t] = szb;
+  __syncthreads();
+  if (r == 0 && g < p.C4) {
+    for (int rr = 1; rr < R; ++rr) { sza += red[0][rr * GB + gl]; szb += red[1][rr * GB + gl]; }
+    if (pa.z) *reinterpret_cast<f32x4*>(pa.part + ((size_t)n * p.NB + b) * C + g * 4) = sza;
+    if (pb.z) *reinterpret_cast<f32x4*>(pb.part + ((size_t)n * p.NB + b) * C + g * 4) = szb;
   }
 }
 
@@ -951,7 +1114,7 @@ extern "C" int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W,
   return (int64_t)N * nb * ((C + 3) / 4 * 4) * 2 + (int64_t)N * ((C + 3) / 4 * 4) * 2;
 }
 
-extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream) {
+static int norm_bwd_check(const hrv_norm_bwd_t* d) {
   HRV_REQUIRE(d && d->x && d->mean && d->rstd && d->dout && d->dnh && d->dx && d->workspace, "norm_bwd: null pointer");
   HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->C > 0 && d->C % 4 == 0, "norm_bwd: extent (C %% 4 == 0)");
   HRV_REQUIRE((d->noise_z == nullptr) == (d->noise_scale == nullptr), "norm_bwd: noise_z/noise_scale go together");
@@ -959,22 +1122,26 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   HRV_REQUIRE(((d->x_cstride | d->x_coff | d->out_cstride | d->out_coff | d->g1p_cstride | d->g1p_coff | d->dout_cstride |
                 d->dout_coff | d->dnh_cstride | d->dnh_coff | d->dgb_cstride | d->dgb_coff | d->dx_cstride | d->dx_coff) & 3) == 0,
               "norm_bwd: strides/offsets must be multiples of 4");
-  const int HW = d->H * d->W, C = d->C;
-  const int nb = norm_slabs(HW);
-  float* part = d->workspace;
-  float* m1 = part + (size_t)d->N * nb * C * 2;
-  float* m2 = m1 + (size_t)d->N * C;
-  hipStream_t st = (hipStream_t)stream;
-  XSrc xs;
-  xs.x = d->x; xs.x_cs = d->x_cstride; xs.x_co = d->x_coff; xs.H = d->H; xs.W = d->W;
-  xs.x2 = d->x2; xs.x2_cs = d->x2_cstride; xs.x2_co = d->x2_coff; xs.up_g = d->x_up_channels / 4;
+  const int C = d->C;
   if (d->x_up_channels > 0) {
     HRV_REQUIRE(d->x2 && d->x_up_channels % 4 == 0 && d->x_up_channels < C && d->H % 2 == 0 && d->W % 2 == 0 &&
                     d->x_coff + d->x_up_channels <= d->x_cstride && d->x2_cstride % 4 == 0 && d->x2_coff % 4 == 0 &&
                     d->x2_coff + (C - d->x_up_channels) <= d->x2_cstride && ((uintptr_t)d->x2 & 15) == 0,
                 "norm_bwd: upsampled source (%d of %d channels, %d x %d)", d->x_up_channels, C, d->H, d->W);
   }
-  NormBwdParams p;
+  HRV_REQUIRE(!(d->dx_bf16 && d->dx_accumulate), "norm_bwd: a bf16 dx cannot be accumulated into");
+  return HRV_OK;
+}
+
+// workspace layout: [N][nb][C][2] slab partials (stage 1; reused as [N][nb][C] by stage 2) | m1 [N][C] | m2 [N][C]
+static void norm_bwd_fill(const hrv_norm_bwd_t* d, NormBwdParams& p, NormBwd2Params& q, float*& m1, float*& m2) {
+  const int C = d->C, nb = norm_slabs(d->H * d->W);
+  float* part = d->workspace;
+  m1 = part + (size_t)d->N * nb * C * 2;
+  m2 = m1 + (size_t)d->N * C;
+  XSrc xs;
+  xs.x = d->x; xs.x_cs = d->x_cstride; xs.x_co = d->x_coff; xs.H = d->H; xs.W = d->W;
+  xs.x2 = d->x2; xs.x2_cs = d->x2_cstride; xs.x2_co = d->x2_coff; xs.up_g = d->x_up_channels / 4;
   p.xs = xs; p.z = d->noise_z; p.ns = d->noise_scale;
   p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
   p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff; p.g1p_bf16 = d->g1p_bf16;
@@ -983,28 +1150,76 @@ extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;
   p.dgb_bf16 = d->dgb_bf16; p.out_bf16 = d->out_bf16;
-  hipLaunchKernelGGL(norm_bwd_stage1_kernel, dim3(nb, d->N, norm_chunks(C / 4)), dim3(256), 0, st, p);
-  int rc = check_launch("norm_bwd_stage1_kernel");
-  if (rc) return rc;
-  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((d->N * C * 16 + 255) / 256), dim3(256), 0, st, part, d->N, nb, C, HW, m1, m2);
-  rc = check_launch("norm_bwd_finalize_kernel");
-  if (rc) return rc;
-  NormBwd2Params q;
   q.xs = xs; q.z = d->noise_z; q.ns = d->noise_scale;
   q.mean = d->mean; q.rstd = d->rstd; q.m1 = m1; q.m2 = m2;
   q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff; q.dnh_bf16 = d->dnh_bf16;
   q.dx = d->dx; q.dx_cs = d->dx_cstride; q.dx_co = d->dx_coff; q.accumulate = d->dx_accumulate;
   q.dx_bf16 = d->dx_bf16;
-  HRV_REQUIRE(!(d->dx_bf16 && d->dx_accumulate), "norm_bwd: a bf16 dx cannot be accumulated into");
-  q.N = d->N; q.H = d->H; q.W = d->W; q.C4 = C / 4; q.NB = nb; q.part = part;  // partials are free again
+  q.N = d->N; q.H = d->H; q.W = d->W; q.C4 = C / 4; q.NB = nb; q.part = part;  // partials are free again in stage 2
+}
+
+extern "C" int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream) {
+  int rc = norm_bwd_check(d);
+  if (rc) return rc;
+  const int HW = d->H * d->W, C = d->C;
+  const int nb = norm_slabs(HW);
+  hipStream_t st = (hipStream_t)stream;
+  NormBwdParams p;
+  NormBwd2Params q;
+  float *m1, *m2;
+  norm_bwd_fill(d, p, q, m1, m2);
+  hipLaunchKernelGGL(norm_bwd_stage1_kernel, dim3(nb, d->N, norm_chunks(C / 4)), dim3(256), 0, st, p);
+  rc = check_launch("norm_bwd_stage1_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((d->N * C * 16 + 255) / 256), dim3(256), 0, st, p.part, d->N, nb, C, HW, m1, m2);
+  rc = check_launch("norm_bwd_finalize_kernel");
+  if (rc) return rc;
   hipLaunchKernelGGL(norm_bwd_stage2_kernel, dim3(nb, d->N, norm_chunks(C / 4)), dim3(256), 0, st, q);
   rc = check_launch("norm_bwd_stage2_kernel");
   if (rc) return rc;
   if (d->noise_z && d->dnoise_scale) {
-    hipLaunchKernelGGL(sum_rows_kernel<>, dim3((C + 15) / 16), dim3(256), 0, st, part, d->N * nb, C, d->dnoise_scale,
+    hipLaunchKernelGGL(sum_rows_kernel<>, dim3((C + 15) / 16), dim3(256), 0, st, p.part, d->N * nb, C, d->dnoise_scale,
                        d->dns_accumulate);
     rc = check_launch("sum_rows_kernel");
   }
+  return rc;
+}
+
+extern "C" int hrv_spade_norm_bwd2_nhwc_f32(const hrv_norm_bwd_t* a, const hrv_norm_bwd_t* b, hrv_stream_t stream) {
+  int rc = norm_bwd_check(a);
+  if (rc) return rc;
+  rc = norm_bwd_check(b);
+  if (rc) return rc;
+  HRV_REQUIRE(a->x == b->x && a->x2 == b->x2 && a->x_cstride == b->x_cstride && a->x_coff == b->x_coff && a->x_up_channels == b->x_up_channels &&
+                  a->N == b->N && a->H == b->H && a->W == b->W && a->C == b->C,
+              "norm_bwd2: both norms must normalise the same x");
+  HRV_REQUIRE(!a->dx_bf16 && !a->dx_accumulate && a->workspace != b->workspace && a->dnh != b->dnh, "norm_bwd2: dx fp32 (written, = dx_a + dx_b); separate scratch");
+  const int HW = a->H * a->W, C = a->C;
+  const int nb = norm_slabs(HW);
+  hipStream_t st = (hipStream_t)stream;
+  NormBwdParams pa, pb;
+  NormBwd2Params qa, qb;
+  float *m1a, *m2a, *m1b, *m2b;
+  norm_bwd_fill(a, pa, qa, m1a, m2a);
+  norm_bwd_fill(b, pb, qb, m1b, m2b);
+  hipLaunchKernelGGL(norm_bwd2_stage1_kernel, dim3(nb, a->N, norm_chunks(C / 4)), dim3(256), 0, st, pa, pb);
+  rc = check_launch("norm_bwd2_stage1_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((a->N * C * 16 + 255) / 256), dim3(256), 0, st, pa.part, a->N, nb, C, HW, m1a, m2a);
+  hipLaunchKernelGGL(norm_bwd_finalize_kernel, dim3((a->N * C * 16 + 255) / 256), dim3(256), 0, st, pb.part, a->N, nb, C, HW, m1b, m2b);
+  rc = check_launch("norm_bwd_finalize_kernel");
+  if (rc) return rc;
+  hipLaunchKernelGGL(norm_bwd2_stage2_kernel, dim3(nb, a->N, norm_chunks(C / 4)), dim3(256), 0, st, qa, qb);
+  rc = check_launch("norm_bwd2_stage2_kernel");
+  if (rc) return rc;
+  const hrv_norm_bwd_t* ds[2] = {a, b};
+  const NormBwdParams* ps[2] = {&pa, &pb};
+  for (int k = 0; k < 2; ++k)
+    if (ds[k]->noise_z && ds[k]->dnoise_scale) {
+      hipLaunchKernelGGL(sum_rows_kernel<>, dim3((C + 15) / 16), dim3(256), 0, st, ps[k]->part, a->N * nb, C, ds[k]->dnoise_scale,
+                         ds[k]->dns_accumulate);
+      rc = check_launch("sum_rows_kernel");
+    }
   return rc;
 }
 

@@ -340,22 +340,31 @@ class SpadeT:
         ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)
         return out, ctx
 
+    def norm_args(self, ctx, dout: Act):
+        """keyword arguments of T.norm_bwd for this norm (without x / dx) + the noise-scale gradient buffer"""
+        n = self.norm
+        dns = None
+        if ctx["z"] is not None:
+            dns = grad_buffer(n.noise_scale) if self.Cp == self.C else torch.empty(self.Cp, device=dout.t.device)
+        return dict(mean=ctx["mean"], rstd=ctx["rstd"], dout=dout, act=self.act, slope=0.2,
+                    out=ctx["out"] if self.act != ACT_NONE else None, g1p=ctx["g1p"], z=ctx["z"],
+                    noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dnoise_scale=dns,
+                    dgb_bf16=ctx["actv"].bf16)   # [dgamma|dbeta] feeds matrix cores only (gb.wgrad, gb.dgrad)
+
     def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool, dact: Act,
                  dx_bf16: bool = False) -> Act:
         """``dact``: this norm's slice of the block-wide d(actv) tensor (the block back-propagates its norms'
         conv_shared together, BlockT.backward)."""
+        a = self.norm_args(ctx, dout)
+        dx, dgb = T.norm_bwd(ctx["x"], dx=dx, dx_accumulate=dx_accumulate, dx_bf16=dx_bf16 and ctx["actv"].bf16, **a)
+        self.after_norm(ctx, dgb, a["dnoise_scale"], grads, dact)
+        return dx
+
+    def after_norm(self, ctx, dgb: Act, dns: Optional[torch.Tensor], grads: Grads, dact: Act):
+        """what follows the normalisation backward: the noise-scale gradient, the gamma|beta weight and data gradients"""
         n = self.norm
         C_, Cp = self.C, self.Cp
-        dev = dout.t.device
-        dns = None
-        if ctx["z"] is not None:
-            dns = grad_buffer(n.noise_scale) if Cp == C_ else torch.empty(Cp, device=dev)
-        dx, dgb = T.norm_bwd(ctx["x"], ctx["mean"], ctx["rstd"], dout, act=self.act, slope=0.2,
-                             out=ctx["out"] if self.act != ACT_NONE else None, g1p=ctx["g1p"], z=ctx["z"],
-                             noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dx=dx,
-                             dx_accumulate=dx_accumulate, dnoise_scale=dns,
-                             dgb_bf16=ctx["actv"].bf16,   # [dgamma|dbeta] feeds matrix cores only (gb.wgrad, gb.dgrad)
-                             dx_bf16=dx_bf16 and ctx["actv"].bf16)
+        dev = dgb.t.device
         if dns is not None:
             _acc(grads, n.noise_scale, dns[:C_])
         else:
@@ -395,7 +404,6 @@ class SpadeT:
             #  parameter pair may be recorded -- train_ops._pack_batched)
             T.conv_dgrad(dgb, wcat, actv.H, actv.W, 1, 1, act_mask=actv, slope=0.0, out=dact, name=self.name + ".gb.dgrad",
                          batch=getattr(self.shared, "pack_batch", None) if Cp == C_ else None)
-        return dx
 
 
 class BlockT:
@@ -549,6 +557,18 @@ class BlockT:
         # that level's matrix-core tensors in bf16
         d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid), dx_bf16=True)
         d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads, dx_bf16=dh16 and ctx["h0"].bf16)
+        if (self.learned and ctx["n0"]["z"] is not None and ctx["ns"]["z"] is not None and not x.bf16 and
+                os.environ.get("HRV_NORM_BWD2", "0") != "0"):
+            # norm_0 and norm_s normalise the same x: one pass per stage over it, dx = dx_0 + dx_s written once (opt-in: bit-identical,
+            # 29 % fewer bytes -- and measured 10-17 % SLOWER than the two sequential calls at up_2..up_4: 168 / 132 registers leave
+            # three waves per SIMD where the single kernels keep four, and capping them at 128 spills)
+            d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads, dx_bf16=dh16 and ctx["hs"].bf16)
+            a0, as_ = self.n0.norm_args(ctx["n0"], d_h0), self.ns_.norm_args(ctx["ns"], d_hs)
+            d_x, dgb0, dgbs = T.norm_bwd2(x, a0, as_)
+            self.n0.after_norm(ctx["n0"], dgb0, a0["dnoise_scale"], grads, dact_all.slice(hid * k0, hid))
+            self.ns_.after_norm(ctx["ns"], dgbs, as_["dnoise_scale"], grads, dact_all.slice(0, hid))
+            self.shared_backward(ctx["segx"], dact_all, grads)
+            return d_x
         d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False, dact_all.slice(hid * k0, hid))
         if self.learned:
             d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads, dx_bf16=dh16 and ctx["hs"].bf16)

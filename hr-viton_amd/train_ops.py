@@ -582,13 +582,9 @@ def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False)
 # ---------------------------------------------------------------------------------------------
 # HBM-bound training kernels (train.hip)
 # ---------------------------------------------------------------------------------------------
-def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int = ACT_NONE, slope: float = 0.2,
-             out: Optional[Act] = None, g1p: Optional[Act] = None, z: Optional[torch.Tensor] = None,
-             noise_scale: Optional[torch.Tensor] = None, want_dgb: bool = False, dx: Optional[Act] = None,
-             dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False,
-             dgb_bf16: bool = False, dx_bf16: bool = False):
-    """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None).  ``dgb_bf16``: store
-    [dgamma | dbeta] in bf16 (mixed precision: only the gamma|beta conv's matrix-core backward reads it)."""
+def _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, want_dgb, dx, dx_accumulate, dnoise_scale, dns_accumulate,
+                   dgb_bf16, dx_bf16):
+    """-> (descriptor, dx Act, dgb Act or None, keep-alive tensors)"""
     lib = _lib.load()
     N, H, W, Cp = x.N, x.H, x.W, x.Cp
     dev = x.t.device
@@ -632,9 +628,37 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
     d.dns_accumulate = 1 if dns_accumulate else 0
     d.dnoise_scale = None if dnoise_scale is None else dnoise_scale.data_ptr()
     d.workspace = ws.data_ptr()
-    with _Timed("norm_bwd", "spade_norm_bwd", 0.0, 4.0 * N * H * W * Cp * (7 + (2 if want_dgb else 0))):
+    return d, dx, dgb, (dnh, ws)
+
+
+def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int = ACT_NONE, slope: float = 0.2,
+             out: Optional[Act] = None, g1p: Optional[Act] = None, z: Optional[torch.Tensor] = None,
+             noise_scale: Optional[torch.Tensor] = None, want_dgb: bool = False, dx: Optional[Act] = None,
+             dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False,
+             dgb_bf16: bool = False, dx_bf16: bool = False):
+    """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None).  ``dgb_bf16``: store
+    [dgamma | dbeta] in bf16 (mixed precision: only the gamma|beta conv's matrix-core backward reads it)."""
+    lib = _lib.load()
+    d, dx, dgb, _keep = _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, want_dgb, dx, dx_accumulate, dnoise_scale,
+                                       dns_accumulate, dgb_bf16, dx_bf16)
+    with _Timed("norm_bwd", "spade_norm_bwd", 0.0, 4.0 * x.N * x.H * x.W * x.Cp * (7 + (2 if want_dgb else 0))):
         _lib.check(lib.hrv_spade_norm_bwd_nhwc_f32(C.byref(d), _stream()), "hrv_spade_norm_bwd_nhwc_f32")
     return dx, dgb
+
+
+def norm_bwd2(x: Act, a: dict, b: dict):
+    """Two normalisations of the same x in one pass per stage (hrv_spade_norm_bwd2_nhwc_f32): ``a`` / ``b`` hold the keyword
+    arguments of norm_bwd except x / dx / dx_accumulate.  Returns (dx = dx_a + dx_b (fp32), dgb_a, dgb_b)."""
+    lib = _lib.load()
+    da, dx, dgb_a, _ka = _norm_bwd_desc(x, a["mean"], a["rstd"], a["dout"], a.get("act", ACT_NONE), a.get("slope", 0.2), a.get("out"), a.get("g1p"),
+                                        a.get("z"), a.get("noise_scale"), a.get("want_dgb", False), None, False, a.get("dnoise_scale"),
+                                        a.get("dns_accumulate", False), a.get("dgb_bf16", False), False)
+    db, _, dgb_b, _kb = _norm_bwd_desc(x, b["mean"], b["rstd"], b["dout"], b.get("act", ACT_NONE), b.get("slope", 0.2), b.get("out"), b.get("g1p"),
+                                       b.get("z"), b.get("noise_scale"), b.get("want_dgb", False), dx, False, b.get("dnoise_scale"),
+                                       b.get("dns_accumulate", False), b.get("dgb_bf16", False), False)
+    with _Timed("norm_bwd", "spade_norm_bwd x2", 0.0, 4.0 * x.N * x.H * x.W * x.Cp * (10 + 2 * (a.get("want_dgb", False) + b.get("want_dgb", False)))):
+        _lib.check(lib.hrv_spade_norm_bwd2_nhwc_f32(C.byref(da), C.byref(db), _stream()), "hrv_spade_norm_bwd2_nhwc_f32")
+    return dx, dgb_a, dgb_b
 
 
 LOSS_L1, LOSS_HINGE_D_FAKE, LOSS_HINGE_D_REAL, LOSS_NEG_MEAN, LOSS_MSE = 0, 1, 2, 3, 4

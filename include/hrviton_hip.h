@@ -310,6 +310,10 @@ typedef struct {
 int hrv_thin_conv_supported(int32_t KH, int32_t KW, int32_t src_channels, int32_t out_columns);
 int hrv_thin_conv_bf16(const hrv_thin_conv_t* d, hrv_stream_t stream);
 int hrv_spade_norm_bwd_nhwc_f32(const hrv_norm_bwd_t* d, hrv_stream_t stream);
+/* Two normalisations of the SAME x (norm_0 and norm_s of a learned-shortcut SPADEResBlock, network_generator.py:158-166) in one
+ * pass per stage: x is read once, a->dx <- dx_a + dx_b is written once (b->dx is ignored); everything else per descriptor.
+ * Bit-identical to hrv_spade_norm_bwd_nhwc_f32(a) followed by (b with dx = a->dx, dx_accumulate = 1). */
+int hrv_spade_norm_bwd2_nhwc_f32(const hrv_norm_bwd_t* a, const hrv_norm_bwd_t* b, hrv_stream_t stream);
 /* Loss value + gradient in one pass.  mode 0: L1 |a-b| (feature matching / VGG,
  * train_generator.py:300-312); 1: hinge-D fake max(1+a,0); 2: hinge-D real max(1-a,0);
  * 3: -a (generator hinge) (network_generator.py:365-376); 4: (a-b)^2 (LSGAN, networks.py:258-299).

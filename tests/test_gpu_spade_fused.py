@@ -228,3 +228,56 @@ def test_block_reads_the_upsampled_input_in_place_bit_identically():
             assert torch.equal(a[2][k], b[2][k]), k
     finally:
         T.MMA_BF16[0] = False
+
+
+@pytest.mark.parametrize("up", [False, True], ids=["materialised_x", "upsampled_in_place"])
+def test_one_pass_backward_of_the_two_norms_over_the_block_input_is_bit_identical(monkeypatch, up):
+    """hrv_spade_norm_bwd2_nhwc_f32: norm_0 and norm_s of a learned-shortcut block normalise the same x -- one pass per stage over
+    it, dx = dx_0 + dx_s written once.  Same values, one commutative fp32 add: the gradient of the block input and every
+    parameter gradient are bit-identical to the two sequential calls (HRV_NORM_BWD2=0, the default: the one-pass form measured
+    slower, see gen_train.BlockT.backward)."""
+    from argparse import Namespace
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import gen_train, ops, train_ops as T
+    from hr_viton_amd.network_generator import SPADEResBlock
+    T.MMA_BF16[0] = True
+    try:
+        torch.manual_seed(2)
+        N, H, W = 1, 384, 352
+        opt = Namespace(norm_G="spectralaliasinstance", gen_semantic_nc=7)
+        blk = SPADEResBlock(opt, 80, 32, use_mask_norm=False).cuda()
+        with torch.no_grad():
+            for n_, p_ in blk.named_parameters():
+                if n_.endswith("noise_scale"):
+                    p_.normal_(0, 0.1)
+        bt = gen_train.BlockT(blk, "up_4")
+        lab = torch.randint(0, 7, (N, H, W, 1), device="cuda")
+        seg = ops.Act(torch.zeros(N, H, W, 8, device="cuda").scatter_(3, lab, 1.0), 7)
+        if up:
+            x = ops.ActUp(ops.Act(torch.randn(N, H // 2, W // 2, 64, device="cuda"), 64), ops.Act(torch.randn(N, H, W, 16, device="cuda"), 16))
+        else:
+            x = ops.Act(torch.randn(N, H, W, 80, device="cuda"), 80)
+        zs = [torch.randn(N, W, H, 1, device="cuda") for _ in range(3)]
+        dout = ops.Act(torch.randn(N, H, W, 32, device="cuda") * 0.1, 32)
+        res = []
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HRV_NORM_BWD2", flag)
+            for p_ in blk.parameters():
+                p_.grad = None
+            T.prepare_convs(bt, bt.convs() + [n_.shared for n_ in bt.norms()], False)
+            ops.profile_begin()
+            o, ctx = bt.forward(x, seg, 0, zs, None, 0, ops.ACT_NONE, save=True)
+            grads = {}
+            d_x = bt.backward(ctx, dout, grads)
+            recs = ops.profile_end()
+            torch.cuda.synchronize()
+            res.append((d_x.t.clone(), {n_: grads[p_].detach().clone() for n_, p_ in blk.named_parameters() if p_ in grads},
+                        [r[1] for r in recs if r[0] == "norm_bwd"]))
+        a, b = res
+        assert a[2].count("spade_norm_bwd x2") == 1 and a[2].count("spade_norm_bwd") == 1 and b[2].count("spade_norm_bwd") == 3, (a[2], b[2])
+        assert torch.equal(a[0], b[0]), "gradient of the block input"
+        assert a[1].keys() == b[1].keys()
+        for k in a[1]:
+            assert torch.equal(a[1][k], b[1][k]), k
+    finally:
+        T.MMA_BF16[0] = False

@@ -13,7 +13,7 @@ bash tools/profile_traffic.sh train_generator > $OUT/profile_traffic.log 2>&1
 cp gpurun_out/traffic_train_generator/*.summary.txt gpurun_out/traffic_train_generator/*.json $OUT/ 2>/dev/null
 # (on the box only: the default run below prices its traffic from the passes just taken; the copy under profiles/ that is
 #  committed afterwards is this same file)
-cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r03_pmc_traffic_train_generator.json 2>/dev/null
+cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r04_pmc_traffic_train_generator.json 2>/dev/null
 timeout 1200 python bench.py --dump-launches $OUT/launches_default.txt 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 cut -c1-300 $OUT/bench_default.json
 b() { name=$1; shift; timeout 400 python bench.py "$@" --no-cpu-baseline --no-extras --dump-launches $OUT/launches_$name.txt 2>$OUT/$name.err | tail -1 > $OUT/$name.json; cut -c1-200 $OUT/$name.json; }
@@ -28,4 +28,12 @@ bash tools/launch_count.sh > $OUT/launch_count.log 2>&1
 cp gpurun_out/launch_count/per_step.txt $OUT/launches_per_iteration.txt 2>/dev/null
 timeout 500 bash tools/dp_overlap.sh > $OUT/dp_overlap.log 2>&1
 cp gpurun_out/dp_overlap/overlap.txt $OUT/dp_overlap.txt 2>/dev/null
+# round 4: the fused SPADE forward / the two-blocks-per-CU convolution against what they replaced, SQ counters of the fused kernel,
+# the cost of leaving CUs to concurrent collectives
+timeout 300 python tools/fused_bench.py 5 > $OUT/fused_bench.txt 2>&1
+timeout 300 python tools/p2_bench.py 5 > $OUT/p2_bench.txt 2>&1
+timeout 400 bash tools/profile_fused.sh > $OUT/profile_fused.log 2>&1
+cp gpurun_out/pmc_fused/sq1.summary.txt $OUT/pmc_fused_sq1.summary.txt 2>/dev/null
+cp gpurun_out/pmc_fused/sq2.summary.txt $OUT/pmc_fused_sq2.summary.txt 2>/dev/null
+for R in 0 8 16; do timeout 300 python bench.py --reserve-cus $R --steps 8 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('reserve-cus $R:', d['ms_per_step'], 'ms/step', d['value'], 'img/s, persistent grid', d['config']['persistent_grid_cus'], 'CUs')"; done > $OUT/reserve_cus.txt 2>&1
 ls -la $OUT | head -40

@@ -7,8 +7,9 @@ import json
 import re
 import sys
 
-CONV = re.compile(r"hrv::(conv_mfma_kernel|conv_wgrad|conv_patchw|spade_gb_kernel|thin_conv)")
-FAMILIES = ("spade_gb_kernel", "conv_mfma_kernel", "conv_wgrad_tr", "conv_wgrad", "thin_conv", "norm_bwd", "instnorm")
+CONV = re.compile(r"hrv::(conv_mfma_kernel|conv_wgrad|conv_patchw|spade_gb_kernel|spade_fused_kernel|conv_p2_kernel|thin_conv)")
+FAMILIES = ("spade_fused_kernel", "conv_p2_kernel", "spade_gb_kernel", "conv_mfma_kernel", "conv_wgrad_tr", "conv_wgrad", "thin_conv", "norm_bwd",
+            "instnorm")
 
 
 def per_kernel(path, counter):
