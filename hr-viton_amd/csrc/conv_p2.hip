@@ -72,7 +72,9 @@ struct P2Plan {
 
 static bool p2_plan(int Cin, int Cout, P2Plan& pl) {
   memset(&pl, 0, sizeof(pl));
-  if (Cin < 32 || Cin % 32 != 0 || Cout < 64 || Cout % 64 != 0) return false;
+  // K runs over 32-channel chunks; a source whose width is 16 off a multiple of 32 (the generator's 144 / 272-channel block inputs)
+  // ends with a half-empty chunk: its upper 16 channels arrive as zeros (out-of-range DMA offsets) against zero weights
+  if (Cin < 32 || Cin % 16 != 0 || Cout < 64 || Cout % 64 != 0) return false;
   const int NT = Cout / 32;
   const int n2 = (NT % 4 == 2) ? 1 : 0;
   const int n4 = (NT - 2 * n2) / 4;
@@ -85,7 +87,7 @@ static bool p2_plan(int Cin, int Cout, P2Plan& pl) {
     pl.tile0[i] = t0;
     t0 += pl.ntp[i];
     pl.woff[i] = (unsigned)off;
-    off += (long long)(Cin / 32) * 9 * pl.ntp[i] * 2048;
+    off += (long long)((Cin + 31) / 32) * 9 * pl.ntp[i] * 2048;
   }
   pl.bytes = off;
   return off < (long long)0xFFFFFFF0;
@@ -168,8 +170,8 @@ __device__ __forceinline__ void p2_patch_piece(const P2Params& p, unsigned char*
   const int P = pp * 16 + (lane >> 2), g = lane & 3;
   const int hy = (P * 3277) >> 16, hx = P - P2_PW * hy;              // P / 20, P % 20 (P < 368)
   const int y = T.y0 - 1 + hy, x = T.x0 - 1 + hx;
-  const bool ok = hy < 18 && hx < 18 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W;
   const int gs = g ^ ((hx >> 2) & 3);
+  const bool ok = hy < 18 && hx < 18 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && chunk * 32 + gs * 8 < p.Cin;
   const unsigned off = ((unsigned)(y * p.W + x) * (unsigned)p.src_cs + (unsigned)(p.src_co + chunk * 32 + gs * 8)) * 2u;
   dma16(a_rsrc, reinterpret_cast<float*>(smem + P2_PATCH_OFF + buf * P2_PBUF + pp * 1024), ok ? off : 0xFFFFFFF0u, 0u);
 }
@@ -526,7 +528,7 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   p.src = d->src; p.src_cs = d->src_cstride; p.src_co = d->src_coff; p.Cin = d->Cin; p.src_bytes = (unsigned)sbytes;
   p.N = d->N; p.H = d->H; p.W = d->W;
   p.wp = d->w_packed; p.w_bytes = (unsigned)pl.bytes;
-  p.npass = pl.npass; p.nchunk = d->Cin / 32;
+  p.npass = pl.npass; p.nchunk = (d->Cin + 31) / 32;
   for (int i = 0; i < pl.npass; ++i) { p.ntp[i] = pl.ntp[i]; p.tile0[i] = pl.tile0[i]; p.woff[i] = pl.woff[i]; }
   p.m_tiles = d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16);
   p.bias = d->bias; p.act = d->act; p.slope = d->act_slope;

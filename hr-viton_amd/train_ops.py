@@ -426,8 +426,10 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
         return _thin_conv(a0, w, 0, sigma, wscale, shift, residual, 0, act, slope, out, name,
                           2.0 * N * Ho * Wo * Cout * cin * KH * KW)
     if (mb and len(srcs) == 1 and up0 == 0 and out_up == 0 and residual is None and (KH, KW, stride, pad) == (3, 3, 1, 1) and a0.bf16 and
-            a0.C == cin and cin % 32 == 0 and Cout % 64 == 0 and w.is_contiguous() and conv_p2_ok(cin, Cout, N, H, W)):
-        # plain 3x3 over one bf16 source: the two-blocks-per-CU kernel (VGG19's 128..512-channel layers)
+            a0.C == cin and cin % 16 == 0 and a0.cstride % 8 == 0 and a0.coff % 8 == 0 and Cout % 64 == 0 and w.is_contiguous() and
+            (out is None or out.cstride % (8 if out.bf16 else 4) == 0) and conv_p2_ok(cin, Cout, N, H, W)):
+        # plain 3x3 over one bf16 source: the two-blocks-per-CU kernel (VGG19's 128..512-channel layers; SPADEResBlock.conv_0 of
+        # up_2 / up_3: 272 -> 128, 144 -> 64)
         if out is None:
             out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16)
         pk = conv_p2_pack(0, w, None, cin, Cout, sigma, wscale, frozen)

@@ -16,7 +16,8 @@ def _bf(t):
 
 
 @pytest.mark.parametrize("Cin,Cout,N,H,W,out_bf16", [(64, 128, 1, 250, 270, True), (128, 256, 2, 40, 56, True), (256, 64, 1, 33, 47, False),
-                                                      (96, 192, 1, 64, 48, True), (512, 128, 1, 24, 32, False)])
+                                                      (96, 192, 1, 64, 48, True), (512, 128, 1, 24, 32, False), (144, 64, 1, 72, 88, False),
+                                                      (272, 128, 1, 40, 48, False), (80, 64, 1, 33, 40, True)])
 def test_forward_bias_relu_matches_torch(Cin, Cout, N, H, W, out_bf16):
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd import ops, train_ops as T
