@@ -490,7 +490,15 @@ extern "C" int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32
   P2Plan pl;
   if (!p2_plan(Cin, Cout, pl)) return 0;
   const int64_t tiles = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16);
-  return tiles >= 2 * (int64_t)persistent_cus() ? 1 : 0;      // two blocks per CU: fewer tiles leave half the slots empty
+  // two blocks per CU; measured down to 1.5 tiles per CU (VGG19's 128 x 96 level at 8 images: 384 tiles, 908 -> 1050+ TF/s) the kernel
+  // still beats the generic tiles, below that they fill the chip better (HRV_CONV_P2_MIN_TILES_X4: threshold in quarter-tiles per CU)
+  static int q4 = -1;
+  if (q4 < 0) {
+    const char* e = getenv("HRV_CONV_P2_MIN_TILES_X4");
+    q4 = e ? atoi(e) : 6;
+    if (q4 < 1) q4 = 6;
+  }
+  return 4 * tiles >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
 
 extern "C" int hrv_conv_p2_pack_dev(int32_t mode, const float* w, const float* w2, int32_t Cin, int32_t Cout, const float* sigma, float wscale,
