@@ -24,6 +24,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -153,12 +155,35 @@ class _SpadePlan:
         cs = norm.conv_shared[0]
         self.label_nc = cs.in_channels
         self.cs = cs      # conv_shared parameters: the owning block batches its norms' 3x3s into one 1x1 (see _BlockPlan)
+        self.norm_params = (norm.conv_gamma.weight, norm.conv_gamma.bias, norm.conv_beta.weight, norm.conv_beta.bias)
+        self._gf = None
         self.mod = SpadeModulate(norm.conv_gamma.weight, norm.conv_gamma.bias, norm.conv_beta.weight,
                                  norm.conv_beta.bias, norm.noise_scale, device, act, name + ".conv_gamma|beta", bf16=bf16)
 
-    def __call__(self, x: Act, actv: Act, z: Optional[torch.Tensor]) -> Act:
+    def fused_ok(self, x: Act, seg: Act) -> bool:
+        """conv_shared can run inside the gamma|beta kernel (csrc/spade_fused.hip: bf16 plan, >= 2 tiles per CU)"""
+        from . import train_ops as T
+        m = self.mod
+        return bool(m.bf16 and m.Cp == m.Creal and seg.bf16 and seg.cstride == 8 and seg.coff == 0 and self.label_nc <= 8 and
+                    x.cstride % 4 == 0 and T.spade_fused_ok(m.Creal, self.cs.out_channels, self.label_nc, x.N, x.H, x.W))
+
+    def __call__(self, x: Act, actv: Optional[Act], z: Optional[torch.Tensor], fused=None) -> Act:
         zz = z if (z is not None and self.mod.has_noise) else None
         mean, rstd = ops.instnorm_stats(x, zz, self.mod.ns if zz is not None else None)
+        if fused is not None:
+            # SPADENorm end to end in one launch: actv = ReLU(conv_shared(label map)) never reaches HBM
+            from . import train_ops as T
+            seg, shift = fused
+            dev = x.t.device
+            if getattr(self, "_gf", None) is None:      # frozen weights: packed once per plan
+                f32 = lambda t: t.detach().to(dev, torch.float32).contiguous()      # noqa: E731
+                n = self.norm_params
+                self._gf = (T.spade_fused_pack(f32(self.cs.weight), f32(self.cs.bias), f32(n[0]), f32(n[2])), f32(n[1]), f32(n[3]))
+            pk, bg, bb = self._gf
+            out = ops.alloc(x.N, x.H, x.W, self.mod.Creal, dev, bf16=True)
+            T.spade_fused_forward(seg, shift, x, mean, rstd, zz, self.mod.ns if zz is not None else None, pk, bg, bb, self.mod.conv.act,
+                                  self.mod.conv.slope, out, None, None, self.mod.conv.name.replace("conv_gamma|beta", "conv_shared+gamma|beta"))
+            return out
         return self.mod(actv, x, mean, rstd, zz)
 
 
@@ -218,6 +243,13 @@ class _BlockPlan:
         """x_s + conv_1(lrelu(norm_1(conv_0(lrelu(norm_0(x)))))) -- network_generator.py:163-173.
         ``zs``: noise draws in the reference's call order (norm_s, norm_0, norm_1)."""
         zi = iter(zs)
+        if os.environ.get("HRV_SPADE_FUSED", "1") != "0" and all(n_.fused_ok(x, seg) for n_ in self.norms):
+            # every norm of the block computes its conv_shared inside its gamma|beta kernel: no conv_shared launch, no actv tensor
+            f = (seg, seg_shift)
+            x_s = self.cs([self.ns_(x, None, next(zi), f)]) if self.learned else x
+            dx = self.c0([self.n0(x, None, next(zi), f)])
+            h1 = self.n1(dx, None, next(zi), f)
+            return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
         # every norm of the block sees the same nearest-resized label map (network_generator.py:112-113)
         actv_all = self.shared([ops.tap_expand(seg, seg_shift, 3)])
         actv = [actv_all.slice(i * self.nh, self.nh) for i in range(len(self.norms))]
