@@ -279,12 +279,13 @@ def wl_generator(ctx, mixed, B, train):
         crit_vgg = VGGLoss(opt).to(dev)
         for m in (gen, dis, crit_vgg):
             broadcast_module(m)
-        graph = bool(ctx["args"].graph and world == 1)      # --graph: the whole iteration replayed as one hipGraph
+        graph = bool(ctx["args"].graph)      # --graph: the whole iteration replayed as one hipGraph (N > 1: three graph segments,
+        #                                       the two gradient all-reduces between them -- hr_viton_amd.graph.GraphedIteration)
         og = Adam(gen.parameters(), lr=opt.G_lr, betas=(0.0, 0.9), device_step=graph)
         od = Adam(dis.parameters(), lr=opt.D_lr, betas=(0.0, 0.9), device_step=graph)
         fake = int(os.environ.get("HRV_FAKE_ALLREDUCE", "0") or 0) > 0     # 1-GPU overlap trace (tools/dp_overlap.sh)
-        sg = og.make_grad_sync() if (world > 1 or fake) else None
-        sd = od.make_grad_sync() if (world > 1 or fake) else None
+        sg = og.make_grad_sync(graph=graph) if (world > 1 or fake) else None
+        sd = od.make_grad_sync(graph=graph) if (world > 1 or fake) else None
         for s_ in (sg, sd):
             if s_ is not None:
                 attach_grad_sync(s_)
@@ -343,7 +344,8 @@ def wl_generator(ctx, mixed, B, train):
                     workload="BASELINE configs[3] (SURVEY 8d config #4, headline): train_generator.py 1024x768, "
                              f"{B} img/GPU, " + ("--fp16 (bf16 MFMA operands, fp32 accumulate)" if mixed else "fp32") +
                              ", SPADE ngf=64 'most' + multiscale-D + VGG/feat-match, random-init weights" +
-                             (" [whole iteration replayed as one hipGraph]" if graph else ""),
+                             (" [whole iteration replayed as " + ("one hipGraph]" if world == 1 else "three hipGraph segments, the gradient "
+                                                                "all-reduces between them]") if graph else ""),
                     traffic_tag="train_generator")
     gen.eval()
 
@@ -529,7 +531,8 @@ def main():
     ap.add_argument("--reserve-cus", type=int, default=-1,
                     help="CUs the persistent kernels leave free (hrv_set_reserved_cus) for kernels that run concurrently with them: "
                          "RCCL's collectives under data parallelism.  Default: HRV_RESERVE_CUS or 0")
-    ap.add_argument("--graph", action="store_true", help="tryon_infer / train_generator (1 GPU): replay the step as one captured hipGraph")
+    ap.add_argument("--graph", action="store_true", help="tryon_infer / train_generator: replay the step as one captured hipGraph (train_generator on N > 1 GPUs: graph "
+                         "segments with the gradient all-reduces between them)")
     args = ap.parse_args()
     mixed = (args.workload in ("train_generator", "tryon_infer") or args.bf16) and not args.fp32
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:

@@ -7,8 +7,8 @@ synchronises -- is recorded once into a hipGraph (``torch.cuda.CUDAGraph`` IS hi
 with one host call per step.  Inputs live in static device buffers that ``__call__`` refreshes; outputs are the
 static tensors the captured step produced (valid until the next replay).
 
-``GraphedTrainStep`` captures a whole train_generator.py iteration the same way (single process: the data-parallel
-bucket all-reduces stay host-driven).  The iteration is GPU-bound (kernel time == wall time), so the replay is
+``GraphedTrainStep`` captures a whole train_generator.py iteration the same way (data parallel: a chain of three graphs with
+the two gradient all-reduces as host calls between them -- GraphedIteration).  The iteration is GPU-bound (kernel time == wall time), so the replay is
 no faster than eager -- it exists so that the launch path is not on the critical path when a future kernel set is faster."""
 from __future__ import annotations
 
@@ -108,30 +108,68 @@ def graphed_condition(opt, tocg, input1: torch.Tensor, input2: torch.Tensor, war
 
 
 class GraphedIteration:
-    """``fn()`` -- a whole training iteration over STATIC device buffers, optimizer steps included -- as one hipGraph.
+    """``fn()`` -- a whole training iteration over STATIC device buffers, optimizer steps included -- as one hipGraph, or, under
+    data-parallel training, as a CHAIN of hipGraphs with the gradient collectives between them.
     ``optimizers``: hr_viton_amd.optim.Adam instances built with ``device_step=True`` (their learning rates are pushed to
-    the device before every replay)."""
+    the device before every replay).  Data parallel: give every optimizer ``make_grad_sync(graph=True)``
+    (parallel.GraphGradSync) -- the capture is cut where an optimizer waits for its gradients (segment | all-reduce of that
+    optimizer's whole flat gradient buffer | segment ...); all segments share one graph memory pool and replay in capture order.
+    The bucketed, backward-overlapped GradSync is host-driven and cannot be captured: refused."""
 
     def __init__(self, fn: Callable[[], object], optimizers, warmup: int = 3):
+        import gc
+        from .parallel import GraphGradSync
         _lib.load()
+        syncs = []
         for o in optimizers:
             if not getattr(o, "device_step", False):
                 raise HrvError("GraphedIteration: build the optimizers with hr_viton_amd.optim.Adam(..., device_step=True)")
-            if getattr(o, "grad_sync", None) is not None:
-                raise HrvError("GraphedIteration: data-parallel gradient synchronisation is host-driven; single process only")
+            gs = getattr(o, "grad_sync", None)
+            if gs is not None and not isinstance(gs, GraphGradSync):
+                raise HrvError("GraphedIteration: the bucketed GradSync is host-driven; under data-parallel training build the "
+                               "synchronisation with optimizer.make_grad_sync(graph=True)")
+            if gs is not None:
+                syncs.append(gs)
         self.optimizers = list(optimizers)
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(max(1, warmup)):          # eager iterations: plans, pack records, flat buffers, device scalars
-                fn()
+                fn()                                 # (a GraphGradSync reduces eagerly here: the replicas stay in lock-step)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.warmup_iterations = max(1, warmup)
-        self.graph = torch.cuda.CUDAGraph()
+        self.graphs = [torch.cuda.CUDAGraph()]
+        self.cuts = []                               # cuts[i]: the GraphGradSync reduced between graphs[i] and graphs[i + 1]
         guard = CaptureGuard()
-        with torch.cuda.graph(self.graph):
-            self.static_out = fn()
+        if not syncs:
+            with torch.cuda.graph(self.graphs[0]):
+                self.static_out = fn()
+        else:
+            pool = torch.cuda.graph_pool_handle()
+
+            def cut(sync):
+                self.graphs[-1].capture_end()
+                self.cuts.append(sync)
+                self.graphs.append(torch.cuda.CUDAGraph())
+                self.graphs[-1].capture_begin(pool=pool)
+            for gs in syncs:
+                gs.cut = cut
+            gc.collect()
+            torch.cuda.empty_cache()
+            cap = torch.cuda.Stream()
+            cap.wait_stream(torch.cuda.current_stream())
+            try:
+                with torch.cuda.stream(cap):
+                    self.graphs[0].capture_begin(pool=pool)
+                    self.static_out = fn()
+                    self.graphs[-1].capture_end()
+            finally:
+                for gs in syncs:
+                    gs.cut = None
+            torch.cuda.current_stream().wait_stream(cap)
+            torch.cuda.synchronize()
+        self.graph = self.graphs[0]
         self.guard = guard.after()
         self.replays = 0
 
@@ -139,7 +177,10 @@ class GraphedIteration:
         self.guard.check("GraphedIteration")
         for o in self.optimizers:
             o.push_lr()
-        self.graph.replay()
+        for i, g in enumerate(self.graphs):
+            g.replay()
+            if i < len(self.cuts):
+                self.cuts[i].reduce()
         self.replays += 1
         return self.static_out
 
@@ -148,7 +189,8 @@ class GraphedTrainStep:
     """One train_generator.py iteration (pipeline.generator_train_step: G step + D step, both Adam updates) as one hipGraph.
 
     Requirements, checked here: both optimizers were built with ``device_step=True`` (step count and learning rate on the
-    device -- a replay must not freeze them); no GradSync (single process).  ``inputs``: {'x': [N,9,H,W], 'parse7': the
+    device -- a replay must not freeze them); data parallel: ``make_grad_sync(graph=True)`` on both (three graph segments with
+    the two gradient all-reduces between them, GraphedIteration).  ``inputs``: {'x': [N,9,H,W], 'parse7': the
     label-map activation tensor [N,H,W,8], 'im': [N,3,H,W]} -- static buffers refreshed by ``__call__``.  SPADE noise is
     drawn inside the captured region (torch's graph-safe Philox) unless ``noise`` / ``noise_d`` plane dicts are given
     (then they are static inputs too).  Losses come back as the static tensors of the capture."""
@@ -161,8 +203,6 @@ class GraphedTrainStep:
         for o in (opt_g, opt_d):
             if not getattr(o, "device_step", False):
                 raise HrvError("GraphedTrainStep: build the optimizers with hr_viton_amd.optim.Adam(..., device_step=True)")
-            if getattr(o, "grad_sync", None) is not None:
-                raise HrvError("GraphedTrainStep: data-parallel gradient synchronisation is host-driven; single process only")
         self.opt_g, self.opt_d = opt_g, opt_d
         self.static_in = {k: v.clone() for k, v in inputs.items()}
         self.noise = None if noise is None else {k: [z.clone() for z in v] for k, v in noise.items()}
@@ -171,7 +211,8 @@ class GraphedTrainStep:
         def body():
             b = self.static_in
             return generator_train_step(opt, generator, discriminator, crit_gan, crit_feat, crit_vgg, opt_g, opt_d, b["x"],
-                                        Act(b["parse7"], 7), b["im"], noise=self.noise, noise_d=self.noise_d)
+                                        Act(b["parse7"], 7), b["im"], getattr(opt_g, "grad_sync", None),
+                                        getattr(opt_d, "grad_sync", None), noise=self.noise, noise_d=self.noise_d)
         self._it = GraphedIteration(body, (opt_g, opt_d), warmup)
         self.graph, self.static_out = self._it.graph, self._it.static_out
         self.replays = 0

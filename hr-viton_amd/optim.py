@@ -85,14 +85,20 @@ class Adam(torch.optim.Optimizer):
             p._hrv_flat_grad = st["g"][off:off + k].view_as(p.data)
         return st
 
-    def make_grad_sync(self, bucket_mb: float = 64.0, process_group=None):
+    def make_grad_sync(self, bucket_mb: float = 64.0, process_group=None, graph: bool = False):
         """Data-parallel gradient synchronisation that all-reduces contiguous slices of THIS optimizer's flat
         gradient buffer in place (parallel.GradSync): the backward plans write each gradient into its slot, the
-        bucket collectives run on the buffer itself, the fused step reads it -- zero gradient copies."""
-        from .parallel import GradSync
-        assert len(self.param_groups) == 1, "one parameter group per fused optimizer"
+        bucket collectives run on the buffer itself, the fused step reads it -- zero gradient copies.
+        ``graph=True``: the variant for a hipGraph-captured iteration (parallel.GraphGradSync: one collective over the whole
+        buffer between two graph segments)."""
+        from .parallel import GradSync, GraphGradSync
+        if len(self.param_groups) != 1:
+            raise ops.HrvError("make_grad_sync: one parameter group per fused optimizer")
         st = self._flat.get(0) or self._setup(0, self.param_groups[0])
-        self.grad_sync = GradSync(None, bucket_mb, process_group, flat=st["g"], spans=st["spans"])
+        if graph:
+            self.grad_sync = GraphGradSync(st["g"], st["spans"], process_group)
+        else:
+            self.grad_sync = GradSync(None, bucket_mb, process_group, flat=st["g"], spans=st["spans"])
         return self.grad_sync
 
     @torch.no_grad()

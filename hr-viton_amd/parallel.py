@@ -184,6 +184,38 @@ class GradSync:
                 h.wait()
 
 
+class GraphGradSync(GradSync):
+    """The gradient synchronisation of a hipGraph-captured data-parallel iteration (graph.GraphedIteration): a collective is a
+    HOST call (RCCL's own stream and launch protocol; gloo stages through the host), so it cannot live inside the capture.
+    The iteration is captured as SEGMENTS instead -- the backward plans hand their gradients over exactly as they do to
+    GradSync (in place in the optimizer's flat buffer), nothing is reduced bucket by bucket, and ``wait()`` -- the first thing the
+    fused optimizer step does -- calls ``cut(self)``: during the capture that ends the running segment and opens the next one;
+    on every replay the wrapper all-reduces ``whole`` (the optimizer's ENTIRE flat gradient buffer, one collective) between
+    the two segments.  1 / world rides in the fused Adam launch as with GradSync."""
+
+    def __init__(self, flat: torch.Tensor, spans, process_group=None):
+        super().__init__(None, 1 << 20, process_group, flat=flat, spans=spans, big_mb=1 << 20, tail_mb=1 << 20)
+        self.whole = flat
+        self.cut = None               # set by graph.GraphedIteration for the capture
+
+    def _fire(self, b):
+        b["handle"] = True
+
+    def reduce(self):
+        """what a replay does where the capture was cut"""
+        if self.world > 1:
+            dist.all_reduce(self.whole, op=dist.ReduceOp.SUM, group=self.pg)
+
+    def wait(self):
+        if not self.enabled:
+            return
+        super().wait()                # zero-fills parameters without a gradient; no collective was started
+        if self.cut is not None and self.whole.is_cuda and torch.cuda.is_current_stream_capturing():
+            self.cut(self)
+        else:
+            self.reduce()             # eager (the warm-up iterations): same result as the replayed segments
+
+
 def broadcast_module(module: torch.nn.Module, src: int = 0, process_group=None):
     """Initial replica synchronisation (parameters and buffers, incl. the spectral-norm u, v)."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(process_group) == 1:

@@ -341,3 +341,111 @@ def test_two_rank_iteration_equals_the_single_process_iteration_on_the_concatena
         if big.any():
             assert float((w2[k] - v)[big].abs().max()) < 2e-6, k
     print("worst relative gradient difference 2 ranks vs 1 process:", worst)
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# the hipGraph-captured iteration under data parallelism: three graph segments, the gradient all-reduces between them
+# ------------------------------------------------------------------------------------------------------------------
+def _graph_dp_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), LOCAL_RANK="0", WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                          MASTER_PORT=str(port), HRV_DIST_BACKEND="gloo")
+        _wd = _watchdog("graphdp", rank)
+        import torch.distributed as dist
+        import hr_viton_amd  # noqa: F401
+        from hr_viton_amd import dist as hdist
+        from hr_viton_amd import gen_train, ops
+        from hr_viton_amd.gen_train import attach_grad_sync
+        from hr_viton_amd.graph import GraphedIteration, GraphedTrainStep
+        from hr_viton_amd.losses import GANLoss, L1Loss
+        from hr_viton_amd.optim import Adam
+        from hr_viton_amd.parallel import GraphGradSync
+        from hr_viton_amd.pipeline import generator_train_step
+        hdist.init_from_env()
+        dev = torch.device("cuda", 0)
+        torch.cuda.set_device(0)
+
+        def build(graph):
+            opt, gen, dis, x, seg, real, noises = _eq_setup(dev)      # identical replicas; per-rank sample and noise below
+            og = Adam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9), device_step=True)
+            od = Adam(dis.parameters(), lr=2e-3, betas=(0.0, 0.9), device_step=True)
+            sg, sd = og.make_grad_sync(bucket_mb=0.25, graph=graph), od.make_grad_sync(bucket_mb=0.05, graph=graph)
+            attach_grad_sync(sg)
+            attach_grad_sync(sd)
+            sl = slice(rank, rank + 1)
+            pick = lambda nz: {k: [z[sl].to(dev).contiguous() for z in v] for k, v in nz.items()}      # noqa: E731
+            inputs = {"x": x[sl].to(dev), "parse7": ops.to_nhwc(seg[sl].to(dev)).t, "im": real[sl].to(dev)}
+            return opt, gen, dis, og, od, sg, sd, inputs, pick(noises[0]), pick(noises[1])
+
+        def snapshot(gen, dis, og, od):
+            torch.cuda.synchronize()
+            sd_ = {"G." + k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+            sd_.update({"D." + k: v.detach().cpu().clone() for k, v in dis.state_dict().items()})
+            for tag, o in (("og", og), ("od", od)):
+                st = o._flat[0]
+                sd_[tag + ".m"], sd_[tag + ".v"] = st["m"].detach().cpu().clone(), st["v"].detach().cpu().clone()
+                sd_[tag + ".step"] = st["step_dev"].detach().cpu().clone()
+            return sd_
+        # ---- eager data parallel (bucketed GradSync, collectives started from inside the backward): four iterations
+        opt, gen, dis, og, od, sg, sd, inputs, nz, nzd = build(False)
+        assert len(sg.buckets) >= 2
+        for _ in range(4):
+            le, _o = generator_train_step(opt, gen, dis, GANLoss("hinge"), L1Loss(), None, og, od, inputs["x"],
+                                          ops.Act(inputs["parse7"], 7), inputs["im"], sg, sd, noise=nz, noise_d=nzd)
+        want = snapshot(gen, dis, og, od)
+        want_l = {k: float(v) for k, v in le.items()}
+        # ---- the same start, captured: two eager warm-up iterations (GraphGradSync reduces eagerly there) + two replays
+        opt, gen, dis, og, od, sg, sd, inputs, nz, nzd = build(True)
+        assert isinstance(sg, GraphGradSync) and isinstance(sd, GraphGradSync)
+        gs = GraphedTrainStep(opt, gen, dis, GANLoss("hinge"), L1Loss(), None, og, od, inputs, noise=nz, noise_d=nzd, warmup=2)
+        n_graphs, n_cuts = len(gs._it.graphs), len(gs._it.cuts)
+        for _ in range(2):
+            lg, _o = gs(inputs)
+        got = snapshot(gen, dis, og, od)
+        bad = [k for k in want if not torch.equal(want[k], got[k])]
+        got_l = {k: float(v) for k, v in lg.items()}
+        # the bucketed GradSync inside a capture is refused
+        refused = False
+        try:
+            o2 = Adam([torch.nn.Parameter(torch.zeros(64, device=dev))], lr=1e-3, device_step=True)
+            o2.make_grad_sync()
+            GraphedIteration(lambda: None, (o2,), warmup=1)
+        except ops.HrvError:
+            refused = True
+        wg = torch.cat([p.detach().flatten() for p in gen.parameters()])
+        sums = torch.stack([wg.double().sum(), wg.double().abs().sum()]).cpu()
+        gathered = [torch.zeros_like(sums) for _ in range(world)]
+        dist.all_gather(gathered, sums)
+        q.put((rank, n_graphs, n_cuts, bad, want_l == got_l, refused, [t.tolist() for t in gathered], int(got["og.step"]),
+               want_l["GAN_Feat"]))
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc()))
+
+
+def test_two_rank_graph_segments_equal_the_eager_data_parallel_iterations():
+    """graph.GraphedTrainStep under data parallelism (optimizer.make_grad_sync(graph=True)): the iteration is captured as three
+    hipGraph segments cut where an optimizer waits for its gradients -- [G forward/backward, D pass of the G step] | all-reduce
+    of G's flat gradient buffer | [Adam(G), D-step forward/backward] | all-reduce of D's buffer | [Adam(D)].  Two warm-up
+    iterations + two replays end in bit-identical weights, spectral-norm buffers, Adam moments and step counts as four eager
+    data-parallel iterations (bucketed GradSync) from the same start, on both ranks, with different data per rank."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_dp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=240) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert len(r) == 9, r
+    for rank, n_graphs, n_cuts, bad, same_losses, refused, sums, step, _lf in res:
+        assert n_graphs == 3 and n_cuts == 2, (n_graphs, n_cuts)
+        assert bad == [], bad[:5]
+        assert same_losses and refused and step == 4
+        assert sums[0] == sums[1]                       # replicas identical
+    assert res[0][8] != res[1][8]                       # the ranks saw different data

@@ -36,4 +36,9 @@ timeout 400 bash tools/profile_fused.sh > $OUT/profile_fused.log 2>&1
 cp gpurun_out/pmc_fused/sq1.summary.txt $OUT/pmc_fused_sq1.summary.txt 2>/dev/null
 cp gpurun_out/pmc_fused/sq2.summary.txt $OUT/pmc_fused_sq2.summary.txt 2>/dev/null
 for R in 0 8 16; do timeout 300 python bench.py --reserve-cus $R --steps 8 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('reserve-cus $R:', d['ms_per_step'], 'ms/step', d['value'], 'img/s, persistent grid', d['config']['persistent_grid_cus'], 'CUs')"; done > $OUT/reserve_cus.txt 2>&1
+# two ranks time-slicing the one GPU over gloo (functional smoke of the N > 1 launch, never a measurement): eager bucketed
+# GradSync, and the captured iteration as three hipGraph segments with the all-reduces between them
+HRV_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --steps 3 --warmup 2 --no-cpu-baseline --no-extras 2>$OUT/bench_2rank_gloo.err | tail -1 > $OUT/bench_2rank_gloo_one_gpu_smoke.json
+HRV_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --graph --steps 3 --warmup 2 --no-cpu-baseline --no-extras 2>$OUT/bench_2rank_gloo_graph.err | tail -1 > $OUT/bench_2rank_gloo_graph_one_gpu_smoke.json
+cut -c1-400 $OUT/bench_2rank_gloo_one_gpu_smoke.json $OUT/bench_2rank_gloo_graph_one_gpu_smoke.json
 ls -la $OUT | head -40
