@@ -52,12 +52,14 @@ struct P2Params {
   int N, H, W;
   const void* wp; unsigned w_bytes;
   int npass;
-  int ntp[P2_MAXP];         // column tiles of 32 per pass (4 or 2)
+  int ntp[P2_MAXP];         // column tiles of 32 per pass (4; the last pass 1..3)
   int tile0[P2_MAXP];
   unsigned woff[P2_MAXP];
   int nchunk;               // Cin / 32
   int m_tiles;
+  int Cout;
   const float* bias;        // [Cout] or nullptr
+  const void* res; int res_cs, res_co, res_f32;                      // residual added before the activation (fp32 or bf16 NHWC slice)
   int act; float slope;
   const void* mask; int mask_cs, mask_co; float mask_slope;          // bf16: out *= (mask > 0 ? 1 : mask_slope)
   void* out; int out_cs, out_co, out_f32;
@@ -74,16 +76,17 @@ static bool p2_plan(int Cin, int Cout, P2Plan& pl) {
   memset(&pl, 0, sizeof(pl));
   // K runs over 32-channel chunks; a source whose width is 16 off a multiple of 32 (the generator's 144 / 272-channel block inputs)
   // ends with a half-empty chunk: its upper 16 channels arrive as zeros (out-of-range DMA offsets) against zero weights
-  if (Cin < 32 || Cin % 16 != 0 || Cout < 64 || Cout % 64 != 0) return false;
-  const int NT = Cout / 32;
-  const int n2 = (NT % 4 == 2) ? 1 : 0;
-  const int n4 = (NT - 2 * n2) / 4;
-  if (n4 + n2 > P2_MAXP) return false;
-  pl.npass = n4 + n2;
+  // columns: any multiple of 4 from 32 up (a bf16 `out` needs a multiple of 8: checked at the launch); the last column tile may be
+  // partly or -- never -- wholly padding: its weights are packed as zeros, its bias / mask / residual reads and its stores are bounded
+  if (Cin < 32 || Cin % 16 != 0 || Cout < 32 || Cout % 4 != 0) return false;
+  const int NT = (Cout + 31) / 32;
+  const int n4 = NT / 4, rem = NT % 4;
+  if (n4 + (rem ? 1 : 0) > P2_MAXP) return false;
+  pl.npass = n4 + (rem ? 1 : 0);
   long long off = 0;
   int t0 = 0;
   for (int i = 0; i < pl.npass; ++i) {
-    pl.ntp[i] = i < n4 ? 4 : 2;
+    pl.ntp[i] = i < n4 ? 4 : rem;
     pl.tile0[i] = t0;
     t0 += pl.ntp[i];
     pl.woff[i] = (unsigned)off;
@@ -180,7 +183,7 @@ __device__ __forceinline__ void p2_patch_piece(const P2Params& p, unsigned char*
 template <int NTP>
 __device__ __forceinline__ void p2_head(const P2Params& p, const int pass, unsigned char* const smem, const P2Tile T, const int wave,
                                         const int lane) {
-  constexpr int NPW = NTP * 2, NBW = NPW / 4 > 0 ? NPW / 4 : 1;
+  constexpr int NPW = NTP * 2, NBW = (NPW + 3) / 4;
   const rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const char*>(p.src) + (size_t)T.n * p.src_bytes, p.src_bytes);
   const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
 #pragma unroll
@@ -190,7 +193,7 @@ __device__ __forceinline__ void p2_head(const P2Params& p, const int pass, unsig
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
       int idx = wave + 4 * k;
-      idx = idx < NPW ? idx : idx - 4;
+      idx = idx < NPW ? idx : (NPW >= 4 ? idx - 4 : idx % NPW);
       dma16(w_rsrc, reinterpret_cast<float*>(smem + q * P2_SB + idx * 1024), (unsigned)lane * 16u,
             p.woff[pass] + (unsigned)q * (unsigned)(NPW * 1024) + (unsigned)idx * 1024u);
     }
@@ -204,7 +207,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l31 = lane & 31, lh = lane >> 5;
   constexpr int NPW = NTP * 2;                               // 1-KB pieces (column tile, k-step) of a k-tile
-  constexpr int NBW = NPW / 4 > 0 ? NPW / 4 : 1;             // DMA instructions per wave per k-tile (NTP 4: 2; NTP 2: 1)
+  constexpr int NBW = (NPW + 3) / 4;                         // DMA instructions per wave per k-tile (NTP 4, 3: 2; NTP 2, 1: 1)
   constexpr int NST = 4 * NTP;                               // global stores of one epilogue per wave (bf16 out; fp32: 8 NTP)
   unsigned char* const ring = smem;
   float* const cbuf = reinterpret_cast<float*>(smem + P2_CB_OFF);
@@ -216,8 +219,8 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   const int nchunk = p.nchunk;
 
   auto dma_w = [&](const int kt, const int st, const int k) {
-    int idx = wave + 4 * k;
-    idx = idx < NPW ? idx : idx - 4;
+    int idx = wave + 4 * k;                                  // (a wave beyond the last piece re-requests an earlier one: same bytes, same place)
+    idx = idx < NPW ? idx : (NPW >= 4 ? idx - 4 : idx % NPW);
     dma16(w_rsrc, reinterpret_cast<float*>(ring + st * P2_SB + idx * 1024), (unsigned)lane * 16u,
           wbase + (unsigned)kt * (unsigned)(NPW * 1024) + (unsigned)idx * 1024u);
   };
@@ -227,7 +230,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
   if (p.tlog && tid == 0 && first) p.tlog[(size_t)bid * 8 + 0] = wall_clock64();
-  if (load_consts && tid < NTP * 32) cbuf[tid] = p.bias ? p.bias[tile0 * 32 + tid] : 0.f;
+  if (load_consts && tid < NTP * 32) cbuf[tid] = (p.bias && tile0 * 32 + tid < p.Cout) ? p.bias[tile0 * 32 + tid] : 0.f;
 
   const int ty = 4 * wave + (l31 >> 4), tx = l31 & 15;
   // fragment addresses: pixel (ty + kh, tx + kw) of the patch, 16-byte group (2 s + lh) ^ ((hx >> 2) & 3)
@@ -378,17 +381,41 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
     }
   const float sl = p.act == HRV_ACT_LRELU ? p.slope : (p.act == HRV_ACT_RELU ? 0.f : 1.f);      // act(v) = max(v, v * sl)
   const float msl = p.mask_slope;
+  const bool relu = p.act == HRV_ACT_RELU;
 #pragma unroll
   for (int j = 0; j < NTP; ++j) {
     // mask of this column tile (data gradient: the activation the forward stored; only its sign is used)
     u16x4 mv[2][4];
+    const int colj = (tile0 + j) * 32 + 4 * lhe;             // this lane's first column of group g: colj + 8 g
     if (p.mask) {
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          mv[i][g] = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.mask) + (size_t)pidx[i] * p.mask_cs + p.mask_co +
-                                                     (tile0 + j) * 32 + 8 * g + 4 * lhe);
+        for (int g = 0; g < 4; ++g) {
+          const u16x4 z4 = {0, 0, 0, 0};
+          mv[i][g] = colj + 8 * g < p.Cout ? *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.mask) +
+                                                                              (size_t)pidx[i] * p.mask_cs + p.mask_co + colj + 8 * g)
+                                           : z4;
+        }
+    }
+    f32x4 rv[2][4];
+    if (p.res) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 r = {0.f, 0.f, 0.f, 0.f};
+          if (colj + 8 * g < p.Cout) {
+            const size_t o = (size_t)pidx[i] * p.res_cs + p.res_co + colj + 8 * g;
+            if (p.res_f32) r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + o);
+            else {
+              const u16x4 h = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.res) + o);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) r[e] = bf2f(h[e]);
+            }
+          }
+          rv[i][g] = r;
+        }
     }
     f32x4 vv[2][4];
 #pragma unroll
@@ -397,9 +424,10 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         f32x4 t = p2_acc4(acc[i][j], g) + b;
+        if (p.res) t = t + rv[i][g];
         const f32x4 ts = t * sl;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = fmaxf(t[e], ts[e]);
+        for (int e = 0; e < 4; ++e) t[e] = relu ? fmaxf(t[e], 0.f) : fmaxf(t[e], ts[e]);      // (ReLU: +0, never v * 0 = -0)
         if (p.mask) {
 #pragma unroll
           for (int e = 0; e < 4; ++e) t[e] = bf2f(mv[i][g][e]) > 0.f ? t[e] : t[e] * msl;
@@ -421,7 +449,8 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
         for (int k = 0; k < 2; ++k) {
           const int r = (lane_e >> 2) + 16 * k, kk = lane_e & 3;
           const f32x4 v = *reinterpret_cast<const f32x4*>(sb0 + i * 2560 + r * RS + kk * 16);
-          p2_store16(v, o_rsrc, pp4[i][k] < 0 ? 0xFFFFFFF0u : (unsigned)(pp4[i][k] * p.out_cs + p.out_co + (tile0 + j) * 32 + kk * 8) * 2u);
+          p2_store16(v, o_rsrc, (pp4[i][k] < 0 || (tile0 + j) * 32 + kk * 8 >= p.Cout) ? 0xFFFFFFF0u
+                                    : (unsigned)(pp4[i][k] * p.out_cs + p.out_co + (tile0 + j) * 32 + kk * 8) * 2u);
         }
     } else {
       // fp32 rows: one 32-pixel half at a time (32 rows x 128 B + pad)
@@ -435,7 +464,8 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
           const int t = lane_e + 64 * k, r = t >> 3, kk = t & 7;
           const f32x4 v = *reinterpret_cast<const f32x4*>(sb0 + r * RSF + kk * 16);
           const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
-          p2_store16(v, o_rsrc, (y < p.H && x < p.W) ? (unsigned)((y * p.W + x) * p.out_cs + p.out_co + (tile0 + j) * 32 + kk * 4) * 4u : 0xFFFFFFF0u);
+          p2_store16(v, o_rsrc, (y < p.H && x < p.W && (tile0 + j) * 32 + kk * 4 < p.Cout)
+                                    ? (unsigned)((y * p.W + x) * p.out_cs + p.out_co + (tile0 + j) * 32 + kk * 4) * 4u : 0xFFFFFFF0u);
         }
       }
     }
@@ -525,7 +555,11 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   const int64_t sbytes = (int64_t)d->H * d->W * d->src_cstride * 2;
   HRV_REQUIRE(sbytes < (int64_t)0xFFFFFFF0, "conv_p2: one image of the source exceeds the 32-bit buffer range");
   const int oes = d->out_f32 ? 4 : 2, oal = d->out_f32 ? 4 : 8;
-  HRV_REQUIRE(d->out_cstride % oal == 0 && d->out_coff % oal == 0 && d->out_coff + d->Cout <= d->out_cstride, "conv_p2: out slice");
+  HRV_REQUIRE(d->out_cstride % oal == 0 && d->out_coff % oal == 0 && d->Cout % oal == 0 && d->out_coff + d->Cout <= d->out_cstride,
+              "conv_p2: out slice");
+  HRV_REQUIRE(d->residual == nullptr || (d->res_cstride % 4 == 0 && d->res_coff % 4 == 0 && d->res_coff + d->Cout <= d->res_cstride &&
+                                         ((uintptr_t)d->residual & 15) == 0),
+              "conv_p2: residual slice");
   HRV_REQUIRE((int64_t)d->H * d->W * d->out_cstride * oes < (int64_t)0xFFFFFFF0, "conv_p2: one image of `out` exceeds 4 GB");
   HRV_REQUIRE((((uintptr_t)d->src | (uintptr_t)d->w_packed | (uintptr_t)d->out) & 15) == 0 && ((uintptr_t)d->bias & 3) == 0, "conv_p2: alignment");
   HRV_REQUIRE(d->mask == nullptr || (d->mask_cstride % 4 == 0 && d->mask_coff % 4 == 0 && ((uintptr_t)d->mask & 7) == 0 &&
@@ -539,7 +573,9 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   p.npass = pl.npass; p.nchunk = (d->Cin + 31) / 32;
   for (int i = 0; i < pl.npass; ++i) { p.ntp[i] = pl.ntp[i]; p.tile0[i] = pl.tile0[i]; p.woff[i] = pl.woff[i]; }
   p.m_tiles = d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16);
+  p.Cout = d->Cout;
   p.bias = d->bias; p.act = d->act; p.slope = d->act_slope;
+  p.res = d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff; p.res_f32 = d->res_f32;
   p.mask = d->mask; p.mask_cs = d->mask_cstride; p.mask_co = d->mask_coff; p.mask_slope = d->mask_slope;
   p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff; p.out_f32 = d->out_f32;
   p.tlog = diag_tlog(p.m_tiles);
@@ -549,7 +585,9 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
     int b = a;
     while (b < pl.npass && pl.ntp[b] == pl.ntp[a]) ++b;
     if (pl.ntp[a] == 4) hipLaunchKernelGGL((conv_p2_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
-    else hipLaunchKernelGGL((conv_p2_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+    else if (pl.ntp[a] == 3) hipLaunchKernelGGL((conv_p2_kernel<3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+    else if (pl.ntp[a] == 2) hipLaunchKernelGGL((conv_p2_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+    else hipLaunchKernelGGL((conv_p2_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
     a = b;
   }
   return check_launch("conv_p2_kernel");

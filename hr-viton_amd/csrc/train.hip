@@ -679,9 +679,10 @@ __global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int 
     const int n = (int)(t / Ho);
     const size_t s = (((size_t)n * 2 * Ho + 2 * ho) * 2 * Wo + 2 * wo) * xcs + g * 4;
     if constexpr (XB) {
-      // bf16 storage: the inputs are ReLU outputs (>= +0, never NaN), for which the order of the 16-bit patterns IS the
-      // order of the values -- an integer max on the stored elements, exact, no conversion
-      typedef unsigned short u16x4v __attribute__((ext_vector_type(4)));
+      // bf16 storage: the inputs are ReLU outputs (>= 0, never NaN), for which the order of the 16-bit patterns read as SIGNED
+      // integers IS the order of the values (-0 = 0x8000 = -32768 sorts below every +x: a ReLU written as max(v, v * 0) stores
+      // -0 for v < 0) -- an integer max on the stored elements, exact, no conversion
+      typedef short u16x4v __attribute__((ext_vector_type(4)));
       const unsigned short* xs = reinterpret_cast<const unsigned short*>(x);
       const u16x4v a = *reinterpret_cast<const u16x4v*>(xs + s), b = *reinterpret_cast<const u16x4v*>(xs + s + xcs),
                    c = *reinterpret_cast<const u16x4v*>(xs + s + (size_t)2 * Wo * xcs),
@@ -689,7 +690,7 @@ __global__ void maxpool2_kernel(const float* __restrict__ x, int N, int Ho, int 
       u16x4v o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        const unsigned short p = a[e] > b[e] ? a[e] : b[e], q = c[e] > d[e] ? c[e] : d[e];
+        const short p = a[e] > b[e] ? a[e] : b[e], q = c[e] > d[e] ? c[e] : d[e];
         o[e] = p > q ? p : q;
       }
       *reinterpret_cast<u16x4v*>(reinterpret_cast<unsigned short*>(y) + pix * ycs + g * 4) = o;

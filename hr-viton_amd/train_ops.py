@@ -418,22 +418,28 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
         with _Timed("conv", name, 2.0 * N * Ho * Wo * cin * KH * KW, ops.act_bytes(a0) + 4.0 * N * Ho * Wo):
             _lib.check(lib.hrv_conv_cout1_fwd_f32(C.byref(d), _stream()), f"hrv_conv_cout1_fwd_f32[{name}]")
         return out
-    if (len(srcs) == 1 and up0 == 0 and out_up == 0 and w.is_contiguous() and
+    p2_bf = out.bf16 if out is not None else (out_bf16 and Cout % 8 == 0)
+    p2 = (mb and len(srcs) == 1 and up0 == 0 and out_up == 0 and (KH, KW, stride, pad) == (3, 3, 1, 1) and a0.bf16 and
+          a0.C == cin and cin % 16 == 0 and a0.cstride % 8 == 0 and a0.coff % 8 == 0 and Cout % (8 if p2_bf else 4) == 0 and w.is_contiguous() and
+          (out is None or (out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0)) and
+          (residual is None or (type(residual) is Act and residual.C == Cout and residual.cstride % 4 == 0 and residual.coff % 4 == 0 and
+                                residual.t.data_ptr() % 16 == 0)) and
+          conv_p2_ok(cin, Cout, N, H, W))
+    if (not p2 and len(srcs) == 1 and up0 == 0 and out_up == 0 and w.is_contiguous() and
             _thin_ok(a0, KH, KW, stride, pad, Cout, N, H, W) and (out is None or out.cstride % 4 == 0)):
         assert a0.C == cin, (name, a0.C, cin)
         if out is None:
             out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16 and Cout % 4 == 0)
         return _thin_conv(a0, w, 0, sigma, wscale, shift, residual, 0, act, slope, out, name,
                           2.0 * N * Ho * Wo * Cout * cin * KH * KW)
-    if (mb and len(srcs) == 1 and up0 == 0 and out_up == 0 and residual is None and (KH, KW, stride, pad) == (3, 3, 1, 1) and a0.bf16 and
-            a0.C == cin and cin % 16 == 0 and a0.cstride % 8 == 0 and a0.coff % 8 == 0 and Cout % 64 == 0 and w.is_contiguous() and
-            (out is None or out.cstride % (8 if out.bf16 else 4) == 0) and conv_p2_ok(cin, Cout, N, H, W)):
+    if p2:
         # plain 3x3 over one bf16 source: the two-blocks-per-CU kernel (VGG19's 128..512-channel layers; SPADEResBlock.conv_0 of
         # up_2 / up_3: 272 -> 128, 144 -> 64)
         if out is None:
-            out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=out_bf16)
+            out = ops.alloc(N, Ho, Wo, Cout, a0.t.device, bf16=p2_bf)
         pk = conv_p2_pack(0, w, None, cin, Cout, sigma, wscale, frozen)
-        return conv_p2(a0, pk, Cout, out, bias=shift, act=act, slope=slope, name=name, flops=2.0 * N * Ho * Wo * Cout * cin * 9)
+        return conv_p2(a0, pk, Cout, out, bias=shift, act=act, slope=slope, residual=residual, name=name,
+                       flops=2.0 * N * Ho * Wo * Cout * cin * 9)
     cfg = _bf16_tile(Cout) if mb else _f32_tile(N * Ho * Wo, Cout)
     if mb:                 # bf16-stored source: the halo patch stays in LDS (ops.patch_tile)
         if KH == 1 and KW == 1 and a0.bf16 and len(srcs) == 1 and a0.Cp <= 128 and Cout % 64 == 0:
@@ -487,12 +493,15 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         with _Timed("conv", name, fl, ops.act_bytes(out) * (2 if add is not None else 1) + 4.0 * N * Ho * Wo):
             _lib.check(lib.hrv_conv_cout1_dgrad_f32(C.byref(d), _stream()), f"hrv_conv_cout1_dgrad_f32[{name}]")
         return out
-    if (add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
+    p2 = (mb and stride == 1 and (KH, KW, pad) == (3, 3, 1) and (Ho, Wo) == (H, W) and dy.bf16 and add is None and dy.C == Cout and
+          Cout % 16 == 0 and dy.cstride % 8 == 0 and dy.coff % 8 == 0 and cin % (8 if out.bf16 else 4) == 0 and
+          out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0 and
+          (act_mask is None or (act_mask.bf16 and act_mask.C == cin and act_mask.cstride % 4 == 0 and act_mask.coff % 4 == 0)) and
+          w.is_contiguous() and conv_p2_ok(Cout, cin, N, H, W))
+    if (not p2 and add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
-    if (mb and stride == 1 and (KH, KW, pad) == (3, 3, 1) and (Ho, Wo) == (H, W) and dy.bf16 and add is None and dy.C == Cout and
-            Cout % 32 == 0 and cin % 64 == 0 and (act_mask is None or (act_mask.bf16 and act_mask.C == cin)) and w.is_contiguous() and
-            conv_p2_ok(Cout, cin, N, H, W)):
+    if p2:
         # a stride-1 data gradient is a 'same' 3x3 convolution over dY: the two-blocks-per-CU kernel
         pk = (conv_p2_pack(2, pair[0], pair[1], Cout, cin) if pair is not None else
               conv_p2_pack(1, w, None, Cout, cin, sigma, wscale, frozen))
@@ -1232,8 +1241,9 @@ def conv_p2_pack(mode: int, w: torch.Tensor, w2: Optional[torch.Tensor], K: int,
 
 
 def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.2,
-            mask: Optional[Act] = None, mask_slope: float = 0.0, name: str = "conv", flops: float = 0.0, tag: str = ""):
-    """out = act(conv3x3(src) + bias) [* (mask > 0 ? 1 : mask_slope)] on csrc/conv_p2.hip."""
+            mask: Optional[Act] = None, mask_slope: float = 0.0, name: str = "conv", flops: float = 0.0, tag: str = "",
+            residual: Optional[Act] = None):
+    """out = act(conv3x3(src) + bias [+ residual]) [* (mask > 0 ? 1 : mask_slope)] on csrc/conv_p2.hip."""
     lib = _lib.load()
     assert src.bf16 and out.C == cols
     d = _lib.hrv_conv_p2_t()
@@ -1247,7 +1257,11 @@ def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[
         assert mask.bf16 and mask.C == cols
         d.mask, d.mask_cstride, d.mask_coff, d.mask_slope = mask.t.data_ptr(), mask.cstride, mask.coff, mask_slope
     d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
-    nb = ops.act_bytes(src) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0) + 2.0 * src.C * cols * 9
+    if residual is not None:
+        assert residual.C == cols
+        d.residual, d.res_cstride, d.res_coff, d.res_f32 = residual.t.data_ptr(), residual.cstride, residual.coff, 0 if residual.bf16 else 1
+    nb = (ops.act_bytes(src) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0) +
+          (ops.act_bytes(residual) if residual is not None else 0.0) + 2.0 * src.C * cols * 9)
     with ops._Timed("conv", name + tag, flops, nb):
         _lib.check(lib.hrv_conv_p2_bf16(C.byref(d), _stream()), f"hrv_conv_p2_bf16[{name}]")
     return out

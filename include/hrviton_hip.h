@@ -751,10 +751,11 @@ int hrv_spade_fused_pack_dev(const float* w_shared, const float* b_shared, int32
                              const float* w_beta, int32_t C, void* out, hrv_stream_t stream);
 int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t stream);
 
-/* 3x3 stride-1 'same' convolution over ONE bf16-stored NHWC source with Cin % 32 == 0 and Cout % 64 == 0, two blocks per CU
+/* 3x3 stride-1 'same' convolution over ONE bf16-stored NHWC source with Cin % 16 == 0 (>= 32) and Cout % 4 == 0 (>= 32; a bf16 `out`:
+ * % 8), two blocks per CU
  * (conv_p2.hip): nn.Conv2d forward (VGG19 of the perceptual loss, networks.py:201-233) and data gradients -- of such a
  * convolution (mode 1) or of the SPADE (conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118).
- *   out = act(conv + bias[c]) [* (mask > 0 ? 1 : mask_slope)], bf16 or fp32 NHWC slice.
+ *   out = act(conv + bias[c] [+ residual]) [* (mask > 0 ? 1 : mask_slope)], bf16 or fp32 NHWC slice.
  * `Cin` = K (channels of `src`), `Cout` = columns, whatever the mode; w_packed from hrv_conv_p2_pack_dev of the same mode:
  *   mode 0: w = the layer's OIHW weight [Cout][Cin][3][3];
  *   mode 1: w = the FORWARD layer's OIHW weight [Cin][Cout][3][3] (its output channels are this call's K), taps flipped;
@@ -769,6 +770,8 @@ typedef struct hrv_conv_p2 {
   int32_t act; float act_slope;
   const void* mask; int32_t mask_cstride, mask_coff; float mask_slope; int32_t out_f32;
   void* out; int32_t out_cstride, out_coff;
+  int32_t res_f32;                                           /* residual dtype: 1 fp32, 0 bf16 */
+  const void* residual; int32_t res_cstride, res_coff;       /* optional NHWC slice added BEFORE the activation (SPADEResBlock: x_s + dx) */
 } hrv_conv_p2_t;
 int64_t hrv_conv_p2_packed_bytes(int32_t Cin, int32_t Cout);   /* -1: shape not served */
 int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32_t H, int32_t W);

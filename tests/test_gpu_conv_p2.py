@@ -1,8 +1,9 @@
 """csrc/conv_p2.hip -- the two-blocks-per-CU 3x3 convolution over one bf16 source (32-channel chunks double-buffered in LDS) --
 against plain torch on the same bf16-rounded operands: nn.Conv2d forward with bias + ReLU (VGG19, networks.py:201-233), the data
 gradient of such a convolution with the ReLU mask of its input (mode 1), and the data gradient of the SPADE
-(conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118); K of 64 .. 544 (2 .. 17 chunks),
-128 / 256 / 64 / 192 columns (4-tile passes, a 2-tile pass, both), extents that are not multiples of the 16x16 tile, more tiles
+(conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118); K of 32 .. 544 (1 .. 17 chunks),
+128 / 256 / 64 / 192 columns (4-tile passes, a 2-tile pass, both) and column counts that end inside a 32-column tile (32, 36, 48, 80, 144,
+272: 1- and 3-tile passes, bounded bias / mask / residual reads and stores), the residual of SPADEResBlock (x_s + dx, fp32 or bf16), extents that are not multiples of the 16x16 tile, more tiles
 than resident blocks, bf16 and fp32 outputs, channel slices of wider tensors."""
 import pytest
 import torch
@@ -17,7 +18,10 @@ def _bf(t):
 
 @pytest.mark.parametrize("Cin,Cout,N,H,W,out_bf16", [(64, 128, 1, 250, 270, True), (128, 256, 2, 40, 56, True), (256, 64, 1, 33, 47, False),
                                                       (96, 192, 1, 64, 48, True), (512, 128, 1, 24, 32, False), (144, 64, 1, 72, 88, False),
-                                                      (272, 128, 1, 40, 48, False), (80, 64, 1, 33, 40, True)])
+                                                      (272, 128, 1, 40, 48, False), (80, 64, 1, 33, 40, True),
+                                                      (80, 32, 1, 64, 48, True), (144, 80, 1, 40, 56, True), (32, 36, 1, 33, 47, False),
+                                                      (48, 48, 2, 32, 32, True), (64, 144, 1, 40, 40, False), (128, 272, 1, 24, 40, True),
+                                                      (64, 64, 4, 256, 128, True), (64, 64, 1, 33, 47, True), (32, 64, 1, 40, 40, False)])
 def test_forward_bias_relu_matches_torch(Cin, Cout, N, H, W, out_bf16):
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd import ops, train_ops as T
@@ -35,10 +39,15 @@ def test_forward_bias_relu_matches_torch(Cin, Cout, N, H, W, out_bf16):
     tol = (want.abs() * 2 ** -8 if out_bf16 else 0.0) + 2e-4 * float(want.abs().max())
     assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
     assert bool((oall[..., :8] == 7.0).all()) and bool((oall[..., 8 + Cout:] == 7.0).all())      # neighbours untouched
+    if out_bf16:      # ReLU gives +0 (the bf16 max pool orders stored patterns)
+        assert int((oall.view(torch.int16) == -32768).sum()) == 0
 
 
 @pytest.mark.parametrize("Ck,Ccol,N,H,W,out_bf16,masked", [(128, 64, 1, 70, 50, True, True), (256, 128, 1, 48, 40, True, True),
-                                                            (64, 128, 2, 32, 48, False, False), (128, 256, 1, 40, 24, True, True)])
+                                                            (64, 128, 2, 32, 48, False, False), (128, 256, 1, 40, 24, True, True),
+                                                            (64, 144, 1, 40, 56, True, True), (32, 80, 1, 48, 40, True, True),
+                                                            (32, 48, 1, 33, 40, True, False), (128, 272, 1, 24, 32, True, True),
+                                                            (64, 80, 2, 32, 32, False, True)])
 def test_data_gradient_with_relu_mask_matches_torch(Ck, Ccol, N, H, W, out_bf16, masked):
     """dX = conv^T(dY) * relu'(x): the forward layer maps Ccol -> Ck channels (VGG19's backward, vgg.py)."""
     import hr_viton_amd  # noqa: F401
@@ -84,6 +93,32 @@ def test_pair_data_gradient_matches_torch(C_, N, H, W, cs_mult, out_bf16):
     assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
     if cs_mult > 1:
         assert bool((dact_all[..., :dact.coff] == 7.0).all())
+
+
+@pytest.mark.parametrize("Cin,Cout,res_bf16,out_bf16,act", [(80, 64, False, False, 0), (48, 32, False, True, 2), (144, 128, True, False, 0),
+                                                             (80, 80, False, True, 1)])
+def test_forward_with_residual_matches_torch(Cin, Cout, res_bf16, out_bf16, act):
+    """SPADEResBlock: out = act(x_s + conv_1(h) + bias) (network_generator.py:168-170; the last block's LeakyReLU rides along)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(7 * Cin + Cout)
+    N, H, W = 2, 40, 56
+    x = ops.Act(torch.randn(N, H, W, Cin, generator=g).to(torch.bfloat16).cuda(), Cin)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * (2.0 / (9 * Cin)) ** 0.5).cuda()
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    rall = torch.randn(N, H, W, Cout + 12, generator=g)
+    rall = (rall.to(torch.bfloat16) if res_bf16 else rall).cuda()
+    res = ops.Act(rall, Cout, 4)
+    oall = torch.full((N, H, W, Cout + 16), 7.0, device="cuda", dtype=torch.bfloat16 if out_bf16 else torch.float32)
+    out = ops.Act(oall, Cout, 8)
+    T.conv_p2(x, T.conv_p2_pack(0, w, None, Cin, Cout), Cout, out, bias=b, act=act, slope=0.2, residual=res, name="t")
+    torch.cuda.synchronize()
+    want = F.conv2d(x.t.float().permute(0, 3, 1, 2), _bf(w), b, padding=1).permute(0, 2, 3, 1) + rall[..., 4:4 + Cout].float()
+    want = F.relu(want) if act == 1 else (F.leaky_relu(want, 0.2) if act == 2 else want)
+    got = oall[..., 8:8 + Cout].float()
+    tol = (want.abs() * 2 ** -8 if out_bf16 else 0.0) + 2e-4 * float(want.abs().max())
+    assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+    assert bool((oall[..., :8] == 7.0).all()) and bool((oall[..., 8 + Cout:] == 7.0).all())
 
 
 def test_training_convs_route_through_the_kernel_and_match_the_generic_tiles(monkeypatch):

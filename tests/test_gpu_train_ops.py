@@ -797,6 +797,10 @@ def test_bf16_stored_pool_and_loss_kernels_match_fp32_on_the_same_values():
     xa, xf = ops.Act(x, 64), ops.Act(x.float(), 64)
     p16, p32 = T.maxpool2x2(xa), T.maxpool2x2(xf)
     assert p16.bf16 and torch.equal(p16.t.float(), p32.t)
+    # a ReLU written as max(v, v * 0) stores -0 (pattern 0x8000) for v < 0: the pool must not rank it above positive values
+    xn = torch.where(x == 0, torch.full_like(x, -0.0), x)
+    assert int((xn.view(torch.int16) == -32768).sum()) > 1000
+    assert torch.equal(T.maxpool2x2(ops.Act(xn, 64)).t.float(), p32.t)
     dy = ops.Act(torch.randn(2, 10, 12, 64, generator=g).cuda(), 64)
     assert torch.equal(T.maxpool2x2_bwd(xa, dy, relu=True).t, T.maxpool2x2_bwd(xf, dy, relu=True).t)
     l16, l32 = torch.zeros(1, device="cuda"), torch.zeros(1, device="cuda")
