@@ -167,9 +167,15 @@ class _SpadePlan:
         return bool(m.bf16 and m.Cp == m.Creal and seg.bf16 and seg.cstride == 8 and seg.coff == 0 and self.label_nc <= 8 and
                     x.cstride % 4 == 0 and T.spade_fused_ok(m.Creal, self.cs.out_channels, self.label_nc, x.N, x.H, x.W))
 
-    def __call__(self, x: Act, actv: Optional[Act], z: Optional[torch.Tensor], fused=None) -> Act:
+    def fused_ok_shape(self, N: int, H: int, W: int, seg: Act) -> bool:
+        from . import train_ops as T
+        m = self.mod
+        return bool(m.bf16 and m.Cp == m.Creal and seg.bf16 and seg.cstride == 8 and seg.coff == 0 and self.label_nc <= 8 and
+                    T.spade_fused_ok(m.Creal, self.cs.out_channels, self.label_nc, N, H, W))
+
+    def __call__(self, x: Act, actv: Optional[Act], z: Optional[torch.Tensor], fused=None, stats=None) -> Act:
         zz = z if (z is not None and self.mod.has_noise) else None
-        mean, rstd = ops.instnorm_stats(x, zz, self.mod.ns if zz is not None else None)
+        mean, rstd = stats if stats is not None else ops.instnorm_stats(x, zz, self.mod.ns if zz is not None else None)
         if fused is not None:
             # SPADENorm end to end in one launch: actv = ReLU(conv_shared(label map)) never reaches HBM
             from . import train_ops as T
@@ -217,6 +223,12 @@ class _BlockPlan:
                             name=name + ".conv_0", bf16=bf16, out_f32=True)   # dx feeds norm_1's InstanceNorm
         self.c1_scale = torch.full((blk.output_nc,), 1.0 / s1)
         self.c1_w, self.c1_b = _raw_weight(blk.conv_1), blk.conv_1.bias
+        # bf16 serving: conv_0 / conv_1 of the fine levels run on the training forward's kernels (train_ops.conv_forward_fast)
+        self._fast = None
+        if bf16:
+            dv = lambda t: None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()    # noqa: E731
+            self._fast = dict(w0=dv(_raw_weight(blk.conv_0)), b0=dv(blk.conv_0.bias), s0=1.0 / s0,
+                              w1=dv(self.c1_w), b1=dv(self.c1_b), s1=1.0 / s1)
         self.device, self.name, self.blk = device, name, blk
         self._c1 = {}
         if self.learned:
@@ -238,18 +250,57 @@ class _BlockPlan:
                                       out_f32=(act == ACT_NONE))
         return self._c1[act]
 
+    def _conv0(self, h0: Act) -> Act:
+        if self._fast is not None:
+            from . import train_ops as T
+            f = self._fast
+            r = T.conv_forward_fast(f["w0"], h0, 1, f["s0"], f["b0"], None, ACT_NONE, 0.2, None, False, self.name + ".conv_0",
+                                    ("serve", id(self), 0))
+            if r is not None:
+                return r
+        return self.c0([h0])
+
+    def _conv1(self, h1: Act, x_s: Act, out: Optional[Act], out_up: int, out_act: int) -> Act:
+        if self._fast is not None and out_up == 0 and type(x_s) is Act:
+            from . import train_ops as T
+            f = self._fast
+            r = T.conv_forward_fast(f["w1"], h1, 1, f["s1"], f["b1"], x_s, out_act, 0.2, out, out_act != ACT_NONE, self.name + ".conv_1",
+                                    ("serve", id(self), 1))
+            if r is not None:
+                return r
+        return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
+
+    def reads_upsampled_input(self, N: int, H: int, W: int, C_in: int, seg: Act) -> bool:
+        """This block can read its input as ops.ActUp = cat(up2(previous output), stem) without the 4-fold fp32 copy ever being
+        written (bf16 serving: a learned-shortcut block whose norms all run on csrc/spade_fused.hip -- the one-pass statistics of
+        norm_s / norm_0 and that kernel are the only readers of x; a zero noise_scale rides through as z * 0).  HRV_XUP=0: off."""
+        if os.environ.get("HRV_XUP", "1") == "0" or os.environ.get("HRV_SPADE_FUSED", "1") == "0" or not (self.bf16 and self.learned):
+            return False
+        if H % 2 or W % 2 or (C_in - 16) % 32 != 0 or self.n0.mod.Creal != C_in or self.ns_.mod.Creal != C_in:
+            return False
+        return all(n_.fused_ok_shape(N, H, W, seg) for n_ in self.norms)
+
     def __call__(self, x: Act, seg: Act, seg_shift: int, zs: Sequence[Optional[torch.Tensor]], out: Optional[Act],
                  out_up: int, out_act: int) -> Act:
         """x_s + conv_1(lrelu(norm_1(conv_0(lrelu(norm_0(x)))))) -- network_generator.py:163-173.
         ``zs``: noise draws in the reference's call order (norm_s, norm_0, norm_1)."""
         zi = iter(zs)
+        if isinstance(x, ops.ActUp):
+            # (the caller checked reads_upsampled_input) norm_s and norm_0 normalise the same x: one statistics pass over lo / hi
+            f = (seg, seg_shift)
+            z_s, z_0 = next(zi), next(zi)
+            st_s, st_0 = ops.instnorm_stats2(x, z_s, self.ns_.mod.ns, z_0, self.n0.mod.ns)
+            x_s = self.cs([self.ns_(x, None, z_s, f, st_s)])
+            dx = self._conv0(self.n0(x, None, z_0, f, st_0))
+            h1 = self.n1(dx, None, next(zi), f)
+            return self._conv1(h1, x_s, out, out_up, out_act)
         if os.environ.get("HRV_SPADE_FUSED", "1") != "0" and all(n_.fused_ok(x, seg) for n_ in self.norms):
             # every norm of the block computes its conv_shared inside its gamma|beta kernel: no conv_shared launch, no actv tensor
             f = (seg, seg_shift)
             x_s = self.cs([self.ns_(x, None, next(zi), f)]) if self.learned else x
-            dx = self.c0([self.n0(x, None, next(zi), f)])
+            dx = self._conv0(self.n0(x, None, next(zi), f))
             h1 = self.n1(dx, None, next(zi), f)
-            return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
+            return self._conv1(h1, x_s, out, out_up, out_act)
         # every norm of the block sees the same nearest-resized label map (network_generator.py:112-113)
         actv_all = self.shared([ops.tap_expand(seg, seg_shift, 3)])
         actv = [actv_all.slice(i * self.nh, self.nh) for i in range(len(self.norms))]
@@ -258,9 +309,9 @@ class _BlockPlan:
             x_s = self.cs([self.ns_(x, next(ai), next(zi))])
         else:
             x_s = x
-        dx = self.c0([self.n0(x, next(ai), next(zi))])
+        dx = self._conv0(self.n0(x, next(ai), next(zi)))
         h1 = self.n1(dx, next(ai), next(zi))
-        return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
+        return self._conv1(h1, x_s, out, out_up, out_act)
 
 
 class SPADEGenerator(BaseNetwork):
@@ -322,6 +373,12 @@ class SPADEGenerator(BaseNetwork):
                      for i in range(len(P["blocks"]))]
         P["img"] = ConvLayer(self.conv_img.weight, [self.conv_img.in_channels], device, shift=self.conv_img.bias, pad=1,
                              act=ACT_TANH, name="conv_img", bf16=bf, out_f32=True)
+        if bf:
+            dv = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()      # noqa: E731
+            P["stem_fast"] = [dict(w=dv(getattr(self, f"conv_{i}").weight), b=dv(getattr(self, f"conv_{i}").bias))
+                              for i in range(len(P["blocks"]))]
+            P["img_fast"] = dict(w=self.conv_img.weight.detach().to(device=device, dtype=torch.float32).contiguous(),
+                                 b=self.conv_img.bias.detach().to(device=device, dtype=torch.float32).contiguous())
         return P
 
     def _get_plan(self, device):
@@ -376,6 +433,7 @@ class SPADEGenerator(BaseNetwork):
             return [torch.randn(N, w, h, 1, device=dev) for _ in range(k)]
 
         cur: Optional[Act] = None
+        noise_ok = noise is None or all(all(z is not None for z in v) for v in noise.values())
         for j, name in enumerate(names):
             blk = P["blocks"][j]
             h, w = self.sh << j, self.sw << j
@@ -385,7 +443,14 @@ class SPADEGenerator(BaseNetwork):
                 cur = P["stem"][0]([(xin, -shift, ACT_NONE)])
             else:
                 # cur already holds up(prev) in channels [0, cin-16); the stem conv fills the rest
-                P["stem"][j]([(xin, -shift, ACT_NONE)], out=cur.slice(cin - 16, 16))
+                hi = cur.hi if isinstance(cur, ops.ActUp) else cur.slice(cin - 16, 16)
+                done = None
+                if bf and shift == 0 and "stem_fast" in P:      # conv_7: 9 -> 16 channels over every pixel, memory-bound (thin_conv.hip)
+                    from . import train_ops as T
+                    sf = P["stem_fast"][j]
+                    done = T.conv_forward_fast(sf["w"], xin, 1, 1.0, sf["b"], None, ACT_NONE, 0.2, hi, False, f"conv_{j}", ("serve", id(P), 10 + j))
+                if done is None:
+                    P["stem"][j]([(xin, -shift, ACT_NONE)], out=hi)
             assert cur.C == cin and (cur.H, cur.W) == (h, w)
             last = j == nb - 1
             if last:
@@ -393,10 +458,22 @@ class SPADEGenerator(BaseNetwork):
                 cur = blk(cur, sg, shift, draws(name, blk, h, w), None, 0, ACT_LRELU)
             else:
                 nxt_c = getattr(self, names[j + 1]).input_nc
-                nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)     # residual stream / InstanceNorm input: fp32
-                blk(cur, sg, shift, draws(name, blk, h, w), nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
-                cur = nxt
-        img = P["img"]([cur])
+                if noise_ok and P["blocks"][j + 1].reads_upsampled_input(N, h * 2, w * 2, nxt_c, sg):
+                    # the next block reads cat(up2(this output), its stem) in place (ops.ActUp): no 4-fold fp32 copy
+                    lo = ops.alloc(N, h, w, nxt_c - 16, dev)
+                    blk(cur, sg, shift, draws(name, blk, h, w), lo, 0, ACT_NONE)
+                    cur = ops.ActUp(lo, ops.alloc(N, h * 2, w * 2, 16, dev))
+                else:
+                    nxt = ops.alloc(N, h * 2, w * 2, nxt_c, dev)     # residual stream / InstanceNorm input: fp32
+                    blk(cur, sg, shift, draws(name, blk, h, w), nxt.slice(0, nxt_c - 16), 1, ACT_NONE)
+                    cur = nxt
+        img = None
+        if bf and "img_fast" in P:
+            from . import train_ops as T
+            fi = P["img_fast"]
+            img = T.conv_forward_fast(fi["w"], cur, 1, 1.0, fi["b"], None, ACT_TANH, 0.2, None, False, "conv_img", ("serve", id(P), 2))
+        if img is None:
+            img = P["img"]([cur])
         return ops.to_nchw(img)
 
 

@@ -11,7 +11,7 @@ from typing import Optional, Sequence, Tuple
 import torch
 
 from . import _lib, ops
-from .ops import ACT_NONE, Act, _ceil4, _stream, _Timed, _workspace
+from .ops import ACT_LRELU, ACT_NONE, ACT_RELU, Act, _ceil4, _stream, _Timed, _workspace
 
 
 # Mixed-precision training switch (the reference's --fp16 / apex-O1 role): when on, every training
@@ -397,6 +397,41 @@ def _f32_tile(M: int, cout: int) -> int:
     return cfg
 
 
+def _p2_fwd_ok(w: torch.Tensor, a0: Act, stride: int, pad: int, out: Optional[Act], out_is_bf16: bool, residual, act: int) -> bool:
+    """csrc/conv_p2.hip serves this forward layer: 3x3 stride-1 'same' over ONE bf16-stored source read at its own resolution."""
+    Cout, cin, KH, KW = w.shape
+    return ((KH, KW, stride, pad) == (3, 3, 1, 1) and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and a0.bf16 and a0.C == cin and cin % 16 == 0 and
+            a0.cstride % 8 == 0 and
+            a0.coff % 8 == 0 and Cout % (8 if out_is_bf16 else 4) == 0 and w.is_contiguous() and
+            (out is None or (out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0)) and
+            (residual is None or (type(residual) is Act and residual.C == Cout and residual.cstride % 4 == 0 and residual.coff % 4 == 0 and
+                                  residual.t.data_ptr() % 16 == 0)) and
+            conv_p2_ok(cin, Cout, a0.N, a0.H, a0.W))
+
+
+def conv_forward_fast(w: torch.Tensor, a0: Act, pad: int, wscale: float, shift: Optional[torch.Tensor], residual: Optional[Act], act: int,
+                      slope: float, out: Optional[Act], out_bf16: bool, name: str, frozen) -> Optional[Act]:
+    """bf16 SERVING plans (network_generator): a stride-1 layer over one bf16-stored source on conv_p2.hip or thin_conv.hip when one
+    of them serves it -- the kernels of the training forward, same operand rounding as the plan's own ConvLayer (bf16 operands, fp32
+    accumulate) -- else None and the caller's ConvLayer runs.  ``frozen``: any hashable that identifies the weight version (the
+    packed stream is cached under it)."""
+    if os.environ.get("HRV_SERVE_FAST", "1") == "0" or not a0.bf16:
+        return None
+    Cout, cin, KH, KW = w.shape
+    prev = MMA_BF16[0]
+    MMA_BF16[0] = True
+    try:
+        bf = out.bf16 if out is not None else (out_bf16 and Cout % 8 == 0)
+        if not (_p2_fwd_ok(w, a0, 1, pad, out, bf, residual, act) or
+                (w.is_contiguous() and a0.C == cin and _thin_ok(a0, KH, KW, 1, pad, Cout, a0.N, a0.H, a0.W) and
+                 (out is None or out.cstride % 4 == 0))):
+            return None
+        return conv_forward_dev(w, [(a0, 0)], 1, pad, wscale=wscale, shift=shift, residual=residual, act=act, slope=slope, out=out,
+                                name=name, out_bf16=out_bf16, frozen=frozen)
+    finally:
+        MMA_BF16[0] = prev
+
+
 def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: int, pad: int, wscale: float = 1.0,
                      sigma: Optional[torch.Tensor] = None, shift: Optional[torch.Tensor] = None, residual: Optional[Act] = None, act: int = ACT_NONE,
                      slope: float = 0.2, out: Optional[Act] = None, out_up: int = 0, name: str = "conv",
@@ -419,12 +454,10 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
             _lib.check(lib.hrv_conv_cout1_fwd_f32(C.byref(d), _stream()), f"hrv_conv_cout1_fwd_f32[{name}]")
         return out
     p2_bf = out.bf16 if out is not None else (out_bf16 and Cout % 8 == 0)
-    p2 = (mb and len(srcs) == 1 and up0 == 0 and out_up == 0 and (KH, KW, stride, pad) == (3, 3, 1, 1) and a0.bf16 and
-          a0.C == cin and cin % 16 == 0 and a0.cstride % 8 == 0 and a0.coff % 8 == 0 and Cout % (8 if p2_bf else 4) == 0 and w.is_contiguous() and
-          (out is None or (out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0)) and
-          (residual is None or (type(residual) is Act and residual.C == Cout and residual.cstride % 4 == 0 and residual.coff % 4 == 0 and
-                                residual.t.data_ptr() % 16 == 0)) and
-          conv_p2_ok(cin, Cout, N, H, W))
+    p2 = mb and len(srcs) == 1 and up0 == 0 and out_up == 0 and _p2_fwd_ok(w, a0, stride, pad, out, p2_bf, residual, act)
+    if p2 and os.environ.get("HRV_CONV_P2_WIDE", "1") == "0":      # A/B: the kernel's round-4 mid range (64-column multiples, thin kernel first)
+        p2 = (Cout % 64 == 0 and residual is None and
+              not _thin_ok(a0, KH, KW, stride, pad, Cout, N, H, W))
     if (not p2 and len(srcs) == 1 and up0 == 0 and out_up == 0 and w.is_contiguous() and
             _thin_ok(a0, KH, KW, stride, pad, Cout, N, H, W) and (out is None or out.cstride % 4 == 0)):
         assert a0.C == cin, (name, a0.C, cin)
@@ -498,6 +531,8 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
           out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0 and
           (act_mask is None or (act_mask.bf16 and act_mask.C == cin and act_mask.cstride % 4 == 0 and act_mask.coff % 4 == 0)) and
           w.is_contiguous() and conv_p2_ok(Cout, cin, N, H, W))
+    if p2 and os.environ.get("HRV_CONV_P2_WIDE", "1") == "0":
+        p2 = Cout % 32 == 0 and cin % 64 == 0 and not (pair is None and _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W))
     if (not p2 and add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
