@@ -96,7 +96,7 @@ class Adam(torch.optim.Optimizer):
             raise ops.HrvError("make_grad_sync: one parameter group per fused optimizer")
         st = self._flat.get(0) or self._setup(0, self.param_groups[0])
         if graph:
-            self.grad_sync = GraphGradSync(st["g"], st["spans"], process_group)
+            self.grad_sync = GraphGradSync(st["g"], st["spans"], process_group, bucket_mb)
         else:
             self.grad_sync = GradSync(None, bucket_mb, process_group, flat=st["g"], spans=st["spans"])
         return self.grad_sync

@@ -190,11 +190,11 @@ class GraphGradSync(GradSync):
     The iteration is captured as SEGMENTS instead -- the backward plans hand their gradients over exactly as they do to
     GradSync (in place in the optimizer's flat buffer), nothing is reduced bucket by bucket, and ``wait()`` -- the first thing the
     fused optimizer step does -- calls ``cut(self)``: during the capture that ends the running segment and opens the next one;
-    on every replay the wrapper all-reduces ``whole`` (the optimizer's ENTIRE flat gradient buffer, one collective) between
-    the two segments.  1 / world rides in the fused Adam launch as with GradSync."""
+    on every replay the wrapper all-reduces the optimizer's ENTIRE flat gradient buffer (back-to-back collectives over the bucket
+    ranges) between the two segments.  1 / world rides in the fused Adam launch as with GradSync."""
 
-    def __init__(self, flat: torch.Tensor, spans, process_group=None):
-        super().__init__(None, 1 << 20, process_group, flat=flat, spans=spans, big_mb=1 << 20, tail_mb=1 << 20)
+    def __init__(self, flat: torch.Tensor, spans, process_group=None, bucket_mb: float = 64.0):
+        super().__init__(None, bucket_mb, process_group, flat=flat, spans=spans)
         self.whole = flat
         self.cut = None               # set by graph.GraphedIteration for the capture
 
@@ -202,9 +202,12 @@ class GraphGradSync(GradSync):
         b["handle"] = True
 
     def reduce(self):
-        """what a replay does where the capture was cut"""
+        """what a replay does where the capture was cut: the whole flat gradient buffer, as back-to-back collectives over GradSync's
+        contiguous ranges (all in flight together; one 400 MB tensor takes a slow path in gloo)"""
         if self.world > 1:
-            dist.all_reduce(self.whole, op=dist.ReduceOp.SUM, group=self.pg)
+            hs = [dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True) for b in self.buckets]
+            for h in hs:
+                h.wait()
 
     def wait(self):
         if not self.enabled:
