@@ -137,3 +137,71 @@ def test_bucket_cut_policy_big_parameters_alone_and_a_small_tail():
     # degenerate inputs
     assert GradSync.cut_ranges([5], 10, 100, 3) == [(0, 1)]
     assert GradSync.cut_ranges([200, 1, 1], 10, 100, 3) == [(1, 3), (0, 1)]
+
+
+def _graph_sync_worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        os.environ.update(RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        import torch
+        import torch.distributed as dist
+        import hr_viton_amd  # noqa: F401
+        from hr_viton_amd import dist as hdist
+        from hr_viton_amd.gen_train import _acc, attach_grad_sync, detach_grad_sync, grad_buffer
+        from hr_viton_amd.parallel import GraphGradSync
+        hdist.init_from_env("gloo")
+        torch.manual_seed(0)
+        net = torch.nn.Sequential(torch.nn.Linear(300, 200), torch.nn.Linear(200, 100), torch.nn.Linear(100, 7))
+        plist = list(net.parameters())
+        offs, n = [], 0
+        for p in plist:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4
+        flat = torch.zeros(n)
+        spans = [(p, o, p.numel()) for p, o in zip(plist, offs)]
+        for p, o, k in spans:
+            p._hrv_flat_grad = flat[o:o + k].view_as(p.data)
+        sync = GraphGradSync(flat, spans, bucket_mb=0.1)
+        attach_grad_sync(sync)
+        cuts = []
+        sync.cut = cuts.append            # only called while a HIP stream is capturing: never on the CPU
+        sync.begin()
+        grads = {}
+        fired = []
+        for p in reversed(plist[:-1]):    # the last bias gets no gradient
+            g = grad_buffer(p)
+            g.fill_(float(rank + 1))
+            _acc(grads, p, g)
+            fired.append(any(b["handle"] not in (None, True) for b in sync.buckets))
+        flat_before = flat.clone()
+        sync.wait()                       # eager: zero-fills the unused parameter, reduces the whole buffer over the bucket ranges
+        ok = all(torch.equal(sync.grad_of(p), torch.full_like(p, 3.0)) for p in plist[:-1])
+        lo = offs[-1]
+        q.put((rank, ok, not any(fired), bool((flat_before[:lo] == rank + 1).all()), bool((flat[lo:lo + plist[-1].numel()] == 0).all()),
+               len(cuts), len(sync.buckets)))
+        detach_grad_sync(plist)
+        dist.barrier()
+        dist.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        import traceback
+        q.put((rank, "ERROR: " + traceback.format_exc()))
+
+
+def test_graph_grad_sync_reduces_nothing_during_the_backward_and_everything_at_the_wait():
+    """parallel.GraphGradSync (the synchronisation of a hipGraph-captured data-parallel iteration): the backward plans hand their
+    gradients over as to GradSync, NO collective starts during the backward (a captured region cannot host one), and ``wait()`` --
+    outside a capture -- reduces the optimizer's whole flat buffer over the bucket ranges: sums over ranks, zeros for a parameter
+    without a gradient.  (The capture-time protocol -- wait() calls ``cut`` instead -- runs in tests/test_gpu_dp.py.)"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_graph_sync_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(60)
+    for r in res:
+        assert len(r) == 7, r
+        _, ok, quiet, untouched, zeroed, ncuts, nb = r
+        assert ok and quiet and untouched and zeroed and ncuts == 0 and nb >= 2
