@@ -39,6 +39,9 @@ for R in 0 8 16; do timeout 300 python bench.py --reserve-cus $R --steps 8 --war
 # two ranks time-slicing the one GPU over gloo (functional smoke of the N > 1 launch, never a measurement): eager bucketed
 # GradSync, and the captured iteration as three hipGraph segments with the all-reduces between them
 HRV_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --steps 3 --warmup 2 --no-cpu-baseline --no-extras 2>$OUT/bench_2rank_gloo.err | tail -1 > $OUT/bench_2rank_gloo_one_gpu_smoke.json
-HRV_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --graph --steps 3 --warmup 2 --no-cpu-baseline --no-extras 2>$OUT/bench_2rank_gloo_graph.err | tail -1 > $OUT/bench_2rank_gloo_graph_one_gpu_smoke.json
+# (GPU_MAX_HW_QUEUES=1: two PROCESSES replaying graphs on one device oversubscribe its hardware queues with the default of 4 per process
+#  and are time-sliced at every cross-queue dependency -- 17-32 s per iteration; one queue each: the eager figure.  One rank per GPU
+#  never meets this.)
+GPU_MAX_HW_QUEUES=1 HRV_DIST_BACKEND=gloo timeout 500 python bench.py --gpus 2 --graph --steps 3 --warmup 2 --no-cpu-baseline --no-extras 2>$OUT/bench_2rank_gloo_graph.err | tail -1 > $OUT/bench_2rank_gloo_graph_one_gpu_smoke.json
 cut -c1-400 $OUT/bench_2rank_gloo_one_gpu_smoke.json $OUT/bench_2rank_gloo_graph_one_gpu_smoke.json
 ls -la $OUT | head -40
