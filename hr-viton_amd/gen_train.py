@@ -627,6 +627,7 @@ class GeneratorTrainPlan:
         xin_top = ops.to_nhwc(x, bf16=True) if (T.MMA_BF16[0] and W % 4 == 0) else xin
         sg = seg if isinstance(seg, Act) else ops.to_nhwc(seg)
         ctxs = []
+        stem_in = []
         cur = None
         if noise is None:
             # the noise planes of every SPADE layer of this forward from ONE generator launch (network_generator.py:103
@@ -637,13 +638,20 @@ class GeneratorTrainPlan:
             h, w = gen.sh << j, gen.sw << j
             shift = top - j
             cin = getattr(gen, name).input_nc
-            xs = xin_top if shift == 0 else xin
+            xs, xsh = (xin_top, 0) if shift == 0 else (xin, -shift)
+            if (0 < shift <= 2 and xin_top.bf16 and N * h * w >= 65536 and w % 4 == 0 and os.environ.get("HRV_STEM_DOWN", "1") != "0"):
+                # conv_5 / conv_6 read x nearest-down-sampled by 4 / 2 (network_generator.py:226-238: F.interpolate, mode 'nearest' --
+                # source pixel (y << shift, x << shift)): a materialised bf16 copy of those pixels (25 / 6 MB) puts the layer and its
+                # weight gradient on the kernels of the full-resolution stem instead of the strided gather of the generic tiles
+                f = 1 << shift
+                xs, xsh = Act(xin_top.t[:, ::f, ::f, :].contiguous(), xin_top.C), 0
+            stem_in.append((xs, xsh))
             if j == 0:
-                cur = self.stems[0].forward([(xs, -shift)])
+                cur = self.stems[0].forward([(xs, xsh)])
             elif isinstance(cur, ops.ActUp):
-                self.stems[j].forward([(xs, -shift)], out=cur.hi)
+                self.stems[j].forward([(xs, xsh)], out=cur.hi)
             else:
-                self.stems[j].forward([(xs, -shift)], out=cur.slice(cin - 16, 16))
+                self.stems[j].forward([(xs, xsh)], out=cur.slice(cin - 16, 16))
             k = 3 if blk.learned else 2
             zs = [z.to(dev).contiguous() for z in noise[name]]
             assert len(zs) == k, (name, len(zs), k)
@@ -665,7 +673,7 @@ class GeneratorTrainPlan:
             ctxs.append(c)
             cur = o
         img = self.img.forward([(cur, 0)], act=ACT_TANH)
-        return ops.to_nchw(img), dict(blocks=ctxs, last=cur, img=img, xin=xin, xin_top=xin_top)
+        return ops.to_nchw(img), dict(blocks=ctxs, last=cur, img=img, stem_in=stem_in)
 
     def backward(self, ctx, d_img: torch.Tensor) -> Grads:
         grads: Grads = {}
@@ -689,17 +697,18 @@ class GeneratorTrainPlan:
             blk, c = self.blocks[j], ctx["blocks"][j]
             d_x = blk.backward(c, d_cur, grads)
             cin = getattr(gen, self.names[j]).input_nc
-            xin = ctx["xin_top"] if c["shift"] == 0 else ctx["xin"]
+            xin, xsh = ctx["stem_in"][j]
             if j == 0:
-                self.stems[0].backward(d_x, [(xin, -c["shift"])], grads, need_dx=False)
+                self.stems[0].backward(d_x, [(xin, xsh)], grads, need_dx=False)
             else:
                 d_stem = d_x.slice(cin - 16, 16)
                 d_stem_w = None
-                if xin.bf16 and c["shift"] == 0 and not d_stem.bf16:
-                    # full-resolution stem (9 -> 16 channels over every pixel: memory-bound): a bf16 copy of its 16 gradient
-                    # channels puts the weight gradient on the LDS-DMA kernel (both operands bf16): 0.91 -> ~0.2 ms
+                if xin.bf16 and xsh == 0 and not d_stem.bf16:
+                    # a stem that reads a bf16 copy of its input at its own resolution (9 -> 16 channels over every pixel:
+                    # memory-bound): a bf16 copy of its 16 gradient channels puts the weight gradient on the LDS-DMA kernel (both
+                    # operands bf16): 0.91 -> ~0.2 ms at full resolution
                     d_stem_w = Act(d_stem.t[..., d_stem.coff:d_stem.coff + 16].to(torch.bfloat16), 16)
-                self.stems[j].backward(d_stem, [(xin, -c["shift"])], grads, need_dx=False, dy_wgrad=d_stem_w)
+                self.stems[j].backward(d_stem, [(xin, xsh)], grads, need_dx=False, dy_wgrad=d_stem_w)
                 d_cur = T.downsum2x2(d_x.slice(0, cin - 16), out_bf16=self.blocks[j - 1].wants_bf16_dout(ctx["blocks"][j - 1]))
         return grads
 
