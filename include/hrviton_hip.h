@@ -761,7 +761,7 @@ int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t stream);
  *   mode 1: w = the FORWARD layer's OIHW weight [Cin][Cout][3][3] (its output channels are this call's K), taps flipped;
  *   mode 2: (w, w2) = [Cin / 2][Cout][3][3] each, K = [w rows | w2 rows], taps flipped.
  * `sigma` (optional device scalar) and `wscale`: packed weight = w * wscale / sigma[0].
- * hrv_conv_p2_supported: shape served and at least two tiles per CU. */
+ * hrv_conv_p2_supported: shape served and at least 1.5 tiles per CU (HRV_CONV_P2_MIN_TILES_X4: the threshold in quarter-tiles). */
 typedef struct hrv_conv_p2 {
   int32_t N, H, W, Cin;
   const void* src; int32_t src_cstride, src_coff, Cout;
