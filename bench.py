@@ -434,6 +434,10 @@ def roofline_obj(wl, res, north_star):
                          "kernel of the step",
                "achieved": gf["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": gf["frac"],
                "launches_per_step": gf["launches"], "ms_per_step": gf["ms_per_step"],
+               "launch_unit": "one hrv_spade_fused_bf16 call (HIP events around it) = one SPADENorm forward; a norm wider than 5 column "
+                              "tiles runs as two kernel dispatches (one per pass width), so a rocprofv3 trace lists more dispatches "
+                              "(26 per iteration at this config) than launches here -- compare TOTAL kernel time per iteration, not the "
+                              "per-dispatch average",
                "algorithmic_flops_per_launch": gf["flops_per_step"] / max(1, gf["launches"]),
                "algorithmic_bytes_per_launch": round(alg, 1),
                "traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (same launch set as achieved / frac)",
