@@ -76,9 +76,11 @@ static bool p2_plan(int Cin, int Cout, P2Plan& pl) {
   memset(&pl, 0, sizeof(pl));
   // K runs over 32-channel chunks; a source whose width is 16 off a multiple of 32 (the generator's 144 / 272-channel block inputs)
   // ends with a half-empty chunk: its upper 16 channels arrive as zeros (out-of-range DMA offsets) against zero weights
-  // columns: any multiple of 4 from 32 up (a bf16 `out` needs a multiple of 8: checked at the launch); the last column tile may be
-  // partly or -- never -- wholly padding: its weights are packed as zeros, its bias / mask / residual reads and its stores are bounded
-  if (Cin < 32 || Cin % 16 != 0 || Cout < 32 || Cout % 4 != 0) return false;
+  // columns: any count; the last column tile may be partly padding: its weights are packed as zeros, its bias / mask / residual reads
+  // and its stores are bounded at 16-byte groups (8 bf16 / 4 fp32 channels: `out` keeps its channels padded to that, the pad lanes get
+  // act(0 + 0) = 0)
+  // (K: any count -- the patch loader bounds 8-channel groups, the packer zero-fills k >= Cin; a source stores its channels padded to 8)
+  if (Cin < 1 || Cout < 1) return false;
   const int NT = (Cout + 31) / 32;
   const int n4 = NT / 4, rem = NT % 4;
   if (n4 + (rem ? 1 : 0) > P2_MAXP) return false;
@@ -551,19 +553,20 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   HRV_REQUIRE(p2_plan(d->Cin, d->Cout, pl), "conv_p2: unsupported shape (K %d, columns %d)", d->Cin, d->Cout);
   HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && (int64_t)d->N * d->H * d->W < ((int64_t)1 << 31), "conv_p2: bad extent");
   HRV_REQUIRE(d->src && d->w_packed && d->out, "conv_p2: null pointer");
-  HRV_REQUIRE(d->src_cstride % 8 == 0 && d->src_coff % 8 == 0 && d->src_coff + d->Cin <= d->src_cstride, "conv_p2: source slice");
+  HRV_REQUIRE(d->src_cstride % 8 == 0 && d->src_coff % 8 == 0 && d->src_coff + ((d->Cin + 7) & ~7) <= d->src_cstride, "conv_p2: source slice");
   const int64_t sbytes = (int64_t)d->H * d->W * d->src_cstride * 2;
   HRV_REQUIRE(sbytes < (int64_t)0xFFFFFFF0, "conv_p2: one image of the source exceeds the 32-bit buffer range");
   const int oes = d->out_f32 ? 4 : 2, oal = d->out_f32 ? 4 : 8;
-  HRV_REQUIRE(d->out_cstride % oal == 0 && d->out_coff % oal == 0 && d->Cout % oal == 0 && d->out_coff + d->Cout <= d->out_cstride,
-              "conv_p2: out slice");
-  HRV_REQUIRE(d->residual == nullptr || (d->res_cstride % 4 == 0 && d->res_coff % 4 == 0 && d->res_coff + d->Cout <= d->res_cstride &&
+  HRV_REQUIRE(d->out_cstride % oal == 0 && d->out_coff % oal == 0 && d->out_coff + ((d->Cout + oal - 1) / oal) * oal <= d->out_cstride,
+              "conv_p2: out slice (channels padded to 16 bytes)");
+  const int c4 = (d->Cout + 3) & ~3;
+  HRV_REQUIRE(d->residual == nullptr || (d->res_cstride % 4 == 0 && d->res_coff % 4 == 0 && d->res_coff + c4 <= d->res_cstride &&
                                          ((uintptr_t)d->residual & 15) == 0),
               "conv_p2: residual slice");
   HRV_REQUIRE((int64_t)d->H * d->W * d->out_cstride * oes < (int64_t)0xFFFFFFF0, "conv_p2: one image of `out` exceeds 4 GB");
   HRV_REQUIRE((((uintptr_t)d->src | (uintptr_t)d->w_packed | (uintptr_t)d->out) & 15) == 0 && ((uintptr_t)d->bias & 3) == 0, "conv_p2: alignment");
   HRV_REQUIRE(d->mask == nullptr || (d->mask_cstride % 4 == 0 && d->mask_coff % 4 == 0 && ((uintptr_t)d->mask & 7) == 0 &&
-                                     d->mask_coff + d->Cout <= d->mask_cstride),
+                                     d->mask_coff + c4 <= d->mask_cstride),
               "conv_p2: mask slice");
   P2Params p;
   memset(&p, 0, sizeof(p));

@@ -400,10 +400,14 @@ def _f32_tile(M: int, cout: int) -> int:
 def _p2_fwd_ok(w: torch.Tensor, a0: Act, stride: int, pad: int, out: Optional[Act], out_is_bf16: bool, residual, act: int) -> bool:
     """csrc/conv_p2.hip serves this forward layer: 3x3 stride-1 'same' over ONE bf16-stored source read at its own resolution."""
     Cout, cin, KH, KW = w.shape
-    return ((KH, KW, stride, pad) == (3, 3, 1, 1) and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and a0.bf16 and a0.C == cin and cin % 16 == 0 and
-            a0.cstride % 8 == 0 and
-            a0.coff % 8 == 0 and Cout % (8 if out_is_bf16 else 4) == 0 and w.is_contiguous() and
-            (out is None or (out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0)) and
+    oal = 8 if out_is_bf16 else 4
+    # a K that is not a multiple of 16 or a column count off the 16-byte store granule: only where it was measured to win -- a
+    # 3-channel image into >= 64 columns (VGG19 features.0: the thin kernel's tile loop is latency-bound there)
+    odd = cin % 16 != 0 or cin < 32 or Cout % oal != 0
+    return ((KH, KW, stride, pad) == (3, 3, 1, 1) and act in (ACT_NONE, ACT_RELU, ACT_LRELU) and a0.bf16 and a0.C == cin and
+            (not odd or (Cout >= 64 and Cout % oal == 0 and os.environ.get("HRV_CONV_P2_ODD", "1") != "0")) and
+            a0.cstride % 8 == 0 and a0.coff % 8 == 0 and a0.coff + (cin + 7) // 8 * 8 <= a0.cstride and w.is_contiguous() and
+            (out is None or (out.cstride % oal == 0 and out.coff % oal == 0)) and
             (residual is None or (type(residual) is Act and residual.C == Cout and residual.cstride % 4 == 0 and residual.coff % 4 == 0 and
                                   residual.t.data_ptr() % 16 == 0)) and
             conv_p2_ok(cin, Cout, a0.N, a0.H, a0.W))
@@ -526,9 +530,14 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         with _Timed("conv", name, fl, ops.act_bytes(out) * (2 if add is not None else 1) + 4.0 * N * Ho * Wo):
             _lib.check(lib.hrv_conv_cout1_dgrad_f32(C.byref(d), _stream()), f"hrv_conv_cout1_dgrad_f32[{name}]")
         return out
+    oal = 8 if out.bf16 else 4
+    # (columns off the 16-byte store granule: only the >= 64-channel gradient into a 3-channel image, VGG19 features.0 -- the padded
+    #  lanes of `out` receive zeros)
     p2 = (mb and stride == 1 and (KH, KW, pad) == (3, 3, 1) and (Ho, Wo) == (H, W) and dy.bf16 and add is None and dy.C == Cout and
-          Cout % 16 == 0 and dy.cstride % 8 == 0 and dy.coff % 8 == 0 and cin % (8 if out.bf16 else 4) == 0 and
-          out.cstride % (8 if out.bf16 else 4) == 0 and out.coff % (8 if out.bf16 else 4) == 0 and
+          Cout % 16 == 0 and dy.cstride % 8 == 0 and dy.coff % 8 == 0 and
+          (cin % oal == 0 or (pair is None and Cout >= 64 and out.coff + (cin + oal - 1) // oal * oal <= out.cstride and
+                              os.environ.get("HRV_CONV_P2_ODD", "1") != "0")) and
+          out.cstride % oal == 0 and out.coff % oal == 0 and
           (act_mask is None or (act_mask.bf16 and act_mask.C == cin and act_mask.cstride % 4 == 0 and act_mask.coff % 4 == 0)) and
           w.is_contiguous() and conv_p2_ok(Cout, cin, N, H, W))
     if p2 and os.environ.get("HRV_CONV_P2_WIDE", "1") == "0":

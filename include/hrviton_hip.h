@@ -751,8 +751,8 @@ int hrv_spade_fused_pack_dev(const float* w_shared, const float* b_shared, int32
                              const float* w_beta, int32_t C, void* out, hrv_stream_t stream);
 int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t stream);
 
-/* 3x3 stride-1 'same' convolution over ONE bf16-stored NHWC source with Cin % 16 == 0 (>= 32) and Cout % 4 == 0 (>= 32; a bf16 `out`:
- * % 8), two blocks per CU
+/* 3x3 stride-1 'same' convolution over ONE bf16-stored NHWC source, any Cin / Cout (the source keeps its channels padded to 8 with
+ * zeros, `out` / `mask` / `residual` theirs padded to 16 bytes: the pad lanes of `out` receive zeros), two blocks per CU
  * (conv_p2.hip): nn.Conv2d forward (VGG19 of the perceptual loss, networks.py:201-233) and data gradients -- of such a
  * convolution (mode 1) or of the SPADE (conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118).
  *   out = act(conv + bias[c] [+ residual]) [* (mask > 0 ? 1 : mask_slope)], bf16 or fp32 NHWC slice.

@@ -95,6 +95,60 @@ def test_pair_data_gradient_matches_torch(C_, N, H, W, cs_mult, out_bf16):
         assert bool((dact_all[..., :dact.coff] == 7.0).all())
 
 
+def test_three_channel_image_ends_match_torch():
+    """VGG19 features.0 (networks.py:208: Conv2d(3, 64, 3, padding=1) + ReLU over the image) and its data gradient (64 -> 3): K / column
+    counts far below a 32-wide tile -- the source stores its 3 channels padded to 8 (zeros), the gradient its 3 channels padded to 4
+    (the pad lane receives 0)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(11)
+    N, H, W = 2, 70, 90
+    img = torch.randn(N, 3, H, W, generator=g).cuda()
+    x = ops.to_nhwc(img, bf16=True)
+    assert x.bf16 and x.C == 3 and x.cstride % 8 == 0
+    w = (torch.randn(64, 3, 3, 3, generator=g) * 0.2).cuda()
+    b = (torch.randn(64, generator=g) * 0.1).cuda()
+    out = ops.alloc(N, H, W, 64, "cuda", bf16=True)
+    T.conv_p2(x, T.conv_p2_pack(0, w, None, 3, 64), 64, out, bias=b, act=ops.ACT_RELU, name="t")
+    torch.cuda.synchronize()
+    want = F.relu(F.conv2d(_bf(img), _bf(w), b, padding=1)).permute(0, 2, 3, 1)
+    got = out.t[..., :64].float()
+    assert bool(((got - want).abs() <= want.abs() * 2 ** -8 + 2e-4 * float(want.abs().max())).all()), float((got - want).abs().max())
+    dy = ops.Act(torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).cuda(), 64)
+    dx = ops.Act(torch.full((N, H, W, 4), 7.0, device="cuda"), 3)
+    T.conv_p2(dy, T.conv_p2_pack(1, w, None, 64, 3), 3, dx, name="t")
+    torch.cuda.synchronize()
+    wantd = F.conv_transpose2d(dy.t.float().permute(0, 3, 1, 2), _bf(w), padding=1).permute(0, 2, 3, 1)
+    assert float((dx.t[..., :3] - wantd).abs().max()) <= 3e-4 * float(wantd.abs().max())
+    assert bool((dx.t[..., 3] == 0).all())                  # the pad lane stays zero
+
+
+def test_vgg_first_layer_routes_through_the_kernel(monkeypatch):
+    """train_ops routes features.0 and its data gradient onto conv_p2 (HRV_CONV_P2_ODD=0: the thin kernel): same results to bf16 /
+    accumulation-order noise."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    T.MMA_BF16[0] = True
+    try:
+        g = torch.Generator().manual_seed(12)
+        N, H, W = 2, 512, 384
+        img = torch.randn(N, 3, H, W, generator=g).cuda()
+        w = (torch.randn(64, 3, 3, 3, generator=g) * 0.2).cuda()
+        b = (torch.randn(64, generator=g) * 0.1).cuda()
+        dy = ops.Act(torch.randn(N, H, W, 64, generator=g).to(torch.bfloat16).cuda(), 64)
+        res = {}
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HRV_CONV_P2_ODD", flag)
+            y = T.conv_forward_dev(w, [(ops.to_nhwc(img, bf16=True), 0)], 1, 1, shift=b, act=ops.ACT_RELU, out_bf16=True, name="vgg.features.0")
+            dx = T.conv_dgrad(dy, w, H, W, 1, 1, out_bf16=True, name="vgg.features.0.dgrad")
+            torch.cuda.synchronize()
+            res[flag] = (y.t.float().clone(), dx.t[..., :3].float().clone())
+        for a, b_ in zip(res["1"], res["0"]):
+            assert float((a - b_).abs().max()) <= 2 ** -7 * float(b_.abs().max())
+    finally:
+        T.MMA_BF16[0] = False
+
+
 @pytest.mark.parametrize("Cin,Cout,res_bf16,out_bf16,act", [(80, 64, False, False, 0), (48, 32, False, True, 2), (144, 128, True, False, 0),
                                                              (80, 80, False, True, 1)])
 def test_forward_with_residual_matches_torch(Cin, Cout, res_bf16, out_bf16, act):
