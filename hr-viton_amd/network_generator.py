@@ -227,8 +227,11 @@ class _BlockPlan:
         self._fast = None
         if bf16:
             dv = lambda t: None if t is None else t.detach().to(device=device, dtype=torch.float32).contiguous()    # noqa: E731
+            from . import train_ops as T
+            # (tok: unique per plan object -- an id() or a storage address can be recycled by a later plan and would then return
+            #  this plan's packed weights from train_ops' frozen-pack cache)
             self._fast = dict(w0=dv(_raw_weight(blk.conv_0)), b0=dv(blk.conv_0.bias), s0=1.0 / s0,
-                              w1=dv(self.c1_w), b1=dv(self.c1_b), s1=1.0 / s1)
+                              w1=dv(self.c1_w), b1=dv(self.c1_b), s1=1.0 / s1, tok=next(T._PACK_TOKENS))
         self.device, self.name, self.blk = device, name, blk
         self._c1 = {}
         if self.learned:
@@ -255,7 +258,7 @@ class _BlockPlan:
             from . import train_ops as T
             f = self._fast
             r = T.conv_forward_fast(f["w0"], h0, 1, f["s0"], f["b0"], None, ACT_NONE, 0.2, None, False, self.name + ".conv_0",
-                                    ("serve", id(self), 0))
+                                    ("serve", f["tok"], 0))
             if r is not None:
                 return r
         return self.c0([h0])
@@ -265,7 +268,7 @@ class _BlockPlan:
             from . import train_ops as T
             f = self._fast
             r = T.conv_forward_fast(f["w1"], h1, 1, f["s1"], f["b1"], x_s, out_act, 0.2, out, out_act != ACT_NONE, self.name + ".conv_1",
-                                    ("serve", id(self), 1))
+                                    ("serve", f["tok"], 1))
             if r is not None:
                 return r
         return self.conv1(out_act)([h1], out=out, residual=x_s, out_up=out_up)
@@ -377,6 +380,8 @@ class SPADEGenerator(BaseNetwork):
             dv = lambda t: t.detach().to(device=device, dtype=torch.float32).contiguous()      # noqa: E731
             P["stem_fast"] = [dict(w=dv(getattr(self, f"conv_{i}").weight), b=dv(getattr(self, f"conv_{i}").bias))
                               for i in range(len(P["blocks"]))]
+            from . import train_ops as T
+            P["tok"] = next(T._PACK_TOKENS)
             P["img_fast"] = dict(w=self.conv_img.weight.detach().to(device=device, dtype=torch.float32).contiguous(),
                                  b=self.conv_img.bias.detach().to(device=device, dtype=torch.float32).contiguous())
         return P
@@ -448,7 +453,7 @@ class SPADEGenerator(BaseNetwork):
                 if bf and shift == 0 and "stem_fast" in P:      # conv_7: 9 -> 16 channels over every pixel, memory-bound (thin_conv.hip)
                     from . import train_ops as T
                     sf = P["stem_fast"][j]
-                    done = T.conv_forward_fast(sf["w"], xin, 1, 1.0, sf["b"], None, ACT_NONE, 0.2, hi, False, f"conv_{j}", ("serve", id(P), 10 + j))
+                    done = T.conv_forward_fast(sf["w"], xin, 1, 1.0, sf["b"], None, ACT_NONE, 0.2, hi, False, f"conv_{j}", ("serve", P["tok"], 10 + j))
                 if done is None:
                     P["stem"][j]([(xin, -shift, ACT_NONE)], out=hi)
             assert cur.C == cin and (cur.H, cur.W) == (h, w)
@@ -471,7 +476,7 @@ class SPADEGenerator(BaseNetwork):
         if bf and "img_fast" in P:
             from . import train_ops as T
             fi = P["img_fast"]
-            img = T.conv_forward_fast(fi["w"], cur, 1, 1.0, fi["b"], None, ACT_TANH, 0.2, None, False, "conv_img", ("serve", id(P), 2))
+            img = T.conv_forward_fast(fi["w"], cur, 1, 1.0, fi["b"], None, ACT_TANH, 0.2, None, False, "conv_img", ("serve", P["tok"], 2))
         if img is None:
             img = P["img"]([cur])
         return ops.to_nchw(img)

@@ -250,6 +250,17 @@ def test_bf16_serving_paths_agree_at_full_size(monkeypatch):
         assert float((o - ref).abs().mean()) < d_ref, (k, float((o - ref).abs().mean()), float((o - ref).abs().max()), d_ref)
         assert abs(float((o - fp).abs().mean()) - d_ref) <= 0.15 * d_ref + 1e-5, (k, float((o - fp).abs().mean()), d_ref)
     assert d_ref < 8e-3, d_ref        # measured 5.4e-3 (max 8e-2) for every route on this random network with noise_scale ~ N(0, 0.1)
+    # the weights change (a new plan, whose packed streams must not come out of the old plan's cache entries): the fast route still
+    # agrees with the plan's own ConvLayers, and the output really moved
+    g2 = torch.Generator().manual_seed(9)
+    with torch.no_grad():
+        for name in ("up_2", "up_3", "up_4"):
+            for cv in (getattr(m, name).conv_0, getattr(m, name).conv_1):
+                w = cv.weight_orig if hasattr(cv, "weight_orig") else cv.weight
+                w.add_((torch.randn(w.shape, generator=g2) * float(w.std())).to(w.device))
+    new = run()
+    assert float((new - ref).abs().mean()) > 5e-3
+    assert float((run(HRV_SERVE_FAST="0") - new).abs().mean()) < d_ref
 
 
 def test_generator_bf16_engine_matches_bf16_emulation():
