@@ -23,7 +23,7 @@ from .ops import HrvError
 class CaptureGuard:
     """What a captured region baked into its hipGraph besides the tensors torch's graph pool owns: raw addresses of
     Python-owned buffers -- the per-device split-K / weight-gradient workspace (ops._WS), the pack buffers and record tables
-    of the plans' PackBatches, persistent per-plan buffers (S2DConv._w2, the spectral-norm sigma buffer; those are never
+    of the plans' PackBatches, the cached packed streams of frozen weights (train_ops._FROZEN_PACKS), persistent per-plan buffers (S2DConv._w2, the spectral-norm sigma buffer; those are never
     re-allocated while their module lives).  ``before()`` is taken ahead of the capture, ``after()`` behind it:
 
     * every such tensor alive at the end of the capture is KEPT alive by the guard, so a later eager call that grows the
@@ -42,6 +42,10 @@ class CaptureGuard:
         import weakref
         from . import ops
         self.keep = list(ops._WS.values())
+        # packed streams of frozen weights (train_ops' cache: VGG19, the serving plan's conv_p2 layers) that existed before the capture
+        # were baked in by address too; the cache drops everything when it outgrows 256 entries
+        from . import train_ops as T
+        self.keep.extend(v[0] for v in T._FROZEN_PACKS.values())
         for o in list(ops.GRAPH_WATCH):
             if o.runs != self._runs.get(id(o), 0):           # launched inside the captured region
                 self.keep.extend(o.graph_keep())
