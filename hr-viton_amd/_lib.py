@@ -101,7 +101,8 @@ class hrv_conv_p2_t(C.Structure):
                 ("act", C.c_int32), ("act_slope", C.c_float),
                 ("mask", C.c_void_p), ("mask_cstride", C.c_int32), ("mask_coff", C.c_int32), ("mask_slope", C.c_float), ("out_f32", C.c_int32),
                 ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32),
-                ("res_f32", C.c_int32), ("residual", C.c_void_p), ("res_cstride", C.c_int32), ("res_coff", C.c_int32)]
+                ("res_f32", C.c_int32), ("residual", C.c_void_p), ("res_cstride", C.c_int32), ("res_coff", C.c_int32),
+                ("res_after_mask", C.c_int32)]
 
 
 class hrv_conv2d_t(C.Structure):

@@ -59,7 +59,8 @@ struct P2Params {
   int m_tiles;
   int Cout;
   const float* bias;        // [Cout] or nullptr
-  const void* res; int res_cs, res_co, res_f32;                      // residual added before the activation (fp32 or bf16 NHWC slice)
+  const void* res; int res_cs, res_co, res_f32, res_after;           // residual (fp32 or bf16 NHWC slice) added before the activation,
+                                                                     // or -- res_after -- behind activation and mask
   int act; float slope;
   const void* mask; int mask_cs, mask_co; float mask_slope;          // bf16: out *= (mask > 0 ? 1 : mask_slope)
   void* out; int out_cs, out_co, out_f32;
@@ -426,7 +427,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
         f32x4 t = p2_acc4(acc[i][j], g) + b;
-        if (p.res) t = t + rv[i][g];
+        if (p.res && !p.res_after) t = t + rv[i][g];
         const f32x4 ts = t * sl;
 #pragma unroll
         for (int e = 0; e < 4; ++e) t[e] = relu ? fmaxf(t[e], 0.f) : fmaxf(t[e], ts[e]);      // (ReLU: +0, never v * 0 = -0)
@@ -434,6 +435,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
 #pragma unroll
           for (int e = 0; e < 4; ++e) t[e] = bf2f(mv[i][g][e]) > 0.f ? t[e] : t[e] * msl;
         }
+        if (p.res && p.res_after) t = t + rv[i][g];
         vv[i][g] = t;
       }
     }
@@ -578,7 +580,7 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   p.m_tiles = d->N * ((d->H + 15) / 16) * ((d->W + 15) / 16);
   p.Cout = d->Cout;
   p.bias = d->bias; p.act = d->act; p.slope = d->act_slope;
-  p.res = d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff; p.res_f32 = d->res_f32;
+  p.res = d->residual; p.res_cs = d->res_cstride; p.res_co = d->res_coff; p.res_f32 = d->res_f32; p.res_after = d->res_after_mask;
   p.mask = d->mask; p.mask_cs = d->mask_cstride; p.mask_co = d->mask_coff; p.mask_slope = d->mask_slope;
   p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff; p.out_f32 = d->out_f32;
   p.tlog = diag_tlog(p.m_tiles);

@@ -496,13 +496,19 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
 
 def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float = 1.0,
                sigma: Optional[torch.Tensor] = None, act_mask: Optional[Act] = None, slope: float = 0.2, out: Optional[Act] = None,
-               name: str = "dgrad", out_bf16: bool = False, frozen=None, add: Optional[Act] = None, batch=None) -> Act:
+               name: str = "dgrad", out_bf16: bool = False, frozen=None, add: Optional[Act] = None, batch=None,
+               add_after: Optional[Act] = None) -> Act:
     """dX [N,H,W,Cin] of y = conv(x, w*wscale) given dY ([N,Ho,Wo,Cout]); optionally multiplied by the
     activation derivative of ``act_mask`` (x = act(pre) with act = ReLU/LeakyReLU: mask tensor = x).
     ``w`` may be a PAIR (w_gamma, w_beta) for dY = [dgamma | dbeta] (stride 1): packed without a concatenated copy.
     ``add`` (instead of ``act_mask``): a second gradient of the same tensor, summed in the epilogue (the feature-matching
-    tap gradient of a PatchGAN feature joins the gradient flowing down through it: no separate accumulation pass)."""
+    tap gradient of a PatchGAN feature joins the gradient flowing down through it: no separate accumulation pass).
+    ``add_after`` (with or without ``act_mask``): a gradient w.r.t. the same PRE-activation, added behind the mask (VGG19's tap
+    gradients, which carry their ReLU derivative already) -- in the epilogue of csrc/conv_p2.hip where that kernel serves the layer,
+    else by a separate add_slice pass."""
     lib = _lib.load()
+    if add_after is not None:
+        assert add is None and (add_after.N, add_after.H, add_after.W) == (dy.N, H, W)
     assert add is None or act_mask is None, "conv_dgrad: one residual slot (mask or addend)"
     pair = w if isinstance(w, (tuple, list)) else None
     if pair is not None:
@@ -542,6 +548,14 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
           w.is_contiguous() and conv_p2_ok(Cout, cin, N, H, W))
     if p2 and os.environ.get("HRV_CONV_P2_WIDE", "1") == "0":
         p2 = Cout % 32 == 0 and cin % 64 == 0 and not (pair is None and _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W))
+    if add_after is not None:
+        ride = (p2 and add_after.C == cin and add_after.cstride % 4 == 0 and add_after.coff % 4 == 0 and add_after.t.data_ptr() % 16 == 0 and
+                add_after.coff + (cin + 3) // 4 * 4 <= add_after.cstride and os.environ.get("HRV_DGRAD_ADD_AFTER", "1") != "0")
+        if not ride:
+            out = conv_dgrad(dy, pair if pair is not None else w, H, W, stride, pad, wscale, sigma,
+                             act_mask if res_mode == 1 else None, slope, out, name, out_bf16, frozen, None, batch)
+            add_slice(add_after, out, True)
+            return out
     if (not p2 and add is None and pair is None and stride == 1 and (Ho, Wo) == (H, W) and w.is_contiguous() and out.cstride % 4 == 0 and
             _thin_ok(dy, KH, KW, 1, pad, cin, N, H, W)):
         return _thin_conv(dy, w, 1, sigma, wscale, None, act_mask, res_mode, ACT_NONE, slope, out, name, fl)
@@ -549,7 +563,8 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         # a stride-1 data gradient is a 'same' 3x3 convolution over dY: the two-blocks-per-CU kernel
         pk = (conv_p2_pack(2, pair[0], pair[1], Cout, cin) if pair is not None else
               conv_p2_pack(1, w, None, Cout, cin, sigma, wscale, frozen))
-        return conv_p2(dy, pk, cin, out, mask=act_mask if res_mode == 1 else None, mask_slope=slope, name=name, flops=fl)
+        return conv_p2(dy, pk, cin, out, mask=act_mask if res_mode == 1 else None, mask_slope=slope, name=name, flops=fl,
+                       residual=add_after, res_after_mask=add_after is not None)
     if stride == 1:
         if mb and (Ho, Wo) == (H, W):   # a stride-1 data gradient is a 'same' 3x3 convolution over dY
             cfg = ops.patch_tile(dy.bf16, KH, KW, 1, KH - 1 - pad, 1, 0, dy.Cp, cin, N, H, W) or cfg
@@ -1286,8 +1301,8 @@ def conv_p2_pack(mode: int, w: torch.Tensor, w2: Optional[torch.Tensor], K: int,
 
 def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE, slope: float = 0.2,
             mask: Optional[Act] = None, mask_slope: float = 0.0, name: str = "conv", flops: float = 0.0, tag: str = "",
-            residual: Optional[Act] = None):
-    """out = act(conv3x3(src) + bias [+ residual]) [* (mask > 0 ? 1 : mask_slope)] on csrc/conv_p2.hip."""
+            residual: Optional[Act] = None, res_after_mask: bool = False):
+    """out = act(conv3x3(src) + bias [+ residual]) [* (mask > 0 ? 1 : mask_slope)] [+ residual if res_after_mask] on csrc/conv_p2.hip."""
     lib = _lib.load()
     assert src.bf16 and out.C == cols
     d = _lib.hrv_conv_p2_t()
@@ -1304,6 +1319,7 @@ def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[
     if residual is not None:
         assert residual.C == cols
         d.residual, d.res_cstride, d.res_coff, d.res_f32 = residual.t.data_ptr(), residual.cstride, residual.coff, 0 if residual.bf16 else 1
+        d.res_after_mask = 1 if res_after_mask else 0
     nb = (ops.act_bytes(src) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0) +
           (ops.act_bytes(residual) if residual is not None else 0.0) + 2.0 * src.C * cols * 9)
     with ops._Timed("conv", name + tag, flops, nb):

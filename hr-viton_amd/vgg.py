@@ -196,13 +196,15 @@ class _VGGLossFn(torch.autograd.Function):
         # the kernel that produces the gradient (the tap gradients in the loss kernel, pooled tensors in the max-pool
         # backward, conv -> conv transitions as the data gradient's activation mask): no separate masking pass
         d: Optional[Act] = None
+        order = [c[0] for c in _CONVS]
+        joined = set()          # taps whose gradient already joined ``d`` in the epilogue of the data gradient above them
         for item in reversed(saved):
             if item[0] == "pool":
                 if d is not None:
                     d = T.maxpool2x2_bwd(item[1], d, relu=True)
                 continue
             _, idx, src, out = item
-            if idx in _TAPS:
+            if idx in _TAPS and idx not in joined:
                 gi = grads[_TAPS.index(idx)]
                 if gi is not None:
                     gact = Act(gi, out.C)
@@ -214,9 +216,16 @@ class _VGGLossFn(torch.autograd.Function):
                 continue
             w = vgg.conv(idx).weight.data
             fused = idx != 0 and (idx - 1) not in _POOLS        # src is the previous conv's ReLU output
+            # ... and when that previous conv is a tap (relu1_1 .. relu4_1 feed the next conv directly), its loss gradient -- same
+            # tensor, ReLU derivative already applied -- joins this data gradient behind the mask: no separate accumulation pass
+            tap = None
+            prev = order[order.index(idx) - 1] if idx != 0 else None
+            if fused and prev in _TAPS and grads[_TAPS.index(prev)] is not None and grads[_TAPS.index(prev)].dtype == (torch.bfloat16 if d.bf16 else torch.float32):
+                tap = Act(grads[_TAPS.index(prev)], src.C)
+                joined.add(prev)
             d = T.conv_dgrad(d, w, src.H, src.W, 1, 1, act_mask=src if fused else None, slope=0.0,
                              name=f"vgg.features.{idx}.dgrad", frozen=T.frozen_stamp(vgg.conv(idx).weight),
-                             out_bf16=d.bf16)
+                             out_bf16=d.bf16, add_after=tap)
         ctx.saved = ctx.grads = None
         dx = ops.to_nchw(d)
         T.scale_(dx, 1.0, g_out.contiguous())

@@ -755,7 +755,7 @@ int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t stream);
  * zeros, `out` / `mask` / `residual` theirs padded to 16 bytes: the pad lanes of `out` receive zeros), two blocks per CU
  * (conv_p2.hip): nn.Conv2d forward (VGG19 of the perceptual loss, networks.py:201-233) and data gradients -- of such a
  * convolution (mode 1) or of the SPADE (conv_gamma, conv_beta) pair over [dgamma | dbeta] (mode 2, network_generator.py:117-118).
- *   out = act(conv + bias[c] [+ residual]) [* (mask > 0 ? 1 : mask_slope)], bf16 or fp32 NHWC slice.
+ *   out = act(conv + bias[c] [+ residual]) [* (mask > 0 ? 1 : mask_slope)] [+ residual, if res_after_mask], bf16 or fp32 NHWC slice.
  * `Cin` = K (channels of `src`), `Cout` = columns, whatever the mode; w_packed from hrv_conv_p2_pack_dev of the same mode:
  *   mode 0: w = the layer's OIHW weight [Cout][Cin][3][3];
  *   mode 1: w = the FORWARD layer's OIHW weight [Cin][Cout][3][3] (its output channels are this call's K), taps flipped;
@@ -772,6 +772,8 @@ typedef struct hrv_conv_p2 {
   void* out; int32_t out_cstride, out_coff;
   int32_t res_f32;                                           /* residual dtype: 1 fp32, 0 bf16 */
   const void* residual; int32_t res_cstride, res_coff;       /* optional NHWC slice added BEFORE the activation (SPADEResBlock: x_s + dx) */
+  int32_t res_after_mask;                                    /* 1: added behind activation and mask instead (a data gradient that meets
+                                                              * another gradient of the same tensor: VGG19's tap gradients) */
 } hrv_conv_p2_t;
 int64_t hrv_conv_p2_packed_bytes(int32_t Cin, int32_t Cout);   /* -1: shape not served */
 int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32_t H, int32_t W);

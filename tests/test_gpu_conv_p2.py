@@ -199,3 +199,31 @@ def test_training_convs_route_through_the_kernel_and_match_the_generic_tiles(mon
             assert float((a - b_).abs().max()) <= 2 ** -7 * float(b_.abs().max())
     finally:
         T.MMA_BF16[0] = False
+
+
+def test_data_gradient_joins_a_second_gradient_behind_the_mask(monkeypatch):
+    """conv_dgrad(add_after=...): dX = conv^T(dY) * relu'(x) + g (VGG19's tap gradients meet the gradient flowing down through the tap
+    in the epilogue of the data gradient above it; HRV_DGRAD_ADD_AFTER=0: a separate add_slice pass over the bf16 result)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    T.MMA_BF16[0] = True
+    try:
+        g = torch.Generator().manual_seed(21)
+        N, H, W, K, Ccol = 2, 256, 272, 128, 64
+        dy = ops.Act(torch.randn(N, H, W, K, generator=g).to(torch.bfloat16).cuda(), K)
+        w = (torch.randn(K, Ccol, 3, 3, generator=g) * 0.05).cuda()
+        x = ops.Act(torch.relu(torch.randn(N, H, W, Ccol, generator=g)).to(torch.bfloat16).cuda(), Ccol)
+        gi = ops.Act(torch.randn(N, H, W, Ccol, generator=g).to(torch.bfloat16).cuda(), Ccol)
+        conv = F.conv_transpose2d(dy.t.float().permute(0, 3, 1, 2), _bf(w), padding=1).permute(0, 2, 3, 1) * (x.t.float() > 0)
+        want = conv + gi.t.float()
+        for flag in ("1", "0"):
+            monkeypatch.setenv("HRV_DGRAD_ADD_AFTER", flag)
+            d = T.conv_dgrad(dy, w, H, W, 1, 1, act_mask=x, slope=0.0, out_bf16=True, name="l.dgrad", add_after=gi)
+            torch.cuda.synchronize()
+            got = d.t[..., :Ccol].float()
+            # one rounding of the sum (fused) or two (the data gradient stored in bf16, then the sum: the first one is relative to the
+            # gradient, which can cancel against g)
+            tol = (conv.abs() + want.abs()) * 2 ** -8 + 3e-4 * float(want.abs().max())
+            assert bool(((got - want).abs() <= tol).all()), (flag, float((got - want).abs().max()))
+    finally:
+        T.MMA_BF16[0] = False
