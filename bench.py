@@ -8,19 +8,23 @@ VGG19 + feature-matching + hinge losses, fused Adam on both networks; DP all-red
 A "step" is that whole iteration over one synthetic batch already resident in HBM.  N>1: one process per GPU
 (torch.distributed.run, backend nccl = RCCL), weak scaling; value = images of all ranks / max-over-ranks time.
 
-Extra objects on the JSON line:
-  roofline     -- north-star definition: algorithmic FLOPs of the SPADE-generator 3x3 convolutions
-                  (forward, data gradient, weight gradient) / the summed HIP-event durations of exactly those launches,
-                  against the 2.5 PFLOP/s dense bf16 MFMA peak; `whole_step_conv_family` is the same ratio over every
-                  convolution launch of the iteration; `hbm_kinds` prices the HBM-bound launch kinds in GB/s against
-                  6.3 TB/s; `traffic` = HBM bytes per conv launch from the committed rocprofv3 PMC passes of this
-                  command (profiles/, tools/profile_traffic.sh) next to `algorithmic_bytes_per_launch`.
-  cpu_baseline -- the oracle's whole iteration (oracle/step_check.py) on this box's host cores at 256x192 'more'
-                  (BASELINE.md section 4), 1 warm-up + 3 timed, median.
-  parity       -- generator half of the iteration at 512x384 ngf=64 against torch autograd over the oracle: image,
-                  loss terms, every parameter gradient (fp32 engine), and the same with the bf16 engine.
-  extra        -- BASELINE configs[4] (tryon_infer bf16, 16 img/GPU) and configs[1] (tocg inference fp32, with the
-                  argmax index check) measured in the same run.
+Output: the LAST stdout line is ONE compact JSON object under 4 KB (compact_line): the contract keys, `roofline`, `cpu_baseline`, the
+worst `parity` numbers, value / ms / frac of the `extra` configurations.  The full result -- every table, note and sub-object below --
+is written to gpurun_out/bench_detail.json (the line's `detail` key names it); progress goes to stderr.
+  roofline     -- the DOMINANT kernel of the step: the device-kernel family with the largest summed HIP-event time in one iteration
+                  (template instances of one kernel summed -- what heads a rocprofv3 kernel trace of the same command), its
+                  algorithmic FLOPs / that time against the 2.5 PFLOP/s dense bf16 MFMA peak (an HBM-bound family: bytes against
+                  8 TB/s), `traffic` = HBM bytes per launch of exactly that kernel name from the committed rocprofv3 PMC passes of
+                  this command (profiles/, tools/profile_traffic.sh) next to `algorithmic_bytes_per_launch`; `kernels` = the next
+                  families by time; `north_star_set_frac` = the north star's own aggregate: every 3x3 convolution launch
+                  of the SPADE generator (forward, data gradient, weight gradient).  Detail file only: `whole_step_conv_family`,
+                  `hbm_kinds` (the HBM-bound launch kinds in GB/s against 6.3 TB/s), `slowest_launches`.
+  cpu_baseline -- the oracle's whole iteration (oracle/step_check.py) on this box's host cores: ONE image 1024x768 'most', one timed
+                  iteration (and, detail file, 256x192 'more': 1 warm-up + 3 timed, median -- BASELINE.md section 4).
+  parity       -- the generator and discriminator halves of the iteration at 2 x 1024x768 ngf=64 against torch autograd over the
+                  oracle: image, loss terms, every parameter gradient (fp32 engine), and the same with the bf16 engine.
+  extra        -- BASELINE configs[4] (tryon_infer bf16, 16 img/GPU, hipGraph replay), configs[1] (tocg inference fp32, with the
+                  argmax index check), configs[2] (train_condition fp32, b=8) measured in the same run.
 Other workloads: --workload tocg_infer | tryon_infer | train_condition (same JSON shape).
 """
 import argparse
@@ -61,14 +65,15 @@ def _log(msg):
 
 
 def summarize(recs, peak_tflops):
-    """recs: [(kind, name, flops, bytes, ms)] of ONE step -> roofline pieces."""
-    kinds = {}
-    for k, n, fl, by, ms in recs:
-        a = kinds.setdefault(k, [0, 0.0, 0.0, 0.0])
-        a[0] += 1
-        a[1] += ms
-        a[2] += fl
-        a[3] += by
+    """recs: [(kind, name, flops, bytes, ms, kernel)] of ONE step -> roofline pieces."""
+    kinds, kern = {}, {}
+    for k, n, fl, by, ms, kn in recs:
+        for tab, key in ((kinds, k), (kern, kn)):
+            a = tab.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += ms
+            a[2] += fl
+            a[3] += by
     mm = [r for r in recs if r[0] in ("conv", "wgrad")]
     sp = [r for r in mm if is_spade_gen_3x3(r[0], r[1])]
     gb = [r for r in mm if r[1].endswith("[spade_gb]")]      # the SPADE gamma|beta family: fused forward, pair data gradient
@@ -91,22 +96,30 @@ def summarize(recs, peak_tflops):
     gba["algorithmic_bytes_per_launch"] = sum(r[3] for r in gb) / max(1, len(gb))
     gfa = agg(gf)
     gfa["algorithmic_bytes_per_launch"] = sum(r[3] for r in gf) / max(1, len(gf))
-    return {"kinds": kinds, "spade": agg(sp), "all": agg(mm), "hbm": hbm, "gb": gba, "gf": gfa,
+    # per device-kernel family, largest share of the step first: [(kernel, launches, ms, flops, bytes)]
+    by_kernel = sorted(((kn, a[0], a[1], a[2], a[3]) for kn, a in kern.items()), key=lambda r: -r[2])
+    return {"kinds": kinds, "by_kernel": by_kernel, "spade": agg(sp), "all": agg(mm), "hbm": hbm, "gb": gba, "gf": gfa,
             "conv_alg_bytes_per_launch": conv_bytes / max(1, len(mm)), "conv_launches": len(mm),
             "top": sorted(mm, key=lambda r: -r[4])[:6]}
 
 
 def dump_launches(path, recs):
     with open(path, "w") as f:
-        for k, n, fl, by, ms in recs:
+        for k, n, fl, by, ms, kn in recs:
             f.write(f"{k:8s} {n:52s} {ms:9.4f} ms  {fl / (ms * 1e-3) / 1e12 if ms > 0 else 0:8.2f} TFLOP/s  "
-                    f"{by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s\n")
+                    f"{by / (ms * 1e-3) / 1e9 if ms > 0 else 0:9.1f} GB/s  {kn}\n")
+
+
+# launch tag of hr_viton_amd.ops._Timed -> the kernel-family key of tools/traffic_json.py
+_TRAFFIC_FAMILY = {"conv_wgrad_tr_kernel": "conv_wgrad_tr", "conv_wgrad_kernel": "conv_wgrad", "thin_conv_kernel": "thin_conv",
+                   "stats": "instnorm"}
 
 
 def load_traffic(tag, family=None):
     """HBM bytes per launch from the committed PMC passes of this command (cannot be read in-process): of one kernel
     family (``family``, e.g. "spade_gb_kernel") or averaged over every convolution launch."""
-    for rnd in ("r04", "r03", "r02", "r01"):
+    family = _TRAFFIC_FAMILY.get(family, family)
+    for rnd in ("r05", "r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{tag}.json")
         if os.path.exists(tp):
             with open(tp) as f:
@@ -397,7 +410,7 @@ def measure(ctx, wl, steps, warmup, mixed, dump=None):
     dt = hdist.timed_steps(wl.get("timed") or wl["step"], steps, warmup, torch.cuda.synchronize)
     ops.profile_begin()
     wl["step"](0)
-    recs = ops.profile_end()
+    recs = ops.profile_end(kernels=True)
     if dump and ctx["rank"] == 0:
         dump_launches(dump, recs)
     peak = PEAK_BF16_MFMA_TFLOPS if mixed else PEAK_F32_MFMA_TFLOPS
@@ -408,65 +421,181 @@ def measure(ctx, wl, steps, warmup, mixed, dump=None):
     return res
 
 
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s (spec); 6.3 TB/s is the measured copy rate (hbm_kinds)
+
+
+def kernel_row(row, peak_tflops):
+    """(kernel, launches, ms, flops, bytes) -> the roofline fields of ONE device-kernel family of the step."""
+    kn, n, ms, fl, by = row
+    mfma = fl > 0
+    ach = (fl / (ms * 1e-3) / 1e12) if mfma else (by / (ms * 1e-3) / 1e9)
+    peak = peak_tflops if mfma else HBM_PEAK_GBPS
+    return {"kernel": "hrv::" + kn, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
+            "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "launches_per_step": n, "ms_per_step": round(ms, 3),
+            "algorithmic_flops_per_launch": fl / max(1, n), "algorithmic_bytes_per_launch": round(by / max(1, n), 1)}
+
+
 def roofline_obj(wl, res, north_star):
-    """north_star workloads (the SPADE generator runs): the object describes ONE launch set end to end -- the dominant
-    kernel, hrv::spade_gb_kernel (gamma|beta 3x3 convolution + modulate, forward and data gradient): achieved / frac from the
-    HIP-event durations of exactly those launches, algorithmic bytes of exactly those launches, HBM traffic of exactly
-    that kernel name from the PMC passes.  `spade_3x3_set` keeps the north-star aggregate of rounds 1-2 (every 3x3
-    convolution launch of the SPADE generator: forward, data and weight gradients)."""
+    """The object describes the DOMINANT kernel of the step: the device-kernel family with the largest summed HIP-event time over one
+    iteration (what heads the per-kernel table of a rocprofv3 trace of the same command, template instances of one kernel summed) --
+    achieved / frac from the durations of exactly those launches and their algorithmic FLOPs (or bytes, for an HBM-bound kernel), HBM
+    traffic of exactly that kernel name from the PMC passes of this build.  ``kernels``: the same fields for the next families by
+    time (spade_fused_kernel among them); ``north_star_set_*``: every 3x3 convolution launch of the SPADE generator (forward, data and
+    weight gradients) -- the aggregate BASELINE.json's north star prices."""
     s = res["summary"]
-    common = {"whole_step_conv_family": s["all"],
-              "end_to_end_TFLOPs_vs_survey_work": round(wl["B"] * wl["flops_per_img"] / (res["dt"] / res["steps"]) / 1e12, 2),
-              "hbm_kinds": s["hbm"],
-              "slowest_launches": [{"name": r[1], "ms": round(r[4], 3), "TFLOPs": round(r[2] / (r[4] * 1e-3) / 1e12, 1)}
-                                   for r in s["top"]]}
-    gb, gf = s["gb"], s.get("gf", {"launches": 0})
-    if north_star and gf["launches"] > 0:
-        # the dominant kernel: hrv::spade_fused_kernel -- conv_shared + ReLU + the gamma|beta 3x3 convolutions + modulate in one
-        # launch (network_generator.py:93-121).  FLOPs priced: the gamma|beta convolutions only (the north star's work; the
-        # in-kernel conv_shared recompute, +8 % matrix work, is not counted as useful)
-        per_step, src = load_traffic(wl["traffic_tag"], "spade_fused_kernel")
-        traffic = per_step / gf["launches"] if per_step else None
-        alg = gf["algorithmic_bytes_per_launch"]
-        out = {"bound": "mfma",
-               "kernel": "hrv::spade_fused_kernel -- SPADENorm forward fused end to end: conv_shared + ReLU computed in the kernel, the "
-                         "gamma|beta 3x3 convolutions, the modulate epilogue (network_generator.py:93-121); two blocks per CU; the dominant "
-                         "kernel of the step",
-               "achieved": gf["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": gf["frac"],
-               "launches_per_step": gf["launches"], "ms_per_step": gf["ms_per_step"],
-               "launch_unit": "one hrv_spade_fused_bf16 call (HIP events around it) = one SPADENorm forward; a norm wider than 5 column "
-                              "tiles runs as two kernel dispatches (one per pass width), so a rocprofv3 trace lists more dispatches "
-                              "(26 per iteration at this config) than launches here -- compare TOTAL kernel time per iteration, not the "
-                              "per-dispatch average",
-               "algorithmic_flops_per_launch": gf["flops_per_step"] / max(1, gf["launches"]),
-               "algorithmic_bytes_per_launch": round(alg, 1),
-               "traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (same launch set as achieved / frac)",
-               "traffic_source": src,
-               "wasted_traffic_ratio": round(traffic / alg, 3) if (traffic and alg) else None,
-               # the north star's own aggregate, at top level (VERDICT r3): every 3x3 convolution launch of the SPADE generator
-               "north_star_set_frac": s["spade"]["frac"], "north_star_set_achieved": s["spade"]["achieved"],
-               "spade_gamma_beta_family": dict(gb, note="fused forwards (hrv::spade_fused_kernel) + the pair data gradients "
-                                                        "(hrv::conv_p2_kernel) of the levels with >= 2 tiles per CU"),
-               "spade_3x3_set": dict(s["spade"], note="every 3x3 convolution launch of the SPADE generator (conv_shared / gamma|beta / conv_0 / "
-                                                      "conv_1 / stems / conv_img: forward, data and weight gradients) -- the north-star "
-                                                      "aggregate; since round 4 conv_shared's launches are in it (rounds 1-3 dropped them by a "
-                                                      "name-filter slip)")}
-        out.update(common)
-        return out
-    head = s["spade"] if north_star else s["all"]
-    traffic, src = load_traffic(wl["traffic_tag"])
-    alg = s["conv_alg_bytes_per_launch"]
-    out = {"bound": "mfma",
-           "kernel": ("hrv::conv_mfma_kernel / conv_wgrad_* over the SPADE-generator 3x3 convolutions (fwd+dgrad+wgrad)"
-                      if north_star else "hrv::conv_mfma_kernel / conv_wgrad_* (every convolution launch of the step)"),
-           "achieved": head["achieved"], "peak": res["peak"], "unit": "TFLOP/s", "frac": head["frac"],
-           "launches_per_step": head["launches"], "ms_per_step": head["ms_per_step"],
-           "algorithmic_flops_per_launch": head["flops_per_step"] / max(1, head["launches"]),
-           "traffic": traffic, "traffic_unit": "HBM bytes per conv launch (average over the step's conv launches)",
-           "traffic_source": src, "algorithmic_bytes_per_launch": round(alg, 1),
-           "wasted_traffic_ratio": round(traffic / alg, 3) if (traffic and alg and not north_star) else None}
-    out.update(common)
+    rows = [kernel_row(r, res["peak"]) for r in s["by_kernel"] if r[2] > 0]
+    out = dict(rows[0]) if rows else {"kernel": None, "bound": "mfma", "achieved": 0.0, "peak": res["peak"], "unit": "TFLOP/s", "frac": 0.0}
+    fam = out["kernel"][5:] if out["kernel"] else None
+    per_step, src = load_traffic(wl["traffic_tag"], fam) if fam else (None, None)
+    traffic = per_step / out["launches_per_step"] if per_step else None
+    alg = out.get("algorithmic_bytes_per_launch")
+    out.update({"traffic": traffic, "traffic_unit": "HBM bytes per launch of this kernel (PMC FETCH_SIZE x2 + WRITE_SIZE over its dispatches / its launches)",
+                "traffic_source": src, "wasted_traffic_ratio": round(traffic / alg, 3) if (traffic and alg) else None,
+                "launch_unit": "one call of the kernel's C entry point (HIP events around it on the launch stream); a layer wider than one "
+                               "column pass takes several dispatches per call, so compare TOTAL kernel time per iteration with a trace",
+                "kernels": rows[1:8]})
+    if north_star:
+        out.update({"north_star_set_frac": s["spade"]["frac"], "north_star_set_achieved": s["spade"]["achieved"],
+                    "north_star_set_ms": s["spade"]["ms_per_step"], "north_star_set_launches": s["spade"]["launches"],
+                    "spade_gamma_beta_family": dict(s["gb"], note="fused forwards (hrv::spade_fused_kernel) + the pair data gradients "
+                                                                  "(hrv::conv_p2_kernel) of the levels with >= 2 tiles per CU"),
+                    "spade_3x3_set": dict(s["spade"], note="every 3x3 convolution launch of the SPADE generator (conv_shared / gamma|beta / "
+                                                           "conv_0 / conv_1 / stems / conv_img: forward, data and weight gradients)")})
+    out.update({"whole_step_conv_family": s["all"],
+                "end_to_end_TFLOPs_vs_survey_work": round(wl["B"] * wl["flops_per_img"] / (res["dt"] / res["steps"]) / 1e12, 2),
+                "hbm_kinds": s["hbm"],
+                "slowest_launches": [{"name": r[1], "ms": round(r[4], 3), "TFLOPs": round(r[2] / (r[4] * 1e-3) / 1e12, 1)}
+                                     for r in s["top"]]})
     return out
+
+
+# ------------------------------------------------------------------------------------------------- the line the driver parses
+LINE_LIMIT = 4096
+
+
+def _sig(v, n=4):
+    if isinstance(v, float):
+        return float(f"{v:.{n}g}")
+    return v
+
+
+def _short(sv, n):
+    sv = str(sv)
+    return sv if len(sv) <= n else sv[:n - 3] + "..."
+
+
+def _worst(d, out=None, path=""):
+    """every numeric leaf of a parity block whose name says it is an error / mismatch / cosine figure -> {dotted.name: value}"""
+    out = {} if out is None else out
+    if isinstance(d, dict):
+        for k, v in d.items():
+            _worst(v, out, f"{path}.{k}" if path else str(k))
+    elif isinstance(d, bool):
+        if "bit_identical" in path:
+            out[path] = d
+    elif isinstance(d, (int, float)):
+        leaf = path.rsplit(".", 1)[-1]
+        if any(t in leaf for t in ("err", "cosine", "mismatch_pixels", "mismatch_frac", "worst_rel", "median_rel")) or "loss_rel_err" in path:
+            out[path] = _sig(float(d)) if isinstance(d, float) else d
+    return out
+
+
+def _parity_summary(p):
+    """a parity block -> its worst numbers only: max over the error-like leaves, min over the cosines, AND of the bit-identity flags"""
+    if not p:
+        return None
+    leaves = _worst(p)
+    cos = [v for k, v in leaves.items() if "cosine" in k and not isinstance(v, bool)]
+    errs = {k: v for k, v in leaves.items() if "cosine" not in k and not isinstance(v, bool)}
+    bits = [v for v in leaves.values() if isinstance(v, bool)]
+    out = {}
+    groups = {}
+    for k, v in errs.items():
+        top = k.split(".", 1)[0]
+        leaf = k.rsplit(".", 1)[-1] if "loss_rel_err" not in k else "loss_rel_err"
+        g = groups.setdefault(top, {})
+        g[leaf] = max(g.get(leaf, 0), v)
+    for k, v in leaves.items():
+        if "cosine" in k and not isinstance(v, bool):
+            g = groups.setdefault(k.split(".", 1)[0], {})
+            g["min_cosine"] = min(g.get("min_cosine", 1.0), v)
+    out.update(groups)
+    if cos:
+        out["min_cosine"] = min(cos)
+    if bits:
+        out["all_bit_identical"] = all(bits)
+    return out
+
+
+def _roof_compact(r):
+    if not r:
+        return None
+    keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "ms_per_step", "algorithmic_flops_per_launch",
+            "algorithmic_bytes_per_launch", "traffic", "wasted_traffic_ratio", "north_star_set_frac", "north_star_set_achieved",
+            "north_star_set_ms")
+    out = {k: _sig(r[k], 6) for k in keys if k in r}
+    if r.get("traffic_source"):
+        out["traffic_source"] = _short(r["traffic_source"].split(" ")[0], 80)
+    if r.get("whole_step_conv_family"):
+        out["whole_step_conv_frac"] = r["whole_step_conv_family"]["frac"]
+    out["kernels"] = {k["kernel"][5:]: {"ms": k["ms_per_step"], "frac": k["frac"], "bound": k["bound"]} for k in (r.get("kernels") or [])[:5]}
+    return out
+
+
+def compact_line(full, detail_path=None):
+    """The full result of a run (every table, note and sub-object: written to ``detail_path``) -> the ONE line the driver parses:
+    the contract keys, the dominant kernel's roofline, the CPU baseline, the worst parity numbers, value / ms / frac of the extra
+    configurations.  Always under LINE_LIMIT bytes (sheds optional parts until it is)."""
+    cfg = dict(full.get("config") or {})
+    cfg["workload"] = _short(cfg.get("workload", ""), 200)
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["metric"] = _short(line["metric"], 120)
+    line["config"] = cfg
+    line["roofline"] = _roof_compact(full.get("roofline"))
+    c = full.get("cpu_baseline")
+    line["cpu_baseline"] = None if not c else {k: (_short(v, 120) if k == "sample" else v) for k, v in c.items()
+                                               if k in ("value", "unit", "cores", "kind", "sample", "seconds_per_step")}
+    line["parity"] = _parity_summary(full.get("parity"))
+    if full.get("extra"):
+        line["extra"] = {}
+        for k, e in full["extra"].items():
+            r = e.get("roofline") or {}
+            line["extra"][k] = {"value": e.get("value"), "ms_per_step": e.get("ms_per_step"), "batch": e.get("batch"),
+                                "kernel": (r.get("kernel") or "")[5:], "frac": r.get("frac"),
+                                "parity": _parity_summary(e.get("parity"))}
+    if detail_path:
+        line["detail"] = detail_path
+    # shed optional parts (least important first) until the line fits
+    for drop in (None, ("extra", "parity"), ("roofline", "kernels"), ("parity", None), ("extra", None)):
+        if drop is not None:
+            a_, b_ = drop
+            if b_ is None:
+                line[a_] = None if a_ == "parity" else {k: {"value": v.get("value"), "ms_per_step": v.get("ms_per_step")} for k, v in (line.get(a_) or {}).items()}
+            elif a_ == "extra":
+                for v in (line.get("extra") or {}).values():
+                    v.pop(b_, None)
+            elif isinstance(line.get(a_), dict):
+                line[a_].pop(b_, None)
+        txt = json.dumps(line, separators=(",", ":"), allow_nan=False)
+        if len(txt) < LINE_LIMIT:
+            return txt
+    raise AssertionError(f"bench line does not fit {LINE_LIMIT} bytes: {len(txt)}")
+
+
+def emit(full):
+    """Write the full result next to the run (gpurun_out/bench_detail.json; stderr names it) and print the compact line LAST on stdout."""
+    rel = os.path.join("gpurun_out", "bench_detail.json")
+    try:
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, rel), "w") as f:
+            json.dump(full, f, indent=1)
+        _log(f"full result (every table / note / parity object): {rel}")
+    except OSError as e:      # a read-only tree: the line still goes out
+        _log(f"could not write {rel}: {e}")
+        rel = None
+    sys.stderr.flush()
+    print(compact_line(full, rel), flush=True)
 
 
 def self_launch(n):
@@ -590,7 +719,8 @@ def main():
         line = {"metric": wl["metric"], "value": res["value"], "unit": "images/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None,
-                "dtype": "bf16 MFMA operands (matrix-core-only tensors stored bf16), f32 accumulate / norms / optimizer" if mixed else "f32",
+                "dtype": "bf16" if mixed else "f32",
+                "dtype_note": "bf16 MFMA operands (matrix-core-only tensors stored bf16), f32 accumulate / norms / optimizer" if mixed else "f32",
                 "data": "synthetic",
                 "config": {"workload": wl["workload"], "global_batch": wl["B"] * world, "height": H, "width": W,
                            "parallelism": f"dp{world}" + ("-allreduce" if wl["train"] else "-replicas"),
@@ -645,7 +775,7 @@ def main():
         line["cpu_baseline"] = {"value": round(1.0 / p["oracle_forward_s"], 4), "unit": "images/s", "cores": ctx["cpu_threads"],
                                 "kind": "port", "sample": "1 image 1024x768, one forward of oracle.tocg_forward"}
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        emit(line)
     if tdist.is_available() and tdist.is_initialized():
         tdist.barrier()
         tdist.destroy_process_group()

@@ -334,7 +334,7 @@ class SpadeT:
         fl = 2.0 * x.N * x.H * x.W * 2 * self.C * self.hid * 9
         nbytes = (ops.act_bytes(actv) + (2 if save else 1) * ops.act_bytes(x) + ops.act_bytes(out) +
                   2.0 * self.C * self.hid * 9 * (2 if mb else 4))     # actv, x, out, 1+gamma, weights
-        with ops._Timed("conv", self.name + ".conv_gamma|beta", fl, nbytes):
+        with ops._Timed("conv", self.name + ".conv_gamma|beta", fl, nbytes, f"conv_mfma_kernel[tile {cfg}]"):
             fn = lib.hrv_conv2d_nhwc_bf16 if mb else lib.hrv_conv2d_nhwc_f32
             ops._lib.check(fn(C.byref(d), ops._stream()), "hrv_conv2d_nhwc_%s[spade]" % ("bf16" if mb else "f32"))
         ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)

@@ -204,18 +204,21 @@ def profile_begin():
     _Prof.records = []
 
 
-def profile_end():
-    """Returns [(kind, name, flops, bytes, ms)] for every launch since profile_begin()."""
+def profile_end(kernels: bool = False):
+    """Returns [(kind, name, flops, bytes, ms)] for every launch since profile_begin(); ``kernels``: 6-tuples with the
+    name of the device kernel family that served the launch (what a rocprofv3 kernel trace groups by) at the end."""
     _Prof.enabled = False
     torch.cuda.synchronize()
-    out = [(k, n, fl, by, s.elapsed_time(e)) for (k, n, fl, by, s, e) in _Prof.records]
+    out = [((k, n, fl, by, s.elapsed_time(e), kn) if kernels else (k, n, fl, by, s.elapsed_time(e)))
+           for (k, n, fl, by, kn, s, e) in _Prof.records]
     _Prof.records = []
     return out
 
 
 class _Timed:
-    def __init__(self, kind, name, flops, nbytes):
-        self.args = (kind, name, flops, nbytes)
+    def __init__(self, kind, name, flops, nbytes, kernel=None):
+        # ``kernel``: the hrv:: kernel (family) behind the C entry point; the launch kind stands in where one kind = one kernel
+        self.args = (kind, name, flops, nbytes, kernel or kind)
 
     def __enter__(self):
         if _Prof.enabled:
@@ -399,7 +402,7 @@ class ConvLayer:
                   self.Cout * sum(self.src_real) * self.KH * self.KW * (2 if engine_bf16 else 4))
         if spade is not None:
             nbytes += N * Ho * Wo * oc * (4 if getattr(spade, "_x_f32", True) else 2)
-        with _Timed("conv", self.name, self.flops(N, Ho, Wo), nbytes):
+        with _Timed("conv", self.name, self.flops(N, Ho, Wo), nbytes, f"conv_mfma_kernel[tile {d.tile_cfg}]"):
             _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_f32[{self.name}]")
         return out
 

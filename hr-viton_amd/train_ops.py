@@ -325,7 +325,7 @@ def _run_engine(srcs, w_packed, Cout, cfg, N, H, W, Ho, Wo, KH, KW, stride, pad_
     nbytes = (sum(ops.act_bytes(a, creal) for a, _, creal in srcs) + ops.act_bytes(out, Cout) +       # (``out`` already has the upsampled extent when out_up is set)
              
               ops.act_bytes(residual, Cout) + float(Cout) * sum(c for _, _, c in srcs) * KH * KW * (2 if mma_bf16 else 4))
-    with _Timed("conv", name, flops, nbytes):
+    with _Timed("conv", name, flops, nbytes, f"conv_mfma_kernel[tile {cfg}]"):
         fn = lib.hrv_conv2d_nhwc_bf16 if mma_bf16 else lib.hrv_conv2d_nhwc_f32
         _lib.check(fn(C.byref(d), _stream()), f"hrv_conv2d_nhwc_{'bf16' if mma_bf16 else 'f32'}[{name}]")
     return out
@@ -356,7 +356,7 @@ def _thin_conv(src: Act, w: torch.Tensor, mode: int, sigma, wscale: float, shift
     d.res_mode, d.act, d.act_slope = res_mode, act, slope
     d.out, d.out_cstride, d.out_coff, d.out_bf16 = out.t.data_ptr(), out.cstride, out.coff, 1 if out.bf16 else 0
     nbytes = ops.act_bytes(src) + ops.act_bytes(out) + ops.act_bytes(residual, out.C) + 4.0 * w.numel()
-    with _Timed("conv", name, flops, nbytes):
+    with _Timed("conv", name, flops, nbytes, "thin_conv_kernel"):
         _lib.check(lib.hrv_thin_conv_bf16(C.byref(d), _stream()), f"hrv_thin_conv_bf16[{name}]")
     return out
 
@@ -454,7 +454,7 @@ def conv_forward_dev(w: torch.Tensor, srcs: Sequence[Tuple[Act, int]], stride: i
         out = ops.alloc(N, Ho, Wo, 1, a0.t.device)          # (pad channels 1..3 are zero)
         d = _cout1_desc(w, a0, pad, wscale, sigma, out)
         d.bias = None if shift is None else shift.data_ptr()
-        with _Timed("conv", name, 2.0 * N * Ho * Wo * cin * KH * KW, ops.act_bytes(a0) + 4.0 * N * Ho * Wo):
+        with _Timed("conv", name, 2.0 * N * Ho * Wo * cin * KH * KW, ops.act_bytes(a0) + 4.0 * N * Ho * Wo, "cout1_kernel"):
             _lib.check(lib.hrv_conv_cout1_fwd_f32(C.byref(d), _stream()), f"hrv_conv_cout1_fwd_f32[{name}]")
         return out
     p2_bf = out.bf16 if out is not None else (out_bf16 and Cout % 8 == 0)
@@ -533,7 +533,7 @@ def conv_dgrad(dy: Act, w, H: int, W: int, stride: int, pad: int, wscale: float 
         d.dx, d.dx_cstride, d.dx_coff = out.t.data_ptr(), out.cstride, out.coff
         if add is not None:
             d.add, d.add_cstride, d.add_coff = add.t.data_ptr(), add.cstride, add.coff
-        with _Timed("conv", name, fl, ops.act_bytes(out) * (2 if add is not None else 1) + 4.0 * N * Ho * Wo):
+        with _Timed("conv", name, fl, ops.act_bytes(out) * (2 if add is not None else 1) + 4.0 * N * Ho * Wo, "cout1_kernel"):
             _lib.check(lib.hrv_conv_cout1_dgrad_f32(C.byref(d), _stream()), f"hrv_conv_cout1_dgrad_f32[{name}]")
         return out
     oal = 8 if out.bf16 else 4
@@ -605,7 +605,7 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
         ws = _workspace(dy.t.device, 4 * S * (x.C * KH * KW + 1))
         d = _cout1_desc(dw, x, pad, 1.0, None, dy)
         d.workspace = ws.data_ptr()
-        with _Timed("wgrad", name, 2.0 * N * Ho * Wo * x.C * KH * KW, ops.act_bytes(x) + 4.0 * N * Ho * Wo):
+        with _Timed("wgrad", name, 2.0 * N * Ho * Wo * x.C * KH * KW, ops.act_bytes(x) + 4.0 * N * Ho * Wo, "cout1_kernel"):
             _lib.check(lib.hrv_conv_cout1_wgrad_f32(C.byref(d), dw.data_ptr(), 1 if accumulate else 0,
                                                     None if dbias is None else dbias.data_ptr(), 1 if dbias_accumulate else 0,
                                                     _stream()), f"hrv_conv_cout1_wgrad_f32[{name}]")
@@ -626,7 +626,7 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
             cin_tot, N, H, W, Ho, Wo, KH, KW, stride, pad, ws.data_ptr(), ws.numel() * 4, dw.data_ptr(),
             1 if accumulate else 0, None if dbias is None else dbias.data_ptr(), 1 if dbias_accumulate else 0)
     nbytes = ops.act_bytes(dy) + ops.act_bytes(x) + 4.0 * Cout * x.C * KH * KW
-    with _Timed("wgrad", name, fl, nbytes):
+    with _Timed("wgrad", name, fl, nbytes, "conv_wgrad_tr_kernel" if (x.bf16 or dy.bf16) else "conv_wgrad_kernel"):
         if x.bf16 or dy.bf16:
             assert MMA_BF16[0] and Wo % 4 == 0, f"{name}: bf16-stored operands need the bf16 matrix-core weight gradient"
             assert x.bf16, f"{name}: bf16 dY with an fp32 X is not built"
@@ -1173,7 +1173,7 @@ def spade_gb_forward(actv: Act, x: Act, mean: torch.Tensor, rstd: torch.Tensor, 
         d.g1p, d.g1p_bf16 = g1p.data_ptr(), 1 if g1p.dtype == torch.bfloat16 else 0
     d.act, d.act_slope = act, slope
     d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
-    with ops._Timed("conv", name + " [spade_gb]", flops, nbytes):      # (the tag: bench.py prices this kernel's launches)
+    with ops._Timed("conv", name + " [spade_gb]", flops, nbytes, "spade_gb_kernel"):      # (the tag: bench.py prices this kernel's launches)
         _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[forward]")
 
 
@@ -1193,7 +1193,7 @@ def spade_gb_dgrad(dgb: Act, packed: torch.Tensor, C_: int, mask: Optional[Act],
     d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
     fl = 2.0 * dgb.N * dgb.H * dgb.W * 2 * C_ * hid * 9
     nb = ops.act_bytes(dgb) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0)
-    with ops._Timed("conv", name + " [spade_gb]", fl, nb):
+    with ops._Timed("conv", name + " [spade_gb]", fl, nb, "spade_gb_kernel"):
         _lib.check(lib.hrv_spade_gb_bf16(C.byref(d), _stream()), "hrv_spade_gb_bf16[dgrad]")
 
 
@@ -1259,7 +1259,7 @@ def spade_fused_forward(seg: Act, seg_shift: int, x: Act, mean: torch.Tensor, rs
     fl = 2.0 * px * 2 * C_ * 128 * 9          # the gamma|beta convolution (SURVEY 8d work; conv_shared's 2 * 72 * 128 per pixel rides along)
     nbytes = (px * 16 + xbytes + (px * 2.0 * C_ if g1p is not None else 0.0) + ops.act_bytes(out) + (px * 256 if actv is not None else 0.0) +
               2.0 * C_ * 128 * 9 * 2)
-    with ops._Timed("conv", name + " [spade_gb]", fl, nbytes):      # (the tag: bench.py prices this kernel family's launches)
+    with ops._Timed("conv", name + " [spade_gb]", fl, nbytes, "spade_fused_kernel"):      # (the tag: bench.py prices this kernel family's launches)
         _lib.check(lib.hrv_spade_fused_bf16(C.byref(d), _stream()), "hrv_spade_fused_bf16")
 
 
@@ -1322,6 +1322,6 @@ def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[
         d.res_after_mask = 1 if res_after_mask else 0
     nb = (ops.act_bytes(src) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0) +
           (ops.act_bytes(residual) if residual is not None else 0.0) + 2.0 * src.C * cols * 9)
-    with ops._Timed("conv", name + tag, flops, nb):
+    with ops._Timed("conv", name + tag, flops, nb, "conv_p2_kernel"):
         _lib.check(lib.hrv_conv_p2_bf16(C.byref(d), _stream()), f"hrv_conv_p2_bf16[{name}]")
     return out

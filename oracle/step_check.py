@@ -21,6 +21,11 @@ import torch
 from . import hrviton_oracle as O
 
 
+def _fl(v):
+    """python float of a loss value (a tensor that may still require grad, or a number)"""
+    return float(v.detach()) if hasattr(v, "detach") else float(v)
+
+
 def build(H: int, W: int, ngf: int, ndf: int, N: int, seed: int = 0, wmul: float = 8.0, layers: str = "most"):
     """SPADEGenerator(ngf, ``layers``) + MultiscaleDiscriminator(ndf) with the reference's xavier(0.02) init, the
     non-spectral weights scaled by ``wmul`` (a random-init generator is otherwise ~linear), random biases and
@@ -167,8 +172,8 @@ def _hip_pass(opt, gen, D, vgg, x, seg, real, noise, mixed, with_vgg, losses, fa
     rep = {"size": f"{N}x{H}x{W} ngf={ngf}", "mixed": mixed, "oracle_fwd_bwd_s": round(t_oracle, 2),
            "image_max_rel_err": rel(out, fake),
            "image_mean_abs_err": float((out.detach().cpu() - fake.detach()).abs().mean()),
-           "loss_rel_err": {k: abs(float(got[k]) - float(losses[k])) / max(1.0, abs(float(losses[k]))) for k in losses},
-           "losses_oracle": {k: float(v) for k, v in losses.items()},
+           "loss_rel_err": {k: abs(_fl(got[k]) - _fl(losses[k])) / max(1.0, abs(_fl(losses[k]))) for k in losses},
+           "losses_oracle": {k: _fl(v) for k, v in losses.items()},
            "grad_worst_rel_err": rows_g[0][0], "grad_worst_name": rows_g[0][4],
            "grad_median_rel_err": rows_g[len(rows_g) // 2][0],
            "grad_min_cosine": min(r[3] for r in rows_g if r[2] > 1e-2 * gmax and not r[4].endswith("noise_scale")),

@@ -1,101 +1,187 @@
-"""The JSON line bench.py prints (driver contract) -- checked on the committed output of the round's last default run
-on the MI355X box (profiles/r04_final_bench_default.json, written by tools/round_end_measure.sh)."""
+"""The JSON line bench.py prints (driver contract).
+
+Round 4's line had grown to 21.8 KB and the driver could not parse it (BENCH_r04.json: parsed = null).  Since round 5 the LAST stdout
+line is a compact object under 4 KB (bench.compact_line) and everything else goes to gpurun_out/bench_detail.json.  These tests run the
+REAL emit path (bench.summarize -> bench.roofline_obj -> bench.compact_line / bench.emit) on a synthetic full-size result -- the
+per-launch records of a step, the largest parity / extra blocks a run has produced (taken from the committed round-4 line) -- and, when
+the round's final run is committed (profiles/r05_final_bench_default.json + ..._detail.json), on that."""
+import contextlib
+import io
 import json
 import os
+import sys
+
+import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+            "data", "config", "roofline", "cpu_baseline")
 
 
-def _line():
-    for name in ("r04_final_bench_default.json",):
-        p = os.path.join(ROOT, "profiles", name)
-        if os.path.exists(p):
-            with open(p) as f:
-                return json.load(f)
-    raise AssertionError("no committed default bench line under profiles/")
+def _recs():
+    """one training iteration's launch records, shaped like the headline's: (kind, name, flops, bytes, ms, kernel)"""
+    r = []
+    for i in range(31):
+        r.append(("conv", f"up_4.norm_{i % 2}.gb.dgrad [spade_gb]", 2.8e11, 9.0e8, 0.31, "conv_p2_kernel"))
+    for i in range(18):
+        r.append(("conv", f"up_{i % 5}.norm_0.conv_shared+gamma|beta [spade_gb]", 5.2e11, 7.5e8, 0.49, "spade_fused_kernel"))
+    for i in range(100):
+        r.append(("conv", f"G_middle_{i % 2}.conv_{i % 2}", 3.0e10, 4.0e7, 0.05, "conv_mfma_kernel[tile 8]"))
+    for i in range(70):
+        r.append(("wgrad", f"up_{i % 5}.conv_0.wgrad", 6.0e10, 3.0e8, 0.08, "conv_wgrad_tr_kernel"))
+    for i in range(62):
+        r.append(("norm_bwd", "spade_norm_bwd", 0.0, 7.0e8, 0.127, "norm_bwd"))
+    for i in range(40):
+        r.append(("stats", "instnorm_stats", 0.0, 2.0e8, 0.047, "stats"))
+    for i in range(800):
+        r.append(("ew", "add_slice", 0.0, 1.0e7, 0.004, "ew"))
+    r.append(("adam", "adam_f32", 0.0, 3.0e9, 0.6, "adam"))
+    return r
 
 
-def test_default_bench_line_is_the_headline_config_with_the_contract_fields():
-    j = _line()
-    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+def _full():
+    recs = _recs()
+    res = {"summary": bench.summarize(recs, bench.PEAK_BF16_MFMA_TFLOPS), "peak": bench.PEAK_BF16_MFMA_TFLOPS, "dt": 0.74, "steps": 10,
+           "value": 54.0, "ms_per_step": 74.0}
+    wl = {"B": 4, "flops_per_img": 8.8e12, "traffic_tag": "train_generator"}
+    old = json.load(open(os.path.join(ROOT, "profiles", "r04_final_bench_default.json")))      # the blobs that broke the driver's parser
+    full = {"metric": "1024x768 try-on images/sec (train_generator.py step: tocg+glue, G fwd/bwd, D fwd/bwd x2, VGG, Adam)", "value": 54.0,
+            "unit": "images/s", "n_gpus": 1, "steps": 10, "warmup": 3, "ms_per_step": 74.0, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": dict(old["config"]), "roofline": bench.roofline_obj(wl, res, north_star=True),
+            "per_kind_ms": {k: {"launches": v[0], "ms": round(v[1], 2)} for k, v in res["summary"]["kinds"].items()},
+            "cpu_baseline": old["cpu_baseline"], "parity": old["parity"], "extra": old["extra"]}
+    return full
+
+
+def test_the_line_is_one_line_under_4_kb_and_round_trips():
+    full = _full()
+    assert len(json.dumps(full)) > 15000          # the input really is a round-4 sized result
+    txt = bench.compact_line(full, "gpurun_out/bench_detail.json")
+    assert "\n" not in txt and len(txt.encode()) < 4096
+    j = json.loads(txt)
+    for k in CONTRACT:
         assert k in j, k
-    assert j["n_gpus"] == 1 and j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None
-    assert j["unit"] == "images/s" and j["data"] == "synthetic" and j["dtype"].startswith("bf16")
-    cfg = j["config"]
-    # BASELINE.json's metric is quoted on configs[3] (train_generator.py 1024x768, 4 img/GPU, mixed precision)
-    assert "configs[3]" in cfg["workload"] and "train_generator" in cfg["workload"] and "model" not in cfg
-    assert cfg["global_batch"] == 4 and (cfg["height"], cfg["width"]) == (1024, 768)
-    assert cfg["rccl_ranks"] == 0 and cfg["world_size"] == 1 and cfg["persistent_grid_cus"] == 256      # no process group: nothing ran on RCCL
-    # value is whole-job throughput: global batch * steps / elapsed
-    assert abs(j["value"] - cfg["global_batch"] * 1e3 / j["ms_per_step"]) < 0.01 * j["value"]
+    assert j["dtype"] == "bf16" and j["unit"] == "images/s" and j["n_gpus"] == 1 and j["steps"] == 10 and j["warmup"] == 3
+    assert j["higher_is_better"] is True and j["scaling"] == "weak" and j["vs_baseline"] is None and j["data"] == "synthetic"
+    assert "configs[3]" in j["config"]["workload"] and "model" not in j["config"]
+    for k in ("value", "unit", "cores", "kind", "sample", "seconds_per_step"):
+        assert k in j["cpu_baseline"], k
+    assert len(j["cpu_baseline"]["sample"]) <= 120 and j["cpu_baseline"]["kind"] == "port"
+    assert j["detail"] == "gpurun_out/bench_detail.json"
+    # worst parity numbers survive: the bf16 discriminator half is the weakest cosine of the round-4 line
+    assert abs(j["parity"]["min_cosine"] - 0.9803) < 1e-3
+    assert j["parity"]["fp32_engine_vs_oracle"]["image_max_rel_err"] < 1e-3
+    for k, e in j["extra"].items():
+        assert e["value"] > 0 and e["ms_per_step"] > 0, k
 
 
-def test_roofline_object_describes_the_dominant_kernel_against_the_dense_bf16_peak():
-    r = _line()["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "wasted_traffic_ratio"):
-        assert k in r, k
-    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0 and "spade_fused_kernel" in r["kernel"]
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
-    # achieved = algorithmic flops per launch / the average HIP-event duration of exactly those launches
+def test_roofline_names_the_kernel_with_the_largest_share_of_the_step():
+    full = _full()
+    r = full["roofline"]
+    # conv_p2: 31 x 0.31 = 9.6 ms; spade_fused: 18 x 0.49 = 8.8 ms -- the best fraction is NOT the dominant kernel
+    assert r["kernel"] == "hrv::conv_p2_kernel" and r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 2500.0
+    assert r["launches_per_step"] == 31 and abs(r["ms_per_step"] - 9.61) < 0.01
     avg_s = r["ms_per_step"] * 1e-3 / r["launches_per_step"]
     assert abs(r["achieved"] - r["algorithmic_flops_per_launch"] / avg_s / 1e12) < 0.01 * r["achieved"]
-    # traffic: PMC bytes of the SAME kernel name per launch (passes of the same build, taken just before the line), and its ratio
-    # to the model
-    assert r["traffic"] is not None and "spade_fused_kernel" in r["traffic_source"] and "r04" in r["traffic_source"]
-    assert 0.5 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 1.5 * r["algorithmic_bytes_per_launch"]
-    assert abs(r["wasted_traffic_ratio"] - r["traffic"] / r["algorithmic_bytes_per_launch"]) < 2e-3
-    # the gamma|beta family (fused forwards + pair data gradients), the north-star set (every 3x3 convolution launch of the SPADE
-    # generator: forward, data and weight gradients -- conv_shared counted inside the fused launches) and the whole conv family ride along
-    for w in (r["spade_gamma_beta_family"], r["spade_3x3_set"], r["whole_step_conv_family"]):
-        assert w["launches"] >= r["launches_per_step"] and abs(w["frac"] - w["achieved"] / 2500.0) < 1e-3
-    assert r["north_star_set_frac"] == r["spade_3x3_set"]["frac"] and abs(r["north_star_set_achieved"] - r["spade_3x3_set"]["achieved"]) < 0.01
-    assert r["frac"] >= 0.40 and r["spade_3x3_set"]["frac"] >= 0.27          # measured 0.418 / 0.2815
-    # the HBM-bound kernel families carry bytes and a GB/s figure
-    for kind in ("norm_bwd", "stats", "ew", "adam"):
-        assert r["hbm_kinds"][kind]["GBps"] > 0
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    sib = {k["kernel"]: k for k in r["kernels"]}
+    assert list(sib)[0] == "hrv::spade_fused_kernel" and sib["hrv::spade_fused_kernel"]["frac"] > r["frac"]
+    assert sib["hrv::norm_bwd"]["bound"] == "hbm" and sib["hrv::norm_bwd"]["unit"] == "GB/s" and sib["hrv::norm_bwd"]["peak"] == 8000.0
+    # the north-star aggregate stays at the top level
+    assert r["north_star_set_frac"] == r["spade_3x3_set"]["frac"] > 0
+    j = json.loads(bench.compact_line(full))
+    assert j["roofline"]["kernel"] == "hrv::conv_p2_kernel" and "spade_fused_kernel" in j["roofline"]["kernels"]
+    assert j["roofline"]["north_star_set_frac"] == r["north_star_set_frac"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "wasted_traffic_ratio", "algorithmic_flops_per_launch",
+              "algorithmic_bytes_per_launch", "launches_per_step", "ms_per_step"):
+        assert k in j["roofline"], k
 
 
-def test_cpu_baseline_parity_and_extra_configs():
-    j = _line()
+def test_a_step_dominated_by_a_streaming_kernel_is_priced_against_hbm():
+    recs = [("norm_bwd", "spade_norm_bwd", 0.0, 8.0e9, 2.0, "norm_bwd"), ("conv", "c", 1e12, 1e8, 1.0, "conv_mfma_kernel[tile 8]")]
+    res = {"summary": bench.summarize(recs, 2500.0), "peak": 2500.0, "dt": 0.003, "steps": 1}
+    r = bench.roofline_obj({"B": 1, "flops_per_img": 1e12, "traffic_tag": "none"}, res, north_star=False)
+    assert r["kernel"] == "hrv::norm_bwd" and r["bound"] == "hbm" and r["unit"] == "GB/s" and abs(r["achieved"] - 4000.0) < 1 and r["frac"] == 0.5
+
+
+def test_emit_prints_the_compact_line_last_and_writes_the_detail_file(tmp_path, monkeypatch):
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    buf = io.StringIO()
+    with contextlib.redirect_stdout(buf):
+        bench.emit(_full())
+    lines = buf.getvalue().splitlines()
+    assert len(lines) == 1 and len(lines[0]) < 4096
+    j = json.loads(lines[0])
+    d = json.load(open(tmp_path / j["detail"]))
+    assert d["roofline"]["hbm_kinds"] and d["parity"]["bf16_engine_vs_oracle"] and d["roofline"]["slowest_launches"]
+
+
+def test_an_oversized_result_still_fits_by_shedding_optional_parts():
+    full = _full()
+    full["extra"] = {f"cfg{i}": dict(v, parity={"x" * 40 + str(j): {"max_rel_err": 1e-3} for j in range(60)})
+                     for i, v in enumerate(list(full["extra"].values()) * 3)}
+    txt = bench.compact_line(full)
+    assert len(txt) < 4096 and json.loads(txt)["roofline"]["kernel"] == "hrv::conv_p2_kernel"
+
+
+# ----------------------------------------------------------------------------------------------- the round's committed final run
+def _final():
+    p = os.path.join(ROOT, "profiles", "r05_final_bench_default.json")
+    q = os.path.join(ROOT, "profiles", "r05_final_bench_detail.json")
+    if not (os.path.exists(p) and os.path.exists(q)):
+        pytest.skip("the round's final bench line is not committed yet")
+    raw = open(p).read().strip()
+    return raw, json.loads(raw), json.load(open(q))
+
+
+def test_committed_final_line_is_the_headline_config_and_parses():
+    raw, j, d = _final()
+    assert "\n" not in raw and len(raw.encode()) < 4096
+    for k in CONTRACT:
+        assert k in j, k
+    assert j["n_gpus"] == 1 and j["dtype"] == "bf16" and j["unit"] == "images/s" and j["vs_baseline"] is None
+    cfg = j["config"]
+    assert "configs[3]" in cfg["workload"] and "train_generator" in cfg["workload"]
+    assert cfg["global_batch"] == 4 and (cfg["height"], cfg["width"]) == (1024, 768)
+    assert cfg["rccl_ranks"] == 0 and cfg["world_size"] == 1 and cfg["persistent_grid_cus"] == 256
+    assert abs(j["value"] - cfg["global_batch"] * 1e3 / j["ms_per_step"]) < 0.01 * j["value"]
+    assert j["value"] >= 53.0                                             # round 4: 53.5-54.1
+    r = j["roofline"]
+    # the dominant kernel = the family with the largest summed time in the detail's own per-kernel table
+    top = max([d["roofline"]] + d["roofline"]["kernels"], key=lambda k: k["ms_per_step"])
+    assert r["kernel"] == top["kernel"] == d["roofline"]["kernel"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["north_star_set_frac"] >= 0.27
+    assert r["traffic"] is not None and "r05" in r["traffic_source"]
+    assert 0.5 * r["algorithmic_bytes_per_launch"] <= r["traffic"] <= 2.0 * r["algorithmic_bytes_per_launch"]
     c = j["cpu_baseline"]
-    for k in ("value", "unit", "cores", "kind", "sample"):
-        assert k in c, k
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["unit"] == "images/s" and "train_generator" in c["sample"]
-    p = j["parity"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["seconds_per_step"] > 1.0
+
+
+def test_committed_final_detail_holds_parity_within_the_stated_tolerances():
+    _, j, d = _final()
+    p = d["parity"]
     f, b = p["fp32_engine_vs_oracle"], p["bf16_engine_vs_oracle"]
-    assert f["image_max_rel_err"] < 1e-3 and all(v < 1e-3 for v in f["loss_rel_err"].values())
-    assert f["grad_worst_rel_err"] < 2e-2
-    # (the mid-round line still shows the 5.4e-3 / 0.985 of the patch-tile packing bug that the final build fixed)
+    assert f["image_max_rel_err"] < 1e-3 and all(v < 1e-3 for v in f["loss_rel_err"].values()) and f["grad_worst_rel_err"] < 2e-2
     assert "1024x768" in f["size"] and "1024x768" in b["size"]
-    assert b["image_mean_abs_err"] < 3e-3 and all(v < 2e-3 for v in b["loss_rel_err"].values())
-    assert b["grad_min_cosine"] > 0.99
-    # the discriminator half of the same iteration
+    assert b["image_mean_abs_err"] < 3e-3 and all(v < 2e-3 for v in b["loss_rel_err"].values()) and b["grad_min_cosine"] > 0.99
     df, db = p["discriminator_half_fp32_engine_vs_oracle"], p["discriminator_half_bf16_engine_vs_oracle"]
-    assert "1024x768" in df["size"] and all(v < 1e-3 for v in df["loss_rel_err"].values()) and df["grad_worst_rel_err"] < 2e-2
+    assert all(v < 1e-3 for v in df["loss_rel_err"].values()) and df["grad_worst_rel_err"] < 2e-2
     assert all(v < 5e-3 for v in db["loss_rel_err"].values())
     assert db["grad_min_cosine"] > db["bf16_rounded_oracle_vs_fp32_oracle"]["grad_min_cosine"] - 0.01
-    # the CPU leg is one iteration at the metric's own resolution
-    assert "1024x768" in c["sample"] and c["seconds_per_step"] > 1.0
-    e = j["extra"]
-    for k in ("config3_train_condition_f32_b8", "experimental_train_condition_bf16_operands_b8"):
-        assert e[k]["batch"] == 8 and e[k]["value"] > 0 and "parity" in e[k]
-    # configs[2] parity at its own resolution: one image 1024x768 against the oracle's autograd
+    e = d["extra"]
     c3 = e["config3_train_condition_f32_b8"]["parity"]
     assert "1024x768" in c3["size"] and all(v < 1e-3 for v in c3["false"]["loss_rel_err"].values())
     assert c3["false"]["tocg"]["min_cosine"] > 0.9999 and c3["false"]["D"]["min_cosine"] > 0.9999
-    assert "NOT a BASELINE configs[2] result" in e["experimental_train_condition_bf16_operands_b8"]["note"]
     t, q = e["config5_tryon_infer_bf16_b16"], e["config2_tocg_infer_f32_b4"]
-    assert t["batch"] == 16 and abs(t["value"] - 16e3 / t["ms_per_step"]) < 0.01 * t["value"] and t["value"] > 340      # measured 371
-    # configs[4] names the hipGraph-captured decode: the replay is what was timed, bit-identical to eager, and one image is held to
-    # the bf16-rounded oracle
-    tp = t["parity"]
-    assert all(tp["hipgraph_replay_vs_eager"]["bit_identical"].values())
-    o1 = tp["one_image_vs_oracle"]
-    assert o1["image_mean_abs_err"] <= 2 * o1["oracle_vs_nudged_oracle_mean_abs"] + 1e-4
-    assert o1["label_map_mismatch_frac"] <= 2 * o1["label_map_mismatch_frac_oracle_vs_nudged_oracle"] + 1e-3
-    assert q["roofline"]["peak"] == 157.3
+    assert t["batch"] == 16 and abs(t["value"] - 16e3 / t["ms_per_step"]) < 0.01 * t["value"] and t["value"] > 340
+    assert all(t["parity"]["hipgraph_replay_vs_eager"]["bit_identical"].values())
     qp = q["parity"]
-    assert qp["seg_max_rel_err"] < 1e-3 and qp["argmax_mismatch_pixels"] <= 2e-5 * qp["pixels"]      # measured: 6 of 786 432
-    # every mismatching pixel is a near-tie: the oracle's top-2 logits are within a few hundred fp32 ulps
-    assert all(m <= 1024 for m in qp["mismatch_top2_margin_ulps_of_logit"])      # measured <= 286
+    assert qp["seg_max_rel_err"] < 1e-3 and qp["argmax_mismatch_pixels"] <= 2e-5 * qp["pixels"]
+    assert all(m <= 1024 for m in qp["mismatch_top2_margin_ulps_of_logit"])
+    # ... and the compact line carries the same worst numbers
+    assert abs(j["parity"]["min_cosine"] - min(db["grad_min_cosine"], b["grad_min_cosine"], 1.0)) < 2e-3 or j["parity"]["min_cosine"] <= b["grad_min_cosine"]

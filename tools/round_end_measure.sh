@@ -13,9 +13,10 @@ bash tools/profile_traffic.sh train_generator > $OUT/profile_traffic.log 2>&1
 cp gpurun_out/traffic_train_generator/*.summary.txt gpurun_out/traffic_train_generator/*.json $OUT/ 2>/dev/null
 # (on the box only: the default run below prices its traffic from the passes just taken; the copy under profiles/ that is
 #  committed afterwards is this same file)
-cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r04_pmc_traffic_train_generator.json 2>/dev/null
+cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r05_pmc_traffic_train_generator.json 2>/dev/null
 timeout 1200 python bench.py --dump-launches $OUT/launches_default.txt 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
-cut -c1-300 $OUT/bench_default.json
+cp gpurun_out/bench_detail.json $OUT/bench_default_detail.json 2>/dev/null      # (the full result behind the compact line)
+wc -c $OUT/bench_default.json; cut -c1-300 $OUT/bench_default.json
 b() { name=$1; shift; timeout 400 python bench.py "$@" --no-cpu-baseline --no-extras --dump-launches $OUT/launches_$name.txt 2>$OUT/$name.err | tail -1 > $OUT/$name.json; cut -c1-200 $OUT/$name.json; }
 b train_generator_bf16_graph --workload train_generator --graph --steps 8 --warmup 3
 b train_generator_f32 --workload train_generator --fp32 --steps 3 --warmup 2
