@@ -319,9 +319,12 @@ def wl_generator(ctx, mixed, B, train):
             reps = step_check.compare_generator_step(1024, 768, 64, 64, 2, seed=1, mixed=engines, cpu_threads=ctx["cpu_threads"],
                                                      table_path=os.path.join(gp, "bench_grad_parity_gen.txt"))
             out = {"fp32_engine_vs_oracle": reps[False],
-                   "tolerance_fp32": "image / losses 1e-3 rel (north star); per-parameter gradients 2e-2 of max(|g|, 1e-3 module max)"}
+                   "tolerance_fp32": "image / losses 1e-3 rel (north star); per-parameter gradients 2e-2 of max(|g|, 1e-3 module max)",
+                   "tolerance_short": "fp32 engine: image, losses 1e-3 rel, grads 2e-2 of max|g|"}
             if mixed:
                 out["bf16_engine_vs_oracle"] = reps[True]
+                out["tolerance_short"] += ("; bf16 engine: image mean-abs 3e-3, losses 2e-3 (G) / 5e-3 (D), G grad cosine >= 0.99, D grad cosine >= "
+                                           "the fp32 oracle's own bf16-operand evaluation - 0.01 (0.983: operand rounding, not a kernel, sets it)")
                 out["tolerance_bf16"] = ("operands carry 8 mantissa bits: image mean-abs 3e-3 (max 3e-2 of the range), loss terms "
                                          "2e-3 rel, gradient cosine >= 0.99 on every sizeable parameter")
             # the discriminator half of the same iteration (train_generator.py:327-360): D losses, every D gradient, D's Adam step
@@ -470,7 +473,7 @@ def roofline_obj(wl, res, north_star):
 
 
 # ------------------------------------------------------------------------------------------------- the line the driver parses
-LINE_LIMIT = 4096
+LINE_LIMIT = 3800          # (round 4's 21.8 KB line could not be parsed by the driver; the contract test holds the line under 4 KB)
 
 
 def _sig(v, n=4):
@@ -506,17 +509,20 @@ def _parity_summary(p):
         return None
     leaves = _worst(p)
     cos = [v for k, v in leaves.items() if "cosine" in k and not isinstance(v, bool)]
-    errs = {k: v for k, v in leaves.items() if "cosine" not in k and not isinstance(v, bool)}
+    errs = {k: v for k, v in leaves.items() if "cosine" not in k and "median" not in k and not isinstance(v, bool)}
     bits = [v for v in leaves.values() if isinstance(v, bool)]
     out = {}
     groups = {}
     for k, v in errs.items():
         top = k.split(".", 1)[0]
         leaf = k.rsplit(".", 1)[-1] if "loss_rel_err" not in k else "loss_rel_err"
+        if "." not in k:                      # a number at the top level of the block
+            out[k] = v
+            continue
         g = groups.setdefault(top, {})
         g[leaf] = max(g.get(leaf, 0), v)
     for k, v in leaves.items():
-        if "cosine" in k and not isinstance(v, bool):
+        if "cosine" in k and not isinstance(v, bool) and "." in k:
             g = groups.setdefault(k.split(".", 1)[0], {})
             g["min_cosine"] = min(g.get("min_cosine", 1.0), v)
     out.update(groups)
@@ -547,7 +553,7 @@ def compact_line(full, detail_path=None):
     the contract keys, the dominant kernel's roofline, the CPU baseline, the worst parity numbers, value / ms / frac of the extra
     configurations.  Always under LINE_LIMIT bytes (sheds optional parts until it is)."""
     cfg = dict(full.get("config") or {})
-    cfg["workload"] = _short(cfg.get("workload", ""), 200)
+    cfg["workload"] = _short(cfg.get("workload", ""), 150)
     line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                      "vs_baseline", "dtype", "data")}
     line["metric"] = _short(line["metric"], 120)
@@ -557,13 +563,16 @@ def compact_line(full, detail_path=None):
     line["cpu_baseline"] = None if not c else {k: (_short(v, 120) if k == "sample" else v) for k, v in c.items()
                                                if k in ("value", "unit", "cores", "kind", "sample", "seconds_per_step")}
     line["parity"] = _parity_summary(full.get("parity"))
+    if line["parity"] and (full.get("parity") or {}).get("tolerance_short"):
+        line["parity"]["tolerance"] = _short(full["parity"]["tolerance_short"], 300)
     if full.get("extra"):
         line["extra"] = {}
         for k, e in full["extra"].items():
             r = e.get("roofline") or {}
             line["extra"][k] = {"value": e.get("value"), "ms_per_step": e.get("ms_per_step"), "batch": e.get("batch"),
-                                "kernel": (r.get("kernel") or "")[5:], "frac": r.get("frac"),
-                                "parity": _parity_summary(e.get("parity"))}
+                                "kernel": (r.get("kernel") or "")[5:], "frac": r.get("frac")}
+            if not k.startswith("experimental_"):      # (a mode outside BASELINE's configs: value only, its parity block is in the detail file)
+                line["extra"][k]["parity"] = _parity_summary(e.get("parity"))
     if detail_path:
         line["detail"] = detail_path
     # shed optional parts (least important first) until the line fits
