@@ -147,6 +147,7 @@ SYMBOLS = {
     "hrv_set_reserved_cus": (C.c_int, [_i32]),
     "hrv_persistent_cus": (C.c_int, []),
     "hrv_diag_set_tlog": (C.c_int, [_vp, _i64]),
+    "hrv_diag_reload_env": (C.c_int, []),
     "hrv_conv2d_pick_tile": (C.c_int, [_i64, _i32]),
     "hrv_conv2d_tile_bn": (C.c_int, [_i32]),
     "hrv_conv2d_tile_bm": (C.c_int, [_i32]),
@@ -297,6 +298,13 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def reload_env():
+    """The library caches its HRV_* environment switches on first use (no getenv() in a launch path); a process that changes one
+    while it runs -- tests, tools/conv_bench.py -- calls this afterwards."""
+    if _lib is not None:
+        _lib.hrv_diag_reload_env()
 
 
 def check(rc: int, what: str):

@@ -774,7 +774,7 @@ extern "C" int hrv_flow_warp_bwd_nhwc_f32(const hrv_flow_warp_bwd_t* d, hrv_stre
   p.dflow = d->dflow; p.dflow_accumulate = d->dflow_accumulate;
   const size_t npix = (size_t)d->N * d->Ho * d->Wo;
   // wide tensors: d(src) by the LDS-privatised tile kernel, d(flow) (a gather, no atomics) by the per-pixel kernel
-  const char* ev = getenv("HRV_WARP_BWD_TILED");
+  const char* ev = hrv::env("HRV_WARP_BWD_TILED");
   const bool tiled = p.dsrc && d->C >= 16 && (!ev || atoi(ev) != 0);
   if (tiled) {
     const int tx = (d->Wo + WT - 1) / WT, ty = (d->Ho + WT - 1) / WT;

@@ -1284,7 +1284,7 @@ static int fill_params(const hrv_conv2d_t* d, ConvParams& p, bool need_packed, b
     }
     p.m_tiles = (p.M + bm - 1) / bm;
     p.splitk = 1;
-    const char* ev = getenv("HRV_CONV_SPLITK");   // 0 disables, N forces (A/B measurements)
+    const char* ev = hrv::env("HRV_CONV_SPLITK");   // 0 disables, N forces (A/B measurements)
     int want = pick_splitk(p.m_tiles * p.n_tiles, p.KT, d->spade == nullptr);
     if (ev) want = atoi(ev) > 0 ? atoi(ev) : 1;
     if (d->spade) want = 1;
@@ -1309,7 +1309,7 @@ constexpr int kDefaultVariant = 1;
 template <int TM, int TN, int WM, int WN, int RB = 64>
 static int launch_cfg(const ConvParams& p, hipStream_t st) {
   const int nblk = p.m_tiles * p.n_tiles * p.splitk;
-  const char* ev = getenv("HRV_CONV_VARIANT");
+  const char* ev = hrv::env("HRV_CONV_VARIANT");
   int var = ev ? atoi(ev) : kDefaultVariant;
   const int oesz = p.out_f32 ? 4 : 2, resz = p.res_f32 ? 4 : 2;
   const bool vec_ok = (p.Cout & 3) == 0 && ((p.out_cs | p.out_co) & 3) == 0 && (!p.res || ((p.res_cs | p.res_co) & 3) == 0) &&
@@ -1327,7 +1327,7 @@ static int launch_cfg(const ConvParams& p, hipStream_t st) {
       // register-staged); the 128x128 tile measures the same either way (~470-505: both are bound by
       // moving 32 KB per K-tile through the CU's texture path) and keeps the register pipeline.
       // HRV_CONV_GLDS=0/1 forces it off/on (A/B measurements: profiles/r01_conv_bench_bf16_glds.txt).
-      const char* eg = getenv("HRV_CONV_GLDS");
+      const char* eg = hrv::env("HRV_CONV_GLDS");
       const bool want = eg ? atoi(eg) != 0 : (32 * TN * WN == 64 || TM * TN >= 8);
       const bool glds = want && p.w_bytes != 0;
       if (p.src_f32) {
@@ -1428,7 +1428,7 @@ static int launch_patch(const ConvParams& p0, hipStream_t st, int n0_base = 0, i
   p.tlog = diag_tlog(p.m_tiles);       // diag only (hrv_diag_set_tlog): per-tile phase timestamps
   constexpr int PATCH_LDS = ((TMP * WMP * 32 / 16 + 2) * 18 * 64 + ((STV & 16) ? 3 : 2) * BNP * 32) * 4;
   const int per_cu = PATCH_LDS <= 80 * 1024 ? 2 : 1;
-  const char* ep = getenv("HRV_PATCH_PERSIST");
+  const char* ep = hrv::env("HRV_PATCH_PERSIST");
   int grid = (ep && ep[0] == '0') ? nblk : n_cu * per_cu;
   if (grid > nblk) grid = nblk;
   if (vec_ok || p.epi == 1)
@@ -1461,11 +1461,11 @@ static int launch_any(int tile_cfg, const ConvParams& p, hipStream_t st) {
     case 18: {
       // 64-column patch tile: THREE weight stages still fit two blocks per CU (46 KB patch + 3 x 8 KB): one tile's DMA stays
       // in flight across the barrier (counted vmcnt) instead of vmcnt(0) per K-tile.  HRV_CONV_PATCH_ST3=0: two stages (A/B)
-      const char* e3 = getenv("HRV_CONV_PATCH_ST3");
+      const char* e3 = hrv::env("HRV_CONV_PATCH_ST3");
       if (e3 && e3[0] == '0') return launch_patch<1, 2, 4, 1, 0>(p, st);
       // an odd number (>= 3) of 64-column tiles: the even part runs on the 128-column tile (the halo patch is loaded once
       // per 128 columns instead of once per 64), the last 64 columns here.  HRV_CONV_PATCH_SPLIT=0: 64-column tiles only
-      const char* es = getenv("HRV_CONV_PATCH_SPLIT");
+      const char* es = hrv::env("HRV_CONV_PATCH_SPLIT");
       const int c64 = p.CoutPad / 64;
       if (c64 >= 3 && !(es && es[0] == '0')) {
         const int rc = launch_patch<2, 2, 2, 2, 0>(p, st, 0, c64 / 2);
@@ -1568,7 +1568,7 @@ extern "C" int64_t hrv_conv2d_workspace_bytes(const hrv_conv2d_t* d) {
   int chunks = 0;
   for (int i = 0; i < d->nsrc && i < HRV_MAX_SRC; ++i) chunks += (d->src[i].C + HOST_BK - 1) / HOST_BK;
   const int KT = d->KH * d->KW * chunks;
-  const char* ev = getenv("HRV_CONV_SPLITK");
+  const char* ev = hrv::env("HRV_CONV_SPLITK");
   int s = pick_splitk(m_tiles * n_tiles, KT, true);
   if (ev) s = atoi(ev) > 0 ? atoi(ev) : 1;
   if (s > KT) s = KT;
@@ -1602,7 +1602,7 @@ static int conv2d_any(const hrv_conv2d_t* d, hipStream_t stream, bool bf) {
   const bool srcf0 = bf && (d->mixed_flags & 8);
   const int64_t lim = (int64_t)0xFFFFFFF0 / ((bf && !srcf0) ? 2 : 4);
   int64_t cap = d->N;
-  if (const char* e = getenv("HRV_CONV_MAX_BATCH")) {
+  if (const char* e = hrv::env("HRV_CONV_MAX_BATCH")) {
     const long long v = atoll(e);
     if (v > 0 && v < cap) cap = v;
   }

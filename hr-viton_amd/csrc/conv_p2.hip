@@ -528,7 +528,7 @@ extern "C" int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32
   // still beats the generic tiles, below that they fill the chip better (HRV_CONV_P2_MIN_TILES_X4: threshold in quarter-tiles per CU)
   static int q4 = -1;
   if (q4 < 0) {
-    const char* e = getenv("HRV_CONV_P2_MIN_TILES_X4");
+    const char* e = hrv::env("HRV_CONV_P2_MIN_TILES_X4");
     q4 = e ? atoi(e) : 6;
     if (q4 < 1) q4 = 6;
   }

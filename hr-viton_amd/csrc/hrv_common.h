@@ -60,6 +60,11 @@ __device__ __forceinline__ int xcd_remap(int bid, int nblk) {
   return base + (bid >> 3);
 }
 
+// A/B and diagnostic switches (HRV_*): the environment is read ONCE per name and cached -- after a name's first use no launch path
+// calls getenv().  hrv_diag_reload_env() drops the cache (tests / tools that flip a switch inside one process).  Defined in
+// sample.hip; the returned pointer stays valid until the next reload.
+const char* env(const char* name);
+
 // Launch geometry shared by the per-(sample, channel) reduction kernels (InstanceNorm statistics, SPADE / InstanceNorm
 // backward): grid = (pixel slabs, samples, channel chunks).  A block covers <= NORM_GCAP groups of 4 channels, so the
 // 1040-channel / 64x48-pixel levels of the generator spread over 5 x 24 x N blocks instead of 6 x N (they ran at
@@ -68,7 +73,7 @@ constexpr int NORM_GCAP = 64;
 inline int norm_slab_cap() {
   static int cap = 0;
   if (cap == 0) {
-    const char* e = getenv("HRV_NORM_SLABS_MAX");
+    const char* e = hrv::env("HRV_NORM_SLABS_MAX");
     cap = e ? atoi(e) : 256;
     if (cap < 1) cap = 256;
   }

@@ -6,6 +6,9 @@
 #include <string.h>
 
 #include "hrv_common.h"
+#include <mutex>
+#include <string>
+#include <unordered_map>
 
 namespace hrv {
 
@@ -347,10 +350,25 @@ int device_cus() {
   if (dev < HRV_MAX_DEVICES) cus[dev] = n;
   return n;
 }
+static std::mutex g_env_mu;
+static std::unordered_map<std::string, std::pair<bool, std::string>>& env_cache() {
+  static std::unordered_map<std::string, std::pair<bool, std::string>> c;
+  return c;
+}
+const char* env(const char* name) {
+  std::lock_guard<std::mutex> lk(g_env_mu);
+  auto& c = env_cache();
+  auto it = c.find(name);
+  if (it == c.end()) {
+    const char* e = ::getenv(name);
+    it = c.emplace(std::string(name), std::make_pair(e != nullptr, std::string(e ? e : ""))).first;
+  }
+  return it->second.first ? it->second.second.c_str() : nullptr;
+}
 static int g_reserved_cus = -1;      // -1: not set yet (HRV_RESERVE_CUS is read once)
 int persistent_cus() {
   if (g_reserved_cus < 0) {
-    const char* e = getenv("HRV_RESERVE_CUS");
+    const char* e = hrv::env("HRV_RESERVE_CUS");
     int k = e ? atoi(e) : 0;
     g_reserved_cus = k < 0 ? 0 : k;
   }
@@ -361,6 +379,12 @@ static unsigned long long* g_tlog = nullptr;
 static long long g_tlog_tiles = 0;
 unsigned long long* diag_tlog(long long tiles) { return (g_tlog != nullptr && tiles <= g_tlog_tiles) ? g_tlog : nullptr; }
 }  // namespace hrv
+
+extern "C" int hrv_diag_reload_env(void) {
+  std::lock_guard<std::mutex> lk(hrv::g_env_mu);
+  hrv::env_cache().clear();
+  return HRV_OK;
+}
 
 extern "C" int hrv_set_reserved_cus(int32_t k) {
   HRV_REQUIRE(k >= 0 && k < 4096, "set_reserved_cus: %d", k);

@@ -360,7 +360,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_tr_kernel(const WgradTrParams 
 int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, int x_C, int x_cs, int x_co, int x_C_real,
                  int ci_base, int CinTot, int N, int H, int W, int KH, int KW, int pad, float* workspace,
                  long long workspace_bytes, float* dbias, int dbias_accumulate, hipStream_t st, int* S_out) {
-  const char* env = getenv("HRV_WGRAD_TR");
+  const char* env = hrv::env("HRV_WGRAD_TR");
   if (env && env[0] == '0') return 0;
   if (KW < 1 || KW > 3 || KH != KW || pad != KH / 2) return 0;
   if ((dy_cs | dy_co | x_cs | x_co | x_C) & 7) return 0;                         // 16-byte DMA granules (Cout itself may be

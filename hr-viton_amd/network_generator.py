@@ -571,10 +571,33 @@ class NLayerDiscriminator(BaseNetwork):
 
     def forward(self, input):
         if self.training:
-            raise NotImplementedError("hr-viton_amd NLayerDiscriminator: training-mode kernels are not built yet")
+            # one scale of the multi-scale training plan (network_generator.py:278-289 called on its own): same kernels, same
+            # autograd Function; the holder only stands in for the MultiscaleDiscriminator that normally owns the plan
+            from .gen_train import discriminator_train_forward
+            solo = self.__dict__.get("_solo_scale")
+            if solo is None:
+                solo = self.__dict__["_solo_scale"] = _SoloScale(self)
+            feats = discriminator_train_forward(solo, input)[0]
+            return feats if not self.no_ganFeat_loss else feats[-1]
         with torch.no_grad():
             feats = [ops.to_nchw(f) for f in self.forward_act(ops.to_nhwc(input))]
         return feats if not self.no_ganFeat_loss else feats[-1]
+
+
+class _SoloScale:
+    """What gen_train.discriminator_train_forward asks of a MultiscaleDiscriminator, for ONE NLayerDiscriminator used on its own
+    in training mode: its scales (one), its parameters, the feature-list switch.  Not an nn.Module (the discriminator must not
+    become its own grandchild)."""
+
+    def __init__(self, D):
+        self._D = D
+        self.no_ganFeat_loss = D.no_ganFeat_loss
+
+    def children(self):
+        return iter([self._D])
+
+    def parameters(self):
+        return self._D.parameters()
 
 
 class MultiscaleDiscriminator(BaseNetwork):

@@ -57,6 +57,10 @@ int hrv_persistent_cus(void);
  * into which the persistent tile kernels write per-tile phase timestamps while it is set; (NULL, 0) switches it off.  A
  * launch with more tiles than the buffer holds does not log. */
 int hrv_diag_set_tlog(void* buf, int64_t tiles);
+/* The library's A/B and diagnostic switches (environment variables HRV_*) are read from the environment once per
+ * name and cached, so no launch path calls getenv() after a name's first use.  A process that changes one of them while it runs
+ * (tests/, tools/conv_bench.py) calls this to drop the cache. */
+int hrv_diag_reload_env(void);
 
 /* ------------------------------------------------------------------------
  * Convolution engine (implicit GEMM on fp32 MFMA, v_mfma_f32_32x32x2_f32).

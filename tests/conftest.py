@@ -21,3 +21,14 @@ def golden_dir():
 def load_golden(name):
     import torch
     return torch.load(os.path.join(GOLDEN, name), map_location="cpu", weights_only=False)
+
+
+@pytest.fixture(autouse=True)
+def _hrv_env_switches_reloaded():
+    """The HIP library caches its HRV_* environment switches; a test that flips one (monkeypatch.setenv / os.environ) calls
+    hr_viton_amd._lib.reload_env() after setting it, and this fixture -- torn down after monkeypatch has restored the environment --
+    drops the cache again so that the next test starts from the real environment."""
+    yield
+    mod = sys.modules.get("hr_viton_amd._lib")
+    if mod is not None:
+        mod.reload_env()

@@ -1,10 +1,10 @@
-"""Every HRV_* environment switch the product reads (getenv in csrc/, os.environ in the package, bench.py and the entry scripts) has a
+"""Every HRV_* environment switch the product reads (hrv::env -- the cached getenv -- in csrc/, os.environ in the package, bench.py and the entry scripts) has a
 row in INTEGRATION.md's switch table or is named in its text -- an undocumented switch is an A/B knob nobody can find."""
 import os
 import re
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PAT = re.compile(r'(?:getenv\("|environ\.get\("|environ\[")(HRV_[A-Z0-9_]+)')
+PAT = re.compile(r'(?:getenv\("|hrv::env\("|environ\.get\("|environ\[")(HRV_[A-Z0-9_]+)')
 
 
 def test_every_environment_switch_is_listed_in_integration_md():

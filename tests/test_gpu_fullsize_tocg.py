@@ -126,6 +126,7 @@ def test_train_condition_b8_1024x768_kernel_selections_agree(monkeypatch):
             monkeypatch.setenv("HRV_CONV_SPLITK", "0")
             monkeypatch.setenv("HRV_CONV_MAX_BATCH", "1")
             monkeypatch.setenv("HRV_WARP_BWD_TILED", "0")
+            from hr_viton_amd import _lib as _hl; _hl.reload_env()
         runs.append(step_check._cond_step(False, opt, tocg, D, batch))
         torch.cuda.empty_cache()
     (la, ga, da), (lb, gb, db) = runs

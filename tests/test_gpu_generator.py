@@ -335,6 +335,7 @@ def test_conv_sub_batch_launches_are_bit_identical(monkeypatch, bf16):
     want = m(x, seg)
     for cap in ("2", "1"):          # 5 images as 2+2+1 and as 1+1+1+1+1
         monkeypatch.setenv("HRV_CONV_MAX_BATCH", cap)
+        from hr_viton_amd import _lib as _hl; _hl.reload_env()
         torch.manual_seed(5)
         got = m(x, seg)
         assert torch.equal(got, want), cap

@@ -251,6 +251,7 @@ def test_conv_mfma_every_tile_config_and_variant(tile, variant):
     ops = _ops()
     old = os.environ.get("HRV_CONV_VARIANT")
     os.environ["HRV_CONV_VARIANT"] = str(variant)
+    from hr_viton_amd import _lib as _hl; _hl.reload_env()
     try:
         for case in (CONV_CASES[2], CONV_CASES[3], CONV_CASES[4], CONV_CASES[9], CONV_CASES[12]):
             got, ref = _run_conv_case(ops, case, "mfma", tile=tile)
@@ -289,6 +290,7 @@ def test_conv_split_k(splitk):
         for case in (CONV_CASES[2], CONV_CASES[4], CONV_CASES[5], CONV_CASES[9], CONV_CASES[3]):
             for variant in (0, 1):
                 os.environ["HRV_CONV_VARIANT"] = str(variant)
+                from hr_viton_amd import _lib as _hl; _hl.reload_env()
                 got, ref = _run_conv_case(ops, case, "mfma")
                 _assert_close(f"conv_splitk{splitk}_v{variant}_" + case[0], got, ref, 2e-5)
                 got2, _ = _run_conv_case(ops, case, "mfma")

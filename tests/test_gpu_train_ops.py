@@ -506,6 +506,7 @@ def test_wgrad_tr_kernel_bf16_stored_operands(case, monkeypatch):
     try:
         for mode in ("1", "0"):
             monkeypatch.setenv("HRV_WGRAD_TR", mode)
+            from hr_viton_amd import _lib as _hl; _hl.reload_env()
             dw = torch.full((cout, cin + 8, k, k), 7.0, device="cuda")
             db = torch.zeros(cout, device="cuda")
             T.conv_wgrad(as_act(dy), as_act(x), 0, 8, cin + 8, k, k, 1, pad, dw, name=name, dbias=db)
@@ -555,6 +556,7 @@ def test_wgrad_tr_kernel_other_source_widths(case, monkeypatch):
     try:
         for mode in ("1", "0"):
             monkeypatch.setenv("HRV_WGRAD_TR", mode)
+            from hr_viton_amd import _lib as _hl; _hl.reload_env()
             dw = torch.full((cout, cin + 8, k, k), 7.0, device="cuda")
             db = torch.zeros(cout, device="cuda")
             ops.profile_begin()

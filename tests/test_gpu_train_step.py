@@ -572,3 +572,42 @@ def test_graphed_training_iteration_is_bit_identical_to_eager():
     gs._it.guard.watch[0][0]().reset()
     with pytest.raises(HrvError):
         gs(inputs)
+
+
+@pytest.mark.parametrize("no_feat", [False, True])
+def test_standalone_nlayer_discriminator_in_training_mode_equals_scale_0_of_the_multiscale_one(no_feat):
+    """NLayerDiscriminator.forward called on its own in training mode (network_generator.py:278-289): the same plan, kernels and
+    autograd Function as scale 0 of MultiscaleDiscriminator.forward -- features, d(input) and every parameter gradient
+    bit-identical to the multi-scale run on a copy with the same weights and spectral-norm state (that path is held to the
+    oracle by test_discriminator_step_matches_oracle_autograd)."""
+    import copy
+    import hr_viton_amd  # noqa: F401
+    opt, gen, D, x, seg, real, noise = _setup(seed=33, H=128, W=96, wmul=6.0)
+    D.no_ganFeat_loss = no_feat
+    for d_ in D.children():
+        d_.no_ganFeat_loss = no_feat
+    D.cuda().train()
+    D2 = copy.deepcopy(D)
+    solo = D2.discriminator_0
+    g = torch.Generator().manual_seed(9)
+    inp = torch.cat((seg, torch.rand(2, 3, 128, 96, generator=g) * 2 - 1), 1).cuda()
+    ia = inp.clone().requires_grad_(True)
+    fa = D(ia)[0]                                   # scale 0 of the multi-scale forward: list of layer features (or [last])
+    sum((f * f).mean() for f in fa).backward()
+    ib = inp.clone().requires_grad_(True)
+    fb = solo(ib)
+    fb = [fb] if no_feat else fb
+    assert len(fa) == len(fb) == (1 if no_feat else 4)
+    sum((f * f).mean() for f in fb).backward()
+    for u, v in zip(fa, fb):
+        assert torch.equal(u, v)
+    pa, pb = dict(D.discriminator_0.named_parameters()), dict(solo.named_parameters())
+    for n in pa:
+        assert pa[n].grad is not None and pb[n].grad is not None, n
+        assert torch.equal(pa[n].grad, pb[n].grad), n
+    # (d(input) of the multi-scale run also holds scale 1's share: none here -- the loss reads scale 0 only -- but its
+    #  avg-pool backward still runs on a zero gradient, so compare values, not bits)
+    assert torch.allclose(ia.grad, ib.grad, rtol=0, atol=0)
+    # the spectral-norm state advanced alike
+    for (n, a), (_, b) in zip(D.discriminator_0.named_buffers(), solo.named_buffers()):
+        assert torch.equal(a, b), n

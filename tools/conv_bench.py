@@ -64,6 +64,7 @@ def main():
                     continue
                 os.environ["HRV_CONV_TILE"] = str(cfg)
                 os.environ["HRV_CONV_VARIANT"] = str(var)
+                ops._lib.reload_env()
                 s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 s.record()
                 layer(xs, out=out, residual=r, cfg=cfg if mixed else None)
