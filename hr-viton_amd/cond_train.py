@@ -354,6 +354,7 @@ class _TocgFn(torch.autograd.Function):
         if d_outs[nf + 1] is not None:
             warped.add_grad(ops.to_nhwc(d_outs[nf + 1].contiguous()), owned=True)
         grads = tape.backward()
+        T.wgrad_join()
         ctx.tape = ctx.flows = ctx.seg = ctx.warped = None
         return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
@@ -437,6 +438,7 @@ class _CondDFn(torch.autograd.Function):
         need_dx = ctx.needs_input_grad[1]
         d_acts = [None if d is None else ops.to_nhwc(d.contiguous()) for d in d_outs]
         grads, d_in = ctx.plan.backward(ctx.saved, d_acts, need_dx, ctx.need_w)
+        T.wgrad_join()
         ctx.saved = None
         return (None, ops.to_nchw(d_in) if (need_dx and d_in is not None) else None) + \
             tuple(grads.get(p) for p in ctx.params)

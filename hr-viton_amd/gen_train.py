@@ -70,6 +70,8 @@ def _pair_slot(pa: nn.Parameter, pb: nn.Parameter) -> Optional[torch.Tensor]:
 
 def _acc(grads: Grads, p: nn.Parameter, g: torch.Tensor):
     v = flat_grad_slot(p)
+    if p.grad is not None:
+        T.wgrad_join()      # a second contribution: the first may still be in flight on the weight-gradient side stream
     if v is not None:
         if p.grad is None:
             if g.data_ptr() != v.data_ptr():
@@ -126,22 +128,24 @@ class TConv:
         w = self.wparam.data
         Cout, cin, KH, KW = w.shape
         if need_w:
-            G = torch.empty_like(w) if self.spectral else grad_buffer(self.wparam)
-            db = grad_buffer(self.bparam) if self.bparam is not None else None
-            base = 0
-            for a, up in srcs:
-                # the bias gradient rides along with the first source as a ones-column of the same MFMA reduction
-                T.conv_wgrad(dy if dy_wgrad is None else dy_wgrad, a, up, base, cin, KH, KW, self.stride, self.pad, G,
-                             name=self.name + ".wgrad", dbias=db if base == 0 else None)
-                base += a.C
-            if self.spectral:
-                dwo = grad_buffer(self.wparam)
-                T.spectral_grad(G, w, self.u, self.v, self.sigma, dwo)
-                _acc(grads, self.wparam, dwo)
-            else:
-                _acc(grads, self.wparam, G)
-            if db is not None:
-                _acc(grads, self.bparam, db)
+            dyw = dy if dy_wgrad is None else dy_wgrad
+            with T.wgrad_side(dyw.N * dyw.H * dyw.W, dyw, *[a for a, _ in srcs]):      # (a leaf of the backward: second stream)
+                G = torch.empty_like(w) if self.spectral else grad_buffer(self.wparam)
+                db = grad_buffer(self.bparam) if self.bparam is not None else None
+                base = 0
+                for a, up in srcs:
+                    # the bias gradient rides along with the first source as a ones-column of the same MFMA reduction
+                    T.conv_wgrad(dyw, a, up, base, cin, KH, KW, self.stride, self.pad, G,
+                                 name=self.name + ".wgrad", dbias=db if base == 0 else None)
+                    base += a.C
+                if self.spectral:
+                    dwo = grad_buffer(self.wparam)
+                    T.spectral_grad(G, w, self.u, self.v, self.sigma, dwo)
+                    _acc(grads, self.wparam, dwo)
+                else:
+                    _acc(grads, self.wparam, G)
+                if db is not None:
+                    _acc(grads, self.bparam, db)
         if not need_dx:
             return None
         a0, up0 = srcs[0]
@@ -377,17 +381,18 @@ class SpadeT:
             wcat = torch.zeros((2 * Cp, self.hid, 3, 3), device=dev)
             wcat[:C_] = n.conv_gamma.weight.data
             wcat[Cp:Cp + C_] = n.conv_beta.weight.data
-        dwcat, db = _pair_slot(n.conv_gamma.weight, n.conv_beta.weight), _pair_slot(n.conv_gamma.bias, n.conv_beta.bias)
-        if Cp != C_ or dwcat is None or db is None:
-            dwcat = torch.empty((2 * Cp, self.hid, 3, 3), device=dev)
-            db = torch.empty(2 * Cp, device=dev)
-        T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad", dbias=db)
-        direct = flat_grad_slot(n.conv_gamma.weight) is not None
-        keep = (lambda t: t) if direct else (lambda t: t.clone())     # slices are copied into the flat slots by _acc
-        _acc(grads, n.conv_gamma.weight, keep(dwcat[:C_]))
-        _acc(grads, n.conv_beta.weight, keep(dwcat[Cp:Cp + C_]))
-        _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
-        _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
+        with T.wgrad_side(dgb.N * dgb.H * dgb.W, dgb, actv):      # (a leaf of the backward: second stream at the coarse levels)
+            dwcat, db = _pair_slot(n.conv_gamma.weight, n.conv_beta.weight), _pair_slot(n.conv_gamma.bias, n.conv_beta.bias)
+            if Cp != C_ or dwcat is None or db is None:
+                dwcat = torch.empty((2 * Cp, self.hid, 3, 3), device=dev)
+                db = torch.empty(2 * Cp, device=dev)
+            T.conv_wgrad(dgb, actv, 0, 0, self.hid, 3, 3, 1, 1, dwcat, name=self.name + ".gb.wgrad", dbias=db)
+            direct = flat_grad_slot(n.conv_gamma.weight) is not None
+            keep = (lambda t: t) if direct else (lambda t: t.clone())     # slices are copied into the flat slots by _acc
+            _acc(grads, n.conv_gamma.weight, keep(dwcat[:C_]))
+            _acc(grads, n.conv_beta.weight, keep(dwcat[Cp:Cp + C_]))
+            _acc(grads, n.conv_gamma.bias, keep(db[:C_]))
+            _acc(grads, n.conv_beta.bias, keep(db[Cp:Cp + C_]))
         # d actv, with the ReLU derivative of conv_shared fused (slope 0)
         if (Cp == C_ and T.MMA_BF16[0] and dgb.bf16 and actv.bf16 and dact.cstride % 8 == 0 and (2 * C_) % 32 == 0 and
                 T.conv_p2_ok(2 * C_, self.hid, actv.N, actv.H, actv.W)):
@@ -482,16 +487,17 @@ class BlockT:
     def shared_backward(self, segx: Act, dact_all: Act, grads: Grads):
         norms = self.norms()
         hid, cp = norms[0].hid, segx.C // 9
-        dw = torch.empty((hid * len(norms), segx.C, 1, 1), device=dact_all.t.device)
-        db = torch.empty(hid * len(norms), device=dact_all.t.device)
-        T.conv_wgrad(dact_all, segx, 0, 0, segx.C, 1, 1, 1, 0, dw, name=self.name + ".conv_shared.wgrad", dbias=db)
-        # tap-major 1x1 gradient -> the norms' [hid, c, 3, 3] weight / bias gradients (their flat-buffer slots when free)
-        gws = [grad_buffer(n_.shared.wparam) for n_ in norms]
-        gbs = [grad_buffer(n_.shared.bparam) for n_ in norms]
-        T.shared_taps_grad(dw, db, gws, gbs, cp)
-        for n_, gw, gb in zip(norms, gws, gbs):
-            _acc(grads, n_.shared.wparam, gw)
-            _acc(grads, n_.shared.bparam, gb)
+        with T.wgrad_side(dact_all.N * dact_all.H * dact_all.W, dact_all, segx):
+            dw = torch.empty((hid * len(norms), segx.C, 1, 1), device=dact_all.t.device)
+            db = torch.empty(hid * len(norms), device=dact_all.t.device)
+            T.conv_wgrad(dact_all, segx, 0, 0, segx.C, 1, 1, 1, 0, dw, name=self.name + ".conv_shared.wgrad", dbias=db)
+            # tap-major 1x1 gradient -> the norms' [hid, c, 3, 3] weight / bias gradients (their flat-buffer slots when free)
+            gws = [grad_buffer(n_.shared.wparam) for n_ in norms]
+            gbs = [grad_buffer(n_.shared.bparam) for n_ in norms]
+            T.shared_taps_grad(dw, db, gws, gbs, cp)
+            for n_, gw, gb in zip(norms, gws, gbs):
+                _acc(grads, n_.shared.wparam, gw)
+                _acc(grads, n_.shared.bparam, gb)
 
     def forward(self, x: Act, seg: Act, seg_shift: int, zs, out: Optional[Act], out_up: int, out_act: int,
                 save: bool = True):
@@ -724,6 +730,7 @@ class _GenFn(torch.autograd.Function):
     def backward(ctx, d_out):
         grads = ctx.plan.backward(ctx.saved, d_out)
         ctx.saved = None
+        T.wgrad_join()
         return (None, None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
@@ -948,6 +955,7 @@ class _DiscFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         grads, d_in, rows = _disc_backward(ctx, d_outs, ctx.needs_input_grad[2])
+        T.wgrad_join()
         d_inp = None
         if d_in is not None:
             d_inp = ops.to_nchw(d_in)
@@ -1035,6 +1043,7 @@ class _DiscPairFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, *d_outs):
         grads, d_in, rows = _disc_backward(ctx, d_outs, ctx.needs_input_grad[3])
+        T.wgrad_join()
         N, Ca, Cb = ctx.cut
         d_fake = None
         if d_in is not None:

@@ -246,7 +246,8 @@ def _workspace(device, nbytes: int) -> torch.Tensor:
     reading it before the next one writes).  A request beyond the current size REPLACES the tensor; a captured hipGraph
     that recorded the old address keeps the old tensor alive itself (graph.CaptureGuard), so its replays stay on memory
     nobody else owns."""
-    key = str(device)
+    # (one scratch per STREAM: weight gradients may run on a second stream next to the data-gradient chain -- train_ops.wgrad_side)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
     t = _WS.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)

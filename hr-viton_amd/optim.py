@@ -107,6 +107,8 @@ class Adam(torch.optim.Optimizer):
         if closure is not None:
             with torch.enable_grad():            # like torch.optim: the closure may call backward()
                 loss = closure()
+        from . import train_ops as _T
+        _T.wgrad_join()            # weight gradients of the last backward may sit on the side stream (train_ops.wgrad_side)
         world_scale = 1.0
         if self.grad_sync is not None:
             self.grad_sync.wait()

@@ -159,6 +159,9 @@ class GradSync:
             self._fire(b)
 
     def _fire(self, b):
+        if b["flat"].is_cuda:
+            from . import train_ops as _T
+            _T.wgrad_sync_for_collective()      # slots of this bucket may have been written on the weight-gradient side stream
         if self.world > 1:
             b["handle"] = dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.pg, async_op=True)
         elif int(os.environ.get("HRV_FAKE_ALLREDUCE", "0") or 0) > 0 and b["flat"].is_cuda:

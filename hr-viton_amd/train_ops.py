@@ -30,6 +30,83 @@ def _bf16_tile(cout: int) -> int:
 _FROZEN_PACKS: dict = {}
 
 
+# ---------------------------------------------------------------------------------------------------------------
+# Weight gradients on a second stream.  In a backward plan only the DATA gradients form the dependency chain; a layer's weight
+# gradient hangs off it as a leaf.  At the low-resolution levels of the SPADE generator (8x6 .. 128x96 pixels, 1024 / 512 / 256
+# channels: network_generator.py:188-198,224-236) a kernel launches 48-400 blocks on 256 CUs, so chain and leaves run next to
+# each other instead of one after the other.  ``with wgrad_side(pixels, dy, x):`` forks (the side stream waits for what the
+# current stream has enqueued so far), runs the body on the side stream, and tells the caching allocator which of the current
+# stream's tensors the side stream reads; ``wgrad_join()`` -- end of every backward Function, start of the fused optimizer step,
+# a gradient bucket's all-reduce -- makes the current stream wait for the side stream.  HRV_WGRAD_SIDE=0 switches it off;
+# HRV_WGRAD_SIDE_MAXPIX (default 65536) is the largest N*H*W that still goes to the side stream: above it a weight gradient fills
+# the chip on its own and concurrency buys nothing.  Never inside a hipGraph capture (graph.GraphedIteration: one stream).
+# ---------------------------------------------------------------------------------------------------------------
+class _Side:
+    streams: dict = {}      # device index -> torch.cuda.Stream
+    pending: dict = {}      # device index -> True while the side stream holds work the main stream has not waited for
+    active = [False]        # inside a ``with wgrad_side`` body
+
+
+def wgrad_side_maxpix() -> int:
+    if os.environ.get("HRV_WGRAD_SIDE", "1") == "0":
+        return 0
+    return int(os.environ.get("HRV_WGRAD_SIDE_MAXPIX", "65536") or 0)
+
+
+class wgrad_side:
+    def __init__(self, pixels: int, *reads):
+        self.on = (0 < pixels <= wgrad_side_maxpix()) and not _Side.active[0] and not torch.cuda.is_current_stream_capturing()
+        self.reads = reads
+
+    def __enter__(self):
+        if not self.on:
+            return self
+        dev = torch.cuda.current_device()
+        side = _Side.streams.get(dev)
+        if side is None:
+            side = _Side.streams[dev] = torch.cuda.Stream(device=dev)
+        self.side = side
+        side.wait_stream(torch.cuda.current_stream(dev))
+        self.ctx = torch.cuda.stream(side)
+        self.ctx.__enter__()
+        _Side.active[0] = True
+        _Side.pending[dev] = True
+        return self
+
+    def __exit__(self, *exc):
+        if not self.on:
+            return False
+        _Side.active[0] = False
+        self.ctx.__exit__(*exc)
+        for t in self.reads:          # allocated on the main stream, read on the side stream: not to be reused before that read
+            if t is not None:
+                (t.t if isinstance(t, Act) else t).record_stream(self.side)
+        return False
+
+
+def wgrad_join(device=None):
+    """The current stream waits for the weight gradients enqueued on the side stream (no-op when there are none)."""
+    if not _Side.pending:          # never forked in this process (also: a CPU-only process)
+        return
+    dev = torch.cuda.current_device() if device is None else torch.device(device).index
+    if _Side.pending.get(dev) and not _Side.active[0]:
+        torch.cuda.current_stream(dev).wait_stream(_Side.streams[dev])
+        _Side.pending[dev] = False
+
+
+def wgrad_sync_for_collective():
+    """A gradient bucket is about to be all-reduced from the current stream: its slots were written on both streams."""
+    if not _Side.pending:
+        return
+    dev = torch.cuda.current_device()
+    if not _Side.pending.get(dev):
+        return
+    if _Side.active[0]:
+        pass          # on the side stream: the fork already ordered it behind everything the main stream had enqueued
+    else:
+        wgrad_join(dev)
+
+
 _PACK_TOKENS = itertools.count(1)
 
 
