@@ -755,6 +755,30 @@ def generator_train_forward(gen: nn.Module, x: torch.Tensor, seg, noise=None) ->
 DROP_MASKS: List[torch.Tensor] = []
 
 
+class _EngineMode:
+    """``with _EngineMode(fp32):`` -- the convolutions inside run on the fp32 matrix-core engine although the step is in mixed
+    precision (T.MMA_BF16): a layer whose operand rounding the caller wants out of the comparison (HRV_D_F32_LAYERS)."""
+
+    def __init__(self, fp32: bool):
+        self.fp32 = fp32
+
+    def __enter__(self):
+        self.old = T.MMA_BF16[0]
+        if self.fp32:
+            T.MMA_BF16[0] = False
+
+    def __exit__(self, *exc):
+        T.MMA_BF16[0] = self.old
+        return False
+
+
+def _d_f32_layers() -> int:
+    """HRV_D_F32_LAYERS=<k>: the first k convolutions of every PatchGAN scale (and their gradients) keep fp32 operands in a
+    mixed-precision step -- model0 reads the raw image and label map; default 0 (amp O1 runs every convolution in half precision,
+    train_generator.py:186-190)."""
+    return int(os.environ.get("HRV_D_F32_LAYERS", "0") or 0)
+
+
 class DiscTrainPlan:
     """One NLayerDiscriminator: conv0+lrelu, [SNconv, IN, lrelu] x (n_layers-1), conv_last."""
 
@@ -817,9 +841,11 @@ class DiscTrainPlan:
         if not prepared:
             self.refresh_s2d()
             T.prepare_convs(self, [conv for _, conv in self.layers], power_iteration)
-        for kind, conv in self.layers:
+        kf = _d_f32_layers()
+        for li, (kind, conv) in enumerate(self.layers):
             if kind in ("in", "in_drop"):
-                c = conv.forward([(a, 0)])
+                with _EngineMode(li < kf):
+                    c = conv.forward([(a, 0)])
                 mean, rstd = ops.instnorm_stats(c)
                 f = ops.instnorm_apply(c, mean, rstd, ACT_LRELU, 0.2)
                 entry = dict(src=a, c=c, mean=mean, rstd=rstd, f=f)
@@ -835,7 +861,8 @@ class DiscTrainPlan:
                     entry["mask"] = m
                 ctx.append(entry)
             else:
-                f = conv.forward([(a, 0)], act=ACT_LRELU if kind == "lrelu" else ACT_NONE)
+                with _EngineMode(li < kf):
+                    f = conv.forward([(a, 0)], act=ACT_LRELU if kind == "lrelu" else ACT_NONE)
                 ctx.append(dict(src=a, f=f))
             feats.append(f)
             a = f
@@ -873,8 +900,9 @@ class DiscTrainPlan:
             # the feature-matching gradient of this layer's INPUT feature rides along with the data gradient
             tap = dfeats[i - 1] if i > 0 else None
             tap_in_dnext = tap is not None and tap.t.dtype == torch.float32 and tap.t.shape[:3] == c["src"].t.shape[:3]
-            d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx), need_w=need_w,
-                                   add=tap if tap_in_dnext else None)
+            with _EngineMode(i < _d_f32_layers()):
+                d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx), need_w=need_w,
+                                       add=tap if tap_in_dnext else None)
         return d_next
 
 

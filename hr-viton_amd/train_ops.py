@@ -37,9 +37,11 @@ _FROZEN_PACKS: dict = {}
 # each other instead of one after the other.  ``with wgrad_side(pixels, dy, x):`` forks (the side stream waits for what the
 # current stream has enqueued so far), runs the body on the side stream, and tells the caching allocator which of the current
 # stream's tensors the side stream reads; ``wgrad_join()`` -- end of every backward Function, start of the fused optimizer step,
-# a gradient bucket's all-reduce -- makes the current stream wait for the side stream.  HRV_WGRAD_SIDE=0 switches it off;
-# HRV_WGRAD_SIDE_MAXPIX (default 65536) is the largest N*H*W that still goes to the side stream: above it a weight gradient fills
-# the chip on its own and concurrency buys nothing.  Never inside a hipGraph capture (graph.GraphedIteration: one stream).
+# a gradient bucket's all-reduce -- makes the current stream wait for the side stream.  OPT-IN (HRV_WGRAD_SIDE=1): measured on the
+# headline iteration (tools/ab_wgrad_side.sh, profiles/r05_ab_wgrad_side.txt) it buys nothing -- 72.1-72.7 ms off, 71.5-72.7 ms on for
+# every threshold, inside the run-to-run spread: the iteration is bound by the power the chip may draw, and two under-filled kernels
+# side by side cost the energy of the two one after the other.  HRV_WGRAD_SIDE_MAXPIX (default 65536) is the largest N*H*W that goes
+# to the side stream.  Never inside a hipGraph capture (graph.GraphedIteration: one stream).
 # ---------------------------------------------------------------------------------------------------------------
 class _Side:
     streams: dict = {}      # device index -> torch.cuda.Stream
@@ -48,7 +50,7 @@ class _Side:
 
 
 def wgrad_side_maxpix() -> int:
-    if os.environ.get("HRV_WGRAD_SIDE", "1") == "0":
+    if os.environ.get("HRV_WGRAD_SIDE", "0") != "1":
         return 0
     return int(os.environ.get("HRV_WGRAD_SIDE_MAXPIX", "65536") or 0)
 

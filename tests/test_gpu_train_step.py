@@ -551,7 +551,7 @@ def test_graphed_training_iteration_is_bit_identical_to_eager():
             # an eager call that outgrows the shared split-K / weight-gradient workspace replaces the tensor; the graph
             # recorded the old address and must keep that memory to itself (graph.CaptureGuard) -- poison what a freed
             # workspace would have been recycled into
-            dev = str(inputs["x"].device)
+            dev = (str(inputs["x"].device), torch.cuda.current_stream().cuda_stream)      # (one scratch per device and stream)
             old = ops._WS[dev]
             new = ops._workspace(inputs["x"].device, 2 * old.numel() * 4 + 4096)
             assert new.data_ptr() != old.data_ptr() and any(t.data_ptr() == old.data_ptr() for t in gs._it.guard.keep)
@@ -611,3 +611,51 @@ def test_standalone_nlayer_discriminator_in_training_mode_equals_scale_0_of_the_
     # the spectral-norm state advanced alike
     for (n, a), (_, b) in zip(D.discriminator_0.named_buffers(), solo.named_buffers()):
         assert torch.equal(a, b), n
+
+
+def test_weight_gradients_on_the_side_stream_leave_the_iteration_bit_identical(monkeypatch):
+    """train_ops.wgrad_side (opt-in, HRV_WGRAD_SIDE=1): the weight gradients of every level run on a second stream next to the
+    data-gradient chain -- forked per leaf, joined at the end of each backward Function and in front of the fused optimizer step.
+    Same kernels on the same operands: four mixed-precision iterations end in bit-identical generator / discriminator weights
+    and Adam moments with and without it (a missing fork / join / record_stream shows up here as a difference)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import gen_train, ops, pipeline
+    from hr_viton_amd import train_ops as T
+    from hr_viton_amd.losses import GANLoss, L1Loss
+    from hr_viton_amd.optim import Adam
+
+    def run(side):
+        monkeypatch.setenv("HRV_WGRAD_SIDE", "1" if side else "0")
+        monkeypatch.setenv("HRV_WGRAD_SIDE_MAXPIX", "1000000000")
+        opt, gen, D, x, seg, real, noise = _setup(seed=4, wmul=8.0)
+        opt.lambda_feat, opt.lambda_vgg, opt.no_vgg_loss = 10.0, 10.0, True
+        gen.cuda().train()
+        D.cuda().train()
+        og = Adam(gen.parameters(), lr=1e-3, betas=(0.0, 0.9))
+        od = Adam(D.parameters(), lr=4e-3, betas=(0.0, 0.9))
+        xc, realc, parse7 = x.cuda(), real.cuda(), ops.to_nhwc(seg.cuda())
+        g = torch.Generator().manual_seed(77)
+        oldm = T.MMA_BF16[0]
+        T.MMA_BF16[0] = True
+        forks0 = sum(1 for v in T._Side.pending.values())
+        try:
+            for _ in range(4):
+                nz = [gen_train.noise_planes(gen, x.shape[0], torch.randn(gen_train.noise_elems(gen, x.shape[0]), generator=g))
+                      for _ in range(2)]
+                pipeline.generator_train_step(opt, gen, D, GANLoss("hinge"), L1Loss(), None, og, od, xc, parse7, realc,
+                                              noise=nz[0], noise_d=nz[1])
+        finally:
+            T.MMA_BF16[0] = oldm
+        torch.cuda.synchronize()
+        sd = {"G." + k: v.detach().cpu().clone() for k, v in gen.state_dict().items()}
+        sd.update({"D." + k: v.detach().cpu().clone() for k, v in D.state_dict().items()})
+        for tag, o in (("og", og), ("od", od)):
+            sd[tag + ".m"], sd[tag + ".v"] = o._flat[0]["m"].detach().cpu().clone(), o._flat[0]["v"].detach().cpu().clone()
+        return sd, forks0
+
+    a, _ = run(False)
+    b, _ = run(True)
+    assert T._Side.streams, "the side stream was never used"
+    assert not any(T._Side.pending.values()), "a backward left weight gradients un-joined"
+    for k in a:
+        assert torch.equal(a[k], b[k]), k

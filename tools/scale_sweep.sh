@@ -22,10 +22,18 @@ for R in 0 8 16; do
 import json, sys
 rows = [json.loads(l) for l in open(sys.argv[1]) if l.startswith("{")]
 base = next((r["value"] for r in rows if r["n_gpus"] == 1), None)
+pts = []
 for r in rows:
     eff = r["value"] / (base * r["n_gpus"]) if base else float("nan")
     print(f"{sys.argv[1].split('/')[-1]}: N={r['n_gpus']} {r['value']:.2f} img/s {r['ms_per_step']:.2f} ms/step  efficiency {eff:.3f}  "
           f"backend {r['config']['dist_backend']} rccl_ranks {r['config']['rccl_ranks']} grid CUs {r['config'].get('persistent_grid_cus')}")
+    pts.append({"n_gpus": r["n_gpus"], "value": r["value"], "ms_per_step": r["ms_per_step"], "scaling_efficiency": round(eff, 4),
+                "speedup_vs_1": round(r["value"] / base, 3) if base else None, "dist_backend": r["config"]["dist_backend"],
+                "rccl_ranks": r["config"]["rccl_ranks"]})
+# ONE machine-readable line per reserve setting (the shape of a SCALE record: the bench lines' own numbers per N, weak scaling)
+if rows:
+    print(json.dumps({"metric": rows[0]["metric"], "unit": rows[0]["unit"], "scaling": rows[0].get("scaling", "weak"),
+                      "reserve_cus": int(sys.argv[1].split("_R")[-1].split(".")[0]), "points": pts}))
 PY
 done
 R=$(python - <<PY
