@@ -246,12 +246,20 @@ def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: 
     sd0_g = {k: v.detach().clone() for k, v in gen.state_dict().items()}
     sd0_d = {k: v.detach().clone() for k, v in D.state_dict().items()}
     reports = {}
+    import os
     for mx in engines:
+        # an engine entry is True / False, or (True, {environment switches}, label): the bf16 engine under those switches, reported
+        # under ``label`` (tools/d_f32_layers.py: which PatchGAN layers keep fp32 operands) -- the oracle above is computed once
+        env, label = {}, None
+        if isinstance(mx, tuple):
+            mx, env, label = mx
         gen.load_state_dict(sd0_g)
         D.load_state_dict(sd0_d)
         for p_ in D.parameters():
             p_.grad = None
         T.MMA_BF16[0] = bool(mx)
+        old_env = {k: os.environ.get(k) for k in env}
+        os.environ.update(env)
         try:
             xc, sc, rc = x.cuda(), seg.cuda(), real.cuda()
             with torch.no_grad():
@@ -267,6 +275,11 @@ def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: 
             torch.cuda.synchronize()
         finally:
             T.MMA_BF16[0] = False
+            for k, v in old_env.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
         gmax = max(float(w.abs().max()) for w in want_g.values())
 
         def table(got):
@@ -302,7 +315,7 @@ def compare_discriminator_step(H: int, W: int, ngf: int = 64, ndf: int = 64, N: 
             rq = table(wantq_g)
             rep["bf16_rounded_oracle_vs_fp32_oracle"] = {"grad_worst_rel_err": rq[0][0], "grad_median_rel_err": rq[len(rq) // 2][0],
                                                          "grad_min_cosine": min(r_[3] for r_ in rq if r_[2] > 1e-2 * gmax)}
-        reports[bool(mx)] = rep
+        reports[bool(mx) if label is None else label] = rep
         if table_path:
             with open(table_path.replace(".txt", "_bf16.txt" if mx else "_f32.txt"), "w") as f:
                 f.write(f"# discriminator step {rep['size']} mixed={bool(mx)}: rel_err abs_err |want|max cosine name\n")
