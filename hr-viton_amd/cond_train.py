@@ -298,7 +298,11 @@ class CondTrainPlan:
         self.E2 = [_RB(net.PoseEncoder[i], f"PoseEncoder.{i}") for i in range(5)]
         self.mid = _RB(net.conv, "conv")
         self.seg = [_RB(net.SegDecoder[i], f"SegDecoder.{i}") for i in range(5)]
-        self.out = _RB(net.out_layer, "out_layer")
+        self.encoder_warp = net.warp_feature == "encoder"
+        if net.out_layer_opt == "relu":
+            self.out, self.out_conv = _RB(net.out_layer, "out_layer"), None
+        else:                                                                       # networks.py:57-61
+            self.out, self.out_conv = _RB(net.out_layer[0], "out_layer.0"), TConv(net.out_layer[1], 1, 0, "out_layer.1")
         self.conv1 = [TConv(m, 1, 0, f"conv1.{i}") for i, m in enumerate(net.conv1)]
         self.conv2 = [TConv(m, 1, 0, f"conv2.{i}") for i, m in enumerate(net.conv2)]
         self.flow = [FlowConv(m, f"flow_conv.{i}") for i, m in enumerate(net.flow_conv)]
@@ -328,9 +332,15 @@ class CondTrainPlan:
                 warped, fup = warp(tape, T1, flows[-1], iH, iW, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
                 b = conv(tape, self.bott[i - 1], [x], act=ACT_RELU)
                 flows.append(self.flow[i].forward(tape, [warped, b], fup))          # networks.py:137
-                x = self.seg[i](tape, [x, e2, warped])                              # networks.py:141
+                if not self.encoder_warp:
+                    x = self.seg[i](tape, [x, e2, warped])                          # networks.py:141
+                else:                                                               # networks.py:143-144
+                    warped_e1, _ = warp(tape, e1, flows[-2], iH, iW, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
+                    x = self.seg[i](tape, [x, e2, warped_e1])
         warped_in, _ = warp(tape, x1, flows[-1], H, W, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0)
         seg = self.out(tape, [x, x2, warped_in])
+        if self.out_conv is not None:
+            seg = conv(tape, self.out_conv, [seg])
         return tape, flows, seg, warped_in
 
 

@@ -115,9 +115,9 @@ class ConditionGenerator(nn.Module):
         super().__init__()
         self.warp_feature = opt.warp_feature
         self.out_layer_opt = opt.out_layer
-        if self.warp_feature != "T1" or self.out_layer_opt != "relu":
-            raise NotImplementedError("hr-viton_amd implements the reference defaults warp_feature='T1', "
-                                      "out_layer='relu' (test_generator.py:54-55)")
+        if self.warp_feature not in ("T1", "encoder") or self.out_layer_opt not in ("relu", "conv"):
+            raise ValueError(f"warp_feature={self.warp_feature!r} / out_layer={self.out_layer_opt!r}: the reference knows "
+                             "'T1' | 'encoder' and 'relu' | 'conv' (networks.py:37-61)")
         self.input1_nc, self.input2_nc, self.output_nc, self.ngf = input1_nc, input2_nc, output_nc, ngf
         # --fp16 (test_generator.py:34): inference with bf16 matrix-core operands over fp32 tensors; the default is
         # the fp32 engine (the path held to the 1e-3 parity bar)
@@ -131,10 +131,17 @@ class ConditionGenerator(nn.Module):
         self.ClothEncoder = encoder(input1_nc)
         self.PoseEncoder = encoder(input2_nc)
         self.conv = ResBlock(ngf * 4, ngf * 8, "same", norm_layer)
-        dec_io = [(ngf * 8, ngf * 4), (ngf * 4 * 2 + ngf * 4, ngf * 4), (ngf * 4 * 2 + ngf * 4, ngf * 2),
-                  (ngf * 2 * 2 + ngf * 4, ngf), (ngf * 1 * 2 + ngf * 4, ngf)]
+        if self.warp_feature == "T1":       # in_nc = [x, skip connection, warped T1] (networks.py:37-45)
+            dec_io = [(ngf * 8, ngf * 4), (ngf * 4 * 2 + ngf * 4, ngf * 4), (ngf * 4 * 2 + ngf * 4, ngf * 2),
+                      (ngf * 2 * 2 + ngf * 4, ngf), (ngf * 1 * 2 + ngf * 4, ngf)]
+        else:                               # 'encoder': [x, skip connection, warped cloth-encoder feature E1] (networks.py:46-54)
+            dec_io = [(ngf * 8, ngf * 4), (ngf * 4 * 3, ngf * 4), (ngf * 4 * 3, ngf * 2), (ngf * 2 * 3, ngf), (ngf * 1 * 3, ngf)]
         self.SegDecoder = nn.Sequential(*[ResBlock(i, o, "up", norm_layer) for i, o in dec_io])
-        self.out_layer = ResBlock(ngf + input1_nc + input2_nc, output_nc, "same", norm_layer)
+        if self.out_layer_opt == "relu":
+            self.out_layer = ResBlock(ngf + input1_nc + input2_nc, output_nc, "same", norm_layer)
+        else:                               # 'conv' (networks.py:57-61): a ResBlock to ngf channels, then a 1x1 to the logits
+            self.out_layer = nn.Sequential(ResBlock(ngf + input1_nc + input2_nc, ngf, "same", norm_layer),
+                                           nn.Conv2d(ngf, output_nc, kernel_size=1, bias=True))
         lat = [ngf, ngf * 2, ngf * 4, ngf * 4]
         self.conv1 = nn.Sequential(*[nn.Conv2d(c, ngf * 4, 1, bias=True) for c in lat])
         self.conv2 = nn.Sequential(*[nn.Conv2d(c, ngf * 4, 1, bias=True) for c in lat])
@@ -164,10 +171,16 @@ class ConditionGenerator(nn.Module):
         dec_out = [c4, c4, ngf * 2, ngf, ngf]
         seg = [_ResBlockPlan(self.SegDecoder[0], [ngf * 8], device, "SegDecoder.0", mx)]
         for i in range(1, 5):
-            # cat([x, E2[4-i], warped_T1]) -- networks.py:141
-            seg.append(_ResBlockPlan(self.SegDecoder[i], [dec_out[i - 1], enc[4 - i], c4], device, f"SegDecoder.{i}", mx))
+            # cat([x, E2[4-i], warped_T1]) -- networks.py:141; 'encoder': the third source is the warped E1[4-i] (:143-144)
+            third = c4 if self.warp_feature == "T1" else enc[4 - i]
+            seg.append(_ResBlockPlan(self.SegDecoder[i], [dec_out[i - 1], enc[4 - i], third], device, f"SegDecoder.{i}", mx))
         P["seg"] = seg
-        P["out"] = _ResBlockPlan(self.out_layer, [ngf, self.input2_nc, self.input1_nc], device, "out_layer", mx)
+        if self.out_layer_opt == "relu":
+            P["out"] = _ResBlockPlan(self.out_layer, [ngf, self.input2_nc, self.input1_nc], device, "out_layer", mx)
+        else:
+            P["out"] = _ResBlockPlan(self.out_layer[0], [ngf, self.input2_nc, self.input1_nc], device, "out_layer.0", mx)
+            m = self.out_layer[1]
+            P["out_conv"] = ConvLayer(m.weight, [m.in_channels], device, shift=m.bias, pad=0, name="out_layer.1", mma_bf16=mx)
         P["conv1"] = [ConvLayer(m.weight, [m.in_channels], device, shift=m.bias, pad=0, name=f"conv1.{i}", mma_bf16=mx)
                       for i, m in enumerate(self.conv1)]
         P["conv2"] = [ConvLayer(m.weight, [m.in_channels], device, shift=m.bias, pad=0, name=f"conv2.{i}", mma_bf16=mx)
@@ -243,17 +256,25 @@ class ConditionGenerator(nn.Module):
                 a2 = P["conv2"][4 - i]([e2])
                 T2 = ops.resize_bilinear(T2, iH, iW, 0.5, 0.5, addend=a2)
                 # flow upsample + flow_norm + make_grid + grid_sample in one kernel (networks.py:133-135)
-                warped, fup = ops.flow_warp(T1, flow_list[-1], iH, iW, 0.5, 0.5,
+                flow_prev = flow_list[-1]
+                warped, fup = ops.flow_warp(T1, flow_prev, iH, iW, 0.5, 0.5,
                                             (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
                 b = P["bott"][i - 1]([x])
                 fl = Act(torch.empty((N, iH, iW, 2), dtype=torch.float32, device=input1.device), 2)
                 # flow = up(flow) + flow_conv(cat([warped_T1, bottleneck(x)]))  (networks.py:137)
                 P["flow"][i]([warped, b], out=fl, residual=Act(fup, 2))
                 flow_list.append(fl.t)
-                x = P["seg"][i]([x, e2, warped])
+                if self.warp_feature == "T1":
+                    x = P["seg"][i]([x, e2, warped])
+                else:       # the decoder reads the cloth-encoder feature itself, warped by the same (upsampled previous) flow
+                    warped_e1, _ = ops.flow_warp(e1, flow_prev, iH, iW, 0.5, 0.5, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0,
+                                                 want_flow_up=False)
+                    x = P["seg"][i]([x, e2, warped_e1])
         warped_in, _ = ops.flow_warp(x1, flow_list[-1], H, W, 0.5, 0.5, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0,
                                      want_flow_up=False)
         seg = P["out"]([x, x2, warped_in])
+        if self.out_layer_opt == "conv":
+            seg = P["out_conv"]([seg])
         seg_nchw = ops.to_nchw(seg)
         warped_nchw = ops.to_nchw(warped_in)
         c = self.input1_nc

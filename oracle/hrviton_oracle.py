@@ -206,7 +206,7 @@ def tocg_forward(sd: SD, input1: Tensor, input2: Tensor,
 
     Returns (flow_list [5 x [N,h,w,2]], x [N,13,H,W], warped_c, warped_cm).
     """
-    assert warp_feature == "T1" and out_layer == "relu", "oracle restates the default config"
+    assert warp_feature in ("T1", "encoder") and out_layer in ("relu", "conv"), (warp_feature, out_layer)
     E1: List[Tensor] = []
     E2: List[Tensor] = []
     for i in range(5):
@@ -237,14 +237,22 @@ def tocg_forward(sd: SD, input1: Tensor, input2: Tensor,
             flow = flow + F.conv2d(torch.cat([warped_T1, b], 1), sd[f"flow_conv.{i}.weight"],
                                    sd[f"flow_conv.{i}.bias"], padding=1).permute(0, 2, 3, 1)
             flow_list.append(flow)
-            x = resblock(sd, f"SegDecoder.{i}", torch.cat([x, E2[4 - i], warped_T1], 1), "up")
+            if warp_feature == "T1":                                                   # networks.py:140-141
+                x = resblock(sd, f"SegDecoder.{i}", torch.cat([x, E2[4 - i], warped_T1], 1), "up")
+            else:                                                                      # 'encoder', networks.py:142-144
+                warped_E1 = grid_sample_bilinear_border(E1[4 - i], flow_norm + grid)
+                x = resblock(sd, f"SegDecoder.{i}", torch.cat([x, E2[4 - i], warped_E1], 1), "up")
     N, _, iH, iW = input1.shape
     grid = make_grid(N, iH, iW)
     flow = resize_bilinear(flow_list[-1].permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1)
     flow_norm = torch.cat([flow[..., 0:1] / ((iW / 2 - 1.0) / 2.0),
                            flow[..., 1:2] / ((iH / 2 - 1.0) / 2.0)], 3)
     warped_input1 = grid_sample_bilinear_border(input1, flow_norm + grid)
-    x = resblock(sd, "out_layer", torch.cat([x, input2, warped_input1], 1), "same")
+    if out_layer == "relu":                                                            # networks.py:54-55
+        x = resblock(sd, "out_layer", torch.cat([x, input2, warped_input1], 1), "same")
+    else:                                                                              # 'conv', networks.py:56-60
+        x = resblock(sd, "out_layer.0", torch.cat([x, input2, warped_input1], 1), "same")
+        x = _tq(x, sd["out_layer.1.weight"], sd["out_layer.1.bias"])
     return flow_list, x, warped_input1[:, :-1], warped_input1[:, -1:]
 
 
@@ -603,7 +611,7 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
                            lasttvonly: bool = True, interflowloss: bool = True, occlusion: bool = False,
                            Ddownx2: bool = True, composition: str = "warp_grad", tvlambda: float = 2.0,
                            CElamda: float = 10.0, GANlambda: float = 1.0, num_D: int = 2, drop_masks=None,
-                           edgeawaretv: str = "no_edge", add_lasttv: bool = False):
+                           edgeawaretv: str = "no_edge", add_lasttv: bool = False, warp_feature: str = "T1", out_layer: str = "relu"):
     """One iteration of train_condition.py:136-277 up to the two loss sums (the caller runs backward).
     `batch`: cloth, cloth_mask (already binarised :140), parse_agnostic, densepose, parse_onehot (label
     indices [N,1,H,W]), parse (one-hot 13), pcm, parse_cloth.  sd_vgg None drops the VGG terms
@@ -614,7 +622,7 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
     label_onehot, label, pcm, im_c = batch["parse_onehot"], batch["parse"], batch["pcm"], batch["parse_cloth"]
     BN_TRAIN["on"], BN_TRAIN["stats"] = True, {}
     try:
-        flow_list, fake_segmap, warped_c, warped_cm = tocg_forward(sd_g, input1, input2)
+        flow_list, fake_segmap, warped_c, warped_cm = tocg_forward(sd_g, input1, input2, warp_feature, out_layer)
     finally:
         BN_TRAIN["on"] = False
     seg_raw = fake_segmap

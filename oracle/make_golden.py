@@ -215,6 +215,38 @@ def main():
         print(f, os.path.getsize(os.path.join(OUT, f)) // 1024, "KiB")
 
 
+def tocg_variants():
+    """ConditionGenerator(warp_feature='encoder', out_layer='conv') of the REAL reference -- the decoder reads the warped cloth-encoder
+    feature instead of the warped T1 (networks.py:46-54,142-144) and ends in ResBlock + Conv2d 1x1 (networks.py:57-61) -- eval
+    forward on seeded inputs.  Its own generator and seeds: the other fixtures regenerate byte-identically."""
+    import torch
+    import torch.nn as nn
+    torch.set_num_threads(max(1, os.cpu_count() or 1))
+    ref_networks, _ = _import_reference()
+    g = torch.Generator().manual_seed(4321)
+    torch.manual_seed(17)
+    opt = Namespace(cuda=False, warp_feature="encoder", out_layer="conv")
+    NGF = 8
+    tocg = ref_networks.ConditionGenerator(opt, input1_nc=4, input2_nc=16, output_nc=13, ngf=NGF, norm_layer=nn.BatchNorm2d)
+    with torch.no_grad():
+        _randomize_bn(tocg, g)
+        for fc in tocg.flow_conv:
+            fc.weight.mul_(4.0)
+    tocg.eval()
+    N, H, W = 1, 96, 64
+    input1 = torch.cat([torch.rand(N, 3, H, W, generator=g) * 2 - 1, (torch.rand(N, 1, H, W, generator=g) > 0.5).float()], 1)
+    lab = torch.randint(0, 13, (N, 1, H, W), generator=g)
+    input2 = torch.cat([torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0), torch.rand(N, 3, H, W, generator=g) * 2 - 1], 1)
+    with torch.no_grad():
+        flow_list, seg, wc, wcm = tocg(opt, input1, input2)
+    name = "tocg_encoder_conv_ngf8_96x64.pt"
+    torch.save({"ngf": NGF, "warp_feature": "encoder", "out_layer": "conv",
+                "state_dict": {k: v.clone() for k, v in tocg.state_dict().items()},
+                "input1": input1, "input2": input2, "flow_list": flow_list, "seg": seg, "warped_c": wc, "warped_cm": wcm},
+               os.path.join(OUT, name))
+    print(name, os.path.getsize(os.path.join(OUT, name)) // 1024, "KiB")
+
+
 def condstep():
     """One tocg + D training iteration of the REAL reference (train_condition.py:136-286 re-composed on
     CPU from the reference's own classes; config --Ddownx2 --lasttvonly --interflowloss, VGG terms
@@ -367,7 +399,10 @@ if __name__ == "__main__":
         condstep()
     elif len(sys.argv) > 1 and sys.argv[1] == "dataset":
         dataset()
+    elif len(sys.argv) > 1 and sys.argv[1] == "tocg_variants":
+        tocg_variants()
     else:
         main()
         condstep()
         dataset()
+        tocg_variants()

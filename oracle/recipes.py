@@ -48,11 +48,13 @@ def condstep_opt(cuda: bool):
     return Namespace(cuda=cuda, warp_feature="T1", out_layer="relu", semantic_nc=13, output_nc=13)
 
 
-def condstep_build(tocg_cls, define_D, cuda: bool = False, ngf: int = 8, N: int = 2, H: int = 128, W: int = 96):
+def condstep_build(tocg_cls, define_D, cuda: bool = False, ngf: int = 8, N: int = 2, H: int = 128, W: int = 96,
+                   warp_feature: str = "T1", out_layer: str = "relu"):
     """ConditionGenerator(ngf=8) + define_D(33 ch, Ddownx2, num_D=2) + one synthetic train_condition.py
     batch (default N=2, 128x96, ngf=8 -- the golden recipe; the full-size parity tests pass the timed sizes).  tocg keeps torch's default conv init with randomised BatchNorm affine terms
     and non-trivial running statistics; D uses the reference's weights_init (N(0, 0.02)) scaled x2."""
     opt = condstep_opt(cuda)
+    opt.warp_feature, opt.out_layer = warp_feature, out_layer      # (defaults: the golden recipe, networks.py:37-61)
     torch.manual_seed(31)
     tocg = tocg_cls(opt, input1_nc=4, input2_nc=16, output_nc=13, ngf=ngf, norm_layer=torch.nn.BatchNorm2d)
     D = define_D(input_nc=4 + 16 + 13, Ddownx2=True, Ddropout=False, n_layers_D=3, spectral=False, num_D=2)

@@ -605,3 +605,68 @@ def test_g_d_separate_ordering_uses_the_updated_generator():
     # and it differs from the default ordering's D loss (pre-update fake maps)
     assert abs(float(r["d_fake"].detach()) - float(want_f)) > 1e-6
     assert int(tocg.out_layer.block[1].num_batches_tracked) == 2     # two training-mode forwards
+
+
+@pytest.mark.parametrize("wf,ol", [("encoder", "conv"), ("encoder", "relu"), ("T1", "conv")])
+def test_condition_training_iteration_of_the_tocg_variants_matches_oracle(wf, ol):
+    """train_condition.py --warp_feature encoder / --out_layer conv (networks.py:46-61,142-144): the decoder's third source is the
+    cloth-encoder feature warped by the same upsampled flow as T1 (a second consumer of that flow and of E1 on the tape), and the
+    logits come out of ResBlock + Conv2d 1x1.  One iteration on the HIP path against torch autograd over the oracle (pinned to the
+    reference by tests/golden/tocg_encoder_conv_ngf8_96x64.pt): loss terms, every tocg / D parameter gradient."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import networks, pipeline
+    from hr_viton_amd.losses import L1Loss
+    from hr_viton_amd.optim import Adam
+    from oracle.recipes import condstep_build
+    opt, tocg, D, batch = condstep_build(networks.ConditionGenerator, networks.define_D, warp_feature=wf, out_layer=ol)
+    opt.lasttvonly, opt.interflowloss, opt.occlusion, opt.clothmask_composition = True, True, False, "warp_grad"
+    opt.edgeawaretv, opt.add_lasttv = "no_edge", False
+    opt.tvlambda, opt.CElamda, opt.GANlambda, opt.no_GAN_loss = 2.0, 10.0, 1.0, False
+    sd_g = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in tocg.state_dict().items()}
+    sd_d = {k: v.detach().clone().requires_grad_(True) for k, v in D.state_dict().items()}
+    r = O.condition_train_losses(sd_g, sd_d, None, batch, occlusion=False, composition="warp_grad", edgeawaretv="no_edge",
+                                 add_lasttv=False, warp_feature=wf, out_layer=ol)
+    r["loss_G"].backward(retain_graph=True)
+    g_grads = {k: (None if v.grad is None else v.grad.clone()) for k, v in sd_g.items()}
+    for v in sd_d.values():
+        v.grad = None
+    r["loss_D"].backward()
+    tocg.cuda().train()
+    D.cuda().train()
+    opt_g = Adam(tocg.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    opt_d = Adam(D.parameters(), lr=0.0002, betas=(0.5, 0.999))
+    grads_g, grads_d = {}, {}
+    step_g, step_d = opt_g.step, opt_d.step
+
+    def sg():
+        grads_g.update({n: p.grad.detach().clone() for n, p in tocg.named_parameters() if p.grad is not None})
+        return step_g()
+
+    def sdd():
+        grads_d.update({n: p.grad.detach().clone() for n, p in D.named_parameters() if p.grad is not None})
+        return step_d()
+
+    opt_g.step, opt_d.step = sg, sdd
+    losses = pipeline.condition_train_step(opt, tocg, D, L1Loss(), None, networks.GANLoss(use_lsgan=True), opt_g, opt_d,
+                                           {k: v.cuda() for k, v in batch.items()})
+    for k in ("l1", "tv", "ce", "g_gan", "loss_G", "d_fake", "d_real", "loss_D"):
+        want, got = float(r[k].detach()), float(losses[k].detach())
+        assert abs(got - want) < 1e-4 * max(1.0, abs(want)), (k, got, want)
+
+    class _G:
+        def __init__(self, mod, grads):
+            self.mod, self.grads = mod, grads
+
+        def named_parameters(self):
+            for n, p in self.mod.named_parameters():
+                yield n, Namespace(grad=self.grads.get(n))
+
+    class _W:
+        def __init__(self, g):
+            self.grad = g
+
+    _compare_grads(_G(tocg, grads_g), {k: _W(g_grads[k]) for k in sd_g}, 5e-3, f"tocg_{wf}_{ol} step")
+    _compare_grads(_G(D, grads_d), {k: _W(v.grad) for k, v in sd_d.items()}, 5e-4, f"tocgD_{wf}_{ol} step")
+    # every parameter of the variant's extra pieces got a gradient
+    if ol == "conv":
+        assert "out_layer.1.weight" in grads_g and "out_layer.0.block.0.weight" in grads_g

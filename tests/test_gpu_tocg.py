@@ -21,10 +21,10 @@ def _rel(a, b):
     return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
 
 
-def _build(ngf, sd=None, seed=0):
+def _build(ngf, sd=None, seed=0, warp_feature="T1", out_layer="relu"):
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd.networks import ConditionGenerator
-    opt = Namespace(cuda=True, warp_feature="T1", out_layer="relu")
+    opt = Namespace(cuda=True, warp_feature=warp_feature, out_layer=out_layer)
     torch.manual_seed(seed)
     m = ConditionGenerator(opt, 4, 16, 13, ngf=ngf, norm_layer=nn.BatchNorm2d)
     if sd is not None:
@@ -79,6 +79,31 @@ def test_tocg_golden_reference_vectors():
     m.cuda().eval()
     outs = m(opt, g["input1"].cuda(), g["input2"].cuda())
     _check(outs, (g["flow_list"], g["seg"], g["warped_c"], g["warped_cm"]))
+
+
+def test_tocg_encoder_conv_variant_golden_reference_vectors():
+    """ConditionGenerator(warp_feature='encoder', out_layer='conv') (networks.py:46-61,142-144): reference state-dict keys load,
+    the eval forward reproduces vectors of the real reference (flows, logits -- negative values included --, warped cloth, mask)."""
+    g = load_golden("tocg_encoder_conv_ngf8_96x64.pt")
+    opt, m = _build(g["ngf"], g["state_dict"], warp_feature=g["warp_feature"], out_layer=g["out_layer"])
+    m.cuda().eval()
+    outs = m(opt, g["input1"].cuda(), g["input2"].cuda())
+    _check(outs, (g["flow_list"], g["seg"], g["warped_c"], g["warped_cm"]))
+    assert (outs[1] < 0).any()
+
+
+@pytest.mark.parametrize("wf,ol", [("encoder", "relu"), ("T1", "conv")])
+def test_tocg_variants_vs_oracle_live(wf, ol):
+    """each variant on its own, ngf=16 at 128x96, against the oracle (pinned to the reference by the combined golden above)"""
+    opt, m = _build(16, seed=5, warp_feature=wf, out_layer=ol)
+    _randomize(m, 7)
+    m.eval()
+    input1, input2 = _rand_inputs(2, 128, 96, 13)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        want = O.tocg_forward(sd, input1, input2, wf, ol)
+    m.cuda()
+    _check(m(opt, input1.cuda(), input2.cuda()), want)
 
 
 def test_tocg_two_arg_forward_and_plan_refresh():

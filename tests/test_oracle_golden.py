@@ -39,6 +39,20 @@ def test_tocg_matches_reference():
     assert g["flow_list"][-1].abs().max() > 0.5
 
 
+def test_tocg_encoder_conv_variant_matches_reference():
+    """warp_feature='encoder' (the decoder reads the warped cloth-encoder feature, networks.py:46-54,142-144) + out_layer='conv'
+    (ResBlock + Conv2d 1x1, networks.py:57-61): the restatement against vectors of the real reference."""
+    g = load_golden("tocg_encoder_conv_ngf8_96x64.pt")
+    flow_list, seg, wc, wcm = O.tocg_forward(g["state_dict"], g["input1"], g["input2"], g["warp_feature"], g["out_layer"])
+    for a, b in zip(flow_list, g["flow_list"]):
+        assert a.shape == b.shape
+        _close(a, b)
+    _close(seg, g["seg"])
+    _close(wc, g["warped_c"], 1e-4)
+    _close(wcm, g["warped_cm"], 1e-4)
+    assert g["flow_list"][-1].abs().max() > 0.5 and (g["seg"] < 0).any()      # flows are exercised; logits are not ReLU outputs
+
+
 def test_spade_generator_matches_reference():
     g = load_golden("gen_ngf2_256x128.pt")
     out = O.spade_generator_forward(g["state_dict"], g["x"], g["seg"], 256, 128, "most", noise=g["noise"])

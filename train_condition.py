@@ -11,7 +11,8 @@ kernels (hr_viton_amd.cond_train, .functional, .losses, .vgg); one iteration is
     on RCCL during the backward (hr_viton_amd.parallel.GradSync).
   * ``--synthetic`` feeds VITON-HD-shaped random batches (no dataset / torchvision in this image);
     the tensorboard / validation-IoU blocks (train_condition.py:311-418) are out of scope.
-  * not on the HIP path (raise NotImplementedError): --upsample nearest, --warp_feature encoder, --out_layer conv.
+  * --warp_feature encoder / --out_layer conv (networks.py:46-61,142-144) are on the HIP path (round 5); --upsample nearest raises
+    NotImplementedError.
 """
 import argparse
 import os
