@@ -756,6 +756,69 @@ extern "C" int hrv_resize_bilinear_bwd_nhwc_f32(const float* dy, int32_t N, int3
   return check_launch("resize_bwd_kernel");
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// F.interpolate(mode='nearest') over planes [P][H][W] -> [P][Ho][Wo] and its adjoint: train_condition.py:242 with --upsample nearest
+// (the inter-flow loss resizes every intermediate flow to the image size).  torch's legacy nearest: src = min(floorf(dst * scale),
+// in - 1) with scale = (float)in / out.  The adjoint is a gather (deterministic): a source pixel sums the output pixels whose
+// source index -- computed with the SAME float expression -- is that pixel; candidates are bracketed by the inverse map +- 1.
+// ---------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int nearest_src(int dst, float scale, int in_size) {
+  const int s = (int)floorf((float)dst * scale);
+  return s < in_size - 1 ? s : in_size - 1;
+}
+
+__global__ void resize_nearest_planes_kernel(const float* __restrict__ in, size_t total, int H, int W, int Ho, int Wo, float sh,
+                                             float sw, float* __restrict__ out) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int x = (int)(i % Wo);
+    const size_t t = i / Wo;
+    const int y = (int)(t % Ho);
+    const size_t p = t / Ho;
+    out[i] = in[(p * H + nearest_src(y, sh, H)) * W + nearest_src(x, sw, W)];
+  }
+}
+
+__global__ void resize_nearest_planes_bwd_kernel(const float* __restrict__ dout, size_t total, int H, int W, int Ho, int Wo, float sh,
+                                                 float sw, float* __restrict__ dx) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int sx = (int)(i % W);
+    const size_t t = i / W;
+    const int sy = (int)(t % H);
+    const size_t p = t / H;
+    int y0 = (int)floorf((float)sy / sh) - 1, y1 = (int)floorf((float)(sy + 1) / sh) + 1;
+    int x0 = (int)floorf((float)sx / sw) - 1, x1 = (int)floorf((float)(sx + 1) / sw) + 1;
+    if (sy == H - 1) y1 = Ho - 1;          // (the clamp maps every overshooting output to the last source row / column)
+    if (sx == W - 1) x1 = Wo - 1;
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > Ho - 1 ? Ho - 1 : y1; x1 = x1 > Wo - 1 ? Wo - 1 : x1;
+    float acc = 0.f;
+    for (int y = y0; y <= y1; ++y) {
+      if (nearest_src(y, sh, H) != sy) continue;
+      for (int x = x0; x <= x1; ++x)
+        if (nearest_src(x, sw, W) == sx) acc += dout[(p * Ho + y) * Wo + x];
+    }
+    dx[i] = acc;
+  }
+}
+
+extern "C" int hrv_resize_nearest_nchw_f32(const float* in, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, float* out,
+                                           hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_nearest: bad args");
+  const size_t total = (size_t)planes * Ho * Wo;
+  hipLaunchKernelGGL(resize_nearest_planes_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, total, H, W, Ho, Wo,
+                     (float)H / (float)Ho, (float)W / (float)Wo, out);
+  return check_launch("resize_nearest_planes_kernel");
+}
+
+extern "C" int hrv_resize_nearest_nchw_bwd_f32(const float* dout, int32_t planes, int32_t Ho, int32_t Wo, int32_t H, int32_t W, float* dx,
+                                               hrv_stream_t stream) {
+  HRV_REQUIRE(dout && dx && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_nearest_bwd: bad args");
+  const size_t total = (size_t)planes * H * W;
+  hipLaunchKernelGGL(resize_nearest_planes_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, total, H, W, Ho,
+                     Wo, (float)H / (float)Ho, (float)W / (float)Wo, dx);
+  return check_launch("resize_nearest_planes_bwd_kernel");
+}
+
 extern "C" int hrv_flow_warp_bwd_nhwc_f32(const hrv_flow_warp_bwd_t* d, hrv_stream_t stream) {
   HRV_REQUIRE(d && d->flow_up && d->dout && (d->dsrc || d->dflow), "flow_warp_bwd: null pointer");
   HRV_REQUIRE(d->N > 0 && d->H > 0 && d->W > 0 && d->Ho > 0 && d->Wo > 0 && d->C > 0 && d->C % 4 == 0,

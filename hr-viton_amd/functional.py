@@ -2,7 +2,7 @@
 between the networks (train_condition.py:164-252, train_generator.py:235-238):
 
     grid_sample(input, grid, padding_mode='border')     F.grid_sample       (bilinear, align_corners=False)
-    interpolate(x, size=/scale_factor=, mode='bilinear')F.interpolate
+    interpolate(x, size=/scale_factor=, mode='bilinear' | 'nearest')   F.interpolate
     softmax(x, dim=1)                                   F.softmax / torch.softmax
     cross_entropy2d(input, target)                      utils.cross_entropy2d (utils.py:29-42)
     tv_loss(flow)                                       the |d/dy| + |d/dx| means of train_condition.py:190-199
@@ -148,13 +148,62 @@ def _interp_backward(ctx, dout):
 _interp_op.register_autograd(_interp_backward, setup_context=_interp_setup)
 
 
+@_op("interpolate_nearest")
+def _interp_nearest_op(x: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
+    lib = _lib.load()
+    x = _f32c(x, "interpolate")
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+    _lib.check(lib.hrv_resize_nearest_nchw_f32(x.data_ptr(), N * Cc, H, W, Ho, Wo, out.data_ptr(), _stream()), "hrv_resize_nearest_nchw_f32")
+    return out
+
+
+@_interp_nearest_op.register_fake
+def _(x, Ho, Wo):
+    return x.new_empty((x.shape[0], x.shape[1], Ho, Wo))
+
+
+@_op("interpolate_nearest_backward")
+def _interp_nearest_bwd_op(dout: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    lib = _lib.load()
+    dout = dout.contiguous()
+    N, Cc, Ho, Wo = dout.shape
+    dx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dout.device)
+    _lib.check(lib.hrv_resize_nearest_nchw_bwd_f32(dout.data_ptr(), N * Cc, Ho, Wo, H, W, dx.data_ptr(), _stream()),
+               "hrv_resize_nearest_nchw_bwd_f32")
+    return dx
+
+
+@_interp_nearest_bwd_op.register_fake
+def _(dout, H, W):
+    return dout.new_empty((dout.shape[0], dout.shape[1], H, W))
+
+
+def _interp_nearest_setup(ctx, inputs, output):
+    ctx.geom = (inputs[0].shape[2], inputs[0].shape[3])
+
+
+def _interp_nearest_backward(ctx, dout):
+    return _interp_nearest_bwd_op(dout, *ctx.geom), None, None
+
+
+_interp_nearest_op.register_autograd(_interp_nearest_backward, setup_context=_interp_nearest_setup)
+
+
 def interpolate(input: torch.Tensor, size: Optional[Union[int, Sequence[int]]] = None,
                 scale_factor: Optional[float] = None, mode: str = "bilinear",
                 align_corners: Optional[bool] = None) -> torch.Tensor:
     """F.interpolate(mode='bilinear', align_corners=False) -- SURVEY App. A.2: with scale_factor the given
-    factor is the source ratio, with size= it is in/out."""
+    factor is the source ratio, with size= it is in/out -- and mode='nearest' with size= (train_condition.py:242 under
+    --upsample nearest)."""
+    if mode == "nearest" and not align_corners:
+        if size is None:
+            raise NotImplementedError("hr-viton_amd interpolate(mode='nearest'): size= form only (train_condition.py:242)")
+        Ho, Wo = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))
+        _f32c(input, "interpolate")
+        return _interp_nearest_op(input, Ho, Wo)
     if mode != "bilinear" or align_corners:
-        raise NotImplementedError("hr-viton_amd interpolate: mode='bilinear', align_corners=False only")
+        raise NotImplementedError("hr-viton_amd interpolate: mode='bilinear' | 'nearest', align_corners=False only")
     H, W = input.shape[2], input.shape[3]
     if size is not None:
         Ho, Wo = (size, size) if isinstance(size, int) else (int(size[0]), int(size[1]))

@@ -195,7 +195,8 @@ def condition_train_step(opt, tocg, D, crit_l1, crit_vgg, crit_gan, opt_g, opt_d
         for i in range(len(flow_list) - 1):
             flow = flow_list[i]
             _, fH, fW, _ = flow.size()
-            flow = HF.interpolate(flow.permute(0, 3, 1, 2), size=c_paired.shape[2:], mode="bilinear").permute(0, 2, 3, 1)
+            flow = HF.interpolate(flow.permute(0, 3, 1, 2), size=c_paired.shape[2:],
+                                  mode=getattr(opt, "upsample", "bilinear")).permute(0, 2, 3, 1)      # :242 (--upsample)
             flow_norm = torch.cat([flow[:, :, :, 0:1] / ((fW - 1.0) / 2.0), flow[:, :, :, 1:2] / ((fH - 1.0) / 2.0)], 3)
             warped_cm_i = HF.grid_sample(cm_paired, flow_norm + grid, padding_mode="border")
             warped_cm_i = remove_overlap(soft_for_overlap, warped_cm_i)

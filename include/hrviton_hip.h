@@ -628,6 +628,13 @@ int hrv_bn_bwd_nhwc_f32(const float* dy, int32_t dy_cstride, int32_t dy_coff, co
 int hrv_resize_bilinear_bwd_nhwc_f32(const float* dy, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t dy_cstride,
                                      int32_t dy_coff, float rh, float rw, float* dx, int32_t H, int32_t W,
                                      int32_t dx_cstride, int32_t dx_coff, int32_t accumulate, hrv_stream_t stream);
+/* F.interpolate(mode='nearest') over planes [planes][H][W] -> [planes][Ho][Wo] (an NCHW tensor: planes = N*C) and its adjoint
+ * (gather form, deterministic): the inter-flow loss of train_condition.py:242 under --upsample nearest.  torch's legacy nearest:
+ * src = min(floorf(dst * (float)in / out), in - 1). */
+int hrv_resize_nearest_nchw_f32(const float* in, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, float* out,
+                                hrv_stream_t stream);
+int hrv_resize_nearest_nchw_bwd_f32(const float* dout, int32_t planes, int32_t Ho, int32_t Wo, int32_t H, int32_t W, float* dx,
+                                    hrv_stream_t stream);
 /* Adjoint of hrv_flow_warp_nhwc_f32 (F.grid_sample backward, networks.py:135,152): given the
  * saved un-normalised flow at the output resolution (flow_up) and dout [N,Ho,Wo,C]:
  *   dsrc  [N,H,W,C]   += scatter of the four bilinear taps (fp32 atomics; zero-init or an

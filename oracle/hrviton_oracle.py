@@ -611,7 +611,8 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
                            lasttvonly: bool = True, interflowloss: bool = True, occlusion: bool = False,
                            Ddownx2: bool = True, composition: str = "warp_grad", tvlambda: float = 2.0,
                            CElamda: float = 10.0, GANlambda: float = 1.0, num_D: int = 2, drop_masks=None,
-                           edgeawaretv: str = "no_edge", add_lasttv: bool = False, warp_feature: str = "T1", out_layer: str = "relu"):
+                           edgeawaretv: str = "no_edge", add_lasttv: bool = False, warp_feature: str = "T1", out_layer: str = "relu",
+                           upsample: str = "bilinear"):
     """One iteration of train_condition.py:136-277 up to the two loss sums (the caller runs backward).
     `batch`: cloth, cloth_mask (already binarised :140), parse_agnostic, densepose, parse_onehot (label
     indices [N,1,H,W]), parse (one-hot 13), pcm, parse_cloth.  sd_vgg None drops the VGG terms
@@ -657,7 +658,7 @@ def condition_train_losses(sd_g: SD, sd_d: SD, sd_vgg: Optional[SD], batch: Dict
             flow = flow_list[i]
             _, fH, fW, _ = flow.shape
             grid = make_grid(N, iH, iW)
-            flow = resize_bilinear(flow.permute(0, 3, 1, 2), size=(iH, iW)).permute(0, 2, 3, 1)
+            flow = (resize_bilinear if upsample == "bilinear" else resize_nearest)(flow.permute(0, 3, 1, 2), size=(iH, iW)).permute(0, 2, 3, 1)   # :242
             flow_norm = torch.cat([flow[..., 0:1] / ((fW - 1.0) / 2.0), flow[..., 1:2] / ((fH - 1.0) / 2.0)], 3)
             w_c = grid_sample_bilinear_border(c_paired, flow_norm + grid)
             w_cm = grid_sample_bilinear_border(cm_paired, flow_norm + grid)

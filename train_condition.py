@@ -11,8 +11,8 @@ kernels (hr_viton_amd.cond_train, .functional, .losses, .vgg); one iteration is
     on RCCL during the backward (hr_viton_amd.parallel.GradSync).
   * ``--synthetic`` feeds VITON-HD-shaped random batches (no dataset / torchvision in this image);
     the tensorboard / validation-IoU blocks (train_condition.py:311-418) are out of scope.
-  * --warp_feature encoder / --out_layer conv (networks.py:46-61,142-144) are on the HIP path (round 5); --upsample nearest raises
-    NotImplementedError.
+  * --warp_feature encoder / --out_layer conv (networks.py:46-61,142-144) and --upsample nearest (the inter-flow loss's flow
+    resize, train_condition.py:242 -- the only place the reference's scripts use the flag) are on the HIP path (round 5).
 """
 import argparse
 import os
@@ -98,8 +98,6 @@ def get_opt(argv=None):
                    help="plumbing / bench runs only: a RANDOMLY initialised VGG19 in the perceptual loss (no network here to "
                         "download the pretrained weights); implied by --synthetic")
     opt = p.parse_args(argv)
-    if opt.upsample != "bilinear":
-        raise NotImplementedError("hr-viton_amd train_condition: --upsample nearest is not on the HIP path")
     return opt
 
 
