@@ -29,13 +29,20 @@ bash tools/launch_count.sh > $OUT/launch_count.log 2>&1
 cp gpurun_out/launch_count/per_step.txt $OUT/launches_per_iteration.txt 2>/dev/null
 timeout 500 bash tools/dp_overlap.sh > $OUT/dp_overlap.log 2>&1
 cp gpurun_out/dp_overlap/overlap.txt $OUT/dp_overlap.txt 2>/dev/null
-# round 4: the fused SPADE forward / the two-blocks-per-CU convolution against what they replaced, SQ counters of the fused kernel,
-# the cost of leaving CUs to concurrent collectives
+# round 5: SQ counters of every kernel of the iteration itself (matrix-pipe busy of the dominant kernel INSIDE the iteration), the
+# PatchGAN layer-by-layer precision sweep.  (tools/fused_bench.py / p2_bench.py / profile_fused.sh: the round-4 kernels are unchanged,
+# their numbers are profiles/r04_final_*; HRV_FULL_SWEEP=1 re-runs them.)
+timeout 400 bash tools/profile_iter_sq.sh > $OUT/profile_iter_sq.log 2>&1
+cp gpurun_out/pmc_iter/mfma_busy_per_kernel.txt $OUT/mfma_busy_per_kernel.txt 2>/dev/null
+cp gpurun_out/pmc_iter/sq1.summary.txt $OUT/pmc_iter_sq1.summary.txt 2>/dev/null
+timeout 300 python tools/d_f32_layers.py 0:all 2:fwd 15:all > $OUT/d_f32_layers.txt 2>$OUT/d_f32_layers.err
+if [ "${HRV_FULL_SWEEP:-0}" = "1" ]; then
 timeout 300 python tools/fused_bench.py 5 > $OUT/fused_bench.txt 2>&1
 timeout 300 python tools/p2_bench.py 5 > $OUT/p2_bench.txt 2>&1
 timeout 400 bash tools/profile_fused.sh > $OUT/profile_fused.log 2>&1
 cp gpurun_out/pmc_fused/sq1.summary.txt $OUT/pmc_fused_sq1.summary.txt 2>/dev/null
 cp gpurun_out/pmc_fused/sq2.summary.txt $OUT/pmc_fused_sq2.summary.txt 2>/dev/null
+fi
 for R in 0 8 16; do timeout 300 python bench.py --reserve-cus $R --steps 8 --warmup 3 --no-cpu-baseline --no-extras 2>/dev/null | tail -1 | python -c "import json,sys; d=json.loads(sys.stdin.readline()); print('reserve-cus $R:', d['ms_per_step'], 'ms/step', d['value'], 'img/s, persistent grid', d['config']['persistent_grid_cus'], 'CUs')"; done > $OUT/reserve_cus.txt 2>&1
 # two ranks time-slicing the one GPU over gloo (functional smoke of the N > 1 launch, never a measurement): eager bucketed
 # GradSync, and the captured iteration as three hipGraph segments with the all-reduces between them
