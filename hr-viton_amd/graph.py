@@ -33,10 +33,15 @@ class CaptureGuard:
       module) makes the graph STALE -- its pack launches would read the weights' old addresses: ``check()`` raises HrvError
       instead of replaying."""
 
-    def __init__(self):
+    def __init__(self, modules=()):
         from . import ops
         self._runs = {id(o): o.runs for o in list(ops.GRAPH_WATCH)}
         self.keep, self.watch = [], []
+        # inference modules whose cached plan (packed weight streams, per-layer constants: ``module._plan``) the captured region
+        # reads by address: the plan object alive at the end of the capture is kept (its buffers stay the graph's), and a module
+        # that has REBUILT its plan since (a parameter changed: eval between training steps, load_state_dict) makes the graph stale
+        self._modules = list(modules)
+        self.plans = []
 
     def after(self):
         import weakref
@@ -50,6 +55,7 @@ class CaptureGuard:
             if o.runs != self._runs.get(id(o), 0):           # launched inside the captured region
                 self.keep.extend(o.graph_keep())
                 self.watch.append((weakref.ref(o), o.generation))
+        self.plans = [(weakref.ref(m), getattr(m, "_plan", None)) for m in self._modules]
         return self
 
     def check(self, who: str):
@@ -58,11 +64,19 @@ class CaptureGuard:
             if o is not None and o.generation != gen:
                 raise HrvError(f"{who}: a weight-pack batch of the captured plan was reset after the capture (a weight moved to a new "
                                "address); the graph holds the old addresses -- capture again")
+        for ref, plan in self.plans:
+            m = ref()
+            key = getattr(m, "_plan_key", None) if m is not None else None
+            moved = (key is not None and len(key) > 1 and
+                     key[1] != tuple(t._version for t in list(m.parameters()) + list(m.buffers())))      # changed, not yet re-planned
+            if m is not None and plan is not None and (getattr(m, "_plan", None) is not plan or moved):
+                raise HrvError(f"{who}: {type(m).__name__} rebuilt its inference plan (or changed its weights) after the capture; the graph "
+                               "still reads the packed weights of the old plan -- capture again")
 
 
 class GraphedStep:
     def __init__(self, fn: Callable[[Dict[str, torch.Tensor]], object], example_inputs: Dict[str, torch.Tensor],
-                 warmup: int = 2):
+                 warmup: int = 2, modules=()):
         """``fn(inputs) -> tensors`` (any nesting of dict / list / tuple).  ``example_inputs`` fix shapes and dtypes.
         ``warmup`` eager calls run first on a side stream so that every lazily built plan, packed weight and
         cached table exists before the capture (nothing may be created on the host during it)."""
@@ -79,7 +93,7 @@ class GraphedStep:
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
-        guard = CaptureGuard()
+        guard = CaptureGuard(modules)       # (``modules``: the networks whose cached inference plans ``fn`` runs)
         with torch.cuda.graph(self.graph), torch.no_grad():
             self.static_out = fn(self.static_in)
         self.guard = guard.after()
@@ -103,12 +117,13 @@ def graphed_tryon(opt, tocg, generator, example_inputs: Dict[str, torch.Tensor],
     """The body of test_generator.py:118-219 (pipeline.tryon_step) as one hipGraph."""
     from .pipeline import tryon_step
     keys = ("cloth", "cloth_mask", "parse_agnostic", "densepose", "agnostic")
-    return GraphedStep(lambda b: tryon_step(opt, tocg, generator, b), {k: example_inputs[k] for k in keys}, warmup)
+    return GraphedStep(lambda b: tryon_step(opt, tocg, generator, b), {k: example_inputs[k] for k in keys}, warmup,
+                       modules=(tocg, generator))
 
 
 def graphed_condition(opt, tocg, input1: torch.Tensor, input2: torch.Tensor, warmup: int = 2) -> GraphedStep:
     """ConditionGenerator.forward (networks.py:98-159) as one hipGraph; call with {'input1':…, 'input2':…}."""
-    return GraphedStep(lambda b: tocg(opt, b["input1"], b["input2"]), {"input1": input1, "input2": input2}, warmup)
+    return GraphedStep(lambda b: tocg(opt, b["input1"], b["input2"]), {"input1": input1, "input2": input2}, warmup, modules=(tocg,))
 
 
 class GraphedIteration:
@@ -166,7 +181,16 @@ class GraphedIteration:
             try:
                 with torch.cuda.stream(cap):
                     self.graphs[0].capture_begin(pool=pool)
-                    self.static_out = fn()
+                    try:
+                        self.static_out = fn()
+                    except BaseException:
+                        # fn() raised inside a capture: close the open segment so the stream does not stay in capture mode (every later
+                        # launch on it would fail with "operation not permitted when stream is capturing"), then let the error out
+                        try:
+                            self.graphs[-1].capture_end()
+                        except Exception:
+                            pass
+                        raise
                     self.graphs[-1].capture_end()
             finally:
                 for gs in syncs:

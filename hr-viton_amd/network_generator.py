@@ -390,6 +390,13 @@ class SPADEGenerator(BaseNetwork):
         key = (str(device), tuple(t._version for t in list(self.parameters()) + list(self.buffers())), ops.weights_epoch(self.parameters()),
                self._use_bf16())
         if self._plan is None or self._plan_key != key:
+            old = self._plan
+            if old is not None:          # the replaced plan's packed streams in train_ops' frozen-pack cache are dead entries now
+                from . import train_ops as T
+                toks = [old["tok"]] if "tok" in old else []
+                toks += [b._fast["tok"] for b in old.get("blocks", []) if getattr(b, "_fast", None)]
+                if toks:
+                    T.evict_serving_packs(toks)
             self._plan = self._build_plan(device)
             self._plan_key = key
         return self._plan

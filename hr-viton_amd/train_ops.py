@@ -30,6 +30,19 @@ def _bf16_tile(cout: int) -> int:
 _FROZEN_PACKS: dict = {}
 
 
+def evict_serving_packs(tokens):
+    """Drop the cached packed streams of a serving plan that is being replaced (network_generator.SPADEGenerator._get_plan): their
+    keys carry the plan's own tokens (``frozen=("serve", tok, k)``) and can never be hit again -- without this they sat in
+    _FROZEN_PACKS until its wholesale clear at 256 entries, which also drops VGG19's packs.  A captured hipGraph that
+    recorded such a stream by address keeps the tensor alive itself (graph.CaptureGuard)."""
+    toks = set(tokens)
+    dead = [k for k in _FROZEN_PACKS
+            if any(isinstance(e, tuple) and len(e) == 3 and e[0] == "serve" and e[1] in toks for e in k)]
+    for k in dead:
+        del _FROZEN_PACKS[k]
+    return len(dead)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # Weight gradients on a second stream.  In a backward plan only the DATA gradients form the dependency chain; a layer's weight
 # gradient hangs off it as a leaf.  At the low-resolution levels of the SPADE generator (8x6 .. 128x96 pixels, 1024 / 512 / 256

@@ -224,3 +224,14 @@ def test_hipgraph_replay_is_bit_identical_to_eager():
     want = tocg(opt, i1, i2)
     got = gc({"input1": i1, "input2": i2})
     assert torch.equal(got[1], want[1]) and torch.equal(got[2], want[2]) and torch.equal(got[0][-1], want[0][-1])
+    # a weight change rebuilds the module's inference plan (new packed streams): the graph still reads the old plan's buffers --
+    # kept alive by the guard, but stale -- so a replay is refused, loudly (it used to read freed memory silently)
+    with torch.no_grad():
+        tocg.out_layer.block[4].bias.add_(0.5)
+    with pytest.raises(HrvError, match="rebuilt its inference plan"):      # (changed, no eager call yet: the parameter versions moved)
+        gc({"input1": i1, "input2": i2})
+    tocg(opt, i1, i2)                                  # eager call: the plan is rebuilt for the new weights
+    with pytest.raises(HrvError, match="rebuilt its inference plan"):
+        gc({"input1": i1, "input2": i2})
+    with pytest.raises(HrvError, match="rebuilt its inference plan"):
+        g(b0)
