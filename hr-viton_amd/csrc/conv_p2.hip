@@ -525,12 +525,14 @@ extern "C" int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32
   if (!p2_plan(Cin, Cout, pl)) return 0;
   const int64_t tiles = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16);
   // two blocks per CU; measured down to 1.5 tiles per CU (VGG19's 128 x 96 level at 8 images: 384 tiles, 908 -> 1050+ TF/s) the kernel
-  // still beats the generic tiles, below that they fill the chip better (HRV_CONV_P2_MIN_TILES_X4: threshold in quarter-tiles per CU)
+  // beats the generic tiles clearly; round 5 took the threshold to 0.75 tiles per CU (the generator's 128 x 96 level at 4 images: 192
+  // tiles) on a same-box alternating A/B of the whole iteration -- 72.28 -> 71.96 ms, three rounds, every pair in favour
+  // (profiles/r05_ab_p2_threshold.txt).  HRV_CONV_P2_MIN_TILES_X4: the threshold in quarter-tiles per CU
   static int q4 = -1;
   if (q4 < 0) {
     const char* e = hrv::env("HRV_CONV_P2_MIN_TILES_X4");
-    q4 = e ? atoi(e) : 6;
-    if (q4 < 1) q4 = 6;
+    q4 = e ? atoi(e) : 3;
+    if (q4 < 1) q4 = 3;
   }
   return 4 * tiles >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
