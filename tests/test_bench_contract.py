@@ -172,7 +172,8 @@ def test_committed_final_detail_holds_parity_within_the_stated_tolerances():
     df, db = p["discriminator_half_fp32_engine_vs_oracle"], p["discriminator_half_bf16_engine_vs_oracle"]
     assert all(v < 1e-3 for v in df["loss_rel_err"].values()) and df["grad_worst_rel_err"] < 2e-2
     assert all(v < 5e-3 for v in db["loss_rel_err"].values())
-    assert db["grad_min_cosine"] > db["bf16_rounded_oracle_vs_fp32_oracle"]["grad_min_cosine"] - 0.01
+    # the D half is held to the fp32 oracle itself (round 4: only to the oracle's own bf16-operand evaluation, 0.983)
+    assert db["grad_min_cosine"] > 0.99 > db["bf16_rounded_oracle_vs_fp32_oracle"]["grad_min_cosine"]
     e = d["extra"]
     c3 = e["config3_train_condition_f32_b8"]["parity"]
     assert "1024x768" in c3["size"] and all(v < 1e-3 for v in c3["false"]["loss_rel_err"].values())

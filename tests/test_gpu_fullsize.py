@@ -156,9 +156,11 @@ def test_discriminator_step_1024x768_batch2_vs_oracle_autograd():
     assert rep["grad_worst_rel_err"] < 1e-2 and rep["grad_min_cosine"] > 0.9999, rep
     assert rep["post_step_weight_frac_off_by_more_than_lr_tenth"] < 1e-3, rep
     rep = reps[True]
-    # bf16 operands (8 mantissa bits): loss terms 5e-3 relative; the gradient (hinge / LeakyReLU masks: discontinuous) is no
-    # further from the fp32 one than the oracle's OWN bf16-operand evaluation is (cosine within 0.01, median error within 1.5x)
+    # bf16 operands (8 mantissa bits): loss terms 5e-3 relative; the gradient (hinge / LeakyReLU masks: discontinuous) against the
+    # FP32 oracle: cosine >= 0.99 -- PatchGAN model1's forward keeps fp32 operands in the D step (gen_train._d_f32; measured 0.9916;
+    # every convolution on bf16 operands: 0.980, the oracle's own bf16-operand evaluation: 0.983, the bound of rounds 3-4) -- and a
+    # median error no worse than that evaluation's
     ref = rep["bf16_rounded_oracle_vs_fp32_oracle"]
     assert all(v < 5e-3 for v in rep["loss_rel_err"].values()), rep
-    assert rep["grad_min_cosine"] > ref["grad_min_cosine"] - 0.01 and rep["grad_min_cosine"] > 0.95, rep
-    assert rep["grad_median_rel_err"] < 1.5 * ref["grad_median_rel_err"] + 1e-3, rep
+    assert rep["grad_min_cosine"] > 0.99 > ref["grad_min_cosine"], rep
+    assert rep["grad_median_rel_err"] < ref["grad_median_rel_err"] + 1e-3, rep
