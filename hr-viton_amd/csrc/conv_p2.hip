@@ -528,12 +528,9 @@ extern "C" int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32
   // beats the generic tiles clearly; round 5 took the threshold to 0.75 tiles per CU (the generator's 128 x 96 level at 4 images: 192
   // tiles) on a same-box alternating A/B of the whole iteration -- 72.28 -> 71.96 ms, three rounds, every pair in favour
   // (profiles/r05_ab_p2_threshold.txt).  HRV_CONV_P2_MIN_TILES_X4: the threshold in quarter-tiles per CU
-  static int q4 = -1;
-  if (q4 < 0) {
-    const char* e = hrv::env("HRV_CONV_P2_MIN_TILES_X4");
-    q4 = e ? atoi(e) : 3;
-    if (q4 < 1) q4 = 3;
-  }
+  const char* e = hrv::env("HRV_CONV_P2_MIN_TILES_X4");      // (cached by hrv::env: no getenv here after the first call)
+  int q4 = e ? atoi(e) : 3;
+  if (q4 < 1) q4 = 3;
   return 4 * tiles >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
 
