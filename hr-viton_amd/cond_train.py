@@ -15,6 +15,7 @@ running_mean / running_var / num_batches_tracked are updated in place like nn.Ba
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, List, Optional, Sequence, Tuple
 
 import torch
@@ -100,10 +101,18 @@ def conv(tape: Tape, tc: TConv, srcs: Sequence[Var], act: int = ACT_NONE) -> Var
         if act != ACT_NONE:
             T.act_bwd_(d, out.a, act, 0.2)
         need_dx = any(v.req for v in srcs)
-        dx = tc.backward(d, acts, tape.grads, need_dx=need_dx)
+        # a source that already holds a gradient (a ResBlock's residual: bn2's backward delivered d(out) to it before conv_1's data
+        # gradient exists, networks.py:196-198): the data gradient adds it in its epilogue (the engine's residual slot) instead of a
+        # separate accumulation pass over the tensor (78 add_slice launches, 21.6 ms per configs[2] iteration before)
+        g0 = srcs[0].g if len(srcs) == 1 else None
+        fuse = (g0 is not None and srcs[0].req and tc.stride == 1 and not g0.bf16 and not d.bf16 and g0.coff == 0 and
+                g0.C == srcs[0].a.C and g0.cstride == g0.Cp and os.environ.get("HRV_TAPE_FUSE_ACC", "1") != "0")
+        dx = tc.backward(d, acts, tape.grads, need_dx=need_dx, add=g0 if fuse else None)
         if dx is None:
             return
-        if len(srcs) == 1:
+        if fuse:
+            srcs[0].g = dx                      # = conv^T(d) + the gradient that was there
+        elif len(srcs) == 1:
             srcs[0].add_grad(dx, owned=True)
         else:
             c0 = 0
