@@ -993,3 +993,36 @@ def test_fused_adam_keeps_a_step_count_per_parameter_like_torch():
             assert _rel(q.detach(), p.detach()) < 2e-6, (it, i)
     sd = ho.state_dict()["state"]
     assert [int(sd[i]["step"]) for i in range(4)] == [sum(m[i] for m in present) for i in range(4)] == [4, 4, 4, 3]
+
+
+def test_wgrad_tr_kernel_below_its_default_size(monkeypatch):
+    """HRV_WGRAD_TR_MIN_PIX lowers the smallest N*H*W conv_wgrad_tr_kernel takes (default 32768): the generator's 64x48 level
+    (2 x 64 x 48 = 6144 pixels here, a 48-pixel row inside the 64-pixel row tile) against torch's conv2d_weight and against the
+    register-transposing kernel that serves the level by default."""
+    ops, T = _mods()
+    cout, N, H, W, cin, k, pad = 160, 2, 64, 48, 128, 3, 1
+    g = torch.Generator().manual_seed(12)
+    rb = lambda t: t.to(torch.bfloat16).to(torch.float32)  # noqa: E731
+    x = rb(torch.randn(N, cin, H, W, generator=g))
+    dy = rb(torch.randn(N, cout, H, W, generator=g) * (torch.rand(N, cout, H, W, generator=g) > 0.3))
+    res = {}
+    T.MMA_BF16[0] = True
+    try:
+        for minpix in ("4096", "32768"):
+            monkeypatch.setenv("HRV_WGRAD_TR_MIN_PIX", minpix)
+            from hr_viton_amd import _lib as _hl; _hl.reload_env()
+            dw = torch.zeros((cout, cin, k, k), device="cuda")
+            db = torch.zeros(cout, device="cuda")
+            ops.profile_begin()
+            T.conv_wgrad(ops.to_nhwc(dy.cuda(), bf16=True), ops.to_nhwc(x.cuda(), bf16=True), 0, 0, cin, k, k, 1, pad, dw, name="lowres", dbias=db)
+            ops.profile_end()
+            torch.cuda.synchronize()
+            res[minpix] = (dw.cpu(), db.cpu())
+    finally:
+        T.MMA_BF16[0] = False
+    ref = torch.nn.grad.conv2d_weight(x, (cout, cin, k, k), dy, stride=1, padding=pad)
+    scale = ref.abs().max().item()
+    for key in res:
+        assert (res[key][0] - ref).abs().max().item() <= 3e-5 * scale + 1e-5, key
+        assert (res[key][1] - dy.sum((0, 2, 3))).abs().max().item() <= 1e-4 * dy.abs().sum((0, 2, 3)).max().item(), key
+    assert not torch.equal(res["4096"][0], res["32768"][0]), "the two settings ran the same kernel (summation orders would differ)"
