@@ -810,7 +810,12 @@ extern "C" int hrv_spade_fused_supported(int32_t C, int32_t hid, int32_t label_n
   GfPlan pl;
   if (hid != 128 || label_nc < 1 || label_nc > 8 || !gf_plan(C, pl)) return 0;
   const int64_t tiles = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16);
-  return tiles >= 2 * (int64_t)persistent_cus() ? 1 : 0;      // two blocks per CU: fewer tiles leave half the slots empty
+  // two blocks per CU: fewer tiles leave half the slots empty.  HRV_SPADE_FUSED_MIN_TILES_X4: the threshold in quarter-tiles per CU
+  // (default 8 = two tiles per CU; A/B at 3 -- the 128 x 96 level at 4 images -- in profiles/r05_ab_fused_threshold.txt)
+  const char* e = hrv::env("HRV_SPADE_FUSED_MIN_TILES_X4");
+  int q4 = e ? atoi(e) : 8;
+  if (q4 < 1) q4 = 8;
+  return 4 * tiles >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
 
 extern "C" int hrv_spade_fused_pack_dev(const float* w_shared, const float* b_shared, int32_t label_nc, const float* w_gamma,

@@ -366,10 +366,12 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
   if ((dy_cs | dy_co | x_cs | x_co | x_C) & 7) return 0;                         // 16-byte DMA granules (Cout itself may be
                                                                                   // anything: rows >= Cout are never written)
   const long long P = (long long)N * H * W;
-  // low-resolution levels: weight-bound, old kernel.  HRV_WGRAD_TR_MIN_PIX (default 32768): the smallest N*H*W this kernel takes
+  // low-resolution levels: weight-bound, old kernel.  HRV_WGRAD_TR_MIN_PIX: the smallest N*H*W this kernel takes -- 8192 since round 5
+  // (the 64 x 48 level at 4 images: three same-box pairs of the whole iteration, each 0.16-0.27 ms in favour,
+  // profiles/r05_ab_wgrad_tr_min.txt); 32768 before
   const char* emin = hrv::env("HRV_WGRAD_TR_MIN_PIX");
-  const long long pmin = emin ? atoll(emin) : 32768;
-  if (P < (pmin > 0 ? pmin : 32768) || W < 32) return 0;
+  const long long pmin = emin ? atoll(emin) : 8192;
+  if (P < (pmin > 0 ? pmin : 8192) || W < 32) return 0;
   const int gpt = (x_C + 31) / 32;
   const int taps = KH * KW;
   WgradTrParams p;

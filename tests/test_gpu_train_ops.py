@@ -1008,7 +1008,7 @@ def test_wgrad_tr_kernel_below_its_default_size(monkeypatch):
     res = {}
     T.MMA_BF16[0] = True
     try:
-        for minpix in ("4096", "32768"):
+        for minpix in ("4096", "32768"):      # (the default is 8192: this 6144-pixel case sits below it)
             monkeypatch.setenv("HRV_WGRAD_TR_MIN_PIX", minpix)
             from hr_viton_amd import _lib as _hl; _hl.reload_env()
             dw = torch.zeros((cout, cin, k, k), device="cuda")
