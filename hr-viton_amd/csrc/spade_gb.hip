@@ -773,7 +773,11 @@ extern "C" int hrv_spade_gb_supported(int32_t mode, int32_t C, int32_t Cp, int32
   GbPlan pl;
   if (!gb_plan(mode, C, Cp, hid, pl)) return 0;
   const int64_t tiles = (int64_t)N * ((H + 15) / 16) * ((W + 15) / 16);
-  return tiles >= 256 ? 1 : 0;      // fewer tiles than CUs: the generic tiles (more, smaller blocks; split-K) fill the chip better
+  // fewer tiles than CUs: the generic tiles (more, smaller blocks; split-K) fill the chip better.  HRV_SPADE_GB_MIN_TILES: the threshold
+  const char* e = hrv::env("HRV_SPADE_GB_MIN_TILES");
+  int tmin = e ? atoi(e) : 256;
+  if (tmin < 1) tmin = 256;
+  return tiles >= tmin ? 1 : 0;
 }
 
 extern "C" int hrv_spade_gb_pack_dev(int32_t mode, const float* w_gamma, const float* w_beta, int32_t C, int32_t Cp, int32_t hid,
