@@ -185,4 +185,7 @@ def test_committed_final_detail_holds_parity_within_the_stated_tolerances():
     assert qp["seg_max_rel_err"] < 1e-3 and qp["argmax_mismatch_pixels"] <= 2e-5 * qp["pixels"]
     assert all(m <= 1024 for m in qp["mismatch_top2_margin_ulps_of_logit"])
     # ... and the compact line carries the same worst numbers
-    assert abs(j["parity"]["min_cosine"] - min(db["grad_min_cosine"], b["grad_min_cosine"], 1.0)) < 2e-3 or j["parity"]["min_cosine"] <= b["grad_min_cosine"]
+    # (the engine's worst cosine: the oracle's own bf16-operand evaluation, a yardstick kept in the detail file, is not part of it)
+    assert abs(j["parity"]["min_cosine"] - min(db["grad_min_cosine"], b["grad_min_cosine"], 1.0)) < 2e-3
+    # the compact line IS bench.compact_line of the detail file
+    assert json.loads(bench.compact_line(d, j.get("detail"))) == j
