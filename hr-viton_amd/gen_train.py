@@ -772,20 +772,24 @@ class _EngineMode:
         return False
 
 
-def _d_f32(layer: int, part: str, own_step: bool = True) -> bool:
+def _d_f32(layer: int, part: str, own_step: bool = True, scale: int = 0) -> bool:
     """Mixed precision: does convolution ``layer`` of a PatchGAN scale keep fp32 operands in ``part`` ("fwd": the forward, "bwd": its
     data and weight gradients)?  Default: the FORWARD of layer 1 (model1: 64 -> 128, 4x4 stride 2, the first spectral-normalised
-    layer, reading LeakyReLU(model0) and feeding the first InstanceNorm) in the discriminator's OWN step.  Measured
+    layer, reading LeakyReLU(model0) and feeding the first InstanceNorm) of ``discriminator_1`` (the half-resolution scale) in the
+    discriminator's OWN step.  Measured
     (tools/d_f32_layers.py, profiles/r05_d_f32_layers.txt: the D half of the iteration at 2 x 1024x768 against torch autograd over
     the fp32 oracle): every convolution on bf16 operands gives a D-gradient cosine of 0.980 (the oracle's own bf16-operand evaluation:
     0.983); model1's forward on fp32 operands 0.992; model0 makes no difference (0.981), model1's gradients none (0.980), model1 +
-    model2 forwards 0.994, the whole PatchGAN in fp32 0.997 (the rest is the bf16 generator's fake image).  Cost of the default:
-    ~0.9 ms of the 73 ms iteration (both scales; 1.8 ms if the generator step's pass through D took it too -- its gradient cosine
-    is 0.998 without).  HRV_D_F32_MASK=<bitmask of layer indices> (or HRV_D_F32_LAYERS=<k>: the first k layers),
-    HRV_D_F32_PARTS=all|fwd|bwd, HRV_D_F32_SCOPE=dstep|always; HRV_D_F32_MASK=0: every convolution in bf16 (what amp O1 does,
-    train_generator.py:186-190)."""
+    model2 forwards 0.994, the whole PatchGAN in fp32 0.997 (the rest is the bf16 generator's fake image); and only the half-resolution
+    scale matters: model1's forward of discriminator_1 alone 0.992, of discriminator_0 alone 0.980 (a quarter of the pixels average
+    the rounding less).  Cost of the default: 0.27 ms of the 72 ms iteration (both scales: 1.2 ms; both passes through D: 1.8 ms --
+    the generator step's gradient cosine is 0.998 without).  HRV_D_F32_MASK=<bitmask of layer indices> (or HRV_D_F32_LAYERS=<k>: the
+    first k layers), HRV_D_F32_PARTS=all|fwd|bwd, HRV_D_F32_SCOPE=dstep|always, HRV_D_F32_SCALES=<bitmask of discriminator_k>;
+    HRV_D_F32_MASK=0: every convolution in bf16 (what amp O1 does, train_generator.py:186-190)."""
     mask = int(os.environ.get("HRV_D_F32_MASK", "2") or 0) | ((1 << int(os.environ.get("HRV_D_F32_LAYERS", "0") or 0)) - 1)
     if not (mask >> layer) & 1:
+        return False
+    if not (int(os.environ.get("HRV_D_F32_SCALES", "2") or 0) >> scale) & 1:      # bit k = discriminator_k; default: the half-resolution scale
         return False
     if not own_step and os.environ.get("HRV_D_F32_SCOPE", "dstep") != "always":
         return False
@@ -855,9 +859,10 @@ class DiscTrainPlan:
             self.refresh_s2d()
             T.prepare_convs(self, [conv for _, conv in self.layers], power_iteration)
         own = getattr(self, "own_step", True)      # (False: the generator step's pass through D -- its parameter gradients are discarded)
+        sc = getattr(self, "scale_index", 0)
         for li, (kind, conv) in enumerate(self.layers):
             if kind in ("in", "in_drop"):
-                with _EngineMode(_d_f32(li, "fwd", own)):
+                with _EngineMode(_d_f32(li, "fwd", own, sc)):
                     c = conv.forward([(a, 0)])
                 mean, rstd = ops.instnorm_stats(c)
                 f = ops.instnorm_apply(c, mean, rstd, ACT_LRELU, 0.2)
@@ -874,7 +879,7 @@ class DiscTrainPlan:
                     entry["mask"] = m
                 ctx.append(entry)
             else:
-                with _EngineMode(_d_f32(li, "fwd", own)):
+                with _EngineMode(_d_f32(li, "fwd", own, sc)):
                     f = conv.forward([(a, 0)], act=ACT_LRELU if kind == "lrelu" else ACT_NONE)
                 ctx.append(dict(src=a, f=f))
             feats.append(f)
@@ -913,7 +918,7 @@ class DiscTrainPlan:
             # the feature-matching gradient of this layer's INPUT feature rides along with the data gradient
             tap = dfeats[i - 1] if i > 0 else None
             tap_in_dnext = tap is not None and tap.t.dtype == torch.float32 and tap.t.shape[:3] == c["src"].t.shape[:3]
-            with _EngineMode(_d_f32(i, "bwd", need_w)):
+            with _EngineMode(_d_f32(i, "bwd", need_w, getattr(self, "scale_index", 0))):
                 d_next = conv.backward(d_c, [(c["src"], 0)], grads, need_dx=(i > 0 or need_dx), need_w=need_w,
                                        add=tap if tap_in_dnext else None)
         return d_next
@@ -935,7 +940,7 @@ class MultiscaleDTrainPlan:
         own = not getattr(self.msd, "_hrv_discard_param_grads", False)
         for k, p in enumerate(self.plans):
             inputs.append(a)
-            p.own_step = own
+            p.own_step, p.scale_index = own, k
             feats, c = p.forward(a, power_iteration, prepared=True)
             feats_all.append(feats)
             ctxs.append(c)
