@@ -495,7 +495,8 @@ def _worst(d, out=None, path=""):
         for k, v in d.items():
             if "rounded_oracle_vs" in str(k) or "oracle_vs_nudged" in str(k):
                 continue        # (the oracle's OWN bf16-operand / nudged re-evaluation: a yardstick in the detail file, not an engine error)
-            _worst(v, out, f"{path}.{k}" if path else str(k))
+            ks = str(k).lower() if isinstance(k, bool) else str(k)      # (engine keys False / True: as json.dump writes them)
+            _worst(v, out, f"{path}.{ks}" if path else ks)
     elif isinstance(d, bool):
         if "bit_identical" in path:
             out[path] = d
