@@ -253,6 +253,8 @@ SYMBOLS = {
                                                    _i32, _i32, _i32, _vp]),
     "hrv_resize_nearest_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_resize_nearest_nchw_bwd_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_resize_nearest_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _i32, _vp]),
+    "hrv_resize_nearest_bwd_nhwc_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "hrv_flow_warp_bwd_nhwc_f32": (C.c_int, [C.POINTER(hrv_flow_warp_bwd_t), _vp]),
     "hrv_grid_sample_nchw_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "hrv_grid_sample_nchw_bwd_f32": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _vp]),

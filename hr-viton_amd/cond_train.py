@@ -156,10 +156,12 @@ def bn_act(tape: Tape, bn: nn.BatchNorm2d, x: Var, act: int, residual: Optional[
     return out
 
 
-def up2(tape: Tape, x: Var, addend: Optional[Var] = None) -> Var:
-    """F.interpolate(x, scale_factor=2, 'bilinear') (+ addend) -- networks.py:130-131,181."""
+def up2(tape: Tape, x: Var, addend: Optional[Var] = None, mode: str = "bilinear") -> Var:
+    """F.interpolate(x, scale_factor=2, mode) (+ addend) -- networks.py:130-131,181."""
     H, W = x.a.H, x.a.W
-    out = Var(ops.resize_bilinear(x.a, 2 * H, 2 * W, 0.5, 0.5, addend=None if addend is None else addend.a))
+    near = mode == "nearest"
+    ad = None if addend is None else addend.a
+    out = Var(ops.resize_nearest(x.a, 2 * H, 2 * W, addend=ad) if near else ops.resize_bilinear(x.a, 2 * H, 2 * W, 0.5, 0.5, addend=ad))
 
     def bwd():
         d = out.g
@@ -167,7 +169,9 @@ def up2(tape: Tape, x: Var, addend: Optional[Var] = None) -> Var:
         if d is None:
             return
         if x.req:
-            if x.g is None:
+            if near:
+                x.g = T.resize_nearest_bwd(d, H, W) if x.g is None else T.resize_nearest_bwd(d, H, W, dx=x.g, accumulate=True)
+            elif x.g is None:
                 x.g = T.resize_bilinear_bwd(d, H, W, 0.5, 0.5)
             else:
                 T.resize_bilinear_bwd(d, H, W, 0.5, 0.5, dx=x.g, accumulate=True)
@@ -179,11 +183,17 @@ def up2(tape: Tape, x: Var, addend: Optional[Var] = None) -> Var:
 
 
 def warp(tape: Tape, src: Var, flow_prev: FlowVar, Ho: int, Wo: int, norm_x: float, norm_y: float,
-         want_flow_up: bool = True) -> Tuple[Var, FlowVar]:
-    """up2(flow) -> normalise -> + base grid -> grid_sample(src) in one kernel (networks.py:133-135)."""
+         want_flow_up: bool = True, mode: str = "bilinear") -> Tuple[Var, FlowVar]:
+    """up2(flow) -> normalise -> + base grid -> grid_sample(src) in one kernel (networks.py:133-135).  ``mode`` 'nearest'
+    (forward(upsample='nearest')): the flow is up-sampled by selection first and the kernel reads it at ratio 1."""
     fh, fw = flow_prev.t.shape[1], flow_prev.t.shape[2]
     rh, rw = fh / Ho, fw / Wo
-    warped_a, fup_t = ops.flow_warp(src.a, flow_prev.t, Ho, Wo, rh, rw, norm_x, norm_y, want_flow_up=True)
+    near = mode == "nearest"
+    if near:
+        warped_a, fup_t = ops.flow_warp(src.a, ops.resize_nearest_dense(flow_prev.t, Ho, Wo), Ho, Wo, 1.0, 1.0, norm_x, norm_y,
+                                        want_flow_up=True)
+    else:
+        warped_a, fup_t = ops.flow_warp(src.a, flow_prev.t, Ho, Wo, rh, rw, norm_x, norm_y, want_flow_up=True)
     warped, fup = Var(warped_a), FlowVar(fup_t)
 
     def bwd():
@@ -199,7 +209,8 @@ def warp(tape: Tape, src: Var, flow_prev: FlowVar, Ho: int, Wo: int, norm_x: flo
             else:
                 T.flow_warp_bwd(src.a, fup.t, norm_x, norm_y, d, dsrc, dflow, True)
         if dflow is not None:
-            flow_prev.add_grad(T.resize_bilinear_bwd_dense(dflow, fh, fw, rh, rw), owned=True)
+            flow_prev.add_grad(T.resize_nearest_bwd_dense(dflow, fh, fw) if near else T.resize_bilinear_bwd_dense(dflow, fh, fw, rh, rw),
+                               owned=True)
 
     tape.record(bwd)
     return warped, fup
@@ -317,8 +328,9 @@ class CondTrainPlan:
         self.flow = [FlowConv(m, f"flow_conv.{i}") for i, m in enumerate(net.flow_conv)]
         self.bott = [TConv(m[0], 1, 1, f"bottleneck.{i}") for i, m in enumerate(net.bottleneck)]
 
-    def forward(self, input1: torch.Tensor, input2: torch.Tensor):
+    def forward(self, input1: torch.Tensor, input2: torch.Tensor, upsample: str = "bilinear"):
         tape = Tape()
+        um = upsample
         N, _, H, W = input1.shape
         x1, x2 = Var(ops.to_nhwc(input1), req=False), Var(ops.to_nhwc(input2), req=False)
         E1: List[Var] = []
@@ -336,17 +348,17 @@ class CondTrainPlan:
                 flows.append(self.flow[0].forward(tape, [T1, T2], None))
                 x = self.seg[0](tape, [self.mid(tape, [T2])])
             else:
-                T1 = up2(tape, T1, addend=conv(tape, self.conv1[4 - i], [e1]))      # networks.py:130
-                T2 = up2(tape, T2, addend=conv(tape, self.conv2[4 - i], [e2]))      # networks.py:131
-                warped, fup = warp(tape, T1, flows[-1], iH, iW, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
+                T1 = up2(tape, T1, addend=conv(tape, self.conv1[4 - i], [e1]), mode=um)      # networks.py:130
+                T2 = up2(tape, T2, addend=conv(tape, self.conv2[4 - i], [e2]), mode=um)      # networks.py:131
+                warped, fup = warp(tape, T1, flows[-1], iH, iW, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0, mode=um)
                 b = conv(tape, self.bott[i - 1], [x], act=ACT_RELU)
                 flows.append(self.flow[i].forward(tape, [warped, b], fup))          # networks.py:137
                 if not self.encoder_warp:
                     x = self.seg[i](tape, [x, e2, warped])                          # networks.py:141
                 else:                                                               # networks.py:143-144
-                    warped_e1, _ = warp(tape, e1, flows[-2], iH, iW, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
+                    warped_e1, _ = warp(tape, e1, flows[-2], iH, iW, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0, mode=um)
                     x = self.seg[i](tape, [x, e2, warped_e1])
-        warped_in, _ = warp(tape, x1, flows[-1], H, W, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0)
+        warped_in, _ = warp(tape, x1, flows[-1], H, W, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0, mode=um)
         seg = self.out(tape, [x, x2, warped_in])
         if self.out_conv is not None:
             seg = conv(tape, self.out_conv, [seg])
@@ -355,8 +367,8 @@ class CondTrainPlan:
 
 class _TocgFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, plan, input1, input2, *params):
-        tape, flows, seg, warped = plan.forward(input1, input2)
+    def forward(ctx, plan, input1, input2, upsample, *params):
+        tape, flows, seg, warped = plan.forward(input1, input2, upsample)
         ctx.tape, ctx.flows, ctx.seg, ctx.warped, ctx.params = tape, flows, seg, warped, params
         ctx.set_materialize_grads(False)       # an unused output arrives as None (handled below), not as a zero tensor
         return tuple(f.t for f in flows) + (ops.to_nchw(seg.a), ops.to_nchw(warped.a))
@@ -375,10 +387,10 @@ class _TocgFn(torch.autograd.Function):
         grads = tape.backward()
         T.wgrad_join()
         ctx.tape = ctx.flows = ctx.seg = ctx.warped = None
-        return (None, None, None) + tuple(grads.get(p) for p in ctx.params)
+        return (None, None, None, None) + tuple(grads.get(p) for p in ctx.params)
 
 
-def condition_train_forward(net: nn.Module, input1: torch.Tensor, input2: torch.Tensor):
+def condition_train_forward(net: nn.Module, input1: torch.Tensor, input2: torch.Tensor, upsample: str = "bilinear"):
     """ConditionGenerator.forward in training mode: (flow_list, x, warped_c, warped_cm)."""
     ops.require_cuda(input1, "ConditionGenerator.forward(input1)")
     ops.require_cuda(input2, "ConditionGenerator.forward(input2)")
@@ -389,10 +401,10 @@ def condition_train_forward(net: nn.Module, input1: torch.Tensor, input2: torch.
     if plan is None:
         plan = net._train_plan = CondTrainPlan(net)
     if not torch.is_grad_enabled():
-        _, flows, seg, warped = plan.forward(input1, input2)
+        _, flows, seg, warped = plan.forward(input1, input2, upsample)
         outs = tuple(f.t for f in flows) + (ops.to_nchw(seg.a), ops.to_nchw(warped.a))
     else:
-        outs = _TocgFn.apply(plan, input1, input2, *list(net.parameters()))
+        outs = _TocgFn.apply(plan, input1, input2, upsample, *list(net.parameters()))
     flow_list, x, w = list(outs[:5]), outs[5], outs[6]
     c = net.input1_nc
     return flow_list, x, w[:, :c - 1], w[:, c - 1:]

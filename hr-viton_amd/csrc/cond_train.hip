@@ -817,6 +817,72 @@ __global__ void resize_nearest_planes_bwd_kernel(const float* __restrict__ dout,
   }
 }
 
+// the same selection over NHWC activations (any C, channel slices) with an optional addend: ConditionGenerator.forward(upsample='nearest'),
+// networks.py:130-133,150 -- T = nearest_x2(T) + conv1x1(E), and the x2 flow upsample in front of the warp
+__global__ void resize_nearest_nhwc_kernel(const float* __restrict__ in, size_t total, int H, int W, int C, int ics, int ico, int Ho, int Wo,
+                                           float sh, float sw, const float* __restrict__ add, int acs, int aco, float* __restrict__ out,
+                                           int ocs, int oco) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int x = (int)(t % Wo); t /= Wo;
+    const int y = (int)(t % Ho);
+    const size_t n = t / Ho;
+    const size_t op = (n * Ho + y) * Wo + x;
+    float v = in[((n * H + nearest_src(y, sh, H)) * W + nearest_src(x, sw, W)) * ics + ico + c];
+    if (add) v += add[op * acs + aco + c];
+    out[op * ocs + oco + c] = v;
+  }
+}
+
+__global__ void resize_nearest_nhwc_bwd_kernel(const float* __restrict__ dout, size_t total, int H, int W, int C, int dcs, int dco, int Ho,
+                                               int Wo, float sh, float sw, float* __restrict__ dx, int xcs, int xco, int accumulate) {
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C);
+    size_t t = i / C;
+    const int sx = (int)(t % W); t /= W;
+    const int sy = (int)(t % H);
+    const size_t n = t / H;
+    int y0 = (int)floorf((float)sy / sh) - 1, y1 = (int)floorf((float)(sy + 1) / sh) + 1;
+    int x0 = (int)floorf((float)sx / sw) - 1, x1 = (int)floorf((float)(sx + 1) / sw) + 1;
+    if (sy == H - 1) y1 = Ho - 1;
+    if (sx == W - 1) x1 = Wo - 1;
+    y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0;
+    y1 = y1 > Ho - 1 ? Ho - 1 : y1; x1 = x1 > Wo - 1 ? Wo - 1 : x1;
+    float acc = 0.f;
+    for (int y = y0; y <= y1; ++y) {
+      if (nearest_src(y, sh, H) != sy) continue;
+      for (int x = x0; x <= x1; ++x)
+        if (nearest_src(x, sw, W) == sx) acc += dout[((n * Ho + y) * Wo + x) * dcs + dco + c];
+    }
+    float* o = dx + ((n * H + sy) * W + sx) * xcs + xco + c;
+    *o = accumulate ? *o + acc : acc;
+  }
+}
+
+extern "C" int hrv_resize_nearest_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                                           int32_t Ho, int32_t Wo, const float* addend, int32_t add_cstride, int32_t add_coff, float* out,
+                                           int32_t out_cstride, int32_t out_coff, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "resize_nearest_nhwc: bad args");
+  HRV_REQUIRE(in_cstride >= in_coff + C && out_cstride >= out_coff + C && (!addend || add_cstride >= add_coff + C),
+              "resize_nearest_nhwc: channel slices out of range");
+  const size_t total = (size_t)N * Ho * Wo * C;
+  hipLaunchKernelGGL(resize_nearest_nhwc_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, total, H, W, C, in_cstride,
+                     in_coff, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo, addend, add_cstride, add_coff, out, out_cstride, out_coff);
+  return check_launch("resize_nearest_nhwc_kernel");
+}
+
+extern "C" int hrv_resize_nearest_bwd_nhwc_f32(const float* dout, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t d_cstride,
+                                               int32_t d_coff, float* dx, int32_t H, int32_t W, int32_t dx_cstride, int32_t dx_coff,
+                                               int32_t accumulate, hrv_stream_t stream) {
+  HRV_REQUIRE(dout && dx && N > 0 && H > 0 && W > 0 && C > 0 && Ho > 0 && Wo > 0, "resize_nearest_bwd_nhwc: bad args");
+  HRV_REQUIRE(d_cstride >= d_coff + C && dx_cstride >= dx_coff + C, "resize_nearest_bwd_nhwc: channel slices out of range");
+  const size_t total = (size_t)N * H * W * C;
+  hipLaunchKernelGGL(resize_nearest_nhwc_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, dout, total, H, W, C, d_cstride,
+                     d_coff, Ho, Wo, (float)H / (float)Ho, (float)W / (float)Wo, dx, dx_cstride, dx_coff, accumulate);
+  return check_launch("resize_nearest_nhwc_bwd_kernel");
+}
+
 extern "C" int hrv_resize_nearest_nchw_f32(const float* in, int32_t planes, int32_t H, int32_t W, int32_t Ho, int32_t Wo, float* out,
                                            hrv_stream_t stream) {
   HRV_REQUIRE(in && out && planes > 0 && H > 0 && W > 0 && Ho > 0 && Wo > 0, "resize_nearest: bad args");

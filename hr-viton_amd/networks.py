@@ -212,19 +212,19 @@ class ConditionGenerator(nn.Module):
             input1, input2 = args
         else:
             raise TypeError("forward(opt, input1, input2) or forward(input1, input2)")
-        if upsample != "bilinear":
-            raise NotImplementedError("HIP path implements upsample='bilinear' (the reference default)")
+        if upsample not in ("bilinear", "nearest"):
+            raise ValueError(f"upsample={upsample!r}: the reference's scripts know 'bilinear' | 'nearest' (test_generator.py:63)")
         if self.training:
             # batch-statistics BatchNorm + tape-recorded backward (train_condition.py:116,158)
             from .cond_train import condition_train_forward
             if not next(self.parameters()).is_cuda:
                 raise RuntimeError("hr-viton_amd ConditionGenerator: move the module to the GPU (.cuda()) first; "
                                    "there is no CPU path")
-            return condition_train_forward(self, input1, input2)
-        return self._forward_eval(input1, input2)
+            return condition_train_forward(self, input1, input2, upsample)
+        return self._forward_eval(input1, input2, upsample)
 
     @torch.no_grad()
-    def _forward_eval(self, input1: torch.Tensor, input2: torch.Tensor):
+    def _forward_eval(self, input1: torch.Tensor, input2: torch.Tensor, upsample: str = "bilinear"):
         ops.require_cuda(input1, "ConditionGenerator.forward(input1)")
         ops.require_cuda(input2, "ConditionGenerator.forward(input2)")
         N, _, H, W = input1.shape
@@ -252,12 +252,19 @@ class ConditionGenerator(nn.Module):
             else:
                 # T = up2(T) + conv1x1(E)  (networks.py:130-131): 1x1 conv, then resize with fused addend
                 a1 = P["conv1"][4 - i]([e1])
-                T1 = ops.resize_bilinear(T1, iH, iW, 0.5, 0.5, addend=a1)
                 a2 = P["conv2"][4 - i]([e2])
-                T2 = ops.resize_bilinear(T2, iH, iW, 0.5, 0.5, addend=a2)
+                near = upsample == "nearest"
+                if not near:
+                    T1 = ops.resize_bilinear(T1, iH, iW, 0.5, 0.5, addend=a1)
+                    T2 = ops.resize_bilinear(T2, iH, iW, 0.5, 0.5, addend=a2)
+                    flow_prev, fr = flow_list[-1], 0.5
+                else:       # upsample='nearest' (networks.py:130-133): the flow is up-sampled by selection first, the warp kernel then
+                    #         reads it at ratio 1 (its bilinear taps collapse to the pixel itself)
+                    T1 = ops.resize_nearest(T1, iH, iW, addend=a1)
+                    T2 = ops.resize_nearest(T2, iH, iW, addend=a2)
+                    flow_prev, fr = ops.resize_nearest_dense(flow_list[-1], iH, iW), 1.0
                 # flow upsample + flow_norm + make_grid + grid_sample in one kernel (networks.py:133-135)
-                flow_prev = flow_list[-1]
-                warped, fup = ops.flow_warp(T1, flow_prev, iH, iW, 0.5, 0.5,
+                warped, fup = ops.flow_warp(T1, flow_prev, iH, iW, fr, fr,
                                             (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0)
                 b = P["bott"][i - 1]([x])
                 fl = Act(torch.empty((N, iH, iW, 2), dtype=torch.float32, device=input1.device), 2)
@@ -267,11 +274,15 @@ class ConditionGenerator(nn.Module):
                 if self.warp_feature == "T1":
                     x = P["seg"][i]([x, e2, warped])
                 else:       # the decoder reads the cloth-encoder feature itself, warped by the same (upsampled previous) flow
-                    warped_e1, _ = ops.flow_warp(e1, flow_prev, iH, iW, 0.5, 0.5, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0,
+                    warped_e1, _ = ops.flow_warp(e1, flow_prev, iH, iW, fr, fr, (iW / 2 - 1.0) / 2.0, (iH / 2 - 1.0) / 2.0,
                                                  want_flow_up=False)
                     x = P["seg"][i]([x, e2, warped_e1])
-        warped_in, _ = ops.flow_warp(x1, flow_list[-1], H, W, 0.5, 0.5, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0,
-                                     want_flow_up=False)
+        if upsample == "nearest":                                                        # networks.py:150
+            warped_in, _ = ops.flow_warp(x1, ops.resize_nearest_dense(flow_list[-1], H, W), H, W, 1.0, 1.0, (W / 2 - 1.0) / 2.0,
+                                         (H / 2 - 1.0) / 2.0, want_flow_up=False)
+        else:
+            warped_in, _ = ops.flow_warp(x1, flow_list[-1], H, W, 0.5, 0.5, (W / 2 - 1.0) / 2.0, (H / 2 - 1.0) / 2.0,
+                                         want_flow_up=False)
         seg = P["out"]([x, x2, warped_in])
         if self.out_layer_opt == "conv":
             seg = P["out_conv"]([seg])

@@ -604,6 +604,28 @@ def resize_bilinear(a: Act, Ho: int, Wo: int, rh: float, rw: float, addend: Opti
     return out
 
 
+def resize_nearest(a: Act, Ho: int, Wo: int, addend: Optional[Act] = None, out: Optional[Act] = None) -> Act:
+    """hrv_resize_nearest_nhwc_f32: out = F.interpolate(a, mode='nearest') (+ addend) -- networks.py:130-131 with upsample='nearest'."""
+    lib = _lib.load()
+    if out is None:
+        out = alloc(a.N, Ho, Wo, a.C, a.t.device)
+    add_ptr, acs, aco = (None, 0, 0) if addend is None else (addend.t.data_ptr(), addend.cstride, addend.coff)
+    with _Timed("resize", "nearest", 0.0, 4.0 * a.N * Ho * Wo * a.Cp * (2 if addend is None else 3)):
+        _lib.check(lib.hrv_resize_nearest_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, Ho, Wo, add_ptr, acs, aco,
+                                                   out.t.data_ptr(), out.cstride, out.coff, _stream()), "hrv_resize_nearest_nhwc_f32")
+    return out
+
+
+def resize_nearest_dense(t: torch.Tensor, Ho: int, Wo: int) -> torch.Tensor:
+    """the same on a dense [N,h,w,C] tensor of any C (the 2-channel flows, networks.py:133,150)"""
+    lib = _lib.load()
+    N, H, W, Cc = t.shape
+    out = torch.empty((N, Ho, Wo, Cc), dtype=torch.float32, device=t.device)
+    _lib.check(lib.hrv_resize_nearest_nhwc_f32(t.data_ptr(), N, H, W, Cc, Cc, 0, Ho, Wo, None, 0, 0, out.data_ptr(), Cc, 0, _stream()),
+               "hrv_resize_nearest_nhwc_f32")
+    return out
+
+
 def flow_warp(src: Act, flow: torch.Tensor, Ho: int, Wo: int, rh: float, rw: float, norm_x: float, norm_y: float,
               out: Optional[Act] = None, want_flow_up: bool = True):
     """hrv_flow_warp_nhwc_f32.  ``flow`` is [N,fh,fw,2] (reference layout).

@@ -1193,6 +1193,29 @@ def resize_bilinear_bwd_dense(dy: torch.Tensor, H: int, W: int, rh: float, rw: f
     return dx
 
 
+def resize_nearest_bwd(dy: Act, H: int, W: int, dx: Optional[Act] = None, accumulate: bool = False) -> Act:
+    """Adjoint of ops.resize_nearest: dx[N,H,W,C] (+)= sum of the output pixels that selected each source pixel."""
+    lib = _lib.load()
+    if dx is None:
+        dx = ops.alloc(dy.N, H, W, dy.C, dy.t.device)
+        accumulate = False
+    with _Timed("resize", "nearest_bwd", 0.0, 4.0 * dy.N * dy.H * dy.W * dy.Cp * 2):
+        _lib.check(lib.hrv_resize_nearest_bwd_nhwc_f32(dy.t.data_ptr(), dy.N, dy.H, dy.W, dy.Cp, dy.cstride, dy.coff, dx.t.data_ptr(), H, W,
+                                                       dx.cstride, dx.coff, 1 if accumulate else 0, _stream()),
+                   "hrv_resize_nearest_bwd_nhwc_f32")
+    return dx
+
+
+def resize_nearest_bwd_dense(dy: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """Same adjoint on a dense [N,Ho,Wo,C] tensor of any C (the 2-channel flows)."""
+    lib = _lib.load()
+    N, Ho, Wo, Cc = dy.shape
+    dx = torch.empty((N, H, W, Cc), dtype=torch.float32, device=dy.device)
+    _lib.check(lib.hrv_resize_nearest_bwd_nhwc_f32(dy.data_ptr(), N, Ho, Wo, Cc, Cc, 0, dx.data_ptr(), H, W, Cc, 0, 0, _stream()),
+               "hrv_resize_nearest_bwd_nhwc_f32")
+    return dx
+
+
 def flow_warp_bwd(src: Act, flow_up: torch.Tensor, norm_x: float, norm_y: float, dout: Act,
                   dsrc: Optional[Act], dflow: Optional[torch.Tensor], dflow_accumulate: bool = False):
     """Adjoint of ops.flow_warp.  ``dsrc`` (an accumulator Act, already initialised) receives the atomic

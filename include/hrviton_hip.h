@@ -635,6 +635,15 @@ int hrv_resize_nearest_nchw_f32(const float* in, int32_t planes, int32_t H, int3
                                 hrv_stream_t stream);
 int hrv_resize_nearest_nchw_bwd_f32(const float* dout, int32_t planes, int32_t Ho, int32_t Wo, int32_t H, int32_t W, float* dx,
                                     hrv_stream_t stream);
+/* The same nearest selection over NHWC activations (any C, channel slices), out = nearest(in) (+ addend), and its adjoint
+ * dx (+)= N^T dout: ConditionGenerator.forward(upsample='nearest') -- networks.py:130-131 (T = up(T) + conv1x1(E)), :133 / :150 (the
+ * flow upsampled by 2 in front of the warp; the warp kernel then reads it at ratio 1). */
+int hrv_resize_nearest_nhwc_f32(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                                int32_t Ho, int32_t Wo, const float* addend, int32_t add_cstride, int32_t add_coff, float* out,
+                                int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+int hrv_resize_nearest_bwd_nhwc_f32(const float* dout, int32_t N, int32_t Ho, int32_t Wo, int32_t C, int32_t d_cstride, int32_t d_coff,
+                                    float* dx, int32_t H, int32_t W, int32_t dx_cstride, int32_t dx_coff, int32_t accumulate,
+                                    hrv_stream_t stream);
 /* Adjoint of hrv_flow_warp_nhwc_f32 (F.grid_sample backward, networks.py:135,152): given the
  * saved un-normalised flow at the output resolution (flow_up) and dout [N,Ho,Wo,C]:
  *   dsrc  [N,H,W,C]   += scatter of the four bilinear taps (fp32 atomics; zero-init or an

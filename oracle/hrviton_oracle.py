@@ -201,12 +201,15 @@ def resblock(sd: SD, p: str, x: Tensor, scale: str) -> Tensor:
 
 
 def tocg_forward(sd: SD, input1: Tensor, input2: Tensor,
-                 warp_feature: str = "T1", out_layer: str = "relu"):
+                 warp_feature: str = "T1", out_layer: str = "relu", upsample: str = "bilinear"):
     """ConditionGenerator.forward -- networks.py:98-159.
 
     Returns (flow_list [5 x [N,h,w,2]], x [N,13,H,W], warped_c, warped_cm).
     """
     assert warp_feature in ("T1", "encoder") and out_layer in ("relu", "conv"), (warp_feature, out_layer)
+    assert upsample in ("bilinear", "nearest"), upsample
+    up2 = (lambda t: resize_bilinear(t, scale_factor=2)) if upsample == "bilinear" else \
+        (lambda t: resize_nearest(t, (2 * t.shape[2], 2 * t.shape[3])))      # F.interpolate(t, scale_factor=2, mode=upsample): :130-133,150
     E1: List[Tensor] = []
     E2: List[Tensor] = []
     for i in range(5):
@@ -225,11 +228,11 @@ def tocg_forward(sd: SD, input1: Tensor, input2: Tensor,
             x = resblock(sd, "conv", T2, "same")
             x = resblock(sd, "SegDecoder.0", x, "up")
         else:
-            T1 = resize_bilinear(T1, scale_factor=2) + _tq(
+            T1 = up2(T1) + _tq(
                 E1[4 - i], sd[f"conv1.{4 - i}.weight"], sd[f"conv1.{4 - i}.bias"])
-            T2 = resize_bilinear(T2, scale_factor=2) + _tq(
+            T2 = up2(T2) + _tq(
                 E2[4 - i], sd[f"conv2.{4 - i}.weight"], sd[f"conv2.{4 - i}.bias"])
-            flow = resize_bilinear(flow_list[i - 1].permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1)
+            flow = up2(flow_list[i - 1].permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
             flow_norm = torch.cat([flow[..., 0:1] / ((iW / 2 - 1.0) / 2.0),
                                    flow[..., 1:2] / ((iH / 2 - 1.0) / 2.0)], 3)
             warped_T1 = grid_sample_bilinear_border(T1, flow_norm + grid)
@@ -244,7 +247,7 @@ def tocg_forward(sd: SD, input1: Tensor, input2: Tensor,
                 x = resblock(sd, f"SegDecoder.{i}", torch.cat([x, E2[4 - i], warped_E1], 1), "up")
     N, _, iH, iW = input1.shape
     grid = make_grid(N, iH, iW)
-    flow = resize_bilinear(flow_list[-1].permute(0, 3, 1, 2), scale_factor=2).permute(0, 2, 3, 1)
+    flow = up2(flow_list[-1].permute(0, 3, 1, 2)).permute(0, 2, 3, 1)
     flow_norm = torch.cat([flow[..., 0:1] / ((iW / 2 - 1.0) / 2.0),
                            flow[..., 1:2] / ((iH / 2 - 1.0) / 2.0)], 3)
     warped_input1 = grid_sample_bilinear_border(input1, flow_norm + grid)

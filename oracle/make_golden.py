@@ -239,10 +239,12 @@ def tocg_variants():
     input2 = torch.cat([torch.zeros(N, 13, H, W).scatter_(1, lab, 1.0), torch.rand(N, 3, H, W, generator=g) * 2 - 1], 1)
     with torch.no_grad():
         flow_list, seg, wc, wcm = tocg(opt, input1, input2)
+        nf, ns, nwc, nwcm = tocg(opt, input1, input2, upsample="nearest")      # networks.py:98,130-133,150: the forward's third mode
     name = "tocg_encoder_conv_ngf8_96x64.pt"
     torch.save({"ngf": NGF, "warp_feature": "encoder", "out_layer": "conv",
                 "state_dict": {k: v.clone() for k, v in tocg.state_dict().items()},
-                "input1": input1, "input2": input2, "flow_list": flow_list, "seg": seg, "warped_c": wc, "warped_cm": wcm},
+                "input1": input1, "input2": input2, "flow_list": flow_list, "seg": seg, "warped_c": wc, "warped_cm": wcm,
+                "nearest": {"flow_list": nf, "seg": ns, "warped_c": nwc, "warped_cm": nwcm}},
                os.path.join(OUT, name))
     print(name, os.path.getsize(os.path.join(OUT, name)) // 1024, "KiB")
 

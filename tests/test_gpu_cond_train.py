@@ -697,3 +697,43 @@ def test_condition_training_iteration_of_the_tocg_variants_matches_oracle(wf, ol
     # every parameter of the variant's extra pieces got a gradient
     if ol == "conv":
         assert "out_layer.1.weight" in grads_g and "out_layer.0.block.0.weight" in grads_g
+
+
+@pytest.mark.parametrize("wf", ["T1", "encoder"])
+def test_condition_generator_training_forward_with_nearest_upsampling_matches_oracle(wf):
+    """ConditionGenerator.forward(opt, input1, input2, upsample='nearest') in training mode (networks.py:98,130-133,150): T1 / T2 and the
+    flows are up-sampled by selection (ops.resize_nearest / its gather-form adjoint; the warp kernel reads the pre-up-sampled flow at
+    ratio 1).  Outputs and every parameter gradient of a loss over all four outputs against torch autograd over the oracle with
+    batch-statistics BatchNorm (the oracle's nearest mode is pinned to the real reference by tests/golden/tocg_encoder_conv_...)."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import networks
+    from oracle.recipes import condstep_build
+    opt, tocg, _D, batch = condstep_build(networks.ConditionGenerator, networks.define_D, warp_feature=wf)
+    input1 = torch.cat([batch["cloth"], batch["cloth_mask"]], 1)
+    input2 = torch.cat([batch["parse_agnostic"], batch["densepose"]], 1)
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running_" not in k) for k, v in tocg.state_dict().items()}
+    g = torch.Generator().manual_seed(3)
+    O.BN_TRAIN["on"], O.BN_TRAIN["stats"] = True, {}
+    try:
+        wf_, ws_, wc_, wm_ = O.tocg_forward(sd, input1, input2, wf, "relu", "nearest")
+    finally:
+        O.BN_TRAIN["on"] = False
+    ws = [torch.randn(t.shape, generator=g) for t in list(wf_) + [ws_, wc_, wm_]]
+    (sum((f * w).sum() for f, w in zip(wf_, ws[:5])) + (ws_ * ws[5]).sum() + (wc_ * ws[6]).sum() + (wm_ * ws[7]).sum()).backward()
+    tocg.cuda().train()
+    gf, gs, gc, gm = tocg(opt, input1.cuda(), input2.cuda(), upsample="nearest")
+    for i, (a, b) in enumerate(zip(gf, wf_)):
+        _close(f"flow{i}", a, b.detach(), 2e-5)
+    _close("seg", gs, ws_.detach(), 2e-5)
+    _close("warped_c", gc, wc_.detach(), 2e-4)
+    (sum((f * w.cuda()).sum() for f, w in zip(gf, ws[:5])) + (gs * ws[5].cuda()).sum() + (gc * ws[6].cuda()).sum() +
+     (gm * ws[7].cuda()).sum()).backward()
+
+    class _W:
+        def __init__(self, g_):
+            self.grad = g_
+    _compare_grads(tocg, {k: _W(v.grad) for k, v in sd.items()}, 3e-2, f"tocg_nearest_{wf} fwd-bwd")
+    names = [n for n, p in tocg.named_parameters() if p.grad is not None and sd[n].grad is not None]
+    a_ = torch.cat([dict(tocg.named_parameters())[n].grad.detach().cpu().flatten() for n in names])
+    b_ = torch.cat([sd[n].grad.flatten() for n in names])
+    assert float(F.cosine_similarity(a_, b_, dim=0)) > 0.9998

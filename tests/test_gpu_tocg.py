@@ -90,6 +90,9 @@ def test_tocg_encoder_conv_variant_golden_reference_vectors():
     outs = m(opt, g["input1"].cuda(), g["input2"].cuda())
     _check(outs, (g["flow_list"], g["seg"], g["warped_c"], g["warped_cm"]))
     assert (outs[1] < 0).any()
+    # forward(opt, input1, input2, upsample='nearest') (networks.py:98,130-133,150): T and the flows up-sampled by selection
+    n = g["nearest"]
+    _check(m(opt, g["input1"].cuda(), g["input2"].cuda(), upsample="nearest"), (n["flow_list"], n["seg"], n["warped_c"], n["warped_cm"]))
 
 
 @pytest.mark.parametrize("wf,ol", [("encoder", "relu"), ("T1", "conv")])

@@ -51,6 +51,15 @@ def test_tocg_encoder_conv_variant_matches_reference():
     _close(wc, g["warped_c"], 1e-4)
     _close(wcm, g["warped_cm"], 1e-4)
     assert g["flow_list"][-1].abs().max() > 0.5 and (g["seg"] < 0).any()      # flows are exercised; logits are not ReLU outputs
+    # forward(..., upsample='nearest') (networks.py:98,130-133,150) on the same weights
+    n = g["nearest"]
+    flow_list, seg, wc, wcm = O.tocg_forward(g["state_dict"], g["input1"], g["input2"], g["warp_feature"], g["out_layer"], "nearest")
+    for a, b in zip(flow_list, n["flow_list"]):
+        _close(a, b)
+    _close(seg, n["seg"])
+    _close(wc, n["warped_c"], 1e-4)
+    _close(wcm, n["warped_cm"], 1e-4)
+    assert (n["seg"] - g["seg"]).abs().max() > 1e-2                          # the mode changes the result
 
 
 def test_spade_generator_matches_reference():
