@@ -719,7 +719,7 @@ def test_condition_generator_training_forward_with_nearest_upsampling_matches_or
     finally:
         O.BN_TRAIN["on"] = False
     def smooth_like(t):      # low-frequency loss weights: a white-noise weight on a warped image turns ONE flipped floor() cell of the
-        if t.dim() == 4 and t.shape[2] >= 16:      # sampler into a visible change of the flow-path gradients (cf. oracle.recipes.condstep_build)
+        if t.dim() == 4 and t.shape[2] >= 16 and t.shape[3] >= 16:      # (NCHW images; the [N,h,w,2] flows keep white noise)
             lo = torch.randn(t.shape[0], t.shape[1], t.shape[2] // 8, t.shape[3] // 8, generator=g)
             return F.interpolate(lo, size=t.shape[2:], mode="bilinear", align_corners=False)
         return torch.randn(t.shape, generator=g)
