@@ -738,9 +738,9 @@ def test_condition_generator_training_forward_with_nearest_upsampling_matches_or
         def __init__(self, g_):
             self.grad = g_
     # forward outputs agree to 2e-5 (above); the gradient is discontinuous in the sampling coordinates (floor() cells of six to ten warps):
-    # a flipped cell moves the small flow-path parameters (measured with white-noise weights: 8.8e-2 on bottleneck.1 in the encoder
-    # variant, <= 2e-2 elsewhere), so each parameter is bounded loosely and the DIRECTION over all parameters tightly
-    _compare_grads(tocg, {k: _W(v.grad) for k, v in sd.items()}, 2e-1, f"tocg_nearest_{wf} fwd-bwd")
+    # measured worst parameter 3.7e-3 (encoder) with these smooth weights -- 8.8e-2 with white-noise weights, where ONE flipped cell
+    # shows -- so 3e-2 per parameter and the DIRECTION over all parameters tightly
+    _compare_grads(tocg, {k: _W(v.grad) for k, v in sd.items()}, 3e-2, f"tocg_nearest_{wf} fwd-bwd")
     names = [n for n, p in tocg.named_parameters() if p.grad is not None and sd[n].grad is not None]
     a_ = torch.cat([dict(tocg.named_parameters())[n].grad.detach().cpu().flatten() for n in names])
     b_ = torch.cat([sd[n].grad.flatten() for n in names])
