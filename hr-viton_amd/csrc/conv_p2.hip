@@ -28,8 +28,27 @@ __device__ __forceinline__ void p2_store16(f32x4 v, rsrc_t r, unsigned voff) {
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, v), r, (int)voff, 0, 0);
 }
+typedef unsigned p2_u32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ p2_u32x2 p2_load8(rsrc_t r, unsigned voff, int soff) { return __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff, soff, 0); }
+__device__ __forceinline__ f32x4 p2_load16(rsrc_t r, unsigned voff, int soff) {
+  return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, soff, 0));
+}
+// v_permlane32_swap: lanes 0..31 of the result pair hold (lo, lo of lane + 32), lanes 32..63 hold (hi of lane - 32, hi)
+__device__ __forceinline__ p2_u32x2 p2_swap32(unsigned lo, unsigned hi) {
+  const auto s = __builtin_amdgcn_permlane32_swap(lo, hi, false, false);
+  p2_u32x2 r;
+  r[0] = s[0]; r[1] = s[1];
+  return r;
+}
+// (by value: __builtin_bit_cast applied to a vector ELEMENT expression reads element 0 whatever the index)
+__device__ __forceinline__ unsigned p2_bits(float f) { return __builtin_bit_cast(unsigned, f); }
 #else
 __device__ inline void p2_store16(f32x4, rsrc_t, unsigned) {}
+typedef unsigned p2_u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline p2_u32x2 p2_load8(rsrc_t, unsigned, int) { return p2_u32x2{0, 0}; }
+__device__ inline f32x4 p2_load16(rsrc_t, unsigned, int) { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ inline p2_u32x2 p2_swap32(unsigned a, unsigned b) { return p2_u32x2{a, b}; }
+__device__ inline unsigned p2_bits(float) { return 0u; }
 #endif
 
 __device__ __forceinline__ f32x4 p2_acc4(const f32x16& a, int g) {
@@ -202,7 +221,9 @@ __device__ __forceinline__ void p2_head(const P2Params& p, const int pass, unsig
     }
 }
 
-template <int NTP>
+// EPI: what the epilogue can be asked for -- 0: bias + activation; 1: + mask; 2: mask and / or residual in any combination (the
+// lean instances keep the registers of the others' operands out of the allocation)
+template <int NTP, int EPI>
 __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsigned char* const smem, const P2Tile T, const int bid,
                                         const bool load_consts, const bool wait_all, const bool first, const bool last, const int nxt_pass,
                                         const P2Tile NT_) {
@@ -243,14 +264,6 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   for (int kw = 0; kw < 3; ++kw) axk[kw] = (unsigned)((lh ^ (((tx + kw) >> 2) & 3)) << 4);
   const unsigned char* const b_lb = ring + lane * 16;
 
-  f32x16 acc[2][NTP];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < NTP; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
   // The head (chunk 0, k-tiles 0 and 1) has landed.  Behind it in this wave's queue sit only the previous pass's epilogue
   // stores (they need not drain) -- unless this pass loaded constants or is the block's first
   if (wait_all || load_consts) __builtin_amdgcn_s_waitcnt(p2_wait(0));
@@ -258,6 +271,16 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   else __builtin_amdgcn_s_waitcnt(p2_wait(NST));
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
+  // the accumulators start at the bias (cbuf: this pass's columns, zeros without a bias; published by the barrier above)
+  f32x16 acc[2][NTP];
+#pragma unroll
+  for (int j = 0; j < NTP; ++j)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 b = *reinterpret_cast<const f32x4*>(cbuf + j * 32 + 8 * g + 4 * lh);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { acc[0][j][4 * g + e] = b[e]; acc[1][j][4 * g + e] = b[e]; }
+    }
   if (p.tlog && tid == 0 && first) p.tlog[(size_t)bid * 8 + 1] = wall_clock64();
 
   // ---- main loop: chunks x 9 taps.  A fragments double-buffered, B fragments refilled in place (see spade_fused.hip)
@@ -349,13 +372,20 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
 #undef P2_ORDER
   if (p.tlog && tid == 0 && last) p.tlog[(size_t)bid * 8 + 2] = wall_clock64();
 
-  // ---- epilogue.  D layout (swapped operands): lane -> pixel l31; regs 4g..4g+3 -> columns 8g + 4 lh + (0..3) of the tile
+  // ---- epilogue.  D layout (swapped operands): lane -> pixel l31; regs 4g..4g+3 -> columns 8g + 4 lh + (0..3) of the tile.
+  // The bias is already in the accumulators.  What is left per element is the activation, the mask and the residual -- each
+  // behind a wave-uniform branch around a whole column tile, nothing per-element that a descriptor flag decides (measured: the
+  // co-resident block's MFMA stream leaves this wave about one VALU issue per MFMA slot, so the epilogue's length is its VALU
+  // count; 400 VALU + an LDS round trip per column tile took 4 us each, tools/p2_timeline.py) -- then rows leave straight from
+  // the registers: the lane pair (l, l + 32) holds columns 8g .. 8g+3 and 8g+4 .. 8g+7 of ONE pixel, v_permlane32_swap hands the
+  // lower lane both halves of an even group and the upper lane both halves of the odd group next to it, and every lane stores 16
+  // contiguous bytes (bf16: 8 columns; fp32: 2 x 4 columns).  No LDS staging, no wait on the stores.
   asm volatile("" ::: "memory");
   __builtin_amdgcn_s_waitcnt(p2_wait(63));
   __builtin_amdgcn_s_barrier();                // every wave is done with the patch buffers and the weight ring
   asm volatile("" ::: "memory");
-  // the next (tile, pass) of this block: its head flies while this epilogue computes and stores
-  if (nxt_pass >= 0) p2_head<NTP>(p, nxt_pass, smem, NT_, wave, lane);
+  unsigned long long tl_e0 = 0, tl_pack = 0;
+  if (p.tlog && tid == 0 && last) tl_e0 = wall_clock64();
   int lane_e = lane;
   asm volatile("" : "+v"(lane_e));
   const int l31e = lane_e & 31, lhe = lane_e >> 5;
@@ -363,121 +393,140 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   const int oes = p.out_f32 ? 4 : 2;
   const rsrc_t o_rsrc = make_rsrc(reinterpret_cast<const char*>(p.out) + (size_t)pt_n * img_px * p.out_cs * oes,
                                   (unsigned)(img_px * p.out_cs * oes));
-  unsigned char* const sb0 = smem + P2_PATCH_OFF + P2_PBUF + wave * 5120;      // (buffer 0 and the ring are being refilled)
-  static_assert(4 * 5120 <= P2_PBUF, "epilogue scratch fits a patch buffer");
-  // this lane's two pixels (mask reads) and the pixels of the scratch rows it stores
+  const bool has_mask = EPI >= 1 && p.mask != nullptr, has_res = EPI == 2 && p.res != nullptr;
+  const int res_es = p.res_f32 ? 4 : 2;
+  const rsrc_t m_rsrc = make_rsrc(has_mask ? reinterpret_cast<const char*>(p.mask) + (size_t)pt_n * img_px * p.mask_cs * 2 : nullptr,
+                                  has_mask ? (unsigned)(img_px * p.mask_cs * 2) : 0u);
+  const rsrc_t r_rsrc = make_rsrc(has_res ? reinterpret_cast<const char*>(p.res) + (size_t)pt_n * img_px * p.res_cs * res_es : nullptr,
+                                  has_res ? (unsigned)(img_px * p.res_cs * res_es) : 0u);
+  // this lane's two pixels
   const int tye = 4 * wave + (l31e >> 4), pxe = pt_x0 + (l31e & 15);
-  int pidx[2];
+  unsigned pix[2];
+  bool pok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int py = pt_y0 + tye + 2 * i;
-    pidx[i] = (py < p.H && pxe < p.W) ? (pt_n * p.H + py) * p.W + pxe : 0;
+    pok[i] = py < p.H && pxe < p.W;
+    pix[i] = (unsigned)(py * p.W + pxe);
   }
-  int pp4[2][2];
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  // mask of column tile j: 4 bf16 per (pixel, group) -- the lane's own columns.  One offset register per pixel (out of the image:
+  // an offset no constant below brings back into range -> zeros), the (j, g) part rides in the instruction's scalar offset;
+  // columns beyond Cout read whatever lies there (at worst zeros past the end of the tensor): those lanes store nothing
+  constexpr unsigned P2_OOB = 0xF0000000u;
+  unsigned moff[2], roff[2];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int i = 0; i < 2; ++i) {
+    moff[i] = pok[i] ? (pix[i] * (unsigned)p.mask_cs + (unsigned)(p.mask_co + tile0 * 32 + 4 * lhe)) * 2u : P2_OOB;
+    roff[i] = pok[i] ? (pix[i] * (unsigned)p.res_cs + (unsigned)(p.res_co + tile0 * 32 + 4 * lhe)) * (unsigned)res_es : P2_OOB;
+  }
+  auto load_mask = [&](const int j, u32x2_t (&mv)[2][4]) {
 #pragma unroll
-    for (int k = 0; k < 2; ++k) {
-      const int r = (lane_e >> 2) + 16 * k;
-      const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
-      pp4[i][k] = (y < p.H && x < p.W) ? y * p.W + x : -1;
-    }
-  const float sl = p.act == HRV_ACT_LRELU ? p.slope : (p.act == HRV_ACT_RELU ? 0.f : 1.f);      // act(v) = max(v, v * sl)
-  const float msl = p.mask_slope;
-  const bool relu = p.act == HRV_ACT_RELU;
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) mv[i][g] = p2_load8(m_rsrc, moff[i], (j * 32 + 8 * g) * 2);
+  };
+  u32x2_t mv[2][4];
+  if (has_mask) load_mask(0, mv);
+  // the next (tile, pass) of this block: its head flies while this epilogue computes and stores
+  if (nxt_pass >= 0) p2_head<NTP>(p, nxt_pass, smem, NT_, wave, lane);
+  const bool relu = p.act == HRV_ACT_RELU, lrelu = p.act == HRV_ACT_LRELU;
+  const float sl = p.slope, msl = p.mask_slope;
 #pragma unroll
   for (int j = 0; j < NTP; ++j) {
-    // mask of this column tile (data gradient: the activation the forward stored; only its sign is used)
-    u16x4 mv[2][4];
-    const int colj = (tile0 + j) * 32 + 4 * lhe;             // this lane's first column of group g: colj + 8 g
-    if (p.mask) {
 #pragma unroll
-      for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 2; ++i) {
+      f32x4 vv[4], rv[4];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const u16x4 z4 = {0, 0, 0, 0};
-          mv[i][g] = colj + 8 * g < p.Cout ? *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.mask) +
-                                                                              (size_t)pidx[i] * p.mask_cs + p.mask_co + colj + 8 * g)
-                                           : z4;
-        }
-    }
-    f32x4 rv[2][4];
-    if (p.res) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
+      for (int g = 0; g < 4; ++g) vv[g] = p2_acc4(acc[i][j], g);
+      if (has_res) {
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          f32x4 r = {0.f, 0.f, 0.f, 0.f};
-          if (colj + 8 * g < p.Cout) {
-            const size_t o = (size_t)pidx[i] * p.res_cs + p.res_co + colj + 8 * g;
-            if (p.res_f32) r = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.res) + o);
-            else {
-              const u16x4 h = *reinterpret_cast<const u16x4*>(reinterpret_cast<const unsigned short*>(p.res) + o);
-#pragma unroll
-              for (int e = 0; e < 4; ++e) r[e] = bf2f(h[e]);
-            }
+          if (p.res_f32) {
+            rv[g] = p2_load16(r_rsrc, roff[i], (j * 32 + 8 * g) * 4);
+          } else {
+            const u32x2_t h = p2_load8(r_rsrc, roff[i], (j * 32 + 8 * g) * 2);
+            rv[g][0] = __builtin_bit_cast(float, h[0] << 16); rv[g][1] = __builtin_bit_cast(float, h[0] & 0xFFFF0000u);
+            rv[g][2] = __builtin_bit_cast(float, h[1] << 16); rv[g][3] = __builtin_bit_cast(float, h[1] & 0xFFFF0000u);
           }
-          rv[i][g] = r;
         }
-    }
-    f32x4 vv[2][4];
+        if (!p.res_after) {
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const f32x4 b = *reinterpret_cast<const f32x4*>(cbuf + j * 32 + 8 * g + 4 * lhe);
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        f32x4 t = p2_acc4(acc[i][j], g) + b;
-        if (p.res && !p.res_after) t = t + rv[i][g];
-        const f32x4 ts = t * sl;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) t[e] = relu ? fmaxf(t[e], 0.f) : fmaxf(t[e], ts[e]);      // (ReLU: +0, never v * 0 = -0)
-        if (p.mask) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) t[e] = bf2f(mv[i][g][e]) > 0.f ? t[e] : t[e] * msl;
-        }
-        if (p.res && p.res_after) t = t + rv[i][g];
-        vv[i][g] = t;
-      }
-    }
-    if (!p.out_f32) {
-      // both 32-pixel halves staged together as bf16 (two buffers of 32 rows x 64 B + pad); rows leave 16 bytes per lane
-      constexpr int RS = 80;
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-          *reinterpret_cast<p2_bf16x4*>(sb0 + i * 2560 + l31e * RS + 16 * g + 8 * lhe) = __builtin_convertvector(vv[i][g], p2_bf16x4);
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-          const int r = (lane_e >> 2) + 16 * k, kk = lane_e & 3;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(sb0 + i * 2560 + r * RS + kk * 16);
-          p2_store16(v, o_rsrc, (pp4[i][k] < 0 || (tile0 + j) * 32 + kk * 8 >= p.Cout) ? 0xFFFFFFF0u
-                                    : (unsigned)(pp4[i][k] * p.out_cs + p.out_co + (tile0 + j) * 32 + kk * 8) * 2u);
-        }
-    } else {
-      // fp32 rows: one 32-pixel half at a time (32 rows x 128 B + pad)
-      constexpr int RSF = 144;
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) *reinterpret_cast<f32x4*>(sb0 + l31e * RSF + 32 * g + 16 * lhe) = vv[i][g];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const int t = lane_e + 64 * k, r = t >> 3, kk = t & 7;
-          const f32x4 v = *reinterpret_cast<const f32x4*>(sb0 + r * RSF + kk * 16);
-          const int y = pt_y0 + 4 * wave + 2 * i + (r >> 4), x = pt_x0 + (r & 15);
-          p2_store16(v, o_rsrc, (y < p.H && x < p.W && (tile0 + j) * 32 + kk * 4 < p.Cout)
-                                    ? (unsigned)((y * p.W + x) * p.out_cs + p.out_co + (tile0 + j) * 32 + kk * 4) * 4u : 0xFFFFFFF0u);
+            for (int e = 0; e < 4; ++e) vv[g][e] += rv[g][e];
         }
       }
+      if (relu) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[g][e] = fmaxf(vv[g][e], 0.f);      // (+0, never v * 0 = -0)
+      } else if (lrelu) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[g][e] = fmaxf(vv[g][e], vv[g][e] * sl);
+      }
+      if (has_mask) {
+        // out *= (mask > 0 ? 1 : mask_slope): the sign / zero test runs on the stored 16-bit patterns
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const u32x2_t m = mv[i][g];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const unsigned w_ = m[e >> 1];
+            const bool keep = (e & 1) ? ((int)w_ > 0xFFFF) : ((short)(w_ & 0xFFFFu) > 0);
+            vv[g][e] = keep ? vv[g][e] : vv[g][e] * msl;
+          }
+        }
+      }
+      if (has_res && p.res_after) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) vv[g][e] += rv[g][e];
+      }
+      const unsigned pbase = pix[i] * (unsigned)p.out_cs + (unsigned)(p.out_co + (tile0 + j) * 32);
+      if (!p.out_f32) {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const u32x2_t X = __builtin_bit_cast(u32x2_t, __builtin_convertvector(vv[2 * gp], p2_bf16x4));
+          const u32x2_t Y = __builtin_bit_cast(u32x2_t, __builtin_convertvector(vv[2 * gp + 1], p2_bf16x4));
+          const u32x2_t s0 = p2_swap32(X[0], Y[0]), s1 = p2_swap32(X[1], Y[1]);
+          const u32x4_t o = {s0[0], s1[0], s0[1], s1[1]};
+          const int gcol = 8 * (2 * gp + lhe);
+          p2_store16(__builtin_bit_cast(f32x4, o), o_rsrc,
+                     (!pok[i] || (tile0 + j) * 32 + gcol >= p.Cout) ? 0xFFFFFFF0u : (pbase + (unsigned)gcol) * 2u);
+        }
+      } else {
+#pragma unroll
+        for (int gp = 0; gp < 2; ++gp) {
+          const f32x4 xa = vv[2 * gp], xb = vv[2 * gp + 1];
+          const u32x2_t a0 = p2_swap32(p2_bits(xa[0]), p2_bits(xb[0]));
+          const u32x2_t a1 = p2_swap32(p2_bits(xa[1]), p2_bits(xb[1]));
+          const u32x2_t a2 = p2_swap32(p2_bits(xa[2]), p2_bits(xb[2]));
+          const u32x2_t a3 = p2_swap32(p2_bits(xa[3]), p2_bits(xb[3]));
+          const u32x4_t lo_ = {a0[0], a1[0], a2[0], a3[0]}, hi_ = {a0[1], a1[1], a2[1], a3[1]};
+          const f32x4 lo4 = __builtin_bit_cast(f32x4, lo_), hi4 = __builtin_bit_cast(f32x4, hi_);
+          const int gcol = 8 * (2 * gp + lhe);
+          const int colg = (tile0 + j) * 32 + gcol;
+          p2_store16(lo4, o_rsrc, (!pok[i] || colg >= p.Cout) ? 0xFFFFFFF0u : (pbase + (unsigned)gcol) * 4u);
+          p2_store16(hi4, o_rsrc, (!pok[i] || colg + 4 >= p.Cout) ? 0xFFFFFFF0u : (pbase + (unsigned)gcol + 4u) * 4u);
+        }
+      }
     }
+    if (has_mask && j + 1 < NTP) load_mask(j + 1, mv);        // (into the registers just consumed: in flight under the next tile's first half)
+    if (p.tlog && tid == 0 && last) tl_pack |= ((wall_clock64() - tl_e0) & 0xFFFFull) << (16 * (j & 3));      // diag: ticks since the epilogue began
   }
-  if (p.tlog && tid == 0 && last) p.tlog[(size_t)bid * 8 + 6] = wall_clock64();
+  if (p.tlog && tid == 0 && last) {
+    p.tlog[(size_t)bid * 8 + 7] = tl_pack;
+    p.tlog[(size_t)bid * 8 + 6] = wall_clock64();
+  }
 }
 
-template <int NTP>
+template <int NTP, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_p2_kernel(const P2Params p, const int pass0, const int pass1) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2_LDS];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
@@ -501,7 +550,7 @@ __global__ __launch_bounds__(256, 2) void conv_p2_kernel(const P2Params p, const
       const int nxt_pass = !lastp ? pass + 1 : (nbid < p.m_tiles ? pass0 : -1);
       const bool lc = c_pass != pass;
       c_pass = pass;
-      p2_pass<NTP>(p, pass, smem, T, bid, lc, bid == (int)blockIdx.x && pass == pass0, pass == pass0, lastp, nxt_pass, lastp ? TN : T);
+      p2_pass<NTP, EPI>(p, pass, smem, T, bid, lc, bid == (int)blockIdx.x && pass == pass0, pass == pass0, lastp, nxt_pass, lastp ? TN : T);
     }
     if (p.tlog) {
       __builtin_amdgcn_s_waitcnt(p2_wait(0));
@@ -588,10 +637,20 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   for (int a = 0; a < pl.npass;) {
     int b = a;
     while (b < pl.npass && pl.ntp[b] == pl.ntp[a]) ++b;
-    if (pl.ntp[a] == 4) hipLaunchKernelGGL((conv_p2_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
-    else if (pl.ntp[a] == 3) hipLaunchKernelGGL((conv_p2_kernel<3>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
-    else if (pl.ntp[a] == 2) hipLaunchKernelGGL((conv_p2_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
-    else hipLaunchKernelGGL((conv_p2_kernel<1>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
+    const dim3 g3(grid), b3(256);
+    const hipStream_t st = (hipStream_t)stream;
+    const int epi = p.res ? 2 : (p.mask ? 1 : 0);
+#define P2_LAUNCH(NTP_)                                                                                                 \
+  {                                                                                                                     \
+    if (epi == 0) hipLaunchKernelGGL((conv_p2_kernel<NTP_, 0>), g3, b3, 0, st, p, a, b);                                \
+    else if (epi == 1) hipLaunchKernelGGL((conv_p2_kernel<NTP_, 1>), g3, b3, 0, st, p, a, b);                           \
+    else hipLaunchKernelGGL((conv_p2_kernel<NTP_, 2>), g3, b3, 0, st, p, a, b);                                         \
+  }
+    if (pl.ntp[a] == 4) P2_LAUNCH(4)
+    else if (pl.ntp[a] == 3) P2_LAUNCH(3)
+    else if (pl.ntp[a] == 2) P2_LAUNCH(2)
+    else P2_LAUNCH(1)
+#undef P2_LAUNCH
     a = b;
   }
   return check_launch("conv_p2_kernel");
