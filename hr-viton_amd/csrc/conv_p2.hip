@@ -198,7 +198,11 @@ __device__ __forceinline__ void p2_patch_piece(const P2Params& p, unsigned char*
   const int gs = g ^ ((hx >> 2) & 3);
   const bool ok = hy < 18 && hx < 18 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && chunk * 32 + gs * 8 < p.Cin;
   const unsigned off = ((unsigned)(y * p.W + x) * (unsigned)p.src_cs + (unsigned)(p.src_co + chunk * 32 + gs * 8)) * 2u;
+#ifdef P2_EXP_L2PATCH      // timing experiment only (wrong results): every patch piece reads the same 23 KB -- L2 hits, same instruction stream
+  dma16(a_rsrc, reinterpret_cast<float*>(smem + P2_PATCH_OFF + buf * P2_PBUF + pp * 1024), (unsigned)(pp * 1024 + lane * 16), 0u);
+#else
   dma16(a_rsrc, reinterpret_cast<float*>(smem + P2_PATCH_OFF + buf * P2_PBUF + pp * 1024), ok ? off : 0xFFFFFFF0u, 0u);
+#endif
 }
 
 // The head of a (tile, pass): chunk 0 of the patch -> buffer 0 (6 pieces per wave), k-tiles 0 / 1 -> ring stages 0 / 1.
@@ -317,6 +321,35 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
       if ((NP) > 0 && j == NTP - 1) __builtin_amdgcn_sched_group_barrier(0x010, 1, 0);                     \
     }                                                                                                      \
   }
+  // ---- the mask of the epilogue (EPI >= 1): 4 bf16 per (pixel, group of the lane's own columns), one column tile at a time.  One
+  // offset register per pixel (out of the image: an offset no constant below brings back into range -> zeros), the (j, g) part
+  // rides in the instruction's scalar offset; columns beyond Cout read whatever lies there (at worst zeros past the end of the
+  // tensor): those lanes store nothing.  EPI == 1 requests column tile 0 under the LAST chunk's tap 6 (the loads are younger
+  // than every LDS-DMA piece of the pass: the counted waits behind them allow 8 more in flight) and double-buffers the rest.
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  constexpr unsigned P2_OOB = 0xF0000000u;
+  constexpr bool MASK_EARLY = EPI == 1;
+  u32x2_t mv[2][2][4];
+  unsigned moff[2] = {P2_OOB, P2_OOB};
+  rsrc_t m_rsrc = make_rsrc(nullptr, 0u);
+  auto mask_setup = [&]() {
+    int lane_m = lane;
+    asm volatile("" : "+v"(lane_m));        // (lane-only index arithmetic: kept out of the persistent loop's live ranges)
+    const int tym = 4 * wave + ((lane_m & 31) >> 4), pxm = pt_x0 + (lane_m & 15);
+    m_rsrc = make_rsrc(reinterpret_cast<const char*>(p.mask) + (size_t)pt_n * p.H * p.W * p.mask_cs * 2, (unsigned)((size_t)p.H * p.W * p.mask_cs * 2));
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int py = pt_y0 + tym + 2 * i;
+      moff[i] = (py < p.H && pxm < p.W) ? ((unsigned)(py * p.W + pxm) * (unsigned)p.mask_cs + (unsigned)(p.mask_co + tile0 * 32 + 4 * (lane_m >> 5))) * 2u : P2_OOB;
+    }
+  };
+  auto load_mask = [&](const int j, u32x2_t (&m)[2][4]) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) m[i][g] = p2_load8(m_rsrc, moff[i], (j * 32 + 8 * g) * 2);
+  };
   int kt = 0;                     // current k-tile of the pass (chunk * 9 + tap)
   // One k-tile = tap TAP of the current chunk, in ring stage TAP % 3.  On entry fa[0] / fb hold its k-step 0.
   // LASTC: the chunk is the last of the pass (no further chunk to prefetch; its taps 7 / 8 request no weights, tap 8 has no
@@ -331,9 +364,18 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
     P2_READ_A(1, TAP_, 1)
     P2_STEP(0, true, ST, 1, DMAW, DMAP)
     P2_ORDER(2, true, DMAW ? NBW : 0, DMAP ? 1 : 0)
+    if constexpr (MASK_EARLY && LASTC && TAP_ == 6) {
+      mask_setup();
+      load_mask(0, mv[0]);
+    }
     if constexpr (NEXT) {
       asm volatile("" ::: "memory");
-      __builtin_amdgcn_s_waitcnt(p2_wait((DMAW ? NBW : 0) + (DMAP ? 1 : 0)));
+      // k-tile kt + 1 must have landed.  In flight may stay what this wave requested BEHIND it: the previous tap's patch piece (requested
+      // late in that tap, after k-tile kt + 1), this tap's k-tile kt + 2 and this tap's patch piece -- a patch piece (HBM, not the
+      // L2-resident weight stream) gets two k-tiles to arrive instead of one
+      constexpr bool DMAP_PREV = !LASTC && TAP_ >= 1 && TAP_ <= 6;
+      constexpr int MASK_FLY = (MASK_EARLY && LASTC && TAP_ >= 6) ? 8 : 0;      // (the mask loads of column tile 0: youngest in the queue)
+      __builtin_amdgcn_s_waitcnt(p2_wait((DMAW ? NBW : 0) + (DMAP ? 1 : 0) + (DMAP_PREV ? 1 : 0) + MASK_FLY));
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (TAP_ == 8) {                              // next k-tile: tap 0 of the next chunk, the other patch buffer
@@ -393,48 +435,32 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   const int oes = p.out_f32 ? 4 : 2;
   const rsrc_t o_rsrc = make_rsrc(reinterpret_cast<const char*>(p.out) + (size_t)pt_n * img_px * p.out_cs * oes,
                                   (unsigned)(img_px * p.out_cs * oes));
-  const bool has_mask = EPI >= 1 && p.mask != nullptr, has_res = EPI == 2 && p.res != nullptr;
+  const bool has_mask = EPI == 1 || (EPI == 2 && p.mask != nullptr), has_res = EPI == 2 && p.res != nullptr;
   const int res_es = p.res_f32 ? 4 : 2;
-  const rsrc_t m_rsrc = make_rsrc(has_mask ? reinterpret_cast<const char*>(p.mask) + (size_t)pt_n * img_px * p.mask_cs * 2 : nullptr,
-                                  has_mask ? (unsigned)(img_px * p.mask_cs * 2) : 0u);
   const rsrc_t r_rsrc = make_rsrc(has_res ? reinterpret_cast<const char*>(p.res) + (size_t)pt_n * img_px * p.res_cs * res_es : nullptr,
                                   has_res ? (unsigned)(img_px * p.res_cs * res_es) : 0u);
   // this lane's two pixels
   const int tye = 4 * wave + (l31e >> 4), pxe = pt_x0 + (l31e & 15);
-  unsigned pix[2];
+  unsigned pix[2], roff[2];
   bool pok[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int py = pt_y0 + tye + 2 * i;
     pok[i] = py < p.H && pxe < p.W;
     pix[i] = (unsigned)(py * p.W + pxe);
-  }
-  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
-  // mask of column tile j: 4 bf16 per (pixel, group) -- the lane's own columns.  One offset register per pixel (out of the image:
-  // an offset no constant below brings back into range -> zeros), the (j, g) part rides in the instruction's scalar offset;
-  // columns beyond Cout read whatever lies there (at worst zeros past the end of the tensor): those lanes store nothing
-  constexpr unsigned P2_OOB = 0xF0000000u;
-  unsigned moff[2], roff[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    moff[i] = pok[i] ? (pix[i] * (unsigned)p.mask_cs + (unsigned)(p.mask_co + tile0 * 32 + 4 * lhe)) * 2u : P2_OOB;
     roff[i] = pok[i] ? (pix[i] * (unsigned)p.res_cs + (unsigned)(p.res_co + tile0 * 32 + 4 * lhe)) * (unsigned)res_es : P2_OOB;
   }
-  auto load_mask = [&](const int j, u32x2_t (&mv)[2][4]) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) mv[i][g] = p2_load8(m_rsrc, moff[i], (j * 32 + 8 * g) * 2);
-  };
-  u32x2_t mv[2][4];
-  if (has_mask) load_mask(0, mv);
+  if (!MASK_EARLY && has_mask) {
+    mask_setup();
+    load_mask(0, mv[0]);
+  }
   // the next (tile, pass) of this block: its head flies while this epilogue computes and stores
   if (nxt_pass >= 0) p2_head<NTP>(p, nxt_pass, smem, NT_, wave, lane);
   const bool relu = p.act == HRV_ACT_RELU, lrelu = p.act == HRV_ACT_LRELU;
   const float sl = p.slope, msl = p.mask_slope;
 #pragma unroll
   for (int j = 0; j < NTP; ++j) {
+    if (MASK_EARLY && j + 1 < NTP) load_mask(j + 1, mv[(j + 1) & 1]);       // (column tile j's mask has been in flight for a whole tile)
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       f32x4 vv[4], rv[4];
@@ -473,7 +499,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
         // out *= (mask > 0 ? 1 : mask_slope): the sign / zero test runs on the stored 16-bit patterns
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-          const u32x2_t m = mv[i][g];
+          const u32x2_t m = mv[MASK_EARLY ? (j & 1) : 0][i][g];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const unsigned w_ = m[e >> 1];
@@ -517,7 +543,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
         }
       }
     }
-    if (has_mask && j + 1 < NTP) load_mask(j + 1, mv);        // (into the registers just consumed: in flight under the next tile's first half)
+    if (!MASK_EARLY && has_mask && j + 1 < NTP) load_mask(j + 1, mv[0]);      // (into the registers just consumed)
     if (p.tlog && tid == 0 && last) tl_pack |= ((wall_clock64() - tl_e0) & 0xFFFFull) << (16 * (j & 3));      // diag: ticks since the epilogue began
   }
   if (p.tlog && tid == 0 && last) {
