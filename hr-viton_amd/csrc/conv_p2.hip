@@ -84,6 +84,7 @@ struct P2Params {
   const void* mask; int mask_cs, mask_co; float mask_slope;          // bf16: out *= (mask > 0 ? 1 : mask_slope)
   void* out; int out_cs, out_co, out_f32;
   unsigned long long* tlog;
+  int pp;                   // one (tile, pass) per unit of work (see conv_p2_kernel)
 };
 
 struct P2Plan {
@@ -556,10 +557,18 @@ template <int NTP, int EPI>
 __global__ __launch_bounds__(256, 2) void conv_p2_kernel(const P2Params p, const int pass0, const int pass1) {
   __shared__ __attribute__((aligned(1024))) unsigned char smem[P2_LDS];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
-  if ((int)blockIdx.x < p.m_tiles) p2_head<NTP>(p, pass0, smem, p2_tile(p, blockIdx.x), wave, lane);
+  // A unit of work = one tile with the launch's passes pass0 .. pass1 one after the other (the source patch of the later passes
+  // comes out of L2) -- or, p.pp (fewer tiles than resident blocks: the 64 x 48 / 32 x 24 levels), ONE (tile, pass): the passes
+  // of a tile run on different CUs at the same time
+  const int npg = pass1 - pass0;
+  const int units = p.pp ? p.m_tiles * npg : p.m_tiles;
+  auto unit_tile = [&](const int u) { return p.pp ? u / npg : u; };
+  auto unit_pass = [&](const int u) { return p.pp ? pass0 + u % npg : pass0; };
+  if ((int)blockIdx.x < units) p2_head<NTP>(p, unit_pass(blockIdx.x), smem, p2_tile(p, unit_tile(blockIdx.x)), wave, lane);
   int c_pass = -1;
 #pragma unroll 1
-  for (int bid = blockIdx.x; bid < p.m_tiles; bid += gridDim.x) {
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int bid = unit_tile(u);
     if (p.tlog && threadIdx.x == 0) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -568,15 +577,16 @@ __global__ __launch_bounds__(256, 2) void conv_p2_kernel(const P2Params p, const
       p.tlog[(size_t)bid * 8 + 5] = blockIdx.x;
     }
     const P2Tile T = p2_tile(p, bid);
-    const int nbid = bid + gridDim.x;
-    const P2Tile TN = p2_tile(p, nbid < p.m_tiles ? nbid : bid);
+    const int nu = u + gridDim.x;
+    const P2Tile TN = p2_tile(p, unit_tile(nu < units ? nu : u));
+    const int pa = unit_pass(u), pb = p.pp ? pa + 1 : pass1;
 #pragma unroll 1
-    for (int pass = pass0; pass < pass1; ++pass) {
-      const bool lastp = pass == pass1 - 1;
-      const int nxt_pass = !lastp ? pass + 1 : (nbid < p.m_tiles ? pass0 : -1);
+    for (int pass = pa; pass < pb; ++pass) {
+      const bool lastp = pass == pb - 1;
+      const int nxt_pass = !lastp ? pass + 1 : (nu < units ? unit_pass(nu) : -1);
       const bool lc = c_pass != pass;
       c_pass = pass;
-      p2_pass<NTP, EPI>(p, pass, smem, T, bid, lc, bid == (int)blockIdx.x && pass == pass0, pass == pass0, lastp, nxt_pass, lastp ? TN : T);
+      p2_pass<NTP, EPI>(p, pass, smem, T, bid, lc, u == (int)blockIdx.x && pass == pa, pass == pa, lastp, nxt_pass, lastp ? TN : T);
     }
     if (p.tlog) {
       __builtin_amdgcn_s_waitcnt(p2_wait(0));
@@ -606,7 +616,10 @@ extern "C" int hrv_conv_p2_supported(int32_t Cin, int32_t Cout, int32_t N, int32
   const char* e = hrv::env("HRV_CONV_P2_MIN_TILES_X4");      // (cached by hrv::env: no getenv here after the first call)
   int q4 = e ? atoi(e) : 3;
   if (q4 < 1) q4 = 3;
-  return 4 * tiles >= q4 * (int64_t)persistent_cus() ? 1 : 0;
+  // (round 6: counted in UNITS of work -- a level with fewer tiles than resident blocks spreads the column passes of a tile over
+  //  the CUs, so what has to fill the chip is tiles x passes: the 64 x 48 level's 48 tiles x 4 passes of a 512-column layer)
+  const int64_t units = tiles < 2 * (int64_t)persistent_cus() ? tiles * pl.npass : tiles;
+  return 4 * units >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
 
 extern "C" int hrv_conv_p2_pack_dev(int32_t mode, const float* w, const float* w2, int32_t Cin, int32_t Cout, const float* sigma, float wscale,
@@ -658,11 +671,14 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   p.mask = d->mask; p.mask_cs = d->mask_cstride; p.mask_co = d->mask_coff; p.mask_slope = d->mask_slope;
   p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff; p.out_f32 = d->out_f32;
   p.tlog = diag_tlog(p.m_tiles);
-  int grid = 2 * persistent_cus();
-  if (grid > p.m_tiles) grid = p.m_tiles;
+  const int cap = 2 * persistent_cus();
+  p.pp = p.m_tiles < cap ? 1 : 0;
+  if (p.pp) p.tlog = nullptr;          // (the timeline's slots are per tile)
   for (int a = 0; a < pl.npass;) {
     int b = a;
     while (b < pl.npass && pl.ntp[b] == pl.ntp[a]) ++b;
+    const long long units = p.pp ? (long long)p.m_tiles * (b - a) : p.m_tiles;
+    const int grid = units < cap ? (int)units : cap;
     const dim3 g3(grid), b3(256);
     const hipStream_t st = (hipStream_t)stream;
     const int epi = p.res ? 2 : (p.mask ? 1 : 0);

@@ -32,10 +32,37 @@ def bench(fn, rounds):
     return {k: sorted(v)[len(v) // 2] for k, v in ts.items()}
 
 
+# round 6: the generator's coarse levels (fewer tiles than resident blocks: the passes of a tile run on different CUs)
+COARSE = [("up_1.conv_0 528->256 @128x96", 528, 256, 128, 96), ("up_1.conv_1 256->256 @128x96", 256, 256, 128, 96),
+          ("up_0.conv_0 1040->512 @64x48", 1040, 512, 64, 48), ("up_0.conv_1 512->512 @64x48", 512, 512, 64, 48),
+          ("G_middle_1.conv_0 1040->1024 @32x24", 1040, 1024, 32, 24), ("G_middle_1.conv_1 1024->1024 @32x24", 1024, 1024, 32, 24),
+          ("G_middle_0.conv_1 1024->1024 @16x12", 1024, 1024, 16, 12)]
+
+
+def coarse(rounds):
+    for q4 in ("3", "1"):
+        os.environ["HRV_CONV_P2_MIN_TILES_X4"] = q4
+        from hr_viton_amd import _lib
+        _lib.load().hrv_diag_reload_env()
+        for name, cin, cout, H, W in COARSE:
+            N = 4
+            x = ops.Act(torch.randn(N, H, W, (cin + 7) // 8 * 8, device="cuda").to(torch.bfloat16), cin)
+            w = torch.randn(cout, cin, 3, 3, device="cuda") * 0.02
+            b = torch.zeros(cout, device="cuda")
+            dy = ops.Act(torch.randn(N, H, W, cout, device="cuda").to(torch.bfloat16), cout)
+            fl = 2.0 * N * H * W * cin * cout * 9
+            f = bench(lambda: T.conv_forward_dev(w, [(x, 0)], 1, 1, shift=b, act=ops.ACT_NONE, out_bf16=False, name="l"), rounds)
+            d = bench(lambda: T.conv_dgrad(dy, w, H, W, 1, 1, out_bf16=True, name="l.dgrad"), rounds)
+            print(f"[min quarter-units per CU {q4}] {name}: fwd p2 {f['1'] * 1e3:.0f} us {fl / f['1'] / 1e9:7.1f} TF/s | generic {f['0'] * 1e3:.0f} us {fl / f['0'] / 1e9:7.1f}   "
+                  f"dgrad p2 {d['1'] * 1e3:.0f} us {fl / d['1'] / 1e9:7.1f} | generic {d['0'] * 1e3:.0f} us {fl / d['0'] / 1e9:7.1f}   (incl. pack)", flush=True)
+
+
 def main():
     rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 7
     T.MMA_BF16[0] = True
     torch.manual_seed(0)
+    if len(sys.argv) > 2 and sys.argv[2] == "coarse":
+        return coarse(rounds)
     for N in (4, 8):
         for name, cin, cout, H, W in VGG:
             x = ops.Act(torch.relu(torch.randn(N, H, W, cin, device="cuda")).to(torch.bfloat16), cin)
