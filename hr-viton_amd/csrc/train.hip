@@ -82,6 +82,7 @@ struct NormBwdParams {
   int g1p_bf16;                              // (1 + gamma) stored as bf16 (the dedicated gamma|beta kernel writes it so)
   int dnh_bf16;                              // dnh (stage 1 -> stage 2) stored as bf16
   int dout_bf16;                             // dout stored as bf16 (the data gradient of a bf16-stored SPADE output)
+  int dbeta_in_place;                        // dout IS the dbeta half of dgb (its producer wrote it there, activation derivative applied): not stored again
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -157,10 +158,10 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
           const size_t ge = pix * p.dgb_cs + p.dgb_co + g * 4;
           if (p.dgb_bf16) {
             st4_bf16(p.dgb, ge, dpre * nh);
-            st4_bf16(p.dgb, ge + C, dpre);
+            if (!p.dbeta_in_place) st4_bf16(p.dgb, ge + C, dpre);
           } else {
             *reinterpret_cast<f32x4*>(p.dgb + ge) = dpre * nh;
-            *reinterpret_cast<f32x4*>(p.dgb + ge + C) = dpre;
+            if (!p.dbeta_in_place) *reinterpret_cast<f32x4*>(p.dgb + ge + C) = dpre;
           }
         }
         s1 += dnh;
@@ -361,10 +362,10 @@ __global__ __launch_bounds__(256) void norm_bwd2_stage1_kernel(const NormBwdPara
         const size_t ge = pix * q.dgb_cs + q.dgb_co + g * 4;
         if (q.dgb_bf16) {
           st4_bf16(q.dgb, ge, dpre * nh);
-          st4_bf16(q.dgb, ge + C, dpre);
+          if (!q.dbeta_in_place) st4_bf16(q.dgb, ge + C, dpre);
         } else {
           *reinterpret_cast<f32x4*>(q.dgb + ge) = dpre * nh;
-          *reinterpret_cast<f32x4*>(q.dgb + ge + C) = dpre;
+          if (!q.dbeta_in_place) *reinterpret_cast<f32x4*>(q.dgb + ge + C) = dpre;
         }
       }
       s1 += dnh;
@@ -1151,6 +1152,10 @@ static void norm_bwd_fill(const hrv_norm_bwd_t* d, NormBwdParams& p, NormBwd2Par
   p.dgb = d->dgb; p.dgb_cs = d->dgb_cstride; p.dgb_co = d->dgb_coff;
   p.N = d->N; p.H = d->H; p.W = d->W; p.C4 = C / 4; p.act = d->act; p.slope = d->act_slope; p.NB = nb; p.part = part;
   p.dgb_bf16 = d->dgb_bf16; p.out_bf16 = d->out_bf16;
+  // dout handed over as the dbeta half of dgb (same buffer, same pixel stride, C channels up, same storage, no activation left
+  // to differentiate): dbeta = dout is already where it belongs
+  p.dbeta_in_place = (d->dgb != nullptr && (const void*)d->dout == (const void*)d->dgb && d->dout_cstride == d->dgb_cstride &&
+                      d->dout_coff == d->dgb_coff + C && d->dout_bf16 == d->dgb_bf16 && d->act == HRV_ACT_NONE) ? 1 : 0;
   q.xs = xs; q.z = d->noise_z; q.ns = d->noise_scale;
   q.mean = d->mean; q.rstd = d->rstd; q.m1 = m1; q.m2 = m2;
   q.dnh = d->dnh; q.dn_cs = d->dnh_cstride; q.dn_co = d->dnh_coff; q.dnh_bf16 = d->dnh_bf16;

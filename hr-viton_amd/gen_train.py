@@ -123,8 +123,10 @@ class TConv:
 
     def backward(self, dy: Act, srcs: Sequence[Tuple[Act, int]], grads: Grads, need_dx: bool = True,
                  act_mask: Optional[Act] = None, slope: float = 0.2, need_w: bool = True, dx_bf16: bool = False,
-                 dy_wgrad: Optional[Act] = None, add: Optional[Act] = None) -> Optional[Act]:
-        """``dy_wgrad``: a bf16 copy of ``dy`` for the weight gradient (so a bf16-stored source takes the LDS-DMA kernel)."""
+                 dy_wgrad: Optional[Act] = None, add: Optional[Act] = None, dx_out: Optional[Act] = None) -> Optional[Act]:
+        """``dy_wgrad``: a bf16 copy of ``dy`` for the weight gradient (so a bf16-stored source takes the LDS-DMA kernel).
+        ``dx_out``: where the data gradient goes (a channel slice of a wider tensor: the dbeta half of a SPADE norm's
+        [dgamma | dbeta], SpadeT.dout_slot)."""
         w = self.wparam.data
         Cout, cin, KH, KW = w.shape
         if need_w:
@@ -150,7 +152,7 @@ class TConv:
             return None
         a0, up0 = srcs[0]
         H, W = (a0.H << up0, a0.W << up0) if up0 >= 0 else (a0.H >> -up0, a0.W >> -up0)
-        return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope,
+        return T.conv_dgrad(dy, w, H, W, self.stride, self.pad, sigma=self.sigma, act_mask=act_mask, slope=slope, out=dx_out,
                             name=self.name + ".dgrad", out_bf16=dx_bf16, add=add, batch=getattr(self, "pack_batch", None))
 
 
@@ -355,11 +357,25 @@ class SpadeT:
                     noise_scale=ctx["ns"] if ctx["z"] is not None else None, want_dgb=True, dnoise_scale=dns,
                     dgb_bf16=ctx["actv"].bf16)   # [dgamma|dbeta] feeds matrix cores only (gb.wgrad, gb.dgrad)
 
+    def dout_slot(self, ctx, want_bf16: bool):
+        """(dgb, its dbeta half, the activation mask) when the gradient of this norm's output can be WRITTEN into the dbeta half of
+        [dgamma | dbeta] by the data gradient that produces it, LeakyReLU derivative applied in that kernel's epilogue (mixed
+        precision, dense channels): the normalisation backward then reads neither the activation output nor stores dbeta again --
+        4 of its ~28 bytes per element.  Else None (HRV_DBETA_INPLACE=0: always None)."""
+        if (os.environ.get("HRV_DBETA_INPLACE", "1") == "0" or os.environ.get("HRV_NORM_BWD2", "0") != "0" or
+                not T.MMA_BF16[0] or not want_bf16 or self.Cp != self.C or
+                self.C % 8 != 0 or not ctx["actv"].bf16 or not ctx["out"].bf16):
+            return None
+        dgb, dbeta = T.norm_bwd_dgb(ctx["x"], True)
+        return dgb, dbeta, (ctx["out"] if self.act != ACT_NONE else None)
+
     def backward(self, ctx, dout: Act, grads: Grads, dx: Optional[Act], dx_accumulate: bool, dact: Act,
-                 dx_bf16: bool = False) -> Act:
+                 dx_bf16: bool = False, dgb: Optional[Act] = None) -> Act:
         """``dact``: this norm's slice of the block-wide d(actv) tensor (the block back-propagates its norms'
-        conv_shared together, BlockT.backward)."""
+        conv_shared together, BlockT.backward).  ``dgb``: ``dout`` is its dbeta half (dout_slot), activation derivative applied."""
         a = self.norm_args(ctx, dout)
+        if dgb is not None:
+            a.update(act=ACT_NONE, out=None, dgb=dgb)
         dx, dgb = T.norm_bwd(ctx["x"], dx=dx, dx_accumulate=dx_accumulate, dx_bf16=dx_bf16 and ctx["actv"].bf16, **a)
         self.after_norm(ctx, dgb, a["dnoise_scale"], grads, dact)
         return dx
@@ -558,11 +574,19 @@ class BlockT:
         # d(h): the gradient of a bf16-STORED SPADE output, read once by that norm's backward -- stored in bf16 as well
         # (autocast hands the gradient of a half-precision convolution input back in half precision; HRV_DH_BF16=0: fp32)
         dh16 = bool(T.MMA_BF16[0] and os.environ.get("HRV_DH_BF16", "1") != "0")
-        d_h1 = self.c1.backward(d_out, [(ctx["h1"], 0)], grads, dx_bf16=dh16 and ctx["h1"].bf16)
+        def down(conv, d_y, h, norm, nctx):
+            """d(h) of h = act(norm(.)) through ``conv``: into the dbeta half of the norm's [dgamma | dbeta] where that is possible"""
+            slot = norm.dout_slot(nctx, dh16 and h.bf16)
+            if slot is None:
+                return conv.backward(d_y, [(h, 0)], grads, dx_bf16=dh16 and h.bf16), None
+            dgb, dbeta, mask = slot
+            conv.backward(d_y, [(h, 0)], grads, act_mask=mask, slope=0.2, dx_out=dbeta)
+            return dbeta, dgb
+        d_h1, dgb1 = down(self.c1, d_out, ctx["h1"], self.n1, ctx["n1"])
         # d(conv_0 output) is read by conv_0's weight / data gradient only: bf16 when the mixed-precision plan stores
         # that level's matrix-core tensors in bf16
-        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid), dx_bf16=True)
-        d_h0 = self.c0.backward(d_dx, [(ctx["h0"], 0)], grads, dx_bf16=dh16 and ctx["h0"].bf16)
+        d_dx = self.n1.backward(ctx["n1"], d_h1, grads, None, False, dact_all.slice(hid * (k0 + 1), hid), dx_bf16=True, dgb=dgb1)
+        d_h0, dgb0 = down(self.c0, d_dx, ctx["h0"], self.n0, ctx["n0"])
         if (self.learned and ctx["n0"]["z"] is not None and ctx["ns"]["z"] is not None and not x.bf16 and
                 os.environ.get("HRV_NORM_BWD2", "0") != "0"):
             # norm_0 and norm_s normalise the same x: one pass per stage over it, dx = dx_0 + dx_s written once (opt-in: bit-identical,
@@ -575,10 +599,10 @@ class BlockT:
             self.ns_.after_norm(ctx["ns"], dgbs, as_["dnoise_scale"], grads, dact_all.slice(0, hid))
             self.shared_backward(ctx["segx"], dact_all, grads)
             return d_x
-        d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False, dact_all.slice(hid * k0, hid))
+        d_x = self.n0.backward(ctx["n0"], d_h0, grads, None, False, dact_all.slice(hid * k0, hid), dgb=dgb0)
         if self.learned:
-            d_hs = self.cs.backward(d_out, [(ctx["hs"], 0)], grads, dx_bf16=dh16 and ctx["hs"].bf16)
-            self.ns_.backward(ctx["ns"], d_hs, grads, d_x, True, dact_all.slice(0, hid))
+            d_hs, dgbs = down(self.cs, d_out, ctx["hs"], self.ns_, ctx["ns"])
+            self.ns_.backward(ctx["ns"], d_hs, grads, d_x, True, dact_all.slice(0, hid), dgb=dgbs)
         else:
             T.add_slice(d_out, d_x, True)
         self.shared_backward(ctx["segx"], dact_all, grads)

@@ -745,7 +745,7 @@ def colsum(a: Act, out: Optional[torch.Tensor] = None, accumulate: bool = False)
 # HBM-bound training kernels (train.hip)
 # ---------------------------------------------------------------------------------------------
 def _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, want_dgb, dx, dx_accumulate, dnoise_scale, dns_accumulate,
-                   dgb_bf16, dx_bf16):
+                   dgb_bf16, dx_bf16, dgb=None):
     """-> (descriptor, dx Act, dgb Act or None, keep-alive tensors)"""
     lib = _lib.load()
     N, H, W, Cp = x.N, x.H, x.W, x.Cp
@@ -756,8 +756,9 @@ def _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, wa
         dx_accumulate = False
     # stage 1 -> stage 2 intermediate: bf16 in mixed precision (written once, read once: 4 of the ~34 bytes per element)
     dnh = torch.empty((N, H, W, Cp), dtype=torch.bfloat16 if MMA_BF16[0] else torch.float32, device=dev)
-    dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.bfloat16 if dgb_bf16 else torch.float32, device=dev),
-              2 * Cp) if want_dgb else None
+    if dgb is None:      # (a caller-provided dgb: its dbeta half already holds dout -- hrviton_hip.h, "dbeta in place")
+        dgb = Act(torch.empty((N, H, W, 2 * Cp), dtype=torch.bfloat16 if dgb_bf16 else torch.float32, device=dev),
+                  2 * Cp) if want_dgb else None
     ws = torch.empty(lib.hrv_norm_bwd_workspace_elems(N, H, W, Cp), dtype=torch.float32, device=dev)
     d = _lib.hrv_norm_bwd_t()
     d.N, d.H, d.W, d.C = N, H, W, Cp
@@ -780,7 +781,7 @@ def _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, wa
     d.dnh, d.dnh_cstride, d.dnh_coff = dnh.data_ptr(), Cp, 0
     d.dnh_bf16 = 1 if dnh.dtype == torch.bfloat16 else 0
     if dgb is not None:
-        d.dgb, d.dgb_cstride, d.dgb_coff = dgb.t.data_ptr(), 2 * Cp, 0
+        d.dgb, d.dgb_cstride, d.dgb_coff = dgb.t.data_ptr(), dgb.cstride, dgb.coff
         d.dgb_bf16 = 1 if dgb.bf16 else 0
     d.dx, d.dx_cstride, d.dx_coff = dx.t.data_ptr(), dx.cstride, dx.coff
     d.dx_accumulate = 1 if dx_accumulate else 0
@@ -797,15 +798,24 @@ def norm_bwd(x: Act, mean: torch.Tensor, rstd: torch.Tensor, dout: Act, act: int
              out: Optional[Act] = None, g1p: Optional[Act] = None, z: Optional[torch.Tensor] = None,
              noise_scale: Optional[torch.Tensor] = None, want_dgb: bool = False, dx: Optional[Act] = None,
              dx_accumulate: bool = False, dnoise_scale: Optional[torch.Tensor] = None, dns_accumulate: bool = False,
-             dgb_bf16: bool = False, dx_bf16: bool = False):
+             dgb_bf16: bool = False, dx_bf16: bool = False, dgb: Optional[Act] = None):
     """hrv_spade_norm_bwd_nhwc_f32.  Returns (dx Act, dgb Act [.., 2C] or None).  ``dgb_bf16``: store
-    [dgamma | dbeta] in bf16 (mixed precision: only the gamma|beta conv's matrix-core backward reads it)."""
+    [dgamma | dbeta] in bf16 (mixed precision: only the gamma|beta conv's matrix-core backward reads it).  ``dgb``: the
+    [dgamma | dbeta] tensor allocated by the caller whose dbeta half ``dout`` is (norm_bwd_dgb / the header's "dbeta in place")."""
     lib = _lib.load()
     d, dx, dgb, _keep = _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, want_dgb, dx, dx_accumulate, dnoise_scale,
-                                       dns_accumulate, dgb_bf16, dx_bf16)
+                                       dns_accumulate, dgb_bf16, dx_bf16, dgb)
     with _Timed("norm_bwd", "spade_norm_bwd", 0.0, 4.0 * x.N * x.H * x.W * x.Cp * (7 + (2 if want_dgb else 0))):
         _lib.check(lib.hrv_spade_norm_bwd_nhwc_f32(C.byref(d), _stream()), "hrv_spade_norm_bwd_nhwc_f32")
     return dx, dgb
+
+
+def norm_bwd_dgb(x: Act, bf16: bool) -> Tuple[Act, Act]:
+    """The [dgamma | dbeta] tensor of a SPADE norm over ``x`` and its dbeta half: the data gradient that produces the norm's ``dout``
+    writes it straight into that half (activation derivative applied in its epilogue), norm_bwd(dgb=...) then neither reads the
+    activation output nor stores dbeta a second time."""
+    dgb = Act(torch.empty((x.N, x.H, x.W, 2 * x.Cp), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.t.device), 2 * x.Cp)
+    return dgb, dgb.slice(x.Cp, x.C)
 
 
 def norm_bwd2(x: Act, a: dict, b: dict):

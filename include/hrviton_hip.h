@@ -262,7 +262,10 @@ int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t cstride, i
  *     dx = rstd*(dnh - mean_hw(dnh) - nh*mean_hw(dnh*nh));  dnoise_scale = sum dx*z.
  * g1p = 1+gamma (NULL: plain InstanceNorm, dgb must be NULL); dgb receives
  * [dgamma | dbeta] (2C channels); dnh is a C-channel scratch/output tensor.
- * workspace: hrv_norm_bwd_workspace_elems floats.  Deterministic (2-stage sums). */
+ * workspace: hrv_norm_bwd_workspace_elems floats.  Deterministic (2-stage sums).
+ * dbeta in place: when `dout` IS the dbeta half of `dgb` (same base pointer, same pixel stride, dout_coff == dgb_coff + C,
+ * same storage type, act == NONE -- the data gradient that produced dout wrote it there with the activation derivative
+ * applied in its own epilogue) the kernel reads it from there and does not store dbeta again. */
 typedef struct hrv_norm_bwd {
   int32_t N, H, W, C;
   const float* x;     int32_t x_cstride, x_coff;
