@@ -428,14 +428,25 @@ def measure(ctx, wl, steps, warmup, mixed, dump=None):
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E ~8 TB/s (spec); 6.3 TB/s is the measured copy rate (hbm_kinds)
 
 
+# Sustained ceilings of THIS part, measured (round 6): tools/probes/mfma_roof.hip, profiles/r06_mfma_roof.txt -- a register-resident
+# v_mfma_f32_32x32x16_bf16 loop on all 256 CUs holds 2 433 TFLOP/s at 2.38 GHz on all-zero operands (the datasheet condition) and
+# 1 866-1 872 TFLOP/s at 1.86-1.87 GHz / 1.32-1.36 kW of the 1.4 kW cap on random operands: the power limit, not the pipes, sets the
+# rate real data can reach.  HBM: 6.29 TB/s measured copy rate (MI355X_MICROARCH.md) against the 8 TB/s specification.
+ACHIEVABLE_BF16_TFLOPS = 1870.0
+RIDGE_FLOP_PER_BYTE = 2500e12 / (HBM_PEAK_GBPS * 1e9)      # 312: below it a kernel is priced against HBM, whatever its MFMA count
+
+
 def kernel_row(row, peak_tflops):
-    """(kernel, launches, ms, flops, bytes) -> the roofline fields of ONE device-kernel family of the step."""
+    """(kernel, launches, ms, flops, bytes) -> the roofline fields of ONE device-kernel family of the step.  Bound by arithmetic
+    intensity (algorithmic FLOPs / algorithmic bytes against the ridge of the two peaks), not by "has FLOPs"."""
     kn, n, ms, fl, by = row
-    mfma = fl > 0
+    mfma = fl > 0 and (by <= 0 or fl / by >= RIDGE_FLOP_PER_BYTE * (peak_tflops / 2500.0))
     ach = (fl / (ms * 1e-3) / 1e12) if mfma else (by / (ms * 1e-3) / 1e9)
     peak = peak_tflops if mfma else HBM_PEAK_GBPS
+    ach_peak = (ACHIEVABLE_BF16_TFLOPS if peak_tflops >= 2000.0 else peak_tflops) if mfma else HBM_ACHIEVABLE_GBPS
     return {"kernel": "hrv::" + kn, "bound": "mfma" if mfma else "hbm", "achieved": round(ach, 2), "peak": peak,
-            "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "launches_per_step": n, "ms_per_step": round(ms, 3),
+            "unit": "TFLOP/s" if mfma else "GB/s", "frac": round(ach / peak, 4), "achievable_peak": ach_peak,
+            "frac_of_achievable": round(ach / ach_peak, 4), "launches_per_step": n, "ms_per_step": round(ms, 3),
             "algorithmic_flops_per_launch": fl / max(1, n), "algorithmic_bytes_per_launch": round(by / max(1, n), 1)}
 
 
@@ -540,7 +551,7 @@ def _parity_summary(p):
 def _roof_compact(r):
     if not r:
         return None
-    keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "launches_per_step", "ms_per_step", "algorithmic_flops_per_launch",
+    keys = ("bound", "kernel", "achieved", "peak", "unit", "frac", "achievable_peak", "frac_of_achievable", "launches_per_step", "ms_per_step", "algorithmic_flops_per_launch",
             "algorithmic_bytes_per_launch", "traffic", "wasted_traffic_ratio", "north_star_set_frac", "north_star_set_achieved",
             "north_star_set_ms")
     out = {k: _sig(r[k], 6) for k in keys if k in r}

@@ -70,14 +70,10 @@ const char* env(const char* name);
 // 1040-channel / 64x48-pixel levels of the generator spread over 5 x 24 x N blocks instead of 6 x N (they ran at
 // 50-200 GB/s), and slabs are >= 128 pixels (fixed-order second stage over <= 256 slab partials).
 constexpr int NORM_GCAP = 64;
-inline int norm_slab_cap() {
-  static int cap = 0;
-  if (cap == 0) {
-    const char* e = hrv::env("HRV_NORM_SLABS_MAX");
-    cap = e ? atoi(e) : 256;
-    if (cap < 1) cap = 256;
-  }
-  return cap;
+inline int norm_slab_cap() {      // (hrv::env is the cache: no static copy here that hrv_diag_reload_env could not reach)
+  const char* e = hrv::env("HRV_NORM_SLABS_MAX");
+  const int cap = e ? atoi(e) : 256;
+  return cap < 1 ? 256 : cap;
 }
 inline int norm_slabs(int HW) {
   const int nb = (HW + 127) / 128, cap = norm_slab_cap();

@@ -350,21 +350,29 @@ int device_cus() {
   if (dev < HRV_MAX_DEVICES) cus[dev] = n;
   return n;
 }
+// HRV_* switches: the environment is read once per name and cached.  The cache hands out pointers that stay valid for the life of
+// the process: a reload (hrv_diag_reload_env) re-reads every cached name and, where the value changed, points the entry at a NEW
+// copy -- the old one is never freed, so a launch on another thread (the autograd backward thread) that still parses the pointer it
+// got before the reload reads valid memory (clear() here was a use-after-free under that race).
 static std::mutex g_env_mu;
-static std::unordered_map<std::string, std::pair<bool, std::string>>& env_cache() {
-  static std::unordered_map<std::string, std::pair<bool, std::string>> c;
+static std::unordered_map<std::string, const char*>& env_cache() {
+  static std::unordered_map<std::string, const char*> c;
+  return c;
+}
+static const char* env_copy(const char* e) {
+  if (!e) return nullptr;
+  char* c = (char*)malloc(strlen(e) + 1);      // (deliberately leaked: see above)
+  if (c) strcpy(c, e);
   return c;
 }
 const char* env(const char* name) {
   std::lock_guard<std::mutex> lk(g_env_mu);
   auto& c = env_cache();
   auto it = c.find(name);
-  if (it == c.end()) {
-    const char* e = ::getenv(name);
-    it = c.emplace(std::string(name), std::make_pair(e != nullptr, std::string(e ? e : ""))).first;
-  }
-  return it->second.first ? it->second.second.c_str() : nullptr;
+  if (it == c.end()) it = c.emplace(std::string(name), env_copy(::getenv(name))).first;
+  return it->second;
 }
+static bool g_reserved_explicit = false;      // hrv_set_reserved_cus was called: a reload keeps that value
 static int g_reserved_cus = -1;      // -1: not set yet (HRV_RESERVE_CUS is read once)
 int persistent_cus() {
   if (g_reserved_cus < 0) {
@@ -382,13 +390,19 @@ unsigned long long* diag_tlog(long long tiles) { return (g_tlog != nullptr && ti
 
 extern "C" int hrv_diag_reload_env(void) {
   std::lock_guard<std::mutex> lk(hrv::g_env_mu);
-  hrv::env_cache().clear();
+  for (auto& kv : hrv::env_cache()) {
+    const char* e = ::getenv(kv.first.c_str());
+    const bool same = (e == nullptr && kv.second == nullptr) || (e != nullptr && kv.second != nullptr && strcmp(e, kv.second) == 0);
+    if (!same) kv.second = hrv::env_copy(e);
+  }
+  if (!hrv::g_reserved_explicit) hrv::g_reserved_cus = -1;      // HRV_RESERVE_CUS is read again
   return HRV_OK;
 }
 
 extern "C" int hrv_set_reserved_cus(int32_t k) {
   HRV_REQUIRE(k >= 0 && k < 4096, "set_reserved_cus: %d", k);
   hrv::g_reserved_cus = k;
+  hrv::g_reserved_explicit = true;
   return HRV_OK;
 }
 

@@ -798,19 +798,24 @@ class _EngineMode:
 
 def _d_f32(layer: int, part: str, own_step: bool = True, scale: int = 0) -> bool:
     """Mixed precision: does convolution ``layer`` of a PatchGAN scale keep fp32 operands in ``part`` ("fwd": the forward, "bwd": its
-    data and weight gradients)?  Default: the FORWARD of layer 1 (model1: 64 -> 128, 4x4 stride 2, the first spectral-normalised
-    layer, reading LeakyReLU(model0) and feeding the first InstanceNorm) of ``discriminator_1`` (the half-resolution scale) in the
-    discriminator's OWN step.  Measured
-    (tools/d_f32_layers.py, profiles/r05_d_f32_layers.txt: the D half of the iteration at 2 x 1024x768 against torch autograd over
-    the fp32 oracle): every convolution on bf16 operands gives a D-gradient cosine of 0.980 (the oracle's own bf16-operand evaluation:
-    0.983); model1's forward on fp32 operands 0.992; model0 makes no difference (0.981), model1's gradients none (0.980), model1 +
-    model2 forwards 0.994, the whole PatchGAN in fp32 0.997 (the rest is the bf16 generator's fake image); and only the half-resolution
-    scale matters: model1's forward of discriminator_1 alone 0.992, of discriminator_0 alone 0.980 (a quarter of the pixels average
-    the rounding less).  Cost of the default: 0.27 ms of the 72 ms iteration (both scales: 1.2 ms; both passes through D: 1.8 ms --
-    the generator step's gradient cosine is 0.998 without).  HRV_D_F32_MASK=<bitmask of layer indices> (or HRV_D_F32_LAYERS=<k>: the
-    first k layers), HRV_D_F32_PARTS=all|fwd|bwd, HRV_D_F32_SCOPE=dstep|always, HRV_D_F32_SCALES=<bitmask of discriminator_k>;
-    HRV_D_F32_MASK=0: every convolution in bf16 (what amp O1 does, train_generator.py:186-190)."""
-    mask = int(os.environ.get("HRV_D_F32_MASK", "2") or 0) | ((1 << int(os.environ.get("HRV_D_F32_LAYERS", "0") or 0)) - 1)
+    data and weight gradients)?  Default (round 6): the FORWARDS of layers 0, 1, 2 (model0 .. model2: everything in front of the last
+    InstanceNorm) of ``discriminator_1`` (the half-resolution scale) in the discriminator's OWN step.  Measured (tools/d_f32_layers.py:
+    the D half of the iteration at 2 x 1024x768 against torch autograd over the fp32 oracle; profiles/r06_d_f32_seeds.txt), minimum
+    cosine over D's parameter gradients on the seeds 1 / 2 / 3 of the draw:
+        every convolution on bf16 operands (amp O1's choice)      0.980 (seed 1; the oracle's own bf16-operand evaluation: 0.983)
+        model1 forward (round 5's default)                        0.9915 / 0.9825 / 0.9903   -- seed 2 falls under 0.99
+        model1 + model2 forwards                                  0.9938 / 0.9893 / 0.9927
+        model0 + model1 forwards                                  0.9920 / 0.9823 / 0.9930
+        model0 + model1 + model2 forwards (the default)           0.9975 / 0.9960 / 0.9973   (+ model3: the same)
+    i.e. the rounding that matters is that of the WHOLE chain in front of the half-resolution scale's last InstanceNorm (a quarter
+    of the pixels average it less than the full-resolution scale does); operand rounding in the gradients is invisible, and the
+    full-resolution scale needs nothing.  Cost of the default: +0.25 ms of the 71.6 ms iteration, same box (mask 2: 71.57, mask 7:
+    71.81; both scales or both passes through D cost 1.2 - 1.8 ms -- the generator step's gradient cosine is 0.998 without).
+    HRV_D_F32_MASK=<bitmask of layer indices> (or HRV_D_F32_LAYERS=<k>: the first k layers), HRV_D_F32_PARTS=all|fwd|bwd,
+    HRV_D_F32_SCOPE=dstep|always, HRV_D_F32_SCALES=<bitmask of discriminator_k>; HRV_D_F32_MASK=0: every convolution in bf16 (what
+    amp O1 does, train_generator.py:186-190).  The tocg discriminator's plans (cond_train: DiscTrainPlan.from_sequential) carry no
+    scale index: they count as scale 0 and keep bf16 operands under the default scale mask."""
+    mask = int(os.environ.get("HRV_D_F32_MASK", "7") or 0) | ((1 << int(os.environ.get("HRV_D_F32_LAYERS", "0") or 0)) - 1)
     if not (mask >> layer) & 1:
         return False
     if not (int(os.environ.get("HRV_D_F32_SCALES", "2") or 0) >> scale) & 1:      # bit k = discriminator_k; default: the half-resolution scale

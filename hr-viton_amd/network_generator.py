@@ -598,7 +598,9 @@ class _SoloScale:
 
     def __init__(self, D):
         self._D = D
-        self.no_ganFeat_loss = D.no_ganFeat_loss
+
+    # (forwarded, not snapshotted: a flag flipped after the first call must be the one the training forward sees)
+    no_ganFeat_loss = property(lambda self: self._D.no_ganFeat_loss)
 
     def children(self):
         return iter([self._D])

@@ -241,13 +241,18 @@ _WS = {}
 GRAPH_WATCH = weakref.WeakSet()
 
 
+WS_PER_STREAM = [False]      # set by train_ops.wgrad_side while its body runs on the side stream
+
+
 def _workspace(device, nbytes: int) -> torch.Tensor:
     """Per-device split-K scratch (stream-ordered reuse: every conv launch on the stream finishes
     reading it before the next one writes).  A request beyond the current size REPLACES the tensor; a captured hipGraph
     that recorded the old address keeps the old tensor alive itself (graph.CaptureGuard), so its replays stay on memory
     nobody else owns."""
-    # (one scratch per STREAM: weight gradients may run on a second stream next to the data-gradient chain -- train_ops.wgrad_side)
-    key = (str(device), torch.cuda.current_stream(device).cuda_stream)
+    # One scratch per device -- except inside a ``train_ops.wgrad_side`` body (opt-in, HRV_WGRAD_SIDE=1), where the weight gradients
+    # run on a second stream NEXT to the data-gradient chain and get that stream's own scratch.  (Keyed by every current stream, the
+    # warm-up and capture streams of graph.GraphedStep each grew a full-size scratch that nothing released -- ADVICE r5.)
+    key = (str(device), torch.cuda.current_stream(device).cuda_stream if WS_PER_STREAM[0] else 0)
     t = _WS.get(key)
     if t is None or t.numel() * 4 < nbytes:
         t = torch.empty((nbytes + 3) // 4, dtype=torch.float32, device=device)

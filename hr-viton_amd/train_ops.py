@@ -86,12 +86,14 @@ class wgrad_side:
         self.ctx.__enter__()
         _Side.active[0] = True
         _Side.pending[dev] = True
+        ops.WS_PER_STREAM[0] = True        # (the side stream's own split-K / weight-gradient scratch)
         return self
 
     def __exit__(self, *exc):
         if not self.on:
             return False
         _Side.active[0] = False
+        ops.WS_PER_STREAM[0] = False
         self.ctx.__exit__(*exc)
         for t in self.reads:          # allocated on the main stream, read on the side stream: not to be reused before that read
             if t is not None:

@@ -157,7 +157,10 @@ class _VGGLossFn(torch.autograd.Function):
         c = getattr(vgg, "_ycache", None)
         cached = (c is not None and c[0] is y and not torch.cuda.is_current_stream_capturing() and
                   c[1] == (y.data_ptr(), y._version, tuple(y.shape), ops.WEIGHTS_EPOCH[0], bool(T.MMA_BF16[0]), ops.LOAD_EPOCH[0]))
-        # x | y as ONE batch of 2N (13 launches instead of 26, bit-identical).  Memory: the backward's saved tensors are first-half VIEWS of
+        # x | y as ONE batch of 2N (13 launches instead of 26).  Equal to the two passes bit for bit where both forms pick the same
+        # kernel for every layer; doubling the batch can cross conv_p2's units-per-CU threshold at a level (the generic tile for N,
+        # conv_p2 for 2N) and the forms then agree to reassociation only (the bit-identity test runs at a size below the threshold,
+        # tests/test_gpu_train_ops.py).  Memory: the backward's saved tensors are first-half VIEWS of
         # the 2N-image activations, so the y half of every saved conv input / pool tensor stays alive until the backward is done --
         # about twice the VGG saved-activation footprint of the two-pass form (1.3 GB more at 4 x 1024x768 in bf16: nothing on 288 GB);
         # this path does not fill the target cache (_ycache).  HRV_VGG_BATCH=0: two passes, the y pass under no_grad.

@@ -26,7 +26,7 @@ def _recs():
     """one training iteration's launch records, shaped like the headline's: (kind, name, flops, bytes, ms, kernel)"""
     r = []
     for i in range(31):
-        r.append(("conv", f"up_4.norm_{i % 2}.gb.dgrad [spade_gb]", 2.8e11, 9.0e8, 0.31, "conv_p2_kernel"))
+        r.append(("conv", f"up_4.norm_{i % 2}.gb.dgrad [spade_gb]", 2.8e11, 6.2e8, 0.31, "conv_p2_kernel"))      # (455 FLOP/B: the family's real ratio)
     for i in range(18):
         r.append(("conv", f"up_{i % 5}.norm_0.conv_shared+gamma|beta [spade_gb]", 5.2e11, 7.5e8, 0.49, "spade_fused_kernel"))
     for i in range(100):
@@ -100,6 +100,17 @@ def test_roofline_names_the_kernel_with_the_largest_share_of_the_step():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "wasted_traffic_ratio", "algorithmic_flops_per_launch",
               "algorithmic_bytes_per_launch", "launches_per_step", "ms_per_step"):
         assert k in j["roofline"], k
+
+
+def test_a_low_intensity_convolution_is_priced_against_hbm_and_rows_carry_the_measured_ceilings():
+    # "any family with flops > 0 is MFMA-bound" mislabelled cout1 / thin_conv (tens of FLOP per byte)
+    thin = bench.kernel_row(("thin_conv_kernel", 4, 0.9, 4 * 4.6e10, 4 * 9.0e8), 2500.0)
+    assert thin["bound"] == "hbm" and thin["unit"] == "GB/s" and thin["peak"] == 8000.0 and thin["achievable_peak"] == 6300.0
+    dense = bench.kernel_row(("conv_p2_kernel", 60, 15.0, 60 * 2.31e11, 60 * 5.08e8), 2500.0)
+    assert dense["bound"] == "mfma" and dense["peak"] == 2500.0 and dense["achievable_peak"] == bench.ACHIEVABLE_BF16_TFLOPS
+    assert abs(dense["frac_of_achievable"] - dense["achieved"] / bench.ACHIEVABLE_BF16_TFLOPS) < 1e-3
+    j = json.loads(bench.compact_line(_full()))
+    assert j["roofline"]["achievable_peak"] == bench.ACHIEVABLE_BF16_TFLOPS and 0 < j["roofline"]["frac_of_achievable"] < 1
 
 
 def test_a_step_dominated_by_a_streaming_kernel_is_priced_against_hbm():

@@ -162,5 +162,16 @@ def test_discriminator_step_1024x768_batch2_vs_oracle_autograd():
     # median error no worse than that evaluation's
     ref = rep["bf16_rounded_oracle_vs_fp32_oracle"]
     assert all(v < 5e-3 for v in rep["loss_rel_err"].values()), rep
-    assert rep["grad_min_cosine"] > 0.99 > ref["grad_min_cosine"], rep
+    assert rep["grad_min_cosine"] > 0.99, rep
     assert rep["grad_median_rel_err"] < ref["grad_median_rel_err"] + 1e-3, rep
+
+
+@pytest.mark.parametrize("seed", [2, 3])
+def test_discriminator_step_bf16_cosine_holds_on_other_draws(seed):
+    """the bf16 D-gradient bound on more than the one seed it was tuned on.  With round 5's default (model1's forward
+    alone on fp32 operands) seed 2 gives 0.9825; the chain model0..model2 of the half-resolution scale gives 0.9975 / 0.9960 /
+    0.9973 on seeds 1 / 2 / 3 (gen_train._d_f32, profiles/r06_d_f32_seeds.txt)."""
+    reps = step_check.compare_discriminator_step(1024, 768, 64, 64, 2, seed=seed, mixed=(True,), cpu_threads=min(os.cpu_count() or 1, 32))
+    rep = reps[True]
+    assert all(v < 5e-3 for v in rep["loss_rel_err"].values()), rep
+    assert rep["grad_min_cosine"] > 0.99, rep

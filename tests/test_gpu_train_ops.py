@@ -996,7 +996,7 @@ def test_fused_adam_keeps_a_step_count_per_parameter_like_torch():
 
 
 def test_wgrad_tr_kernel_below_its_default_size(monkeypatch):
-    """HRV_WGRAD_TR_MIN_PIX lowers the smallest N*H*W conv_wgrad_tr_kernel takes (default 32768): the generator's 64x48 level
+    """HRV_WGRAD_TR_MIN_PIX lowers the smallest N*H*W conv_wgrad_tr_kernel takes (default 8192): the generator's 64x48 level
     (2 x 64 x 48 = 6144 pixels here, a 48-pixel row inside the 64-pixel row tile) against torch's conv2d_weight and against the
     register-transposing kernel that serves the level by default."""
     ops, T = _mods()

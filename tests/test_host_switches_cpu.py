@@ -19,10 +19,10 @@ def test_patchgan_fp32_layer_selection(monkeypatch):
     G, _ = _mods()
     for k in ("HRV_D_F32_MASK", "HRV_D_F32_LAYERS", "HRV_D_F32_PARTS", "HRV_D_F32_SCOPE", "HRV_D_F32_SCALES"):
         monkeypatch.delenv(k, raising=False)
-    # default: model1's FORWARD of discriminator_1 (the half-resolution scale), in the discriminator's own step only
+    # default (round 6): the FORWARDS of model0 .. model2 of discriminator_1 (the half-resolution scale), in the discriminator's own step only
     assert G._d_f32(1, "fwd", True, 1) and not G._d_f32(1, "bwd", True, 1) and not G._d_f32(1, "fwd", False, 1)
     assert not G._d_f32(1, "fwd", True, 0)
-    assert not any(G._d_f32(i, "fwd", True, 1) for i in (0, 2, 3))
+    assert [G._d_f32(i, "fwd", True, 1) for i in range(4)] == [True, True, True, False]
     monkeypatch.setenv("HRV_D_F32_SCALES", "3")          # (the rest of this test: both scales)
     monkeypatch.setenv("HRV_D_F32_MASK", "0")
     assert not any(G._d_f32(i, p, True) for i in range(4) for p in ("fwd", "bwd"))      # amp O1's choice: everything in bf16

@@ -16,13 +16,18 @@ def main():
     import torch  # noqa: F401
     import hr_viton_amd  # noqa: F401
     from oracle import step_check
-    specs = sys.argv[1:] or ["0:all", "2:all", "2:fwd", "2:bwd", "6:fwd", "6:all", "4:all", "3:all", "14:all", "15:all"]
+    args = [a for a in sys.argv[1:] if "=" not in a]
+    kv = dict(a.split("=", 1) for a in sys.argv[1:] if "=" in a)          # seed=2 wmul=4: another draw / weight scale
+    seed, wmul = int(kv.get("seed", "1")), float(kv.get("wmul", "8"))
+    specs = args or ["0:all", "2:all", "2:fwd", "2:bwd", "6:fwd", "6:all", "4:all", "3:all", "14:all", "15:all"]
     engines = []
     for sp in specs:
         m, parts = sp.split(":")[:2]
         scales = sp.split(":")[2] if sp.count(":") > 1 else "255"      # mask:parts[:scale bitmask]
         engines.append((True, {"HRV_D_F32_MASK": m, "HRV_D_F32_PARTS": parts, "HRV_D_F32_LAYERS": "0", "HRV_D_F32_SCALES": scales}, sp))
-    rep = step_check.compare_discriminator_step(1024, 768, 64, 64, 2, seed=1, mixed=tuple(engines), cpu_threads=min(os.cpu_count() or 1, 32))
+    rep = step_check.compare_discriminator_step(1024, 768, 64, 64, 2, seed=seed, wmul=wmul, mixed=tuple(engines),
+                                                 cpu_threads=min(os.cpu_count() or 1, 32))
+    print("seed %d wmul %g" % (seed, wmul))
     out = {}
     for sp in specs:
         r = rep[sp]

@@ -30,6 +30,11 @@ for r in rows:
     pts.append({"n_gpus": r["n_gpus"], "value": r["value"], "ms_per_step": r["ms_per_step"], "scaling_efficiency": round(eff, 4),
                 "speedup_vs_1": round(r["value"] / base, 3) if base else None, "dist_backend": r["config"]["dist_backend"],
                 "rccl_ranks": r["config"]["rccl_ranks"]})
+# the first real run judges itself: DESIGN.md 7e's prediction next to the measured weak-scaling efficiency at the largest N
+if pts and pts[-1]["n_gpus"] > 1:
+    pred = "0.97-0.98 (eager GradSync: ~1.5 ms of ring all-reduce exposed behind the last two 64 MiB buckets; 0.95 if RCCL's kernels cost what --reserve-cus 8 costs)"
+    print(f"{sys.argv[1].split('/')[-1]}: N={pts[-1]['n_gpus']} measured efficiency {pts[-1]['scaling_efficiency']:.3f}  |  predicted at N=8: {pred}; "
+          "graph-chain mode (--graph): 0.94 (402 MB all-reduced between two replays with nothing under it)")
 # ONE machine-readable line per reserve setting (the shape of a SCALE record: the bench lines' own numbers per N, weak scaling)
 if rows:
     print(json.dumps({"metric": rows[0]["metric"], "unit": rows[0]["unit"], "scaling": rows[0].get("scaling", "weak"),
