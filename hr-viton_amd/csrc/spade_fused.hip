@@ -88,6 +88,7 @@ struct GfParams {
   void* out; int out_cs, out_co;
   void* actv; int actv_cs, actv_co;        // optional: ReLU(conv_shared(seg)) as bf16 NHWC (training forward, for the backward)
   unsigned long long* tlog;
+  int pp;                   // one (tile, pass) per unit of work (see spade_fused_kernel)
 };
 
 struct GfPlan {
@@ -766,10 +767,17 @@ __global__ __launch_bounds__(256, 2) void spade_fused_kernel(const GfParams p, c
   if (threadIdx.x < 128)
     reinterpret_cast<float*>(smem + GF_CB_OFF)[5 * GF_CV + threadIdx.x] =
         reinterpret_cast<const float*>(reinterpret_cast<const char*>(p.wp) + GF_WSH_B)[threadIdx.x];
-  if ((int)blockIdx.x < p.m_tiles) gf_head<NTP>(p, pass0, smem, gf_tile(p, blockIdx.x), true, wave, lane);
+  // A unit of work = one tile with the launch's passes pass0 .. pass1 one after the other (label patch loaded once) -- or, p.pp (fewer
+  // tiles than resident blocks: the 128 x 96 / 64 x 48 levels), ONE (tile, pass): the passes of a tile run on different CUs at once
+  const int npg = pass1 - pass0;
+  const int units = p.pp ? p.m_tiles * npg : p.m_tiles;
+  auto unit_tile = [&](const int u) { return p.pp ? u / npg : u; };
+  auto unit_pass = [&](const int u) { return p.pp ? pass0 + u % npg : pass0; };
+  if ((int)blockIdx.x < units) gf_head<NTP>(p, unit_pass(blockIdx.x), smem, gf_tile(p, unit_tile(blockIdx.x)), true, wave, lane);
   int c_n = -1, c_pass = -1;                   // (image, pass) of the constants in LDS
 #pragma unroll 1
-  for (int bid = blockIdx.x; bid < p.m_tiles; bid += gridDim.x) {
+  for (int u = blockIdx.x; u < units; u += gridDim.x) {
+    const int bid = unit_tile(u);
     if (p.tlog && threadIdx.x == 0) {
       unsigned hw, xcc;
       asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
@@ -778,15 +786,16 @@ __global__ __launch_bounds__(256, 2) void spade_fused_kernel(const GfParams p, c
       p.tlog[(size_t)bid * 8 + 5] = blockIdx.x;
     }
     const GfTile T = gf_tile(p, bid);
-    const int nbid = bid + gridDim.x;
-    const GfTile TN = gf_tile(p, nbid < p.m_tiles ? nbid : bid);
+    const int nu = u + gridDim.x;
+    const GfTile TN = gf_tile(p, unit_tile(nu < units ? nu : u));
+    const int pa = unit_pass(u), pb = p.pp ? pa + 1 : pass1;
 #pragma unroll 1
-    for (int pass = pass0; pass < pass1; ++pass) {
-      const bool lastp = pass == pass1 - 1;
-      const int nxt_pass = !lastp ? pass + 1 : (nbid < p.m_tiles ? pass0 : -1);
+    for (int pass = pa; pass < pb; ++pass) {
+      const bool lastp = pass == pb - 1;
+      const int nxt_pass = !lastp ? pass + 1 : (nu < units ? unit_pass(nu) : -1);
       const bool lc = c_n != T.n || c_pass != pass;
       c_n = T.n; c_pass = pass;
-      gf_pass<NTP>(p, pass, smem, T, bid, lc, bid == (int)blockIdx.x && pass == pass0, p.actv != nullptr && pass == 0, pass == pass0, lastp,
+      gf_pass<NTP>(p, pass, smem, T, bid, lc, u == (int)blockIdx.x && pass == pa, p.actv != nullptr && pass == 0, pass == pa, lastp,
                    nxt_pass, lastp ? TN : T, lastp);
     }
     if (p.tlog) {
@@ -815,7 +824,9 @@ extern "C" int hrv_spade_fused_supported(int32_t C, int32_t hid, int32_t label_n
   const char* e = hrv::env("HRV_SPADE_FUSED_MIN_TILES_X4");
   int q4 = e ? atoi(e) : 8;
   if (q4 < 1) q4 = 8;
-  return 4 * tiles >= q4 * (int64_t)persistent_cus() ? 1 : 0;
+  // (round 6: counted in UNITS of work -- with fewer tiles than resident blocks the passes of a tile spread over the CUs)
+  const int64_t units = tiles < 2 * (int64_t)persistent_cus() ? tiles * pl.npass : tiles;
+  return 4 * units >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
 
 extern "C" int hrv_spade_fused_pack_dev(const float* w_shared, const float* b_shared, int32_t label_nc, const float* w_gamma,
@@ -875,12 +886,15 @@ extern "C" int hrv_spade_fused_bf16(const hrv_spade_fused_t* d, hrv_stream_t str
   p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
   p.actv = d->actv; p.actv_cs = d->actv_cstride; p.actv_co = d->actv_coff;
   p.tlog = diag_tlog(p.m_tiles);
-  int grid = 2 * persistent_cus();
-  if (grid > p.m_tiles) grid = p.m_tiles;
+  const int cap = 2 * persistent_cus();
+  p.pp = p.m_tiles < cap ? 1 : 0;
+  if (p.pp) p.tlog = nullptr;          // (the timeline's slots are per tile)
   // the passes of equal width share a launch: 4-tile passes, a 2-tile pass, the 5-tile tail pass
   for (int a = 0; a < pl.npass;) {
     int b = a;
     while (b < pl.npass && pl.ntp[b] == pl.ntp[a]) ++b;
+    const long long units = p.pp ? (long long)p.m_tiles * (b - a) : p.m_tiles;
+    const int grid = units < cap ? (int)units : cap;
     if (pl.ntp[a] == 4) hipLaunchKernelGGL((spade_fused_kernel<4>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
     else if (pl.ntp[a] == 2) hipLaunchKernelGGL((spade_fused_kernel<2>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
     else hipLaunchKernelGGL((spade_fused_kernel<5>), dim3(grid), dim3(256), 0, (hipStream_t)stream, p, a, b);
