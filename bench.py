@@ -119,7 +119,7 @@ def load_traffic(tag, family=None):
     """HBM bytes per launch from the committed PMC passes of this command (cannot be read in-process): of one kernel
     family (``family``, e.g. "spade_gb_kernel") or averaged over every convolution launch."""
     family = _TRAFFIC_FAMILY.get(family, family)
-    for rnd in ("r05", "r04", "r03", "r02", "r01"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02", "r01"):
         tp = os.path.join(ROOT, "profiles", f"{rnd}_pmc_traffic_{tag}.json")
         if os.path.exists(tp):
             with open(tp) as f:

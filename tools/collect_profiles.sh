@@ -23,6 +23,11 @@ c reserve_cus.txt final_reserve_cus.txt
 c mfma_busy_per_kernel.txt final_mfma_busy_per_kernel.txt
 c pmc_iter_sq1.summary.txt final_pmc_iter_sq1.summary.txt
 c d_f32_layers.txt final_d_f32_layers.txt
+c stalls_per_kernel.txt final_stalls_per_kernel.txt
+c power_clock_bench.txt final_power_clock.txt
+c p2_timeline.txt final_p2_timeline.txt
+c p2_bench.txt final_p2_bench.txt
+c p2_bench_coarse.txt final_p2_bench_coarse.txt
 c bench_2rank_gloo_one_gpu_smoke.json final_bench_2rank_gloo_one_gpu_smoke.json
 c bench_2rank_gloo_graph_one_gpu_smoke.json final_bench_2rank_gloo_graph_one_gpu_smoke.json
 [ -s gpurun_out/pytest_gpu.txt ] && tail -5 gpurun_out/pytest_gpu.txt > $P/${R}_final_pytest_gpu.txt

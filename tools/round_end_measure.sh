@@ -13,7 +13,7 @@ bash tools/profile_traffic.sh train_generator > $OUT/profile_traffic.log 2>&1
 cp gpurun_out/traffic_train_generator/*.summary.txt gpurun_out/traffic_train_generator/*.json $OUT/ 2>/dev/null
 # (on the box only: the default run below prices its traffic from the passes just taken; the copy under profiles/ that is
 #  committed afterwards is this same file)
-cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r05_pmc_traffic_train_generator.json 2>/dev/null
+cp gpurun_out/traffic_train_generator/pmc_traffic_train_generator.json profiles/r06_pmc_traffic_train_generator.json 2>/dev/null
 timeout 1200 python bench.py --dump-launches $OUT/launches_default.txt 2>$OUT/bench_default.err | tail -1 > $OUT/bench_default.json
 cp gpurun_out/bench_detail.json $OUT/bench_default_detail.json 2>/dev/null      # (the full result behind the compact line)
 wc -c $OUT/bench_default.json; cut -c1-300 $OUT/bench_default.json
@@ -35,7 +35,15 @@ cp gpurun_out/dp_overlap/overlap.txt $OUT/dp_overlap.txt 2>/dev/null
 timeout 400 bash tools/profile_iter_sq.sh > $OUT/profile_iter_sq.log 2>&1
 cp gpurun_out/pmc_iter/mfma_busy_per_kernel.txt $OUT/mfma_busy_per_kernel.txt 2>/dev/null
 cp gpurun_out/pmc_iter/sq1.summary.txt $OUT/pmc_iter_sq1.summary.txt 2>/dev/null
-timeout 300 python tools/d_f32_layers.py 0:all 2:fwd 15:all > $OUT/d_f32_layers.txt 2>$OUT/d_f32_layers.err
+timeout 300 python tools/d_f32_layers.py 0:all 2:fwd:2 7:fwd:2 15:all > $OUT/d_f32_layers.txt 2>$OUT/d_f32_layers.err
+# round 6: what the matrix pipes wait for (LDS / issue-stall counters per kernel inside the iteration), power + clock under the
+# iteration, the conv_p2 phase timeline and micro-benchmark at HEAD
+timeout 500 bash tools/profile_iter_stalls.sh > $OUT/profile_iter_stalls.log 2>&1
+cp gpurun_out/pmc_stalls/stalls_per_kernel.txt $OUT/stalls_per_kernel.txt 2>/dev/null
+timeout 200 python tools/power_clock_sampler.py $OUT/power_clock_bench.txt -- python bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-extras > $OUT/power_clock_bench.log 2>&1
+timeout 200 python tools/p2_timeline.py > $OUT/p2_timeline.txt 2>&1
+timeout 300 python tools/p2_bench.py 5 > $OUT/p2_bench.txt 2>&1
+timeout 200 python tools/p2_bench.py 5 coarse > $OUT/p2_bench_coarse.txt 2>&1
 if [ "${HRV_FULL_SWEEP:-0}" = "1" ]; then
 timeout 300 python tools/fused_bench.py 5 > $OUT/fused_bench.txt 2>&1
 timeout 300 python tools/p2_bench.py 5 > $OUT/p2_bench.txt 2>&1
