@@ -58,13 +58,18 @@ __device__ __forceinline__ f32x4 p2_acc4(const f32x16& a, int g) {
 }
 
 constexpr int P2_MAXP = 16;
-constexpr int P2_SB = 8192;                              // ring stage: 32 k x 128 columns
 constexpr int P2_PW = 20;                                // patch pitch in pixels (a multiple of 4: the swizzle keys on hx)
 constexpr int P2_PBUF = 23 * 1024;                       // 18 x 20 pixels x 64 B = 23,040, DMA'd as 23 pieces of 1 KB
-constexpr int P2_PATCH_OFF = 3 * P2_SB;                  // 24,576
-constexpr int P2_CB_OFF = P2_PATCH_OFF + 2 * P2_PBUF;    // 71,680
-constexpr int P2_LDS = P2_CB_OFF + 512;                  // 72,192
-static_assert(2 * ((P2_LDS + 1279) / 1280) * 1280 <= 160 * 1024, "two blocks per CU");
+// LDS layout by pass width NTP (column tiles of 32): [ring: 3 stages of 32 k x 32 NTP columns][patch x 2][bias].  NTP 4: 72,192 B,
+// two blocks per CU; NTP 1 (the 32-column layers of the 1024 x 768 level: HBM / latency-bound, 104-122 registers): 53,760 B,
+// THREE blocks per CU
+constexpr int p2_sb(int ntp) { return ntp * 2048; }                                      // ring stage
+constexpr int p2_patch_off(int ntp) { return 3 * p2_sb(ntp); }
+constexpr int p2_cb_off(int ntp) { return p2_patch_off(ntp) + 2 * P2_PBUF; }
+constexpr int p2_lds(int ntp) { return p2_cb_off(ntp) + 512; }
+constexpr int p2_blocks_per_cu(int ntp) { return ntp == 1 ? 3 : 2; }
+static_assert(2 * ((p2_lds(4) + 1279) / 1280) * 1280 <= 160 * 1024, "two blocks per CU");
+static_assert(3 * ((p2_lds(1) + 1279) / 1280) * 1280 <= 160 * 1024, "three blocks per CU for single-tile passes");
 
 struct P2Params {
   const void* src; int src_cs, src_co, Cin; unsigned src_bytes;     // bf16 NHWC; src_bytes: ONE image
@@ -190,6 +195,7 @@ typedef __bf16 p2_bf16x4 __attribute__((ext_vector_type(4)));
 // piece `pp` (0..22; 23 folds back: same bytes to the same place) of the 32-channel chunk `chunk` of the tile's halo patch
 // -> patch buffer `buf`.  16 halo pixels x 4 groups of 8 channels per piece (linear patch order, pitch 20); the 16-byte
 // groups of a pixel are XOR-swizzled by (hx >> 2) & 3 on the SOURCE side.  Out of the image / beyond pixel 360: zeros.
+template <int NTP>
 __device__ __forceinline__ void p2_patch_piece(const P2Params& p, unsigned char* const smem, const rsrc_t a_rsrc, const P2Tile T, const int chunk,
                                                const int buf, int pp, const int lane) {
   pp = pp < 23 ? pp : 22;
@@ -200,9 +206,9 @@ __device__ __forceinline__ void p2_patch_piece(const P2Params& p, unsigned char*
   const bool ok = hy < 18 && hx < 18 && (unsigned)y < (unsigned)p.H && (unsigned)x < (unsigned)p.W && chunk * 32 + gs * 8 < p.Cin;
   const unsigned off = ((unsigned)(y * p.W + x) * (unsigned)p.src_cs + (unsigned)(p.src_co + chunk * 32 + gs * 8)) * 2u;
 #ifdef P2_EXP_L2PATCH      // timing experiment only (wrong results): every patch piece reads the same 23 KB -- L2 hits, same instruction stream
-  dma16(a_rsrc, reinterpret_cast<float*>(smem + P2_PATCH_OFF + buf * P2_PBUF + pp * 1024), (unsigned)(pp * 1024 + lane * 16), 0u);
+  dma16(a_rsrc, reinterpret_cast<float*>(smem + p2_patch_off(NTP) + buf * P2_PBUF + pp * 1024), (unsigned)(pp * 1024 + lane * 16), 0u);
 #else
-  dma16(a_rsrc, reinterpret_cast<float*>(smem + P2_PATCH_OFF + buf * P2_PBUF + pp * 1024), ok ? off : 0xFFFFFFF0u, 0u);
+  dma16(a_rsrc, reinterpret_cast<float*>(smem + p2_patch_off(NTP) + buf * P2_PBUF + pp * 1024), ok ? off : 0xFFFFFFF0u, 0u);
 #endif
 }
 
@@ -214,14 +220,14 @@ __device__ __forceinline__ void p2_head(const P2Params& p, const int pass, unsig
   const rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const char*>(p.src) + (size_t)T.n * p.src_bytes, p.src_bytes);
   const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
 #pragma unroll
-  for (int k = 0; k < 6; ++k) p2_patch_piece(p, smem, a_rsrc, T, 0, 0, k * 4 + wave, lane);
+  for (int k = 0; k < 6; ++k) p2_patch_piece<NTP>(p, smem, a_rsrc, T, 0, 0, k * 4 + wave, lane);
 #pragma unroll
   for (int q = 0; q < 2; ++q)
 #pragma unroll
     for (int k = 0; k < NBW; ++k) {
       int idx = wave + 4 * k;
       idx = idx < NPW ? idx : (NPW >= 4 ? idx - 4 : idx % NPW);
-      dma16(w_rsrc, reinterpret_cast<float*>(smem + q * P2_SB + idx * 1024), (unsigned)lane * 16u,
+      dma16(w_rsrc, reinterpret_cast<float*>(smem + q * p2_sb(NTP) + idx * 1024), (unsigned)lane * 16u,
             p.woff[pass] + (unsigned)q * (unsigned)(NPW * 1024) + (unsigned)idx * 1024u);
     }
 }
@@ -239,7 +245,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   constexpr int NBW = (NPW + 3) / 4;                         // DMA instructions per wave per k-tile (NTP 4, 3: 2; NTP 2, 1: 1)
   constexpr int NST = 4 * NTP;                               // global stores of one epilogue per wave (bf16 out; fp32: 8 NTP)
   unsigned char* const ring = smem;
-  float* const cbuf = reinterpret_cast<float*>(smem + P2_CB_OFF);
+  float* const cbuf = reinterpret_cast<float*>(smem + p2_cb_off(NTP));
   const rsrc_t w_rsrc = make_rsrc(p.wp, p.w_bytes);
   const rsrc_t a_rsrc = make_rsrc(reinterpret_cast<const char*>(p.src) + (size_t)T.n * p.src_bytes, p.src_bytes);
   const unsigned wbase = p.woff[pass];
@@ -250,7 +256,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
   auto dma_w = [&](const int kt, const int st, const int k) {
     int idx = wave + 4 * k;                                  // (a wave beyond the last piece re-requests an earlier one: same bytes, same place)
     idx = idx < NPW ? idx : (NPW >= 4 ? idx - 4 : idx % NPW);
-    dma16(w_rsrc, reinterpret_cast<float*>(ring + st * P2_SB + idx * 1024), (unsigned)lane * 16u,
+    dma16(w_rsrc, reinterpret_cast<float*>(ring + st * p2_sb(NTP) + idx * 1024), (unsigned)lane * 16u,
           wbase + (unsigned)kt * (unsigned)(NPW * 1024) + (unsigned)idx * 1024u);
   };
 
@@ -290,7 +296,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
 
   // ---- main loop: chunks x 9 taps.  A fragments double-buffered, B fragments refilled in place (see spade_fused.hip)
   f32x4 fa[2][2], fb[NTP];
-  const unsigned char* pbuf = smem + P2_PATCH_OFF;          // patch buffer of the current chunk
+  const unsigned char* pbuf = smem + p2_patch_off(NTP);          // patch buffer of the current chunk
   int chunk = 0;
 #define P2_READ_A(SET, TAP, S)                                                                             \
   {                                                                                                        \
@@ -299,7 +305,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
     fa[SET][0] = *reinterpret_cast<const f32x4*>(ap_ + ax_);                                               \
     fa[SET][1] = *reinterpret_cast<const f32x4*>(ap_ + 2 * P2_PW * 64 + ax_);                              \
   }
-#define P2_READ_B(J, ST, S) fb[J] = *reinterpret_cast<const f32x4*>(b_lb + (ST) * P2_SB + ((J) * 2 + (S)) * 1024);
+#define P2_READ_B(J, ST, S) fb[J] = *reinterpret_cast<const f32x4*>(b_lb + (ST) * p2_sb(NTP) + ((J) * 2 + (S)) * 1024);
 #define P2_STEP(SET, REFILL, ST, SN, DMAW, DMAP)                                                           \
   {                                                                                                        \
     _Pragma("unroll") for (int j = 0; j < NTP; ++j) {                                                      \
@@ -309,7 +315,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
                                                           __builtin_bit_cast(bf16x8, fa[SET][1]), acc[1][j], 0, 0, 0); \
       if constexpr (REFILL) { P2_READ_B(j, ST, SN) }                                                       \
       if constexpr (DMAW) { if (j < NBW) dma_w(kt + 2, (TAP_ + 2) % 3, j); }                               \
-      if constexpr (DMAP) { if (j == NTP - 1) p2_patch_piece(p, smem, a_rsrc, T, chunk + 1, (chunk + 1) & 1, TAP_ * 4 + wave, lane); } \
+      if constexpr (DMAP) { if (j == NTP - 1) p2_patch_piece<NTP>(p, smem, a_rsrc, T, chunk + 1, (chunk + 1) & 1, TAP_ * 4 + wave, lane); } \
     }                                                                                                      \
   }
 #define P2_ORDER(NA, REFILL, NW, NP)                                                                       \
@@ -380,7 +386,7 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
       if constexpr (TAP_ == 8) {                              // next k-tile: tap 0 of the next chunk, the other patch buffer
-        pbuf = smem + P2_PATCH_OFF + ((chunk + 1) & 1) * P2_PBUF;
+        pbuf = smem + p2_patch_off(NTP) + ((chunk + 1) & 1) * P2_PBUF;
       }
       P2_READ_A(0, (TAP_ + 1) % 9, 0)
       P2_STEP(1, true, (TAP_ + 1) % 3, 0, false, false)
@@ -554,8 +560,8 @@ __device__ __forceinline__ void p2_pass(const P2Params& p, const int pass, unsig
 }
 
 template <int NTP, int EPI>
-__global__ __launch_bounds__(256, 2) void conv_p2_kernel(const P2Params p, const int pass0, const int pass1) {
-  __shared__ __attribute__((aligned(1024))) unsigned char smem[P2_LDS];
+__global__ __launch_bounds__(256, p2_blocks_per_cu(NTP)) void conv_p2_kernel(const P2Params p, const int pass0, const int pass1) {
+  __shared__ __attribute__((aligned(1024))) unsigned char smem[p2_lds(NTP)];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // A unit of work = one tile with the launch's passes pass0 .. pass1 one after the other (the source patch of the later passes
   // comes out of L2) -- or, p.pp (fewer tiles than resident blocks: the 64 x 48 / 32 x 24 levels), ONE (tile, pass): the passes
@@ -671,13 +677,13 @@ extern "C" int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream) {
   p.mask = d->mask; p.mask_cs = d->mask_cstride; p.mask_co = d->mask_coff; p.mask_slope = d->mask_slope;
   p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff; p.out_f32 = d->out_f32;
   p.tlog = diag_tlog(p.m_tiles);
-  const int cap = 2 * persistent_cus();
-  p.pp = p.m_tiles < cap ? 1 : 0;
+  p.pp = p.m_tiles < 2 * persistent_cus() ? 1 : 0;
   if (p.pp) p.tlog = nullptr;          // (the timeline's slots are per tile)
   for (int a = 0; a < pl.npass;) {
     int b = a;
     while (b < pl.npass && pl.ntp[b] == pl.ntp[a]) ++b;
     const long long units = p.pp ? (long long)p.m_tiles * (b - a) : p.m_tiles;
+    const int cap = p2_blocks_per_cu(pl.ntp[a]) * persistent_cus();      // resident blocks: three per CU for single-tile passes
     const int grid = units < cap ? (int)units : cap;
     const dim3 g3(grid), b3(256);
     const hipStream_t st = (hipStream_t)stream;
