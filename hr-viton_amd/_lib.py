@@ -105,6 +105,18 @@ class hrv_conv_p2_t(C.Structure):
                 ("res_after_mask", C.c_int32)]
 
 
+class hrv_conv_s2_t(C.Structure):
+    _fields_ = [("mode", C.c_int32),
+                ("N", C.c_int32), ("Hs", C.c_int32), ("Ws", C.c_int32), ("K", C.c_int32),
+                ("src", C.c_void_p), ("src_cstride", C.c_int32), ("src_coff", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("cols", C.c_int32), ("Cph", C.c_int32),
+                ("w_packed", C.c_void_p), ("bias", C.c_void_p),
+                ("act", C.c_int32), ("act_slope", C.c_float),
+                ("out", C.c_void_p), ("out_cstride", C.c_int32), ("out_coff", C.c_int32), ("out_f32", C.c_int32),
+                ("residual", C.c_void_p), ("res_cstride", C.c_int32), ("res_coff", C.c_int32), ("res_f32", C.c_int32),
+                ("mask", C.c_void_p), ("mask_cstride", C.c_int32), ("mask_coff", C.c_int32), ("mask_slope", C.c_float)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -272,6 +284,14 @@ SYMBOLS = {
     "hrv_conv_p2_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32]),
     "hrv_conv_p2_pack_dev": (C.c_int, [_i32, _vp, _vp, _i32, _i32, _vp, _f, _vp, _vp]),
     "hrv_conv_p2_bf16": (C.c_int, [C.POINTER(hrv_conv_p2_t), _vp]),
+    "hrv_conv_s2_packed_bytes": (C.c_int64, [_i32, _i32, _i32]),
+    "hrv_conv_s2_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "hrv_conv_s2_pack_dev": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp]),
+    "hrv_conv_s2_bf16": (C.c_int, [C.POINTER(hrv_conv_s2_t), _vp]),
+    "hrv_space_to_depth2_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_instnorm_apply_nhwc_bf16out": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32, _i32, _vp]),
+    "hrv_scale_bf16": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
+    "hrv_pad_width_nhwc_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hrv_spade_fused_packed_bytes": (C.c_int64, [_i32]),
     "hrv_spade_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "hrv_spade_fused_pack_dev": (C.c_int, [_vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp]),

@@ -882,6 +882,149 @@ class DiscTrainPlan:
             if isinstance(conv, S2DConv):
                 conv.refresh()
 
+    # ---- mixed precision with bf16-STORED feature maps (csrc/conv_s2.hip) -----------------------------------------------------
+    def _s2_chain(self, a: Act, own: bool, sc: int) -> bool:
+        """Does this scale run on csrc/conv_s2.hip with its feature maps stored in bf16?  Mixed precision only, the reference's
+        NLayerDiscriminator shape ([conv 4x4 s2 + LReLU] [SN conv 4x4 s2 + IN + LReLU]+ [conv 4x4 s1 -> 1]), every convolution of
+        the scale on bf16 operands (a layer kept on fp32 operands by _d_f32 -- the half-resolution scale in D's own step -- keeps
+        the whole scale on the fp32-stored path), even input extents, shapes the kernel serves.  HRV_D_BF16=0: off."""
+        if not T.MMA_BF16[0] or os.environ.get("HRV_D_BF16", "1") == "0" or a.bf16 or len(self.layers) < 3:
+            return False
+        kinds = [k for k, _ in self.layers]
+        if kinds[0] != "lrelu" or kinds[-1] != "plain" or any(k != "in" for k in kinds[1:-1]):
+            return False
+        c0 = self.layers[0][1]
+        if not isinstance(c0, S2DConv) or c0._w2 is None or a.H % 2 or a.W % 2 or a.Cp != c0.Cq:
+            return False
+        if any(_d_f32(li, part, own, sc) for li in range(len(self.layers)) for part in ("fwd", "bwd")):
+            return False
+        H, W, N = a.H // 2 + 1, a.W // 2 + 1, a.N
+        cin = c0.conv.out_channels
+        if cin % 64 or not T.conv_s2_ok(T.S2_CELLS, 4 * c0.Cq, cin, 0, N, H, W):
+            return False
+        for _, conv in self.layers[1:-1]:
+            m = conv.conv
+            if (tuple(m.kernel_size), tuple(m.stride), tuple(m.padding)) != ((4, 4), (2, 2), (2, 2)) or m.in_channels != cin:
+                return False
+            Ho, Wo = H // 2 + 1, W // 2 + 1
+            if not (T.conv_s2_ok(T.S2_FWD, cin, m.out_channels, 0, N, Ho, Wo) and
+                    T.conv_s2_ok(T.S2_DGRAD, m.out_channels, 4 * cin, cin, N // 2, H, W)):
+                return False
+            H, W, cin = Ho, Wo, m.out_channels
+        return True
+
+    def _forward_s2(self, a: Act):
+        """The scale's forward with f0, f1, ... stored in bf16 (the last InstanceNorm output stays fp32: the one-channel
+        convolution behind it is a dot-product kernel over fp32)."""
+        feats, ctx = [], []
+        n_in = len(self.layers) - 2
+        for li, (kind, conv) in enumerate(self.layers):
+            b = conv.bparam
+            bias = None if b is None else b.data
+            if li == 0:
+                a2 = T.space_to_depth2_bf16(a)
+                Cout = conv.conv.out_channels
+                f = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device, bf16=True)
+                pk = T.conv_s2_pack(T.S2_CELLS, conv.w2, 4 * conv.Cq, Cout, sigma=conv.sigma)
+                T.conv_s2(T.S2_CELLS, a2, pk, Cout, f, bias=bias, act=ACT_LRELU, slope=0.2, name=conv.name,
+                          flops=2.0 * f.N * f.H * f.W * Cout * conv.conv.in_channels * 16)
+                ctx.append(dict(src=a, a2=a2, f=f, s2=True))
+            elif kind == "in":
+                Cout, cin = conv.conv.out_channels, conv.conv.in_channels
+                c = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device)
+                pk = T.conv_s2_pack(T.S2_FWD, conv.wparam.data, cin, Cout, sigma=conv.sigma)
+                T.conv_s2(T.S2_FWD, a, pk, Cout, c, bias=bias, name=conv.name, flops=2.0 * c.N * c.H * c.W * Cout * cin * 16)
+                mean, rstd = ops.instnorm_stats(c)
+                if li < n_in:
+                    f = T.instnorm_apply_bf16(c, mean, rstd, ACT_LRELU, 0.2)
+                else:
+                    f = ops.instnorm_apply(c, mean, rstd, ACT_LRELU, 0.2)
+                ctx.append(dict(src=a, c=c, mean=mean, rstd=rstd, f=f, s2=True))
+            else:
+                f = conv.forward([(a, 0)], act=ACT_NONE)
+                ctx.append(dict(src=a, f=f))
+            feats.append(f)
+            a = f
+        return feats, ctx
+
+    def _backward_s2(self, ctx, dfeats: List[Optional[Act]], grads: Grads, need_dx: bool, rows: Optional[int], need_w: bool) -> Optional[Act]:
+        def cut(a):
+            if rows is None or a is None:
+                return a
+            return Act(a.t[:rows], a.C, a.coff) if isinstance(a, Act) else a[:rows]
+
+        def param_grads(conv, G):
+            if conv.spectral:
+                dwo = grad_buffer(conv.wparam)
+                T.spectral_grad(G, conv.wparam.data, conv.u, conv.v, conv.sigma, dwo)
+                _acc(grads, conv.wparam, dwo)
+            else:
+                _acc(grads, conv.wparam, G)
+
+        d_next: Optional[Act] = None
+        tap_in_dnext = False
+        for i in range(len(self.layers) - 1, -1, -1):
+            kind, conv = self.layers[i]
+            c = {k: cut(v) for k, v in ctx[i].items() if k != "s2"}
+            d = dfeats[i]
+            if d is None and d_next is None:
+                continue
+            if d is None or tap_in_dnext:
+                d = d_next
+            elif d_next is not None:
+                T.add_slice(d_next, d, True)
+            if i == len(self.layers) - 1:          # the one-channel convolution: as on the fp32-stored path
+                tap = dfeats[i - 1]
+                tap_in_dnext = tap is not None and tap.t.dtype == torch.float32 and tap.t.shape[:3] == c["src"].t.shape[:3]
+                d_next = conv.backward(d, [(c["src"], 0)], grads, need_dx=True, need_w=need_w, add=tap if tap_in_dnext else None)
+                continue
+            if kind == "in":
+                d_c, _ = T.norm_bwd(c["c"], c["mean"], c["rstd"], d, act=ACT_LRELU, slope=0.2, out=c["f"], dx_bf16=True)
+                src = c["src"]                      # bf16 feature of the layer in front
+                m = conv.conv
+                w = conv.wparam.data
+                if need_w:
+                    G = torch.empty_like(w) if conv.spectral else grad_buffer(conv.wparam)
+                    db = grad_buffer(conv.bparam) if conv.bparam is not None else None
+                    T.conv_wgrad(d_c, src, 0, 0, m.in_channels, 4, 4, 2, 2, G, name=conv.name + ".wgrad", dbias=db)
+                    param_grads(conv, G)
+                    if db is not None:
+                        _acc(grads, conv.bparam, db)
+                tap = dfeats[i - 1]
+                tap_ok = tap is not None and tap.t.shape[:3] == src.t.shape[:3] and tap.C == src.C
+                dx = ops.alloc(src.N, src.H, src.W, src.C, src.t.device, bf16=True)
+                pk = T.conv_s2_pack(T.S2_DGRAD, w, m.out_channels, 4 * m.in_channels, m.in_channels, sigma=conv.sigma)
+                # the gradient of the layer's input feature: + its feature-matching tap; the feature behind model0 is LeakyReLU(pre):
+                # its derivative rides along as the mask (the features behind an InstanceNorm get theirs in norm_bwd)
+                T.conv_s2(T.S2_DGRAD, d_c, pk, 4 * m.in_channels, dx, Cph=m.in_channels, residual=tap if tap_ok else None,
+                          mask=src if i == 1 else None, mask_slope=0.2, name=conv.name + ".dgrad",
+                          flops=2.0 * d_c.N * d_c.H * d_c.W * m.out_channels * m.in_channels * 16)
+                if tap is not None and not tap_ok:
+                    raise AssertionError("PatchGAN bf16 path: feature-matching tap of an unexpected shape")
+                tap_in_dnext = tap is not None      # (for i == 1 the sum is already multiplied by LeakyReLU'(f0))
+                d_next = dx
+                continue
+            # model0 (its LeakyReLU derivative was applied by model1's data gradient)
+            a2 = c["a2"]
+            w = conv.wparam.data
+            Cout, cin = w.shape[0], w.shape[1]
+            if d_next is None or d is not d_next:      # (a tap of f0 was summed, and LeakyReLU'(f0) applied, by model1's data gradient)
+                raise AssertionError("PatchGAN bf16 path: model0's output gradient comes from model1's data gradient")
+            if need_w:
+                dw2 = torch.empty_like(conv._w2)
+                db = grad_buffer(conv.bparam) if conv.bparam is not None else None
+                T.conv_wgrad(d, a2, 0, 0, 4 * conv.Cq, 2, 2, 1, 1, dw2.view(Cout, 4 * conv.Cq, 2, 2), name=conv.name + ".wgrad", dbias=db)
+                G = dw2[:, :, :, :cin].permute(0, 3, 4, 1, 5, 2).reshape(Cout, cin, 4, 4)      # back to (co, c, kh, kw)
+                param_grads(conv, G)
+                if db is not None:
+                    _acc(grads, conv.bparam, db)
+            d_next = None
+            if need_dx:
+                d2 = T.conv_dgrad(d, conv.w2, a2.H, a2.W, 1, 1, sigma=conv.sigma, name=conv.name + ".dgrad",
+                                  batch=getattr(conv, "pack_batch", None))
+                d_next = T.depth_to_space2(d2, c["src"].C)
+        return d_next
+
     def forward(self, a: Act, power_iteration: bool, prepared: bool = False):
         feats, ctx = [], []
         if not prepared:
@@ -889,6 +1032,8 @@ class DiscTrainPlan:
             T.prepare_convs(self, [conv for _, conv in self.layers], power_iteration)
         own = getattr(self, "own_step", True)      # (False: the generator step's pass through D -- its parameter gradients are discarded)
         sc = getattr(self, "scale_index", 0)
+        if self._s2_chain(a, own, sc):
+            return self._forward_s2(a)
         for li, (kind, conv) in enumerate(self.layers):
             if kind in ("in", "in_drop"):
                 with _EngineMode(_d_f32(li, "fwd", own, sc)):
@@ -923,6 +1068,8 @@ class DiscTrainPlan:
             if rows is None or a is None:
                 return a
             return Act(a.t[:rows], a.C, a.coff) if isinstance(a, Act) else a[:rows]
+        if ctx and ctx[0].get("s2"):
+            return self._backward_s2(ctx, dfeats, grads, need_dx, rows, need_w)
         d_next: Optional[Act] = None   # gradient flowing back into feats[i] from layer i+1
         tap_in_dnext = False           # dfeats[i] already summed into d_next by layer i+1's data-gradient epilogue
         for i in range(len(self.layers) - 1, -1, -1):

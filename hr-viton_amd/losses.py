@@ -26,7 +26,10 @@ class _LossFn(torch.autograd.Function):
             bc = None if b is None else b.detach().contiguous()
         n = ac.numel()
         out = torch.zeros(1, dtype=torch.float32, device=a.device)
-        grad = T.loss(ac, bc, mode, 1.0 / n, 1.0 / n, out, accumulate=False, want_grad=ctx.needs_input_grad[0])
+        # (a bf16-stored operand -- the PatchGAN's feature taps in mixed precision -- gets its gradient in bf16 as well: autograd
+        #  wants the input's dtype back, and the data gradient that adds it reads half the bytes)
+        grad = T.loss(ac, bc, mode, 1.0 / n, 1.0 / n, out, accumulate=False, want_grad=ctx.needs_input_grad[0],
+                      grad_bf16=ac.dtype == torch.bfloat16)
         ctx.grad = grad
         return out
 

@@ -705,6 +705,9 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
                                                     _stream()), f"hrv_conv_cout1_wgrad_f32[{name}]")
         return
     wo_real = Wo
+    if MMA_BF16[0] and Wo % 4 != 0 and dy.bf16 and x.bf16 and dy.coff == 0 and dy.cstride == dy.C and dy.C % 8 == 0:
+        dy = pad_width_bf16(dy)          # (the same zero columns for a bf16-stored dY: the PatchGAN with bf16 feature maps)
+        Wo = dy.W
     if (MMA_BF16[0] and Wo % 4 != 0 and Wo >= 32 and not (x.bf16 or dy.bf16) and dy.coff == 0 and dy.cstride == dy.Cp):
         # odd-sized maps (the PatchGAN's 513 / 257 / 129 columns): the bf16 matrix-core kernel stages quads of 4 pixels
         # of one image row, so dY gets zero columns up to the next multiple of 4 -- they add nothing to dW or the bias
@@ -1111,8 +1114,8 @@ def act_bwd_(d: Act, y: Act, act: int, slope: float = 0.2):
 
 def scale_(x: torch.Tensor, s_host: float = 1.0, s_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     lib = _lib.load()
-    _lib.check(lib.hrv_scale_f32(x.data_ptr(), x.numel(), s_host, None if s_dev is None else s_dev.data_ptr(), _stream()),
-               "hrv_scale_f32")
+    fn = lib.hrv_scale_bf16 if x.dtype == torch.bfloat16 else lib.hrv_scale_f32      # (a bf16 loss gradient: PatchGAN feature taps)
+    _lib.check(fn(x.data_ptr(), x.numel(), s_host, None if s_dev is None else s_dev.data_ptr(), _stream()), "hrv_scale_f32")
     return x
 
 
@@ -1452,3 +1455,95 @@ def conv_p2(src: Act, packed: torch.Tensor, cols: int, out: Act, bias: Optional[
     with ops._Timed("conv", name + tag, flops, nb, "conv_p2_kernel"):
         _lib.check(lib.hrv_conv_p2_bf16(C.byref(d), _stream()), f"hrv_conv_p2_bf16[{name}]")
     return out
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# csrc/conv_s2.hip -- PatchGAN's 4x4 stride-2 pad-2 convolution over a bf16-stored feature map, and its data gradient
+# (NLayerDiscriminator, network_generator.py:263-272)
+# ---------------------------------------------------------------------------------------------------------------
+S2_FWD, S2_DGRAD, S2_CELLS = 0, 1, 2
+
+
+def conv_s2_ok(mode: int, K: int, cols: int, Cph: int, N: int, Ho: int, Wo: int) -> bool:
+    """hrv_conv_s2_supported (HRV_CONV_S2=0 switches the kernel off for A/B runs)."""
+    if os.environ.get("HRV_CONV_S2", "1") == "0":
+        return False
+    return bool(_lib.load().hrv_conv_s2_supported(mode, K, cols, Cph, N, Ho, Wo))
+
+
+def conv_s2_pack(mode: int, w: torch.Tensor, K: int, cols: int, Cph: int = 0, sigma: Optional[torch.Tensor] = None,
+                 wscale: float = 1.0) -> torch.Tensor:
+    """The bf16 fragment-order weight stream of hrv_conv_s2_bf16: mode S2_FWD (w = the layer's OIHW [cols][K][4][4]), S2_DGRAD (w = the
+    forward OIHW [K][Cph][4][4], cols = 4 Cph) or S2_CELLS (w = [cols][K][2][2] over a space-to-depth source)."""
+    lib = _lib.load()
+    assert w.is_contiguous() and w.dtype == torch.float32
+    nbytes = lib.hrv_conv_s2_packed_bytes(mode, K, cols)
+    assert nbytes > 0, (mode, K, cols)
+    buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
+    _lib.check(lib.hrv_conv_s2_pack_dev(mode, w.data_ptr(), K, cols, Cph, None if sigma is None else sigma.data_ptr(), wscale,
+                                        buf.data_ptr(), _stream()), "hrv_conv_s2_pack_dev")
+    return buf
+
+
+def conv_s2(mode: int, src: Act, packed: torch.Tensor, cols: int, out: Act, Cph: int = 0, bias: Optional[torch.Tensor] = None,
+            act: int = ACT_NONE, slope: float = 0.2, residual: Optional[Act] = None, mask: Optional[Act] = None, mask_slope: float = 0.0,
+            name: str = "conv", flops: float = 0.0):
+    """out = act(conv(src) + bias [+ residual]) [* (mask > 0 ? 1 : mask_slope)] on csrc/conv_s2.hip (see hrv_conv_s2_t)."""
+    lib = _lib.load()
+    assert src.bf16 and out.C == (Cph if mode == S2_DGRAD else cols), (out.C, cols, Cph)
+    d = _lib.hrv_conv_s2_t()
+    d.mode, d.N, d.Hs, d.Ws, d.K = mode, src.N, src.H, src.W, src.C
+    d.src, d.src_cstride, d.src_coff = src.t.data_ptr(), src.cstride, src.coff
+    d.Ho, d.Wo, d.cols, d.Cph = out.H, out.W, cols, Cph
+    d.w_packed = packed.data_ptr()
+    if bias is not None:
+        d.bias = bias.data_ptr()
+    d.act, d.act_slope = act, slope
+    d.out, d.out_cstride, d.out_coff, d.out_f32 = out.t.data_ptr(), out.cstride, out.coff, 0 if out.bf16 else 1
+    if residual is not None:
+        assert residual.C == out.C and (residual.N, residual.H, residual.W) == (out.N, out.H, out.W)
+        d.residual, d.res_cstride, d.res_coff, d.res_f32 = residual.t.data_ptr(), residual.cstride, residual.coff, 0 if residual.bf16 else 1
+    if mask is not None:
+        assert mask.bf16 and mask.C == out.C and (mask.N, mask.H, mask.W) == (out.N, out.H, out.W)
+        d.mask, d.mask_cstride, d.mask_coff, d.mask_slope = mask.t.data_ptr(), mask.cstride, mask.coff, mask_slope
+    nb = (ops.act_bytes(src) + ops.act_bytes(out) + (ops.act_bytes(mask) if mask is not None else 0.0) +
+          (ops.act_bytes(residual) if residual is not None else 0.0) + 2.0 * src.C * cols * (16 if mode == S2_FWD else 4))
+    with ops._Timed("conv", name, flops, nb, "conv_s2_kernel"):
+        _lib.check(lib.hrv_conv_s2_bf16(C.byref(d), _stream()), f"hrv_conv_s2_bf16[{name}]")
+    return out
+
+
+def space_to_depth2_bf16(a: Act) -> Act:
+    """[N,H,W,C] fp32 -> dense bf16 [N,H/2,W/2,4*Cp], channel ((y&1)*2 + (x&1))*Cp + c (hrv_space_to_depth2_nhwc_bf16)."""
+    lib = _lib.load()
+    assert not a.bf16 and a.H % 2 == 0 and a.W % 2 == 0
+    out = torch.empty((a.N, a.H // 2, a.W // 2, 4 * a.Cp), dtype=torch.bfloat16, device=a.t.device)
+    with _Timed("layout", "space_to_depth2", 0.0, 1.5 * ops.act_bytes(a)):
+        _lib.check(lib.hrv_space_to_depth2_nhwc_bf16(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, out.data_ptr(), _stream()),
+                   "hrv_space_to_depth2_nhwc_bf16")
+    return Act(out, 4 * a.Cp)
+
+
+def instnorm_apply_bf16(a: Act, mean: torch.Tensor, rstd: torch.Tensor, act: int = ACT_NONE, slope: float = 0.2) -> Act:
+    """lrelu((a - mean) * rstd) of an fp32 ``a`` stored in bf16 (a feature map that only matrix cores and the L1 tap read)."""
+    lib = _lib.load()
+    assert not a.bf16 and a.C % 8 == 0
+    out = ops.alloc(a.N, a.H, a.W, a.C, a.t.device, bf16=True)
+    with _Timed("apply", "instnorm_apply", 0.0, 6.0 * a.N * a.H * a.W * a.Cp):
+        _lib.check(lib.hrv_instnorm_apply_nhwc_bf16out(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, mean.data_ptr(), rstd.data_ptr(),
+                                                       act, slope, out.t.data_ptr(), out.cstride, out.coff, _stream()),
+                   "hrv_instnorm_apply_nhwc_bf16out")
+    return out
+
+
+def pad_width_bf16(a: Act, mult: int = 4) -> Act:
+    """A dense bf16 activation with zero columns appended up to a multiple of ``mult`` (conv_wgrad's quad staging of dY)."""
+    lib = _lib.load()
+    assert a.bf16 and a.coff == 0 and a.cstride == a.C and a.C % 8 == 0 and a.t.is_contiguous()
+    Wp = (a.W + mult - 1) // mult * mult
+    if Wp == a.W:
+        return a
+    out = torch.empty((a.N, a.H, Wp, a.C), dtype=torch.bfloat16, device=a.t.device)
+    with _Timed("layout", "pad_width", 0.0, 2.0 * ops.act_bytes(a)):
+        _lib.check(lib.hrv_pad_width_nhwc_bf16(a.t.data_ptr(), a.N * a.H, a.W, a.C, Wp, out.data_ptr(), _stream()), "hrv_pad_width_nhwc_bf16")
+    return Act(out, a.C)

@@ -804,6 +804,45 @@ int hrv_conv_p2_pack_dev(int32_t mode, const float* w, const float* w2, int32_t 
                          void* out, hrv_stream_t stream);
 int hrv_conv_p2_bf16(const hrv_conv_p2_t* d, hrv_stream_t stream);
 
+/* PatchGAN's 4x4 stride-2 pad-2 convolution over a bf16-stored NHWC feature map, and its data gradient, as ONE launch family
+ * on the two-blocks-per-CU skeleton of hrv_conv_p2_bf16 (conv_s2.hip; NLayerDiscriminator, network_generator.py:263-272:
+ * nn.Conv2d(nf_prev, nf, kernel_size=4, stride=2, padding=2) and autograd's gradient w.r.t. its input).
+ *   mode 0  forward: src [N][Hs][Ws][K] -> out [N][Ho = Hs/2+1][Wo = Ws/2+1][cols]; w = the layer's OIHW weight [cols][K][4][4].
+ *   mode 1  data gradient: src = dY [N][Hs][Ws][K] (K = the forward layer's OUTPUT channels) -> out = dX [N][Ho][Wo][Cph]
+ *           (Hs = Ho/2+1), cols = 4 * Cph (the four output phases are column passes); w = the forward OIHW weight [K][Cph][4][4].
+ *   mode 2  a 2x2 stride-1 convolution, pad 1 on top / left only: src = a space-to-depth image [N][Hs][Ws][K] -> out
+ *           [N][Ho in {Hs, Hs+1}][Wo ...][cols]; w = [cols][K][2][2] (PatchGAN's model0: 10 channels -> 4 x 12 per cell).
+ *   out = act(conv + bias[c] [+ residual]) [* (mask > 0 ? 1 : mask_slope)]; residual / mask: slices shaped like `out`.
+ * K % 8 == 0 (mode 0: % 32), cols % 64 == 0, Cph % 32 == 0.  w_packed from hrv_conv_s2_pack_dev of the same (mode, K, cols, Cph). */
+typedef struct hrv_conv_s2 {
+  int32_t mode;
+  int32_t N, Hs, Ws, K;
+  const void* src; int32_t src_cstride, src_coff;
+  int32_t Ho, Wo, cols, Cph;
+  const void* w_packed;
+  const float* bias;
+  int32_t act; float act_slope;
+  void* out; int32_t out_cstride, out_coff, out_f32;
+  const void* residual; int32_t res_cstride, res_coff, res_f32;
+  const void* mask; int32_t mask_cstride, mask_coff; float mask_slope;
+} hrv_conv_s2_t;
+int64_t hrv_conv_s2_packed_bytes(int32_t mode, int32_t K, int32_t cols);   /* -1: shape not served */
+int hrv_conv_s2_supported(int32_t mode, int32_t K, int32_t cols, int32_t Cph, int32_t N, int32_t Ho, int32_t Wo);
+int hrv_conv_s2_pack_dev(int32_t mode, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
+                         void* out, hrv_stream_t stream);
+int hrv_conv_s2_bf16(const hrv_conv_s2_t* d, hrv_stream_t stream);
+/* bf16-storage companions of hrv_conv_s2_bf16 (the PatchGAN with bf16-stored feature maps): the space-to-depth image of model0's
+ * input written in bf16 (cf. hrv_space_to_depth2_nhwc_f32), InstanceNorm2d(affine=False) + LeakyReLU written in bf16
+ * (cf. hrv_instnorm_apply_nhwc_f32; network_generator.py:268-269), x *= s_host * (s_dev ? s_dev[0] : 1) over a bf16 loss gradient
+ * (cf. hrv_scale_f32), and out[r][w] = w < W ? in[r][w] : 0 for a dY whose width the quad-staged weight gradient needs padded to 4. */
+int hrv_space_to_depth2_nhwc_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
+                                  int32_t in_coff, uint16_t* out, hrv_stream_t stream);
+int hrv_instnorm_apply_nhwc_bf16out(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
+                                    const float* mean, const float* rstd, int32_t act, float act_slope, uint16_t* out,
+                                    int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
+int hrv_scale_bf16(uint16_t* x, int64_t n, float s_host, const float* s_dev, hrv_stream_t stream);
+int hrv_pad_width_nhwc_bf16(const uint16_t* in, int64_t rows, int32_t W, int32_t C, int32_t Wp, uint16_t* out, hrv_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif
