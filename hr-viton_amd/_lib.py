@@ -40,7 +40,8 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p),
                 ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32), ("dx_bf16", C.c_int32), ("g1p_bf16", C.c_int32),
                 ("dnh_bf16", C.c_int32), ("dout_bf16", C.c_int32),
-                ("x_up_channels", C.c_int32), ("x2", C.c_void_p), ("x2_cstride", C.c_int32), ("x2_coff", C.c_int32)]
+                ("x_up_channels", C.c_int32), ("x2", C.c_void_p), ("x2_cstride", C.c_int32), ("x2_coff", C.c_int32),
+                ("x_bf16", C.c_int32)]
 
 
 class hrv_sn_job_t(C.Structure):
@@ -291,6 +292,7 @@ SYMBOLS = {
     "hrv_space_to_depth2_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_instnorm_apply_nhwc_bf16out": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32, _i32, _vp]),
     "hrv_scale_bf16": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
+    "hrv_split3_nhwc_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hrv_pad_width_nhwc_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hrv_spade_fused_packed_bytes": (C.c_int64, [_i32]),
     "hrv_spade_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),

@@ -125,6 +125,7 @@ static bool s2_plan(int mode, int K, int cols, S2Plan& pl) {
 struct S2PackParams {
   S2Plan pl;
   int mode, K, cols, Cph;
+  int split3;             // modes 0 / 2: K = 3 K0 over a source [hi | lo | hi]; weight thirds [hi(w) | hi(w) | w - hi(w)] of the K0-channel w
   const float* w;
   const float* sigma;     // optional: weights are divided by sigma[0] (spectral norm)
   float wscale;
@@ -154,19 +155,29 @@ __global__ __launch_bounds__(256) void s2_pack_kernel(const S2PackParams p) {
 #pragma unroll
   for (int e = 0; e < 8; ++e) {
     float w = 0.f;
+    int third = 0;
     if (col < p.cols) {
       if (p.mode == 0) {
         const int sub = chunk / cpc, c = (chunk - sub * cpc) * 32 + kk0 + e;
-        if (c < p.K) w = p.w[(((size_t)col * p.K + c) * 4 + 2 * a + (sub >> 1)) * 4 + 2 * b + (sub & 1)];
+        if (c < p.K) {
+          const int K0 = p.split3 ? p.K / 3 : p.K, c0 = p.split3 ? c % K0 : c;
+          w = p.w[(((size_t)col * K0 + c0) * 4 + 2 * a + (sub >> 1)) * 4 + 2 * b + (sub & 1)];
+          third = p.split3 ? c / K0 : 0;
+        }
       } else if (p.mode == 1) {
         const int k = chunk * 32 + kk0 + e, ph = col / p.Cph, ci = col - ph * p.Cph;
         if (k < p.K) w = p.w[(((size_t)k * p.Cph + ci) * 4 + 2 * (1 - a) + (ph >> 1)) * 4 + 2 * (1 - b) + (ph & 1)];
       } else {
         const int k = chunk * 32 + kk0 + e;
-        if (k < p.K) w = p.w[(((size_t)col * p.K + k) * 2 + a) * 2 + b];
+        if (k < p.K) {
+          const int K0 = p.split3 ? p.K / 3 : p.K, k0 = p.split3 ? k % K0 : k;
+          w = p.w[(((size_t)col * K0 + k0) * 2 + a) * 2 + b];
+          third = p.split3 ? k / K0 : 0;
+        }
       }
     }
-    v[e] = f2bf(w * sc);
+    const float ws = w * sc;
+    v[e] = third == 2 ? f2bf(ws - bf2f(f2bf(ws))) : f2bf(ws);
   }
   uint4 o;
   o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
@@ -605,15 +616,18 @@ extern "C" int hrv_conv_s2_supported(int32_t mode, int32_t K, int32_t cols, int3
   return 4 * units >= q4 * (int64_t)persistent_cus() ? 1 : 0;
 }
 
-extern "C" int hrv_conv_s2_pack_dev(int32_t mode, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
+extern "C" int hrv_conv_s2_pack_dev(int32_t mode_flags, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
                                     void* out, hrv_stream_t stream) {
   HRV_REQUIRE(w && out, "conv_s2_pack: null pointer");
+  const int mode = mode_flags & 3, split3 = (mode_flags & HRV_S2_SPLIT3) ? 1 : 0;
+  HRV_REQUIRE(!split3 || (mode != 1 && K % 3 == 0 && (K / 3) % 8 == 0 && (mode != 0 || (K / 3) % 32 == 0)),
+              "conv_s2_pack: split3 is for modes 0 / 2, K = 3 x (a multiple of 8; mode 0: of 32) (mode %d, K %d)", mode, K);
   S2PackParams pp;
   HRV_REQUIRE(s2_plan(mode, K, cols, pp.pl), "conv_s2_pack: unsupported shape (mode %d, K %d, columns %d)", mode, K, cols);
   HRV_REQUIRE(mode != 0 || K % 32 == 0, "conv_s2_pack: forward K must be a multiple of 32 (got %d)", K);
   HRV_REQUIRE(mode != 1 || (Cph >= 32 && Cph % 32 == 0 && cols == 4 * Cph), "conv_s2_pack: data gradient columns = 4 x Cph (Cph %d, columns %d)", Cph, cols);
   HRV_REQUIRE(((uintptr_t)out & 15) == 0, "conv_s2_pack: out must be 16-byte aligned");
-  pp.mode = mode; pp.K = K; pp.cols = cols; pp.Cph = Cph > 0 ? Cph : 1;
+  pp.mode = mode; pp.K = K; pp.cols = cols; pp.Cph = Cph > 0 ? Cph : 1; pp.split3 = split3;
   pp.w = w; pp.sigma = sigma; pp.wscale = wscale; pp.out = (unsigned short*)out;
   const long long groups = pp.pl.bytes / 16;
   hipLaunchKernelGGL(s2_pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pp);
@@ -760,6 +774,31 @@ __global__ void pad_width_bf16_kernel(const uint4* __restrict__ in, size_t rows,
   }
 }
 
+// out[p][0:C] = hi(x), out[p][C:2C] = bf16(x - hi(x)), out[p][2C:3C] = hi(x): the operand layout of a convolution that multiplies the
+// three products hi*hi + lo*hi + hi*lo on the bf16 matrix cores (~16 mantissa bits)
+__global__ void split3_bf16_kernel(const float* __restrict__ x, size_t npix, int C4, int cs, int co, unsigned short* __restrict__ out) {
+  const size_t total = npix * C4;
+  const int C = C4 * 4;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int g = (int)(i % C4);
+    const size_t pix = i / C4;
+    const f32x4 v = *reinterpret_cast<const f32x4*>(x + pix * cs + co + g * 4);
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = f2bf(v[e]);
+      l[e] = f2bf(v[e] - bf2f(h[e]));
+    }
+    uint2 hh, ll;
+    hh.x = h[0] | ((unsigned)h[1] << 16); hh.y = h[2] | ((unsigned)h[3] << 16);
+    ll.x = l[0] | ((unsigned)l[1] << 16); ll.y = l[2] | ((unsigned)l[3] << 16);
+    unsigned short* o = out + pix * (3 * (size_t)C) + g * 4;
+    *reinterpret_cast<uint2*>(o) = hh;
+    *reinterpret_cast<uint2*>(o + C) = ll;
+    *reinterpret_cast<uint2*>(o + 2 * C) = hh;
+  }
+}
+
 static inline int s2_grid_for(size_t work) {
   size_t g = (work + 255) / 256;
   const size_t cap = 256 * 16;
@@ -805,4 +844,13 @@ extern "C" int hrv_pad_width_nhwc_bf16(const uint16_t* in, int64_t rows, int32_t
   hipLaunchKernelGGL(pad_width_bf16_kernel, dim3(s2_grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const uint4*)in, (size_t)rows, W, Wp, C / 8,
                      (uint4*)out);
   return check_launch("pad_width_bf16_kernel");
+}
+
+extern "C" int hrv_split3_nhwc_bf16(const float* x, int64_t npix, int32_t C, int32_t cstride, int32_t coff, uint16_t* out, hrv_stream_t stream) {
+  HRV_REQUIRE(x && out && npix > 0 && C > 0 && C % 4 == 0 && cstride % 4 == 0 && coff % 4 == 0 && coff + C <= cstride &&
+                  ((uintptr_t)x & 15) == 0 && ((uintptr_t)out & 7) == 0,
+              "split3: 4-channel granules");
+  hipLaunchKernelGGL(split3_bf16_kernel, dim3(s2_grid_for((size_t)npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, (size_t)npix, C / 4, cstride,
+                     coff, out);
+  return check_launch("split3_bf16_kernel");
 }

@@ -553,7 +553,11 @@ class BlockT:
             x_s = x
             z_0 = next(zi)
         h0, ctx["n0"] = self.n0.forward(x, next(ai), z_0, save, fused, st_0)
-        dx = self.c0.forward([(h0, 0)])
+        # conv_0's output feeds norm_1 only (its statistics, the fused SPADE epilogue, the normalisation backward): stored in bf16
+        # where those readers take it -- what autocast leaves a half-precision convolution's output as (HRV_DX_BF16=0: fp32)
+        dx16 = bool(T.MMA_BF16[0] and fused is not None and h0.bf16 and self.c0.conv.out_channels % 8 == 0 and
+                    os.environ.get("HRV_DX_BF16", "1") != "0")
+        dx = self.c0.forward([(h0, 0)], out_bf16=dx16)
         h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi), save, fused)
         # the last block's activated output only feeds conv_img (matrix cores + the sign mask of its data gradient)
         o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up,
@@ -896,7 +900,12 @@ class DiscTrainPlan:
         c0 = self.layers[0][1]
         if not isinstance(c0, S2DConv) or c0._w2 is None or a.H % 2 or a.W % 2 or a.Cp != c0.Cq:
             return False
-        if any(_d_f32(li, part, own, sc) for li in range(len(self.layers)) for part in ("fwd", "bwd")):
+        if any(_d_f32(li, "bwd", own, sc) for li in range(len(self.layers))):
+            return False
+        split = [_d_f32(li, "fwd", own, sc) for li in range(len(self.layers))]
+        # a forward kept on fp32 operands runs as three bf16 products over split operands (hi*hi + lo*hi + hi*lo: ~16 mantissa
+        # bits; HRV_D_SPLIT3=0: such a scale stays on the fp32-stored path and the fp32 matrix-core engine)
+        if any(split) and (os.environ.get("HRV_D_SPLIT3", "1") == "0" or (4 * c0.Cq) % 8 or c0.Cq % 2):
             return False
         H, W, N = a.H // 2 + 1, a.W // 2 + 1, a.N
         cin = c0.conv.out_channels
@@ -913,37 +922,54 @@ class DiscTrainPlan:
             H, W, cin = Ho, Wo, m.out_channels
         return True
 
-    def _forward_s2(self, a: Act):
+    def _forward_s2(self, a: Act, own: bool, sc: int):
         """The scale's forward with f0, f1, ... stored in bf16 (the last InstanceNorm output stays fp32: the one-channel
-        convolution behind it is a dot-product kernel over fp32)."""
+        convolution behind it is a dot-product kernel over fp32).  A layer _d_f32 keeps on fp32 operands reads its source as
+        [hi | lo | hi] (T.split3 of the fp32 feature in front of it) against weights packed [hi | hi | lo]; the backward's bf16
+        operand of that feature is the hi third."""
         feats, ctx = [], []
         n_in = len(self.layers) - 2
+        split = [_d_f32(li, "fwd", own, sc) for li in range(len(self.layers))]
+        sbf = None            # the bf16 operand of the feature in front of the current layer (bf16 Act, or the hi third of its split)
         for li, (kind, conv) in enumerate(self.layers):
             b = conv.bparam
             bias = None if b is None else b.data
+            nxt_split = li + 1 < len(self.layers) - 1 and split[li + 1]        # the next 4x4 stride-2 layer reads split operands
             if li == 0:
-                a2 = T.space_to_depth2_bf16(a)
-                Cout = conv.conv.out_channels
-                f = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device, bf16=True)
-                pk = T.conv_s2_pack(T.S2_CELLS, conv.w2, 4 * conv.Cq, Cout, sigma=conv.sigma)
-                T.conv_s2(T.S2_CELLS, a2, pk, Cout, f, bias=bias, act=ACT_LRELU, slope=0.2, name=conv.name,
-                          flops=2.0 * f.N * f.H * f.W * Cout * conv.conv.in_channels * 16)
+                Cout, K0 = conv.conv.out_channels, 4 * conv.Cq
+                if split[0]:
+                    a2s = T.split3(T.space_to_depth2(a))
+                    a2, src2 = Act(a2s.t, K0, 0), a2s
+                else:
+                    a2 = src2 = T.space_to_depth2_bf16(a)
+                f = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device, bf16=not nxt_split)
+                pk = T.conv_s2_pack(T.S2_CELLS, conv.w2, src2.C, Cout, sigma=conv.sigma, split3=split[0])
+                T.conv_s2(T.S2_CELLS, src2, pk, Cout, f, bias=bias, act=ACT_LRELU, slope=0.2, name=conv.name,
+                          flops=2.0 * f.N * f.H * f.W * Cout * conv.conv.in_channels * 16 * (3 if split[0] else 1))
                 ctx.append(dict(src=a, a2=a2, f=f, s2=True))
             elif kind == "in":
                 Cout, cin = conv.conv.out_channels, conv.conv.in_channels
                 c = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device)
-                pk = T.conv_s2_pack(T.S2_FWD, conv.wparam.data, cin, Cout, sigma=conv.sigma)
-                T.conv_s2(T.S2_FWD, a, pk, Cout, c, bias=bias, name=conv.name, flops=2.0 * c.N * c.H * c.W * Cout * cin * 16)
+                pk = T.conv_s2_pack(T.S2_FWD, conv.wparam.data, src.C, Cout, sigma=conv.sigma, split3=split[li])
+                T.conv_s2(T.S2_FWD, src, pk, Cout, c, bias=bias, name=conv.name,
+                          flops=2.0 * c.N * c.H * c.W * Cout * cin * 16 * (3 if split[li] else 1))
                 mean, rstd = ops.instnorm_stats(c)
-                if li < n_in:
+                if li < n_in and not nxt_split:
                     f = T.instnorm_apply_bf16(c, mean, rstd, ACT_LRELU, 0.2)
                 else:
                     f = ops.instnorm_apply(c, mean, rstd, ACT_LRELU, 0.2)
-                ctx.append(dict(src=a, c=c, mean=mean, rstd=rstd, f=f, s2=True))
+                ctx.append(dict(src=sbf, c=c, mean=mean, rstd=rstd, f=f, s2=True))
             else:
-                f = conv.forward([(a, 0)], act=ACT_NONE)
+                with _EngineMode(split[li]):
+                    f = conv.forward([(a, 0)], act=ACT_NONE)
                 ctx.append(dict(src=a, f=f))
             feats.append(f)
+            # what the next layer multiplies / the backward reads as this feature's bf16 operand
+            if nxt_split:
+                src = T.split3(f)
+                sbf = Act(src.t, f.C, 0)
+            else:
+                src = sbf = f
             a = f
         return feats, ctx
 
@@ -1033,7 +1059,7 @@ class DiscTrainPlan:
         own = getattr(self, "own_step", True)      # (False: the generator step's pass through D -- its parameter gradients are discarded)
         sc = getattr(self, "scale_index", 0)
         if self._s2_chain(a, own, sc):
-            return self._forward_s2(a)
+            return self._forward_s2(a, own, sc)
         for li, (kind, conv) in enumerate(self.layers):
             if kind in ("in", "in_drop"):
                 with _EngineMode(_d_f32(li, "fwd", own, sc)):

@@ -772,6 +772,7 @@ def _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, wa
         d.x_up_channels, d.x2, d.x2_cstride, d.x2_coff = x.lo.C, x.hi.t.data_ptr(), x.hi.cstride, x.hi.coff
     else:
         d.x, d.x_cstride, d.x_coff = x.t.data_ptr(), x.cstride, x.coff
+        d.x_bf16 = 1 if x.bf16 else 0
     if z is not None:
         d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
     d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()
@@ -1472,17 +1473,30 @@ def conv_s2_ok(mode: int, K: int, cols: int, Cph: int, N: int, Ho: int, Wo: int)
 
 
 def conv_s2_pack(mode: int, w: torch.Tensor, K: int, cols: int, Cph: int = 0, sigma: Optional[torch.Tensor] = None,
-                 wscale: float = 1.0) -> torch.Tensor:
+                 wscale: float = 1.0, split3: bool = False) -> torch.Tensor:
     """The bf16 fragment-order weight stream of hrv_conv_s2_bf16: mode S2_FWD (w = the layer's OIHW [cols][K][4][4]), S2_DGRAD (w = the
-    forward OIHW [K][Cph][4][4], cols = 4 Cph) or S2_CELLS (w = [cols][K][2][2] over a space-to-depth source)."""
+    forward OIHW [K][Cph][4][4], cols = 4 Cph) or S2_CELLS (w = [cols][K][2][2] over a space-to-depth source).  ``split3`` (S2_FWD /
+    S2_CELLS): K = 3 x w's input channels, for a source from ``split3`` -- HRV_S2_SPLIT3 in the header."""
     lib = _lib.load()
     assert w.is_contiguous() and w.dtype == torch.float32
     nbytes = lib.hrv_conv_s2_packed_bytes(mode, K, cols)
     assert nbytes > 0, (mode, K, cols)
     buf = torch.empty(nbytes // 2, dtype=torch.bfloat16, device=w.device)
-    _lib.check(lib.hrv_conv_s2_pack_dev(mode, w.data_ptr(), K, cols, Cph, None if sigma is None else sigma.data_ptr(), wscale,
-                                        buf.data_ptr(), _stream()), "hrv_conv_s2_pack_dev")
+    _lib.check(lib.hrv_conv_s2_pack_dev(mode | (4 if split3 else 0), w.data_ptr(), K, cols, Cph, None if sigma is None else sigma.data_ptr(),
+                                        wscale, buf.data_ptr(), _stream()), "hrv_conv_s2_pack_dev")
     return buf
+
+
+def split3(a: Act) -> Act:
+    """fp32 activation -> dense bf16 [hi | lo | hi] (3 C channels, hrv_split3_nhwc_bf16): the source of a convolution packed with
+    ``split3`` -- hi*hi + lo*hi + hi*lo on the bf16 matrix cores."""
+    lib = _lib.load()
+    assert not a.bf16 and a.C % 4 == 0
+    out = torch.empty((a.N, a.H, a.W, 3 * a.C), dtype=torch.bfloat16, device=a.t.device)
+    with _Timed("layout", "split3", 0.0, 2.5 * ops.act_bytes(a)):
+        _lib.check(lib.hrv_split3_nhwc_bf16(a.t.data_ptr(), a.N * a.H * a.W, a.C, a.cstride, a.coff, out.data_ptr(), _stream()),
+                   "hrv_split3_nhwc_bf16")
+    return Act(out, 3 * a.C)
 
 
 def conv_s2(mode: int, src: Act, packed: torch.Tensor, cols: int, out: Act, Cph: int = 0, bias: Optional[torch.Tensor] = None,

@@ -295,6 +295,8 @@ typedef struct hrv_norm_bwd {
    * at (h >> 1, w >> 1), the remaining C - x_up_channels from `x2` = hi [N][H][W][x2_cstride] */
   int32_t x_up_channels;
   const float* x2;    int32_t x2_cstride, x2_coff;
+  int32_t x_bf16;     /* 1: `x` is stored as bf16 (element strides / offsets; never with x_up_channels): the output of a convolution
+                       * inside a SPADEResBlock in mixed precision -- what autocast leaves a half-precision convolution's output as */
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 
@@ -826,6 +828,10 @@ typedef struct hrv_conv_s2 {
   const void* residual; int32_t res_cstride, res_coff, res_f32;
   const void* mask; int32_t mask_cstride, mask_coff; float mask_slope;
 } hrv_conv_s2_t;
+#define HRV_S2_SPLIT3 4   /* or-ed into hrv_conv_s2_pack_dev's mode (0 / 2): K = 3 K0 over a source laid out [hi | lo | hi]
+                           * (hrv_split3_nhwc_bf16), w has K0 input channels and is packed as [hi(w) | hi(w) | w - hi(w)]: the
+                           * convolution sums hi*hi + lo*hi + hi*lo -- fp32 operands to ~16 mantissa bits on the bf16 matrix cores
+                           * (the half-resolution PatchGAN scale in D's own step, gen_train._d_f32) */
 int64_t hrv_conv_s2_packed_bytes(int32_t mode, int32_t K, int32_t cols);   /* -1: shape not served */
 int hrv_conv_s2_supported(int32_t mode, int32_t K, int32_t cols, int32_t Cph, int32_t N, int32_t Ho, int32_t Wo);
 int hrv_conv_s2_pack_dev(int32_t mode, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
@@ -841,6 +847,8 @@ int hrv_instnorm_apply_nhwc_bf16out(const float* x, int32_t N, int32_t H, int32_
                                     const float* mean, const float* rstd, int32_t act, float act_slope, uint16_t* out,
                                     int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);
 int hrv_scale_bf16(uint16_t* x, int64_t n, float s_host, const float* s_dev, hrv_stream_t stream);
+/* out[p] = [hi(x[p]) | bf16(x[p] - hi(x[p])) | hi(x[p])] (3 C bf16 channels, dense) of an fp32 NHWC slice: see HRV_S2_SPLIT3 */
+int hrv_split3_nhwc_bf16(const float* x, int64_t npix, int32_t C, int32_t cstride, int32_t coff, uint16_t* out, hrv_stream_t stream);
 int hrv_pad_width_nhwc_bf16(const uint16_t* in, int64_t rows, int32_t W, int32_t C, int32_t Wp, uint16_t* out, hrv_stream_t stream);
 
 #ifdef __cplusplus

@@ -101,3 +101,39 @@ def test_cells_form_matches_torch(Cin, Cout, N, H, W):
     got = out.t.float()
     tol = want.abs() * 2 ** -8 + 2e-4 * float(want.abs().max())
     assert bool(((got - want).abs() <= tol).all()), float((got - want).abs().max())
+
+
+@pytest.mark.parametrize("mode,Cin,Cout,N,H,W", [("fwd", 64, 128, 2, 129, 97), ("fwd", 128, 256, 1, 65, 49), ("cells", 12, 64, 2, 128, 96)])
+def test_split3_operands_reach_fp32_accuracy(mode, Cin, Cout, N, H, W):
+    """HRV_S2_SPLIT3: the source as [hi | lo | hi] (T.split3), the weight packed [hi | hi | lo] -- hi*hi + lo*hi + hi*lo against the
+    fp32 convolution of the UNROUNDED operands: ~2^-16 relative instead of the 2^-8 of plain bf16 operands."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    g = torch.Generator().manual_seed(Cin + H)
+    b = (torch.randn(Cout, generator=g) * 0.1).cuda()
+    if mode == "fwd":
+        x = torch.randn(N, H, W, Cin, generator=g).cuda()
+        w = (torch.randn(Cout, Cin, 4, 4, generator=g) * (2.0 / (16 * Cin)) ** 0.5).cuda()
+        want = F.conv2d(x.permute(0, 3, 1, 2).double(), w.double(), b.double(), stride=2, padding=2).permute(0, 2, 3, 1)
+        src = T.split3(ops.Act(x, Cin))
+        pk = T.conv_s2_pack(T.S2_FWD, w, 3 * Cin, Cout, split3=True)
+        out = ops.alloc(N, H // 2 + 1, W // 2 + 1, Cout, "cuda")
+        T.conv_s2(T.S2_FWD, src, pk, Cout, out, bias=b, name="t")
+        plain = ops.alloc(N, H // 2 + 1, W // 2 + 1, Cout, "cuda")
+        T.conv_s2(T.S2_FWD, ops.Act(x.to(torch.bfloat16), Cin), T.conv_s2_pack(T.S2_FWD, w, Cin, Cout), Cout, plain, bias=b, name="t")
+    else:
+        x = torch.randn(N, H // 2, W // 2, 4 * Cin, generator=g).cuda()          # a space-to-depth image
+        w = (torch.randn(Cout, 4 * Cin, 2, 2, generator=g) * 0.1).cuda()
+        want = F.conv2d(F.pad(x.permute(0, 3, 1, 2).double(), (1, 1, 1, 1)), w.double(), b.double()).permute(0, 2, 3, 1)
+        src = T.split3(ops.Act(x, 4 * Cin))
+        pk = T.conv_s2_pack(T.S2_CELLS, w, 12 * Cin, Cout, split3=True)
+        out = ops.alloc(N, H // 2 + 1, W // 2 + 1, Cout, "cuda")
+        T.conv_s2(T.S2_CELLS, src, pk, Cout, out, bias=b, name="t")
+        plain = ops.alloc(N, H // 2 + 1, W // 2 + 1, Cout, "cuda")
+        T.conv_s2(T.S2_CELLS, ops.Act(x.to(torch.bfloat16), 4 * Cin), T.conv_s2_pack(T.S2_CELLS, w, 4 * Cin, Cout), Cout, plain, bias=b, name="t")
+    torch.cuda.synchronize()
+    scale = float(want.abs().max())
+    err = float((out.t.double() - want).abs().max()) / scale
+    err_plain = float((plain.t.double() - want).abs().max()) / scale
+    assert err < 2e-5, (err, err_plain)
+    assert err < err_plain / 50, (err, err_plain)

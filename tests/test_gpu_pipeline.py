@@ -51,6 +51,27 @@ def test_make_parse_vs_oracle(comp):
     assert torch.equal(got_parse.sum(1), torch.ones(N, H, W))
 
 
+@pytest.mark.parametrize("H,W", [(128, 96), (77, 53)])
+def test_gauss_blur_sliding_window_is_bit_identical(monkeypatch, H, W):
+    """hrv_gauss_blur_nhwc_f32: eight outputs per thread over a sliding window (the default) == one output per thread (HRV_GAUSS8=0),
+    bit for bit -- every output sums the same taps in the same order."""
+    glue, ops = _mods()
+    from hr_viton_amd import _lib
+    g = torch.Generator().manual_seed(3)
+    N, h, w = 2, 32, 24
+    seg = F.relu(torch.randn(N, 13, h, w, generator=g)).cuda()
+    cm = torch.rand(N, 1, h, w, generator=g).cuda()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("HRV_GAUSS8", flag)
+        _lib.reload_env()
+        gauss, _, _ = glue.make_parse(seg, cm, H, W, "warp_grad")
+        outs.append(gauss.t.clone())
+    monkeypatch.delenv("HRV_GAUSS8")
+    _lib.reload_env()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_hires_warp_and_occlusion_vs_oracle():
     glue, ops = _mods()
     g = torch.Generator().manual_seed(2)
