@@ -40,8 +40,7 @@ class hrv_norm_bwd_t(C.Structure):
                 ("dns_accumulate", C.c_int32), ("dnoise_scale", C.c_void_p), ("workspace", C.c_void_p),
                 ("dgb_bf16", C.c_int32), ("out_bf16", C.c_int32), ("dx_bf16", C.c_int32), ("g1p_bf16", C.c_int32),
                 ("dnh_bf16", C.c_int32), ("dout_bf16", C.c_int32),
-                ("x_up_channels", C.c_int32), ("x2", C.c_void_p), ("x2_cstride", C.c_int32), ("x2_coff", C.c_int32),
-                ("x_bf16", C.c_int32)]
+                ("x_up_channels", C.c_int32), ("x2", C.c_void_p), ("x2_cstride", C.c_int32), ("x2_coff", C.c_int32)]
 
 
 class hrv_sn_job_t(C.Structure):

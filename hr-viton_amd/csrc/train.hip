@@ -38,24 +38,16 @@ struct XSrc {
   const float* x; int x_cs, x_co;
   const float* x2; int x2_cs, x2_co, up_g;
   int H, W;
-  int x_bf16;             // x is STORED in bf16 (a convolution output inside a SPADEResBlock in mixed precision; never with x2)
 };
 // a thread's channel group g is fixed: its source (tensor, stride, low-resolution or not) is resolved once, per pixel only the
 // pixel index differs
 struct XThread {
-  const float* base;      // channel group g of pixel 0 of sample n (bf16 storage: the same element position, 2-byte elements)
-  int cs, lo, W, Wl, bf16;
+  const float* base;      // channel group g of pixel 0 of sample n
+  int cs, lo, W, Wl;
 };
 __device__ __forceinline__ XThread xsrc_thread(const XSrc& s, int n, int g) {
   XThread t;
   t.W = s.W; t.Wl = s.W >> 1;
-  t.bf16 = s.x_bf16;
-  if (s.x_bf16) {         // (no low-resolution part: ActUp inputs are fp32)
-    t.lo = 0;
-    t.cs = s.x_cs;
-    t.base = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(s.x) + (size_t)n * s.H * s.W * s.x_cs + s.x_co + g * 4);
-    return t;
-  }
   t.lo = (s.up_g > 0 && g < s.up_g) ? 1 : 0;
   if (s.up_g > 0 && !t.lo) {
     t.cs = s.x2_cs;
@@ -101,10 +93,6 @@ __device__ __forceinline__ f32x4 ld4_bf16(const void* base, size_t elem) {
   v[2] = __builtin_bit_cast(float, u.y << 16); v[3] = __builtin_bit_cast(float, u.y & 0xFFFF0000u);
   return v;
 }
-__device__ __forceinline__ f32x4 xsrc_load(const XThread& t, int px) {
-  if (t.bf16) return ld4_bf16(t.base, (size_t)px * t.cs);
-  return ld4(xsrc_ptr(t, px));
-}
 typedef __bf16 bf16x4t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ void st4_bf16(void* base, size_t elem, f32x4 v) {
   *reinterpret_cast<bf16x4t*>(reinterpret_cast<unsigned short*>(base) + elem) = __builtin_convertvector(v, bf16x4t);
@@ -133,7 +121,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stage1_kernel(const NormBwdParam
       auto load = [&](int px) {
         In L;
         const size_t pix = (size_t)n * HW + px;
-        L.v = xsrc_load(xt, px);
+        L.v = ld4(xsrc_ptr(xt, px));
         L.zz = 0.f;
         if (p.z) {
           const int h = px / p.W, w = px - h * p.W;
@@ -261,7 +249,7 @@ __global__ __launch_bounds__(256) void norm_bwd_stage2_kernel(const NormBwd2Para
       auto load = [&](int px) {
         In L;
         const size_t pix = (size_t)n * HW + px;
-        L.v = xsrc_load(xt, px);
+        L.v = ld4(xsrc_ptr(xt, px));
         L.zz = 0.f;
         if (p.z) {
           const int h = px / p.W, w = px - h * p.W;
@@ -352,7 +340,7 @@ __global__ __launch_bounds__(256) void norm_bwd2_stage1_kernel(const NormBwdPara
     auto load = [&](int px) {
       In L;
       const size_t pix = (size_t)n * HW + px;
-      L.v = xsrc_load(xt, px);
+      L.v = ld4(xsrc_ptr(xt, px));
       const int h = px / p.W, w = px - h * p.W;
       L.a = load1(pa, pix, h, w);
       L.b = load1(pb, pix, h, w);
@@ -430,7 +418,7 @@ __global__ __launch_bounds__(256) void norm_bwd2_stage2_kernel(const NormBwd2Par
     auto load = [&](int px) {
       In L;
       const size_t pix = (size_t)n * HW + px;
-      L.v = xsrc_load(xt, px);
+      L.v = ld4(xsrc_ptr(xt, px));
       const int h = px / p.W, w = px - h * p.W;
       const size_t zi = ((size_t)n * p.W + w) * p.H + h;
       L.za = pa.z ? pa.z[zi] : 0.f;
@@ -1144,7 +1132,6 @@ static int norm_bwd_check(const hrv_norm_bwd_t* d) {
                 "norm_bwd: upsampled source (%d of %d channels, %d x %d)", d->x_up_channels, C, d->H, d->W);
   }
   HRV_REQUIRE(!(d->dx_bf16 && d->dx_accumulate), "norm_bwd: a bf16 dx cannot be accumulated into");
-  HRV_REQUIRE(!(d->x_bf16 && d->x_up_channels > 0), "norm_bwd: a bf16-stored x has no upsampled part");
   return HRV_OK;
 }
 
@@ -1157,7 +1144,6 @@ static void norm_bwd_fill(const hrv_norm_bwd_t* d, NormBwdParams& p, NormBwd2Par
   XSrc xs;
   xs.x = d->x; xs.x_cs = d->x_cstride; xs.x_co = d->x_coff; xs.H = d->H; xs.W = d->W;
   xs.x2 = d->x2; xs.x2_cs = d->x2_cstride; xs.x2_co = d->x2_coff; xs.up_g = d->x_up_channels / 4;
-  xs.x_bf16 = d->x_bf16;
   p.xs = xs; p.z = d->noise_z; p.ns = d->noise_scale;
   p.mean = d->mean; p.rstd = d->rstd; p.out = d->out; p.out_cs = d->out_cstride; p.out_co = d->out_coff;
   p.g1p = d->g1p; p.g_cs = d->g1p_cstride; p.g_co = d->g1p_coff; p.g1p_bf16 = d->g1p_bf16;

@@ -547,17 +547,14 @@ class BlockT:
                 ms, m0 = ops.instnorm_stats2(x, z_s, ns_s, z_0, ns_0)
                 st_s, st_0 = (ns_s, ms), (ns_0, m0)
             hs, ctx["ns"] = self.ns_.forward(x, next(ai), z_s, save, fused, st_s)
+            # (round 6, measured and not kept: this shortcut output and conv_0's output stored in bf16 -- DESIGN.md 7f)
             x_s = self.cs.forward([(hs, 0)])
             ctx["hs"] = hs
         else:
             x_s = x
             z_0 = next(zi)
         h0, ctx["n0"] = self.n0.forward(x, next(ai), z_0, save, fused, st_0)
-        # conv_0's output feeds norm_1 only (its statistics, the fused SPADE epilogue, the normalisation backward): stored in bf16
-        # where those readers take it -- what autocast leaves a half-precision convolution's output as (HRV_DX_BF16=0: fp32)
-        dx16 = bool(T.MMA_BF16[0] and fused is not None and h0.bf16 and self.c0.conv.out_channels % 8 == 0 and
-                    os.environ.get("HRV_DX_BF16", "1") != "0")
-        dx = self.c0.forward([(h0, 0)], out_bf16=dx16)
+        dx = self.c0.forward([(h0, 0)])
         h1, ctx["n1"] = self.n1.forward(dx, next(ai), next(zi), save, fused)
         # the last block's activated output only feeds conv_img (matrix cores + the sign mask of its data gradient)
         o = self.c1.forward([(h1, 0)], residual=x_s, act=out_act, out=out, out_up=out_up,

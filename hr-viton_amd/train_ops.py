@@ -772,7 +772,6 @@ def _norm_bwd_desc(x, mean, rstd, dout, act, slope, out, g1p, z, noise_scale, wa
         d.x_up_channels, d.x2, d.x2_cstride, d.x2_coff = x.lo.C, x.hi.t.data_ptr(), x.hi.cstride, x.hi.coff
     else:
         d.x, d.x_cstride, d.x_coff = x.t.data_ptr(), x.cstride, x.coff
-        d.x_bf16 = 1 if x.bf16 else 0
     if z is not None:
         d.noise_z, d.noise_scale = z.data_ptr(), noise_scale.data_ptr()
     d.mean, d.rstd = mean.data_ptr(), rstd.data_ptr()

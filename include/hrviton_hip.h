@@ -295,8 +295,6 @@ typedef struct hrv_norm_bwd {
    * at (h >> 1, w >> 1), the remaining C - x_up_channels from `x2` = hi [N][H][W][x2_cstride] */
   int32_t x_up_channels;
   const float* x2;    int32_t x2_cstride, x2_coff;
-  int32_t x_bf16;     /* 1: `x` is stored as bf16 (element strides / offsets; never with x_up_channels): the output of a convolution
-                       * inside a SPADEResBlock in mixed precision -- what autocast leaves a half-precision convolution's output as */
 } hrv_norm_bwd_t;
 int64_t hrv_norm_bwd_workspace_elems(int32_t N, int32_t H, int32_t W, int32_t C);
 

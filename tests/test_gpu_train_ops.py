@@ -153,34 +153,6 @@ def test_spade_norm_backward_vs_autograd(C, H, W, noise, spade):
         assert _rel(dns, ns.grad) < 5e-5
 
 
-@pytest.mark.parametrize("C,H,W,noise", [(32, 12, 10, True), (64, 17, 13, False)])
-def test_spade_norm_backward_bf16_stored_x(C, H, W, noise):
-    """hrv_norm_bwd_t.x_bf16: x stored in bf16 (conv_0's output inside a SPADEResBlock in mixed precision) -- the same values as the
-    fp32 tensor holding the rounded numbers, so the results are bit-identical to the fp32-stored call."""
-    ops, T = _mods()
-    g = torch.Generator().manual_seed(C + H + 1)
-    N = 2
-    xb = (torch.randn(N, H, W, C, generator=g) * 2 + 1).to(torch.bfloat16).cuda()
-    zc = torch.randn(N, W, H, 1, generator=g).cuda().contiguous() if noise else None
-    nsc = (torch.randn(C, generator=g) * 0.5).cuda() if noise else None
-    x16, x32 = ops.Act(xb, C), ops.Act(xb.float(), C)
-    mu, rs = ops.instnorm_stats(x32, zc, nsc)
-    mu16, rs16 = ops.instnorm_stats(x16, zc, nsc)
-    assert _rel(mu16, mu) < 1e-6 and _rel(rs16, rs) < 1e-5
-    dout = ops.Act(torch.randn(N, H, W, C, generator=g).cuda(), C)
-    out = ops.Act(torch.randn(N, H, W, C, generator=g).cuda(), C)
-    g1p = ops.Act(1 + torch.randn(N, H, W, C, generator=g).cuda(), C)
-    res = []
-    for xa in (x32, x16):
-        dns = torch.zeros(C, device="cuda") if noise else None
-        dx, dgb = T.norm_bwd(xa, mu, rs, dout, act=ops.ACT_LRELU, slope=0.2, out=out, g1p=g1p, z=zc, noise_scale=nsc, want_dgb=True,
-                             dnoise_scale=dns)
-        res.append((dx.t.clone(), dgb.t.clone(), None if dns is None else dns.clone()))
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-    if noise:
-        assert torch.equal(res[0][2], res[1][2])
-
-
 def test_losses_value_and_gradient():
     ops, T = _mods()
     g = torch.Generator().manual_seed(1)
