@@ -117,6 +117,11 @@ class hrv_conv_s2_t(C.Structure):
                 ("mask", C.c_void_p), ("mask_cstride", C.c_int32), ("mask_coff", C.c_int32), ("mask_slope", C.c_float)]
 
 
+class hrv_s2_pack_job_t(C.Structure):
+    _fields_ = [("mode_flags", C.c_int32), ("K", C.c_int32), ("cols", C.c_int32), ("Cph", C.c_int32),
+                ("w", C.c_void_p), ("sigma", C.c_void_p), ("wscale", C.c_float), ("_pad", C.c_int32), ("out", C.c_void_p)]
+
+
 class hrv_conv2d_t(C.Structure):
     _fields_ = [("N", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Ho", C.c_int32), ("Wo", C.c_int32),
                 ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32), ("pad", C.c_int32),
@@ -287,8 +292,10 @@ SYMBOLS = {
     "hrv_conv_s2_packed_bytes": (C.c_int64, [_i32, _i32, _i32]),
     "hrv_conv_s2_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "hrv_conv_s2_pack_dev": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp]),
+    "hrv_conv_s2_pack_multi_dev": (C.c_int, [_i32, C.POINTER(hrv_s2_pack_job_t), _vp]),
     "hrv_conv_s2_bf16": (C.c_int, [C.POINTER(hrv_conv_s2_t), _vp]),
     "hrv_space_to_depth2_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_space_to_depth2_cells_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_instnorm_apply_nhwc_bf16out": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32, _i32, _vp]),
     "hrv_scale_bf16": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
     "hrv_split3_nhwc_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),

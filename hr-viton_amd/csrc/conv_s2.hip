@@ -132,8 +132,7 @@ struct S2PackParams {
   unsigned short* out;
 };
 
-__global__ __launch_bounds__(256) void s2_pack_kernel(const S2PackParams p) {
-  const long long G = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void s2_pack_group(const S2PackParams& p, const long long G) {
   if (G >= p.pl.bytes / 16) return;
   int pass = 0;
   for (int i = 1; i < p.pl.npass; ++i)
@@ -183,6 +182,18 @@ __global__ __launch_bounds__(256) void s2_pack_kernel(const S2PackParams p) {
   o.x = v[0] | ((unsigned)v[1] << 16); o.y = v[2] | ((unsigned)v[3] << 16);
   o.z = v[4] | ((unsigned)v[5] << 16); o.w = v[6] | ((unsigned)v[7] << 16);
   reinterpret_cast<uint4*>(p.out)[G] = o;
+}
+
+__global__ __launch_bounds__(256) void s2_pack_kernel(const S2PackParams p) {
+  s2_pack_group(p, (long long)blockIdx.x * blockDim.x + threadIdx.x);
+}
+
+// several weights in one launch (a PatchGAN pass packs 3 forward / 2 data-gradient weights per scale): blockIdx.y = the job
+constexpr int S2_MAXJOBS = 8;
+struct S2PackMulti { S2PackParams j[S2_MAXJOBS]; };
+__global__ __launch_bounds__(256) void s2_pack_multi_kernel(const S2PackMulti m) {
+  const S2PackParams& p = m.j[blockIdx.y];
+  for (long long G = (long long)blockIdx.x * blockDim.x + threadIdx.x; G < p.pl.bytes / 16; G += (long long)gridDim.x * blockDim.x) s2_pack_group(p, G);
 }
 
 // ------------------------------------------------------------------------------------------------ the kernel
@@ -617,21 +628,37 @@ extern "C" int hrv_conv_s2_supported(int32_t mode, int32_t K, int32_t cols, int3
 }
 
 extern "C" int hrv_conv_s2_pack_dev(int32_t mode_flags, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
-                                    void* out, hrv_stream_t stream) {
+                                    void* out, hrv_stream_t stream);
+
+static int s2_pack_fill(S2PackParams& pp, int32_t mode_flags, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
+                        void* out) {
   HRV_REQUIRE(w && out, "conv_s2_pack: null pointer");
   const int mode = mode_flags & 3, split3 = (mode_flags & HRV_S2_SPLIT3) ? 1 : 0;
   HRV_REQUIRE(!split3 || (mode != 1 && K % 3 == 0 && (K / 3) % 8 == 0 && (mode != 0 || (K / 3) % 32 == 0)),
               "conv_s2_pack: split3 is for modes 0 / 2, K = 3 x (a multiple of 8; mode 0: of 32) (mode %d, K %d)", mode, K);
-  S2PackParams pp;
   HRV_REQUIRE(s2_plan(mode, K, cols, pp.pl), "conv_s2_pack: unsupported shape (mode %d, K %d, columns %d)", mode, K, cols);
   HRV_REQUIRE(mode != 0 || K % 32 == 0, "conv_s2_pack: forward K must be a multiple of 32 (got %d)", K);
   HRV_REQUIRE(mode != 1 || (Cph >= 32 && Cph % 32 == 0 && cols == 4 * Cph), "conv_s2_pack: data gradient columns = 4 x Cph (Cph %d, columns %d)", Cph, cols);
   HRV_REQUIRE(((uintptr_t)out & 15) == 0, "conv_s2_pack: out must be 16-byte aligned");
   pp.mode = mode; pp.K = K; pp.cols = cols; pp.Cph = Cph > 0 ? Cph : 1; pp.split3 = split3;
   pp.w = w; pp.sigma = sigma; pp.wscale = wscale; pp.out = (unsigned short*)out;
-  const long long groups = pp.pl.bytes / 16;
-  hipLaunchKernelGGL(s2_pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pp);
-  return check_launch("s2_pack_kernel");
+  return HRV_OK;
+}
+
+extern "C" int hrv_conv_s2_pack_multi_dev(int32_t n, const hrv_s2_pack_job_t* jobs, hrv_stream_t stream) {
+  HRV_REQUIRE(jobs && n > 0 && n <= S2_MAXJOBS, "conv_s2_pack_multi: 1 .. %d jobs", S2_MAXJOBS);
+  S2PackMulti m;
+  memset(&m, 0, sizeof(m));
+  long long most = 0;
+  for (int i = 0; i < n; ++i) {
+    const int rc = s2_pack_fill(m.j[i], jobs[i].mode_flags, jobs[i].w, jobs[i].K, jobs[i].cols, jobs[i].Cph, jobs[i].sigma, jobs[i].wscale, jobs[i].out);
+    if (rc) return rc;
+    if (m.j[i].pl.bytes / 16 > most) most = m.j[i].pl.bytes / 16;
+  }
+  long long gx = (most + 255) / 256;
+  if (gx > 512) gx = 512;
+  hipLaunchKernelGGL(s2_pack_multi_kernel, dim3((unsigned)gx, (unsigned)n), dim3(256), 0, (hipStream_t)stream, m);
+  return check_launch("s2_pack_multi_kernel");
 }
 
 extern "C" int hrv_conv_s2_bf16(const hrv_conv_s2_t* d, hrv_stream_t stream) {
@@ -729,6 +756,41 @@ __global__ void s2d_bf16_kernel(const float* __restrict__ a, int N, int H, int W
   }
 }
 
+// The space-to-depth image of model0's input as conv_s2's mode 2 reads it: out[n][cy][cx][(dy*2+dx)*C + c] = in[n][2cy+dy][2cx+dx][c],
+// bf16, over Hp x Wp >= H/2 x W/2 cells (cells / sub-pixels outside the image: zeros -- a one-cell border makes the layer a 'same' 2x2
+// convolution, which is what the LDS-DMA weight-gradient kernel serves); split3: [hi | lo | hi] of that image (HRV_S2_SPLIT3).
+__global__ void s2d_cells_kernel(const float* __restrict__ a, int N, int H, int W, int C4, int cs, int co, unsigned short* __restrict__ b, int Hp,
+                                 int Wp, int split3) {
+  const size_t total = (size_t)N * Hp * Wp * 4 * C4;
+  const int C = C4 * 4, K0 = 4 * C, ocs = split3 ? 3 * K0 : K0;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c4 = (int)(i % C4);
+    size_t t = i / C4;
+    const int sub = (int)(t & 3); t >>= 2;
+    const int cx = (int)(t % Wp); t /= Wp;
+    const int cy = (int)(t % Hp);
+    const int n = (int)(t / Hp);
+    const int y = 2 * cy + (sub >> 1), x = 2 * cx + (sub & 1);
+    f32x4 v = (f32x4)(0.f);
+    if (y < H && x < W) v = *reinterpret_cast<const f32x4*>(a + (((size_t)n * H + y) * W + x) * cs + co + 4 * c4);
+    unsigned short h[4], l[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      h[e] = f2bf(v[e]);
+      l[e] = f2bf(v[e] - bf2f(h[e]));
+    }
+    uint2 hh, ll;
+    hh.x = h[0] | ((unsigned)h[1] << 16); hh.y = h[2] | ((unsigned)h[3] << 16);
+    ll.x = l[0] | ((unsigned)l[1] << 16); ll.y = l[2] | ((unsigned)l[3] << 16);
+    unsigned short* o = b + (((size_t)n * Hp + cy) * Wp + cx) * ocs + sub * C + 4 * c4;
+    *reinterpret_cast<uint2*>(o) = hh;
+    if (split3) {
+      *reinterpret_cast<uint2*>(o + K0) = ll;
+      *reinterpret_cast<uint2*>(o + 2 * K0) = hh;
+    }
+  }
+}
+
 __global__ void instnorm_apply_bf16out_kernel(const float* __restrict__ x, int N, int HW, int C4, int cs, int co, const float* __restrict__ mean,
                                               const float* __restrict__ rstd, int act, float slope, unsigned short* __restrict__ out, int ocs,
                                               int oco) {
@@ -818,6 +880,18 @@ extern "C" int hrv_space_to_depth2_nhwc_bf16(const float* in, int32_t N, int32_t
   return check_launch("s2d_bf16_kernel");
 }
 
+extern "C" int hrv_space_to_depth2_cells_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                                              int32_t Hp, int32_t Wp, int32_t split3, uint16_t* out, hrv_stream_t stream) {
+  HRV_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0, "space_to_depth2_cells: bad args");
+  HRV_REQUIRE(C % 4 == 0 && in_cstride % 4 == 0 && in_coff % 4 == 0 && in_coff + C <= in_cstride && Hp >= (H + 1) / 2 && Wp >= (W + 1) / 2 &&
+                  ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0,
+              "space_to_depth2_cells: 4-channel granules, Hp x Wp cells covering the image");
+  const size_t total = (size_t)N * Hp * Wp * 4 * (C / 4);
+  hipLaunchKernelGGL(s2d_cells_kernel, dim3(s2_grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C / 4, in_cstride, in_coff, out, Hp, Wp,
+                     split3 ? 1 : 0);
+  return check_launch("s2d_cells_kernel");
+}
+
 extern "C" int hrv_instnorm_apply_nhwc_bf16out(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
                                                const float* mean, const float* rstd, int32_t act, float act_slope, uint16_t* out,
                                                int32_t out_cstride, int32_t out_coff, hrv_stream_t stream) {
@@ -853,4 +927,14 @@ extern "C" int hrv_split3_nhwc_bf16(const float* x, int64_t npix, int32_t C, int
   hipLaunchKernelGGL(split3_bf16_kernel, dim3(s2_grid_for((size_t)npix * (C / 4))), dim3(256), 0, (hipStream_t)stream, x, (size_t)npix, C / 4, cstride,
                      coff, out);
   return check_launch("split3_bf16_kernel");
+}
+
+extern "C" int hrv_conv_s2_pack_dev(int32_t mode_flags, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
+                                    void* out, hrv_stream_t stream) {
+  S2PackParams pp;
+  const int rc = s2_pack_fill(pp, mode_flags, w, K, cols, Cph, sigma, wscale, out);
+  if (rc) return rc;
+  const long long groups = pp.pl.bytes / 16;
+  hipLaunchKernelGGL(s2_pack_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pp);
+  return check_launch("s2_pack_kernel");
 }

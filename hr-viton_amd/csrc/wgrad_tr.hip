@@ -402,6 +402,10 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
     cls = 5;
     p.co_tiles = Cout / 64; tm = 2;
     p.col_tiles = 1;
+  } else if (KW == 2 && Cout % 64 == 0 && gpt == 2) {
+    cls = 8;      // 2x2 over <= 64 channels (round 6: PatchGAN's model0 over its space-to-depth image, conv_s2.hip mode 2)
+    p.co_tiles = Cout / 64; tm = 2;
+    p.col_tiles = 1;
   } else if (Cout <= 32 && taps * gpt <= 28 && gpt <= 3) {
     cls = gpt == 3 ? (taps == 1 ? 3 : 1) : (gpt == 1 && taps == 9 ? 2 : -1);
     p.co_tiles = 1; p.col_tiles = 1; tm = 1;
@@ -443,6 +447,8 @@ int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, 
     hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 7, 1, 4, 9, 1>), dim3(nblk), dim3(256), 0, st, p);
   } else if (cls == 7) {      // 3x3 over 256 channels: 24 groups per kernel row -> 4 waves x 6
     hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 6, 1, 4, 8, 1>), dim3(nblk), dim3(256), 0, st, p);
+  } else if (cls == 8) {      // 2x2 over <= 64 channels: 8 groups -> 4 waves x 2, every tap in one block
+    hipLaunchKernelGGL((conv_wgrad_tr_kernel<2, 2, 1, 4, 2, 2>), dim3(nblk), dim3(256), 0, st, p);
   } else if (cls == 1) {      // 3x3 over <= 96 channels: 27 groups -> 4 waves x 7
     hipLaunchKernelGGL((conv_wgrad_tr_kernel<1, 7, 1, 4, 3, 3>), dim3(nblk), dim3(256), 0, st, p);
   } else if (cls == 2) {      // 3x3 over 32 channels: 9 groups -> 4 waves x 3

@@ -885,17 +885,20 @@ class DiscTrainPlan:
 
     # ---- mixed precision with bf16-STORED feature maps (csrc/conv_s2.hip) -----------------------------------------------------
     def _s2_chain(self, a: Act, own: bool, sc: int) -> bool:
+        return self._s2_chain_dims(a.N, a.H, a.W, a.Cp, a.bf16, own, sc)
+
+    def _s2_chain_dims(self, aN: int, aH: int, aW: int, aCp: int, abf16: bool, own: bool, sc: int) -> bool:
         """Does this scale run on csrc/conv_s2.hip with its feature maps stored in bf16?  Mixed precision only, the reference's
         NLayerDiscriminator shape ([conv 4x4 s2 + LReLU] [SN conv 4x4 s2 + IN + LReLU]+ [conv 4x4 s1 -> 1]), every convolution of
         the scale on bf16 operands (a layer kept on fp32 operands by _d_f32 -- the half-resolution scale in D's own step -- keeps
         the whole scale on the fp32-stored path), even input extents, shapes the kernel serves.  HRV_D_BF16=0: off."""
-        if not T.MMA_BF16[0] or os.environ.get("HRV_D_BF16", "1") == "0" or a.bf16 or len(self.layers) < 3:
+        if not T.MMA_BF16[0] or os.environ.get("HRV_D_BF16", "1") == "0" or abf16 or len(self.layers) < 3:
             return False
         kinds = [k for k, _ in self.layers]
         if kinds[0] != "lrelu" or kinds[-1] != "plain" or any(k != "in" for k in kinds[1:-1]):
             return False
         c0 = self.layers[0][1]
-        if not isinstance(c0, S2DConv) or c0._w2 is None or a.H % 2 or a.W % 2 or a.Cp != c0.Cq:
+        if not isinstance(c0, S2DConv) or c0._w2 is None or aH % 2 or aW % 2 or aCp != c0.Cq:
             return False
         if any(_d_f32(li, "bwd", own, sc) for li in range(len(self.layers))):
             return False
@@ -904,7 +907,7 @@ class DiscTrainPlan:
         # bits; HRV_D_SPLIT3=0: such a scale stays on the fp32-stored path and the fp32 matrix-core engine)
         if any(split) and (os.environ.get("HRV_D_SPLIT3", "1") == "0" or (4 * c0.Cq) % 8 or c0.Cq % 2):
             return False
-        H, W, N = a.H // 2 + 1, a.W // 2 + 1, a.N
+        H, W, N = aH // 2 + 1, aW // 2 + 1, aN
         cin = c0.conv.out_channels
         if cin % 64 or not T.conv_s2_ok(T.S2_CELLS, 4 * c0.Cq, cin, 0, N, H, W):
             return False
@@ -919,6 +922,23 @@ class DiscTrainPlan:
             H, W, cin = Ho, Wo, m.out_channels
         return True
 
+    def s2_fwd_jobs(self, own: bool, sc: int):
+        """(layer index, conv_s2_pack_multi job) of the scale's forward: the caller packs them in one launch and leaves the streams in
+        ``self._s2_pk`` (MultiscaleDTrainPlan.forward)."""
+        split = [_d_f32(li, "fwd", own, sc) for li in range(len(self.layers))]
+        jobs = []
+        for li, (kind, conv) in enumerate(self.layers[:-1]):
+            m = conv.conv
+            if li == 0:
+                jobs.append((0, (T.S2_CELLS, conv.w2, 4 * conv.Cq * (3 if split[0] else 1), m.out_channels, 0, conv.sigma, split[0])))
+            else:
+                jobs.append((li, (T.S2_FWD, conv.wparam.data, m.in_channels * (3 if split[li] else 1), m.out_channels, 0, conv.sigma, split[li])))
+        return jobs
+
+    def s2_bwd_jobs(self):
+        return [(i, (T.S2_DGRAD, conv.wparam.data, conv.conv.out_channels, 4 * conv.conv.in_channels, conv.conv.in_channels, conv.sigma, False))
+                for i, (kind, conv) in enumerate(self.layers) if kind == "in"]
+
     def _forward_s2(self, a: Act, own: bool, sc: int):
         """The scale's forward with f0, f1, ... stored in bf16 (the last InstanceNorm output stays fp32: the one-channel
         convolution behind it is a dot-product kernel over fp32).  A layer _d_f32 keeps on fp32 operands reads its source as
@@ -928,26 +948,31 @@ class DiscTrainPlan:
         n_in = len(self.layers) - 2
         split = [_d_f32(li, "fwd", own, sc) for li in range(len(self.layers))]
         sbf = None            # the bf16 operand of the feature in front of the current layer (bf16 Act, or the hi third of its split)
+        pre = getattr(self, "_s2_pk", None) or {}      # streams packed ahead, one launch for both scales
+        self._s2_pk = {}
         for li, (kind, conv) in enumerate(self.layers):
             b = conv.bparam
             bias = None if b is None else b.data
             nxt_split = li + 1 < len(self.layers) - 1 and split[li + 1]        # the next 4x4 stride-2 layer reads split operands
             if li == 0:
                 Cout, K0 = conv.conv.out_channels, 4 * conv.Cq
-                if split[0]:
-                    a2s = T.split3(T.space_to_depth2(a))
-                    a2, src2 = Act(a2s.t, K0, 0), a2s
-                else:
-                    a2 = src2 = T.space_to_depth2_bf16(a)
+                # (one cell of zeros below / right of the image: out = cells + 1 makes this a 'same' 2x2 convolution -- the shape the
+                #  LDS-DMA weight-gradient kernel serves)
+                src2 = T.space_to_depth2_cells(a, a.H // 2 + 1, a.W // 2 + 1, split3=split[0])
+                a2 = Act(src2.t, K0, 0)
                 f = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device, bf16=not nxt_split)
-                pk = T.conv_s2_pack(T.S2_CELLS, conv.w2, src2.C, Cout, sigma=conv.sigma, split3=split[0])
+                pk = pre.pop(0, None)
+                if pk is None:
+                    pk = T.conv_s2_pack(T.S2_CELLS, conv.w2, src2.C, Cout, sigma=conv.sigma, split3=split[0])
                 T.conv_s2(T.S2_CELLS, src2, pk, Cout, f, bias=bias, act=ACT_LRELU, slope=0.2, name=conv.name,
                           flops=2.0 * f.N * f.H * f.W * Cout * conv.conv.in_channels * 16 * (3 if split[0] else 1))
                 ctx.append(dict(src=a, a2=a2, f=f, s2=True))
             elif kind == "in":
                 Cout, cin = conv.conv.out_channels, conv.conv.in_channels
                 c = ops.alloc(a.N, a.H // 2 + 1, a.W // 2 + 1, Cout, a.t.device)
-                pk = T.conv_s2_pack(T.S2_FWD, conv.wparam.data, src.C, Cout, sigma=conv.sigma, split3=split[li])
+                pk = pre.pop(li, None)
+                if pk is None:
+                    pk = T.conv_s2_pack(T.S2_FWD, conv.wparam.data, src.C, Cout, sigma=conv.sigma, split3=split[li])
                 T.conv_s2(T.S2_FWD, src, pk, Cout, c, bias=bias, name=conv.name,
                           flops=2.0 * c.N * c.H * c.W * Cout * cin * 16 * (3 if split[li] else 1))
                 mean, rstd = ops.instnorm_stats(c)
@@ -986,6 +1011,8 @@ class DiscTrainPlan:
 
         d_next: Optional[Act] = None
         tap_in_dnext = False
+        pre = getattr(self, "_s2_pkd", None) or {}
+        self._s2_pkd = {}
         for i in range(len(self.layers) - 1, -1, -1):
             kind, conv = self.layers[i]
             c = {k: cut(v) for k, v in ctx[i].items() if k != "s2"}
@@ -1016,7 +1043,9 @@ class DiscTrainPlan:
                 tap = dfeats[i - 1]
                 tap_ok = tap is not None and tap.t.shape[:3] == src.t.shape[:3] and tap.C == src.C
                 dx = ops.alloc(src.N, src.H, src.W, src.C, src.t.device, bf16=True)
-                pk = T.conv_s2_pack(T.S2_DGRAD, w, m.out_channels, 4 * m.in_channels, m.in_channels, sigma=conv.sigma)
+                pk = pre.pop(i, None)
+                if pk is None:
+                    pk = T.conv_s2_pack(T.S2_DGRAD, w, m.out_channels, 4 * m.in_channels, m.in_channels, sigma=conv.sigma)
                 # the gradient of the layer's input feature: + its feature-matching tap; the feature behind model0 is LeakyReLU(pre):
                 # its derivative rides along as the mask (the features behind an InstanceNorm get theirs in norm_bwd)
                 T.conv_s2(T.S2_DGRAD, d_c, pk, 4 * m.in_channels, dx, Cph=m.in_channels, residual=tap if tap_ok else None,
@@ -1043,7 +1072,7 @@ class DiscTrainPlan:
                     _acc(grads, conv.bparam, db)
             d_next = None
             if need_dx:
-                d2 = T.conv_dgrad(d, conv.w2, a2.H, a2.W, 1, 1, sigma=conv.sigma, name=conv.name + ".dgrad",
+                d2 = T.conv_dgrad(d, conv.w2, c["src"].H // 2, c["src"].W // 2, 1, 1, sigma=conv.sigma, name=conv.name + ".dgrad",
                                   batch=getattr(conv, "pack_batch", None))
                 d_next = T.depth_to_space2(d2, c["src"].C)
         return d_next
@@ -1137,6 +1166,18 @@ class MultiscaleDTrainPlan:
             p.refresh_s2d()
         T.prepare_convs(self, [conv for p in self.plans for _, conv in p.layers], power_iteration)
         own = not getattr(self.msd, "_hrv_discard_param_grads", False)
+        # the weight streams of the scales that run on csrc/conv_s2.hip: one launch for all of them
+        if os.environ.get("HRV_S2_PACK_MULTI", "1") != "0":
+            dims, jobs, owners = (a.N, a.H, a.W, a.Cp, a.bf16), [], []
+            for k, p in enumerate(self.plans):
+                p._s2_pk = {}
+                if p._s2_chain_dims(*dims, own, k):
+                    for li, job in p.s2_fwd_jobs(own, k):
+                        jobs.append(job)
+                        owners.append((p, li))
+                dims = (dims[0], (dims[1] - 1) // 2 + 1, (dims[2] - 1) // 2 + 1, dims[3], False)
+            for (p, li), buf in zip(owners, T.conv_s2_pack_multi(jobs)):
+                p._s2_pk[li] = buf
         for k, p in enumerate(self.plans):
             inputs.append(a)
             p.own_step, p.scale_index = own, k
@@ -1150,6 +1191,16 @@ class MultiscaleDTrainPlan:
     def backward(self, ctx, dfeats_all, need_dx: bool, rows: Optional[int] = None, need_w: bool = True):
         grads: Grads = {}
         d_in_next: Optional[Act] = None
+        if os.environ.get("HRV_S2_PACK_MULTI", "1") != "0":
+            jobs, owners = [], []
+            for k, p in enumerate(self.plans):
+                p._s2_pkd = {}
+                if ctx["ctxs"][k] and ctx["ctxs"][k][0].get("s2"):
+                    for i, job in p.s2_bwd_jobs():
+                        jobs.append(job)
+                        owners.append((p, i))
+            for (p, i), buf in zip(owners, T.conv_s2_pack_multi(jobs)):
+                p._s2_pkd[i] = buf
         for k in range(len(self.plans) - 1, -1, -1):
             a = ctx["inputs"][k]
             if rows is not None:

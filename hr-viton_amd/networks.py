@@ -235,9 +235,15 @@ class ConditionGenerator(nn.Module):
         x2 = ops.to_nhwc(input2)
         E1: List[Act] = []
         E2: List[Act] = []
+        # the two encoders are independent chains of small launches (at 256x192: 6 .. 768 tiles each): PoseEncoder runs on the side
+        # stream next to ClothEncoder (HRV_TOCG_SIDE=0: one after the other on one stream)
+        from . import train_ops as _T
+        with _T.side_region(x2, on=os.environ.get("HRV_TOCG_SIDE", "1") != "0"):
+            for i in range(5):
+                E2.append(P["E2"][i]([x2 if i == 0 else E2[-1]]))
         for i in range(5):
             E1.append(P["E1"][i]([x1 if i == 0 else E1[-1]]))
-            E2.append(P["E2"][i]([x2 if i == 0 else E2[-1]]))
+        _T.wgrad_join(input1.device)
         flow_list: List[torch.Tensor] = []
         T1 = T2 = x = None
         for i in range(5):

@@ -101,6 +101,17 @@ class wgrad_side:
         return False
 
 
+class side_region(wgrad_side):
+    """``with side_region(*reads):`` -- the body runs on the device's side stream NEXT to what the caller enqueues on the current stream
+    afterwards, until ``wgrad_join()``: an independent chain of small launches (the frozen condition generator's second encoder: 15
+    convolutions of 6 .. 768 tiles each).  Same mechanics as wgrad_side (own split-K scratch, no nesting, never under a hipGraph
+    capture) without its opt-in switch and size cap."""
+
+    def __init__(self, *reads, on: bool = True):
+        self.on = on and not _Side.active[0] and not torch.cuda.is_current_stream_capturing()
+        self.reads = reads
+
+
 def wgrad_join(device=None):
     """The current stream waits for the weight gradients enqueued on the side stream (no-op when there are none)."""
     if not _Side.pending:          # never forked in this process (also: a CPU-only process)
@@ -705,7 +716,9 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
                                                     _stream()), f"hrv_conv_cout1_wgrad_f32[{name}]")
         return
     wo_real = Wo
-    if MMA_BF16[0] and Wo % 4 != 0 and dy.bf16 and x.bf16 and dy.coff == 0 and dy.cstride == dy.C and dy.C % 8 == 0:
+    tr2 = (stride == 1 and (Ho, Wo) == (H, W) and KH == KW == 2 and pad == 1 and x_up == 0 and Cout % 64 == 0 and 32 < x.Cp <= 64 and
+           N * Ho * Wo >= 8192 and os.environ.get("HRV_WGRAD_TR", "1") != "0")          # (wgrad_tr.hip's 2x2 class takes any width)
+    if MMA_BF16[0] and Wo % 4 != 0 and dy.bf16 and x.bf16 and dy.coff == 0 and dy.cstride == dy.C and dy.C % 8 == 0 and not tr2:
         dy = pad_width_bf16(dy)          # (the same zero columns for a bf16-stored dY: the PatchGAN with bf16 feature maps)
         Wo = dy.W
     if (MMA_BF16[0] and Wo % 4 != 0 and Wo >= 32 and not (x.bf16 or dy.bf16) and dy.coff == 0 and dy.cstride == dy.Cp):
@@ -725,7 +738,7 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     nbytes = ops.act_bytes(dy) + ops.act_bytes(x) + 4.0 * Cout * x.C * KH * KW
     with _Timed("wgrad", name, fl, nbytes, "conv_wgrad_tr_kernel" if (x.bf16 or dy.bf16) else "conv_wgrad_kernel"):
         if x.bf16 or dy.bf16:
-            assert MMA_BF16[0] and Wo % 4 == 0, f"{name}: bf16-stored operands need the bf16 matrix-core weight gradient"
+            assert MMA_BF16[0] and (Wo % 4 == 0 or tr2), f"{name}: bf16-stored operands need the bf16 matrix-core weight gradient"
             assert x.bf16, f"{name}: bf16 dY with an fp32 X is not built"
             _lib.check(lib.hrv_conv2d_wgrad_bf16mma_st_nhwc_f32(*args, (1 if dy.bf16 else 0) | 2, _stream()),
                        "hrv_conv2d_wgrad_bf16mma_st_nhwc_f32")
@@ -1486,6 +1499,34 @@ def conv_s2_pack(mode: int, w: torch.Tensor, K: int, cols: int, Cph: int = 0, si
     return buf
 
 
+def conv_s2_pack_multi(jobs) -> list:
+    """conv_s2_pack of several weights in ONE launch (hrv_conv_s2_pack_multi_dev, <= 8 per launch).  ``jobs``: (mode, w, K, cols, Cph,
+    sigma, split3) tuples; returns the packed streams (views of one buffer) in order."""
+    lib = _lib.load()
+    if not jobs:
+        return []
+    sizes = []
+    for mode, w, K, cols, Cph, sigma, sp in jobs:
+        assert w.is_contiguous() and w.dtype == torch.float32
+        nb = lib.hrv_conv_s2_packed_bytes(mode, K, cols)
+        assert nb > 0 and nb % 16 == 0, (mode, K, cols)
+        sizes.append(nb // 2)
+    buf = torch.empty(sum(sizes), dtype=torch.bfloat16, device=jobs[0][1].device)
+    outs, off = [], 0
+    for n in sizes:
+        outs.append(buf[off:off + n])
+        off += n
+    for i0 in range(0, len(jobs), 8):
+        chunk = jobs[i0:i0 + 8]
+        arr = (_lib.hrv_s2_pack_job_t * len(chunk))()
+        for q, (mode, w, K, cols, Cph, sigma, sp) in enumerate(chunk):
+            arr[q].mode_flags, arr[q].K, arr[q].cols, arr[q].Cph = mode | (4 if sp else 0), K, cols, Cph
+            arr[q].w, arr[q].sigma = w.data_ptr(), (None if sigma is None else sigma.data_ptr())
+            arr[q].wscale, arr[q].out = 1.0, outs[i0 + q].data_ptr()
+        _lib.check(lib.hrv_conv_s2_pack_multi_dev(len(chunk), arr, _stream()), "hrv_conv_s2_pack_multi_dev")
+    return outs
+
+
 def split3(a: Act) -> Act:
     """fp32 activation -> dense bf16 [hi | lo | hi] (3 C channels, hrv_split3_nhwc_bf16): the source of a convolution packed with
     ``split3`` -- hi*hi + lo*hi + hi*lo on the bf16 matrix cores."""
@@ -1535,6 +1576,19 @@ def space_to_depth2_bf16(a: Act) -> Act:
         _lib.check(lib.hrv_space_to_depth2_nhwc_bf16(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, out.data_ptr(), _stream()),
                    "hrv_space_to_depth2_nhwc_bf16")
     return Act(out, 4 * a.Cp)
+
+
+def space_to_depth2_cells(a: Act, Hp: int, Wp: int, split3: bool = False) -> Act:
+    """[N,H,W,C] fp32 -> dense bf16 [N,Hp,Wp,4*Cp] (x3 as [hi | lo | hi] with ``split3``), cells / sub-pixels outside the image zero
+    (hrv_space_to_depth2_cells_bf16)."""
+    lib = _lib.load()
+    assert not a.bf16
+    K = 4 * a.Cp * (3 if split3 else 1)
+    out = torch.empty((a.N, Hp, Wp, K), dtype=torch.bfloat16, device=a.t.device)
+    with _Timed("layout", "space_to_depth2", 0.0, (1.5 + (1.0 if split3 else 0.0)) * ops.act_bytes(a)):
+        _lib.check(lib.hrv_space_to_depth2_cells_bf16(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, Hp, Wp, 1 if split3 else 0,
+                                                      out.data_ptr(), _stream()), "hrv_space_to_depth2_cells_bf16")
+    return Act(out, K)
 
 
 def instnorm_apply_bf16(a: Act, mean: torch.Tensor, rstd: torch.Tensor, act: int = ACT_NONE, slope: float = 0.2) -> Act:

@@ -834,6 +834,13 @@ int64_t hrv_conv_s2_packed_bytes(int32_t mode, int32_t K, int32_t cols);   /* -1
 int hrv_conv_s2_supported(int32_t mode, int32_t K, int32_t cols, int32_t Cph, int32_t N, int32_t Ho, int32_t Wo);
 int hrv_conv_s2_pack_dev(int32_t mode, const float* w, int32_t K, int32_t cols, int32_t Cph, const float* sigma, float wscale,
                          void* out, hrv_stream_t stream);
+/* up to 8 weights in one launch (a PatchGAN pass packs three forward / two data-gradient weights per scale) */
+typedef struct hrv_s2_pack_job {
+  int32_t mode_flags, K, cols, Cph;
+  const float* w; const float* sigma; float wscale; int32_t _pad;
+  void* out;
+} hrv_s2_pack_job_t;
+int hrv_conv_s2_pack_multi_dev(int32_t n, const hrv_s2_pack_job_t* jobs, hrv_stream_t stream);
 int hrv_conv_s2_bf16(const hrv_conv_s2_t* d, hrv_stream_t stream);
 /* bf16-storage companions of hrv_conv_s2_bf16 (the PatchGAN with bf16-stored feature maps): the space-to-depth image of model0's
  * input written in bf16 (cf. hrv_space_to_depth2_nhwc_f32), InstanceNorm2d(affine=False) + LeakyReLU written in bf16
@@ -841,6 +848,10 @@ int hrv_conv_s2_bf16(const hrv_conv_s2_t* d, hrv_stream_t stream);
  * (cf. hrv_scale_f32), and out[r][w] = w < W ? in[r][w] : 0 for a dY whose width the quad-staged weight gradient needs padded to 4. */
 int hrv_space_to_depth2_nhwc_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
                                   int32_t in_coff, uint16_t* out, hrv_stream_t stream);
+/* ... the same image over Hp x Wp cells (>= H/2 x W/2; cells and sub-pixels outside the image are zeros: with a one-cell border model0
+ * is a 'same' 2x2 convolution, the shape hrv_conv2d_wgrad_bf16mma_st_nhwc_f32's LDS-DMA kernel serves), optionally as [hi | lo | hi] */
+int hrv_space_to_depth2_cells_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
+                                   int32_t Hp, int32_t Wp, int32_t split3, uint16_t* out, hrv_stream_t stream);
 int hrv_instnorm_apply_nhwc_bf16out(const float* x, int32_t N, int32_t H, int32_t W, int32_t C, int32_t cstride, int32_t coff,
                                     const float* mean, const float* rstd, int32_t act, float act_slope, uint16_t* out,
                                     int32_t out_cstride, int32_t out_coff, hrv_stream_t stream);

@@ -137,3 +137,57 @@ def test_split3_operands_reach_fp32_accuracy(mode, Cin, Cout, N, H, W):
     err_plain = float((plain.t.double() - want).abs().max()) / scale
     assert err < 2e-5, (err, err_plain)
     assert err < err_plain / 50, (err, err_plain)
+
+
+@pytest.mark.parametrize("N,H,W,Cq,Cout", [(2, 129, 97, 12, 64), (1, 257, 193, 12, 64), (2, 65, 77, 16, 128)])
+def test_cells_weight_gradient_on_the_lds_dma_kernel(N, H, W, Cq, Cout):
+    """model0's weight gradient: the space-to-depth image carries a one-cell zero border, so the layer is a 'same' 2x2 convolution (pad 1
+    on top / left) and wgrad_tr.hip's 2x2 class serves it at any width -- against autograd on the same bf16-rounded operands, with the
+    bias gradient."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    T.MMA_BF16[0] = True
+    try:
+        g = torch.Generator().manual_seed(N + H)
+        K = 4 * Cq
+        xs = torch.randn(N, H, W, K, generator=g)
+        xs[:, -1] = 0
+        xs[:, :, -1] = 0                                   # the zero border
+        xs = xs.to(torch.bfloat16).cuda()
+        dy = torch.randn(N, H, W, Cout, generator=g).to(torch.bfloat16).cuda()
+        dw = torch.empty(Cout, K, 2, 2, device="cuda")
+        db = torch.empty(Cout, device="cuda")
+        ops.profile_begin()
+        T.conv_wgrad(ops.Act(dy, Cout), ops.Act(xs, K), 0, 0, K, 2, 2, 1, 1, dw, name="m0.wgrad", dbias=db)
+        recs = ops.profile_end()
+        torch.cuda.synchronize()
+        assert not any("pad_width" in r[1] for r in recs), [r[1] for r in recs]
+        w = torch.zeros(Cout, K, 2, 2, device="cuda", requires_grad=True)
+        b = torch.zeros(Cout, device="cuda", requires_grad=True)
+        y = F.conv2d(F.pad(xs.float().permute(0, 3, 1, 2), (1, 0, 1, 0)), w, b)
+        y.backward(dy.float().permute(0, 3, 1, 2))
+        assert float((dw - w.grad).abs().max()) <= 2e-3 * float(w.grad.abs().max()), float((dw - w.grad).abs().max())
+        assert float((db - b.grad).abs().max()) <= 2e-3 * float(b.grad.abs().max())
+    finally:
+        T.MMA_BF16[0] = False
+
+
+def test_pack_multi_equals_single_packs():
+    """hrv_conv_s2_pack_multi_dev: the weight streams of several layers from one launch are the streams of the single packs, bit for bit."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import train_ops as T
+    g = torch.Generator().manual_seed(5)
+    sig = torch.tensor([1.3], device="cuda")
+    w0 = torch.randn(64, 48, 2, 2, generator=g).cuda()
+    w1 = torch.randn(128, 64, 4, 4, generator=g).cuda()
+    w2 = torch.randn(256, 128, 4, 4, generator=g).cuda()
+    jobs = [(T.S2_CELLS, w0, 48, 64, 0, None, False), (T.S2_FWD, w1, 64, 128, 0, sig, False), (T.S2_FWD, w2, 384, 256, 0, sig, True),
+            (T.S2_DGRAD, w1, 128, 256, 64, sig, False), (T.S2_DGRAD, w2, 256, 512, 128, None, False), (T.S2_CELLS, w0, 144, 64, 0, sig, True),
+            (T.S2_FWD, w1, 192, 128, 0, None, True), (T.S2_FWD, w2, 128, 256, 0, None, False), (T.S2_FWD, w1, 64, 128, 0, None, False)]
+    got = T.conv_s2_pack_multi(jobs)
+    torch.cuda.synchronize()
+    assert len(got) == len(jobs)
+    for (mode, w, K, cols, Cph, s_, sp), buf in zip(jobs, got):
+        want = T.conv_s2_pack(mode, w, K, cols, Cph, sigma=s_, split3=sp)
+        torch.cuda.synchronize()
+        assert torch.equal(buf.view(torch.int16), want.view(torch.int16)), (mode, K, cols)
