@@ -235,10 +235,12 @@ class ConditionGenerator(nn.Module):
         x2 = ops.to_nhwc(input2)
         E1: List[Act] = []
         E2: List[Act] = []
-        # the two encoders are independent chains of small launches (at 256x192: 6 .. 768 tiles each): PoseEncoder runs on the side
-        # stream next to ClothEncoder (HRV_TOCG_SIDE=0: one after the other on one stream)
+        # the two encoders are independent chains: at 4 x 1024x768 PoseEncoder runs on the side stream next to ClothEncoder (70.9 ->
+        # 72.8 images/s); at the 256x192 of the frozen condition generator inside train_generator.py the fork / join costs more than the
+        # 6 .. 768-tile launches gain (67.0 -> 67.4 ms per iteration, three alternations) -- HRV_TOCG_SIDE=0 / 1: never / always
         from . import train_ops as _T
-        with _T.side_region(x2, on=os.environ.get("HRV_TOCG_SIDE", "1") != "0"):
+        side = os.environ.get("HRV_TOCG_SIDE", "auto")
+        with _T.side_region(x2, on=(side == "1" or (side != "0" and N * H * W >= (1 << 20)))):
             for i in range(5):
                 E2.append(P["E2"][i]([x2 if i == 0 else E2[-1]]))
         for i in range(5):
