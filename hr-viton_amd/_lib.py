@@ -299,6 +299,7 @@ SYMBOLS = {
     "hrv_instnorm_apply_nhwc_bf16out": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32, _i32, _vp]),
     "hrv_scale_bf16": (C.c_int, [_vp, _i64, _f, _vp, _vp]),
     "hrv_split3_nhwc_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "hrv_conv2d_wgrad_s2_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "hrv_pad_width_nhwc_bf16": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "hrv_spade_fused_packed_bytes": (C.c_int64, [_i32]),
     "hrv_spade_fused_supported": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32]),

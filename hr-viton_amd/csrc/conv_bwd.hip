@@ -969,6 +969,11 @@ namespace hrv {
 int wgrad_tr_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, int x_C, int x_cs, int x_co, int x_C_real,
                  int ci_base, int CinTot, int N, int H, int W, int KH, int KW, int pad, float* workspace,
                  long long workspace_bytes, float* dbias, int dbias_accumulate, hipStream_t st, int* S_out);
+// wgrad_s2.hip: the same for PatchGAN's 4x4 stride-2 pad-2 layers (1: launched, 0: shape not served)
+int wgrad_s2_try(const void* dy, int dy_cs, int dy_co, int Cout, const void* x, int x_C, int x_cs, int x_co, int x_C_real, int ci_base,
+                 int CinTot, int N, int H, int W, int Ho, int Wo, float* workspace, long long workspace_bytes, float* dbias, hipStream_t st,
+                 int* S_out);
+int wgrad_s2_serves(int Cout, int x_C, int x_cs, int x_co, int dy_cs, int dy_co, int N, int H, int W);
 }
 
 static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int32_t Cout, const float* x, int32_t x_C,
@@ -998,6 +1003,20 @@ static int wgrad_impl(const float* dy, int32_t dy_cstride, int32_t dy_coff, int3
                                KH, KW, pad, workspace, workspace_bytes, dbias, dbias_accumulate, (hipStream_t)stream, &S2);
     if (r < 0) return r;
     if (r == 1) {      // (the kernel left its bias partials right behind the S2 weight slabs, as the kernels below do)
+      const size_t total = (size_t)Cout * x_C_real * KH * KW;
+      const int nb = grid_for(total);
+      hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb + (dbias ? (Cout + 15) / 16 : 0)), dim3(256), 0, (hipStream_t)stream, workspace,
+                         S2, KH * KW, Cout, CinTot, ci_base, x_C_real, dw_oihw, accumulate, nb,
+                         workspace + (size_t)S2 * KH * KW * Cout * CinTot, dbias, dbias_accumulate);
+      return check_launch("wgrad_reduce_kernel");
+    }
+  }
+  if (mma_bf16 && x_bf16 && dy_bf16 && stride == 2 && KH == 4 && KW == 4 && pad == 2 && x_up_shift == 0) {
+    int S2 = 0;
+    const int r = wgrad_s2_try(dy, dy_cstride, dy_coff, Cout, x, x_C, x_cstride, x_coff, x_C_real, ci_base, CinTot, N, H, W, Ho, Wo, workspace,
+                               workspace_bytes, dbias, (hipStream_t)stream, &S2);
+    if (r < 0) return r;
+    if (r == 1) {
       const size_t total = (size_t)Cout * x_C_real * KH * KW;
       const int nb = grid_for(total);
       hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(nb + (dbias ? (Cout + 15) / 16 : 0)), dim3(256), 0, (hipStream_t)stream, workspace,
@@ -1108,4 +1127,9 @@ extern "C" int hrv_colsum_nhwc_f32(const float* x, int64_t P, int32_t C, int32_t
   if (rc) return rc;
   hipLaunchKernelGGL(colsum_final_kernel, dim3((C + 255) / 256), dim3(256), 0, st, workspace, nb, C, Cpad, out, accumulate);
   return check_launch("colsum_final_kernel");
+}
+
+extern "C" int hrv_conv2d_wgrad_s2_supported(int32_t Cout, int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t dy_cstride, int32_t dy_coff,
+                                             int32_t N, int32_t H, int32_t W) {
+  return hrv::wgrad_s2_serves(Cout, x_C, x_cstride, x_coff, dy_cstride, dy_coff, N, H, W);
 }

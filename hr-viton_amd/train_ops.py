@@ -718,6 +718,10 @@ def conv_wgrad(dy: Act, x: Act, x_up: int, ci_base: int, cin_tot: int, KH: int, 
     wo_real = Wo
     tr2 = (stride == 1 and (Ho, Wo) == (H, W) and KH == KW == 2 and pad == 1 and x_up == 0 and Cout % 64 == 0 and 32 < x.Cp <= 64 and
            N * Ho * Wo >= 8192 and os.environ.get("HRV_WGRAD_TR", "1") != "0")          # (wgrad_tr.hip's 2x2 class takes any width)
+    if (not tr2 and MMA_BF16[0] and dy.bf16 and x.bf16 and x_up == 0 and (KH, KW, stride, pad) == (4, 4, 2, 2) and
+            (Ho, Wo) == (H // 2 + 1, W // 2 + 1) and
+            lib.hrv_conv2d_wgrad_s2_supported(Cout, x.Cp, x.cstride, x.coff, dy.cstride, dy.coff, N, H, W)):
+        tr2 = True                      # (wgrad_s2.hip: any width as well)
     if MMA_BF16[0] and Wo % 4 != 0 and dy.bf16 and x.bf16 and dy.coff == 0 and dy.cstride == dy.C and dy.C % 8 == 0 and not tr2:
         dy = pad_width_bf16(dy)          # (the same zero columns for a bf16-stored dY: the PatchGAN with bf16 feature maps)
         Wo = dy.W

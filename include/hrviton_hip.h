@@ -858,6 +858,10 @@ int hrv_instnorm_apply_nhwc_bf16out(const float* x, int32_t N, int32_t H, int32_
 int hrv_scale_bf16(uint16_t* x, int64_t n, float s_host, const float* s_dev, hrv_stream_t stream);
 /* out[p] = [hi(x[p]) | bf16(x[p] - hi(x[p])) | hi(x[p])] (3 C bf16 channels, dense) of an fp32 NHWC slice: see HRV_S2_SPLIT3 */
 int hrv_split3_nhwc_bf16(const float* x, int64_t npix, int32_t C, int32_t cstride, int32_t coff, uint16_t* out, hrv_stream_t stream);
+/* 1: hrv_conv2d_wgrad_bf16mma_st_nhwc_f32 serves this 4x4 stride-2 pad-2 layer (bf16-stored dY and X) with the LDS-DMA kernel of
+ * wgrad_s2.hip -- any output width; 0: the quad-staged kernel, which needs Wo % 4 == 0 (hrv_pad_width_nhwc_bf16) */
+int hrv_conv2d_wgrad_s2_supported(int32_t Cout, int32_t x_C, int32_t x_cstride, int32_t x_coff, int32_t dy_cstride, int32_t dy_coff,
+                                  int32_t N, int32_t H, int32_t W);
 int hrv_pad_width_nhwc_bf16(const uint16_t* in, int64_t rows, int32_t W, int32_t C, int32_t Wp, uint16_t* out, hrv_stream_t stream);
 
 #ifdef __cplusplus

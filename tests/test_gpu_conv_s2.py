@@ -191,3 +191,33 @@ def test_pack_multi_equals_single_packs():
         want = T.conv_s2_pack(mode, w, K, cols, Cph, sigma=s_, split3=sp)
         torch.cuda.synchronize()
         assert torch.equal(buf.view(torch.int16), want.view(torch.int16)), (mode, K, cols)
+
+
+@pytest.mark.parametrize("Cin,Cout,N,H,W,cs_mult", [(64, 128, 2, 193, 161, 1), (128, 256, 2, 129, 129, 1), (64, 128, 1, 257, 193, 3),
+                                                     (128, 256, 1, 258, 194, 1), (64, 256, 1, 513, 385, 1)])
+def test_stride2_weight_gradient_on_the_lds_dma_kernel(Cin, Cout, N, H, W, cs_mult):
+    """csrc/wgrad_s2.hip: dW and db of the 4x4 stride-2 pad-2 layer over bf16-stored dY and X (X also as the hi third of a split
+    tensor), odd and even extents, no width-padding copy of dY -- against autograd on the same bf16-rounded operands."""
+    import hr_viton_amd  # noqa: F401
+    from hr_viton_amd import ops, train_ops as T
+    T.MMA_BF16[0] = True
+    try:
+        g = torch.Generator().manual_seed(Cin + H)
+        Ho, Wo = H // 2 + 1, W // 2 + 1
+        xall = torch.randn(N, H, W, Cin * cs_mult, generator=g).to(torch.bfloat16).cuda()
+        dy = torch.randn(N, Ho, Wo, Cout, generator=g).to(torch.bfloat16).cuda()
+        dw = torch.empty(Cout, Cin, 4, 4, device="cuda")
+        db = torch.empty(Cout, device="cuda")
+        ops.profile_begin()
+        T.conv_wgrad(ops.Act(dy, Cout), ops.Act(xall, Cin, 0), 0, 0, Cin, 4, 4, 2, 2, dw, name="m1.wgrad", dbias=db)
+        recs = ops.profile_end()
+        torch.cuda.synchronize()
+        assert not any("pad_width" in r[1] for r in recs), [r[1] for r in recs]
+        w = torch.zeros(Cout, Cin, 4, 4, device="cuda", requires_grad=True)
+        b = torch.zeros(Cout, device="cuda", requires_grad=True)
+        y = F.conv2d(xall[..., :Cin].float().permute(0, 3, 1, 2), w, b, stride=2, padding=2)
+        y.backward(dy.float().permute(0, 3, 1, 2))
+        assert float((dw - w.grad).abs().max()) <= 2e-3 * float(w.grad.abs().max()), float((dw - w.grad).abs().max())
+        assert float((db - b.grad).abs().max()) <= 2e-3 * float(b.grad.abs().max())
+    finally:
+        T.MMA_BF16[0] = False

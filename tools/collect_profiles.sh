@@ -28,6 +28,7 @@ c power_clock_bench.txt final_power_clock.txt
 c p2_timeline.txt final_p2_timeline.txt
 c p2_bench.txt final_p2_bench.txt
 c p2_bench_coarse.txt final_p2_bench_coarse.txt
+c s2_bench.txt final_s2_bench.txt
 c bench_2rank_gloo_one_gpu_smoke.json final_bench_2rank_gloo_one_gpu_smoke.json
 c bench_2rank_gloo_graph_one_gpu_smoke.json final_bench_2rank_gloo_graph_one_gpu_smoke.json
 [ -s gpurun_out/pytest_gpu.txt ] && tail -5 gpurun_out/pytest_gpu.txt > $P/${R}_final_pytest_gpu.txt

@@ -52,7 +52,14 @@ def main():
         v["NGPU"] = m.group(1) if m else "n/a"
     except Exception:
         v["NGPU"] = "n/a"
-    print(json.dumps(v, indent=1))
+    try:      # the PatchGAN family and the per-family table of the iteration (tools/launch_summary.py of the default run's launches)
+        rows = [l.rstrip() for l in open(P("final_launch_summary_train_generator_bf16.txt")) if l.strip()]
+        dms = sum(float(l.split()[-6]) for l in rows if l.startswith(("conv D fwd", "conv D dgrad", "wgrad D")))
+        v["DMS"] = f"{dms:.2f}"
+        v["TABLE"] = "```\n" + "\n".join(rows) + "\n```"
+    except Exception:
+        v["DMS"] = v["TABLE"] = "n/a"
+    print(json.dumps({k: (x if k != "TABLE" else "...") for k, x in v.items()}, indent=1))
     for doc in ("README.md", "DESIGN.md"):
         path = os.path.join(ROOT, doc)
         s = open(path).read()

@@ -44,6 +44,7 @@ timeout 200 python tools/power_clock_sampler.py $OUT/power_clock_bench.txt -- py
 timeout 200 python tools/p2_timeline.py > $OUT/p2_timeline.txt 2>&1
 timeout 300 python tools/p2_bench.py 5 > $OUT/p2_bench.txt 2>&1
 timeout 200 python tools/p2_bench.py 5 coarse > $OUT/p2_bench_coarse.txt 2>&1
+timeout 200 python tools/s2_bench.py 5 > $OUT/s2_bench.txt 2>&1
 if [ "${HRV_FULL_SWEEP:-0}" = "1" ]; then
 timeout 300 python tools/fused_bench.py 5 > $OUT/fused_bench.txt 2>&1
 timeout 300 python tools/p2_bench.py 5 > $OUT/p2_bench.txt 2>&1
