@@ -294,7 +294,6 @@ SYMBOLS = {
     "hrv_conv_s2_pack_dev": (C.c_int, [_i32, _vp, _i32, _i32, _i32, _vp, _f, _vp, _vp]),
     "hrv_conv_s2_pack_multi_dev": (C.c_int, [_i32, C.POINTER(hrv_s2_pack_job_t), _vp]),
     "hrv_conv_s2_bf16": (C.c_int, [C.POINTER(hrv_conv_s2_t), _vp]),
-    "hrv_space_to_depth2_nhwc_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_space_to_depth2_cells_bf16": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp]),
     "hrv_instnorm_apply_nhwc_bf16out": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _f, _vp, _i32, _i32, _vp]),
     "hrv_scale_bf16": (C.c_int, [_vp, _i64, _f, _vp, _vp]),

@@ -734,27 +734,9 @@ extern "C" int hrv_conv_s2_bf16(const hrv_conv_s2_t* d, hrv_stream_t stream) {
 
 // ------------------------------------------------------------------------------------------------ bf16-storage companions
 // What the PatchGAN needs around the kernel above when its feature maps are STORED in bf16 (mixed precision): the space-to-depth
-// image of model0's input, InstanceNorm2d + LeakyReLU written in bf16, the upstream scalar applied to a bf16 loss gradient, and a
+// image of model0's input (over cells, optionally split), InstanceNorm2d + LeakyReLU written in bf16, the upstream scalar applied to a bf16 loss gradient, and a
 // width-padded copy of a bf16 dY for the quad-staged weight-gradient kernel (conv_bwd.hip: Wo % 4 == 0).
 namespace hrv {
-
-__global__ void s2d_bf16_kernel(const float* __restrict__ a, int N, int H, int W, int C4, int cs, int co, unsigned short* __restrict__ b) {
-  const size_t total = (size_t)N * H * W * C4;
-  const int Hc = H >> 1, Wc = W >> 1, C = C4 * 4;
-  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int c4 = (int)(i % C4);
-    size_t t = i / C4;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int n = (int)(t / H);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(a + (((size_t)n * H + y) * W + x) * cs + co + 4 * c4);
-    const size_t cell = ((((size_t)n * Hc + (y >> 1)) * Wc + (x >> 1)) * 4 + (y & 1) * 2 + (x & 1)) * C + 4 * c4;
-    uint2 o;
-    o.x = f2bf(v[0]) | ((unsigned)f2bf(v[1]) << 16);
-    o.y = f2bf(v[2]) | ((unsigned)f2bf(v[3]) << 16);
-    *reinterpret_cast<uint2*>(b + cell) = o;
-  }
-}
 
 // The space-to-depth image of model0's input as conv_s2's mode 2 reads it: out[n][cy][cx][(dy*2+dx)*C + c] = in[n][2cy+dy][2cx+dx][c],
 // bf16, over Hp x Wp >= H/2 x W/2 cells (cells / sub-pixels outside the image: zeros -- a one-cell border makes the layer a 'same' 2x2
@@ -868,17 +850,6 @@ static inline int s2_grid_for(size_t work) {
 }
 
 }  // namespace hrv
-
-extern "C" int hrv_space_to_depth2_nhwc_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
-                                             int32_t in_coff, uint16_t* out, hrv_stream_t stream) {
-  HRV_REQUIRE(in && out && N > 0 && H > 0 && W > 0 && C > 0, "space_to_depth2_bf16: bad args");
-  HRV_REQUIRE(H % 2 == 0 && W % 2 == 0 && C % 4 == 0 && in_cstride % 4 == 0 && in_coff % 4 == 0 && in_coff + C <= in_cstride &&
-                  ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 7) == 0,
-              "space_to_depth2_bf16: even extents, 4-channel granules");
-  const size_t total = (size_t)N * H * W * (C / 4);
-  hipLaunchKernelGGL(s2d_bf16_kernel, dim3(s2_grid_for(total)), dim3(256), 0, (hipStream_t)stream, in, N, H, W, C / 4, in_cstride, in_coff, out);
-  return check_launch("s2d_bf16_kernel");
-}
 
 extern "C" int hrv_space_to_depth2_cells_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
                                               int32_t Hp, int32_t Wp, int32_t split3, uint16_t* out, hrv_stream_t stream) {

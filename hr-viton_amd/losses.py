@@ -25,7 +25,7 @@ class _LossFn(torch.autograd.Function):
             ac = a.contiguous()
             bc = None if b is None else b.detach().contiguous()
         n = ac.numel()
-        out = torch.zeros(1, dtype=torch.float32, device=a.device)
+        out = torch.empty(1, dtype=torch.float32, device=a.device)      # (accumulate=False below: the kernel's final stage WRITES out[0])
         # (a bf16-stored operand -- the PatchGAN's feature taps in mixed precision -- gets its gradient in bf16 as well: autograd
         #  wants the input's dtype back, and the data gradient that adds it reads half the bytes)
         grad = T.loss(ac, bc, mode, 1.0 / n, 1.0 / n, out, accumulate=False, want_grad=ctx.needs_input_grad[0],

@@ -1571,17 +1571,6 @@ def conv_s2(mode: int, src: Act, packed: torch.Tensor, cols: int, out: Act, Cph:
     return out
 
 
-def space_to_depth2_bf16(a: Act) -> Act:
-    """[N,H,W,C] fp32 -> dense bf16 [N,H/2,W/2,4*Cp], channel ((y&1)*2 + (x&1))*Cp + c (hrv_space_to_depth2_nhwc_bf16)."""
-    lib = _lib.load()
-    assert not a.bf16 and a.H % 2 == 0 and a.W % 2 == 0
-    out = torch.empty((a.N, a.H // 2, a.W // 2, 4 * a.Cp), dtype=torch.bfloat16, device=a.t.device)
-    with _Timed("layout", "space_to_depth2", 0.0, 1.5 * ops.act_bytes(a)):
-        _lib.check(lib.hrv_space_to_depth2_nhwc_bf16(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, out.data_ptr(), _stream()),
-                   "hrv_space_to_depth2_nhwc_bf16")
-    return Act(out, 4 * a.Cp)
-
-
 def space_to_depth2_cells(a: Act, Hp: int, Wp: int, split3: bool = False) -> Act:
     """[N,H,W,C] fp32 -> dense bf16 [N,Hp,Wp,4*Cp] (x3 as [hi | lo | hi] with ``split3``), cells / sub-pixels outside the image zero
     (hrv_space_to_depth2_cells_bf16)."""

@@ -846,9 +846,8 @@ int hrv_conv_s2_bf16(const hrv_conv_s2_t* d, hrv_stream_t stream);
  * input written in bf16 (cf. hrv_space_to_depth2_nhwc_f32), InstanceNorm2d(affine=False) + LeakyReLU written in bf16
  * (cf. hrv_instnorm_apply_nhwc_f32; network_generator.py:268-269), x *= s_host * (s_dev ? s_dev[0] : 1) over a bf16 loss gradient
  * (cf. hrv_scale_f32), and out[r][w] = w < W ? in[r][w] : 0 for a dY whose width the quad-staged weight gradient needs padded to 4. */
-int hrv_space_to_depth2_nhwc_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride,
-                                  int32_t in_coff, uint16_t* out, hrv_stream_t stream);
-/* ... the same image over Hp x Wp cells (>= H/2 x W/2; cells and sub-pixels outside the image are zeros: with a one-cell border model0
+/* the space-to-depth image of model0's input (cf. hrv_space_to_depth2_nhwc_f32) in bf16 over Hp x Wp cells (>= H/2 x W/2; cells and
+ * sub-pixels outside the image are zeros: with a one-cell border model0
  * is a 'same' 2x2 convolution, the shape hrv_conv2d_wgrad_bf16mma_st_nhwc_f32's LDS-DMA kernel serves), optionally as [hi | lo | hi] */
 int hrv_space_to_depth2_cells_bf16(const float* in, int32_t N, int32_t H, int32_t W, int32_t C, int32_t in_cstride, int32_t in_coff,
                                    int32_t Hp, int32_t Wp, int32_t split3, uint16_t* out, hrv_stream_t stream);
