@@ -32,60 +32,88 @@ struct Cout1Params {
 };
 
 constexpr int C1_STRIP = 8;
+constexpr int C1_ROWS = 4;
 
-// forward: one wave per strip of 8 output pixels of a row; lane = 4 channels (x channel groups of 256); weights in LDS
+// forward: one wave per block of C1_ROWS x C1_STRIP output pixels; lane = 4 channels (x channel groups of 256).  Round 6: the first
+// build walked one output row per wave with its weights in LDS -- 0.116 ms for the 102 MB of f2 at 8 x 129 x 97 x 256, and neither the
+// 5.5-fold re-read of the input out of L2 nor the one-load-at-a-time column loop was the bound (a row-sliding window and eleven loads
+// in flight moved it to 0.100): every (column, kernel row, tap, output) product re-read its weight from LDS, 1.26 MB per wave, the
+// CU's LDS bandwidth.  The 16 taps x 4 channels of a lane now sit in 64 registers (zeros beyond K), the C1_ROWS + K - 1 input rows of
+// the block are read once each with all their columns requested up front.
 __global__ __launch_bounds__(256) void cout1_fwd_kernel(const Cout1Params p) {
-  extern __shared__ float wl[];                     // [K*K][C]
   const int KK = p.K * p.K;
   const float mul = p.sigma ? p.wscale / p.sigma[0] : p.wscale;
-  for (int i = threadIdx.x; i < KK * p.C; i += 256) {
-    const int tap = i / p.C, c = i - tap * p.C;
-    wl[i] = c1_rb(p.w[(size_t)c * KK + tap] * mul, p.round_bf16);
-  }
-  __syncthreads();
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int strips_per_row = (p.Wo + C1_STRIP - 1) / C1_STRIP;
-  const int total = p.N * p.Ho * strips_per_row;
+  const int strips_per_row = (p.Wo + C1_STRIP - 1) / C1_STRIP, row_groups = (p.Ho + C1_ROWS - 1) / C1_ROWS;
+  const int total = p.N * row_groups * strips_per_row;
   const float b = p.bias ? p.bias[0] : 0.f;
   for (int s = blockIdx.x * 4 + wave; s < total; s += gridDim.x * 4) {
     const int sx = s % strips_per_row;
     const int t = s / strips_per_row;
-    const int ho = t % p.Ho, n = t / p.Ho;
-    const int wo0 = sx * C1_STRIP;
-    float acc[C1_STRIP];
+    const int rg = t % row_groups, n = t / row_groups;
+    const int wo0 = sx * C1_STRIP, ho0 = rg * C1_ROWS;
+    float acc[C1_ROWS][C1_STRIP];
 #pragma unroll
-    for (int o = 0; o < C1_STRIP; ++o) acc[o] = 0.f;
+    for (int a = 0; a < C1_ROWS; ++a)
+#pragma unroll
+      for (int o = 0; o < C1_STRIP; ++o) acc[a][o] = 0.f;
     for (int c0 = lane * 4; c0 < p.C; c0 += 256) {
-      for (int r = 0; r < p.K; ++r) {
-        const int h = ho + r - p.pad;
-        if (h < 0 || h >= p.H) continue;
+      float4 wq[4][4];                                             // [kernel row][tap]: the lane's four channels
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int kw = 0; kw < 4; ++kw) {
+          const bool in = r < p.K && kw < p.K;
+          const float* wp_ = p.w + (size_t)c0 * KK + (in ? r * p.K + kw : 0);
+          wq[r][kw].x = in ? c1_rb(wp_[0] * mul, p.round_bf16) : 0.f;
+          wq[r][kw].y = in ? c1_rb(wp_[KK] * mul, p.round_bf16) : 0.f;
+          wq[r][kw].z = in ? c1_rb(wp_[2 * KK] * mul, p.round_bf16) : 0.f;
+          wq[r][kw].w = in ? c1_rb(wp_[3 * KK] * mul, p.round_bf16) : 0.f;
+        }
+#pragma unroll
+      for (int ri = 0; ri < C1_ROWS + 3; ++ri) {                   // input row ho0 + ri - pad (K <= 4)
+        const int h = ho0 + ri - p.pad;
+        if (ri >= C1_ROWS + p.K - 1 || h < 0 || h >= p.H) continue;
         const float* xrow = p.x + ((size_t)n * p.H + h) * p.W * p.xcs + p.xco + c0;
-        const float* wr = wl + (size_t)r * p.K * p.C + c0;
-        // input columns wo0 - pad .. wo0 + STRIP - 1 - pad + K - 1; column q feeds output o = q - kw (kw = 0..K-1)
-        for (int q = 0; q < C1_STRIP + p.K - 1; ++q) {
+        // input columns wo0 - pad .. wo0 + STRIP - 1 - pad + K - 1, all requested before the first is used; column q feeds output
+        // o = q - kw (kw = 0..K-1) of the output rows ri - r (kernel row r = 0..K-1) that lie inside the block
+        float4 xq[C1_STRIP + 3];
+#pragma unroll
+        for (int q = 0; q < C1_STRIP + 3; ++q) {
           const int wi = wo0 + q - p.pad;
-          if (wi < 0 || wi >= p.W) continue;
-          float4 xv = *reinterpret_cast<const float4*>(xrow + (size_t)wi * p.xcs);
+          const bool ok = q < C1_STRIP + p.K - 1 && wi >= 0 && wi < p.W;
+          xq[q] = ok ? *reinterpret_cast<const float4*>(xrow + (size_t)wi * p.xcs) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+#pragma unroll
+        for (int q = 0; q < C1_STRIP + 3; ++q) {
+          float4 xv = xq[q];
           xv.x = c1_rb(xv.x, p.round_bf16); xv.y = c1_rb(xv.y, p.round_bf16);
           xv.z = c1_rb(xv.z, p.round_bf16); xv.w = c1_rb(xv.w, p.round_bf16);
 #pragma unroll
-          for (int o = 0; o < C1_STRIP; ++o) {
-            const int kw = q - o;
-            if (kw >= 0 && kw < p.K) {
-              const float4 wv = *reinterpret_cast<const float4*>(wr + (size_t)kw * p.C);
-              acc[o] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+          for (int r = 0; r < 4; ++r) {
+            const int orow = ri - r;                               // compile-time: ri and r are unrolled
+            if (orow < 0 || orow >= C1_ROWS) continue;
+#pragma unroll
+            for (int o = 0; o < C1_STRIP; ++o) {
+              const int kw = q - o;                                // compile-time; taps beyond K hold zero weights
+              if (kw >= 0 && kw < 4) {
+                const float4 wv = wq[r][kw];
+                acc[orow][o] += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+              }
             }
           }
         }
       }
     }
 #pragma unroll
-    for (int o = 0; o < C1_STRIP; ++o) {
-      float v = acc[o];
+    for (int a = 0; a < C1_ROWS; ++a)
 #pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-      if (lane == 0 && wo0 + o < p.Wo) p.y[(((size_t)n * p.Ho + ho) * p.Wo + wo0 + o) * p.ycs + p.yco] = v + b;
-    }
+      for (int o = 0; o < C1_STRIP; ++o) {
+        float v = acc[a][o];
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+        if (lane == 0 && wo0 + o < p.Wo && ho0 + a < p.Ho) p.y[(((size_t)n * p.Ho + ho0 + a) * p.Wo + wo0 + o) * p.ycs + p.yco] = v + b;
+      }
   }
 }
 
@@ -170,8 +198,8 @@ __global__ __launch_bounds__(256) void cout1_wgrad_kernel(const Cout1Params p) {
     for (int kw = 0; kw < 4; ++kw) acc[kh][kw] = 0.f;
   if (c < p.C) {
     const float* xrow = p.x + ((size_t)row * p.W) * p.xcs + p.xco + c;
-#pragma unroll 4
-    for (int w_ = 0; w_ < p.W; ++w_) {
+#pragma unroll 8
+    for (int w_ = 0; w_ < p.W; ++w_) {      // (eight pixels in flight per thread: 4-byte loads, one block per row -- latency-bound at four)
       const float xv = c1_rb(xrow[(size_t)w_ * p.xcs], p.round_bf16);
       const float* dq = dyl + p.K + w_ + p.pad;
 #pragma unroll
@@ -259,10 +287,8 @@ extern "C" int hrv_conv_cout1_fwd_f32(const hrv_conv_cout1_t* d, hrv_stream_t st
   Cout1Params p;
   int rc = c1_fill(d, p, "conv_cout1_fwd");
   if (rc) return rc;
-  const int lds = p.K * p.K * p.C * 4;
-  rc = c1_lds(reinterpret_cast<const void*>(&cout1_fwd_kernel), lds, "conv_cout1_fwd");
-  if (rc) return rc;
-  const int strips = p.N * p.Ho * ((p.Wo + C1_STRIP - 1) / C1_STRIP);
+  const int lds = 0;                 // (the weights sit in registers since round 6)
+  const int strips = p.N * ((p.Ho + C1_ROWS - 1) / C1_ROWS) * ((p.Wo + C1_STRIP - 1) / C1_STRIP);
   int grid = (strips + 3) / 4;
   if (grid > 2048) grid = 2048;
   hipLaunchKernelGGL(cout1_fwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, p);
