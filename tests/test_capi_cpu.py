@@ -192,3 +192,26 @@ def test_patch_tile_selection():
         assert pt(True, 3, 3, 1, 1, 1, 0, 128, 128, 4, 1024, 768) == 0
     finally:
         del os.environ["HRV_CONV_PATCH"]
+
+
+def test_conv_s2_host_logic(lib):
+    """csrc/conv_s2.hip / wgrad_s2.hip, host side only (round 6): descriptor layouts as the C header declares them, the size of the
+    packed weight stream per mode ([pass][chunk][4 taps][column tile][2 k-steps][64 lanes][16 B]), which shapes the kernels serve."""
+    from hr_viton_amd import _lib
+    assert C.sizeof(_lib.hrv_conv_s2_t) == 152          # 5 x i32 + pad | ptr + 2 x i32 | 4 x i32 | 2 ptr | i32 + f32 | ptr + 3 x i32 + pad | x2 | ...
+    assert C.sizeof(_lib.hrv_s2_pack_job_t) == 48
+    pb = lib.hrv_conv_s2_packed_bytes
+    assert pb(0, 64, 128) == 8 * 4 * 4 * 2048            # forward: 4 sub-pixels x 2 chunks, one 4-tile pass
+    assert pb(0, 128, 256) == 2 * (16 * 4 * 4 * 2048)    # two passes
+    assert pb(1, 128, 256) == 2 * (4 * 4 * 4 * 2048)     # data gradient: K = the forward's 128 outputs, columns = 4 phases x 64
+    assert pb(2, 48, 64) == 2 * 4 * 2 * 2048             # model0 over cells: 1.5 chunks -> 2, a 2-tile pass
+    assert pb(0, 192, 128) == 3 * pb(0, 64, 128)         # split operands: K triples
+    assert pb(0, 60, 128) == -1 and pb(0, 64, 96) == -1 and pb(3, 64, 128) == -1      # K % 8, columns % 64, mode
+    sup = lib.hrv_conv_s2_supported
+    assert sup(0, 64, 128, 0, 8, 257, 193) == 1 and sup(0, 48, 128, 0, 8, 257, 193) == 0      # a forward chunk lies in one sub-pixel
+    assert sup(1, 128, 256, 64, 4, 513, 385) == 1 and sup(1, 128, 256, 48, 4, 513, 385) == 0   # a column tile lies in one phase
+    assert sup(0, 64, 128, 0, 1, 9, 9) == 0                                                     # too few tiles for the persistent grid
+    ws = lib.hrv_conv2d_wgrad_s2_supported
+    assert ws(128, 64, 64, 0, 128, 0, 8, 513, 385) == 1 and ws(256, 128, 128, 0, 256, 0, 8, 257, 193) == 1
+    assert ws(128, 64, 192, 0, 128, 0, 8, 257, 193) == 1          # X as the hi third of a split tensor
+    assert ws(96, 64, 64, 0, 96, 0, 8, 513, 385) == 0 and ws(128, 64, 64, 0, 128, 0, 1, 33, 33) == 0
