@@ -155,12 +155,20 @@ def alloc(N: int, H: int, W: int, C: int, device, bf16: bool = False) -> Act:
     return Act(t, C, 0)
 
 
-def to_nhwc(x: torch.Tensor, out: Optional[Act] = None, bf16: bool = False) -> Act:
-    """fp32 NCHW (reference layout) -> NHWC Act (fp32, or bf16 for the bf16 engine)."""
+def alloc_written(N: int, H: int, W: int, C: int, device, bf16: bool = False) -> Act:
+    """``alloc`` without the zero fill, for a producer that is handed the PADDED channel count and writes every one of them (the pad
+    channels then hold what the kernel computes from its source's zero pads: zeros) -- the resizes, the 3x3 average pool."""
+    return Act(torch.empty((N, H, W, _cpad(C, bf16)), dtype=torch.bfloat16 if bf16 else torch.float32, device=device), C, 0)
+
+
+def to_nhwc(x: torch.Tensor, out: Optional[Act] = None, bf16: bool = False, zero_tail: int = 0) -> Act:
+    """fp32 NCHW (reference layout) -> NHWC Act (fp32, or bf16 for the bf16 engine).  ``zero_tail`` (with ``out``): that many channels
+    behind the converted ones are written as zeros too -- the pad channels of a tensor the caller owns (no separate fill)."""
     require_cuda(x, "to_nhwc")
     x = x.contiguous()
     N, Cc, H, W = x.shape
-    zero_tail = 0      # a caller's ``out`` may be one slice of a concatenation buffer: nothing outside it is touched
+    # (a caller's ``out`` may be one slice of a concatenation buffer: nothing outside it is touched unless the caller says so)
+    assert out is not None or zero_tail == 0
     if out is None:
         # (the converter writes the pad channels of a tensor allocated HERE as zeros itself: no fill of the whole tensor)
         out = Act(torch.empty((N, H, W, _cpad(Cc, bf16)), dtype=torch.bfloat16 if bf16 else torch.float32, device=x.device), Cc, 0)
@@ -506,7 +514,7 @@ def instnorm_apply(a: Act, mean: torch.Tensor, rstd: torch.Tensor, act: int = AC
 def avgpool3x3s2(a: Act) -> Act:
     lib = _lib.load()
     Ho, Wo = (a.H + 2 - 3) // 2 + 1, (a.W + 2 - 3) // 2 + 1
-    out = alloc(a.N, Ho, Wo, a.C, a.t.device)
+    out = alloc_written(a.N, Ho, Wo, a.C, a.t.device)
     with _Timed("pool", "avgpool3x3s2", 0.0, 4.0 * a.N * a.H * a.W * a.Cp * 1.25):
         _lib.check(lib.hrv_avgpool3x3s2_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff,
                                                  out.t.data_ptr(), out.cstride, out.coff, _stream()),
@@ -599,7 +607,7 @@ def resize_bilinear(a: Act, Ho: int, Wo: int, rh: float, rw: float, addend: Opti
     """hrv_resize_bilinear_nhwc_f32: out = bilinear(a) (+ addend)."""
     lib = _lib.load()
     if out is None:
-        out = alloc(a.N, Ho, Wo, a.C, a.t.device)
+        out = alloc_written(a.N, Ho, Wo, a.C, a.t.device)      # (the kernel runs over a.Cp channels)
     add_ptr, acs, aco = (None, 0, 0) if addend is None else (addend.t.data_ptr(), addend.cstride, addend.coff)
     nbytes = 4.0 * a.N * Ho * Wo * a.Cp * (2 if addend is None else 3)
     with _Timed("resize", "bilinear", 0.0, nbytes):
@@ -613,7 +621,7 @@ def resize_nearest(a: Act, Ho: int, Wo: int, addend: Optional[Act] = None, out: 
     """hrv_resize_nearest_nhwc_f32: out = F.interpolate(a, mode='nearest') (+ addend) -- networks.py:130-131 with upsample='nearest'."""
     lib = _lib.load()
     if out is None:
-        out = alloc(a.N, Ho, Wo, a.C, a.t.device)
+        out = alloc_written(a.N, Ho, Wo, a.C, a.t.device)
     add_ptr, acs, aco = (None, 0, 0) if addend is None else (addend.t.data_ptr(), addend.cstride, addend.coff)
     with _Timed("resize", "nearest", 0.0, 4.0 * a.N * Ho * Wo * a.Cp * (2 if addend is None else 3)):
         _lib.check(lib.hrv_resize_nearest_nhwc_f32(a.t.data_ptr(), a.N, a.H, a.W, a.Cp, a.cstride, a.coff, Ho, Wo, add_ptr, acs, aco,

@@ -168,10 +168,9 @@ class _VGGLossFn(torch.autograd.Function):
             N, Cc, H, W = x.shape
             both = Act(torch.empty((2 * N, H, W, 4), dtype=torch.float32, device=x.device), Cc, 0)
             both16 = Act(torch.empty((2 * N, H, W, 8), dtype=torch.bfloat16, device=x.device), Cc, 0)
-            both.t[..., Cc:].zero_()
-            both16.t[..., Cc:].zero_()
-            ops.to_nhwc(x, out=_first_half(both)); ops.to_nhwc(y, out=_second_half(both))
-            ops.to_nhwc(x, out=_first_half(both16)); ops.to_nhwc(y, out=_second_half(both16))
+            # (the converters write the pad channels as zeros themselves: no strided fill of the two tensors)
+            ops.to_nhwc(x, out=_first_half(both), zero_tail=4 - Cc); ops.to_nhwc(y, out=_second_half(both), zero_tail=4 - Cc)
+            ops.to_nhwc(x, out=_first_half(both16), zero_tail=8 - Cc); ops.to_nhwc(y, out=_second_half(both16), zero_tail=8 - Cc)
             taps, saved2 = vgg.features(both, save=need, x_bf16=both16)
             tx, ty = [_first_half(t) for t in taps], [_second_half(t) for t in taps]
             saved = []
