@@ -15,7 +15,8 @@ def _bf(t):
 
 @pytest.mark.parametrize("Cin,Cout,N,H,W,out_bf16,act", [(64, 128, 2, 129, 97, False, 0), (128, 256, 1, 65, 49, False, 0),
                                                           (64, 128, 1, 257, 193, True, 2), (32, 64, 2, 64, 48, True, 0),
-                                                          (64, 192, 1, 40, 57, False, 0), (96, 128, 8, 130, 98, False, 0)])
+                                                          (64, 192, 1, 40, 57, False, 0), (96, 128, 8, 130, 98, False, 0),
+                                                          (64, 128, 4, 513, 385, True, 2)])      # 884 tiles: several units per resident block
 def test_forward_matches_torch(Cin, Cout, N, H, W, out_bf16, act):
     import hr_viton_amd  # noqa: F401
     from hr_viton_amd import ops, train_ops as T
@@ -44,7 +45,8 @@ def test_forward_matches_torch(Cin, Cout, N, H, W, out_bf16, act):
 
 @pytest.mark.parametrize("Ck,Cph,N,H,W,out_bf16,extra", [(128, 64, 2, 129, 97, True, "both"), (256, 128, 1, 65, 49, True, "both"),
                                                           (128, 64, 1, 64, 48, False, "none"), (64, 32, 2, 33, 41, True, "mask"),
-                                                          (128, 64, 1, 257, 193, True, "res32"), (256, 128, 4, 66, 50, True, "both")])
+                                                          (128, 64, 1, 257, 193, True, "res32"), (256, 128, 4, 66, 50, True, "both"),
+                                                          (128, 64, 4, 513, 385, True, "both")])      # 884 tiles x 2 passes
 def test_data_gradient_matches_torch(Ck, Cph, N, H, W, out_bf16, extra):
     """dX = (conv^T(dY) [+ tap]) [* lrelu'(x)]: the forward layer maps Cph -> Ck channels over an H x W input."""
     import hr_viton_amd  # noqa: F401
