@@ -219,6 +219,7 @@ SYMBOLS = {
     "hrv_conv2d_pack_weight_pair_dev": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _ip, _ip, _i32, _i32, _i32,
                                                   _i32, _vp, _ip, _vp]),
     "hrv_spade_vec_prep_f32": (C.c_int, [_vp, _vp, _vp, _i32, _vp, _vp, _vp]),
+    "hrv_spade_vec_prep_multi_f32": (C.c_int, [_i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hrv_shared_taps_prep_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hrv_shared_taps_grad_f32": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
     "hrv_conv2d_workspace_bytes": (_i64, [C.POINTER(hrv_conv2d_t)]),

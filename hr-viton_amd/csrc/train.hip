@@ -1034,6 +1034,24 @@ __global__ __launch_bounds__(256) void spade_vec_prep_kernel(const float* __rest
   if (i < Cp) ns_out[i] = i < C ? ns[i] : 0.f;
 }
 
+// ... for every SPADE norm of a network in ONE launch (blockIdx.y = the norm): 58 launches of 4 us per training iteration otherwise
+constexpr int VEC_MAXJOBS = 32;
+struct VecJobs {
+  const float* gb[VEC_MAXJOBS]; const float* bb[VEC_MAXJOBS]; const float* ns[VEC_MAXJOBS];
+  int C[VEC_MAXJOBS], off_bc[VEC_MAXJOBS], off_ns[VEC_MAXJOBS];
+};
+__global__ __launch_bounds__(256) void spade_vec_prep_multi_kernel(const VecJobs j, float* __restrict__ bc_all, float* __restrict__ ns_all) {
+  const int q = blockIdx.y, C = j.C[q];
+  const int ncols = (C + 31) / 32 * 64, Cp = (C + 3) / 4 * 4;
+  float* const bc = bc_all + j.off_bc[q];
+  float* const nso = ns_all + j.off_ns[q];
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < ncols; i += gridDim.x * 256) {
+    const int l = i & 63, c = (i >> 6) * 32 + (l & 31);
+    bc[i] = c < C ? (l < 32 ? j.gb[q][c] : j.bb[q][c]) : 0.f;
+    if (i < Cp) nso[i] = i < C ? j.ns[q][i] : 0.f;
+  }
+}
+
 // conv_shared (label_nc -> hid, 3x3) of the n norms of a block as ONE 1x1 weight over the tap-expanded label map
 // (ops.tap_expand: tap-major, cp channels per tap): wt[(i*hid + o)][tap*cp + ch] = w_i[o][ch][tap]; bt = concat of biases
 struct SharedTaps {
@@ -1076,6 +1094,27 @@ extern "C" int hrv_spade_vec_prep_f32(const float* gamma_bias, const float* beta
   hipLaunchKernelGGL(spade_vec_prep_kernel, dim3((ncols + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma_bias, beta_bias,
                      noise_scale, C, ncols, Cp, bias_interleaved, noise_scale_padded);
   return check_launch("spade_vec_prep_kernel");
+}
+
+extern "C" int hrv_spade_vec_prep_multi_f32(int32_t n, const float* const* gamma_bias, const float* const* beta_bias,
+                                            const float* const* noise_scale, const int32_t* C, const int32_t* off_bias, const int32_t* off_noise,
+                                            float* bias_interleaved_all, float* noise_scale_padded_all, hrv_stream_t stream) {
+  HRV_REQUIRE(n > 0 && n <= VEC_MAXJOBS && gamma_bias && beta_bias && noise_scale && C && off_bias && off_noise && bias_interleaved_all &&
+                  noise_scale_padded_all, "spade_vec_prep_multi: 1 .. %d norms", VEC_MAXJOBS);
+  VecJobs j;
+  memset(&j, 0, sizeof(j));
+  int cmax = 0;
+  for (int i = 0; i < n; ++i) {
+    HRV_REQUIRE(gamma_bias[i] && beta_bias[i] && noise_scale[i] && C[i] > 0 && off_bias[i] >= 0 && off_noise[i] >= 0 && off_bias[i] % 4 == 0 &&
+                    off_noise[i] % 4 == 0, "spade_vec_prep_multi: job %d", i);
+    j.gb[i] = gamma_bias[i]; j.bb[i] = beta_bias[i]; j.ns[i] = noise_scale[i];
+    j.C[i] = C[i]; j.off_bc[i] = off_bias[i]; j.off_ns[i] = off_noise[i];
+    if (C[i] > cmax) cmax = C[i];
+  }
+  const int ncols = (cmax + 31) / 32 * 64;
+  hipLaunchKernelGGL(spade_vec_prep_multi_kernel, dim3((ncols + 255) / 256, n), dim3(256), 0, (hipStream_t)stream, j, bias_interleaved_all,
+                     noise_scale_padded_all);
+  return check_launch("spade_vec_prep_multi_kernel");
 }
 
 static int shared_taps_fill(SharedTaps& p, const float* const* w, const float* const* b, float* const* gw, float* const* gb,

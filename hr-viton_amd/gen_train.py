@@ -249,6 +249,15 @@ class SpadeT:
         rows_g = torch.tensor([g * 64 + l for g in range(G) for l in range(32) if g * 32 + l < self.C], device=dev)
         self.rows_g, self.rows_b = rows_g, rows_g + 32
 
+    def vecs(self):
+        """(bias of the fused gamma|beta conv in its interleaved column order, noise scale padded to ceil4(C)): from the plan's one
+        launch for all its norms (GeneratorTrainPlan.forward) when that ran for this forward, else one launch of its own."""
+        v = getattr(self, "_vec_pre", None)
+        if v is not None:
+            return v
+        n = self.norm
+        return T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)
+
     def shared_as_1x1(self) -> Tuple[torch.Tensor, torch.Tensor, int]:
         """conv_shared's 3x3 weight as a 1x1 over the tap-expanded label map (ops.tap_expand: tap-major, channel-
         minor, channels padded to one 16-byte group): ([hid, 9*cp, 1, 1], bias, cp)."""
@@ -269,7 +278,7 @@ class SpadeT:
             if stats is not None:
                 ns, (mean, rstd) = stats
             else:
-                ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)[1] if zz is not None else None
+                ns = self.vecs()[1] if zz is not None else None
                 mean, rstd = ops.instnorm_stats(x, zz, ns if zz is not None else None)
             out = ops.alloc(x.N, x.H, x.W, self.C, dev, bf16=True)
             g1p = torch.empty((x.N, x.H, x.W, self.Cp), dtype=torch.bfloat16, device=dev) if save else None
@@ -279,7 +288,7 @@ class SpadeT:
             ctx = dict(x=x, z=zz, ns=ns, mean=mean, rstd=rstd, actv=actv, g1p=Act(g1p, self.C) if save else None, out=out)
             return out, ctx
         # bias of the fused conv in its interleaved (gamma32 | beta32) column order + padded noise scale: one launch
-        bc, ns = T.spade_vec_prep(n.conv_gamma.bias.data, n.conv_beta.bias.data, n.noise_scale.data)
+        bc, ns = self.vecs()
         zz = z  # the noise term is always applied in training (noise_scale is a learnable parameter)
         if stats is not None:
             mean, rstd = stats[1]
@@ -542,8 +551,8 @@ class BlockT:
             z_s, z_0 = next(zi), next(zi)
             if z_s is not None and z_0 is not None and not x.bf16 and os.environ.get("HRV_STATS2", "1") != "0":
                 # norm_s and norm_0 normalise the same x (network_generator.py:158-166) with their own noise draws: one pass over it
-                ns_s = T.spade_vec_prep(self.ns_.norm.conv_gamma.bias.data, self.ns_.norm.conv_beta.bias.data, self.ns_.norm.noise_scale.data)[1]
-                ns_0 = T.spade_vec_prep(self.n0.norm.conv_gamma.bias.data, self.n0.norm.conv_beta.bias.data, self.n0.norm.noise_scale.data)[1]
+                ns_s = self.ns_.vecs()[1]
+                ns_0 = self.n0.vecs()[1]
                 ms, m0 = ops.instnorm_stats2(x, z_s, ns_s, z_0, ns_0)
                 st_s, st_0 = (ns_s, ms), (ns_0, m0)
             hs, ctx["ns"] = self.ns_.forward(x, next(ai), z_s, save, fused, st_s)
@@ -652,6 +661,24 @@ class GeneratorTrainPlan:
                         [n_.shared for b in self.blocks for n_ in b.norms()], power_iteration, backward=save,
                         extra_weights=[w_ for b in self.blocks for n_ in b.norms()
                                        for w_ in (n_.norm.conv_gamma.weight.data, n_.norm.conv_beta.weight.data)])
+        # the bias / noise-scale vectors of every SPADE norm of the pass: one launch (58 launches of 4 us per iteration otherwise)
+        norms_all = [n_ for b in self.blocks for n_ in b.norms()]
+        if os.environ.get("HRV_VEC_PREP_MULTI", "1") != "0":
+            pre = T.spade_vec_prep_multi([(n_.norm.conv_gamma.bias.data, n_.norm.conv_beta.bias.data, n_.norm.noise_scale.data) for n_ in norms_all])
+            for n_, v in zip(norms_all, pre):
+                n_._vec_pre = v
+        try:
+            return self._forward(x, seg, noise, save)
+        finally:
+            for n_ in norms_all:
+                n_._vec_pre = None
+
+    def _forward(self, x: torch.Tensor, seg, noise, save: bool):
+        gen = self.gen
+        N, _, H, W = x.shape
+        nb = len(self.names)
+        top = nb - 1
+        dev = x.device
         xin = ops.to_nhwc(x)
         # mixed precision: the full-resolution stem (conv_7: 9 -> 16 channels over every pixel) reads a bf16 copy of the
         # input (matrix-core operand only) so that it runs on the thin-convolution kernel

@@ -357,6 +357,32 @@ def spade_vec_prep(gamma_bias: torch.Tensor, beta_bias: torch.Tensor, noise_scal
     return bc, ns
 
 
+def spade_vec_prep_multi(items) -> list:
+    """spade_vec_prep of every (gamma_bias, beta_bias, noise_scale) triple of ``items`` in ONE launch per 32 norms
+    (hrv_spade_vec_prep_multi_f32); returns [(bias interleaved, noise scale padded)] as 16-byte-aligned views of two buffers."""
+    lib = _lib.load()
+    if not items:
+        return []
+    dev = items[0][0].device
+    Cs = [g.numel() for g, _, _ in items]
+    nb = [(c + 31) // 32 * 64 for c in Cs]
+    nn_ = [_ceil4(c) for c in Cs]
+    ob = [0] + list(itertools.accumulate(nb))
+    on = [0] + list(itertools.accumulate(nn_))
+    bc_all = torch.empty(ob[-1], dtype=torch.float32, device=dev)
+    ns_all = torch.empty(on[-1], dtype=torch.float32, device=dev)
+    for i0 in range(0, len(items), 32):
+        ch = items[i0:i0 + 32]
+        n = len(ch)
+        P = C.c_void_p * n
+        I = C.c_int32 * n
+        _lib.check(lib.hrv_spade_vec_prep_multi_f32(n, P(*[g.data_ptr() for g, _, _ in ch]), P(*[b.data_ptr() for _, b, _ in ch]),
+                                                    P(*[s_.data_ptr() for _, _, s_ in ch]), I(*Cs[i0:i0 + n]), I(*ob[i0:i0 + n]),
+                                                    I(*on[i0:i0 + n]), bc_all.data_ptr(), ns_all.data_ptr(), _stream()),
+                   "hrv_spade_vec_prep_multi_f32")
+    return [(bc_all[ob[i]:ob[i + 1]], ns_all[on[i]:on[i + 1]]) for i in range(len(items))]
+
+
 def shared_taps_prep(ws: Sequence[torch.Tensor], bs: Sequence[torch.Tensor], cp: int):
     """conv_shared [hid, c, 3, 3] x n -> one 1x1 weight [n*hid, 9*cp, 1, 1] over the tap-expanded label map, + bias."""
     lib = _lib.load()

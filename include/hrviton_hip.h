@@ -395,6 +395,11 @@ int hrv_spectral_norm_bwd_f32(const float* G, const float* w_orig, const float* 
  *  shared_taps_grad: the inverse map of that weight's gradient into the n conv_shared weight / bias gradients. */
 int hrv_spade_vec_prep_f32(const float* gamma_bias, const float* beta_bias, const float* noise_scale, int32_t C,
                            float* bias_interleaved, float* noise_scale_padded, hrv_stream_t stream);
+/* ... of n <= 32 norms in one launch: job i writes its interleaved bias at bias_interleaved_all + off_bias[i] ((C[i] + 31) / 32 * 64
+ * floats) and its padded noise scale at noise_scale_padded_all + off_noise[i] (ceil4(C[i]) floats); offsets are multiples of 4 */
+int hrv_spade_vec_prep_multi_f32(int32_t n, const float* const* gamma_bias, const float* const* beta_bias, const float* const* noise_scale,
+                                 const int32_t* C, const int32_t* off_bias, const int32_t* off_noise, float* bias_interleaved_all,
+                                 float* noise_scale_padded_all, hrv_stream_t stream);
 int hrv_shared_taps_prep_f32(const float* const* w, const float* const* b, int32_t n, int32_t hid, int32_t c, int32_t cp,
                              float* wt, float* bt, hrv_stream_t stream);
 int hrv_shared_taps_grad_f32(const float* dw, const float* db, int32_t n, int32_t hid, int32_t c, int32_t cp,
